@@ -1,0 +1,301 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REAL reference modules.
+
+Run in the build container only (needs /root/reference; it does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference's two hot-path files (afigan/modeling/feat_interpol/generator_rdb.py and
+feature_patch_discriminator.py) are loaded BY PATH with importlib.  They import detectron2 / fvcore
+names at module top; detectron2 v0.1.1 and fvcore are not installed here and there is no network,
+so exactly those names are provided as stand-in modules in sys.modules:
+  detectron2.layers.Conv2d          -> nn.Conv2d subclass applying optional `norm` then `activation`
+  detectron2.layers.ConvTranspose2d -> nn.ConvTranspose2d
+  detectron2.layers.get_norm("BN")  -> nn.BatchNorm2d
+  detectron2.layers.ShapeSpec, detectron2.utils.registry.Registry -> inert placeholders
+  fvcore.nn.weight_init.c2_msra_fill -> kaiming_normal_(fan_out, relu) + zero bias
+Only arrays (inputs / expected outputs) are written; no reference source or bytecode is copied.
+The stage-1 trainer (stage1_trainer.py) is not importable (deep detectron2 imports), so its
+run_step lines 336-433 are replayed here against the imported Generator / Discriminator.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import afigan_oracle as orc  # noqa: E402  (closed-form weight generators shared by both sides)
+
+
+def install_shims():
+    d2 = types.ModuleType("detectron2")
+    layers = types.ModuleType("detectron2.layers")
+    utils = types.ModuleType("detectron2.utils")
+    registry = types.ModuleType("detectron2.utils.registry")
+    fv = types.ModuleType("fvcore")
+    fvnn = types.ModuleType("fvcore.nn")
+    wi = types.ModuleType("fvcore.nn.weight_init")
+
+    class Conv2d(nn.Conv2d):
+        def __init__(self, *a, **kw):
+            norm = kw.pop("norm", None)
+            act = kw.pop("activation", None)
+            super().__init__(*a, **kw)
+            self.norm = norm
+            self.activation = act
+
+        def forward(self, x):
+            x = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+            if self.norm is not None:
+                x = self.norm(x)
+            if self.activation is not None:
+                x = self.activation(x)
+            return x
+
+    def get_norm(norm, ch):
+        assert norm == "BN"
+        return nn.BatchNorm2d(ch)
+
+    class ShapeSpec:  # placeholder
+        pass
+
+    class Registry:  # placeholder
+        def __init__(self, name):
+            self.name = name
+
+        def register(self, obj=None):
+            return obj
+
+    def c2_msra_fill(m):
+        nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+    layers.Conv2d = Conv2d
+    layers.ConvTranspose2d = nn.ConvTranspose2d
+    layers.get_norm = get_norm
+    layers.ShapeSpec = ShapeSpec
+    registry.Registry = Registry
+    wi.c2_msra_fill = c2_msra_fill
+    d2.layers, d2.utils, utils.registry = layers, utils, registry
+    fv.nn, fvnn.weight_init = fvnn, wi
+    for name, mod in [("detectron2", d2), ("detectron2.layers", layers), ("detectron2.utils", utils),
+                      ("detectron2.utils.registry", registry), ("fvcore", fv), ("fvcore.nn", fvnn),
+                      ("fvcore.nn.weight_init", wi)]:
+        sys.modules[name] = mod
+
+
+def load_ref(relpath, name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def sd_np(module):
+    return {k: v.detach().cpu().numpy() for k, v in module.state_dict().items()}
+
+
+def tensor_digest(t: torch.Tensor, nsample=64):
+    """sum, l2 norm, abs-max and a strided sample (fixed stride from numel) of a tensor."""
+    f = t.detach().reshape(-1).double()
+    n = f.numel()
+    stride = max(1, n // nsample)
+    return np.array([f.sum().item(), f.norm().item(), f.abs().max().item()], dtype=np.float64), \
+        f[::stride][:nsample].float().numpy()
+
+
+def grads_digest(named_grads):
+    out = {}
+    for k, g in named_grads.items():
+        d, s = tensor_digest(g)
+        out["gd/" + k] = d
+        out["gs/" + k] = s
+    return out
+
+
+def main():
+    torch.set_num_threads(8)
+    install_shims()
+    G_rdb = load_ref("afigan/modeling/feat_interpol/generator_rdb.py", "ref_generator_rdb")
+    D_mod = load_ref("afigan/modeling/feat_interpol/feature_patch_discriminator.py", "ref_discriminator")
+
+    # ---------------- G-small: full tensors, reference default init ----------------
+    for tag, shape in (("a", (2, 16, 5, 7)), ("b", (1, 16, 7, 11))):
+        torch.manual_seed(1234)
+        G = G_rdb.Generator(in_channels=16, n_residual_dense_blocks=3, growth_rate=4)
+        with torch.no_grad():   # reference zero-inits biases; give them values so bias paths are pinned
+            for k, v in G.state_dict().items():
+                if k.endswith("bias"):
+                    v.copy_(orc.closed_form_tensor(k, v.shape, 0.05))
+        x = torch.randn(shape, generator=torch.Generator().manual_seed(7)).requires_grad_(True)
+        R = torch.randn((shape[0], 16, 2 * shape[2], 2 * shape[3]), generator=torch.Generator().manual_seed(8))
+        out = G(x)
+        (out * R).sum().backward()
+        fx = {"x": x.detach().numpy(), "R": R.numpy(), "out": out.detach().numpy(), "dx": x.grad.numpy()}
+        for k, v in sd_np(G).items():
+            fx["w/" + k] = v
+        for k, p in G.named_parameters():
+            fx["g/" + k] = p.grad.numpy()
+        np.savez_compressed(os.path.join(HERE, f"g_small_{tag}.npz"), **fx)
+        print("g_small", tag, out.shape)
+
+    # ---------------- G-full (config 1 pin), closed-form weights ----------------
+    G = G_rdb.Generator(n_residual_dense_blocks=3)
+    gp = orc.closed_form_generator_params()
+    G.load_state_dict(gp, strict=True)
+    x = torch.randn((1, 256, 25, 34), generator=torch.Generator().manual_seed(0)).requires_grad_(True)
+    out = G(x)
+    out.sum().backward()
+    fx = {
+        "x_seed": np.array([0]), "x_shape": np.array([1, 256, 25, 34]),
+        "out_slice": out.detach()[0, ::16, ::5, ::7].numpy(),          # [16,10,10]
+        "out_chan_sum": out.detach().double().sum(dim=(0, 2, 3)).numpy(),
+        "out_absmax": np.array([out.detach().abs().max().item()]),
+        "out_row": out.detach()[0, :, 17, :].numpy(),                  # [256,68] one full row
+        "dx_slice": x.grad[0, ::16, ::5, ::7].numpy(),
+    }
+    fx.update(grads_digest({k: p.grad for k, p in G.named_parameters()}))
+    dd, ds = tensor_digest(x.grad)
+    fx["gd/x"], fx["gs/x"] = dd, ds
+    np.savez_compressed(os.path.join(HERE, "g_full_cfg1.npz"), **fx)
+    print("g_full", out.shape)
+
+    # ---------------- bilinear index map / ramps (bit-exact) ----------------
+    fx = {}
+    for L in (1, 2, 5, 7, 25):
+        ramp = torch.arange(L, dtype=torch.float32).view(1, 1, L, 1).expand(1, 1, L, 3).contiguous()
+        up = F.interpolate(ramp, scale_factor=2, mode="bilinear")
+        fx[f"ramp_h_{L}"] = up[0, 0, :, 0].numpy()
+        ramp = torch.arange(L, dtype=torch.float32).view(1, 1, 1, L).expand(1, 1, 3, L).contiguous()
+        up = F.interpolate(ramp, scale_factor=2, mode="bilinear")
+        fx[f"ramp_w_{L}"] = up[0, 0, 0, :].numpy()
+    xr = torch.randn((2, 3, 5, 7), generator=torch.Generator().manual_seed(3))
+    fx["rand_in"] = xr.numpy()
+    fx["rand_out"] = F.interpolate(xr, scale_factor=2, mode="bilinear").numpy()
+    np.savez_compressed(os.path.join(HERE, "bilinear.npz"), **fx)
+
+    # ---------------- D, closed-form weights ----------------
+    dp0 = orc.closed_form_discriminator_params()
+    for tag, shape in (("a", (2, 256, 13, 21)), ("b", (1, 256, 7, 11))):
+        D = D_mod.Discriminator()
+        D.load_state_dict(dp0, strict=True)
+        D.train()
+        x = torch.randn(shape, generator=torch.Generator().manual_seed(11)).requires_grad_(True)
+        acts = {}
+        hooks = []
+        for n in range(3):
+            conv = D.Discriminators[0][n][0]
+            # conv.norm input = conv output: capture batch statistics
+            hooks.append(conv.norm.register_forward_hook(
+                lambda m, i, o, n=n: acts.__setitem__(n, i[0].detach())))
+        logits = D.Discriminators[0](x)
+        for h in hooks:
+            h.remove()
+        Rl = torch.randn(logits.shape, generator=torch.Generator().manual_seed(12))
+        (logits * Rl).sum().backward()
+        fx = {"x_seed": np.array([11]), "x_shape": np.array(shape), "R": Rl.numpy(),
+              "logits": logits.detach().numpy(), "dx_slice": x.grad[0, ::16].numpy()}
+        for n in range(3):
+            c = acts[n]
+            fx[f"bn{n}_mean"] = c.mean(dim=(0, 2, 3)).numpy()
+            fx[f"bn{n}_var"] = c.var(dim=(0, 2, 3), unbiased=False).numpy()
+        for k, v in D.state_dict().items():
+            if "running" in k or "num_batches" in k:
+                fx["buf/" + k] = v.numpy()
+        fx.update(grads_digest({k: p.grad for k, p in D.named_parameters()}))
+        dd, ds = tensor_digest(x.grad)
+        fx["gd/x"], fx["gs/x"] = dd, ds
+        np.savez_compressed(os.path.join(HERE, f"d_{tag}.npz"), **fx)
+        print("d", tag, logits.shape)
+
+    # ---------------- stage-1 step replay: stage1_trainer.py:336-433 ----------------
+    G = G_rdb.Generator(n_residual_dense_blocks=3)
+    G.load_state_dict(orc.closed_form_generator_params(), strict=True)
+    D = D_mod.Discriminator()
+    D.load_state_dict(orc.closed_form_discriminator_params(), strict=True)
+    G.train()
+    D.train()
+    gen = torch.Generator().manual_seed(21)
+    lr_features = [torch.randn((2, 256, 13, 21), generator=gen), torch.randn((2, 256, 7, 11), generator=gen)]
+    hr_features = [torch.randn((2, 256, 25, 42), generator=gen), torch.randn((2, 256, 13, 21), generator=gen)]
+    crit = nn.BCEWithLogitsLoss()
+    base_lr, wd, mom = 1e-3, 1e-4, 0.9
+
+    def reshape_stage1(t, size):  # replay of _reshape_stage1 (:437-443)
+        if size[2] != t.size()[2] or size[3] != t.size()[3]:
+            _W = size[2] if size[2] < t.size()[2] else t.size()[2]
+            _H = size[3] if size[3] < t.size()[3] else t.size()[3]
+            return t[:, :, 0:_W, 0:_H]
+        return t
+
+    def make_opt(mod):  # detectron2 v0.1.1 build_optimizer: per-param groups, wd 0 for norm params
+        groups = []
+        for m in mod.modules():
+            for name, p in m.named_parameters(recurse=False):
+                w = 0.0 if isinstance(m, nn.BatchNorm2d) else wd
+                groups.append({"params": [p], "lr": base_lr, "weight_decay": w})
+        return torch.optim.SGD(groups, base_lr, momentum=mom)
+
+    G_opt, D_opt = make_opt(G.Generators[0]), make_opt(D.Discriminators[0])
+    fx = {"seed": np.array([21]), "lr": np.array([base_lr]), "wd": np.array([wd]), "mom": np.array([mom])}
+    d_loss = {}
+    for p_lv, (lr_f, hr_f) in enumerate(zip(lr_features, hr_features), 2):
+        tr = G(lr_f).detach()
+        tr = reshape_stage1(tr, hr_f.size())
+        hr = reshape_stage1(hr_f, tr.size())
+        logit_real = D.Discriminators[0](hr)
+        logit_fake = D.Discriminators[0](tr)
+        real, fake = torch.ones(logit_real.size()), torch.zeros(logit_fake.size())
+        d_loss[f"d_loss_p{p_lv}"] = crit(logit_real, real) + crit(logit_fake, fake)
+        fx[f"crop_p{p_lv}"] = np.array(list(tr.shape))
+    d_losses = sum(d_loss.values())
+    D_opt.zero_grad()
+    d_losses.backward()
+    fx.update({k: np.array([v.item()]) for k, v in d_loss.items()})
+    dg = grads_digest({k: p.grad for k, p in D.named_parameters()})
+    fx.update({"D" + k: v for k, v in dg.items()})
+    D_opt.step()
+    fx.update({"Dw_after/" + k: tensor_digest(p)[0] for k, p in D.named_parameters()})
+
+    g_loss = {}
+    for p_lv, (lr_f, hr_f) in enumerate(zip(lr_features, hr_features), 2):
+        tr = G(lr_f)
+        tr = reshape_stage1(tr, hr_f.size())
+        hr = reshape_stage1(hr_f, tr.size())
+        logit_fake = D.Discriminators[0](tr).detach()
+        logit_real = D.Discriminators[0](hr)
+        real = torch.ones(logit_real.size())
+        adv = crit(logit_fake, real)
+        content = F.l1_loss(tr, hr)
+        assert not adv.requires_grad  # Q1
+        g_loss[f"g_loss_p{p_lv}"] = adv * 1e-3 + content
+        fx[f"adv_loss_p{p_lv}"] = np.array([adv.item()])
+        fx[f"content_loss_p{p_lv}"] = np.array([content.item()])
+    g_losses = sum(g_loss.values())
+    G_opt.zero_grad()
+    g_losses.backward()
+    fx.update({k: np.array([v.item()]) for k, v in g_loss.items()})
+    gg = grads_digest({k: p.grad for k, p in G.named_parameters()})
+    fx.update({"G" + k: v for k, v in gg.items()})
+    G_opt.step()
+    fx.update({"Gw_after/" + k: tensor_digest(p)[0] for k, p in G.named_parameters()})
+    for k, v in D.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            fx["Dbuf_after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "stage1_step.npz"), **fx)
+    print("stage1 step", {k: v.item() for k, v in d_loss.items()}, {k: v.item() for k, v in g_loss.items()})
+
+
+if __name__ == "__main__":
+    main()

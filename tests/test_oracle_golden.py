@@ -1,0 +1,150 @@
+"""Pin the CPU oracle (oracle/afigan_oracle.py) against fixtures produced by the imported reference
+(tests/golden/make_golden.py).  CPU-only; this is the oracle's parity pin."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import afigan_oracle as orc
+
+torch.set_num_threads(8)
+
+
+def _load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name)))
+
+
+def _digest(t, nsample=64):
+    f = t.detach().reshape(-1).double()
+    stride = max(1, f.numel() // nsample)
+    return np.array([f.sum().item(), f.norm().item(), f.abs().max().item()]), f[::stride][:nsample].float().numpy()
+
+
+def _check_digests(fx, grads, prefix="", rtol=2e-4):
+    for k, g in grads.items():
+        d, s = _digest(g)
+        ref_d, ref_s = fx[prefix + "gd/" + k], fx[prefix + "gs/" + k]
+        scale = max(ref_d[2], 1e-12)
+        # l2 norm and abs-max are scale-stable; the plain sum can cancel, so compare it against norm
+        assert abs(d[1] - ref_d[1]) <= rtol * ref_d[1] + 1e-9, (k, d, ref_d)
+        assert abs(d[0] - ref_d[0]) <= rtol * ref_d[1] * np.sqrt(g.numel()) + 1e-9, (k, d, ref_d)
+        np.testing.assert_allclose(s, ref_s, rtol=0, atol=rtol * scale + 1e-9, err_msg=k)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_generator_small_matches_reference(golden_dir, tag):
+    fx = _load(golden_dir, f"g_small_{tag}.npz")
+    p = {k[2:]: torch.from_numpy(v).clone().requires_grad_(True) for k, v in fx.items() if k.startswith("w/")}
+    x = torch.from_numpy(fx["x"]).requires_grad_(True)
+    out = orc.generator_forward(x, p, n_rdb=3)
+    np.testing.assert_allclose(out.detach().numpy(), fx["out"], rtol=1e-5, atol=1e-6)
+    (out * torch.from_numpy(fx["R"])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), fx["dx"], rtol=1e-4, atol=1e-6)
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), fx["g/" + k], rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_generator_full_cfg1_matches_reference(golden_dir):
+    fx = _load(golden_dir, "g_full_cfg1.npz")
+    p = {k: v.requires_grad_(True) for k, v in orc.closed_form_generator_params().items()}
+    x = torch.randn(tuple(fx["x_shape"]), generator=torch.Generator().manual_seed(int(fx["x_seed"][0])))
+    x.requires_grad_(True)
+    out = orc.generator_forward(x, p)
+    assert out.shape == (1, 256, 50, 68)
+    scale = float(fx["out_absmax"][0])
+    np.testing.assert_allclose(out.detach()[0, ::16, ::5, ::7].numpy(), fx["out_slice"], rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(out.detach()[0, :, 17, :].numpy(), fx["out_row"], rtol=0, atol=1e-5 * scale)
+    np.testing.assert_allclose(out.detach().double().sum(dim=(0, 2, 3)).numpy(), fx["out_chan_sum"], rtol=0,
+                               atol=1e-5 * scale * 3400 ** 0.5)
+    out.sum().backward()
+    np.testing.assert_allclose(x.grad[0, ::16, ::5, ::7].numpy(), fx["dx_slice"], rtol=1e-4, atol=1e-5)
+    _check_digests(fx, {k: v.grad for k, v in p.items()})
+
+
+def test_bilinear_index_map_bit_exact(golden_dir):
+    fx = _load(golden_dir, "bilinear.npz")
+    for L in (1, 2, 5, 7, 25):
+        i0, i1, lam = orc.bilinear2x_index_map(L)
+        ramp = torch.arange(L, dtype=torch.float32)
+        up = ramp[i0] * (1 - lam) + ramp[i1] * lam
+        assert np.array_equal(up.numpy(), fx[f"ramp_h_{L}"]), L      # integer ramps: exact
+        assert np.array_equal(up.numpy(), fx[f"ramp_w_{L}"]), L
+        assert set(np.unique(lam.numpy())).issubset({0.0, 0.25, 0.75})
+        assert int(i0[0]) == 0 and int(i1[-1]) == L - 1
+    out = orc.bilinear2x(torch.from_numpy(fx["rand_in"]))
+    np.testing.assert_allclose(out.numpy(), fx["rand_out"], rtol=0, atol=5e-7)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_discriminator_matches_reference(golden_dir, tag):
+    fx = _load(golden_dir, f"d_{tag}.npz")
+    p0 = orc.closed_form_discriminator_params()
+    p = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in p0.items()}
+    x = torch.randn(tuple(fx["x_shape"]), generator=torch.Generator().manual_seed(int(fx["x_seed"][0])))
+    x.requires_grad_(True)
+    logits, upd = orc.discriminator_forward(x, p, training=True)
+    # The last conv is a K=9216 dot product with sum|a*b| ~ 1e3 x |result| and BN layers 2/3 divide by
+    # std ~ 0.035: two fp32 evaluations agree to ~5e-4 of max|logit| only.  Bar: 1e-3 of max|logit|.
+    np.testing.assert_allclose(logits.detach().numpy(), fx["logits"], rtol=0,
+                               atol=1e-3 * np.abs(fx["logits"]).max())
+    for k, v in upd.items():
+        np.testing.assert_allclose(v.detach().numpy(), fx["buf/" + k], rtol=1e-4, atol=1e-5, err_msg=k)
+    (logits * torch.from_numpy(fx["R"])).sum().backward()
+    np.testing.assert_allclose(x.grad[0, ::16].numpy(), fx["dx_slice"], rtol=1e-3, atol=1e-4 * fx["gd/x"][2])
+    grads = {k: v.grad for k, v in p.items() if v.requires_grad}
+    # conv biases feeding a train-mode BN have (mathematically) zero gradient: rounding noise only
+    noise = {k for k in grads if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3")}
+    for k in noise:
+        wn = fx["gd/" + k.replace(".bias", ".weight")][1]
+        assert fx["gd/" + k][2] < 1e-4 * wn and grads[k].abs().max().item() < 1e-4 * wn
+    _check_digests(fx, {k: g for k, g in grads.items() if k not in noise}, rtol=5e-4)
+
+
+def test_stage1_step_matches_reference_replay(golden_dir):
+    fx = _load(golden_dir, "stage1_step.npz")
+    gp = orc.closed_form_generator_params()
+    dp = orc.closed_form_discriminator_params()
+    gen = torch.Generator().manual_seed(int(fx["seed"][0]))
+    lr_f = [torch.randn((2, 256, 13, 21), generator=gen), torch.randn((2, 256, 7, 11), generator=gen)]
+    hr_f = [torch.randn((2, 256, 25, 42), generator=gen), torch.randn((2, 256, 13, 21), generator=gen)]
+    # Q4: crop sizes
+    assert list(fx["crop_p2"]) == [2, 256, 25, 42] and list(fx["crop_p3"]) == [2, 256, 13, 21]
+
+    d_losses, d_grads, d_bufs = orc.stage1_d_phase(gp, dp, lr_f, hr_f)
+    for k, v in d_losses.items():
+        assert abs(v - float(fx[k][0])) < 2e-5 * abs(float(fx[k][0])) + 1e-6, k
+    noise = {k for k in d_grads if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3")}
+    _check_digests(fx, {k: g for k, g in d_grads.items() if k not in noise}, prefix="D", rtol=5e-4)
+
+    # D optimizer step, then the G phase sees the UPDATED D (stage1_trainer.py:381 before :384)
+    params = {k: v for k, v in dp.items() if k in d_grads}
+    mom = {}
+    orc.sgd_momentum_step(params, d_grads, mom, lr=float(fx["lr"][0]), momentum=float(fx["mom"][0]),
+                          weight_decay=float(fx["wd"][0]))
+    dp2 = dict(dp)
+    dp2.update(params)
+    dp2.update(d_bufs)
+    for k in params:
+        ref = fx["Dw_after/" + k]
+        f = params[k].reshape(-1).double()
+        assert abs(f.norm().item() - ref[1]) <= 1e-5 * ref[1] + 1e-9, k
+
+    g_losses, g_grads, d_bufs2 = orc.stage1_g_phase(gp, dp2, lr_f, hr_f)
+    for k, v in g_losses.items():
+        assert abs(v - float(fx[k][0])) < 5e-5 * abs(float(fx[k][0])) + 1e-6, (k, v, fx[k])
+    _check_digests(fx, g_grads, prefix="G", rtol=5e-4)
+    # Q2: BN buffers advance 4x per level per iteration
+    for k, v in d_bufs2.items():
+        ref = fx["Dbuf_after/" + k]
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == int(ref) == 4 * 2
+        else:
+            np.testing.assert_allclose(v.numpy(), ref, rtol=2e-4, atol=1e-5, err_msg=k)
+    gparams = dict(gp)
+    gmom = {}
+    orc.sgd_momentum_step(gparams, g_grads, gmom, lr=float(fx["lr"][0]), momentum=float(fx["mom"][0]),
+                          weight_decay=float(fx["wd"][0]))
+    for k in g_grads:
+        ref = fx["Gw_after/" + k]
+        assert abs(gparams[k].reshape(-1).double().norm().item() - ref[1]) <= 1e-5 * ref[1] + 1e-9, k
