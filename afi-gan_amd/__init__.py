@@ -1,0 +1,20 @@
+"""afigan_amd -- MI355X-native implementation of AFI-GAN's adversarial feature-interpolation hot path.
+
+Drop-in surface (same names / signatures / state_dict keys as the reference modules):
+  * ``Generator``      <- afigan/modeling/feat_interpol/generator_rdb.py:73
+  * ``Discriminator``  <- afigan/modeling/feat_interpol/feature_patch_discriminator.py:16
+  * ``Stage1Step``     <- the G+D iteration of afigan/engine/stage1_trainer.py:305-435
+All forward/backward math runs in hand-written HIP kernels for gfx950 behind the C-ABI of
+``include/afigan_hip.h`` (libafigan_hip.so).  There is no CPU / eager fallback.
+"""
+from . import _lib
+from ._lib import AfiError
+
+_lib.load()     # fail loudly at import time when the HIP library is missing
+
+from . import ops  # noqa: E402
+from .generator_rdb import Generator  # noqa: E402
+from .feature_patch_discriminator import Discriminator  # noqa: E402
+from .stage1 import Stage1Step, warmup_multistep_lr  # noqa: E402
+
+__all__ = ["Generator", "Discriminator", "Stage1Step", "warmup_multistep_lr", "ops", "AfiError"]

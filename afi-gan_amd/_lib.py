@@ -1,0 +1,115 @@
+"""ctypes binding of libafigan_hip.so (the C-ABI declared in include/afigan_hip.h).
+
+This is the reference-side binding a maintainer would add for the hot path.  There is NO
+fallback: if the HIP library is missing or a call returns a non-zero status, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libafigan_hip.so")
+
+AFI_MAX_RDB = 8
+ABI_VERSION = 1
+
+
+class AfiError(RuntimeError):
+    pass
+
+
+class View(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("sN", C.c_longlong), ("sH", C.c_longlong), ("sW", C.c_longlong)]
+
+
+class GenParams(C.Structure):
+    _fields_ = [("C", C.c_int), ("G", C.c_int), ("n_rdb", C.c_int), ("residual_scale", C.c_float),
+                ("w0", C.c_void_p), ("b0", C.c_void_p),
+                ("rdb_w", (C.c_void_p * 5) * AFI_MAX_RDB),
+                ("w7", C.c_void_p), ("b7", C.c_void_p),
+                ("wT", C.c_void_p), ("bT", C.c_void_p),
+                ("w9", C.c_void_p), ("b9", C.c_void_p)]
+
+
+class DiscParams(C.Structure):
+    _fields_ = [("F", C.c_int * 4),
+                ("w", C.c_void_p * 3), ("b", C.c_void_p * 3),
+                ("gamma", C.c_void_p * 3), ("beta", C.c_void_p * 3),
+                ("running_mean", C.c_void_p * 3), ("running_var", C.c_void_p * 3),
+                ("num_batches_tracked", C.c_void_p * 3),
+                ("w3", C.c_void_p), ("b3", C.c_void_p)]
+
+
+class SgdDesc(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("n", C.c_longlong),
+                ("wd", C.c_float), ("pad_", C.c_float)]
+
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+_GP, _DP = C.POINTER(GenParams), C.POINTER(DiscParams)
+
+# name -> (restype, argtypes); every symbol declared in include/afigan_hip.h
+SIGNATURES = {
+    "afi_abi_version": (_i, []),
+    "afi_status_string": (C.c_char_p, [_i]),
+    "afi_generator_fwd_ws_floats": (_ll, [_i] * 6),
+    "afi_generator_bwd_ws_floats": (_ll, [_i] * 6),
+    "afi_generator_fwd": (_i, [_GP, View, _i, _i, _i, View, _vp, _ll, _vp]),
+    "afi_generator_bwd": (_i, [_GP, _GP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "afi_discriminator_fwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
+    "afi_discriminator_bwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
+    "afi_discriminator_fwd": (_i, [_DP, View, _i, _i, _i, _vp, _i, _vp, _ll, _vp]),
+    "afi_discriminator_bwd": (_i, [_DP, _DP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "afi_conv3x3_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, _i, _vp]),
+    "afi_conv3x3_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, View, _vp]),
+    "afi_conv3x3_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_convT6s2_pack_weight": (_i, [_vp, _vp, _i, _i, _vp]),
+    "afi_convT6s2_unpack_wgrad": (_i, [_vp, _vp, _i, _i, _vp]),
+    "afi_convT6s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp]),
+    "afi_convT6s2_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, View, _vp]),
+    "afi_convT6s2_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_bilinear2x_add_fwd": (_i, [View, _i, _i, _i, _i, _f, _vp, _vp]),
+    "afi_bilinear2x_add_bwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
+    "afi_reduce_scratch_floats": (_ll, [_i]),
+    "afi_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "afi_bn_apply_lrelu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
+    "afi_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp]),
+    "afi_colsum_accum": (_i, [_vp, _ll, _i, _ll, _f, _vp, _vp, _vp]),
+    "afi_bce_logits_fwd_bwd": (_i, [_vp, _ll, _f, _f, _vp, _f, _vp, _vp]),
+    "afi_l1_fwd_bwd": (_i, [View, View, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _vp]),
+    "afi_sgd_momentum_step": (_i, [_vp, _i, _ll, _f, _f, _f, _vp]),
+    "afi_scale_inplace": (_i, [_vp, _ll, _f, _vp]),
+    "afi_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "afi_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libafigan_hip.so once; raise AfiError (never fall back) when it is missing or has the wrong ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AfiError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                       "There is no CPU fallback for the AFI-GAN hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.afi_abi_version() != ABI_VERSION:
+        raise AfiError(f"ABI mismatch: library {lib.afi_abi_version()} != binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str = ""):
+    if status != 0:
+        msg = load().afi_status_string(status).decode()
+        raise AfiError(f"{what or 'afigan_hip call'} failed: status {status} ({msg})")
+
+
+def call(name: str, *args):
+    """Call an int-status entry point and raise on failure."""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,71 @@
+// Internal shared definitions for the AFI-GAN gfx950 kernels (not part of the public C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AFI_LRELU_SLOPE 0.2f
+
+// status codes returned across the C-ABI (no exceptions cross it)
+#define AFI_OK 0
+#define AFI_ERR_BAD_ARG 1
+#define AFI_ERR_UNSUPPORTED 2
+#define AFI_ERR_LAUNCH 3
+
+// A pixel-major ("NHWC") tensor view: element (n, y, x, c) lives at p[n*sN + y*sH + x*sW + c].
+// Strides are in elements; the channel stride is always 1.  Cropped views (stage-1 _reshape_stage1)
+// and channel slices of wider buffers (RDB dense buffer) are expressed through p and the strides.
+struct AfiView {
+    float* p;
+    long long sN, sH, sW;
+};
+
+// Parameters of the pixel-M implicit GEMM (forward conv, conv-transpose forward, and both dgrads).
+//   C[m][n] = sum_k A[m][k] * B[k][n],  m <-> (img, y, x) on the GEMM pixel grid N x H x W,
+//   k <-> (tap, kphase, c),  n <-> output column.
+struct AfiPixGemm {
+    // GEMM pixel grid (the low-resolution grid for the conv-transpose variants)
+    int N, H, W;
+    int ntaps;          // 9 (3x3) or 1 (1x1)
+    int Ck;             // channels per (tap, kphase) on the K side
+    int nKphase;        // 1, or 4 when the A side is a pixel-shuffled hi-res tensor (convT dgrad)
+    int Ncols;          // GEMM N
+    // A gather: pixel (y + a_sgn*dy, x + a_sgn*dx) on the grid, scaled by a_up (+ phase) in the tensor
+    AfiView A;
+    int a_sgn;          // +1 forward, -1 dgrad
+    int a_up;           // 1, or 2 for convT dgrad (A is [N, 2H, 2W])
+    // B (weights).  KC form (b_rc = 0): row n at  B + n*b_sRow + tap*b_sTap + c           (k contiguous)
+    //               RC form (b_rc = 1): row k at  B + (kphase*Ck + c)*b_sRow + tap*b_sTap + n  (n contiguous)
+    const float* B;
+    long long b_sRow, b_sTap;
+    // output: column col -> phase = col / CoutPhase, channel = col % CoutPhase;
+    // pixel (y*o_up + (phase>>1), x*o_up + (phase&1))
+    AfiView O;
+    int o_up;           // 1, or 2 for convT forward (O is [N, 2H, 2W])
+    int CoutPhase;      // == Ncols when o_up == 1
+    // epilogue: v = alpha*acc + bias[ch] + beta*O_old + r1s*R1 + r2s*R2 ; lrelu ; * lrelu'(Z)
+    float alpha, beta;
+    const float* bias;  // indexed by channel (col % CoutPhase); may be null
+    AfiView R1; float r1s; int r1_lo, r1_hi;   // applied for channels in [r1_lo, r1_hi); null p = off
+    AfiView R2; float r2s; int r2_lo, r2_hi;
+    int r1_bilinear;    // R1 is a low-res [N, H/2, W/2] tensor, added as its bilinear x2 up-sampling
+    int lrelu;          // apply LeakyReLU(0.2) to v
+    AfiView Z; int z_lo, z_hi;                 // multiply by (Z > 0 ? 1 : 0.2) for channels in [z_lo, z_hi)
+};
+
+// Parameters of the weight-gradient GEMM:  dW[co'][tap][ci] += alpha * sum_pix dY[pix][co'] * X[pix+tap][ci]
+struct AfiWgradGemm {
+    int N, H, W;        // pixel grid (low-res for convT)
+    int ntaps;
+    int Mrows;          // co' count (4*Cout for convT)
+    int Ncols;          // ci count
+    AfiView DY; int dy_up; int CoutPhase;      // dY gather (pixel-shuffled when dy_up == 2)
+    AfiView X;                                  // input activations, gathered at (y+dy, x+dx)
+    float* DW; long long dw_sRow, dw_sTap;      // dW + co'*dw_sRow + tap*dw_sTap + ci
+    float alpha;
+    int splitK;
+};
+
+static inline int afi_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

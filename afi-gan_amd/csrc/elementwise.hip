@@ -1,0 +1,501 @@
+// HBM-bound kernels of the AFI-GAN hot path on gfx950: layout changes, conv-transpose weight (un)packing,
+// BatchNorm statistics / apply / backward, column sums (bias grads), the 1024->1 stencil of the last
+// discriminator conv, BCE-with-logits, L1, bilinear x2 (standalone + backward) and multi-tensor SGD.
+// All of them are float4-vectorised along the contiguous channel dimension of the pixel-major layout;
+// reductions use wavefront shuffles (64 lanes) + one LDS hop per block.
+#include "afi_common.h"
+
+#define AFI_BN_EPS 1e-5f
+#define AFI_BN_MOMENTUM 0.1f
+
+__device__ __forceinline__ float afi_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------- layout: NCHW <-> NHWC
+// in [N][C][P] -> out [N][P][C]   (P = H*W); 32x32 LDS tile, +1 pad
+__global__ __launch_bounds__(256) void afi_nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int P) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (long long)n * C * P;
+    float* dst = out + (long long)n * C * P;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, pp = p0 + tx;
+        if (c < C && pp < P) tile[ty + 8 * i][tx] = src[(long long)c * P + pp];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int pp = p0 + ty + 8 * i, c = c0 + tx;
+        if (c < C && pp < P) dst[(long long)pp * C + c] = tile[tx][ty + 8 * i];
+    }
+}
+__global__ __launch_bounds__(256) void afi_nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int P) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (long long)n * C * P;
+    float* dst = out + (long long)n * C * P;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int pp = p0 + ty + 8 * i, c = c0 + tx;
+        if (c < C && pp < P) tile[ty + 8 * i][tx] = src[(long long)pp * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int c = c0 + ty + 8 * i, pp = p0 + tx;
+        if (c < C && pp < P) dst[(long long)c * P + pp] = tile[tx][ty + 8 * i];
+    }
+}
+
+int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st) {
+    if (N <= 0 || C <= 0 || P <= 0) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_nchw_to_nhwc_kernel, dim3(afi_cdiv(P, 32), afi_cdiv(C, 32), N), dim3(256), 0, st, in, out, C, P);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st) {
+    if (N <= 0 || C <= 0 || P <= 0) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_nhwc_to_nchw_kernel, dim3(afi_cdiv(P, 32), afi_cdiv(C, 32), N), dim3(256), 0, st, in, out, C, P);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- conv-transpose weight pack / grad unpack
+// W  [Cin][Cout][6][6]  (torch ConvTranspose2d layout, generator_rdb.py:101-105)
+// Wp [(phase*Cout + co)][tap][ci],  phase = 2a+c, tap = 3(dy+1)+(dx+1),  ky = a+2-2dy, kx = c+2-2dx
+__global__ void afi_convT_pack_kernel(const float* __restrict__ W, float* __restrict__ Wp, int Cin, int Cout) {
+    const long long total = 36LL * Cin * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int ci = (int)(i % Cin); long long r = i / Cin;
+        int tap = (int)(r % 9); r /= 9;
+        int co = (int)(r % Cout); int phase = (int)(r / Cout);
+        int a = phase >> 1, c = phase & 1, dy = tap / 3 - 1, dx = tap % 3 - 1;
+        int ky = a + 2 - 2 * dy, kx = c + 2 - 2 * dx;
+        Wp[i] = W[(((long long)ci * Cout + co) * 6 + ky) * 6 + kx];
+    }
+}
+// dW[ci][co][ky][kx] += dWp[(phase*Cout+co)][tap][ci]
+__global__ void afi_convT_unpack_grad_kernel(const float* __restrict__ dWp, float* __restrict__ dW, int Cin, int Cout) {
+    const long long total = 36LL * Cin * Cout;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int kx = (int)(i % 6); long long r = i / 6;
+        int ky = (int)(r % 6); r /= 6;
+        int co = (int)(r % Cout); int ci = (int)(r / Cout);
+        int a = ky & 1, c = kx & 1, dy = (a + 2 - ky) / 2, dx = (c + 2 - kx) / 2;
+        int phase = 2 * a + c, tap = 3 * (dy + 1) + (dx + 1);
+        dW[i] += dWp[(((long long)phase * Cout + co) * 9 + tap) * Cin + ci];
+    }
+}
+int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st) {
+    const long long total = 36LL * Cin * Cout;
+    hipLaunchKernelGGL(afi_convT_pack_kernel, dim3((unsigned)min((long long)2048, (total + 255) / 256)), dim3(256), 0, st, W, Wp, Cin, Cout);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st) {
+    const long long total = 36LL * Cin * Cout;
+    hipLaunchKernelGGL(afi_convT_unpack_grad_kernel, dim3((unsigned)min((long long)2048, (total + 255) / 256)), dim3(256), 0, st, dWp, dW, Cin, Cout);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- per-channel reductions over pixels
+// Generic two-value column reduction over a dense [P][C] matrix (ld = C, C % 4 == 0).
+//   MODE 0: s0 = sum (x - K),      s1 = sum (x - K)^2         K = x[0][c]      (BatchNorm statistics)
+//   MODE 1: s0 = sum g,            s1 = sum g * xhat          xhat = (x-mean)*invstd  (BatchNorm backward)
+//   MODE 2: s0 = sum g             (bias gradient)
+// Block = 256 threads = 32 channel quads x 8 pixel lanes; grid = (C/128, chunks). Partials [chunks][2][C].
+#define AFI_RED_MAX_CHUNKS 256
+template <int MODE>
+__global__ __launch_bounds__(256) void afi_colred_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                 const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                                 long long P, int C, long long ld, int rows_per_chunk, float* __restrict__ partial) {
+    __shared__ f32x4 red[2][8][32];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 128 + cq * 4;
+    const bool cok = c < C;
+    f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    if (cok) {
+        f32x4 k = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+        if (MODE == 0) k = *(const f32x4*)(x + c);
+        if (MODE == 1) { mu = *(const f32x4*)(mean + c); is = *(const f32x4*)(invstd + c); }
+        const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+        const long long r1 = (r0 + rows_per_chunk < P) ? r0 + rows_per_chunk : P;
+        for (long long r = r0 + rl; r < r1; r += 8) {
+            if (MODE == 0) {
+                f32x4 v = *(const f32x4*)(x + r * ld + c) - k;
+                s0 += v; s1 += v * v;
+            } else if (MODE == 1) {
+                f32x4 gv = *(const f32x4*)(g + r * ld + c);
+                f32x4 xh = (*(const f32x4*)(x + r * ld + c) - mu) * is;
+                s0 += gv; s1 += gv * xh;
+            } else {
+                s0 += *(const f32x4*)(g + r * ld + c);
+            }
+        }
+    }
+    red[0][rl][cq] = s0; red[1][rl][cq] = s1;
+    __syncthreads();
+    if (rl == 0 && cok) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { s0 += red[0][i][cq]; s1 += red[1][i][cq]; }
+        float* dst = partial + (long long)blockIdx.y * 2 * C;
+        *(f32x4*)(dst + c) = s0;
+        *(f32x4*)(dst + C + c) = s1;
+    }
+}
+
+// BatchNorm statistics finalize: mean / invstd for this call + running-stat update (momentum 0.1, unbiased var)
+__global__ void afi_bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, const float* __restrict__ x0, long long P, int C,
+                                             float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
+                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < chunks; ++i) { s0 += partial[(long long)i * 2 * C + c]; s1 += partial[(long long)i * 2 * C + C + c]; }
+    const float inv_n = 1.f / (float)P;
+    const float d = s0 * inv_n;                     // mean - K
+    const float m = x0[c] + d;
+    float var = s1 * inv_n - d * d;                 // biased
+    var = fmaxf(var, 0.f);
+    mean[c] = m;
+    invstd[c] = rsqrtf(var + AFI_BN_EPS);
+    if (var_out) var_out[c] = var;
+    if (running_mean) {
+        const float unb = var * ((float)P / (float)(P > 1 ? P - 1 : 1));
+        running_mean[c] = (1.f - AFI_BN_MOMENTUM) * running_mean[c] + AFI_BN_MOMENTUM * m;
+        running_var[c] = (1.f - AFI_BN_MOMENTUM) * running_var[c] + AFI_BN_MOMENTUM * unb;
+    }
+}
+
+// y = lrelu((x - mean) * invstd * gamma + beta)
+__global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
+                                          const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                          long long P, int C) {
+    const long long total4 = P * C / 4;
+    const int C4 = C / 4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = *(const f32x4*)(x + i * 4);
+        const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+        const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+        v = (v - mu) * is * ga + be;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * AFI_LRELU_SLOPE;
+        *(f32x4*)(y + i * 4) = v;
+    }
+}
+
+// BatchNorm backward finalize: dgamma += sum g*xhat ; dbeta += sum g ; stash the two sums for the apply pass
+__global__ void afi_bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float gscale,
+                                           float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = 0; i < chunks; ++i) { s0 += partial[(long long)i * 2 * C + c]; s1 += partial[(long long)i * 2 * C + C + c]; }
+    sums[c] = s0; sums[C + c] = s1;
+    if (dbeta) dbeta[c] += gscale * s0;
+    if (dgamma) dgamma[c] += gscale * s1;
+}
+// dx = gamma * invstd * (g - sum_g/P - xhat * sum_gx/P)   (in place on g allowed)
+__global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dx,
+                                        const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                        const float* __restrict__ sums, long long P, int C) {
+    const long long total4 = P * C / 4;
+    const int C4 = C / 4;
+    const float inv_n = 1.f / (float)P;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const f32x4 gv = *(const f32x4*)(g + i * 4), xv = *(const f32x4*)(x + i * 4);
+        const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c), ga = *(const f32x4*)(gamma + c);
+        const f32x4 sg = *(const f32x4*)(sums + c), sgx = *(const f32x4*)(sums + C + c);
+        const f32x4 xh = (xv - mu) * is;
+        *(f32x4*)(dx + i * 4) = ga * is * (gv - sg * inv_n - xh * (sgx * inv_n));
+    }
+}
+// bias gradient finalize: db += alpha * sum
+__global__ void afi_colsum_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float alpha, float* __restrict__ db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s0 = 0.f;
+    for (int i = 0; i < chunks; ++i) s0 += partial[(long long)i * 2 * C + c];
+    db[c] += alpha * s0;
+}
+
+static void afi_red_geometry(long long P, int& chunks, int& rows_per_chunk) {
+    long long want = (P + 63) / 64;
+    if (want > AFI_RED_MAX_CHUNKS) want = AFI_RED_MAX_CHUNKS;
+    if (want < 1) want = 1;
+    rows_per_chunk = (int)((P + want - 1) / want);
+    chunks = (int)((P + rows_per_chunk - 1) / rows_per_chunk);
+}
+extern "C" long long afi_reduce_scratch_floats(int C) { return (long long)AFI_RED_MAX_CHUNKS * 2 * C + 2 * C; }
+
+static unsigned afi_ew_grid(long long work_items) {
+    long long g = (work_items + 255) / 256;
+    if (g > 2048) g = 2048;     // 256 CUs x 8 blocks, grid-stride the rest
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out,
+                        float* running_mean, float* running_var, float* scratch, hipStream_t st) {
+    if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    int chunks, rpc; afi_red_geometry(P, chunks, rpc);
+    hipLaunchKernelGGL((afi_colred_partial_kernel<0>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, P, C, (long long)C, rpc, scratch);
+    hipLaunchKernelGGL(afi_bn_stats_finalize_kernel, dim3(afi_cdiv(C, 256)), dim3(256), 0, st, scratch, chunks, x, P, C, mean, invstd,
+                       var_out, running_mean, running_var);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              long long P, int C, hipStream_t st) {
+    if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_bn_apply_lrelu_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, x, y, mean, invstd, gamma, beta, P, C);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma,
+                      float* dgamma, float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st) {
+    if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    int chunks, rpc; afi_red_geometry(P, chunks, rpc);
+    float* sums = scratch + (long long)AFI_RED_MAX_CHUNKS * 2 * C;
+    hipLaunchKernelGGL((afi_colred_partial_kernel<1>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch);
+    hipLaunchKernelGGL(afi_bn_bwd_finalize_kernel, dim3(afi_cdiv(C, 256)), dim3(256), 0, st, scratch, chunks, C, gscale, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(afi_bn_bwd_apply_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st) {
+    if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    int chunks, rpc; afi_red_geometry(P, chunks, rpc);
+    hipLaunchKernelGGL((afi_colred_partial_kernel<2>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, (const float*)nullptr, g,
+                       (const float*)nullptr, (const float*)nullptr, P, C, ld, rpc, scratch);
+    hipLaunchKernelGGL(afi_colsum_finalize_kernel, dim3(afi_cdiv(C, 256)), dim3(256), 0, st, scratch, chunks, C, alpha, db);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- last discriminator conv (1024 -> 1) as a stencil
+// The 3x3 conv with ONE output channel is computed as  D9[q][t] = <X[q][:], W[t][:]>  (a 1x1 GEMM with 9 columns,
+// run on the MFMA kernel so X is read exactly once) followed by  logit[p] = b + sum_t D9[p + tap_t][t].
+__global__ void afi_stencil9_sum_kernel(const float* __restrict__ d9, int ld, const float* __restrict__ bias, float* __restrict__ out,
+                                        int N, int H, int W) {
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int x = (int)(i % W); long long r = i / W; int y = (int)(r % H); int n = (int)(r / H);
+        float s = bias ? bias[0] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) s += d9[(((long long)n * H + yy) * W + xx) * ld + t];
+        }
+        out[i] = s;
+    }
+}
+// dD9[q][t] = dlogit[q - tap_t] (0 outside); columns 9..ld-1 are written as zeros
+__global__ void afi_stencil9_scatter_kernel(const float* __restrict__ dlogit, float* __restrict__ dd9, int ld, int N, int H, int W) {
+    const long long total = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int x = (int)(i % W); long long r = i / W; int y = (int)(r % H); int n = (int)(r / H);
+        float* dst = dd9 + i * ld;
+        for (int t = 0; t < ld; ++t) {
+            float v = 0.f;
+            if (t < 9) {
+                int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = dlogit[((long long)n * H + yy) * W + xx];
+            }
+            dst[t] = v;
+        }
+    }
+}
+int afi_launch_stencil9_sum(const float* d9, int ld, const float* bias, float* out, int N, int H, int W, hipStream_t st) {
+    hipLaunchKernelGGL(afi_stencil9_sum_kernel, dim3(afi_ew_grid((long long)N * H * W)), dim3(256), 0, st, d9, ld, bias, out, N, H, W);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, int H, int W, hipStream_t st) {
+    hipLaunchKernelGGL(afi_stencil9_scatter_kernel, dim3(afi_ew_grid((long long)N * H * W)), dim3(256), 0, st, dlogit, dd9, ld, N, H, W);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- losses
+// BCE-with-logits (mean) against a constant target t:  loss += lscale * mean(max(z,0) - z t + log1p(exp(-|z|)))
+// dz = gscale * (sigmoid(z) - t) / n   (written only if dz != null)
+__global__ __launch_bounds__(256) void afi_bce_logits_kernel(const float* __restrict__ z, long long n, float target, float lscale,
+                                                             float* __restrict__ loss, float gscale, float* __restrict__ dz) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const float inv_n = 1.f / (float)n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = z[i];
+        const float e = expf(-fabsf(v));
+        s += fmaxf(v, 0.f) - v * target + log1pf(e);
+        if (dz) {
+            const float sig = v >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+            dz[i] = gscale * (sig - target) * inv_n;
+        }
+    }
+    s = afi_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) atomicAdd(loss, lscale * inv_n * (red[0] + red[1] + red[2] + red[3]));
+}
+int afi_launch_bce_logits(const float* z, long long n, float target, float lscale, float* loss, float gscale, float* dz, hipStream_t st) {
+    if (n <= 0) return AFI_ERR_BAD_ARG;
+    long long g = (n + 255) / 256; if (g > 256) g = 256;
+    hipLaunchKernelGGL(afi_bce_logits_kernel, dim3((unsigned)g), dim3(256), 0, st, z, n, target, lscale, loss, gscale, dz);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// L1 (mean) between two pixel-major views over the common crop [N, h, w, C]:
+//   loss += lscale * mean|a - b| ;  da (dense [N, Ha, Wa, C], the full extent of a) = gscale*sign(a-b)/n inside the crop, 0 outside
+__global__ __launch_bounds__(256) void afi_l1_kernel(AfiView a, AfiView b, int N, int h, int w, int C, int Ha, int Wa, float lscale,
+                                                     float* __restrict__ loss, float gscale, float* __restrict__ da) {
+    __shared__ float red[4];
+    const int C4 = C / 4;
+    const long long total = (long long)N * Ha * Wa * C4;   // iterate over the FULL extent of a so da gets its zeros
+    const float inv_n = 1.f / ((float)N * (float)h * (float)w * (float)C);
+    const float gs = gscale * inv_n;
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4; long long r = i / C4;
+        const int x = (int)(r % Wa); r /= Wa; const int y = (int)(r % Ha); const int n = (int)(r / Ha);
+        f32x4 g = {0, 0, 0, 0};
+        if (y < h && x < w) {
+            const f32x4 av = *(const f32x4*)(a.p + n * a.sN + y * a.sH + x * a.sW + c);
+            const f32x4 bv = *(const f32x4*)(b.p + n * b.sN + y * b.sH + x * b.sW + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = av[j] - bv[j];
+                s += fabsf(d);
+                g[j] = d > 0.f ? gs : (d < 0.f ? -gs : 0.f);
+            }
+        }
+        if (da) *(f32x4*)(da + i * 4) = g;
+    }
+    s = afi_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss) atomicAdd(loss, lscale * inv_n * (red[0] + red[1] + red[2] + red[3]));
+}
+int afi_launch_l1(AfiView a, AfiView b, int N, int h, int w, int C, int Ha, int Wa, float lscale, float* loss, float gscale, float* da,
+                  hipStream_t st) {
+    if (N <= 0 || h <= 0 || w <= 0 || C <= 0 || (C & 3) || h > Ha || w > Wa) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_l1_kernel, dim3(afi_ew_grid((long long)N * Ha * Wa * C / 4)), dim3(256), 0, st, a, b, N, h, w, C, Ha, Wa, lscale,
+                       loss, gscale, da);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- bilinear x2 (standalone forward / backward)
+__device__ __forceinline__ void afi_bil_idx2(int o, int L, int& i0, int& i1, float& lam) {
+    float s = fmaxf(0.5f * (float)o - 0.25f, 0.f);
+    i0 = (int)s; lam = s - (float)i0; i1 = min(i0 + 1, L - 1);
+}
+// out[N,2H,2W,C] (dense) = beta*out + bilinear2x(x[N,H,W,C] view)
+__global__ void afi_bilinear2x_fwd_kernel(AfiView x, int N, int H, int W, int C, float beta, float* __restrict__ out) {
+    const int C4 = C / 4;
+    const long long total = (long long)N * 4 * H * W * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4; long long r = i / C4;
+        const int xo = (int)(r % (2 * W)); r /= 2 * W; const int yo = (int)(r % (2 * H)); const int n = (int)(r / (2 * H));
+        int y0, y1, x0, x1; float ly, lx;
+        afi_bil_idx2(yo, H, y0, y1, ly); afi_bil_idx2(xo, W, x0, x1, lx);
+        const float* b = x.p + n * x.sN + c;
+        const f32x4 v00 = *(const f32x4*)(b + y0 * x.sH + x0 * x.sW), v01 = *(const f32x4*)(b + y0 * x.sH + x1 * x.sW);
+        const f32x4 v10 = *(const f32x4*)(b + y1 * x.sH + x0 * x.sW), v11 = *(const f32x4*)(b + y1 * x.sH + x1 * x.sW);
+        f32x4 v = (v00 * (1.f - lx) + v01 * lx) * (1.f - ly) + (v10 * (1.f - lx) + v11 * lx) * ly;
+        if (beta != 0.f) v += beta * *(const f32x4*)(out + i * 4);
+        *(f32x4*)(out + i * 4) = v;
+    }
+}
+// dx[N,H,W,C] (dense) = beta*dx + bilinear2x^T(dout[N,2H,2W,C] dense)
+__global__ void afi_bilinear2x_bwd_kernel(const float* __restrict__ dout, int N, int H, int W, int C, float beta, float* __restrict__ dx) {
+    const int C4 = C / 4;
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4; long long r = i / C4;
+        const int xi = (int)(r % W); r /= W; const int yi = (int)(r % H); const int n = (int)(r / H);
+        f32x4 acc = {0, 0, 0, 0};
+        for (int yo = max(2 * yi - 2, 0); yo <= min(2 * yi + 2, 2 * H - 1); ++yo) {
+            int y0, y1; float ly; afi_bil_idx2(yo, H, y0, y1, ly);
+            const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int xo = max(2 * xi - 2, 0); xo <= min(2 * xi + 2, 2 * W - 1); ++xo) {
+                int x0, x1; float lx; afi_bil_idx2(xo, W, x0, x1, lx);
+                const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
+                if (wx == 0.f) continue;
+                acc += (wy * wx) * *(const f32x4*)(dout + (((long long)n * 2 * H + yo) * 2 * W + xo) * C + c);
+            }
+        }
+        if (beta != 0.f) acc += beta * *(const f32x4*)(dx + i * 4);
+        *(f32x4*)(dx + i * 4) = acc;
+    }
+}
+int afi_launch_bilinear2x_fwd(AfiView x, int N, int H, int W, int C, float beta, float* out, hipStream_t st) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_bilinear2x_fwd_kernel, dim3(afi_ew_grid((long long)N * H * W * C)), dim3(256), 0, st, x, N, H, W, C, beta, out);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_bilinear2x_bwd(const float* dout, int N, int H, int W, int C, float beta, float* dx, hipStream_t st) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_bilinear2x_bwd_kernel, dim3(afi_ew_grid((long long)N * H * W * C / 4)), dim3(256), 0, st, dout, N, H, W, C, beta, dx);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- multi-tensor SGD with momentum
+// torch.optim.SGD semantics (detectron2 build_optimizer): d = g*gscale + wd*p ; buf = mom*buf + d ; p -= lr*buf
+struct AfiSgdDesc { float* p; const float* g; float* m; long long n; float wd; float pad; };
+__global__ void afi_sgd_kernel(const AfiSgdDesc* __restrict__ descs, float lr, float mom, float gscale) {
+    const AfiSgdDesc d = descs[blockIdx.y];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (long long)gridDim.x * blockDim.x) {
+        const float pv = d.p[i];
+        const float dd = d.g[i] * gscale + d.wd * pv;
+        const float b = mom * d.m[i] + dd;
+        d.m[i] = b;
+        d.p[i] = pv - lr * b;
+    }
+}
+int afi_launch_sgd(const void* descs_dev, int ntensors, long long max_n, float lr, float mom, float gscale, hipStream_t st) {
+    if (ntensors <= 0) return AFI_ERR_BAD_ARG;
+    long long gx = (max_n + 255) / 256; if (gx > 512) gx = 512; if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(afi_sgd_kernel, dim3((unsigned)gx, ntensors), dim3(256), 0, st, (const AfiSgdDesc*)descs_dev, lr, mom, gscale);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// scale a flat buffer (used to average all-reduced gradients when the collective sums)
+__global__ void afi_scale_kernel(float* __restrict__ p, long long n, float s) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] *= s;
+}
+int afi_launch_scale(float* p, long long n, float s, hipStream_t st) {
+    hipLaunchKernelGGL(afi_scale_kernel, dim3(afi_ew_grid(n)), dim3(256), 0, st, p, n, s);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- small helpers
+// *out += alpha * sum(v[0..n))
+__global__ __launch_bounds__(256) void afi_sum_accum_kernel(const float* __restrict__ v, long long n, float alpha, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += v[i];
+    s = afi_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, alpha * (red[0] + red[1] + red[2] + red[3]));
+}
+int afi_launch_sum_accum(const float* v, long long n, float alpha, float* out, hipStream_t st) {
+    long long g = (n + 255) / 256; if (g > 64) g = 64; if (g < 1) g = 1;
+    hipLaunchKernelGGL(afi_sum_accum_kernel, dim3((unsigned)g), dim3(256), 0, st, v, n, alpha, out);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+__global__ void afi_inc_i64_kernel(long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }
+int afi_launch_inc_i64(long long* p, hipStream_t st) {
+    hipLaunchKernelGGL(afi_inc_i64_kernel, dim3(1), dim3(64), 0, st, p);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// eval-mode BatchNorm: invstd[c] = rsqrt(running_var[c] + eps)
+__global__ void afi_invstd_kernel(const float* __restrict__ var, float* __restrict__ invstd, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) invstd[c] = rsqrtf(var[c] + AFI_BN_EPS);
+}
+int afi_launch_invstd(const float* var, float* invstd, int C, hipStream_t st) {
+    hipLaunchKernelGGL(afi_invstd_kernel, dim3(afi_cdiv(C, 256)), dim3(256), 0, st, var, invstd, C);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}

@@ -1,0 +1,475 @@
+// fp32-MFMA implicit-GEMM kernels for the AFI-GAN hot path on gfx950 (CDNA4).
+//
+// Every heavy op of the AF interpolator and of the feature-patch discriminator is a 3x3 correlation
+// (SURVEY.md 2.1): forward convs, the ConvTranspose2d(k6,s2,p2) (= 4 phase-wise 3x3 convs + pixel
+// shuffle), their data gradients and their weight gradients.  All of them run through two kernels:
+//
+//   afi_pix_gemm_kernel    C[pixel][col]  = sum_{tap,c} A[pixel (+/-) tap][c] * B[(tap,c)][col]
+//   afi_wgrad_gemm_kernel  dW[row][tap][col] += sum_pixel dY[pixel][row] * X[pixel + tap][col]
+//
+// Design (MI355X-first, not a translated CUDA tiling):
+//   * activations are pixel-major (NHWC): the K dimension (channels of one tap) is contiguous, so a
+//     128-B cache line is one pixel's 32-channel chunk and the tap windows are re-read from L2, not HBM;
+//   * exact-f32 matrix cores: v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, bit-identical to an fmaf chain);
+//     each wave owns MI x NI 32x32 accumulator blocks (64x64 per wave in the 128x128 tile);
+//   * operands are staged through LDS in their NATURAL orientation, so there is never a transpose:
+//       "KC" (k contiguous in memory)  -> LDS [row][BK+4], one ds_read_b128 feeds 4 MFMA k-steps
+//                                         (16-B row pad => conflict-free b128 reads),
+//       "RC" (row contiguous in memory) -> LDS [k][rows], ds_read_b32 (32 consecutive rows per half-wave);
+//     the K order inside a stage is permuted identically for A and B (lane half h owns k = 8s+4h+j);
+//   * register-staged prefetch (global -> VGPR while the MFMAs of the current stage run, VGPR -> LDS after
+//     the barrier), 36 KB of LDS per 256-thread block so 4 blocks (16 waves) share a CU;
+//   * XCD-aware block->tile map: each of the 8 XCDs gets one contiguous run of tiles (n fastest), so the
+//     blocks that share an A tile hit the same private L2;
+//   * fused epilogues: bias, LeakyReLU, alpha/beta, two residual adds, bilinear-x2 skip add, pixel-shuffle
+//     store (conv-transpose), LeakyReLU-derivative mask (dgrad), channel-slice in/out of wider buffers
+//     (the RDB dense buffer replaces every torch.cat of generator_rdb.py:66-68).
+#include "afi_common.h"
+
+#define AFI_BK 32
+#define AFI_LDK (AFI_BK + 4)
+
+__device__ __forceinline__ float afi_lrelu(float v) { return v > 0.f ? v : v * AFI_LRELU_SLOPE; }
+
+// bilinear x2, align_corners=False (generator_rdb.py:125): s = max(0.5*o - 0.25, 0)
+__device__ __forceinline__ void afi_bil_idx(int o, int L, int& i0, int& i1, float& lam) {
+    float s = fmaxf(0.5f * (float)o - 0.25f, 0.f);
+    i0 = (int)s;                 // s >= 0 so truncation == floor
+    lam = s - (float)i0;
+    i1 = min(i0 + 1, L - 1);
+}
+
+template <int BM, int BN, int WM, int WN, bool B_RC>
+__global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, int ntile_n, int ntiles, int chunk) {
+    constexpr int BK = AFI_BK, LDK = AFI_LDK;
+    constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
+    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(MI >= 1 && NI >= 1, "tile too small for the wave layout");
+    constexpr int A_LOADS = BM / 32;                      // float4 loads per thread per stage (A, KC)
+    constexpr int B_F4 = BN / 4;                          // RC: float4 per k-row
+    constexpr int B_LOADS = B_RC ? (BK * B_F4) / 256 : BN / 32;
+    static_assert(B_LOADS >= 1, "tile too small");
+    constexpr int B_ROWS_PER_PASS = 256 / B_F4;           // RC
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                     // [BM][LDK]
+    float* Bs = smem + BM * LDK;                          // KC: [BN][LDK]   RC: [BK][BN]
+    int* rowtab = (int*)(Bs + (B_RC ? BK * BN : BN * LDK));  // [3][BM]: img, y, x of each tile row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    // XCD-aware tile map: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int t = xcd * chunk + jb;
+    if (t >= ntiles) return;
+    const int tile_m = t / ntile_n, tile_n = t - tile_m * ntile_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int HW = p.H * p.W;
+    const long long M = (long long)p.N * HW;
+
+    // decode the tile's rows once (shared by the A gather and the epilogue)
+    if (tid < BM) {
+        long long m = (long long)m0 + tid;
+        int img = -1, y = -(1 << 20), x = -(1 << 20);
+        if (m < M) {
+            img = (int)(m / HW);
+            int rem = (int)(m - (long long)img * HW);
+            y = rem / p.W;
+            x = rem - y * p.W;
+        }
+        rowtab[tid] = img; rowtab[BM + tid] = y; rowtab[2 * BM + tid] = x;
+    }
+    __syncthreads();
+
+    // ---- loader state ----
+    const int aq = tid & 7, ar = tid >> 3;                // A (KC): float4 column, first row
+    long long a_base[A_LOADS]; int a_y[A_LOADS], a_x[A_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        int r = ar + 32 * i;
+        int img = rowtab[r];
+        a_y[i] = rowtab[BM + r]; a_x[i] = rowtab[2 * BM + r];
+        a_base[i] = (long long)(img < 0 ? 0 : img) * p.A.sN;
+    }
+    const int Ck4 = (p.Ck + 3) & ~3;
+    const int cchunks = (p.Ck + BK - 1) / BK;
+    const int nK = p.ntaps * p.nKphase * cchunks;
+
+    f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+
+    auto prefetch = [&](int kc) {
+        int tap = kc / (p.nKphase * cchunks);
+        int rem = kc - tap * (p.nKphase * cchunks);
+        int kph = rem / cchunks;
+        int c0 = (rem - kph * cchunks) * BK;
+        int dy = 0, dx = 0;
+        if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+        dy *= p.a_sgn; dx *= p.a_sgn;
+        const int pa = kph >> 1, pc = kph & 1;
+        const int ca = c0 + 4 * aq;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            int yy = a_y[i] + dy, xx = a_x[i] + dx;
+            bool ok = ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W) && (ca < Ck4);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                const float* src = p.A.p + a_base[i] + (long long)(yy * p.a_up + pa) * p.A.sH +
+                                   (long long)(xx * p.a_up + pc) * p.A.sW + ca;
+                v = *(const f32x4*)src;
+            }
+            a_reg[i] = v;
+        }
+        if constexpr (!B_RC) {
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                int n = n0 + ar + 32 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < p.Ncols && ca < Ck4) v = *(const f32x4*)(p.B + (long long)n * p.b_sRow + (long long)tap * p.b_sTap + ca);
+                b_reg[i] = v;
+            }
+        } else {
+            const int cq = tid % B_F4, kr = tid / B_F4;
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) {
+                int c = c0 + kr + B_ROWS_PER_PASS * i;
+                int n = n0 + 4 * cq;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (c < p.Ck && n < p.Ncols)
+                    v = *(const f32x4*)(p.B + (long long)(kph * p.Ck + c) * p.b_sRow + (long long)tap * p.b_sTap + n);
+                b_reg[i] = v;
+            }
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) *(f32x4*)(As + (ar + 32 * i) * LDK + 4 * aq) = a_reg[i];
+        if constexpr (!B_RC) {
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (ar + 32 * i) * LDK + 4 * aq) = b_reg[i];
+        } else {
+            const int cq = tid % B_F4, kr = tid / B_F4;
+#pragma unroll
+            for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (kr + B_ROWS_PER_PASS * i) * BN + 4 * cq) = b_reg[i];
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    prefetch(0);
+    for (int kc = 0; kc < nK; ++kc) {
+        stage_store();
+        __syncthreads();
+        if (kc + 1 < nK) prefetch(kc + 1);
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            f32x4 a[MI], b[NI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+                a[mi] = *(const f32x4*)(As + ((wm * MI + mi) * 32 + lr) * LDK + s * 8 + lh * 4);
+            if constexpr (!B_RC) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    b[ni] = *(const f32x4*)(Bs + ((wn * NI + ni) * 32 + lr) * LDK + s * 8 + lh * 4);
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b[ni][j] = Bs[(s * 8 + lh * 4 + j) * BN + (wn * NI + ni) * 32 + lr];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: accumulators -> LDS (32 tile rows per wave row at a time) -> float4 rows, so every global access of
+    //      the epilogue (store, residual / mask / bilinear reads) is a contiguous 16 B per lane, 512 B per 32 lanes ----
+    constexpr int LDC = BN + 4;
+    constexpr int C_F4 = BN / 4;
+    static_assert(WM * 32 * LDC <= BM * LDK + (B_RC ? BK * BN : BN * LDK), "C staging tile must fit in the operand tiles");
+    float* Cs = smem;
+    const int Hs = p.H >> 1, Ws = p.W >> 1;               // bilinear source extents (R1 low-res)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + (wn * NI + ni) * 32 + lr] = acc[mi][ni][r];
+        __syncthreads();
+        for (int item = tid; item < WM * 32 * C_F4; item += 256) {
+            const int rloc = item / C_F4, c4 = item - rloc * C_F4;
+            const int rl = ((rloc >> 5) * MI + mi) * 32 + (rloc & 31);
+            const int img = rowtab[rl];
+            const int col = n0 + 4 * c4;
+            if (img < 0 || col >= p.Ncols) continue;
+            const int y = rowtab[BM + rl], x = rowtab[2 * BM + rl];
+            int phase = 0, ch = col;
+            if (p.o_up == 2) { phase = col / p.CoutPhase; ch = col - phase * p.CoutPhase; }
+            const int yo = y * p.o_up + (phase >> 1), xo = x * p.o_up + (phase & 1);
+            float* dst = p.O.p + (long long)img * p.O.sN + (long long)yo * p.O.sH + (long long)xo * p.O.sW + ch;
+            f32x4 v = p.alpha * *(const f32x4*)(Cs + rloc * LDC + 4 * c4);
+            if (p.bias) v += *(const f32x4*)(p.bias + ch);
+            if (p.beta != 0.f) v += p.beta * *(const f32x4*)dst;
+            if (p.R1.p && ch >= p.r1_lo && ch < p.r1_hi) {
+                if (p.r1_bilinear) {
+                    int by0, by1, bx0, bx1; float ly, lx;
+                    afi_bil_idx(y, Hs, by0, by1, ly); afi_bil_idx(x, Ws, bx0, bx1, lx);
+                    const float* rb = p.R1.p + (long long)img * p.R1.sN + ch;
+                    const f32x4 x00 = *(const f32x4*)(rb + (long long)by0 * p.R1.sH + (long long)bx0 * p.R1.sW);
+                    const f32x4 x01 = *(const f32x4*)(rb + (long long)by0 * p.R1.sH + (long long)bx1 * p.R1.sW);
+                    const f32x4 x10 = *(const f32x4*)(rb + (long long)by1 * p.R1.sH + (long long)bx0 * p.R1.sW);
+                    const f32x4 x11 = *(const f32x4*)(rb + (long long)by1 * p.R1.sH + (long long)bx1 * p.R1.sW);
+                    const f32x4 top = x00 * (1.f - lx) + x01 * lx;
+                    const f32x4 bot = x10 * (1.f - lx) + x11 * lx;
+                    v += p.r1s * (top * (1.f - ly) + bot * ly);
+                } else {
+                    v += p.r1s * *(const f32x4*)(p.R1.p + (long long)img * p.R1.sN + (long long)yo * p.R1.sH + (long long)xo * p.R1.sW + ch);
+                }
+            }
+            if (p.R2.p && ch >= p.r2_lo && ch < p.r2_hi)
+                v += p.r2s * *(const f32x4*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch);
+            if (p.lrelu) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = afi_lrelu(v[j]);
+            }
+            if (p.Z.p && ch >= p.z_lo && ch < p.z_hi) {
+                const f32x4 z = *(const f32x4*)(p.Z.p + (long long)img * p.Z.sN + (long long)yo * p.Z.sH + (long long)xo * p.Z.sW + ch);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] *= (z[j] > 0.f ? 1.f : AFI_LRELU_SLOPE);
+            }
+            *(f32x4*)dst = v;
+        }
+        if (mi + 1 < MI) __syncthreads();
+    }
+    (void)zero4;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: both operands are pixel-major, i.e. "RC" for a GEMM whose K runs over pixels
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void afi_wgrad_gemm_kernel(const AfiWgradGemm p, int ntile_m, int ntile_n, int kper) {
+    constexpr int BK = AFI_BK;
+    constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
+    static_assert(WM * WN == 4, "4 waves per block");
+    constexpr int A_F4 = BM / 4, B_F4 = BN / 4;
+    constexpr int A_LOADS = (BK * A_F4) / 256, B_LOADS = (BK * B_F4) / 256;
+    static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small");
+    constexpr int A_RPP = 256 / A_F4, B_RPP = 256 / B_F4;  // k-rows covered per load pass
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [BK][BM]
+    float* Bs = smem + BK * BM;       // [BK][BN]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+
+    int t = blockIdx.x;
+    const int tap = t % p.ntaps; t /= p.ntaps;
+    const int tile_n = t % ntile_n; const int tile_m = t / ntile_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int dy = 0, dx = 0;
+    if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+
+    const int HW = p.H * p.W;
+    const long long P = (long long)p.N * HW;
+    const long long k_begin = (long long)blockIdx.y * kper;
+    const long long k_end = (k_begin + kper < P) ? k_begin + kper : P;
+    if (k_begin >= k_end) return;
+    const int nK = (int)((k_end - k_begin + BK - 1) / BK);
+
+    // per-thread loader state: the pixel of each load pass, advanced by BK pixels per stage
+    const int a_cq = tid % A_F4, a_kr = tid / A_F4;
+    const int b_cq = tid % B_F4, b_kr = tid / B_F4;
+    int an[A_LOADS], ay[A_LOADS], ax[A_LOADS];
+    int bn[B_LOADS], by[B_LOADS], bx[B_LOADS];
+    auto decode = [&](long long pix, int& n, int& y, int& x) {
+        n = (int)(pix / HW);
+        int rem = (int)(pix - (long long)n * HW);
+        y = rem / p.W; x = rem - y * p.W;
+    };
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) decode(k_begin + a_kr + A_RPP * i, an[i], ay[i], ax[i]);
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) decode(k_begin + b_kr + B_RPP * i, bn[i], by[i], bx[i]);
+    const int adv_y = BK / p.W, adv_x = BK - adv_y * p.W;
+    auto advance = [&](int& n, int& y, int& x) {
+        x += adv_x; y += adv_y;
+        if (x >= p.W) { x -= p.W; ++y; }
+        while (y >= p.H) { y -= p.H; ++n; }
+    };
+
+    // A column (co') of this thread: phase / channel split for the pixel-shuffled dY of the conv-transpose
+    const int a_col = m0 + 4 * a_cq;
+    int a_ph = 0, a_ch = a_col;
+    if (p.dy_up == 2) { a_ph = a_col / p.CoutPhase; a_ch = a_col - a_ph * p.CoutPhase; }
+    const bool a_col_ok = a_col < p.Mrows;
+    const int b_col = n0 + 4 * b_cq;
+    const bool b_col_ok = b_col < p.Ncols;
+
+    f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    auto prefetch = [&](int kc) {
+        const long long kb = k_begin + (long long)kc * BK;
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (a_col_ok && kb + a_kr + A_RPP * i < k_end) {
+                const float* src = p.DY.p + (long long)an[i] * p.DY.sN + (long long)(ay[i] * p.dy_up + (a_ph >> 1)) * p.DY.sH +
+                                   (long long)(ax[i] * p.dy_up + (a_ph & 1)) * p.DY.sW + a_ch;
+                v = *(const f32x4*)src;
+            }
+            a_reg[i] = v;
+            advance(an[i], ay[i], ax[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            int yy = by[i] + dy, xx = bx[i] + dx;
+            if (b_col_ok && kb + b_kr + B_RPP * i < k_end && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
+                const float* src = p.X.p + (long long)bn[i] * p.X.sN + (long long)yy * p.X.sH + (long long)xx * p.X.sW + b_col;
+                v = *(const f32x4*)src;
+            }
+            b_reg[i] = v;
+            advance(bn[i], by[i], bx[i]);
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) *(f32x4*)(As + (a_kr + A_RPP * i) * BM + 4 * a_cq) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (b_kr + B_RPP * i) * BN + 4 * b_cq) = b_reg[i];
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    prefetch(0);
+    for (int kc = 0; kc < nK; ++kc) {
+        stage_store();
+        __syncthreads();
+        if (kc + 1 < nK) prefetch(kc + 1);
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            f32x4 a[MI], b[NI];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) a[mi][j] = As[(s * 8 + lh * 4 + j) * BM + (wm * MI + mi) * 32 + lr];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) b[ni][j] = Bs[(s * 8 + lh * 4 + j) * BN + (wn * NI + ni) * 32 + lr];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const bool use_atomic = gridDim.y > 1;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row >= p.Mrows) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = n0 + (wn * NI + ni) * 32 + lr;
+                if (col >= p.Ncols) continue;
+                float* dst = p.DW + (long long)row * p.dw_sRow + (long long)tap * p.dw_sTap + col;
+                float v = p.alpha * acc[mi][ni][r];
+                if (use_atomic) atomicAdd(dst, v); else *dst += v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool B_RC>
+static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
+    const long long M = (long long)p.N * p.H * p.W;
+    const int ntm = afi_cdiv(M, BM), ntn = afi_cdiv(p.Ncols, BN);
+    const int ntiles = ntm * ntn;
+    const int chunk = afi_cdiv(ntiles, 8);
+    const size_t lds = sizeof(float) * (BM * AFI_LDK + (B_RC ? AFI_BK * BN : BN * AFI_LDK)) + sizeof(int) * 3 * BM;
+    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC>), dim3(chunk * 8), dim3(256), lds, st, p, ntn, ntiles, chunk);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st) {
+    const long long M = (long long)p.N * p.H * p.W;
+    if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
+    if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;
+    if (b_rc && (p.Ncols & 3)) return AFI_ERR_UNSUPPORTED;       // RC weight rows are read as float4 along n
+    if (!b_rc && (p.Ck & 3)) return AFI_ERR_UNSUPPORTED;         // KC weight rows are read as float4 along c
+    // tile choice: fill the N side first (weights are shared by every block), shrink M tiles for small maps
+    const bool smallM = M <= 64 * 256;                           // fewer than 256 128-row tiles: use 64-row tiles
+    if (!b_rc) {
+        if (p.Ncols <= 32) return launch_pix<128, 32, 4, 1, false>(p, st);
+        if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, false>(p, st) : launch_pix<128, 64, 2, 2, false>(p, st);
+        return smallM ? launch_pix<64, 64, 2, 2, false>(p, st) : launch_pix<128, 128, 2, 2, false>(p, st);
+    } else {
+        if (p.Ncols <= 32) return launch_pix<128, 32, 4, 1, true>(p, st);
+        if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, true>(p, st) : launch_pix<128, 64, 2, 2, true>(p, st);
+        return smallM ? launch_pix<64, 64, 2, 2, true>(p, st) : launch_pix<128, 128, 2, 2, true>(p, st);
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
+    const long long P = (long long)p.N * p.H * p.W;
+    const int ntm = afi_cdiv(p.Mrows, BM), ntn = afi_cdiv(p.Ncols, BN);
+    const long long tiles = (long long)ntm * ntn * p.ntaps;
+    // split the pixel (K) range until the grid covers the chip ~4x, but keep >= 8 stages per block
+    int splitK = p.splitK;
+    if (splitK <= 0) {
+        splitK = 1;
+        const long long want = 1024;
+        if (tiles < want) splitK = (int)((want + tiles - 1) / tiles);
+        const int maxsplit = (int)((P + 8 * AFI_BK - 1) / (8 * AFI_BK));
+        if (splitK > maxsplit) splitK = maxsplit;
+        if (splitK < 1) splitK = 1;
+    }
+    int kper = (int)((P + splitK - 1) / splitK);
+    kper = ((kper + AFI_BK - 1) / AFI_BK) * AFI_BK;
+    splitK = (int)((P + kper - 1) / kper);
+    const size_t lds = sizeof(float) * AFI_BK * (BM + BN);
+    hipLaunchKernelGGL((afi_wgrad_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles, splitK), dim3(256), lds, st, p, ntm, ntn, kper);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st) {
+    const long long P = (long long)p.N * p.H * p.W;
+    if (P <= 0 || p.Mrows <= 0 || p.Ncols <= 0) return AFI_ERR_BAD_ARG;
+    if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;
+    if ((p.Ncols & 3) || (p.dy_up == 2 && (p.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;   // float4 granularity
+    if (p.Mrows <= 32) return launch_wgrad<32, 128, 1, 4>(p, st);
+    if (p.Mrows <= 64) return launch_wgrad<64, 128, 2, 2>(p, st);
+    return launch_wgrad<128, 128, 2, 2>(p, st);
+}

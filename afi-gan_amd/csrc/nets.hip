@@ -1,0 +1,538 @@
+// C-ABI of libafigan_hip.so: per-op entry points and the whole-network forward / backward sequencing of the
+// AF interpolator (generator_rdb.py:73-130) and the feature-patch discriminator
+// (feature_patch_discriminator.py:16-55).  Host code only: it fills kernel parameter blocks and launches the
+// kernels of igemm.hip / elementwise.hip on the caller's stream.  No allocation, no synchronisation.
+#include <string.h>
+
+#include "../../include/afigan_hip.h"
+#include "afi_common.h"
+
+// ---- launchers implemented in igemm.hip / elementwise.hip
+int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st);
+int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
+int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
+int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
+int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
+int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st);
+int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
+                        float* running_var, float* scratch, hipStream_t st);
+int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                              long long P, int C, hipStream_t st);
+int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                      float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st);
+int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st);
+int afi_launch_stencil9_sum(const float* d9, int ld, const float* bias, float* out, int N, int H, int W, hipStream_t st);
+int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, int H, int W, hipStream_t st);
+int afi_launch_bce_logits(const float* z, long long n, float target, float lscale, float* loss, float gscale, float* dz, hipStream_t st);
+int afi_launch_l1(AfiView a, AfiView b, int N, int h, int w, int C, int Ha, int Wa, float lscale, float* loss, float gscale, float* da,
+                  hipStream_t st);
+int afi_launch_bilinear2x_fwd(AfiView x, int N, int H, int W, int C, float beta, float* out, hipStream_t st);
+int afi_launch_bilinear2x_bwd(const float* dout, int N, int H, int W, int C, float beta, float* dx, hipStream_t st);
+int afi_launch_sgd(const void* descs_dev, int ntensors, long long max_n, float lr, float mom, float gscale, hipStream_t st);
+int afi_launch_scale(float* p, long long n, float s, hipStream_t st);
+int afi_launch_sum_accum(const float* v, long long n, float alpha, float* out, hipStream_t st);
+int afi_launch_inc_i64(long long* p, hipStream_t st);
+int afi_launch_invstd(const float* var, float* invstd, int C, hipStream_t st);
+
+#define AFI_TRY(expr) do { int _s = (expr); if (_s != AFI_OK) return _s; } while (0)
+
+static inline AfiView V(afi_view_t v) { return AfiView{v.p, v.sN, v.sH, v.sW}; }
+static inline AfiView dense_view(const float* p, int H, int W, long long ld) {
+    return AfiView{const_cast<float*>(p), (long long)H * W * ld, (long long)W * ld, ld};
+}
+static inline AfiView ch_off(AfiView v, long long c) { v.p += c; return v; }
+static inline AfiView null_view() { return AfiView{nullptr, 0, 0, 0}; }
+static inline long long align4(long long n) { return (n + 3) & ~3LL; }
+
+static AfiPixGemm pix_default(int N, int H, int W) {
+    AfiPixGemm g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.H = H; g.W = W;
+    g.ntaps = 9; g.nKphase = 1; g.a_sgn = 1; g.a_up = 1; g.o_up = 1;
+    g.alpha = 1.f; g.beta = 0.f; g.r1s = 1.f; g.r2s = 1.f;
+    return g;
+}
+
+// forward 3x3 conv: out = act(alpha*conv(x,w) + bias + beta*out [+ residuals set by the caller])
+static AfiPixGemm conv_fwd_desc(AfiView x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, AfiView out) {
+    AfiPixGemm g = pix_default(N, H, W);
+    g.Ck = Cin; g.Ncols = Cout; g.CoutPhase = Cout;
+    g.A = x; g.B = w; g.b_sRow = 9LL * Cin; g.b_sTap = Cin;
+    g.O = out; g.bias = bias;
+    return g;
+}
+// data gradient of a 3x3 conv with weight w[Cout][3][3][Cin]: dx = alpha*conv^T(dy) + beta*dx
+static AfiPixGemm conv_dgrad_desc(AfiView dy, int N, int H, int W, int Cout, const float* w, int Cin, AfiView dx) {
+    AfiPixGemm g = pix_default(N, H, W);
+    g.a_sgn = -1;
+    g.Ck = Cout; g.Ncols = Cin; g.CoutPhase = Cin;
+    g.A = dy; g.B = w; g.b_sRow = 9LL * Cin; g.b_sTap = Cin;
+    g.O = dx;
+    return g;
+}
+static AfiWgradGemm conv_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha) {
+    AfiWgradGemm g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.H = H; g.W = W; g.ntaps = 9;
+    g.Mrows = Cout; g.Ncols = Cin;
+    g.DY = dy; g.dy_up = 1; g.CoutPhase = Cout;
+    g.X = x; g.DW = dw; g.dw_sRow = 9LL * Cin; g.dw_sTap = Cin;
+    g.alpha = alpha; g.splitK = 0;
+    return g;
+}
+
+extern "C" {
+
+int afi_abi_version(void) { return 1; }
+
+const char* afi_status_string(int s) {
+    switch (s) {
+        case AFI_OK: return "ok";
+        case AFI_ERR_BAD_ARG: return "bad argument";
+        case AFI_ERR_UNSUPPORTED: return "unsupported shape (channel counts must be multiples of 4)";
+        case AFI_ERR_LAUNCH: return "HIP kernel launch failed";
+        case AFI_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ per-op
+int afi_conv3x3_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
+                    float beta, int lrelu, void* stream) {
+    AfiPixGemm g = conv_fwd_desc(V(x), N, H, W, Cin, w, bias, Cout, V(out));
+    g.alpha = alpha; g.beta = beta; g.lrelu = lrelu;
+    return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
+}
+int afi_conv3x3_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
+                      afi_view_t z, void* stream) {
+    AfiPixGemm g = conv_dgrad_desc(V(dy), N, H, W, Cout, w, Cin, V(dx));
+    g.alpha = alpha; g.beta = beta;
+    if (z.p) { g.Z = V(z); g.z_lo = 0; g.z_hi = Cin; }
+    return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
+}
+int afi_conv3x3_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream) {
+    return afi_launch_wgrad_gemm(conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha), (hipStream_t)stream);
+}
+
+int afi_convT6s2_pack_weight(const float* w, float* wp, int Cin, int Cout, void* stream) {
+    return afi_launch_convT_pack(w, wp, Cin, Cout, (hipStream_t)stream);
+}
+int afi_convT6s2_unpack_wgrad(const float* dwp, float* dw, int Cin, int Cout, void* stream) {
+    return afi_launch_convT_unpack_grad(dwp, dw, Cin, Cout, (hipStream_t)stream);
+}
+static AfiPixGemm convT_fwd_desc(AfiView x, int N, int H, int W, int Cin, const float* wp, const float* bias, int Cout, AfiView out) {
+    AfiPixGemm g = pix_default(N, H, W);
+    g.Ck = Cin; g.Ncols = 4 * Cout; g.CoutPhase = Cout; g.o_up = 2;
+    g.A = x; g.B = wp; g.b_sRow = 9LL * Cin; g.b_sTap = Cin;
+    g.O = out; g.bias = bias;
+    return g;
+}
+static AfiPixGemm convT_dgrad_desc(AfiView dy, int N, int H, int W, int Cout, const float* wp, int Cin, AfiView dx) {
+    AfiPixGemm g = pix_default(N, H, W);
+    g.a_sgn = -1; g.a_up = 2; g.nKphase = 4;
+    g.Ck = Cout; g.Ncols = Cin; g.CoutPhase = Cin;
+    g.A = dy; g.B = wp; g.b_sRow = 9LL * Cin; g.b_sTap = Cin;
+    g.O = dx;
+    return g;
+}
+static AfiWgradGemm convT_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dwp, float alpha) {
+    AfiWgradGemm g = conv_wgrad_desc(dy, x, N, H, W, 4 * Cout, Cin, dwp, alpha);
+    g.dy_up = 2; g.CoutPhase = Cout;
+    return g;
+}
+int afi_convT6s2_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* wp, const float* bias, int Cout, afi_view_t out, int lrelu,
+                     void* stream) {
+    if (Cout & 3) return AFI_ERR_UNSUPPORTED;
+    AfiPixGemm g = convT_fwd_desc(V(x), N, H, W, Cin, wp, bias, Cout, V(out));
+    g.lrelu = lrelu;
+    return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
+}
+int afi_convT6s2_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* wp, int Cin, afi_view_t dx, afi_view_t z, void* stream) {
+    if (Cout & 3) return AFI_ERR_UNSUPPORTED;
+    AfiPixGemm g = convT_dgrad_desc(V(dy), N, H, W, Cout, wp, Cin, V(dx));
+    if (z.p) { g.Z = V(z); g.z_lo = 0; g.z_hi = Cin; }
+    return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
+}
+int afi_convT6s2_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dwp, float alpha, void* stream) {
+    if (Cout & 3) return AFI_ERR_UNSUPPORTED;
+    return afi_launch_wgrad_gemm(convT_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dwp, alpha), (hipStream_t)stream);
+}
+
+int afi_bilinear2x_add_fwd(afi_view_t x, int N, int H, int W, int C, float beta, float* out, void* stream) {
+    return afi_launch_bilinear2x_fwd(V(x), N, H, W, C, beta, out, (hipStream_t)stream);
+}
+int afi_bilinear2x_add_bwd(const float* dout, int N, int H, int W, int C, float beta, float* dx, void* stream) {
+    return afi_launch_bilinear2x_bwd(dout, N, H, W, C, beta, dx, (hipStream_t)stream);
+}
+int afi_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var, float* rm, float* rv, float* scratch,
+                 void* stream) {
+    return afi_launch_bn_stats(x, P, C, mean, invstd, var, rm, rv, scratch, (hipStream_t)stream);
+}
+int afi_bn_apply_lrelu_fwd(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                           long long P, int C, void* stream) {
+    return afi_launch_bn_apply_lrelu(x, y, mean, invstd, gamma, beta, P, C, (hipStream_t)stream);
+}
+int afi_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+               float* dbeta, long long P, int C, float* scratch, void* stream) {
+    return afi_launch_bn_bwd(g, x, dx, mean, invstd, gamma, dgamma, dbeta, 1.f, P, C, scratch, (hipStream_t)stream);
+}
+int afi_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, void* stream) {
+    return afi_launch_colsum_accum(g, P, C, ld, alpha, db, scratch, (hipStream_t)stream);
+}
+int afi_bce_logits_fwd_bwd(const float* z, long long n, float target, float lscale, float* loss, float gscale, float* dz, void* stream) {
+    return afi_launch_bce_logits(z, n, target, lscale, loss, gscale, dz, (hipStream_t)stream);
+}
+int afi_l1_fwd_bwd(afi_view_t a, afi_view_t b, int N, int h, int w, int C, int Ha, int Wa, float lscale, float* loss, float gscale,
+                   float* da, void* stream) {
+    return afi_launch_l1(V(a), V(b), N, h, w, C, Ha, Wa, lscale, loss, gscale, da, (hipStream_t)stream);
+}
+int afi_sgd_momentum_step(const afi_sgd_desc_t* descs_dev, int ntensors, long long max_n, float lr, float momentum, float gscale,
+                          void* stream) {
+    return afi_launch_sgd(descs_dev, ntensors, max_n, lr, momentum, gscale, (hipStream_t)stream);
+}
+int afi_scale_inplace(float* p, long long n, float s, void* stream) { return afi_launch_scale(p, n, s, (hipStream_t)stream); }
+int afi_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, void* stream) {
+    return afi_launch_nchw_to_nhwc(in, out, N, C, P, (hipStream_t)stream);
+}
+int afi_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, void* stream) {
+    return afi_launch_nhwc_to_nchw(in, out, N, C, P, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------ generator
+// forward workspace layout (floats):  [Wp 36*C*C][buf_r : n_rdb x P*L][t : P*C][a7 : P*C][u : 4P*C]     L = C + 4G
+struct GenWs {
+    long long P, L;
+    long long o_wp, o_buf, o_t, o_a7, o_u, total;
+};
+static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
+    GenWs w;
+    w.P = (long long)N * H * W; w.L = C + 4LL * G;
+    long long o = 0;
+    w.o_wp = o; o += align4(36LL * C * C);
+    w.o_buf = o; o += align4((long long)n_rdb * w.P * w.L);
+    w.o_t = o; o += align4(w.P * C);
+    w.o_a7 = o; o += align4(w.P * C);
+    w.o_u = o; o += align4(4 * w.P * C);
+    w.total = o;
+    return w;
+}
+long long afi_generator_fwd_ws_floats(int C, int G, int n_rdb, int N, int H, int W) { return gen_ws(C, G, n_rdb, N, H, W).total; }
+
+// backward scratch layout: [dU 4P*C][gA P*C][gB P*C][dBuf0 P*L][dBuf1 P*L][dWp 36*C*C][red]
+struct GenBwdWs {
+    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_red, total;
+};
+static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
+    GenBwdWs w;
+    const long long P = (long long)N * H * W, L = C + 4LL * G;
+    long long o = 0;
+    w.o_du = o; o += align4(4 * P * C);
+    w.o_ga = o; o += align4(P * C);
+    w.o_gb = o; o += align4(P * C);
+    w.o_db0 = o; o += align4(P * L);
+    w.o_db1 = o; o += align4(P * L);
+    w.o_dwp = o; o += align4(36LL * C * C);
+    w.o_red = o; o += align4(afi_reduce_scratch_floats(C));
+    w.total = o;
+    return w;
+}
+long long afi_generator_bwd_ws_floats(int C, int G, int n_rdb, int N, int H, int W) { return gen_bwd_ws(C, G, n_rdb, N, H, W).total; }
+
+static int gen_check(const afi_gen_params_t* p) {
+    if (!p || p->C <= 0 || p->G <= 0 || p->n_rdb < 1 || p->n_rdb > AFI_MAX_RDB) return AFI_ERR_BAD_ARG;
+    if ((p->C & 3) || (p->G & 3)) return AFI_ERR_UNSUPPORTED;
+    return AFI_OK;
+}
+
+int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, int W, afi_view_t outv, float* ws, long long ws_floats,
+                      void* stream) {
+    AFI_TRY(gen_check(prm));
+    if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || !outv.p) return AFI_ERR_BAD_ARG;
+    const int C = prm->C, G = prm->G, R = prm->n_rdb;
+    const GenWs l = gen_ws(C, G, R, N, H, W);
+    if (ws_floats < l.total) return AFI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int L = (int)l.L;
+    const float rs = prm->residual_scale;
+    float* wp = ws + l.o_wp;
+    AfiView x = V(xv);
+    auto buf = [&](int r) { return dense_view(ws + l.o_buf + (long long)r * l.P * L, H, W, L); };
+    AfiView t = dense_view(ws + l.o_t, H, W, C), a7 = dense_view(ws + l.o_a7, H, W, C);
+    AfiView u = dense_view(ws + l.o_u, 2 * H, 2 * W, C);
+
+    AFI_TRY(afi_launch_convT_pack(prm->wT, wp, C, C, st));
+    {   // head conv + LReLU (generator_rdb.py:91-93) -> channels [0,C) of RDB 0's dense buffer
+        AfiPixGemm g = conv_fwd_desc(x, N, H, W, C, prm->w0, prm->b0, C, buf(0));
+        g.lrelu = 1;
+        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+    }
+    for (int r = 0; r < R; ++r) {   // ResidualDenseBlock.forward (generator_rdb.py:64-71); the dense buffer replaces torch.cat
+        AfiView b = buf(r);
+        for (int k = 1; k <= 4; ++k) {
+            const int cin = C + (k - 1) * G;
+            AfiPixGemm g = conv_fwd_desc(b, N, H, W, cin, prm->rdb_w[r][k - 1], nullptr, G, ch_off(b, cin));
+            g.lrelu = 1;
+            AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+        }
+        const bool last = (r == R - 1);
+        AfiPixGemm g = conv_fwd_desc(b, N, H, W, L, prm->rdb_w[r][4], nullptr, C, last ? t : buf(r + 1));
+        g.R1 = b; g.r1_lo = 0; g.r1_hi = C;
+        if (!last) {            // x + rs * conv5
+            g.alpha = rs; g.r1s = 1.f;
+        } else {                // ResidualInResidual.forward (:27-30): rs*(x + rs*conv5) + a0
+            g.alpha = rs * rs; g.r1s = rs;
+            g.R2 = buf(0); g.r2s = 1.f; g.r2_lo = 0; g.r2_hi = C;
+        }
+        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+    }
+    {   // trunk conv + LReLU (:97-99)
+        AfiPixGemm g = conv_fwd_desc(t, N, H, W, C, prm->w7, prm->b7, C, a7);
+        g.lrelu = 1;
+        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+    }
+    {   // ConvTranspose2d k6 s2 p2 + LReLU (:101-105) as a 4-phase 3x3 conv with a pixel-shuffle store
+        AfiPixGemm g = convT_fwd_desc(a7, N, H, W, C, wp, prm->bT, C, u);
+        g.lrelu = 1;
+        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+    }
+    {   // final conv (:107-108) + bilinear x2 skip of the input (:125,130) fused in the epilogue
+        AfiPixGemm g = conv_fwd_desc(u, N, 2 * H, 2 * W, C, prm->w9, prm->b9, C, V(outv));
+        g.R1 = x; g.r1s = 1.f; g.r1_lo = 0; g.r1_hi = C; g.r1_bilinear = 1;
+        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+    }
+    return AFI_OK;
+}
+
+int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
+                      const float* dout, float* dx, float* scratch, long long scratch_floats, void* stream) {
+    AFI_TRY(gen_check(prm));
+    if (!gr || N <= 0 || H <= 0 || W <= 0 || !ws || !dout || !scratch) return AFI_ERR_BAD_ARG;
+    const int C = prm->C, G = prm->G, R = prm->n_rdb;
+    const GenWs l = gen_ws(C, G, R, N, H, W);
+    const GenBwdWs s = gen_bwd_ws(C, G, R, N, H, W);
+    if (scratch_floats < s.total) return AFI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int L = (int)l.L;
+    const long long P = l.P;
+    const float rs = prm->residual_scale;
+    const float* wp = ws + l.o_wp;
+    AfiView x = V(xv);
+    auto buf = [&](int r) { return dense_view(ws + l.o_buf + (long long)r * P * L, H, W, L); };
+    AfiView t = dense_view(ws + l.o_t, H, W, C), a7 = dense_view(ws + l.o_a7, H, W, C);
+    AfiView u = dense_view(ws + l.o_u, 2 * H, 2 * W, C);
+    AfiView dOut = dense_view(dout, 2 * H, 2 * W, C);
+    AfiView dU = dense_view(scratch + s.o_du, 2 * H, 2 * W, C);
+    AfiView gA = dense_view(scratch + s.o_ga, H, W, C), gB = dense_view(scratch + s.o_gb, H, W, C);
+    AfiView dB[2] = {dense_view(scratch + s.o_db0, H, W, L), dense_view(scratch + s.o_db1, H, W, L)};
+    float* dwp = scratch + s.o_dwp;
+    float* red = scratch + s.o_red;
+
+    // ---- final conv (generator_rdb.py:107-108)
+    if (gr->w9) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dOut, u, N, 2 * H, 2 * W, C, C, gr->w9, 1.f), st));
+    if (gr->b9) AFI_TRY(afi_launch_colsum_accum(dout, 4 * P, C, C, 1.f, gr->b9, red, st));
+    {
+        AfiPixGemm g = conv_dgrad_desc(dOut, N, 2 * H, 2 * W, C, prm->w9, C, dU);
+        g.Z = u; g.z_lo = 0; g.z_hi = C;                       // through the LReLU after the conv-transpose
+        AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+    }
+    // ---- conv-transpose (:101-105)
+    if (gr->wT) {
+        if (hipMemsetAsync(dwp, 0, sizeof(float) * 36LL * C * C, st) != hipSuccess) return AFI_ERR_LAUNCH;
+        AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), st));
+        AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, st));
+    }
+    if (gr->bT) AFI_TRY(afi_launch_colsum_accum(dU.p, 4 * P, C, C, 1.f, gr->bT, red, st));
+    {
+        AfiPixGemm g = convT_dgrad_desc(dU, N, H, W, C, wp, C, gA);
+        g.Z = a7; g.z_lo = 0; g.z_hi = C;
+        AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+    }
+    // ---- trunk conv (:97-99): gA = d(pre-activation of a7)
+    if (gr->w7) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gA, t, N, H, W, C, C, gr->w7, 1.f), st));
+    if (gr->b7) AFI_TRY(afi_launch_colsum_accum(gA.p, P, C, C, 1.f, gr->b7, red, st));
+    AFI_TRY(afi_launch_pix_gemm(conv_dgrad_desc(gA, N, H, W, C, prm->w7, C, gB), 1, st));    // gB = dT
+    // ---- ResidualInResidual (:27-30) and the RDB chain (:64-71), last block first
+    AfiView Gt = gB;        // incoming gradient tensor, true gradient = gs * Gt
+    float gs = rs;
+    for (int r = R - 1; r >= 0; --r) {
+        AfiView b = buf(r), d = dB[r & 1];
+        // conv5: out = x + rs*conv5(cat)
+        if (gr->rdb_w[r][4]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(Gt, b, N, H, W, C, L, gr->rdb_w[r][4], rs * gs), st));
+        {
+            AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->rdb_w[r][4], L, d);
+            g.alpha = rs * gs;
+            g.R1 = Gt; g.r1s = gs; g.r1_lo = 0; g.r1_hi = C;           // identity path of the block
+            g.Z = b; g.z_lo = C + 3 * G; g.z_hi = L;                   // conv4's LReLU: its slice is final after this kernel
+            AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+        }
+        for (int k = 4; k >= 1; --k) {
+            const int cin = C + (k - 1) * G;
+            AfiView dyk = ch_off(d, cin);                               // d(pre-activation of conv_k), G channels
+            if (gr->rdb_w[r][k - 1]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dyk, b, N, H, W, G, cin, gr->rdb_w[r][k - 1], 1.f), st));
+            AfiPixGemm g = conv_dgrad_desc(dyk, N, H, W, G, prm->rdb_w[r][k - 1], cin, d);
+            g.beta = 1.f;                                               // dense connections: accumulate
+            if (k >= 2) { g.Z = b; g.z_lo = cin - G; g.z_hi = cin; }    // conv_{k-1}'s slice becomes final
+            if (k == 1 && r == 0) {                                     // RRDB skip (+dT) and the head conv's LReLU
+                g.R2 = gB; g.r2s = 1.f; g.r2_lo = 0; g.r2_hi = C;
+                g.Z = b; g.z_lo = 0; g.z_hi = C;
+            }
+            AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+        }
+        Gt = d; gs = 1.f;                                               // channels [0,C) of d = gradient w.r.t. the block input
+    }
+    // ---- head conv (:91-93): Gt[0:C] = d(pre-activation of a0)
+    if (gr->w0) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(Gt, x, N, H, W, C, C, gr->w0, 1.f), st));
+    if (gr->b0) AFI_TRY(afi_launch_colsum_accum(Gt.p, P, C, L, 1.f, gr->b0, red, st));
+    if (dx) {
+        AFI_TRY(afi_launch_bilinear2x_bwd(dout, N, H, W, C, 0.f, dx, st));           // skip path (:125)
+        AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->w0, C, dense_view(dx, H, W, C));
+        g.beta = 1.f;
+        AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+    }
+    return AFI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ discriminator
+// forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][y2 P*F3][d9 P*16][mean,invstd x3][red]
+struct DiscWs {
+    long long P;
+    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, total;
+};
+static DiscWs disc_ws(const int F[4], int N, int H, int W) {
+    DiscWs w;
+    w.P = (long long)N * H * W;
+    long long o = 0;
+    int fmax = 4;
+    for (int n = 0; n < 3; ++n) {
+        w.o_c[n] = o; o += align4(w.P * F[n + 1]);
+        w.o_y[n] = o; o += align4(w.P * F[n + 1]);
+        if (F[n + 1] > fmax) fmax = F[n + 1];
+    }
+    w.o_d9 = o; o += align4(w.P * 16);
+    for (int n = 0; n < 3; ++n) {
+        w.o_mean[n] = o; o += align4(F[n + 1]);
+        w.o_invstd[n] = o; o += align4(F[n + 1]);
+    }
+    w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));
+    w.total = o;
+    return w;
+}
+long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W) { return disc_ws(F, N, H, W).total; }
+struct DiscBwdWs { long long o_ga, o_gb, o_dd9, o_red, total; };
+static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
+    DiscBwdWs w;
+    const long long P = (long long)N * H * W;
+    int fmax = 4;
+    for (int n = 0; n < 4; ++n) if (F[n] > fmax) fmax = F[n];
+    long long o = 0;
+    w.o_ga = o; o += align4(P * fmax);
+    w.o_gb = o; o += align4(P * fmax);
+    w.o_dd9 = o; o += align4(P * 16);
+    w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));
+    w.total = o;
+    return w;
+}
+long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W) { return disc_bwd_ws(F, N, H, W).total; }
+
+static int disc_check(const afi_disc_params_t* p) {
+    if (!p) return AFI_ERR_BAD_ARG;
+    for (int n = 0; n < 4; ++n) {
+        if (p->F[n] <= 0) return AFI_ERR_BAD_ARG;
+        if (p->F[n] & 3) return AFI_ERR_UNSUPPORTED;
+    }
+    return AFI_OK;
+}
+
+int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, int H, int W, float* logits, int training, float* ws,
+                          long long ws_floats, void* stream) {
+    AFI_TRY(disc_check(prm));
+    if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || !logits) return AFI_ERR_BAD_ARG;
+    const DiscWs l = disc_ws(prm->F, N, H, W);
+    if (ws_floats < l.total) return AFI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long long P = l.P;
+    float* red = ws + l.o_red;
+    AfiView in = V(xv);
+    for (int n = 0; n < 3; ++n) {       // Conv2d 3x3 + bias -> BN -> LeakyReLU (feature_patch_discriminator.py:35-38)
+        const int ci = prm->F[n], co = prm->F[n + 1];
+        float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];
+        float* mean = ws + l.o_mean[n]; float* invstd = ws + l.o_invstd[n];
+        AFI_TRY(afi_launch_pix_gemm(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0, st));
+        if (training) {
+            AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st));
+            if (prm->num_batches_tracked[n]) AFI_TRY(afi_launch_inc_i64(prm->num_batches_tracked[n], st));
+            AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
+        } else {
+            AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
+            AFI_TRY(afi_launch_bn_apply_lrelu(c, y, prm->running_mean[n], invstd, prm->gamma[n], prm->beta[n], P, co, st));
+        }
+        in = dense_view(y, H, W, co);
+    }
+    {   // last conv 3x3 F3 -> 1 (:40-41): D9[q][t] = <y2[q], w3[t]> on the MFMA kernel (1x1, 9 columns), then the 9-tap stencil
+        const int F3 = prm->F[3];
+        float* d9 = ws + l.o_d9;
+        AfiPixGemm g = pix_default(N, H, W);
+        g.ntaps = 1; g.Ck = F3; g.Ncols = 9; g.CoutPhase = 9;
+        g.A = in; g.B = prm->w3; g.b_sRow = F3; g.b_sTap = 0;
+        g.O = dense_view(d9, H, W, 16);
+        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+        AFI_TRY(afi_launch_stencil9_sum(d9, 16, prm->b3, logits, N, H, W, st));
+    }
+    return AFI_OK;
+}
+
+int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
+                          const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream) {
+    AFI_TRY(disc_check(prm));
+    if (!gr || N <= 0 || H <= 0 || W <= 0 || !ws || !dlogits || !scratch) return AFI_ERR_BAD_ARG;
+    const DiscWs l = disc_ws(prm->F, N, H, W);
+    const DiscBwdWs s = disc_bwd_ws(prm->F, N, H, W);
+    if (scratch_floats < s.total) return AFI_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long long P = l.P;
+    float* red = scratch + s.o_red;
+    float* gbuf[2] = {scratch + s.o_ga, scratch + s.o_gb};
+    float* dd9 = scratch + s.o_dd9;
+    const int F3 = prm->F[3];
+    // ---- last conv
+    if (gr->b3) AFI_TRY(afi_launch_sum_accum(dlogits, P, 1.f, gr->b3, st));
+    AFI_TRY(afi_launch_stencil9_scatter(dlogits, dd9, 16, N, H, W, st));
+    AfiView y2 = dense_view(ws + l.o_y[2], H, W, F3);
+    if (gr->w3) {
+        AfiWgradGemm g = conv_wgrad_desc(dense_view(dd9, H, W, 16), y2, N, H, W, 9, F3, gr->w3, 1.f);
+        g.ntaps = 1; g.dw_sRow = F3; g.dw_sTap = 0;
+        AFI_TRY(afi_launch_wgrad_gemm(g, st));
+    }
+    int cur = 0;
+    {
+        AfiPixGemm g = pix_default(N, H, W);
+        g.ntaps = 1; g.a_sgn = -1; g.Ck = 9; g.Ncols = F3; g.CoutPhase = F3;
+        g.A = dense_view(dd9, H, W, 16); g.B = prm->w3; g.b_sRow = F3; g.b_sTap = 0;
+        g.O = dense_view(gbuf[cur], H, W, F3);
+        g.Z = y2; g.z_lo = 0; g.z_hi = F3;
+        AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+    }
+    // ---- conv + BN + LReLU blocks, last first
+    for (int n = 2; n >= 0; --n) {
+        const int ci = prm->F[n], co = prm->F[n + 1];
+        float* g_ = gbuf[cur];                        // d(BN output), already through the LReLU mask
+        const float* c = ws + l.o_c[n];
+        AFI_TRY(afi_launch_bn_bwd(g_, c, g_, ws + l.o_mean[n], ws + l.o_invstd[n], prm->gamma[n], gr->gamma[n], gr->beta[n], 1.f, P, co,
+                                  red, st));          // in place: g_ = d(conv output)
+        if (gr->b[n]) AFI_TRY(afi_launch_colsum_accum(g_, P, co, co, 1.f, gr->b[n], red, st));
+        AfiView gy = dense_view(g_, H, W, co);
+        AfiView xin = (n == 0) ? V(xv) : dense_view(ws + l.o_y[n - 1], H, W, ci);
+        if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), st));
+        if (n > 0) {
+            AfiPixGemm g = conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(gbuf[cur ^ 1], H, W, ci));
+            g.Z = xin; g.z_lo = 0; g.z_hi = ci;
+            AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+            cur ^= 1;
+        } else if (dx) {
+            AFI_TRY(afi_launch_pix_gemm(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(dx, H, W, ci)), 1, st));
+        }
+    }
+    return AFI_OK;
+}
+
+}  // extern "C"

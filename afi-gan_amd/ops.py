@@ -1,0 +1,229 @@
+"""Tensor-level wrappers over the per-op C-ABI entry points (used by the modules, the stage-1 engine and the tests).
+
+All tensors are logically NCHW (what detectron2 hands around) but must be *pixel-major* in memory:
+``stride(1) == 1`` (torch.channels_last, or any crop / channel slice of such a tensor).  ``pixel_major`` converts an
+NCHW-contiguous tensor with the library's own transpose kernel.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import View, call
+
+_NULL_VIEW = View(None, 0, 0, 0)
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _check_cuda(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.AfiError("the AFI-GAN hot path runs on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype != torch.float32:
+            raise _lib.AfiError(f"fp32 only on this path, got {t.dtype}")
+
+
+def is_pixel_major(t: torch.Tensor) -> bool:
+    return t.dim() == 4 and (t.stride(1) == 1 or t.size(1) == 1) and all(s % 4 == 0 for s in (t.stride(0), t.stride(2), t.stride(3))) \
+        and t.data_ptr() % 16 == 0
+
+
+def new_pixel_major(N, C_, H, W, device, zero=False) -> torch.Tensor:
+    """Fresh [N,C,H,W] tensor whose memory is [N][H][W][C]."""
+    f = torch.zeros if zero else torch.empty
+    return f((N, H, W, C_), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def pixel_major(t: torch.Tensor) -> torch.Tensor:
+    """Return `t` itself when it is already pixel-major, else an NHWC copy made by afi_nchw_to_nhwc."""
+    _check_cuda(t)
+    if is_pixel_major(t):
+        return t
+    src = t if t.is_contiguous() else t.contiguous()
+    N, C_, H, W = src.shape
+    out = new_pixel_major(N, C_, H, W, t.device)
+    call("afi_nchw_to_nhwc", C.c_void_p(src.data_ptr()), C.c_void_p(out.data_ptr()), N, C_, H * W, stream_ptr())
+    return out
+
+
+def to_nchw_contiguous(t: torch.Tensor) -> torch.Tensor:
+    """Dense pixel-major tensor -> NCHW-contiguous copy (afi_nhwc_to_nchw)."""
+    _check_cuda(t)
+    N, C_, H, W = t.shape
+    assert t.permute(0, 2, 3, 1).is_contiguous()
+    out = torch.empty((N, C_, H, W), device=t.device, dtype=torch.float32)
+    call("afi_nhwc_to_nchw", C.c_void_p(t.data_ptr()), C.c_void_p(out.data_ptr()), N, C_, H * W, stream_ptr())
+    return out
+
+
+def view_of(t: torch.Tensor, c0: int = 0) -> View:
+    """afi_view_t of a pixel-major tensor (optionally starting at channel c0)."""
+    if not is_pixel_major(t):
+        raise _lib.AfiError(f"tensor is not pixel-major: shape {tuple(t.shape)} strides {t.stride()}")
+    return View(t.data_ptr() + 4 * c0, t.stride(0), t.stride(2), t.stride(3))
+
+
+def is_dense_pm(t: torch.Tensor) -> bool:
+    return t.dim() == 4 and t.permute(0, 2, 3, 1).is_contiguous()
+
+
+def ohwi(w: torch.Tensor) -> torch.Tensor:
+    """[O,I,kh,kw] weight whose memory is [O][kh][kw][I] (what the kernels read); copies only if it is not already."""
+    if w.permute(0, 2, 3, 1).is_contiguous():
+        return w
+    return w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
+def new_ohwi(O, I, kh, kw, device, zero=True) -> torch.Tensor:
+    f = torch.zeros if zero else torch.empty
+    return f((O, kh, kw, I), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+# ------------------------------------------------------------------------------------------------ convs
+def conv3x3_fwd(x, w, bias=None, lrelu=False, out=None, alpha=1.0, beta=0.0):
+    _check_cuda(x, w, bias, out)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    w = ohwi(w)
+    if out is None:
+        out = new_pixel_major(N, Cout, H, W, x.device)
+    call("afi_conv3x3_fwd", view_of(x), N, H, W, Cin, _p(w), _p(bias), Cout, view_of(out), float(alpha), float(beta), int(lrelu),
+         stream_ptr())
+    return out
+
+
+def conv3x3_dgrad(dy, w, dx=None, alpha=1.0, beta=0.0, z=None):
+    _check_cuda(dy, w, dx, z)
+    N, Cout, H, W = dy.shape
+    Cin = w.shape[1]
+    w = ohwi(w)
+    if dx is None:
+        dx = new_pixel_major(N, Cin, H, W, dy.device)
+    call("afi_conv3x3_dgrad", view_of(dy), N, H, W, Cout, _p(w), Cin, view_of(dx), float(alpha), float(beta),
+         view_of(z) if z is not None else _NULL_VIEW, stream_ptr())
+    return dx
+
+
+def conv3x3_wgrad(dy, x, dw=None, alpha=1.0):
+    _check_cuda(dy, x, dw)
+    N, Cout, H, W = dy.shape
+    Cin = x.shape[1]
+    if dw is None:
+        dw = new_ohwi(Cout, Cin, 3, 3, dy.device)
+    assert dw.permute(0, 2, 3, 1).is_contiguous()
+    call("afi_conv3x3_wgrad", view_of(dy), view_of(x), N, H, W, Cout, Cin, _p(dw), float(alpha), stream_ptr())
+    return dw
+
+
+def convT_pack(w_iohw):
+    Cin, Cout = w_iohw.shape[:2]
+    w_iohw = w_iohw.contiguous()
+    wp = torch.empty((4 * Cout, 3, 3, Cin), device=w_iohw.device, dtype=torch.float32)
+    call("afi_convT6s2_pack_weight", _p(w_iohw), _p(wp), Cin, Cout, stream_ptr())
+    return wp
+
+
+def convT_fwd(x, wp, bias, Cout, lrelu=False):
+    N, Cin, H, W = x.shape
+    out = new_pixel_major(N, Cout, 2 * H, 2 * W, x.device)
+    call("afi_convT6s2_fwd", view_of(x), N, H, W, Cin, _p(wp), _p(bias), Cout, view_of(out), int(lrelu), stream_ptr())
+    return out
+
+
+def convT_dgrad(dy, wp, Cin, z=None):
+    N, Cout, H2, W2 = dy.shape
+    H, W = H2 // 2, W2 // 2
+    dx = new_pixel_major(N, Cin, H, W, dy.device)
+    call("afi_convT6s2_dgrad", view_of(dy), N, H, W, Cout, _p(wp), Cin, view_of(dx), view_of(z) if z is not None else _NULL_VIEW,
+         stream_ptr())
+    return dx
+
+
+def convT_wgrad(dy, x):
+    """Returns the gradient in torch's [Cin][Cout][6][6] layout."""
+    N, Cout, H2, W2 = dy.shape
+    _, Cin, H, W = x.shape
+    dwp = torch.zeros((4 * Cout, 3, 3, Cin), device=dy.device, dtype=torch.float32)
+    call("afi_convT6s2_wgrad", view_of(dy), view_of(x), N, H, W, Cout, Cin, _p(dwp), 1.0, stream_ptr())
+    dw = torch.zeros((Cin, Cout, 6, 6), device=dy.device, dtype=torch.float32)
+    call("afi_convT6s2_unpack_wgrad", _p(dwp), _p(dw), Cin, Cout, stream_ptr())
+    return dw
+
+
+# ------------------------------------------------------------------------------------------------ bandwidth ops
+def bilinear2x(x, out=None, beta=0.0):
+    N, C_, H, W = x.shape
+    if out is None:
+        out = new_pixel_major(N, C_, 2 * H, 2 * W, x.device)
+    assert is_dense_pm(out)
+    call("afi_bilinear2x_add_fwd", view_of(x), N, H, W, C_, float(beta), _p(out), stream_ptr())
+    return out
+
+
+def bilinear2x_bwd(dout, dx=None, beta=0.0):
+    N, C_, H2, W2 = dout.shape
+    assert is_dense_pm(dout)
+    if dx is None:
+        dx = new_pixel_major(N, C_, H2 // 2, W2 // 2, dout.device)
+    call("afi_bilinear2x_add_bwd", _p(dout), N, H2 // 2, W2 // 2, C_, float(beta), _p(dx), stream_ptr())
+    return dx
+
+
+def reduce_scratch(C_, device):
+    return torch.empty(_lib.load().afi_reduce_scratch_floats(C_), device=device, dtype=torch.float32)
+
+
+def bn_stats(x2d, running_mean=None, running_var=None):
+    """x2d: dense [P, C].  Returns (mean, invstd, var_biased)."""
+    P, C_ = x2d.shape
+    mean, invstd, var = (torch.empty(C_, device=x2d.device) for _ in range(3))
+    call("afi_bn_stats", _p(x2d), P, C_, _p(mean), _p(invstd), _p(var), _p(running_mean), _p(running_var),
+         _p(reduce_scratch(C_, x2d.device)), stream_ptr())
+    return mean, invstd, var
+
+
+def bn_apply_lrelu(x2d, mean, invstd, gamma, beta):
+    P, C_ = x2d.shape
+    y = torch.empty_like(x2d)
+    call("afi_bn_apply_lrelu_fwd", _p(x2d), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), P, C_, stream_ptr())
+    return y
+
+
+def bn_bwd(g2d, x2d, mean, invstd, gamma, dgamma, dbeta):
+    P, C_ = x2d.shape
+    dx = torch.empty_like(x2d)
+    call("afi_bn_bwd", _p(g2d), _p(x2d), _p(dx), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), P, C_,
+         _p(reduce_scratch(C_, x2d.device)), stream_ptr())
+    return dx
+
+
+def colsum_accum(g2d, db, alpha=1.0):
+    P, C_ = g2d.shape
+    call("afi_colsum_accum", _p(g2d), P, C_, g2d.stride(0), float(alpha), _p(db), _p(reduce_scratch(C_, g2d.device)), stream_ptr())
+    return db
+
+
+def bce_logits(z, target, loss, lscale=1.0, gscale=1.0, want_grad=True):
+    """*loss += lscale * BCEWithLogits(z, target).mean(); returns dz (or None)."""
+    z = z.contiguous()
+    dz = torch.empty_like(z) if want_grad else None
+    call("afi_bce_logits_fwd_bwd", _p(z), z.numel(), float(target), float(lscale), _p(loss), float(gscale), _p(dz), stream_ptr())
+    return dz
+
+
+def l1_crop(a, b, loss, lscale=1.0, gscale=1.0, want_grad=True):
+    """*loss += lscale * l1(a[:, :, :h, :w], b[:, :, :h, :w]) with h, w the common extent; returns da (dense, full extent of a)."""
+    N, C_, Ha, Wa = a.shape
+    h, w = min(Ha, b.shape[2]), min(Wa, b.shape[3])
+    da = new_pixel_major(N, C_, Ha, Wa, a.device) if want_grad else None
+    call("afi_l1_fwd_bwd", view_of(a), view_of(b), N, h, w, C_, Ha, Wa, float(lscale), _p(loss), float(gscale), _p(da), stream_ptr())
+    return da

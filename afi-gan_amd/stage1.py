@@ -1,0 +1,261 @@
+"""Stage-1 AFI-GAN G+D step on MI355X: the body of ``AFIGAN_Trainer.run_step`` (reference stage1_trainer.py:305-435).
+
+Per iteration, over the pyramid levels p2..p6 (lr_features -> G -> tr_features, compared with hr_features):
+  D phase (:334-381): tr = G(lr).detach(); crop both to the common size (:437-443); logits = D(hr), D(tr) as SEPARATE
+      calls (separate BatchNorm batch statistics); d_loss = BCE(logit_real, 1) + BCE(logit_fake, 0); backward;
+      D optimizer step.
+  G phase (:384-433): tr = G(lr); adv = BCE(D(tr).detach(), 1) (no gradient, Q1); content = L1(tr, hr);
+      g_loss = 1e-3*adv + content; backward (L1 only reaches G); G optimizer step.  The two extra D forwards still
+      advance D's BatchNorm running statistics (Q2: 4 updates per level per iteration).
+
+MI355X-first differences in HOW (results are the reference's):
+  * no autograd graph: the engine calls the C-ABI forward/backward entry points directly on persistent workspaces;
+  * each D call is back-propagated right after its forward (gradients accumulate in place), so only one D workspace
+    is alive at a time;
+  * G's forward of the D phase is reused by the G phase (G's weights do not change in between, Q5) unless
+    ``reuse_generator_forward=False``;
+  * gradients live in one flat buffer per network (``param.grad`` are views), so data-parallel training is ONE RCCL
+    all-reduce per network per iteration over xGMI, followed by the fused multi-tensor SGD kernel.  (The reference
+    wraps G/D in DDP but calls ``.module`` so its reducer never fires, Q3; the north-star asks for a real all-reduce.)
+  * losses stay on the device; ``metrics()`` reads them back (one sync) instead of two ``.item()`` syncs + two pickle
+    gathers per iteration (stage1_trainer.py:459,465).
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import SgdDesc, call
+from .feature_patch_discriminator import Discriminator
+from .generator_rdb import Generator
+
+
+def warmup_multistep_lr(base_lr: float, it: int, steps: Sequence[int] = (270000,), gamma: float = 0.1,
+                        warmup_factor: float = 1e-3, warmup_iters: int = 1000) -> float:
+    """detectron2 WarmupMultiStepLR with linear warm-up (v0.1.1 defaults; configs/step1_afigan_training/*.yaml:16-20)."""
+    w = 1.0
+    if it < warmup_iters:
+        a = it / warmup_iters
+        w = warmup_factor * (1 - a) + a
+    return base_lr * w * (gamma ** sum(1 for s in steps if it >= s))
+
+
+class _FlatOptim:
+    """Flat gradient + momentum buffers for one network and the device-side descriptor table of the fused SGD kernel
+    (torch.optim.SGD semantics as configured by detectron2 build_optimizer: momentum 0.9, weight decay 1e-4, 0 for norm
+    parameters; stage1_trainer.py:110-114)."""
+
+    def __init__(self, named_params, weight_decay, weight_decay_norm):
+        self.params = [p for _, p in named_params]
+        dev = self.params[0].device
+        sizes = [p.numel() for p in self.params]
+        offs = np.concatenate([[0], np.cumsum([(n + 3) // 4 * 4 for n in sizes])])
+        self.total = int(offs[-1])
+        self.flat_grad = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        self.flat_mom = torch.zeros(self.total, device=dev, dtype=torch.float32)
+        self.grad_ptrs = []
+        descs = (SgdDesc * len(self.params))()
+        for i, ((name, p), n) in enumerate(zip(named_params, sizes)):
+            o = int(offs[i])
+            seg = self.flat_grad[o:o + n]
+            if p.dim() == 4 and not p.is_contiguous():           # [O,I,kh,kw] stored as [O][kh][kw][I]
+                assert p.permute(0, 2, 3, 1).is_contiguous(), name
+                O, I, kh, kw = p.shape
+                p.grad = seg.view(O, kh, kw, I).permute(0, 3, 1, 2)
+            else:
+                assert p.is_contiguous(), name
+                p.grad = seg.view(p.shape)
+            self.grad_ptrs.append(self.flat_grad.data_ptr() + 4 * o)
+            d = descs[i]
+            d.p, d.g, d.m, d.n = p.data_ptr(), self.grad_ptrs[-1], self.flat_mom.data_ptr() + 4 * o, n
+            d.wd = weight_decay_norm if ".norm." in name else weight_decay
+        raw = np.frombuffer(bytes(descs), dtype=np.uint8).copy()
+        self.descs = torch.from_numpy(raw).to(dev)
+        self.n = len(self.params)
+        self.max_n = max(sizes)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def step(self, lr, momentum, gscale=1.0):
+        call("afi_sgd_momentum_step", C.c_void_p(self.descs.data_ptr()), self.n, self.max_n, float(lr), float(momentum), float(gscale),
+             ops.stream_ptr())
+
+
+class Stage1Step:
+    """One stage-1 iteration (D step then G step) for a Generator / Discriminator pair living on one GPU."""
+
+    def __init__(self, G: Generator, D: Discriminator, base_lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-4,
+                 weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (270000,), lr_gamma: float = 0.1,
+                 warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2,
+                 reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None):
+        self.G, self.D = G, D
+        self.gnet, self.dnet = G, D.Discriminators[0]
+        self.base_lr, self.momentum = base_lr, momentum
+        self.lr_steps, self.lr_gamma, self.warmup_factor, self.warmup_iters = tuple(lr_steps), lr_gamma, warmup_factor, warmup_iters
+        self.first_level = first_level
+        self.reuse_g = reuse_generator_forward
+        self.iter = 0
+        self.pg = process_group
+        if distributed is None:
+            distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size(process_group) > 1
+        self.distributed = distributed
+        self.world = torch.distributed.get_world_size(process_group) if distributed else 1
+        for p in list(G.parameters()) + list(D.parameters()):
+            ops._check_cuda(p)
+        if self.distributed:        # DistributedDataParallel(...) ctor semantics: rank 0's weights everywhere (:80-89)
+            for t in list(G.state_dict().values()) + list(D.state_dict().values()):
+                torch.distributed.broadcast(t, src=0, group=process_group)
+        gnames = dict((id(p), n) for n, p in G.named_parameters())
+        dnames = dict((id(p), n) for n, p in D.named_parameters())
+        self.g_order = G._ordered_params()
+        self.d_order = self.dnet._ordered_params()
+        self.g_opt = _FlatOptim([(gnames[id(p)], p) for p in self.g_order], weight_decay, weight_decay_norm)
+        self.d_opt = _FlatOptim([(dnames[id(p)], p) for p in self.d_order], weight_decay, weight_decay_norm)
+        self._lib = _lib.load()
+        self._gprm, self._gkeep = G._param_struct(self.g_order)
+        self._ggrad, _ = G._param_struct([p.grad for p in self.g_order], already_packed=True)
+        self._dprm, self._dkeep = self.dnet._param_struct(self.d_order)
+        self._dgrad, _ = self.dnet._param_struct([p.grad for p in self.d_order], already_packed=True, grads=True)
+        for p, k in list(zip(self.g_order, self._gkeep)) + list(zip(self.d_order, self._dkeep)):
+            if p.data_ptr() != k.data_ptr():
+                raise _lib.AfiError("parameters must be stored in the kernels' layout ([O][kh][kw][I]); "
+                                    "construct the modules with afigan_amd.Generator / Discriminator")
+        self._buf: Dict[str, torch.Tensor] = {}
+        self.losses = None
+        self._loss_names: List[str] = []
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _scratch(self, key: str, floats: int, device) -> torch.Tensor:
+        t = self._buf.get(key)
+        if t is None or t.numel() < floats:
+            t = torch.empty(int(floats), device=device, dtype=torch.float32)
+            self._buf[key] = t
+        return t
+
+    def lr_at(self, it: int) -> float:
+        return warmup_multistep_lr(self.base_lr, it, self.lr_steps, self.lr_gamma, self.warmup_factor, self.warmup_iters)
+
+    def _g_forward(self, level: int, lr: torch.Tensor, key: str):
+        N, Cc, H, W = lr.shape
+        G = self.G
+        n = self._lib.afi_generator_fwd_ws_floats(G.in_channels, G.growth_rate, G.n_residual_dense_blocks, N, H, W)
+        ws = self._scratch(f"{key}{level}", n, lr.device)
+        out = self._buf.get(f"gout{key}{level}")
+        if out is None or tuple(out.shape) != (N, Cc, 2 * H, 2 * W):
+            out = ops.new_pixel_major(N, Cc, 2 * H, 2 * W, lr.device)
+            self._buf[f"gout{key}{level}"] = out
+        call("afi_generator_fwd", C.byref(self._gprm), ops.view_of(lr), N, H, W, ops.view_of(out), C.c_void_p(ws.data_ptr()), n,
+             ops.stream_ptr())
+        return out, ws
+
+    def _d_forward(self, x: torch.Tensor, ws_key: str):
+        N, _, H, W = x.shape
+        F = (C.c_int * 4)(*self.dnet.F)
+        n = self._lib.afi_discriminator_fwd_ws_floats(F, N, H, W)
+        ws = self._scratch(ws_key, n, x.device)
+        logits = self._scratch(ws_key + "_logits", N * H * W, x.device)
+        call("afi_discriminator_fwd", C.byref(self._dprm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), 1,
+             C.c_void_p(ws.data_ptr()), n, ops.stream_ptr())
+        return logits, ws
+
+    def _d_backward(self, x: torch.Tensor, ws: torch.Tensor, dlogits: torch.Tensor):
+        N, _, H, W = x.shape
+        F = (C.c_int * 4)(*self.dnet.F)
+        n = self._lib.afi_discriminator_bwd_ws_floats(F, N, H, W)
+        sc = self._scratch("d_bwd", n, x.device)
+        call("afi_discriminator_bwd", C.byref(self._dprm), C.byref(self._dgrad), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()),
+             C.c_void_p(dlogits.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n, ops.stream_ptr())
+
+    @staticmethod
+    def _crop_pair(tr: torch.Tensor, hr: torch.Tensor):
+        """_reshape_stage1 applied both ways (stage1_trainer.py:345-346,437-443): crop from the origin, never pad."""
+        h, w = min(tr.shape[2], hr.shape[2]), min(tr.shape[3], hr.shape[3])
+        return tr[:, :, :h, :w], hr[:, :, :h, :w]
+
+    def _allreduce(self, opt: _FlatOptim):
+        if not self.distributed:
+            return
+        torch.distributed.all_reduce(opt.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        call("afi_scale_inplace", C.c_void_p(opt.flat_grad.data_ptr()), opt.total, 1.0 / self.world, ops.stream_ptr())
+
+    # ------------------------------------------------------------------------------------------------ the step
+    def run_step(self, lr_features: Sequence[torch.Tensor], hr_features: Sequence[torch.Tensor]):
+        """lr_features / hr_features: lists over levels (p2..p6) of [N,C,h,w] fp32 GPU tensors (detached guide features).
+        Returns nothing; read ``metrics()`` for the loss values."""
+        if not (self.G.training and self.D.training):
+            raise AssertionError("[Stage1Step] model was changed to eval mode!")       # stage1_trainer.py:309
+        nlev = len(lr_features)
+        assert nlev == len(hr_features) and nlev > 0
+        dev = lr_features[0].device
+        lrs = [ops.pixel_major(t) for t in lr_features]
+        hrs = [ops.pixel_major(t) for t in hr_features]
+        names = []
+        for i in range(nlev):
+            lv = self.first_level + i
+            names += [f"d_loss_p{lv}", f"adv_loss_p{lv}", f"content_loss_p{lv}"]
+        if self.losses is None or self._loss_names != names:
+            self.losses = torch.zeros(len(names), device=dev, dtype=torch.float32)
+            self._loss_names = names
+        self.losses.zero_()
+        lptr = self.losses.data_ptr()
+        lr_now = self.lr_at(self.iter)
+
+        # ---------------- D phase (stage1_trainer.py:334-381)
+        self.d_opt.zero_grad()                                                       # :374
+        trs = []
+        for i in range(nlev):
+            tr, ws = self._g_forward(i, lrs[i], "g_ws")                              # :339-341 (.detach(): no graph anyway)
+            trs.append((tr, ws))
+            tr_c, hr_c = self._crop_pair(tr, hrs[i])                                  # :345-346
+            for x, target, key in ((hr_c, 1.0, "d_ws"), (tr_c, 0.0, "d_ws")):        # :349-353, :355-359
+                logits, dws = self._d_forward(x, key)
+                dz = self._scratch("dlogits", logits.numel(), dev)
+                call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], target, 1.0,
+                     C.c_void_p(lptr + 4 * (3 * i)), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
+                self._d_backward(x, dws, dz)                                         # :375 (accumulates into the flat grads)
+        self._allreduce(self.d_opt)
+        self.d_opt.step(lr_now, self.momentum)                                       # :381
+
+        # ---------------- G phase (:384-433)
+        self.g_opt.zero_grad()                                                       # :426
+        for i in range(nlev):
+            if self.reuse_g:
+                tr, ws = trs[i]                                                      # Q5: identical to recomputing G(lr)
+            else:
+                tr, ws = self._g_forward(i, lrs[i], "g_ws")                          # :389-391
+            tr_c, hr_c = self._crop_pair(tr, hrs[i])
+            for x, key in ((tr_c, "adv"), (hr_c, None)):                             # :399-403 (fake first, then real)
+                logits, _ = self._d_forward(x, "d_ws")
+                if key == "adv":                                                     # :408, no gradient (Q1)
+                    call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], 1.0, 1.0,
+                         C.c_void_p(lptr + 4 * (3 * i + 1)), 0.0, C.c_void_p(None), ops.stream_ptr())
+            N, Cc, Ha, Wa = tr.shape
+            da = self._scratch("g_dout", tr.numel(), dev)
+            call("afi_l1_fwd_bwd", ops.view_of(tr), ops.view_of(hrs[i]), N, tr_c.shape[2], tr_c.shape[3], Cc, Ha, Wa, 1.0,
+                 C.c_void_p(lptr + 4 * (3 * i + 2)), 1.0, C.c_void_p(da.data_ptr()), ops.stream_ptr())      # :410
+            lrt = lrs[i]
+            n = self._lib.afi_generator_bwd_ws_floats(self.G.in_channels, self.G.growth_rate, self.G.n_residual_dense_blocks,
+                                                      lrt.shape[0], lrt.shape[2], lrt.shape[3])
+            sc = self._scratch("g_bwd", n, dev)
+            call("afi_generator_bwd", C.byref(self._gprm), C.byref(self._ggrad), ops.view_of(lrt), lrt.shape[0], lrt.shape[2], lrt.shape[3],
+                 C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n,
+                 ops.stream_ptr())                                                   # :427
+        self._allreduce(self.g_opt)
+        self.g_opt.step(lr_now, self.momentum)                                       # :433
+        self.iter += 1
+
+    def metrics(self, check_finite: bool = True) -> Dict[str, float]:
+        """Loss values of the last step (one device sync).  g_loss_p = 1e-3*adv + content (stage1_trainer.py:411)."""
+        vals = self.losses.detach().cpu().tolist()
+        out = dict(zip(self._loss_names, vals))
+        for k in list(out):
+            if k.startswith("adv_loss_p"):
+                lv = k[len("adv_loss_p"):]
+                out[f"g_loss_p{lv}"] = out[k] * 1e-3 + out[f"content_loss_p{lv}"]
+        if check_finite and not all(np.isfinite(v) for v in out.values()):          # _detect_anomaly (:445-451)
+            raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.iter}!\nloss_dict = {out}")
+        return out

@@ -1,0 +1,160 @@
+/*
+ * afigan_hip.h -- C-ABI of the MI355X-native AFI-GAN hot path (libafigan_hip.so, gfx950).
+ *
+ * The reference (inhavl-shlee/AFI-GAN) is pure Python: its "plugin API" for this path is two nn.Module
+ * classes,  Generator (afigan/modeling/feat_interpol/generator_rdb.py:73-130)  and
+ * Discriminator (afigan/modeling/feat_interpol/feature_patch_discriminator.py:16-55),  plus the loss /
+ * optimizer calls of the stage-1 loop (afigan/engine/stage1_trainer.py:305-443).  It has no FFI of its own,
+ * so this header defines the boundary a binding for that path needs: plain pointers, sizes and a HIP stream;
+ * no torch types; every function returns an int status (AFI_OK == 0) and never throws or allocates.
+ * The Python binding a maintainer would add (ctypes) is shown in INTEGRATION.md and shipped in
+ * afi-gan_amd/_lib.py.
+ *
+ * Conventions
+ *   - Activations are PIXEL-MAJOR ("NHWC"): element (n, y, x, c) of a view lives at
+ *     p[n*sN + y*sH + x*sW + c]; strides are in floats, the channel stride is 1.  A torch tensor in
+ *     torch.channels_last memory format is exactly this (zero copy); cropped views
+ *     (stage1_trainer.py:437-443) and channel slices of wider buffers are expressed through p / strides.
+ *   - 3x3 weights are  [Cout][3][3][Cin]  (the physical layout of a [Cout,Cin,3,3] tensor in channels_last
+ *     format, so the reference's state_dict shapes are unchanged); the ConvTranspose2d weight stays in torch's
+ *     [Cin][Cout][6][6] layout.  All data is fp32; the matrix math runs on v_mfma_f32_32x32x2_f32 (exact f32).
+ *   - Channel counts must be multiples of 4 (float4 granularity); spatial sizes are arbitrary.
+ *   - "accumulate" outputs (all gradients w.r.t. parameters) are += targets: zero them first, like
+ *     optimizer.zero_grad() at stage1_trainer.py:374/426.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ */
+#ifndef AFIGAN_HIP_H
+#define AFIGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFI_OK 0
+#define AFI_ERR_BAD_ARG 1
+#define AFI_ERR_UNSUPPORTED 2
+#define AFI_ERR_LAUNCH 3
+#define AFI_ERR_WORKSPACE 4
+
+#define AFI_MAX_RDB 8
+
+typedef struct afi_view {
+    float* p;
+    long long sN, sH, sW;
+} afi_view_t;
+
+int afi_abi_version(void);
+const char* afi_status_string(int status);
+
+/* ------------------------------------------------------------------ whole-network entry points */
+
+/* Parameters of Generator.Generators[0]  (generator_rdb.py:87-108; state_dict names in SURVEY.md 8b). */
+typedef struct afi_gen_params {
+    int C;                  /* in_channels (256) */
+    int G;                  /* growth_rate (32) */
+    int n_rdb;              /* n_residual_dense_blocks (3 in every caller) */
+    float residual_scale;   /* 0.2 */
+    float* w0; float* b0;                    /* Generators.0.0.0.{weight,bias}                       */
+    float* rdb_w[AFI_MAX_RDB][5];            /* Generators.0.1.RDBs.r.conv{1..4}.0.weight, conv5.weight */
+    float* w7; float* b7;                    /* Generators.0.2.0.{weight,bias}                       */
+    float* wT; float* bT;                    /* Generators.0.3.0.{weight [Cin][Cout][6][6], bias}    */
+    float* w9; float* b9;                    /* Generators.0.4.0.{weight,bias}                       */
+} afi_gen_params_t;
+
+/* floats of workspace needed by afi_generator_fwd (saved activations + packed conv-transpose weight) */
+long long afi_generator_fwd_ws_floats(int C, int G, int n_rdb, int N, int H, int W);
+/* floats of scratch needed by afi_generator_bwd */
+long long afi_generator_bwd_ws_floats(int C, int G, int n_rdb, int N, int H, int W);
+
+/* out[N,2H,2W,C] = bilinear_x2(x) + Generators[0](x)      (Generator.forward, generator_rdb.py:123-130) */
+int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t x, int N, int H, int W, afi_view_t out,
+                      float* ws, long long ws_floats, void* stream);
+/* Backward of the above.  `ws` is the forward workspace (unchanged since the forward), `dout` a DENSE
+ * [N,2H,2W,C] gradient, `grads` the += targets laid out like the params (any pointer may be NULL to skip),
+ * `dx` a DENSE [N,H,W,C] buffer or NULL when the input needs no gradient (stage 1: lr features are detached). */
+int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* grads, afi_view_t x, int N, int H, int W,
+                      const float* ws, const float* dout, float* dx, float* scratch, long long scratch_floats, void* stream);
+
+/* Parameters of Discriminator.Discriminators[0] (feature_patch_discriminator.py:32-41). */
+typedef struct afi_disc_params {
+    int F[4];               /* channels: in (256), 512, 1024, 1024 */
+    float* w[3]; float* b[3];                /* Discriminators.0.n.0.{weight,bias}          n = 0..2 */
+    float* gamma[3]; float* beta[3];         /* Discriminators.0.n.0.norm.{weight,bias}              */
+    float* running_mean[3]; float* running_var[3];
+    long long* num_batches_tracked[3];
+    float* w3; float* b3;                    /* Discriminators.0.3.0.{weight [1][3][3][F3], bias[1]} */
+} afi_disc_params_t;
+
+long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W);
+long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W);
+
+/* logits[N,H,W] (dense) = Discriminators[0](x).  training != 0: batch statistics, running stats advance once,
+ * num_batches_tracked += 1 (torch BatchNorm2d train mode);  training == 0: running statistics. */
+int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t x, int N, int H, int W, float* logits, int training,
+                          float* ws, long long ws_floats, void* stream);
+/* Backward (training-mode forward only).  grads: += targets (w, b, gamma, beta, w3, b3; other fields ignored).
+ * dx: DENSE [N,H,W,F0] or NULL (both reference loops feed detached inputs). */
+int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t* grads, afi_view_t x, int N, int H, int W,
+                          const float* ws, const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream);
+
+/* ------------------------------------------------------------------ per-op entry points (also used by the tests) */
+
+/* out[.., c_out] = act(alpha*conv3x3(x, w) + bias + beta*out);  w [Cout][3][3][Cin]  (generator_rdb.py:39-55,91-99,107) */
+int afi_conv3x3_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+                    afi_view_t out, float alpha, float beta, int lrelu, void* stream);
+/* dx = alpha*conv3x3^T(dy, w) + beta*dx, optionally times lrelu'(z) (z = the activation that produced x) */
+int afi_conv3x3_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx,
+                      float alpha, float beta, afi_view_t z_or_null, void* stream);
+/* dw[Cout][3][3][Cin] += alpha * sum_pix dy (x) x */
+int afi_conv3x3_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
+
+/* ConvTranspose2d(k=6,s=2,p=2) (generator_rdb.py:101-105) on the packed weight wp[4*Cout][3][3][Cin] */
+int afi_convT6s2_pack_weight(const float* w_iohw, float* wp, int Cin, int Cout, void* stream);
+int afi_convT6s2_unpack_wgrad(const float* dwp, float* dw_iohw, int Cin, int Cout, void* stream);   /* dw += */
+int afi_convT6s2_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* wp, const float* bias, int Cout,
+                     afi_view_t out /*[N,2H,2W,Cout]*/, int lrelu, void* stream);
+int afi_convT6s2_dgrad(afi_view_t dy /*[N,2H,2W,Cout]*/, int N, int H, int W, int Cout, const float* wp, int Cin,
+                       afi_view_t dx, afi_view_t z_or_null, void* stream);
+int afi_convT6s2_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dwp, float alpha, void* stream);
+
+/* out (dense [N,2H,2W,C]) = beta*out + bilinear_x2(x), align_corners=False (generator_rdb.py:125) */
+int afi_bilinear2x_add_fwd(afi_view_t x, int N, int H, int W, int C, float beta, float* out, void* stream);
+int afi_bilinear2x_add_bwd(const float* dout, int N, int H, int W, int C, float beta, float* dx, void* stream);
+
+/* train-mode BatchNorm2d over a dense [P][C] matrix + LeakyReLU(0.2)  (feature_patch_discriminator.py:35-38) */
+long long afi_reduce_scratch_floats(int C);
+int afi_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_biased_or_null,
+                 float* running_mean_or_null, float* running_var_or_null, float* scratch, void* stream);
+int afi_bn_apply_lrelu_fwd(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
+                           const float* beta, long long P, int C, void* stream);
+int afi_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma,
+               float* dgamma, float* dbeta, long long P, int C, float* scratch, void* stream);
+/* db[C] += alpha * column sums of the [P][C] matrix g with row stride ld */
+int afi_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, void* stream);
+
+/* nn.BCEWithLogitsLoss() mean vs a constant target (stage1_trainer.py:358-359,408):  *loss += lscale*bce;
+ * dz (or NULL) = gscale * d bce / dz */
+int afi_bce_logits_fwd_bwd(const float* z, long long n, float target, float lscale, float* loss, float gscale, float* dz, void* stream);
+/* F.l1_loss mean over the common crop [N,h,w,C] of a and b (stage1_trainer.py:410,437-443): *loss += lscale*l1;
+ * da (or NULL): DENSE [N,Ha,Wa,C] gradient w.r.t. a (zeros outside the crop) */
+int afi_l1_fwd_bwd(afi_view_t a, afi_view_t b, int N, int h, int w, int C, int Ha, int Wa, float lscale, float* loss,
+                   float gscale, float* da, void* stream);
+
+/* multi-tensor SGD with momentum (torch.optim.SGD as built by detectron2 build_optimizer, stage1_trainer.py:110-114):
+ *   d = g*gscale + wd*p ; buf = momentum*buf + d ; p -= lr*buf.    descs: DEVICE array of afi_sgd_desc_t */
+typedef struct afi_sgd_desc { float* p; const float* g; float* m; long long n; float wd; float pad_; } afi_sgd_desc_t;
+int afi_sgd_momentum_step(const afi_sgd_desc_t* descs_dev, int ntensors, long long max_n, float lr, float momentum,
+                          float gscale, void* stream);
+int afi_scale_inplace(float* p, long long n, float s, void* stream);
+
+/* layout changes at the detectron2 boundary: [N][C][P] <-> [N][P][C] */
+int afi_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, void* stream);
+int afi_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFIGAN_HIP_H */

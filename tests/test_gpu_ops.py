@@ -1,0 +1,188 @@
+"""GPU parity tests of the per-op C-ABI entry points against the CPU oracle / plain torch-CPU fp32 references.
+Tolerance: 1e-3 relative fp32 (north-star), measured as max|diff| <= 1e-3 * max|ref| unless stated; index maps bit-exact."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afigan_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import afigan_amd
+    assert torch.cuda.is_available()
+    return afigan_amd
+
+
+def _close(got, ref, tol=1e-3, what=""):
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
+
+
+def _pm(t):
+    """CPU NCHW tensor -> GPU pixel-major tensor."""
+    return t.cuda().contiguous(memory_format=torch.channels_last)
+
+
+def _rand(*shape, seed=0):
+    return torch.randn(shape, generator=torch.Generator().manual_seed(seed))
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W
+    (1, 16, 16, 5, 7),
+    (2, 20, 4, 7, 11),        # growth conv of the small generator (Cin not a multiple of 32)
+    (1, 32, 64, 13, 21),
+    (2, 256, 32, 25, 34),     # RDB conv1 at config-1 size
+    (1, 288, 256, 9, 10),     # K tail: 288 = 9 chunks of 32
+    (1, 64, 160, 33, 40),     # Cout not a multiple of the N tile
+    (3, 36, 12, 6, 5),
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", CONV_CASES)
+def test_conv3x3_fwd_dgrad_wgrad(amd, N, Cin, Cout, H, W):
+    ops = amd.ops
+    x, w, b = _rand(N, Cin, H, W, seed=1), _rand(Cout, Cin, 3, 3, seed=2) * 0.1, _rand(Cout, seed=3)
+    dy = _rand(N, Cout, H, W, seed=4)
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xg, wg, b, 1, 1)
+    ref.backward(dy)
+    xd, wd, bd, dyd = _pm(x), amd.ops.ohwi(w.cuda()), b.cuda(), _pm(dy)
+    _close(ops.conv3x3_fwd(xd, wd, bd), ref, what="fwd")
+    _close(ops.conv3x3_fwd(xd, wd, bd, lrelu=True), orc.lrelu(ref), what="fwd+lrelu")
+    _close(ops.conv3x3_dgrad(dyd, wd), xg.grad, what="dgrad")
+    _close(ops.conv3x3_wgrad(dyd, xd), wg.grad, what="wgrad")
+    # alpha / beta / mask epilogues
+    old = _rand(N, Cout, H, W, seed=5)
+    got = ops.conv3x3_fwd(xd, wd, None, out=_pm(old).clone(memory_format=torch.preserve_format), alpha=0.2, beta=1.0)
+    _close(got, 0.2 * F.conv2d(x, w, None, 1, 1) + old, what="alpha/beta")
+    z = _rand(N, Cin, H, W, seed=6)
+    got = ops.conv3x3_dgrad(dyd, wd, z=_pm(z))
+    _close(got, xg.grad * torch.where(z > 0, torch.ones_like(z), torch.full_like(z, 0.2)), what="dgrad mask")
+
+
+def test_conv3x3_channel_slices_and_crops(amd):
+    """Channel slices of a wider buffer (the RDB dense buffer) and cropped input views (stage1_trainer.py:437-443)."""
+    ops = amd.ops
+    N, H, W = 2, 9, 12
+    buf = _rand(N, 48, H, W, seed=1)
+    w = _rand(8, 24, 3, 3, seed=2) * 0.1
+    bd = _pm(buf)
+    ref = orc.lrelu(F.conv2d(buf[:, :24], w, None, 1, 1))
+    ops.conv3x3_fwd(bd[:, :24], w.cuda(), None, lrelu=True, out=bd[:, 24:32])
+    _close(bd[:, 24:32], ref, what="slice out")
+    _close(bd[:, :24], buf[:, :24], tol=0, what="slice in untouched")
+    _close(bd[:, 32:], buf[:, 32:], tol=0, what="slice rest untouched")
+    big = _rand(N, 16, H + 3, W + 2, seed=3)
+    w2 = _rand(12, 16, 3, 3, seed=4) * 0.1
+    ref = F.conv2d(big[:, :, :H, :W], w2, None, 1, 1)
+    _close(ops.conv3x3_fwd(_pm(big)[:, :, :H, :W], w2.cuda()), ref, what="cropped view in")
+    dy = _rand(N, 12, H, W, seed=5)
+    xg = big[:, :, :H, :W].clone().requires_grad_(True)
+    wg = w2.clone().requires_grad_(True)
+    F.conv2d(xg, wg, None, 1, 1).backward(dy)
+    _close(ops.conv3x3_wgrad(_pm(dy), _pm(big)[:, :, :H, :W]), wg.grad, what="wgrad cropped x")
+
+
+@pytest.mark.parametrize("N,C,H,W", [(1, 16, 5, 7), (2, 32, 7, 11), (1, 256, 13, 17)])
+def test_conv_transpose_6s2p2(amd, N, C, H, W):
+    ops = amd.ops
+    x, w, b = _rand(N, C, H, W, seed=1), _rand(C, C, 6, 6, seed=2) * 0.05, _rand(C, seed=3)
+    dy = _rand(N, C, 2 * H, 2 * W, seed=4)
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv_transpose2d(xg, wg, b, stride=2, padding=2)
+    ref.backward(dy)
+    wp = ops.convT_pack(w.cuda())
+    _close(ops.convT_fwd(_pm(x), wp, b.cuda(), C), ref, what="convT fwd")
+    _close(ops.convT_dgrad(_pm(dy), wp, C), xg.grad, what="convT dgrad")
+    _close(ops.convT_wgrad(_pm(dy), _pm(x)), wg.grad, what="convT wgrad")
+    # oracle's 4-phase restatement agrees with torch's op too
+    _close(orc.conv_transpose_6s2p2_phases(x, w, b), ref, tol=1e-5, what="oracle phases")
+
+
+def test_bilinear2x_index_map_bit_exact(amd, golden_dir):
+    ops = amd.ops
+    fx = dict(np.load(f"{golden_dir}/bilinear.npz"))
+    for L in (1, 2, 5, 7, 25):
+        ramp = torch.arange(L, dtype=torch.float32).view(1, 1, L, 1).expand(1, 4, L, 3).contiguous()
+        up = ops.bilinear2x(_pm(ramp)).cpu()
+        assert np.array_equal(up[0, 0, :, 0].numpy(), fx[f"ramp_h_{L}"]), L          # integer ramps -> exact: index map is bit-exact
+        ramp = torch.arange(L, dtype=torch.float32).view(1, 1, 1, L).expand(1, 4, 3, L).contiguous()
+        up = ops.bilinear2x(_pm(ramp)).cpu()
+        assert np.array_equal(up[0, 0, 0, :].numpy(), fx[f"ramp_w_{L}"]), L
+    x = _rand(2, 8, 5, 7, seed=3)
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear")
+    _close(ops.bilinear2x(_pm(x)), ref, tol=1e-6, what="bilinear fwd")
+    dout = _rand(2, 8, 10, 14, seed=4)
+    xg = x.clone().requires_grad_(True)
+    F.interpolate(xg, scale_factor=2, mode="bilinear").backward(dout)
+    _close(ops.bilinear2x_bwd(_pm(dout)), xg.grad, tol=1e-6, what="bilinear bwd")
+
+
+@pytest.mark.parametrize("P,C", [(77, 8), (546, 64), (3400, 512), (20000, 128)])
+def test_batchnorm_train_fwd_bwd(amd, P, C):
+    ops = amd.ops
+    x = _rand(P, C, seed=1) * 1.7 + 0.3
+    gamma, beta = 1 + 0.2 * _rand(C, seed=2), 0.1 * _rand(C, seed=3)
+    rm, rv = 0.1 * _rand(C, seed=4), 1 + 0.1 * _rand(C, seed=5).abs()
+    g = _rand(P, C, seed=6)
+    x4 = x.t().reshape(1, C, P, 1).clone().requires_grad_(True)
+    gam, bet = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y, nrm, nrv, mean, var = orc.batchnorm_train(x4, gam, bet, rm, rv)
+    out = orc.lrelu(y)
+    out.backward(g.t().reshape(1, C, P, 1))
+    xd, rmd, rvd = x.cuda(), rm.cuda(), rv.cuda()
+    m, istd, v = ops.bn_stats(xd, rmd, rvd)
+    _close(m, mean, tol=1e-5, what="mean")
+    _close(v, var, tol=1e-4, what="var")
+    _close(rmd, nrm, tol=1e-5, what="running_mean")
+    _close(rvd, nrv, tol=1e-4, what="running_var")
+    yd = ops.bn_apply_lrelu(xd, m, istd, gamma.cuda(), beta.cuda())
+    _close(yd, out.reshape(C, P).t(), tol=1e-4, what="bn+lrelu")
+    # backward: g masked by lrelu' first (the conv dgrad epilogue does that in the network)
+    gm = g.cuda() * torch.where(yd > 0, 1.0, 0.2)
+    dgam, dbet = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx = ops.bn_bwd(gm, xd, m, istd, gamma.cuda(), dgam, dbet)
+    _close(dx, x4.grad.reshape(C, P).t(), tol=1e-3, what="bn dx")
+    _close(dgam, gam.grad, tol=1e-3, what="dgamma")
+    _close(dbet, bet.grad, tol=1e-3, what="dbeta")
+    db = torch.zeros(C, device="cuda")
+    ops.colsum_accum(g.cuda(), db, alpha=0.5)
+    _close(db, 0.5 * g.sum(0), tol=1e-4, what="colsum")
+
+
+def test_losses(amd):
+    ops = amd.ops
+    z = _rand(2, 1, 13, 21, seed=1) * 5
+    for target in (0.0, 1.0):
+        zg = z.clone().requires_grad_(True)
+        ref = F.binary_cross_entropy_with_logits(zg, torch.full_like(z, target))
+        ref.backward()
+        loss = torch.zeros(1, device="cuda")
+        dz = ops.bce_logits(z.cuda(), target, loss)
+        _close(loss, ref.reshape(1), tol=1e-5, what="bce")
+        _close(dz, zg.grad, tol=1e-5, what="bce grad")
+        assert abs(orc.bce_with_logits_mean(z, target).item() - ref.item()) < 1e-6
+    a, b = _rand(2, 16, 14, 22, seed=2), _rand(2, 16, 13, 21, seed=3)
+    ag = a.clone().requires_grad_(True)
+    ref = F.l1_loss(ag[:, :, :13, :21], b)
+    ref.backward()
+    loss = torch.zeros(1, device="cuda")
+    da = ops.l1_crop(_pm(a), _pm(b), loss)
+    _close(loss, ref.reshape(1), tol=1e-5, what="l1")
+    _close(da, ag.grad, tol=1e-6, what="l1 grad (zeros outside the crop)")
+
+
+def test_layout_roundtrip(amd):
+    ops = amd.ops
+    x = _rand(2, 20, 7, 9, seed=1).cuda()
+    pm = ops.pixel_major(x)
+    assert pm.stride(1) == 1 and torch.equal(pm, x)
+    assert torch.equal(ops.to_nchw_contiguous(pm), x)
