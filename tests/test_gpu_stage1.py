@@ -1,0 +1,115 @@
+"""GPU parity of one stage-1 G+D iteration (afi-gan_amd/stage1.py) against the golden replay of
+stage1_trainer.py:336-433 over the reference modules, and against the CPU oracle on a ragged small pyramid."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afigan_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import afigan_amd
+    assert torch.cuda.is_available()
+    return afigan_amd
+
+
+def _digest(t, nsample=64):
+    f = t.detach().contiguous().reshape(-1).double().cpu()
+    stride = max(1, f.numel() // nsample)
+    return np.array([f.sum().item(), f.norm().item(), f.abs().max().item()]), f[::stride][:nsample].float().numpy()
+
+
+def test_stage1_step_vs_reference_replay(amd, golden_dir):
+    fx = dict(np.load(os.path.join(golden_dir, "stage1_step.npz")))
+    G = amd.Generator(n_residual_dense_blocks=3).cuda()
+    D = amd.Discriminator().cuda()
+    G.load_state_dict(orc.closed_form_generator_params(), strict=True)
+    D.load_state_dict(orc.closed_form_discriminator_params(), strict=True)
+    G.train(); D.train()
+    gen = torch.Generator().manual_seed(int(fx["seed"][0]))
+    lr_f = [torch.randn((2, 256, 13, 21), generator=gen), torch.randn((2, 256, 7, 11), generator=gen)]
+    hr_f = [torch.randn((2, 256, 25, 42), generator=gen), torch.randn((2, 256, 13, 21), generator=gen)]
+    step = amd.Stage1Step(G, D, base_lr=float(fx["lr"][0]), momentum=float(fx["mom"][0]), weight_decay=float(fx["wd"][0]),
+                          warmup_iters=0)          # the golden replay uses a constant lr
+    step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
+    m = step.metrics()
+    for k in ("d_loss_p2", "d_loss_p3", "adv_loss_p2", "adv_loss_p3", "content_loss_p2", "content_loss_p3", "g_loss_p2", "g_loss_p3"):
+        ref = float(fx[k][0])
+        assert abs(m[k] - ref) <= 1e-3 * abs(ref), (k, m[k], ref)
+    # gradients left in .grad are those of the D phase / G phase
+    for k, p in D.named_parameters():
+        if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3"):
+            continue                                  # rounding-noise gradients (bias before a train-mode BN)
+        d, s = _digest(p.grad)                      # LeakyReLU mask flips: see test_gpu_modules.test_discriminator_vs_reference
+        rd, rs = fx["Dgd/" + k], fx["Dgs/" + k]
+        assert abs(d[1] - rd[1]) <= 3e-3 * rd[1], (k, d, rd)
+        np.testing.assert_allclose(s, rs, rtol=0, atol=3e-2 * rd[2], err_msg=k)
+    for k, p in G.named_parameters():
+        d, s = _digest(p.grad)
+        rd, rs = fx["Ggd/" + k], fx["Ggs/" + k]
+        assert abs(d[1] - rd[1]) <= 1e-3 * rd[1], (k, d, rd)
+        np.testing.assert_allclose(s, rs, rtol=0, atol=1e-3 * rd[2], err_msg=k)
+    # post-SGD weights
+    for k, p in list(D.named_parameters()) + list(G.named_parameters()):
+        ref = fx[("Dw_after/" if k.startswith("Disc") else "Gw_after/") + k]
+        d, _ = _digest(p)
+        assert abs(d[1] - ref[1]) <= 1e-5 * ref[1] + 1e-9, k
+    # Q2: BN buffers advanced 4x per level
+    sd = D.state_dict()
+    for k in sd:
+        if "num_batches" in k:
+            assert int(sd[k]) == int(fx["Dbuf_after/" + k]) == 8
+        elif "running" in k:
+            ref = torch.from_numpy(fx["Dbuf_after/" + k])
+            assert ((sd[k].cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-3, k
+
+
+@pytest.mark.parametrize("reuse", [True, False])
+def test_stage1_small_ragged_vs_oracle(amd, reuse):
+    """Small channel counts, odd sizes, three levels incl. a crop case (G(7x11)=14x22 vs hr 13x21, Q4)."""
+    C, g = 16, 4
+    gp = orc.closed_form_generator_params(C, 3, g)
+    dp = orc.closed_form_discriminator_params(C)
+    G = amd.Generator(in_channels=C, n_residual_dense_blocks=3, growth_rate=g).cuda()
+    D = amd.Discriminator(in_filters=C).cuda()
+    G.load_state_dict(gp); D.load_state_dict(dp)
+    gen = torch.Generator().manual_seed(3)
+    lr_f = [torch.randn((2, C, 13, 21), generator=gen), torch.randn((2, C, 7, 11), generator=gen), torch.randn((2, C, 4, 6), generator=gen)]
+    hr_f = [torch.randn((2, C, 25, 42), generator=gen), torch.randn((2, C, 13, 21), generator=gen), torch.randn((2, C, 8, 12), generator=gen)]
+    lr0 = 0.01
+    step = amd.Stage1Step(G, D, base_lr=lr0, warmup_iters=0, reuse_generator_forward=reuse)
+    step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
+    m = step.metrics()
+    d_losses, d_grads, d_bufs = orc.stage1_d_phase(gp, dp, lr_f, hr_f, first_level=2)
+    for k, v in d_losses.items():
+        assert abs(m[k] - v) <= 1e-3 * abs(v), (k, m[k], v)
+    dparams = {k: v for k, v in dp.items() if k in d_grads}
+    orc.sgd_momentum_step(dparams, d_grads, {}, lr=lr0)
+    dp2 = dict(dp); dp2.update(dparams); dp2.update(d_bufs)
+    g_losses, g_grads, d_bufs2 = orc.stage1_g_phase(gp, dp2, lr_f, hr_f, first_level=2)
+    for k, v in g_losses.items():
+        assert abs(m[k] - v) <= 1e-3 * abs(v), (k, m[k], v)
+    for k, p in G.named_parameters():
+        ref = g_grads[k]
+        assert ((p.grad.cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-3, k
+    for k, p in D.named_parameters():
+        ref = dparams[k]
+        assert ((p.detach().cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-4, k
+    sd = D.state_dict()
+    for k, v in d_bufs2.items():
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v) == 12
+        else:
+            assert ((sd[k].cpu() - v).abs().max() / v.abs().max()).item() < 1e-3, k
+    gparams = dict(gp)
+    orc.sgd_momentum_step(gparams, g_grads, {}, lr=lr0)
+    for k, p in G.named_parameters():
+        assert ((p.detach().cpu() - gparams[k]).abs().max() / gparams[k].abs().max()).item() < 1e-4, k
+    # second iteration keeps working on the same buffers (momentum path) and stays finite
+    step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
+    assert all(np.isfinite(v) for v in step.metrics().values())
