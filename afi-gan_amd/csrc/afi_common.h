@@ -51,7 +51,7 @@ struct AfiPixGemm {
     AfiView R1; float r1s; int r1_lo, r1_hi;   // applied for channels in [r1_lo, r1_hi); null p = off
     AfiView R2; float r2s; int r2_lo, r2_hi;
     int r1_bilinear;    // R1 is a low-res [N, H/2, W/2] tensor, added as its bilinear x2 up-sampling
-    int lrelu;          // apply LeakyReLU(0.2) to v
+    int lrelu;          // activation on v: 0 none, 1 LeakyReLU(0.2), 2 ReLU
     AfiView Z; int z_lo, z_hi;                 // multiply by (Z > 0 ? 1 : 0.2) for channels in [z_lo, z_hi)
 };
 

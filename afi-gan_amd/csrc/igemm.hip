@@ -244,8 +244,9 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
             if (p.R2.p && ch >= p.r2_lo && ch < p.r2_hi)
                 v += p.r2s * *(const f32x4*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch);
             if (p.lrelu) {
+                const float slope = (p.lrelu == 1) ? AFI_LRELU_SLOPE : 0.f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = afi_lrelu(v[j]);
+                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
             }
             if (p.Z.p && ch >= p.z_lo && ch < p.z_hi) {
                 const f32x4 z = *(const f32x4*)(p.Z.p + (long long)img * p.Z.sN + (long long)yo * p.Z.sH + (long long)xo * p.Z.sW + ch);
@@ -408,6 +409,63 @@ __global__ __launch_bounds__(256) void afi_wgrad_gemm_kernel(const AfiWgradGemm 
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)
+// ------------------------------------------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+struct ProfState {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+} g_prof;
+const char* kKindNames[] = {
+    "pix_gemm<128x128,KC> (conv fwd)", "pix_gemm<128x64,KC>", "pix_gemm<128x32,KC>", "pix_gemm<64x64,KC>",
+    "pix_gemm<128x128,RC> (conv dgrad)", "pix_gemm<128x64,RC>", "pix_gemm<128x32,RC>", "pix_gemm<64x64,RC>",
+    "wgrad_gemm<128x128>", "wgrad_gemm<64x128>", "wgrad_gemm<32x128>"};
+constexpr int kNumKinds = 11;
+hipEvent_t prof_event() {
+    if (g_prof.used == g_prof.pool.size()) {
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        g_prof.pool.push_back(e);
+    }
+    return g_prof.pool[g_prof.used++];
+}
+struct ProfScope {
+    hipStream_t st; int kind; double flops; hipEvent_t a{};
+    ProfScope(hipStream_t s, int k, double f) : st(s), kind(k), flops(f) {
+        if (g_prof.on) { a = prof_event(); (void)hipEventRecord(a, st); }
+    }
+    ~ProfScope() {
+        if (g_prof.on) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops}); }
+    }
+};
+}  // namespace
+
+extern "C" int afi_profile_enable(int on) {
+    g_prof.on = on != 0;
+    if (on) { g_prof.recs.clear(); g_prof.used = 0; }
+    return AFI_OK;
+}
+extern "C" int afi_profile_num_kinds(void) { return kNumKinds; }
+extern "C" const char* afi_profile_kind_name(int kind) { return (kind >= 0 && kind < kNumKinds) ? kKindNames[kind] : ""; }
+// out[0] = launches, out[1] = total ms, out[2] = total algorithmic FLOP of kernel `kind` since afi_profile_enable(1)
+extern "C" int afi_profile_get(int kind, double* out) {
+    out[0] = out[1] = out[2] = 0.0;
+    for (const ProfRec& r : g_prof.recs) {
+        if (r.kind != kind) continue;
+        if (hipEventSynchronize(r.b) != hipSuccess) return AFI_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return AFI_ERR_LAUNCH;
+        out[0] += 1.0; out[1] += ms; out[2] += r.flops;
+    }
+    return AFI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
@@ -418,6 +476,8 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const int ntiles = ntm * ntn;
     const int chunk = afi_cdiv(ntiles, 8);
     const size_t lds = sizeof(float) * (BM * AFI_LDK + (B_RC ? AFI_BK * BN : BN * AFI_LDK)) + sizeof(int) * 3 * BM;
+    const int kind = (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+    ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
     hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC>), dim3(chunk * 8), dim3(256), lds, st, p, ntn, ntiles, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
@@ -460,6 +520,7 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
     kper = ((kper + AFI_BK - 1) / AFI_BK) * AFI_BK;
     splitK = (int)((P + kper - 1) / kper);
     const size_t lds = sizeof(float) * AFI_BK * (BM + BN);
+    ProfScope prof(st, BM == 128 ? 8 : (BM == 64 ? 9 : 10), 2.0 * (double)P * p.Mrows * p.Ncols * p.ntaps);
     hipLaunchKernelGGL((afi_wgrad_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles, splitK), dim3(256), lds, st, p, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }

@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""bench.py -- stage-1 AFI-GAN G+D step on MI355X (BASELINE.json configs[1]) + AF-interpolator fwd+bwd (configs[0] shape).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full stage-1 iteration on a per-GPU batch of 2 synthetic 3x800x1333 images (stage1_trainer.py:305-435):
+two frozen R-50-FPN guide forwards (image and image_x0.5), the D step and the G step over P2..P6 (hand-written HIP kernels),
+the RCCL gradient all-reduce (N > 1) and both fused SGD updates.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.  `value` = images/s of the whole job; weak scaling (2 images per GPU).
+
+Extra objects on the line:
+  roofline      -- the dominant kernel of the timed region (by summed HIP-event time, measured on the launch stream by the
+                   library's own event brackets): algorithmic FLOP / time vs the dense fp32 MFMA peak (157.3 TFLOP/s).
+  cpu_baseline  -- the CPU oracle (kind "port": oracle/afigan_oracle.py, a PyTorch-CPU restatement pinned to the reference's
+                   outputs) timed on this host on a bounded sample of the same workload (levels P3..P6 only), scaled to images/s.
+  af_interpolator -- BASELINE metric 1: Generator fwd+bwd feature-Mpix/s on 1x256x25x34 -> 1x256x50x68 (and batch 16).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+G_FWD_FLOP_PER_INPX = 19_206_144        # SURVEY.md 8(d) / BASELINE.md section 3
+D_FWD_FLOP_PER_PX = 30_689_280
+D_FWDBWD_DETACHED_FLOP_PER_PX = 89_708_544
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch-per-gpu", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-interp", action="store_true", help="skip the AF-interpolator micro-benchmark")
+    ap.add_argument("--synthetic-pyramid", action="store_true",
+                    help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
+    return ap.parse_args()
+
+
+def interp_bench(amd, torch, N, H, W, iters=50, warmup=10):
+    """Generator(n_rdb=3) forward + full backward (input grad + all weight grads, loss = out.sum()) through the C-ABI."""
+    from afigan_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(0)
+    G = amd.Generator(n_residual_dense_blocks=3).cuda()
+    x = ops.pixel_major(torch.randn(N, 256, H, W, generator=torch.Generator().manual_seed(0)).cuda())
+    params = G._ordered_params()
+    prm, keep = G._param_struct(params)
+    grads = [torch.zeros_like(p) for p in params]
+    gst, _ = G._param_struct(grads, already_packed=True)
+    nf = lib.afi_generator_fwd_ws_floats(256, 32, 3, N, H, W)
+    nb = lib.afi_generator_bwd_ws_floats(256, 32, 3, N, H, W)
+    ws = torch.empty(nf, device="cuda")
+    sc = torch.empty(nb, device="cuda")
+    out = ops.new_pixel_major(N, 256, 2 * H, 2 * W, "cuda")
+    dout = ops.new_pixel_major(N, 256, 2 * H, 2 * W, "cuda")
+    dout.fill_(1.0)
+    dx = ops.new_pixel_major(N, 256, H, W, "cuda")
+    st = ops.stream_ptr()
+
+    def one():
+        _lib.call("afi_generator_fwd", C.byref(prm), ops.view_of(x), N, H, W, ops.view_of(out), C.c_void_p(ws.data_ptr()), nf, st)
+        _lib.call("afi_generator_bwd", C.byref(prm), C.byref(gst), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()),
+                  C.c_void_p(dout.data_ptr()), C.c_void_p(dx.data_ptr()), C.c_void_p(sc.data_ptr()), nb, st)
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    out_px = N * 4 * H * W
+    flop = 3 * G_FWD_FLOP_PER_INPX * N * H * W
+    return {"shape": f"{N}x256x{H}x{W}->{N}x256x{2 * H}x{2 * W}", "ms": dt * 1e3, "out_mpix_per_s": out_px / dt / 1e6,
+            "in_mpix_per_s": out_px / 4 / dt / 1e6, "tflops": flop / dt / 1e12, "frac_of_fp32_mfma_peak": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
+
+
+def host_cores():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box exposes 256 logical
+    CPUs but grants 16; running 256 OpenMP threads against a 16-CPU quota throttles to a crawl)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(torch, batch):
+    """Oracle (CPU restatement) on a bounded sample: the stage-1 D phase + G phase over levels P3..P6 of the same pyramid
+    shapes, all host cores; scaled to images/s of the FULL pyramid by the pixel ratio (work is proportional to pixels)."""
+    from oracle import afigan_oracle as orc
+    ncores = host_cores()
+    torch.set_num_threads(ncores)
+    gen = torch.Generator().manual_seed(0)
+    gp = orc.reference_init_generator_params(generator=gen)
+    dp = orc.reference_init_discriminator_params(generator=gen)
+    hr_shapes = [(100, 168), (50, 84), (25, 42), (13, 21)]
+    lr_shapes = [(52, 84), (26, 42), (13, 21), (7, 11)]
+    lr_f = [torch.randn((batch, 256, h, w), generator=gen) for h, w in lr_shapes]
+    hr_f = [torch.randn((batch, 256, h, w), generator=gen) for h, w in hr_shapes]
+    t0 = time.perf_counter()
+    orc.stage1_d_phase(gp, dp, lr_f, hr_f, first_level=3)
+    log(f"  oracle D phase done ({time.perf_counter() - t0:.1f} s)")
+    orc.stage1_g_phase(gp, dp, lr_f, hr_f, first_level=3)
+    dt = time.perf_counter() - t0
+    log(f"  oracle G phase done ({dt:.1f} s)")
+    full_hr = 200 * 336 + 100 * 168 + 50 * 84 + 25 * 42 + 13 * 21
+    frac = sum(h * w for h, w in hr_shapes) / full_hr
+    # G fwd+bwd on the config-1 tensor as well (metric 1)
+    x = torch.randn((1, 256, 25, 34), generator=gen).requires_grad_(True)
+    gq = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    t1 = time.perf_counter()
+    reps = 3
+    for _ in range(reps):
+        orc.generator_forward(x, gq).sum().backward()
+    tg = (time.perf_counter() - t1) / reps
+    return {"value": batch * frac / dt, "unit": "images/s", "cores": ncores, "kind": "port",
+            "sample": f"oracle D+G phases on levels P3..P6 only (batch {batch}; {frac * 100:.2f}% of the pyramid's pixels) took {dt:.2f} s; "
+                      f"scaled by the pixel ratio to the full P2..P6 step (guide net excluded)",
+            "af_interpolator_out_mpix_per_s": 3400 / tg / 1e6, "af_interpolator_ms": tg * 1e3}
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the one JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the AFI-GAN hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build(verbose=False)
+    if dist is not None:
+        dist.barrier()
+    import afigan_amd as amd
+    from afigan_amd import _lib
+    from afigan_amd.guide import GuideR50FPN
+    lib = _lib.load()
+
+    B = args.batch_per_gpu
+    torch.manual_seed(1234)                       # same init on every rank (and rank 0's weights are broadcast anyway)
+    G = amd.Generator(n_residual_dense_blocks=3).to(dev)
+    D = amd.Discriminator().to(dev)
+    G.train(); D.train()
+    step = amd.Stage1Step(G, D, base_lr=1e-3)
+    guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
+    gen = torch.Generator(device=dev).manual_seed(100 + rank)     # each rank owns a different shard of the global batch
+    images = torch.rand((B, 3, 800, 1333), device=dev, generator=gen) * 255.0
+    images_half = torch.nn.functional.interpolate(images, size=(400, 666), mode="bilinear", align_corners=False)
+    hr_shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    lr_shapes = [(104, 168), (52, 84), (26, 42), (13, 21), (7, 11)]
+    if guide is None:
+        syn_hr = [torch.randn((B, 256, h, w), device=dev, generator=gen).contiguous(memory_format=torch.channels_last) for h, w in hr_shapes]
+        syn_lr = [torch.randn((B, 256, h, w), device=dev, generator=gen).contiguous(memory_format=torch.channels_last) for h, w in lr_shapes]
+
+    def one_step():
+        if guide is not None:
+            hr_ = guide(images)                                    # stage1_trainer.py:320
+            lr_ = guide(images_half)                               # :321
+            hr = [hr_[f"p{d}"] for d in range(2, 7)]               # :325-327
+            lr = [lr_[f"p{d}"] for d in range(2, 7)]
+        else:
+            hr, lr = syn_hr, syn_lr
+        step.run_step(lr, hr)
+        return hr, lr
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log("models built; warm-up (the first guide forward lets MIOpen pick/compile its kernels)")
+    if guide is not None:
+        guide(images_half)
+        torch.cuda.synchronize()
+        log("guide forward (half-size image) done")
+        guide(images)
+        torch.cuda.synchronize()
+        log("guide forward (full-size image) done")
+    for i in range(args.warmup):
+        hr, lr = one_step()
+        torch.cuda.synchronize()
+        log(f"warm-up step {i + 1}/{args.warmup} done")
+    if args.warmup:
+        assert [tuple(t.shape[2:]) for t in hr] == hr_shapes and [tuple(t.shape[2:]) for t in lr] == lr_shapes, \
+            ([t.shape for t in hr], [t.shape for t in lr])
+    sync()
+    if rank == 0:
+        lib.afi_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
+    if rank == 0:
+        lib.afi_profile_enable(0)
+    metrics = step.metrics()                      # also the finite-loss check (_detect_anomaly)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel (HIP events recorded by the library on the launch stream)
+    kinds = []
+    for k in range(lib.afi_profile_num_kinds()):
+        out3 = (C.c_double * 3)()
+        _lib.check(lib.afi_profile_get(k, out3), "afi_profile_get")
+        if out3[0] > 0:
+            kinds.append({"kernel": lib.afi_profile_kind_name(k).decode(), "launches": int(out3[0]), "ms_total": out3[1],
+                          "avg_us": out3[1] / out3[0] * 1e3, "tflops": out3[2] / (out3[1] * 1e-3) / 1e12 if out3[1] > 0 else 0.0,
+                          "flop_total": out3[2]})
+    kinds.sort(key=lambda r: -r["ms_total"])
+    dom = kinds[0]
+    gemm_ms = sum(r["ms_total"] for r in kinds)
+    gemm_flop = sum(r["flop_total"] for r in kinds)
+    roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
+                "share_of_step_time": dom["ms_total"] / (elapsed * 1e3),
+                "all_gemm_kernels": {"tflops": gemm_flop / (gemm_ms * 1e-3) / 1e12, "frac": gemm_flop / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                     "share_of_step_time": gemm_ms / (elapsed * 1e3)},
+                "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "flop_total"} for r in kinds]}
+
+    # algorithmic work of one step per image: D fwd 4x hr px + D bwd on 2x hr px; G fwd 2x lr px + G bwd 1x lr px
+    hr_px = sum(h * w for h, w in hr_shapes)
+    lr_px = sum(h * w for h, w in lr_shapes)
+    flop_img = (2 * D_FWD_FLOP_PER_PX + 2 * D_FWDBWD_DETACHED_FLOP_PER_PX) * hr_px + \
+        (2 * G_FWD_FLOP_PER_INPX + 2 * G_FWD_FLOP_PER_INPX - 1_179_648) * lr_px
+    n_img = world * B * args.steps
+    line = {
+        "metric": "stage1_G+D_step_images_per_s", "value": n_img / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
+                               f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "guide": "r50fpn (GEMM 1x1 via hipBLASLt + own 3x3 MFMA conv)" if guide is not None else "synthetic-pyramid",
+                   "reuse_generator_forward": True},
+        "algorithmic_tflop_per_image": flop_img / 1e12,
+        "step_tflops_per_gpu": flop_img * B * args.steps / elapsed / 1e12,
+        "step_frac_of_fp32_mfma_peak": flop_img * B * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+        "roofline": roofline,
+        "losses_last_step": {k: round(v, 5) for k, v in metrics.items()},
+    }
+    log("AF-interpolator micro-benchmark")
+    if not args.no_interp:
+        line["af_interpolator"] = {"metric": "AF-interpolator fwd+bwd feature-Mpix/s (256ch P5->P4)",
+                                   "cfg1": interp_bench(amd, torch, 1, 25, 34), "batch16": interp_bench(amd, torch, 16, 25, 34, iters=20, warmup=5)}
+    log("CPU baseline (oracle) on the host cores")
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(torch, B)
+        line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

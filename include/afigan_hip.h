@@ -102,7 +102,8 @@ int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t*
 
 /* ------------------------------------------------------------------ per-op entry points (also used by the tests) */
 
-/* out[.., c_out] = act(alpha*conv3x3(x, w) + bias + beta*out);  w [Cout][3][3][Cin]  (generator_rdb.py:39-55,91-99,107) */
+/* out[.., c_out] = act(alpha*conv3x3(x, w) + bias + beta*out);  w [Cout][3][3][Cin]  (generator_rdb.py:39-55,91-99,107)
+ * lrelu: 0 = no activation, 1 = LeakyReLU(0.2), 2 = ReLU (used by the bench harness's guide network only) */
 int afi_conv3x3_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
                     afi_view_t out, float alpha, float beta, int lrelu, void* stream);
 /* dx = alpha*conv3x3^T(dy, w) + beta*dx, optionally times lrelu'(z) (z = the activation that produced x) */
@@ -153,6 +154,15 @@ int afi_scale_inplace(float* p, long long n, float s, void* stream);
 /* layout changes at the detectron2 boundary: [N][C][P] <-> [N][P][C] */
 int afi_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, void* stream);
 int afi_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, void* stream);
+
+/* ------------------------------------------------------------------ measurement support (bench.py)
+ * When enabled, every MFMA GEMM launch is bracketed by two hipEvents recorded on the launch stream.
+ * afi_profile_get(kind, out): out[0] launches, out[1] total ms, out[2] total algorithmic FLOP of that kernel since
+ * the last afi_profile_enable(1).  Not thread-safe; meant for one benchmarking thread. */
+int afi_profile_enable(int on);
+int afi_profile_num_kinds(void);
+const char* afi_profile_kind_name(int kind);
+int afi_profile_get(int kind, double* out3);
 
 #ifdef __cplusplus
 }
