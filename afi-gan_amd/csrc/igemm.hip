@@ -28,6 +28,16 @@
 
 #define AFI_BK 32
 #define AFI_LDK (AFI_BK + 4)
+#ifndef AFI_NBUF
+#define AFI_NBUF 1
+#endif
+#ifndef AFI_GATHER_MODE
+#define AFI_GATHER_MODE 0
+#endif
+
+// 16 bytes of zeros: masked lanes of the branch-free gathers read these instead of selecting after the load, so no
+// instruction depends on a global load until the registers are written to LDS a stage later
+__device__ __attribute__((aligned(16))) float afi_zeros[4] = {0.f, 0.f, 0.f, 0.f};   // non-const: stays in the global address space, so the select below keeps global_load (a const array is addrspace(4) and turns every gather into a flat_load)
 
 __device__ __forceinline__ float afi_lrelu(float v) { return v > 0.f ? v : v * AFI_LRELU_SLOPE; }
 
@@ -51,10 +61,14 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     static_assert(B_LOADS >= 1, "tile too small");
     constexpr int B_ROWS_PER_PASS = 256 / B_F4;           // RC
 
+    constexpr int A_TILE = BM * LDK;                      // floats per A stage buffer
+    constexpr int B_TILE = B_RC ? BK * BN : BN * LDK;     // floats per B stage buffer
+    constexpr int STAGE = A_TILE + B_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                     // [BM][LDK]
-    float* Bs = smem + BM * LDK;                          // KC: [BN][LDK]   RC: [BK][BN]
-    int* rowtab = (int*)(Bs + (B_RC ? BK * BN : BN * LDK));  // [3][BM]: img, y, x of each tile row
+    // NBUF stage buffers; buffer b: A at smem + b*STAGE, B right behind it.  Measured on MI355X (D1@P2, 512->1024):
+    // 1 buffer / 2 barriers per stage / 3 blocks per CU = 130 TFLOP/s;  2 buffers / 1 barrier / 2 blocks per CU = 120.
+    constexpr int NBUF = AFI_NBUF;
+    int* rowtab = (int*)(smem + NBUF * STAGE);            // [3][BM]: img, y, x of each tile row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -84,74 +98,90 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     __syncthreads();
 
     // ---- loader state ----
+    // Per tile row: the 64-bit offset of its centre pixel in A and a 9-bit mask of the taps that stay inside the image,
+    // so a stage's gather is one scalar delta (tap / phase / channel chunk) + one add and one bit test per load.
     const int aq = tid & 7, ar = tid >> 3;                // A (KC): float4 column, first row
-    long long a_base[A_LOADS]; int a_y[A_LOADS], a_x[A_LOADS];
+    long long a_off[A_LOADS]; unsigned a_mask[A_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        int r = ar + 32 * i;
-        int img = rowtab[r];
-        a_y[i] = rowtab[BM + r]; a_x[i] = rowtab[2 * BM + r];
-        a_base[i] = (long long)(img < 0 ? 0 : img) * p.A.sN;
+        const int r = ar + 32 * i;
+        const int img = rowtab[r], y = rowtab[BM + r], x = rowtab[2 * BM + r];
+        unsigned m = 0;
+        if (img >= 0) {
+            if (p.ntaps == 9) {
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    const int yy = y + p.a_sgn * (t9 / 3 - 1), xx = x + p.a_sgn * (t9 % 3 - 1);
+                    if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) m |= 1u << t9;
+                }
+            } else {
+                m = 1u;
+            }
+        }
+        a_mask[i] = m;
+        a_off[i] = (long long)(img < 0 ? 0 : img) * p.A.sN + (long long)(y * p.a_up) * p.A.sH + (long long)(x * p.a_up) * p.A.sW + 4 * aq;
     }
     const int Ck4 = (p.Ck + 3) & ~3;
     const int cchunks = (p.Ck + BK - 1) / BK;
     const int nK = p.ntaps * p.nKphase * cchunks;
+    const int b_cq = tid % B_F4, b_kr = tid / B_F4;       // B (RC): float4 column, first k-row
 
     f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
 
-    auto prefetch = [&](int kc) {
-        int tap = kc / (p.nKphase * cchunks);
-        int rem = kc - tap * (p.nKphase * cchunks);
-        int kph = rem / cchunks;
-        int c0 = (rem - kph * cchunks) * BK;
+    // K order: channel chunk outermost, then phase, tap innermost -- the 9 taps of one 32-channel chunk re-read (almost)
+    // the same pixels in consecutive stages, so they hit L2 instead of going back to the fabric 9 times.
+    // The gather of the next stage is issued ONE LOAD AT A TIME between the MFMA groups of the current stage (load_one):
+    // a wave issues in order, so a monolithic block of address arithmetic would leave the matrix pipe idle behind it,
+    // whereas ~10 VALU instructions + 1 load fit in the 256-cycle shadow of each group of four 32x32x2 MFMAs.
+    int k_tap = 0, k_kph = 0, k_c0 = 0;                   // coordinates of the NEXT stage to gather
+    long long k_delta = 0; bool k_cok = false; bool k_more = true;
+    auto stage_setup = [&](bool more) {                  // scalar per-stage part of the addresses
         int dy = 0, dx = 0;
-        if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
-        dy *= p.a_sgn; dx *= p.a_sgn;
-        const int pa = kph >> 1, pc = kph & 1;
-        const int ca = c0 + 4 * aq;
-#pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) {
-            int yy = a_y[i] + dy, xx = a_x[i] + dx;
-            bool ok = ((unsigned)yy < (unsigned)p.H) && ((unsigned)xx < (unsigned)p.W) && (ca < Ck4);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) {
-                const float* src = p.A.p + a_base[i] + (long long)(yy * p.a_up + pa) * p.A.sH +
-                                   (long long)(xx * p.a_up + pc) * p.A.sW + ca;
-                v = *(const f32x4*)src;
-            }
-            a_reg[i] = v;
+        if (p.ntaps == 9) { dy = k_tap / 3 - 1; dx = k_tap - (k_tap / 3) * 3 - 1; }
+        k_delta = (long long)(dy * p.a_sgn * p.a_up + (k_kph >> 1)) * p.A.sH + (long long)(dx * p.a_sgn * p.a_up + (k_kph & 1)) * p.A.sW + k_c0;
+        k_cok = more && (k_c0 + 4 * aq) < Ck4;
+        k_more = more;
+    };
+    auto stage_advance = [&]() {
+        if (++k_tap == p.ntaps) {
+            k_tap = 0;
+            if (++k_kph == p.nKphase) { k_kph = 0; k_c0 += BK; }
         }
-        if constexpr (!B_RC) {
-#pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) {
-                int n = n0 + ar + 32 * i;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (n < p.Ncols && ca < Ck4) v = *(const f32x4*)(p.B + (long long)n * p.b_sRow + (long long)tap * p.b_sTap + ca);
-                b_reg[i] = v;
-            }
-        } else {
-            const int cq = tid % B_F4, kr = tid / B_F4;
-#pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) {
-                int c = c0 + kr + B_ROWS_PER_PASS * i;
-                int n = n0 + 4 * cq;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (c < p.Ck && n < p.Ncols)
-                    v = *(const f32x4*)(p.B + (long long)(kph * p.Ck + c) * p.b_sRow + (long long)tap * p.b_sTap + n);
-                b_reg[i] = v;
+    };
+    auto load_one = [&](int slot) {                       // slot is a compile-time constant after unrolling
+        if (slot < A_LOADS) {
+            const int i = slot;
+            const bool ok = k_cok && ((a_mask[i] >> k_tap) & 1u);
+            const float* src = ok ? p.A.p + (a_off[i] + k_delta) : afi_zeros;   // branch-free: masked lanes read zeros
+            a_reg[i] = *(const f32x4*)src;
+        } else if (slot < A_LOADS + B_LOADS) {
+            const int i = slot - A_LOADS;
+            if constexpr (!B_RC) {
+                const int n = n0 + ar + 32 * i;
+                const bool ok = k_cok && n < p.Ncols;
+                const float* src = ok ? p.B + ((long long)n * p.b_sRow + (long long)k_tap * p.b_sTap + k_c0 + 4 * aq) : afi_zeros;
+                b_reg[i] = *(const f32x4*)src;
+            } else {
+                const int c = k_c0 + b_kr + B_ROWS_PER_PASS * i;
+                const int n = n0 + 4 * b_cq;
+                const bool ok = k_more && c < p.Ck && n < p.Ncols;
+                const float* src = ok ? p.B + ((long long)(k_kph * p.Ck + c) * p.b_sRow + (long long)k_tap * p.b_sTap + n) : afi_zeros;
+                b_reg[i] = *(const f32x4*)src;
             }
         }
     };
-    auto stage_store = [&]() {
+    static_assert(A_LOADS + B_LOADS <= 15, "one load slot per MFMA group");
+    auto stage_store = [&](int buf) {
+        float* As = smem + buf * STAGE;
+        float* Bs = As + A_TILE;
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) *(f32x4*)(As + (ar + 32 * i) * LDK + 4 * aq) = a_reg[i];
         if constexpr (!B_RC) {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (ar + 32 * i) * LDK + 4 * aq) = b_reg[i];
         } else {
-            const int cq = tid % B_F4, kr = tid / B_F4;
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (kr + B_ROWS_PER_PASS * i) * BN + 4 * cq) = b_reg[i];
+            for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (b_kr + B_ROWS_PER_PASS * i) * BN + 4 * b_cq) = b_reg[i];
         }
     };
 
@@ -163,46 +193,115 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    prefetch(0);
-    for (int kc = 0; kc < nK; ++kc) {
-        stage_store();
-        __syncthreads();
-        if (kc + 1 < nK) prefetch(kc + 1);
+    auto read_frags = [&](int buf, int s, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
+        const float* As = smem + buf * STAGE;
+        const float* Bs = As + A_TILE;
 #pragma unroll
-        for (int s = 0; s < BK / 8; ++s) {
-            f32x4 a[MI], b[NI];
+        for (int mi = 0; mi < MI; ++mi)
+            a[mi] = *(const f32x4*)(As + ((wm * MI + mi) * 32 + lr) * LDK + s * 8 + lh * 4);
+        if constexpr (!B_RC) {
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-                a[mi] = *(const f32x4*)(As + ((wm * MI + mi) * 32 + lr) * LDK + s * 8 + lh * 4);
-            if constexpr (!B_RC) {
+            for (int ni = 0; ni < NI; ++ni)
+                b[ni] = *(const f32x4*)(Bs + ((wn * NI + ni) * 32 + lr) * LDK + s * 8 + lh * 4);
+        } else {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    b[ni] = *(const f32x4*)(Bs + ((wn * NI + ni) * 32 + lr) * LDK + s * 8 + lh * 4);
-            } else {
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) b[ni][j] = Bs[(s * 8 + lh * 4 + j) * BN + (wn * NI + ni) * 32 + lr];
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) b[ni][j] = Bs[(s * 8 + lh * 4 + j) * BN + (wn * NI + ni) * 32 + lr];
         }
+    };
+    auto mfma_group = [&](const f32x4 (&a)[MI], const f32x4 (&b)[NI], int j) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+    };
+    // One stage out of LDS buffer `buf`; with `gather` the next stage's global loads are issued inside it.
+    // AFI_GATHER_MODE 0 (default): the whole gather (scalar setup + A_LOADS+B_LOADS loads) sits between the 2nd and 3rd
+    //   k-step and hipcc schedules freely.   Mode 1: fragment reads one k-step ahead (two register sets) and one load per
+    //   MFMA group, pinned by sched_barrier.   Measured on MI355X, D1@P2 512->1024 fwd, TFLOP/s at 3 / 1 blocks per CU:
+    //   mode 0: 129.7 / 106.2      mode 1: 123.5 / 115.2   -- mode 1 shortens one wave's bubble but slows co-resident waves.
+    auto compute_stage = [&](int buf, bool gather, bool more) {
+        if constexpr (AFI_GATHER_MODE == 0) {
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) {
+                f32x4 fa[MI], fb[NI];
+                read_frags(buf, s, fa, fb);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mfma_group(fa, fb, j);
+                if (gather && s == 1) {
+                    stage_setup(more);
+#pragma unroll
+                    for (int slot = 0; slot < A_LOADS + B_LOADS; ++slot) load_one(slot);
+                }
+            }
+        } else {
+            f32x4 fa[2][MI], fb[2][NI];
+            read_frags(buf, 0, fa[0], fb[0]);
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) {
+                if (s + 1 < BK / 8) read_frags(buf, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    mfma_group(fa[s & 1], fb[s & 1], j);
+                    if (gather) {
+                        const int slot = s * 4 + j - 1;          // slot -1: the scalar address setup of the next stage
+                        if (slot == -1) stage_setup(more);
+                        else if (slot < A_LOADS + B_LOADS) load_one(slot);
+                        if (slot < A_LOADS + B_LOADS) __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    };
+    auto prefetch = [&]() {                               // prologue form: all loads of the next stage at once
+        stage_setup(true);
+#pragma unroll
+        for (int slot = 0; slot < A_LOADS + B_LOADS; ++slot) load_one(slot);
+        stage_advance();
+    };
+
+    // de-phase the blocks that share a SIMD: identical blocks launched together otherwise reach their barriers (where no
+    // wave of the block issues MFMAs) at the same moments
+    if (p.stagger) {
+        const int naps = (blockIdx.x * 2654435761u >> 20) % (unsigned)p.stagger;
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+    if constexpr (NBUF == 2) {
+        // Software pipeline, one barrier per stage: while stage kc is multiplied out of LDS buffer kc&1, the registers
+        // holding stage kc+1 (loaded during stage kc-1) are written to the other buffer and the gather of stage kc+2 is issued.
+        prefetch();
+        stage_store(0);
+        if (nK > 1) prefetch();
         __syncthreads();
+        for (int kc = 0; kc < nK; ++kc) {
+            const int cur = kc & 1;
+            if (kc + 1 < nK) stage_store(cur ^ 1);
+            if (kc + 2 < nK) prefetch();
+            compute_stage(cur, false, false);
+            __syncthreads();
+        }
+    } else {
+        // one LDS buffer: registers -> LDS, barrier, MFMAs of the stage with the next stage's gather issued in their middle
+        // (address math and loads overlap the matrix pipe), barrier.
+        prefetch();
+        for (int kc = 0; kc < nK; ++kc) {
+            stage_store(0);
+            __syncthreads();
+            compute_stage(0, true, kc + 1 < nK);          // no branch: past the last stage every lane reads afi_zeros
+            stage_advance();
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: accumulators -> LDS (32 tile rows per wave row at a time) -> float4 rows, so every global access of
     //      the epilogue (store, residual / mask / bilinear reads) is a contiguous 16 B per lane, 512 B per 32 lanes ----
     constexpr int LDC = BN + 4;
     constexpr int C_F4 = BN / 4;
-    static_assert(WM * 32 * LDC <= BM * LDK + (B_RC ? BK * BN : BN * LDK), "C staging tile must fit in the operand tiles");
+    static_assert(WM * 32 * LDC <= NBUF * STAGE, "C staging tile must fit in the operand tiles");
     float* Cs = smem;
     const int Hs = p.H >> 1, Ws = p.W >> 1;               // bilinear source extents (R1 low-res)
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -257,7 +356,6 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
         }
         if (mi + 1 < MI) __syncthreads();
     }
-    (void)zero4;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -469,20 +567,29 @@ extern "C" int afi_profile_get(int kind, double* out) {
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
+#include <stdlib.h>
+static int afi_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
 template <int BM, int BN, int WM, int WN, bool B_RC>
 static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const long long M = (long long)p.N * p.H * p.W;
     const int ntm = afi_cdiv(M, BM), ntn = afi_cdiv(p.Ncols, BN);
     const int ntiles = ntm * ntn;
     const int chunk = afi_cdiv(ntiles, 8);
-    const size_t lds = sizeof(float) * (BM * AFI_LDK + (B_RC ? AFI_BK * BN : BN * AFI_LDK)) + sizeof(int) * 3 * BM;
+    static const int extra_lds = afi_env_int("AFI_EXTRA_LDS", 0);   // experiments: lower the blocks/CU
+    const size_t lds = sizeof(float) * AFI_NBUF * (BM * AFI_LDK + (B_RC ? AFI_BK * BN : BN * AFI_LDK)) + sizeof(int) * 3 * BM + extra_lds;
     const int kind = (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
     hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC>), dim3(chunk * 8), dim3(256), lds, st, p, ntn, ntiles, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
-int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st) {
+int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
+    static const int stagger = afi_env_int("AFI_STAGGER", 0);
+    AfiPixGemm p = p_in;
+    p.stagger = stagger;
     const long long M = (long long)p.N * p.H * p.W;
     if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
     if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;

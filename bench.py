@@ -200,7 +200,7 @@ def main():
         torch.cuda.synchronize()
 
     log("models built; warm-up (the first guide forward lets MIOpen pick/compile its kernels)")
-    if guide is not None:
+    if guide is not None and args.warmup:
         guide(images_half)
         torch.cuda.synchronize()
         log("guide forward (half-size image) done")

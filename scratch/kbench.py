@@ -1,0 +1,30 @@
+"""Micro-benchmark of the MFMA conv kernels on stage-1 shapes (HIP events via torch on the current stream)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import afigan_amd as amd
+from afigan_amd import ops
+
+def t(fn, iters=10, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+cases = [("D2@P3", 2, 100, 168, 1024, 1024), ("D1@P2", 2, 200, 336, 512, 1024), ("D0@P2", 2, 200, 336, 256, 512), ("G0@lrP2", 2, 104, 168, 256, 256),
+         ("RDBc1@lrP2", 2, 104, 168, 256, 32), ("RDBc5@lrP2", 2, 104, 168, 384, 256), ("D2@P4", 2, 50, 84, 1024, 1024), ("G9@cfg1", 1, 50, 68, 256, 256), ("G0@cfg1", 1, 25, 34, 256, 256)]
+which = sys.argv[1:] or ["fwd", "dgrad", "wgrad"]
+for name, N, H, W, Ci, Co in cases:
+    x = ops.new_pixel_major(N, Ci, H, W, "cuda"); x.normal_()
+    w = ops.new_ohwi(Co, Ci, 3, 3, "cuda", zero=False); w.normal_(0, 0.02)
+    dy = ops.new_pixel_major(N, Co, H, W, "cuda"); dy.normal_()
+    out = ops.new_pixel_major(N, Co, H, W, "cuda"); dx = ops.new_pixel_major(N, Ci, H, W, "cuda"); dw = ops.new_ohwi(Co, Ci, 3, 3, "cuda")
+    fl = 2.0 * N * H * W * Ci * Co * 9
+    r = []
+    if "fwd" in which: ms = t(lambda: ops.conv3x3_fwd(x, w, None, out=out)); r.append(f"fwd {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+    if "dgrad" in which: ms = t(lambda: ops.conv3x3_dgrad(dy, w, dx=dx)); r.append(f"dgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+    if "wgrad" in which: ms = t(lambda: ops.conv3x3_wgrad(dy, x, dw=dw)); r.append(f"wgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+    print(f"{name:12s} N{N} {H}x{W} {Ci}->{Co}: " + " | ".join(r), flush=True)
