@@ -42,6 +42,20 @@ def warmup_multistep_lr(base_lr: float, it: int, steps: Sequence[int] = (270000,
     return base_lr * w * (gamma ** sum(1 for s in steps if it >= s))
 
 
+def allreduce_sum_(flat: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum a flat gradient buffer over the data-parallel ranks in place (backend "nccl" == RCCL on ROCm)."""
+    torch.distributed.all_reduce(flat, op=torch.distributed.ReduceOp.SUM, group=group)
+    return flat
+
+
+def broadcast_module_state_(modules, src: int = 0, group=None) -> None:
+    """DistributedDataParallel constructor semantics (stage1_trainer.py:80-89): every rank starts from rank `src`'s
+    parameters and buffers."""
+    for m in modules:
+        for t in m.state_dict().values():
+            torch.distributed.broadcast(t, src=src, group=group)
+
+
 class _FlatOptim:
     """Flat gradient + momentum buffers for one network and the device-side descriptor table of the fused SGD kernel
     (torch.optim.SGD semantics as configured by detectron2 build_optimizer: momentum 0.9, weight decay 1e-4, 0 for norm
@@ -107,8 +121,7 @@ class Stage1Step:
         for p in list(G.parameters()) + list(D.parameters()):
             ops._check_cuda(p)
         if self.distributed:        # DistributedDataParallel(...) ctor semantics: rank 0's weights everywhere (:80-89)
-            for t in list(G.state_dict().values()) + list(D.state_dict().values()):
-                torch.distributed.broadcast(t, src=0, group=process_group)
+            broadcast_module_state_([G, D], 0, process_group)
         gnames = dict((id(p), n) for n, p in G.named_parameters())
         dnames = dict((id(p), n) for n, p in D.named_parameters())
         self.g_order = G._ordered_params()
@@ -177,10 +190,11 @@ class Stage1Step:
         return tr[:, :, :h, :w], hr[:, :, :h, :w]
 
     def _allreduce(self, opt: _FlatOptim):
-        if not self.distributed:
-            return
-        torch.distributed.all_reduce(opt.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
-        call("afi_scale_inplace", C.c_void_p(opt.flat_grad.data_ptr()), opt.total, 1.0 / self.world, ops.stream_ptr())
+        """ONE collective per network per iteration: sum the flat gradient buffer over the ranks (RCCL over xGMI; gloo in
+        the CPU rehearsal).  The 1/world averaging is folded into the fused SGD kernel's gradient scale, so between this
+        call and the optimizer step ``param.grad`` holds the SUM over ranks."""
+        if self.distributed:
+            allreduce_sum_(opt.flat_grad, self.pg)
 
     # ------------------------------------------------------------------------------------------------ the step
     def run_step(self, lr_features: Sequence[torch.Tensor], hr_features: Sequence[torch.Tensor]):
@@ -218,7 +232,7 @@ class Stage1Step:
                      C.c_void_p(lptr + 4 * (3 * i)), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
                 self._d_backward(x, dws, dz)                                         # :375 (accumulates into the flat grads)
         self._allreduce(self.d_opt)
-        self.d_opt.step(lr_now, self.momentum)                                       # :381
+        self.d_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :381
 
         # ---------------- G phase (:384-433)
         self.g_opt.zero_grad()                                                       # :426
@@ -245,7 +259,7 @@ class Stage1Step:
                  C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n,
                  ops.stream_ptr())                                                   # :427
         self._allreduce(self.g_opt)
-        self.g_opt.step(lr_now, self.momentum)                                       # :433
+        self.g_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :433
         self.iter += 1
 
     def metrics(self, check_finite: bool = True) -> Dict[str, float]:

@@ -1,0 +1,151 @@
+"""CPU tests of the host side: drop-in surface (names, signatures, state_dict keys / shapes), LR schedule, flat gradient
+buffers, and the world_size-2 data-parallel plumbing over gloo (the N>1 path of afi-gan_amd/stage1.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import afigan_oracle as orc
+
+
+def _amd():
+    import __graft_entry__ as ge
+    ge.build(verbose=False)
+    import afigan_amd
+    return afigan_amd
+
+
+def test_reference_import_paths_and_signatures():
+    _amd()
+    from afigan.modeling.feat_interpol import generator_rdb as G_rdb              # stage1_trainer.py:31
+    from afigan.modeling.feat_interpol import feature_patch_discriminator as D    # stage1_trainer.py:32
+    import inspect
+    sig = inspect.signature(G_rdb.Generator.__init__)
+    assert [(k, v.default) for k, v in list(sig.parameters.items())[1:]] == [
+        ("in_channels", 256), ("n_residual_dense_blocks", 2), ("growth_rate", 32), ("residual_scale", 0.2), ("scale", 2)]
+    d = D.Discriminator()
+    assert d.current_step == 0 and len(d.Discriminators) == 1 and callable(d.Discriminators[0])
+    g = G_rdb.Generator(n_residual_dense_blocks=3)
+    assert len(g.Generators) == 1
+    assert sum(p.numel() for p in g.parameters()) == 7_834_624
+    assert sum(p.numel() for p in d.parameters()) == 15_352_321
+
+
+@pytest.mark.parametrize("n_rdb", [2, 3])
+def test_state_dict_contract(n_rdb):
+    amd = _amd()
+    g = amd.Generator(n_residual_dense_blocks=n_rdb)
+    want = orc.generator_param_shapes(256, n_rdb, 32)
+    got = {k: tuple(v.shape) for k, v in g.state_dict().items()}
+    assert got == want
+    d = amd.Discriminator()
+    want = orc.discriminator_param_shapes()
+    got = {k: tuple(v.shape) for k, v in d.state_dict().items()}
+    assert got == want
+    assert d.state_dict()["Discriminators.0.0.0.norm.num_batches_tracked"].dtype == torch.int64
+    # loading a plain (NCHW-contiguous) reference checkpoint keeps the kernels' [O][kh][kw][I] memory layout
+    sd = orc.closed_form_generator_params(256, n_rdb, 32)
+    g.load_state_dict(sd, strict=True)
+    w = g.Generators[0][0][0].weight
+    assert w.permute(0, 2, 3, 1).is_contiguous() and torch.equal(w, sd["Generators.0.0.0.weight"])
+    out = g.state_dict()["Generators.0.3.0.weight"]
+    assert tuple(out.shape) == (256, 256, 6, 6) and out.is_contiguous()        # ConvTranspose2d weight stays IOHW
+    # checkpoint.py:94 remap: keys gain the "backbone.srf_module." prefix when the generator sits in an AFI FPN
+    holder = torch.nn.Module()
+    holder.srf_module = g
+    assert all(k.startswith("srf_module.Generators.0.") for k in holder.state_dict())
+
+
+def test_init_statistics_follow_reference():
+    amd = _amd()
+    torch.manual_seed(0)
+    g = amd.Generator(n_residual_dense_blocks=3)
+    w = g.Generators[0][0][0].weight
+    assert abs(w.std().item() - 0.1 * (2.0 / (256 * 9)) ** 0.5) < 2e-4          # kaiming_normal_(fan_in) * 0.1
+    assert g.Generators[0][0][0].bias.abs().max().item() == 0
+    d = amd.Discriminator()
+    w = d.Discriminators[0][1][0].weight
+    assert abs(w.std().item() - (2.0 / (1024 * 9)) ** 0.5) < 2e-4               # c2_msra_fill: fan_out
+    bn = d.Discriminators[0][0][0].norm
+    assert torch.all(bn.weight == 1) and torch.all(bn.running_var == 1) and int(bn.num_batches_tracked) == 0
+
+
+def test_cpu_tensors_fail_loudly():
+    amd = _amd()
+    g = amd.Generator(in_channels=16, growth_rate=4)
+    with pytest.raises(amd.AfiError, match="no CPU fallback"):
+        g(torch.zeros(1, 16, 4, 4))
+    with pytest.raises(amd.AfiError):
+        amd.Generator(in_channels=18)
+
+
+def test_lr_schedule_matches_oracle_and_detectron2_formula():
+    amd = _amd()
+    for it in (0, 1, 500, 999, 1000, 269999, 270000, 299999):
+        a = amd.warmup_multistep_lr(1e-3, it)
+        assert a == pytest.approx(orc.warmup_multistep_lr(1e-3, it), rel=1e-12)
+    assert amd.warmup_multistep_lr(1e-3, 0) == pytest.approx(1e-6)
+    assert amd.warmup_multistep_lr(1e-3, 1000) == pytest.approx(1e-3)
+    assert amd.warmup_multistep_lr(1e-3, 270000) == pytest.approx(1e-4)
+
+
+def test_flat_gradient_buffers_are_views():
+    amd = _amd()
+    from afigan_amd.stage1 import _FlatOptim
+    g = amd.Generator(in_channels=16, n_residual_dense_blocks=2, growth_rate=4)
+    names = {id(p): n for n, p in g.named_parameters()}
+    opt = _FlatOptim([(names[id(p)], p) for p in g._ordered_params()], 1e-4, 0.0)
+    assert opt.total >= sum(p.numel() for p in g.parameters())
+    opt.flat_grad.fill_(3.0)
+    for p in g.parameters():
+        assert p.grad is not None and p.grad.shape == p.shape and torch.all(p.grad == 3.0)
+        assert p.grad.untyped_storage().data_ptr() == opt.flat_grad.untyped_storage().data_ptr()
+        assert p.grad.stride() == p.stride()                                   # same memory layout as the parameter
+    opt.zero_grad()
+    assert all(torch.all(p.grad == 0) for p in g.parameters())
+
+
+def _dp_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import afigan_amd as amd
+    from afigan_amd.stage1 import _FlatOptim, allreduce_sum_, broadcast_module_state_
+    torch.manual_seed(100 + rank)                       # different init per rank: the broadcast must fix that
+    g = amd.Generator(in_channels=16, n_residual_dense_blocks=2, growth_rate=4)
+    d = amd.Discriminator(in_filters=16)
+    broadcast_module_state_([g, d], 0)
+    names = {id(p): n for n, p in g.named_parameters()}
+    opt = _FlatOptim([(names[id(p)], p) for p in g._ordered_params()], 1e-4, 0.0)
+    # per-shard gradients from the CPU oracle on this rank's shard of the global batch
+    gp = {k: v.detach().clone().requires_grad_(True) for k, v in g.state_dict().items()}
+    x = torch.randn((1, 16, 5, 7), generator=torch.Generator().manual_seed(7 + rank))
+    orc.generator_forward(x, gp, n_rdb=2).square().sum().backward()
+    for k, p in g.named_parameters():
+        p.grad.copy_(gp[k].grad)
+    allreduce_sum_(opt.flat_grad)
+    out = {k: (p.grad / world).clone() for k, p in g.named_parameters()}
+    out["__w0"] = g.Generators[0][0][0].weight.detach().clone()
+    out["__shard_grads"] = {k: v.grad.clone() for k, v in gp.items()}
+    torch.save(out, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_allreduce_world2_gloo(tmp_path):
+    """All-reduced gradients == mean over ranks of the per-shard single-rank gradients, and every rank
+    starts from rank 0's weights."""
+    _amd()
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "r0.pt")
+    r1 = torch.load(tmp_path / "r1.pt")
+    assert torch.equal(r0["__w0"], r1["__w0"])
+    for k in r0["__shard_grads"]:
+        mean = (r0["__shard_grads"][k] + r1["__shard_grads"][k]) / 2
+        assert torch.allclose(r0[k], mean, rtol=1e-6, atol=1e-8), k
+        assert torch.equal(r0[k], r1[k]), k
+    assert not torch.equal(r0["__shard_grads"]["Generators.0.0.0.weight"], r1["__shard_grads"]["Generators.0.0.0.weight"])
