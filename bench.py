@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--batch-per-gpu", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-interp", action="store_true", help="skip the AF-interpolator micro-benchmark")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse "
+                    "the multi-process path with several ranks sharing one GPU)")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
     return ap.parse_args()
@@ -150,13 +152,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the AFI-GAN hot path has no CPU fallback)")
+    local_rank = local_rank % torch.cuda.device_count()      # (gloo rehearsal: several ranks may share one GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
     import __graft_entry__ as ge
     if rank == 0:
         ge.build(verbose=False)
@@ -266,6 +272,7 @@ def main():
         "metric": "stage1_G+D_step_images_per_s", "value": n_img / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "backend": (args.backend if world > 1 else None),
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
                                f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",
                    "global_batch": world * B, "parallelism": f"dp{world}", "guide": "r50fpn (GEMM 1x1 via hipBLASLt + own 3x3 MFMA conv)" if guide is not None else "synthetic-pyramid",

@@ -113,3 +113,58 @@ def test_stage1_small_ragged_vs_oracle(amd, reuse):
     # second iteration keeps working on the same buffers (momentum path) and stays finite
     step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
     assert all(np.isfinite(v) for v in step.metrics().values())
+
+
+def _dp_gpu_worker(rank, world, port, tmp):
+    """Two ranks share the one GPU of the test box and talk over gloo (RCCL needs one GPU per rank): exercises the real
+    distributed code path of Stage1Step (broadcast, flat-buffer all-reduce, fused SGD with 1/world) on the HIP kernels."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import afigan_amd as amd
+    C, g = 16, 4
+    torch.manual_seed(50 + rank)                               # different init per rank; the broadcast must fix it
+    G = amd.Generator(in_channels=C, n_residual_dense_blocks=2, growth_rate=g).cuda()
+    D = amd.Discriminator(in_filters=C).cuda()
+    gen = torch.Generator().manual_seed(1000 + rank)           # this rank's shard of the global batch
+    lr_f = [torch.randn((1, C, 7, 11), generator=gen).cuda(), torch.randn((1, C, 4, 6), generator=gen).cuda()]
+    hr_f = [torch.randn((1, C, 13, 21), generator=gen).cuda(), torch.randn((1, C, 8, 12), generator=gen).cuda()]
+    step = amd.Stage1Step(G, D, base_lr=0.01, warmup_iters=0)  # picks up the initialised process group
+    assert step.distributed and step.world == world
+    w0 = {k: v.detach().clone() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())}
+    # single-rank gradients of this shard from the same starting weights (independent engine, no process group)
+    import copy
+    G1, D1 = copy.deepcopy(G), copy.deepcopy(D)
+    solo = amd.Stage1Step(G1, D1, base_lr=0.01, warmup_iters=0, distributed=False)
+    solo.run_step(lr_f, hr_f)
+    step.run_step(lr_f, hr_f)
+    torch.cuda.synchronize()
+    out = {"w0": {k: v.cpu() for k, v in w0.items()},
+           "w1": {k: v.detach().cpu() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())},
+           "g_sum": {k: p.grad.detach().cpu().clone() for k, p in G.named_parameters()},
+           "g_solo": {k: p.grad.detach().cpu().clone() for k, p in G1.named_parameters()},
+           "metrics": step.metrics()}
+    torch.save(out, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stage1_data_parallel_two_ranks_one_gpu(amd, tmp_path):
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    for k in r0["w0"]:
+        assert torch.equal(r0["w0"][k], r1["w0"][k]), k           # broadcast from rank 0
+        if "running" in k or "num_batches" in k:
+            continue                                              # BN buffers are per-rank (plain BN, no sync)
+        assert torch.equal(r0["w1"][k], r1["w1"][k]), k           # identical update on every rank
+    # D's weights differ between the solo and the distributed run, so only G's D-independent gradient (L1 only, Q1) can be
+    # compared: summed all-reduced G grads == sum of the two single-rank G grads (same G weights, own shard each)
+    for k in r0["g_sum"]:
+        want = r0["g_solo"][k] + r1["g_solo"][k]
+        got = r0["g_sum"][k]
+        assert ((got - want).abs().max() / want.abs().max()).item() < 1e-4, k
+        assert torch.equal(r0["g_sum"][k], r1["g_sum"][k]), k
