@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libafigan_hip.so")
+LIB_PATH = os.environ.get("AFI_LIB_PATH") or os.path.join(_HERE, "csrc", "libafigan_hip.so")   # override: A/B kernel builds
 
 AFI_MAX_RDB = 8
 ABI_VERSION = 1

@@ -53,7 +53,6 @@ struct AfiPixGemm {
     int r1_bilinear;    // R1 is a low-res [N, H/2, W/2] tensor, added as its bilinear x2 up-sampling
     int lrelu;          // activation on v: 0 none, 1 LeakyReLU(0.2), 2 ReLU
     AfiView Z; int z_lo, z_hi;                 // multiply by (Z > 0 ? 1 : 0.2) for channels in [z_lo, z_hi)
-    int stagger;        // > 0: blocks nap a pseudo-random 0..stagger-1 x 512 cycles before their main loop
 };
 
 // Parameters of the weight-gradient GEMM:  dW[co'][tap][ci] += alpha * sum_pix dY[pix][co'] * X[pix+tap][ci]

@@ -34,6 +34,9 @@
 #ifndef AFI_GATHER_MODE
 #define AFI_GATHER_MODE 0
 #endif
+#ifndef AFI_GATHER_AT
+#define AFI_GATHER_AT 1      // k-step of the stage after which the next stage's gather is issued (mode 0)
+#endif
 
 // 16 bytes of zeros: masked lanes of the branch-free gathers read these instead of selecting after the load, so no
 // instruction depends on a global load until the registers are written to LDS a stage later
@@ -49,16 +52,18 @@ __device__ __forceinline__ void afi_bil_idx(int o, int L, int& i0, int& i1, floa
     i1 = min(i0 + 1, L - 1);
 }
 
-template <int BM, int BN, int WM, int WN, bool B_RC>
+template <int BM, int BN, int WM, int WN, bool B_RC, int BK>
 __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, int ntile_n, int ntiles, int chunk) {
-    constexpr int BK = AFI_BK, LDK = AFI_LDK;
+    constexpr int LDK = BK + 4;                           // K-contiguous LDS rows: +16 B pad -> conflict-free ds_read_b128
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave layout");
-    constexpr int A_LOADS = BM / 32;                      // float4 loads per thread per stage (A, KC)
+    constexpr int K_F4 = BK / 4;                          // KC: float4 per row of a stage
+    constexpr int K_RPP = 256 / K_F4;                     // KC: rows covered per load pass
+    constexpr int A_LOADS = BM / K_RPP;                   // float4 loads per thread per stage (A, KC)
     constexpr int B_F4 = BN / 4;                          // RC: float4 per k-row
-    constexpr int B_LOADS = B_RC ? (BK * B_F4) / 256 : BN / 32;
-    static_assert(B_LOADS >= 1, "tile too small");
+    constexpr int B_LOADS = B_RC ? (BK * B_F4) / 256 : BN / K_RPP;
+    static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small");
     constexpr int B_ROWS_PER_PASS = 256 / B_F4;           // RC
 
     constexpr int A_TILE = BM * LDK;                      // floats per A stage buffer
@@ -100,11 +105,11 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     // ---- loader state ----
     // Per tile row: the 64-bit offset of its centre pixel in A and a 9-bit mask of the taps that stay inside the image,
     // so a stage's gather is one scalar delta (tap / phase / channel chunk) + one add and one bit test per load.
-    const int aq = tid & 7, ar = tid >> 3;                // A (KC): float4 column, first row
+    const int aq = tid % K_F4, ar = tid / K_F4;           // A (KC): float4 column, first row
     long long a_off[A_LOADS]; unsigned a_mask[A_LOADS];
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-        const int r = ar + 32 * i;
+        const int r = ar + K_RPP * i;
         const int img = rowtab[r], y = rowtab[BM + r], x = rowtab[2 * BM + r];
         unsigned m = 0;
         if (img >= 0) {
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
         } else if (slot < A_LOADS + B_LOADS) {
             const int i = slot - A_LOADS;
             if constexpr (!B_RC) {
-                const int n = n0 + ar + 32 * i;
+                const int n = n0 + ar + K_RPP * i;
                 const bool ok = k_cok && n < p.Ncols;
                 const float* src = ok ? p.B + ((long long)n * p.b_sRow + (long long)k_tap * p.b_sTap + k_c0 + 4 * aq) : afi_zeros;
                 b_reg[i] = *(const f32x4*)src;
@@ -170,15 +175,15 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
             }
         }
     };
-    static_assert(A_LOADS + B_LOADS <= 15, "one load slot per MFMA group");
+    static_assert(AFI_GATHER_MODE == 0 || A_LOADS + B_LOADS <= BK / 2 - 1, "one load slot per MFMA group");
     auto stage_store = [&](int buf) {
         float* As = smem + buf * STAGE;
         float* Bs = As + A_TILE;
 #pragma unroll
-        for (int i = 0; i < A_LOADS; ++i) *(f32x4*)(As + (ar + 32 * i) * LDK + 4 * aq) = a_reg[i];
+        for (int i = 0; i < A_LOADS; ++i) *(f32x4*)(As + (ar + K_RPP * i) * LDK + 4 * aq) = a_reg[i];
         if constexpr (!B_RC) {
 #pragma unroll
-            for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (ar + 32 * i) * LDK + 4 * aq) = b_reg[i];
+            for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (ar + K_RPP * i) * LDK + 4 * aq) = b_reg[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (b_kr + B_ROWS_PER_PASS * i) * BN + 4 * b_cq) = b_reg[i];
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
                 read_frags(buf, s, fa, fb);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mfma_group(fa, fb, j);
-                if (gather && s == 1) {
+                if (gather && s == AFI_GATHER_AT) {
                     stage_setup(more);
 #pragma unroll
                     for (int slot = 0; slot < A_LOADS + B_LOADS; ++slot) load_one(slot);
@@ -262,12 +267,6 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
         stage_advance();
     };
 
-    // de-phase the blocks that share a SIMD: identical blocks launched together otherwise reach their barriers (where no
-    // wave of the block issues MFMAs) at the same moments
-    if (p.stagger) {
-        const int naps = (blockIdx.x * 2654435761u >> 20) % (unsigned)p.stagger;
-        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     if constexpr (NBUF == 2) {
         // Software pipeline, one barrier per stage: while stage kc is multiplied out of LDS buffer kc&1, the registers
         // holding stage kc+1 (loaded during stage kc-1) are written to the other buffer and the gather of stage kc+2 is issued.
@@ -366,13 +365,17 @@ __global__ __launch_bounds__(256) void afi_wgrad_gemm_kernel(const AfiWgradGemm 
     constexpr int BK = AFI_BK;
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
     static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(MI == 1 || MI == 2 || MI == 4, "vector fragment reads");
+    static_assert(NI == 1 || NI == 2 || NI == 4, "vector fragment reads");
     constexpr int A_F4 = BM / 4, B_F4 = BN / 4;
     constexpr int A_LOADS = (BK * A_F4) / 256, B_LOADS = (BK * B_F4) / 256;
     static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small");
-    constexpr int A_RPP = 256 / A_F4, B_RPP = 256 / B_F4;  // k-rows covered per load pass
+    constexpr int A_RPP = 256 / A_F4, B_RPP = 256 / B_F4;  // k-rows (pixels) covered per load pass
+    typedef float fragA __attribute__((ext_vector_type(MI)));
+    typedef float fragB __attribute__((ext_vector_type(NI)));
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                 // [BK][BM]
+    float* As = smem;                 // [BK][BM]   (pixel-major, like the tensors: no transpose anywhere)
     float* Bs = smem + BK * BM;       // [BK][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(256) void afi_wgrad_gemm_kernel(const AfiWgradGemm 
     const int lr = lane & 31, lh = lane >> 5;
 
     int t = blockIdx.x;
-    const int tap = t % p.ntaps; t /= p.ntaps;
+    const int tap = t % p.ntaps; t /= p.ntaps;             // taps fastest: the 9 blocks of one (m, n) tile share dY and most of X in L2
     const int tile_n = t % ntile_n; const int tile_m = t / ntile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     int dy = 0, dx = 0;
@@ -393,60 +396,61 @@ __global__ __launch_bounds__(256) void afi_wgrad_gemm_kernel(const AfiWgradGemm 
     if (k_begin >= k_end) return;
     const int nK = (int)((k_end - k_begin + BK - 1) / BK);
 
-    // per-thread loader state: the pixel of each load pass, advanced by BK pixels per stage
+    // ---- loader state: each load pass walks the pixels k_begin + kr + RPP*i + 32*stage.  (y, x) and the 64-bit element
+    //      offset are advanced incrementally (adds of precomputed constants, no division / 64-bit multiply per stage).
     const int a_cq = tid % A_F4, a_kr = tid / A_F4;
     const int b_cq = tid % B_F4, b_kr = tid / B_F4;
-    int an[A_LOADS], ay[A_LOADS], ax[A_LOADS];
-    int bn[B_LOADS], by[B_LOADS], bx[B_LOADS];
-    auto decode = [&](long long pix, int& n, int& y, int& x) {
-        n = (int)(pix / HW);
-        int rem = (int)(pix - (long long)n * HW);
-        y = rem / p.W; x = rem - y * p.W;
-    };
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) decode(k_begin + a_kr + A_RPP * i, an[i], ay[i], ax[i]);
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) decode(k_begin + b_kr + B_RPP * i, bn[i], by[i], bx[i]);
-    const int adv_y = BK / p.W, adv_x = BK - adv_y * p.W;
-    auto advance = [&](int& n, int& y, int& x) {
-        x += adv_x; y += adv_y;
-        if (x >= p.W) { x -= p.W; ++y; }
-        while (y >= p.H) { y -= p.H; ++n; }
-    };
-
-    // A column (co') of this thread: phase / channel split for the pixel-shuffled dY of the conv-transpose
-    const int a_col = m0 + 4 * a_cq;
+    const int a_col = m0 + 4 * a_cq;                       // co' of this thread's float4
     int a_ph = 0, a_ch = a_col;
     if (p.dy_up == 2) { a_ph = a_col / p.CoutPhase; a_ch = a_col - a_ph * p.CoutPhase; }
     const bool a_col_ok = a_col < p.Mrows;
     const int b_col = n0 + 4 * b_cq;
     const bool b_col_ok = b_col < p.Ncols;
+    const long long a_eH = (long long)p.dy_up * p.DY.sH, a_eW = (long long)p.dy_up * p.DY.sW;
+    const int adv_y = BK / p.W, adv_x = BK - adv_y * p.W;
+    const long long a_adv = adv_y * a_eH + adv_x * a_eW, a_wrapx = a_eH - p.W * a_eW, a_wrapy = p.DY.sN - p.H * a_eH;
+    const long long b_adv = adv_y * p.X.sH + adv_x * p.X.sW, b_wrapx = p.X.sH - p.W * p.X.sW, b_wrapy = p.X.sN - p.H * p.X.sH;
+
+    long long a_off[A_LOADS], b_off[B_LOADS];
+    int ay[A_LOADS], ax[A_LOADS], by[B_LOADS], bx[B_LOADS];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+        const long long pix = k_begin + a_kr + A_RPP * i;
+        const int n = (int)(pix / HW); const int rem = (int)(pix - (long long)n * HW);
+        ay[i] = rem / p.W; ax[i] = rem - ay[i] * p.W;
+        a_off[i] = (long long)n * p.DY.sN + ay[i] * a_eH + ax[i] * a_eW + (a_ph >> 1) * p.DY.sH + (a_ph & 1) * p.DY.sW + a_ch;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const long long pix = k_begin + b_kr + B_RPP * i;
+        const int n = (int)(pix / HW); const int rem = (int)(pix - (long long)n * HW);
+        by[i] = rem / p.W; bx[i] = rem - by[i] * p.W;
+        b_off[i] = (long long)n * p.X.sN + (long long)(by[i] + dy) * p.X.sH + (long long)(bx[i] + dx) * p.X.sW + b_col;
+    }
+    long long k_pix = k_begin;                             // first pixel of the NEXT stage to gather
 
     f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
-    auto prefetch = [&](int kc) {
-        const long long kb = k_begin + (long long)kc * BK;
+    auto prefetch = [&](bool more) {
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (a_col_ok && kb + a_kr + A_RPP * i < k_end) {
-                const float* src = p.DY.p + (long long)an[i] * p.DY.sN + (long long)(ay[i] * p.dy_up + (a_ph >> 1)) * p.DY.sH +
-                                   (long long)(ax[i] * p.dy_up + (a_ph & 1)) * p.DY.sW + a_ch;
-                v = *(const f32x4*)src;
-            }
-            a_reg[i] = v;
-            advance(an[i], ay[i], ax[i]);
+            const bool ok = more && a_col_ok && (k_pix + a_kr + A_RPP * i < k_end);
+            const float* src = ok ? p.DY.p + a_off[i] : afi_zeros;
+            a_reg[i] = *(const f32x4*)src;
+            ax[i] += adv_x; ay[i] += adv_y; a_off[i] += a_adv;
+            if (ax[i] >= p.W) { ax[i] -= p.W; ++ay[i]; a_off[i] += a_wrapx; }
+            while (ay[i] >= p.H) { ay[i] -= p.H; a_off[i] += a_wrapy; }
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            int yy = by[i] + dy, xx = bx[i] + dx;
-            if (b_col_ok && kb + b_kr + B_RPP * i < k_end && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) {
-                const float* src = p.X.p + (long long)bn[i] * p.X.sN + (long long)yy * p.X.sH + (long long)xx * p.X.sW + b_col;
-                v = *(const f32x4*)src;
-            }
-            b_reg[i] = v;
-            advance(bn[i], by[i], bx[i]);
+            const int yy = by[i] + dy, xx = bx[i] + dx;
+            const bool ok = more && b_col_ok && (k_pix + b_kr + B_RPP * i < k_end) && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const float* src = ok ? p.X.p + b_off[i] : afi_zeros;
+            b_reg[i] = *(const f32x4*)src;
+            bx[i] += adv_x; by[i] += adv_y; b_off[i] += b_adv;
+            if (bx[i] >= p.W) { bx[i] -= p.W; ++by[i]; b_off[i] += b_wrapx; }
+            while (by[i] >= p.H) { by[i] -= p.H; b_off[i] += b_wrapy; }
         }
+        k_pix += BK;
     };
     auto stage_store = [&]() {
 #pragma unroll
@@ -463,28 +467,32 @@ __global__ __launch_bounds__(256) void afi_wgrad_gemm_kernel(const AfiWgradGemm 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    prefetch(0);
+    // Fragment reads: a wave's MI (NI) 32-row blocks are INTERLEAVED (block mi = rows base + MI*lane + mi), so one
+    // ds_read_b64 / b128 of MI consecutive floats feeds all MI blocks of a k-step (both operands are pixel-major, i.e.
+    // row-contiguous in LDS; per-row ds_read_b32 would need MI+NI LDS instructions per k-step instead of 2).
+    const float* a_rd = As + (wm * MI * 32 + MI * lr);
+    const float* b_rd = Bs + (wn * NI * 32 + NI * lr);
+    prefetch(true);
     for (int kc = 0; kc < nK; ++kc) {
         stage_store();
         __syncthreads();
-        if (kc + 1 < nK) prefetch(kc + 1);
 #pragma unroll
         for (int s = 0; s < BK / 8; ++s) {
-            f32x4 a[MI], b[NI];
+            fragA a[4]; fragB b[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) a[mi][j] = As[(s * 8 + lh * 4 + j) * BM + (wm * MI + mi) * 32 + lr];
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) b[ni][j] = Bs[(s * 8 + lh * 4 + j) * BN + (wn * NI + ni) * 32 + lr];
+                a[j] = *(const fragA*)(a_rd + (s * 8 + lh * 4 + j) * BM);
+                b[j] = *(const fragB*)(b_rd + (s * 8 + lh * 4 + j) * BN);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NI; ++ni) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi], b[j][ni], acc[mi][ni], 0, 0, 0);
+                    }
+            if (s == 1) prefetch(kc + 1 < nK);              // next stage's gather in the middle of this stage's MFMAs
         }
         __syncthreads();
     }
@@ -494,19 +502,20 @@ __global__ __launch_bounds__(256) void afi_wgrad_gemm_kernel(const AfiWgradGemm 
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row >= p.Mrows) continue;
+            const int row = m0 + wm * MI * 32 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
+            if (row < p.Mrows) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int col = n0 + (wn * NI + ni) * 32 + lr;
-                if (col >= p.Ncols) continue;
-                float* dst = p.DW + (long long)row * p.dw_sRow + (long long)tap * p.dw_sTap + col;
-                float v = p.alpha * acc[mi][ni][r];
-                if (use_atomic) atomicAdd(dst, v); else *dst += v;
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int col = n0 + wn * NI * 32 + NI * lr + ni;
+                    if (col < p.Ncols) {
+                        float* dst = p.DW + (long long)row * p.dw_sRow + (long long)tap * p.dw_sTap + col;
+                        const float v = p.alpha * acc[mi][ni][r];
+                        if (use_atomic) atomicAdd(dst, v); else *dst += v;
+                    }
+                }
             }
         }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)
@@ -572,24 +581,28 @@ static int afi_env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-template <int BM, int BN, int WM, int WN, bool B_RC>
+template <int BM, int BN, int WM, int WN, bool B_RC, int BK = AFI_BK>
 static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const long long M = (long long)p.N * p.H * p.W;
     const int ntm = afi_cdiv(M, BM), ntn = afi_cdiv(p.Ncols, BN);
     const int ntiles = ntm * ntn;
     const int chunk = afi_cdiv(ntiles, 8);
-    static const int extra_lds = afi_env_int("AFI_EXTRA_LDS", 0);   // experiments: lower the blocks/CU
-    const size_t lds = sizeof(float) * AFI_NBUF * (BM * AFI_LDK + (B_RC ? AFI_BK * BN : BN * AFI_LDK)) + sizeof(int) * 3 * BM + extra_lds;
+    const size_t lds = sizeof(float) * AFI_NBUF * (BM * (BK + 4) + (B_RC ? BK * BN : BN * (BK + 4))) + sizeof(int) * 3 * BM;
     const int kind = (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
-    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC>), dim3(chunk * 8), dim3(256), lds, st, p, ntn, ntiles, chunk);
+    if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
+        static const hipError_t attr = hipFuncSetAttribute((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return AFI_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK>), dim3(chunk * 8), dim3(256), lds, st, p, ntn, ntiles, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
 int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
-    static const int stagger = afi_env_int("AFI_STAGGER", 0);
-    AfiPixGemm p = p_in;
-    p.stagger = stagger;
+    // BK = 64 stages for the 128x128 tile are instantiable (AFI_BK64=1) but measured slower on MI355X: 2 blocks/CU, 124 vs 127 TFLOP/s
+    static const int bk64 = afi_env_int("AFI_BK64", 0);
+    const AfiPixGemm& p = p_in;
     const long long M = (long long)p.N * p.H * p.W;
     if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
     if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;
@@ -600,11 +613,13 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     if (!b_rc) {
         if (p.Ncols <= 32) return launch_pix<128, 32, 4, 1, false>(p, st);
         if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, false>(p, st) : launch_pix<128, 64, 2, 2, false>(p, st);
-        return smallM ? launch_pix<64, 64, 2, 2, false>(p, st) : launch_pix<128, 128, 2, 2, false>(p, st);
+        if (smallM) return launch_pix<64, 64, 2, 2, false>(p, st);
+        return (bk64 && p.Ck % 64 == 0) ? launch_pix<128, 128, 2, 2, false, 64>(p, st) : launch_pix<128, 128, 2, 2, false>(p, st);
     } else {
         if (p.Ncols <= 32) return launch_pix<128, 32, 4, 1, true>(p, st);
         if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, true>(p, st) : launch_pix<128, 64, 2, 2, true>(p, st);
-        return smallM ? launch_pix<64, 64, 2, 2, true>(p, st) : launch_pix<128, 128, 2, 2, true>(p, st);
+        if (smallM) return launch_pix<64, 64, 2, 2, true>(p, st);
+        return (bk64 && p.Ck % 64 == 0) ? launch_pix<128, 128, 2, 2, true, 64>(p, st) : launch_pix<128, 128, 2, 2, true>(p, st);
     }
 }
 
