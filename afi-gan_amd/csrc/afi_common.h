@@ -53,6 +53,8 @@ struct AfiPixGemm {
     int r1_bilinear;    // R1 is a low-res [N, H/2, W/2] tensor, added as its bilinear x2 up-sampling
     int lrelu;          // activation on v: 0 none, 1 LeakyReLU(0.2), 2 ReLU
     AfiView Z; int z_lo, z_hi;                 // multiply by (Z > 0 ? 1 : 0.2) for channels in [z_lo, z_hi)
+    // split-K scratch (optional): [splitK][M][roundup4(Ncols)] partial slabs; the launcher picks splitK and fills it in
+    float* partial; long long partial_floats; int splitK;
 };
 
 // Parameters of the weight-gradient GEMM:  dW[co'][tap][ci] += alpha * sum_pix dY[pix][co'] * X[pix+tap][ci]

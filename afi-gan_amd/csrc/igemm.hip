@@ -52,6 +52,68 @@ __device__ __forceinline__ void afi_bil_idx(int o, int L, int& i0, int& i1, floa
     i1 = min(i0 + 1, L - 1);
 }
 
+
+// Fused epilogue of one float4 of accumulators (4 consecutive output columns of one GEMM row):
+//   v = alpha*acc + bias + beta*O_old + r1s*R1 (direct or bilinear x2) + r2s*R2 ; activation ; * lrelu'(Z) ; (pixel-shuffle) store
+__device__ __forceinline__ void afi_epilogue_store(const AfiPixGemm& p, int img, int y, int x, int col, f32x4 accv) {
+    int phase = 0, ch = col;
+    if (p.o_up == 2) { phase = col / p.CoutPhase; ch = col - phase * p.CoutPhase; }
+    const int yo = y * p.o_up + (phase >> 1), xo = x * p.o_up + (phase & 1);
+    float* dst = p.O.p + (long long)img * p.O.sN + (long long)yo * p.O.sH + (long long)xo * p.O.sW + ch;
+    f32x4 v = p.alpha * accv;
+    if (p.bias) v += *(const f32x4*)(p.bias + ch);
+    if (p.beta != 0.f) v += p.beta * *(const f32x4*)dst;
+    if (p.R1.p && ch >= p.r1_lo && ch < p.r1_hi) {
+        if (p.r1_bilinear) {
+            int by0, by1, bx0, bx1; float ly, lx;
+            afi_bil_idx(y, p.H >> 1, by0, by1, ly); afi_bil_idx(x, p.W >> 1, bx0, bx1, lx);
+            const float* rb = p.R1.p + (long long)img * p.R1.sN + ch;
+            const f32x4 x00 = *(const f32x4*)(rb + (long long)by0 * p.R1.sH + (long long)bx0 * p.R1.sW);
+            const f32x4 x01 = *(const f32x4*)(rb + (long long)by0 * p.R1.sH + (long long)bx1 * p.R1.sW);
+            const f32x4 x10 = *(const f32x4*)(rb + (long long)by1 * p.R1.sH + (long long)bx0 * p.R1.sW);
+            const f32x4 x11 = *(const f32x4*)(rb + (long long)by1 * p.R1.sH + (long long)bx1 * p.R1.sW);
+            const f32x4 top = x00 * (1.f - lx) + x01 * lx;
+            const f32x4 bot = x10 * (1.f - lx) + x11 * lx;
+            v += p.r1s * (top * (1.f - ly) + bot * ly);
+        } else {
+            v += p.r1s * *(const f32x4*)(p.R1.p + (long long)img * p.R1.sN + (long long)yo * p.R1.sH + (long long)xo * p.R1.sW + ch);
+        }
+    }
+    if (p.R2.p && ch >= p.r2_lo && ch < p.r2_hi)
+        v += p.r2s * *(const f32x4*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch);
+    if (p.lrelu) {
+        const float slope = (p.lrelu == 1) ? AFI_LRELU_SLOPE : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+    }
+    if (p.Z.p && ch >= p.z_lo && ch < p.z_hi) {
+        const f32x4 z = *(const f32x4*)(p.Z.p + (long long)img * p.Z.sN + (long long)yo * p.Z.sH + (long long)xo * p.Z.sW + ch);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= (z[j] > 0.f ? 1.f : AFI_LRELU_SLOPE);
+    }
+    *(f32x4*)dst = v;
+}
+
+// Second pass of the split-K form (small maps: too few tiles to fill 256 CUs): sum the per-split partial slabs in a FIXED
+// order (bit-reproducible, no atomics, no memset) and apply the fused epilogue.  partial: [splitK][M][ldp].
+__global__ __launch_bounds__(256) void afi_pix_splitk_epilogue_kernel(const AfiPixGemm p) {
+    const int HW = p.H * p.W;
+    const long long M = (long long)p.N * HW;
+    const int ldp = (p.Ncols + 3) & ~3;
+    const int C_F4 = ldp >> 2;
+    const long long total = M * C_F4;
+    for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+        const long long m = it / C_F4;
+        const int col = (int)(it - m * C_F4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < p.splitK; ++ks) v += *(const f32x4*)(p.partial + ((long long)ks * M + m) * ldp + col);
+        const int img = (int)(m / HW);
+        const int rem = (int)(m - (long long)img * HW);
+        const int y = rem / p.W, x = rem - y * p.W;
+        afi_epilogue_store(p, img, y, x, col, v);
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool B_RC, int BK>
 __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, int ntile_n, int ntiles, int chunk) {
     constexpr int LDK = BK + 4;                           // K-contiguous LDS rows: +16 B pad -> conflict-free ds_read_b128
@@ -128,7 +190,12 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     }
     const int Ck4 = (p.Ck + 3) & ~3;
     const int cchunks = (p.Ck + BK - 1) / BK;
-    const int nK = p.ntaps * p.nKphase * cchunks;
+    const int nK_total = p.ntaps * p.nKphase * cchunks;
+    // split-K (blockIdx.y): this block multiplies stages [kc0, kc0 + nK) and leaves the raw partial tile in its slab
+    const int kper = (nK_total + p.splitK - 1) / p.splitK;
+    const int kc0 = blockIdx.y * kper;
+    const int nK = min(kper, nK_total - kc0);
+    if (nK <= 0) return;                                  // (uniform) cannot happen with the launcher's splitK choice
     const int b_cq = tid % B_F4, b_kr = tid / B_F4;       // B (RC): float4 column, first k-row
 
     f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
@@ -138,7 +205,7 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     // The gather of the next stage is issued ONE LOAD AT A TIME between the MFMA groups of the current stage (load_one):
     // a wave issues in order, so a monolithic block of address arithmetic would leave the matrix pipe idle behind it,
     // whereas ~10 VALU instructions + 1 load fit in the 256-cycle shadow of each group of four 32x32x2 MFMAs.
-    int k_tap = 0, k_kph = 0, k_c0 = 0;                   // coordinates of the NEXT stage to gather
+    int k_tap = kc0 % p.ntaps, k_kph = (kc0 / p.ntaps) % p.nKphase, k_c0 = (kc0 / (p.ntaps * p.nKphase)) * BK;   // NEXT stage to gather
     long long k_delta = 0; bool k_cok = false; bool k_more = true;
     auto stage_setup = [&](bool more) {                  // scalar per-stage part of the addresses
         int dy = 0, dx = 0;
@@ -300,7 +367,6 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     constexpr int C_F4 = BN / 4;
     static_assert(WM * 32 * LDC <= NBUF * STAGE, "C staging tile must fit in the operand tiles");
     float* Cs = smem;
-    const int Hs = p.H >> 1, Ws = p.W >> 1;               // bilinear source extents (R1 low-res)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -315,43 +381,13 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
             const int img = rowtab[rl];
             const int col = n0 + 4 * c4;
             if (img < 0 || col >= p.Ncols) continue;
-            const int y = rowtab[BM + rl], x = rowtab[2 * BM + rl];
-            int phase = 0, ch = col;
-            if (p.o_up == 2) { phase = col / p.CoutPhase; ch = col - phase * p.CoutPhase; }
-            const int yo = y * p.o_up + (phase >> 1), xo = x * p.o_up + (phase & 1);
-            float* dst = p.O.p + (long long)img * p.O.sN + (long long)yo * p.O.sH + (long long)xo * p.O.sW + ch;
-            f32x4 v = p.alpha * *(const f32x4*)(Cs + rloc * LDC + 4 * c4);
-            if (p.bias) v += *(const f32x4*)(p.bias + ch);
-            if (p.beta != 0.f) v += p.beta * *(const f32x4*)dst;
-            if (p.R1.p && ch >= p.r1_lo && ch < p.r1_hi) {
-                if (p.r1_bilinear) {
-                    int by0, by1, bx0, bx1; float ly, lx;
-                    afi_bil_idx(y, Hs, by0, by1, ly); afi_bil_idx(x, Ws, bx0, bx1, lx);
-                    const float* rb = p.R1.p + (long long)img * p.R1.sN + ch;
-                    const f32x4 x00 = *(const f32x4*)(rb + (long long)by0 * p.R1.sH + (long long)bx0 * p.R1.sW);
-                    const f32x4 x01 = *(const f32x4*)(rb + (long long)by0 * p.R1.sH + (long long)bx1 * p.R1.sW);
-                    const f32x4 x10 = *(const f32x4*)(rb + (long long)by1 * p.R1.sH + (long long)bx0 * p.R1.sW);
-                    const f32x4 x11 = *(const f32x4*)(rb + (long long)by1 * p.R1.sH + (long long)bx1 * p.R1.sW);
-                    const f32x4 top = x00 * (1.f - lx) + x01 * lx;
-                    const f32x4 bot = x10 * (1.f - lx) + x11 * lx;
-                    v += p.r1s * (top * (1.f - ly) + bot * ly);
-                } else {
-                    v += p.r1s * *(const f32x4*)(p.R1.p + (long long)img * p.R1.sN + (long long)yo * p.R1.sH + (long long)xo * p.R1.sW + ch);
-                }
+            const f32x4 accv = *(const f32x4*)(Cs + rloc * LDC + 4 * c4);
+            if (p.splitK > 1) {
+                const int ldp = (p.Ncols + 3) & ~3;
+                *(f32x4*)(p.partial + ((long long)blockIdx.y * M + (m0 + rl)) * ldp + col) = accv;
+            } else {
+                afi_epilogue_store(p, img, rowtab[BM + rl], rowtab[2 * BM + rl], col, accv);
             }
-            if (p.R2.p && ch >= p.r2_lo && ch < p.r2_hi)
-                v += p.r2s * *(const f32x4*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch);
-            if (p.lrelu) {
-                const float slope = (p.lrelu == 1) ? AFI_LRELU_SLOPE : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
-            }
-            if (p.Z.p && ch >= p.z_lo && ch < p.z_hi) {
-                const f32x4 z = *(const f32x4*)(p.Z.p + (long long)img * p.Z.sN + (long long)yo * p.Z.sH + (long long)xo * p.Z.sW + ch);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] *= (z[j] > 0.f ? 1.f : AFI_LRELU_SLOPE);
-            }
-            *(f32x4*)dst = v;
         }
         if (mi + 1 < MI) __syncthreads();
     }
@@ -595,7 +631,27 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr != hipSuccess) return AFI_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK>), dim3(chunk * 8), dim3(256), lds, st, p, ntn, ntiles, chunk);
+    // split-K for small maps: with fewer tiles than ~2 per CU the serial K loop (72..288 stages of ~0.9 us) is pure latency;
+    // spread it over blockIdx.y, keeping >= 4 stages per block and the slabs inside the caller's workspace
+    AfiPixGemm q = p;
+    q.splitK = 1;
+    const int nK = p.ntaps * p.nKphase * afi_cdiv(p.Ck, BK);
+    if (p.partial && ntiles < 512) {
+        int sk = afi_cdiv(1024, ntiles);
+        if (sk > nK / 4) sk = nK / 4;
+        const long long slab = M * ((p.Ncols + 3) & ~3);
+        if (sk > 1 && slab * sk > p.partial_floats) sk = (int)(p.partial_floats / slab);
+        if (sk > 1) {
+            const int kper = afi_cdiv(nK, sk);
+            q.splitK = afi_cdiv(nK, kper);                // no empty splits
+        }
+    }
+    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK>), dim3(chunk * 8, q.splitK), dim3(256), lds, st, q, ntn, ntiles, chunk);
+    if (q.splitK > 1) {
+        const long long items = M * (((p.Ncols + 3) & ~3) >> 2);
+        long long g = (items + 255) / 256; if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(afi_pix_splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, st, q);
+    }
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

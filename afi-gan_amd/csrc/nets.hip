@@ -36,6 +36,49 @@ int afi_launch_invstd(const float* var, float* invstd, int C, hipStream_t st);
 
 #define AFI_TRY(expr) do { int _s = (expr); if (_s != AFI_OK) return _s; } while (0)
 
+// Fork/join onto one cached side stream, used by the backward passes of SMALL maps: the weight-gradient GEMMs and bias
+// column sums do not feed the data-gradient chain, so they run beside it instead of between its links (at config-1 sizes
+// every kernel occupies a fraction of the 256 CUs).  Events come from a small ring created on first use; fork/join only
+// records and waits on events, so the sequence stays capturable in a hipGraph.
+#include <vector>
+namespace {
+struct SideStream {
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ring;
+    size_t next = 0;
+    bool init() {
+        if (side) return true;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+        ring.resize(128);
+        for (auto& e : ring)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+        return true;
+    }
+    hipEvent_t ev() { hipEvent_t e = ring[next]; next = (next + 1) % ring.size(); return e; }
+};
+thread_local SideStream g_side;
+struct Fork {
+    hipStream_t main, side;
+    bool on;
+    Fork(hipStream_t m, bool enable) : main(m), side(m), on(false) {
+        if (enable && g_side.init()) { side = g_side.side; on = true; after_main(); }
+    }
+    void after_main() {            // work queued on `side` from here on sees everything already queued on `main`
+        if (!on) return;
+        hipEvent_t e = g_side.ev();
+        (void)hipEventRecord(e, main);
+        (void)hipStreamWaitEvent(side, e, 0);
+    }
+    void join() {                  // `main` continues only after everything queued on `side`
+        if (!on) return;
+        hipEvent_t e = g_side.ev();
+        (void)hipEventRecord(e, side);
+        (void)hipStreamWaitEvent(main, e, 0);
+    }
+};
+constexpr long long kSideStreamMaxPixels = 40000;   // above this every GEMM fills the chip on its own
+}  // namespace
+
 static inline AfiView V(afi_view_t v) { return AfiView{v.p, v.sN, v.sH, v.sW}; }
 static inline AfiView dense_view(const float* p, int H, int W, long long ld) {
     return AfiView{const_cast<float*>(p), (long long)H * W * ld, (long long)W * ld, ld};
@@ -200,9 +243,15 @@ int afi_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, void* str
 
 // ------------------------------------------------------------------------------------------------ generator
 // forward workspace layout (floats):  [Wp 36*C*C][buf_r : n_rdb x P*L][t : P*C][a7 : P*C][u : 4P*C]     L = C + 4G
+// split-K scratch shared by the small-map GEMMs of one call: room for 16 slabs of the largest layer, capped at 18 MB
+static long long part_floats(long long max_mn) {
+    const long long cap = 4608LL * 1024;
+    const long long want = 16 * max_mn;
+    return align4(want < cap ? want : cap);
+}
 struct GenWs {
     long long P, L;
-    long long o_wp, o_buf, o_t, o_a7, o_u, total;
+    long long o_wp, o_buf, o_t, o_a7, o_u, o_part, n_part, total;
 };
 static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenWs w;
@@ -213,6 +262,8 @@ static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_t = o; o += align4(w.P * C);
     w.o_a7 = o; o += align4(w.P * C);
     w.o_u = o; o += align4(4 * w.P * C);
+    w.n_part = part_floats(4 * w.P * C);
+    w.o_part = o; o += w.n_part;
     w.total = o;
     return w;
 }
@@ -220,7 +271,7 @@ long long afi_generator_fwd_ws_floats(int C, int G, int n_rdb, int N, int H, int
 
 // backward scratch layout: [dU 4P*C][gA P*C][gB P*C][dBuf0 P*L][dBuf1 P*L][dWp 36*C*C][red]
 struct GenBwdWs {
-    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_red, total;
+    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_red, o_part, n_part, total;
 };
 static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenBwdWs w;
@@ -229,10 +280,12 @@ static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_du = o; o += align4(4 * P * C);
     w.o_ga = o; o += align4(P * C);
     w.o_gb = o; o += align4(P * C);
-    w.o_db0 = o; o += align4(P * L);
-    w.o_db1 = o; o += align4(P * L);
+    w.o_db0 = o; o += align4((long long)n_rdb * P * L);      // one gradient buffer per RDB: no reuse, so the side-stream wgrads never race a later write
+    w.o_db1 = o;
     w.o_dwp = o; o += align4(36LL * C * C);
     w.o_red = o; o += align4(afi_reduce_scratch_floats(C));
+    w.n_part = part_floats(4 * P * C);
+    w.o_part = o; o += w.n_part;
     w.total = o;
     return w;
 }
@@ -252,6 +305,9 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
     const GenWs l = gen_ws(C, G, R, N, H, W);
     if (ws_floats < l.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    float* const part_ = ws + l.o_part;
+    const long long part_n_ = l.n_part;
+    auto PG = [&](AfiPixGemm g, int b_rc) { g.partial = part_; g.partial_floats = part_n_; return afi_launch_pix_gemm(g, b_rc, st); };
     const int L = (int)l.L;
     const float rs = prm->residual_scale;
     float* wp = ws + l.o_wp;
@@ -264,7 +320,7 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
     {   // head conv + LReLU (generator_rdb.py:91-93) -> channels [0,C) of RDB 0's dense buffer
         AfiPixGemm g = conv_fwd_desc(x, N, H, W, C, prm->w0, prm->b0, C, buf(0));
         g.lrelu = 1;
-        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+        AFI_TRY(PG(g, 0));
     }
     for (int r = 0; r < R; ++r) {   // ResidualDenseBlock.forward (generator_rdb.py:64-71); the dense buffer replaces torch.cat
         AfiView b = buf(r);
@@ -272,7 +328,7 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
             const int cin = C + (k - 1) * G;
             AfiPixGemm g = conv_fwd_desc(b, N, H, W, cin, prm->rdb_w[r][k - 1], nullptr, G, ch_off(b, cin));
             g.lrelu = 1;
-            AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+            AFI_TRY(PG(g, 0));
         }
         const bool last = (r == R - 1);
         AfiPixGemm g = conv_fwd_desc(b, N, H, W, L, prm->rdb_w[r][4], nullptr, C, last ? t : buf(r + 1));
@@ -283,22 +339,22 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
             g.alpha = rs * rs; g.r1s = rs;
             g.R2 = buf(0); g.r2s = 1.f; g.r2_lo = 0; g.r2_hi = C;
         }
-        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+        AFI_TRY(PG(g, 0));
     }
     {   // trunk conv + LReLU (:97-99)
         AfiPixGemm g = conv_fwd_desc(t, N, H, W, C, prm->w7, prm->b7, C, a7);
         g.lrelu = 1;
-        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+        AFI_TRY(PG(g, 0));
     }
     {   // ConvTranspose2d k6 s2 p2 + LReLU (:101-105) as a 4-phase 3x3 conv with a pixel-shuffle store
         AfiPixGemm g = convT_fwd_desc(a7, N, H, W, C, wp, prm->bT, C, u);
         g.lrelu = 1;
-        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+        AFI_TRY(PG(g, 0));
     }
     {   // final conv (:107-108) + bilinear x2 skip of the input (:125,130) fused in the epilogue
         AfiPixGemm g = conv_fwd_desc(u, N, 2 * H, 2 * W, C, prm->w9, prm->b9, C, V(outv));
         g.R1 = x; g.r1s = 1.f; g.r1_lo = 0; g.r1_hi = C; g.r1_bilinear = 1;
-        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+        AFI_TRY(PG(g, 0));
     }
     return AFI_OK;
 }
@@ -312,6 +368,9 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     const GenBwdWs s = gen_bwd_ws(C, G, R, N, H, W);
     if (scratch_floats < s.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    float* const part_ = scratch + s.o_part;
+    const long long part_n_ = s.n_part;
+    auto PG = [&](AfiPixGemm g, int b_rc) { g.partial = part_; g.partial_floats = part_n_; return afi_launch_pix_gemm(g, b_rc, st); };
     const int L = (int)l.L;
     const long long P = l.P;
     const float rs = prm->residual_scale;
@@ -323,52 +382,58 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     AfiView dOut = dense_view(dout, 2 * H, 2 * W, C);
     AfiView dU = dense_view(scratch + s.o_du, 2 * H, 2 * W, C);
     AfiView gA = dense_view(scratch + s.o_ga, H, W, C), gB = dense_view(scratch + s.o_gb, H, W, C);
-    AfiView dB[2] = {dense_view(scratch + s.o_db0, H, W, L), dense_view(scratch + s.o_db1, H, W, L)};
+    auto dBuf = [&](int r) { return dense_view(scratch + s.o_db0 + (long long)r * P * L, H, W, L); };
     float* dwp = scratch + s.o_dwp;
-    float* red = scratch + s.o_red;
+    float* red = scratch + s.o_red;                        // column-sum scratch: used on the side stream only
+    Fork fk(st, 4 * P <= kSideStreamMaxPixels);
+    hipStream_t sd = fk.side;                              // weight / bias gradients
 
     // ---- final conv (generator_rdb.py:107-108)
-    if (gr->w9) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dOut, u, N, 2 * H, 2 * W, C, C, gr->w9, 1.f), st));
-    if (gr->b9) AFI_TRY(afi_launch_colsum_accum(dout, 4 * P, C, C, 1.f, gr->b9, red, st));
+    if (gr->w9) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dOut, u, N, 2 * H, 2 * W, C, C, gr->w9, 1.f), sd));
+    if (gr->b9) AFI_TRY(afi_launch_colsum_accum(dout, 4 * P, C, C, 1.f, gr->b9, red, sd));
     {
         AfiPixGemm g = conv_dgrad_desc(dOut, N, 2 * H, 2 * W, C, prm->w9, C, dU);
         g.Z = u; g.z_lo = 0; g.z_hi = C;                       // through the LReLU after the conv-transpose
-        AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+        AFI_TRY(PG(g, 1));
     }
     // ---- conv-transpose (:101-105)
+    fk.after_main();                                       // dU is complete
     if (gr->wT) {
-        if (hipMemsetAsync(dwp, 0, sizeof(float) * 36LL * C * C, st) != hipSuccess) return AFI_ERR_LAUNCH;
-        AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), st));
-        AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, st));
+        if (hipMemsetAsync(dwp, 0, sizeof(float) * 36LL * C * C, sd) != hipSuccess) return AFI_ERR_LAUNCH;
+        AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));
+        AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd));
     }
-    if (gr->bT) AFI_TRY(afi_launch_colsum_accum(dU.p, 4 * P, C, C, 1.f, gr->bT, red, st));
+    if (gr->bT) AFI_TRY(afi_launch_colsum_accum(dU.p, 4 * P, C, C, 1.f, gr->bT, red, sd));
     {
         AfiPixGemm g = convT_dgrad_desc(dU, N, H, W, C, wp, C, gA);
         g.Z = a7; g.z_lo = 0; g.z_hi = C;
-        AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+        AFI_TRY(PG(g, 1));
     }
     // ---- trunk conv (:97-99): gA = d(pre-activation of a7)
-    if (gr->w7) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gA, t, N, H, W, C, C, gr->w7, 1.f), st));
-    if (gr->b7) AFI_TRY(afi_launch_colsum_accum(gA.p, P, C, C, 1.f, gr->b7, red, st));
-    AFI_TRY(afi_launch_pix_gemm(conv_dgrad_desc(gA, N, H, W, C, prm->w7, C, gB), 1, st));    // gB = dT
+    fk.after_main();                                       // gA is complete
+    if (gr->w7) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gA, t, N, H, W, C, C, gr->w7, 1.f), sd));
+    if (gr->b7) AFI_TRY(afi_launch_colsum_accum(gA.p, P, C, C, 1.f, gr->b7, red, sd));
+    AFI_TRY(PG(conv_dgrad_desc(gA, N, H, W, C, prm->w7, C, gB), 1));    // gB = dT
     // ---- ResidualInResidual (:27-30) and the RDB chain (:64-71), last block first
     AfiView Gt = gB;        // incoming gradient tensor, true gradient = gs * Gt
     float gs = rs;
     for (int r = R - 1; r >= 0; --r) {
-        AfiView b = buf(r), d = dB[r & 1];
+        AfiView b = buf(r), d = dBuf(r);
         // conv5: out = x + rs*conv5(cat)
-        if (gr->rdb_w[r][4]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(Gt, b, N, H, W, C, L, gr->rdb_w[r][4], rs * gs), st));
+        fk.after_main();                                   // Gt is complete
+        if (gr->rdb_w[r][4]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(Gt, b, N, H, W, C, L, gr->rdb_w[r][4], rs * gs), sd));
         {
             AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->rdb_w[r][4], L, d);
             g.alpha = rs * gs;
             g.R1 = Gt; g.r1s = gs; g.r1_lo = 0; g.r1_hi = C;           // identity path of the block
             g.Z = b; g.z_lo = C + 3 * G; g.z_hi = L;                   // conv4's LReLU: its slice is final after this kernel
-            AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+            AFI_TRY(PG(g, 1));
         }
         for (int k = 4; k >= 1; --k) {
             const int cin = C + (k - 1) * G;
             AfiView dyk = ch_off(d, cin);                               // d(pre-activation of conv_k), G channels
-            if (gr->rdb_w[r][k - 1]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dyk, b, N, H, W, G, cin, gr->rdb_w[r][k - 1], 1.f), st));
+            fk.after_main();                               // dyk's slice was finalised by the previous dgrad
+            if (gr->rdb_w[r][k - 1]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dyk, b, N, H, W, G, cin, gr->rdb_w[r][k - 1], 1.f), sd));
             AfiPixGemm g = conv_dgrad_desc(dyk, N, H, W, G, prm->rdb_w[r][k - 1], cin, d);
             g.beta = 1.f;                                               // dense connections: accumulate
             if (k >= 2) { g.Z = b; g.z_lo = cin - G; g.z_hi = cin; }    // conv_{k-1}'s slice becomes final
@@ -376,19 +441,21 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
                 g.R2 = gB; g.r2s = 1.f; g.r2_lo = 0; g.r2_hi = C;
                 g.Z = b; g.z_lo = 0; g.z_hi = C;
             }
-            AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+            AFI_TRY(PG(g, 1));
         }
         Gt = d; gs = 1.f;                                               // channels [0,C) of d = gradient w.r.t. the block input
     }
     // ---- head conv (:91-93): Gt[0:C] = d(pre-activation of a0)
-    if (gr->w0) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(Gt, x, N, H, W, C, C, gr->w0, 1.f), st));
-    if (gr->b0) AFI_TRY(afi_launch_colsum_accum(Gt.p, P, C, L, 1.f, gr->b0, red, st));
+    fk.after_main();
+    if (gr->w0) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(Gt, x, N, H, W, C, C, gr->w0, 1.f), sd));
+    if (gr->b0) AFI_TRY(afi_launch_colsum_accum(Gt.p, P, C, L, 1.f, gr->b0, red, sd));
     if (dx) {
         AFI_TRY(afi_launch_bilinear2x_bwd(dout, N, H, W, C, 0.f, dx, st));           // skip path (:125)
         AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->w0, C, dense_view(dx, H, W, C));
         g.beta = 1.f;
-        AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+        AFI_TRY(PG(g, 1));
     }
+    fk.join();
     return AFI_OK;
 }
 
@@ -396,7 +463,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
 // forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][y2 P*F3][d9 P*16][mean,invstd x3][red]
 struct DiscWs {
     long long P;
-    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, total;
+    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_part, n_part, total;
 };
 static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     DiscWs w;
@@ -414,21 +481,25 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
         w.o_invstd[n] = o; o += align4(F[n + 1]);
     }
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));
+    w.n_part = part_floats(w.P * fmax);
+    w.o_part = o; o += w.n_part;
     w.total = o;
     return w;
 }
 long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W) { return disc_ws(F, N, H, W).total; }
-struct DiscBwdWs { long long o_ga, o_gb, o_dd9, o_red, total; };
+struct DiscBwdWs { long long o_g[3], o_dd9, o_red, o_red2, o_part, n_part, total; };
 static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     DiscBwdWs w;
     const long long P = (long long)N * H * W;
     int fmax = 4;
     for (int n = 0; n < 4; ++n) if (F[n] > fmax) fmax = F[n];
     long long o = 0;
-    w.o_ga = o; o += align4(P * fmax);
-    w.o_gb = o; o += align4(P * fmax);
+    for (int n = 0; n < 3; ++n) { w.o_g[n] = o; o += align4(P * F[n + 1]); }   // one gradient buffer per block (no ping-pong reuse)
     w.o_dd9 = o; o += align4(P * 16);
-    w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));
+    w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));       // BatchNorm backward (main stream)
+    w.o_red2 = o; o += align4(afi_reduce_scratch_floats(fmax));      // bias column sums (side stream)
+    w.n_part = part_floats(P * fmax);
+    w.o_part = o; o += w.n_part;
     w.total = o;
     return w;
 }
@@ -450,6 +521,9 @@ int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, in
     const DiscWs l = disc_ws(prm->F, N, H, W);
     if (ws_floats < l.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    float* const part_ = ws + l.o_part;
+    const long long part_n_ = l.n_part;
+    auto PG = [&](AfiPixGemm g, int b_rc) { g.partial = part_; g.partial_floats = part_n_; return afi_launch_pix_gemm(g, b_rc, st); };
     const long long P = l.P;
     float* red = ws + l.o_red;
     AfiView in = V(xv);
@@ -457,7 +531,7 @@ int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, in
         const int ci = prm->F[n], co = prm->F[n + 1];
         float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];
         float* mean = ws + l.o_mean[n]; float* invstd = ws + l.o_invstd[n];
-        AFI_TRY(afi_launch_pix_gemm(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0, st));
+        AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         if (training) {
             AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st));
             if (prm->num_batches_tracked[n]) AFI_TRY(afi_launch_inc_i64(prm->num_batches_tracked[n], st));
@@ -475,7 +549,7 @@ int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, in
         g.ntaps = 1; g.Ck = F3; g.Ncols = 9; g.CoutPhase = 9;
         g.A = in; g.B = prm->w3; g.b_sRow = F3; g.b_sTap = 0;
         g.O = dense_view(d9, H, W, 16);
-        AFI_TRY(afi_launch_pix_gemm(g, 0, st));
+        AFI_TRY(PG(g, 0));
         AFI_TRY(afi_launch_stencil9_sum(d9, 16, prm->b3, logits, N, H, W, st));
     }
     return AFI_OK;
@@ -489,49 +563,55 @@ int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t*
     const DiscBwdWs s = disc_bwd_ws(prm->F, N, H, W);
     if (scratch_floats < s.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
+    float* const part_ = scratch + s.o_part;
+    const long long part_n_ = s.n_part;
+    auto PG = [&](AfiPixGemm g, int b_rc) { g.partial = part_; g.partial_floats = part_n_; return afi_launch_pix_gemm(g, b_rc, st); };
     const long long P = l.P;
     float* red = scratch + s.o_red;
-    float* gbuf[2] = {scratch + s.o_ga, scratch + s.o_gb};
+    float* red2 = scratch + s.o_red2;
     float* dd9 = scratch + s.o_dd9;
+    Fork fk(st, P <= kSideStreamMaxPixels);
+    hipStream_t sd = fk.side;                              // weight / bias gradients run beside the data-gradient chain
     const int F3 = prm->F[3];
     // ---- last conv
-    if (gr->b3) AFI_TRY(afi_launch_sum_accum(dlogits, P, 1.f, gr->b3, st));
+    if (gr->b3) AFI_TRY(afi_launch_sum_accum(dlogits, P, 1.f, gr->b3, sd));
     AFI_TRY(afi_launch_stencil9_scatter(dlogits, dd9, 16, N, H, W, st));
+    fk.after_main();                                       // dd9 is complete
     AfiView y2 = dense_view(ws + l.o_y[2], H, W, F3);
     if (gr->w3) {
         AfiWgradGemm g = conv_wgrad_desc(dense_view(dd9, H, W, 16), y2, N, H, W, 9, F3, gr->w3, 1.f);
         g.ntaps = 1; g.dw_sRow = F3; g.dw_sTap = 0;
-        AFI_TRY(afi_launch_wgrad_gemm(g, st));
+        AFI_TRY(afi_launch_wgrad_gemm(g, sd));
     }
-    int cur = 0;
     {
         AfiPixGemm g = pix_default(N, H, W);
         g.ntaps = 1; g.a_sgn = -1; g.Ck = 9; g.Ncols = F3; g.CoutPhase = F3;
         g.A = dense_view(dd9, H, W, 16); g.B = prm->w3; g.b_sRow = F3; g.b_sTap = 0;
-        g.O = dense_view(gbuf[cur], H, W, F3);
+        g.O = dense_view(scratch + s.o_g[2], H, W, F3);
         g.Z = y2; g.z_lo = 0; g.z_hi = F3;
-        AFI_TRY(afi_launch_pix_gemm(g, 1, st));
+        AFI_TRY(PG(g, 1));
     }
     // ---- conv + BN + LReLU blocks, last first
     for (int n = 2; n >= 0; --n) {
         const int ci = prm->F[n], co = prm->F[n + 1];
-        float* g_ = gbuf[cur];                        // d(BN output), already through the LReLU mask
+        float* g_ = scratch + s.o_g[n];               // d(BN output), already through the LReLU mask
         const float* c = ws + l.o_c[n];
         AFI_TRY(afi_launch_bn_bwd(g_, c, g_, ws + l.o_mean[n], ws + l.o_invstd[n], prm->gamma[n], gr->gamma[n], gr->beta[n], 1.f, P, co,
                                   red, st));          // in place: g_ = d(conv output)
-        if (gr->b[n]) AFI_TRY(afi_launch_colsum_accum(g_, P, co, co, 1.f, gr->b[n], red, st));
+        fk.after_main();                              // g_ = d(conv output) is complete
+        if (gr->b[n]) AFI_TRY(afi_launch_colsum_accum(g_, P, co, co, 1.f, gr->b[n], red2, sd));
         AfiView gy = dense_view(g_, H, W, co);
         AfiView xin = (n == 0) ? V(xv) : dense_view(ws + l.o_y[n - 1], H, W, ci);
-        if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), st));
+        if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0) {
-            AfiPixGemm g = conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(gbuf[cur ^ 1], H, W, ci));
+            AfiPixGemm g = conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(scratch + s.o_g[n - 1], H, W, ci));
             g.Z = xin; g.z_lo = 0; g.z_hi = ci;
-            AFI_TRY(afi_launch_pix_gemm(g, 1, st));
-            cur ^= 1;
+            AFI_TRY(PG(g, 1));
         } else if (dx) {
-            AFI_TRY(afi_launch_pix_gemm(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(dx, H, W, ci)), 1, st));
+            AFI_TRY(PG(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(dx, H, W, ci)), 1));
         }
     }
+    fk.join();
     return AFI_OK;
 }
 
