@@ -114,9 +114,19 @@ __global__ __launch_bounds__(256) void afi_pix_splitk_epilogue_kernel(const AfiP
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool B_RC, int BK>
-__global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, int ntile_n, int ntiles, int chunk) {
+// HALO variant (3x3, stride-1 gathers on large maps): the M tile is an 8x16 pixel patch of one image and the A operand is
+// staged ONCE per 32-channel chunk as the patch's 10x18 halo; the nine taps of the chunk are nine stages that read their
+// fragments from that halo at shifted positions.  Per 9 stages a thread issues 6 A loads instead of 36 (global loads in
+// the MFMA stream cost ~64 issue cycles each on this chip, measured), and the same for the LDS writes.
+#define AFI_HALO_TY 8
+#define AFI_HALO_TX 16
+#define AFI_HALO_PIX ((AFI_HALO_TY + 2) * (AFI_HALO_TX + 2))
+template <int BM, int BN, int WM, int WN, bool B_RC, int BK, bool HALO = false>
+__global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p, int ntile_n, int ntiles, int chunk) {
     constexpr int LDK = BK + 4;                           // K-contiguous LDS rows: +16 B pad -> conflict-free ds_read_b128
+    static_assert(!HALO || (BM == AFI_HALO_TY * AFI_HALO_TX && BK == 32), "halo variant: 8x16 patch, 32-channel chunks");
+    constexpr int H_LOADS = (AFI_HALO_PIX * (BK / 4) + 255) / 256;   // float4 loads per thread per halo (6)
+    constexpr int HW_ = AFI_HALO_TX + 2;                  // halo row pitch in pixels
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
     static_assert(WM * WN == 4, "4 waves per block");
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave layout");
@@ -128,7 +138,8 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small");
     constexpr int B_ROWS_PER_PASS = 256 / B_F4;           // RC
 
-    constexpr int A_TILE = BM * LDK;                      // floats per A stage buffer
+    constexpr int A_SLOTS = HALO ? H_LOADS : A_LOADS;     // A-side load slots (registers) per thread
+    constexpr int A_TILE = (HALO ? AFI_HALO_PIX : BM) * LDK;   // floats per A stage buffer
     constexpr int B_TILE = B_RC ? BK * BN : BN * LDK;     // floats per B stage buffer
     constexpr int STAGE = A_TILE + B_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -149,9 +160,21 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W;
     const long long M = (long long)p.N * HW;
+    int patch_img = 0, patch_y0 = 0, patch_x0 = 0;        // HALO: image and origin of this block's 8x16 patch
 
     // decode the tile's rows once (shared by the A gather and the epilogue)
-    if (tid < BM) {
+    if constexpr (HALO) {
+        const int tiles_x = (p.W + AFI_HALO_TX - 1) / AFI_HALO_TX, tiles_y = (p.H + AFI_HALO_TY - 1) / AFI_HALO_TY;
+        patch_img = tile_m / (tiles_x * tiles_y);
+        const int r = tile_m - patch_img * (tiles_x * tiles_y);
+        patch_y0 = (r / tiles_x) * AFI_HALO_TY;
+        patch_x0 = (r - (r / tiles_x) * tiles_x) * AFI_HALO_TX;
+        if (tid < BM) {
+            const int y = patch_y0 + tid / AFI_HALO_TX, x = patch_x0 + tid % AFI_HALO_TX;
+            const bool ok = y < p.H && x < p.W;
+            rowtab[tid] = ok ? patch_img : -1; rowtab[BM + tid] = y; rowtab[2 * BM + tid] = x;
+        }
+    } else if (tid < BM) {
         long long m = (long long)m0 + tid;
         int img = -1, y = -(1 << 20), x = -(1 << 20);
         if (m < M) {
@@ -168,7 +191,11 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     // Per tile row: the 64-bit offset of its centre pixel in A and a 9-bit mask of the taps that stay inside the image,
     // so a stage's gather is one scalar delta (tap / phase / channel chunk) + one add and one bit test per load.
     const int aq = tid % K_F4, ar = tid / K_F4;           // A (KC): float4 column, first row
-    long long a_off[A_LOADS]; unsigned a_mask[A_LOADS];
+    constexpr int A_STATE = HALO ? 1 : A_LOADS;           // the halo variant recomputes its (rare) addresses instead of keeping them
+    long long a_off[A_STATE]; unsigned a_mask[A_STATE];
+    if constexpr (HALO) {
+        a_off[0] = 0; a_mask[0] = 0;
+    } else
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
         const int r = ar + K_RPP * i;
@@ -198,7 +225,7 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     if (nK <= 0) return;                                  // (uniform) cannot happen with the launcher's splitK choice
     const int b_cq = tid % B_F4, b_kr = tid / B_F4;       // B (RC): float4 column, first k-row
 
-    f32x4 a_reg[A_LOADS], b_reg[B_LOADS];
+    f32x4 a_reg[A_SLOTS], b_reg[B_LOADS];
 
     // K order: channel chunk outermost, then phase, tap innermost -- the 9 taps of one 32-channel chunk re-read (almost)
     // the same pixels in consecutive stages, so they hit L2 instead of going back to the fabric 9 times.
@@ -221,13 +248,25 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
         }
     };
     auto load_one = [&](int slot) {                       // slot is a compile-time constant after unrolling
-        if (slot < A_LOADS) {
+        if (slot < A_SLOTS) {
             const int i = slot;
-            const bool ok = k_cok && ((a_mask[i] >> k_tap) & 1u);
-            const float* src = ok ? p.A.p + (a_off[i] + k_delta) : afi_zeros;   // branch-free: masked lanes read zeros
-            a_reg[i] = *(const f32x4*)src;
-        } else if (slot < A_LOADS + B_LOADS) {
-            const int i = slot - A_LOADS;
+            if constexpr (HALO) {
+                if (k_tap == 0) {                          // (uniform) a new channel chunk starts: fetch its halo once
+                    // halo pixel hp = (tid + 256 i) / 8 of the 10x18 halo, float4 column aq (256 % 8 == 0)
+                    const int hp = (tid + 256 * i) / K_F4;
+                    const int y = patch_y0 - 1 + hp / HW_, x = patch_x0 - 1 + hp % HW_;
+                    const bool ok = k_cok && hp < AFI_HALO_PIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+                    const float* src = ok ? p.A.p + ((long long)patch_img * p.A.sN + (long long)y * p.A.sH + (long long)x * p.A.sW + 4 * aq + k_c0)
+                                          : afi_zeros;
+                    a_reg[i] = *(const f32x4*)src;
+                }
+            } else {
+                const bool ok = k_cok && ((a_mask[i] >> k_tap) & 1u);
+                const float* src = ok ? p.A.p + (a_off[i] + k_delta) : afi_zeros;   // branch-free: masked lanes read zeros
+                a_reg[i] = *(const f32x4*)src;
+            }
+        } else if (slot < A_SLOTS + B_LOADS) {
+            const int i = slot - A_SLOTS;
             if constexpr (!B_RC) {
                 const int n = n0 + ar + K_RPP * i;
                 const bool ok = k_cok && n < p.Ncols;
@@ -242,10 +281,17 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
             }
         }
     };
-    static_assert(AFI_GATHER_MODE == 0 || A_LOADS + B_LOADS <= BK / 2 - 1, "one load slot per MFMA group");
-    auto stage_store = [&](int buf) {
+    static_assert(AFI_GATHER_MODE == 0 || A_SLOTS + B_LOADS <= BK / 2 - 1, "one load slot per MFMA group");
+    auto stage_store = [&](int buf, int tap_of_regs) {
         float* As = smem + buf * STAGE;
         float* Bs = As + A_TILE;
+        if constexpr (HALO) {
+            if (tap_of_regs == 0) {                        // (uniform) the registers hold a fresh halo
+#pragma unroll
+                for (int i = 0; i < H_LOADS; ++i)
+                    if (tid + 256 * i < AFI_HALO_PIX * K_F4) *(f32x4*)(As + ((tid + 256 * i) / K_F4) * LDK + 4 * aq) = a_reg[i];
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) *(f32x4*)(As + (ar + K_RPP * i) * LDK + 4 * aq) = a_reg[i];
         if constexpr (!B_RC) {
@@ -265,9 +311,18 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    auto read_frags = [&](int buf, int s, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
+    auto read_frags = [&](int buf, int s, int tap, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
         const float* As = smem + buf * STAGE;
         const float* Bs = As + A_TILE;
+        if constexpr (HALO) {
+            // tile row m = 32*blk + lr is patch pixel (m / 16, m % 16); tap (dy, dx) reads halo pixel (+1 + sgn*dy, +1 + sgn*dx)
+            const int shift = p.a_sgn * ((tap / 3 - 1) * HW_ + (tap - (tap / 3) * 3 - 1));
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int hp = (((wm * MI + mi) * 32 + lr) / AFI_HALO_TX + 1) * HW_ + (lr % AFI_HALO_TX) + 1 + shift;
+                a[mi] = *(const f32x4*)(As + hp * LDK + s * 8 + lh * 4);
+            }
+        } else
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
             a[mi] = *(const f32x4*)(As + ((wm * MI + mi) * 32 + lr) * LDK + s * 8 + lh * 4);
@@ -294,34 +349,34 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     //   k-step and hipcc schedules freely.   Mode 1: fragment reads one k-step ahead (two register sets) and one load per
     //   MFMA group, pinned by sched_barrier.   Measured on MI355X, D1@P2 512->1024 fwd, TFLOP/s at 3 / 1 blocks per CU:
     //   mode 0: 129.7 / 106.2      mode 1: 123.5 / 115.2   -- mode 1 shortens one wave's bubble but slows co-resident waves.
-    auto compute_stage = [&](int buf, bool gather, bool more) {
+    auto compute_stage = [&](int buf, bool gather, bool more, int tap) {
         if constexpr (AFI_GATHER_MODE == 0) {
 #pragma unroll
             for (int s = 0; s < BK / 8; ++s) {
                 f32x4 fa[MI], fb[NI];
-                read_frags(buf, s, fa, fb);
+                read_frags(buf, s, tap, fa, fb);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) mfma_group(fa, fb, j);
                 if (gather && s == AFI_GATHER_AT) {
                     stage_setup(more);
 #pragma unroll
-                    for (int slot = 0; slot < A_LOADS + B_LOADS; ++slot) load_one(slot);
+                    for (int slot = 0; slot < A_SLOTS + B_LOADS; ++slot) load_one(slot);
                 }
             }
         } else {
             f32x4 fa[2][MI], fb[2][NI];
-            read_frags(buf, 0, fa[0], fb[0]);
+            read_frags(buf, 0, tap, fa[0], fb[0]);
 #pragma unroll
             for (int s = 0; s < BK / 8; ++s) {
-                if (s + 1 < BK / 8) read_frags(buf, s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                if (s + 1 < BK / 8) read_frags(buf, s + 1, tap, fa[(s + 1) & 1], fb[(s + 1) & 1]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     mfma_group(fa[s & 1], fb[s & 1], j);
                     if (gather) {
                         const int slot = s * 4 + j - 1;          // slot -1: the scalar address setup of the next stage
                         if (slot == -1) stage_setup(more);
-                        else if (slot < A_LOADS + B_LOADS) load_one(slot);
-                        if (slot < A_LOADS + B_LOADS) __builtin_amdgcn_sched_barrier(0);
+                        else if (slot < A_SLOTS + B_LOADS) load_one(slot);
+                        if (slot < A_SLOTS + B_LOADS) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
@@ -330,33 +385,36 @@ __global__ __launch_bounds__(256) void afi_pix_gemm_kernel(const AfiPixGemm p, i
     auto prefetch = [&]() {                               // prologue form: all loads of the next stage at once
         stage_setup(true);
 #pragma unroll
-        for (int slot = 0; slot < A_LOADS + B_LOADS; ++slot) load_one(slot);
+        for (int slot = 0; slot < A_SLOTS + B_LOADS; ++slot) load_one(slot);
         stage_advance();
     };
 
     if constexpr (NBUF == 2) {
         // Software pipeline, one barrier per stage: while stage kc is multiplied out of LDS buffer kc&1, the registers
         // holding stage kc+1 (loaded during stage kc-1) are written to the other buffer and the gather of stage kc+2 is issued.
+        static_assert(!HALO, "the halo variant is single-buffered");
         prefetch();
-        stage_store(0);
+        stage_store(0, 0);
         if (nK > 1) prefetch();
         __syncthreads();
         for (int kc = 0; kc < nK; ++kc) {
             const int cur = kc & 1;
-            if (kc + 1 < nK) stage_store(cur ^ 1);
+            if (kc + 1 < nK) stage_store(cur ^ 1, 0);
             if (kc + 2 < nK) prefetch();
-            compute_stage(cur, false, false);
+            compute_stage(cur, false, false, 0);
             __syncthreads();
         }
     } else {
         // one LDS buffer: registers -> LDS, barrier, MFMAs of the stage with the next stage's gather issued in their middle
         // (address math and loads overlap the matrix pipe), barrier.
+        int c_tap = kc0 % p.ntaps;                         // tap of the stage about to be multiplied (== of the registers' data)
         prefetch();
         for (int kc = 0; kc < nK; ++kc) {
-            stage_store(0);
+            stage_store(0, c_tap);
             __syncthreads();
-            compute_stage(0, true, kc + 1 < nK);          // no branch: past the last stage every lane reads afi_zeros
+            compute_stage(0, true, kc + 1 < nK, c_tap);   // no branch: past the last stage every lane reads afi_zeros
             stage_advance();
+            if (++c_tap == p.ntaps) c_tap = 0;
             __syncthreads();
         }
     }
@@ -617,17 +675,18 @@ static int afi_env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-template <int BM, int BN, int WM, int WN, bool B_RC, int BK = AFI_BK>
+template <int BM, int BN, int WM, int WN, bool B_RC, int BK = AFI_BK, bool HALO = false>
 static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const long long M = (long long)p.N * p.H * p.W;
-    const int ntm = afi_cdiv(M, BM), ntn = afi_cdiv(p.Ncols, BN);
+    const int ntm = HALO ? p.N * afi_cdiv(p.H, AFI_HALO_TY) * afi_cdiv(p.W, AFI_HALO_TX) : afi_cdiv(M, BM);
+    const int ntn = afi_cdiv(p.Ncols, BN);
     const int ntiles = ntm * ntn;
     const int chunk = afi_cdiv(ntiles, 8);
-    const size_t lds = sizeof(float) * AFI_NBUF * (BM * (BK + 4) + (B_RC ? BK * BN : BN * (BK + 4))) + sizeof(int) * 3 * BM;
+    const size_t lds = sizeof(float) * AFI_NBUF * ((HALO ? AFI_HALO_PIX : BM) * (BK + 4) + (B_RC ? BK * BN : BN * (BK + 4))) + sizeof(int) * 3 * BM;
     const int kind = (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
-        static const hipError_t attr = hipFuncSetAttribute((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK>,
+        static const hipError_t attr = hipFuncSetAttribute((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr != hipSuccess) return AFI_ERR_LAUNCH;
     }
@@ -636,7 +695,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     AfiPixGemm q = p;
     q.splitK = 1;
     const int nK = p.ntaps * p.nKphase * afi_cdiv(p.Ck, BK);
-    if (p.partial && ntiles < 512) {
+    if (!HALO && p.partial && ntiles < 512) {
         int sk = afi_cdiv(1024, ntiles);
         if (sk > nK / 4) sk = nK / 4;
         const long long slab = M * ((p.Ncols + 3) & ~3);
@@ -646,7 +705,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
             q.splitK = afi_cdiv(nK, kper);                // no empty splits
         }
     }
-    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK>), dim3(chunk * 8, q.splitK), dim3(256), lds, st, q, ntn, ntiles, chunk);
+    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO>), dim3(chunk * 8, q.splitK), dim3(256), lds, st, q, ntn, ntiles, chunk);
     if (q.splitK > 1) {
         const long long items = M * (((p.Ncols + 3) & ~3) >> 2);
         long long g = (items + 255) / 256; if (g > 2048) g = 2048;
@@ -666,15 +725,21 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     if (!b_rc && (p.Ck & 3)) return AFI_ERR_UNSUPPORTED;         // KC weight rows are read as float4 along c
     // tile choice: fill the N side first (weights are shared by every block), shrink M tiles for small maps
     const bool smallM = M <= 64 * 256;                           // fewer than 256 128-row tiles: use 64-row tiles
+    // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work
+    static const int halo_on = afi_env_int("AFI_HALO", 1);
+    const long long padded = (long long)p.N * afi_cdiv(p.H, AFI_HALO_TY) * AFI_HALO_TY * afi_cdiv(p.W, AFI_HALO_TX) * AFI_HALO_TX;
+    const bool halo = halo_on && p.ntaps == 9 && p.nKphase == 1 && p.a_up == 1 && !smallM && p.Ncols > 64 && padded * 100 <= M * 112;
     if (!b_rc) {
         if (p.Ncols <= 32) return launch_pix<128, 32, 4, 1, false>(p, st);
         if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, false>(p, st) : launch_pix<128, 64, 2, 2, false>(p, st);
         if (smallM) return launch_pix<64, 64, 2, 2, false>(p, st);
+        if (halo) return launch_pix<128, 128, 2, 2, false, 32, true>(p, st);
         return (bk64 && p.Ck % 64 == 0) ? launch_pix<128, 128, 2, 2, false, 64>(p, st) : launch_pix<128, 128, 2, 2, false>(p, st);
     } else {
         if (p.Ncols <= 32) return launch_pix<128, 32, 4, 1, true>(p, st);
         if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, true>(p, st) : launch_pix<128, 64, 2, 2, true>(p, st);
         if (smallM) return launch_pix<64, 64, 2, 2, true>(p, st);
+        if (halo) return launch_pix<128, 128, 2, 2, true, 32, true>(p, st);
         return (bk64 && p.Ck % 64 == 0) ? launch_pix<128, 128, 2, 2, true, 64>(p, st) : launch_pix<128, 128, 2, 2, true>(p, st);
     }
 }

@@ -76,7 +76,7 @@ struct Fork {
         (void)hipStreamWaitEvent(main, e, 0);
     }
 };
-constexpr long long kSideStreamMaxPixels = 40000;   // above this every GEMM fills the chip on its own
+constexpr long long kSideStreamMaxPixels = 12000;   // above this every GEMM fills the chip on its own (and overlapping kernels only perturb each other)
 }  // namespace
 
 static inline AfiView V(afi_view_t v) { return AfiView{v.p, v.sN, v.sH, v.sW}; }

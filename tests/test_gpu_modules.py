@@ -173,3 +173,48 @@ def test_discriminator_eval_mode_and_buffers(amd):
             assert _rel(sd[k], v) < 1e-3, k
         if "num_batches" in k:
             assert int(sd[k]) == 3
+
+
+def test_discriminator_large_map_halo_path(amd):
+    """A map large enough for the halo-staged conv kernels (18,432 pixels), small channel counts to keep the oracle cheap."""
+    Cin = 64
+    dp = orc.closed_form_discriminator_params(Cin)
+    D = amd.Discriminator(in_filters=Cin).cuda()
+    D.load_state_dict(dp)
+    D.train()
+    x = torch.randn((1, Cin, 72, 256), generator=torch.Generator().manual_seed(9))
+    xg = x.cuda().requires_grad_(True)
+    logits = D(xg)
+    (logits * logits).mean().backward()
+    pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in dp.items()}
+    xr = x.clone().requires_grad_(True)
+    lref, _ = orc.discriminator_forward(xr, pr, training=True)
+    (lref * lref).mean().backward()
+    assert _rel(logits, lref) < 1e-3
+
+    def l2(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return ((a - b).norm() / b.norm()).item()
+    assert l2(xg.grad, xr.grad) < 3e-3
+    for k, p in D.named_parameters():
+        if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3"):
+            continue
+        assert l2(_logical(p.grad), pr[k].grad) < 3e-3, k
+
+
+def test_generator_large_map_halo_path(amd):
+    C, g = 128, 32
+    gp = orc.closed_form_generator_params(C, 2, g)
+    G = amd.Generator(in_channels=C, n_residual_dense_blocks=2, growth_rate=g).cuda()
+    G.load_state_dict(gp)
+    x = torch.randn((1, C, 72, 256), generator=torch.Generator().manual_seed(4))
+    xg = x.cuda().requires_grad_(True)
+    out = G(xg)
+    out.sum().backward()
+    pr = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = orc.generator_forward(xr, pr, n_rdb=2)
+    ref.sum().backward()
+    assert _rel(out, ref) < 1e-3 and _rel(xg.grad, xr.grad) < 1e-3
+    for k, p in G.named_parameters():
+        assert _rel(_logical(p.grad), pr[k].grad) < 1e-3, k

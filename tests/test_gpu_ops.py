@@ -43,6 +43,10 @@ CONV_CASES = [
     (1, 288, 256, 9, 10),     # K tail: 288 = 9 chunks of 32
     (1, 64, 160, 33, 40),     # Cout not a multiple of the N tile
     (3, 36, 12, 6, 5),
+    # large maps: the 8x16-patch HALO variant of the 128x128 kernel (M > 16384 pixels, Cout > 64, patch waste < 12 %)
+    (1, 32, 128, 72, 256),    # exact patch grid
+    (1, 16, 192, 100, 168),   # ragged patch grid (13 x 11 patches), Cout not a multiple of 128
+    (2, 36, 128, 97, 100),    # > 12 % patch waste: stays on the linear-tile kernel
 ]
 
 
