@@ -455,16 +455,17 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
 // weight gradient: both operands are pixel-major, i.e. "RC" for a GEMM whose K runs over pixels
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void afi_wgrad_gemm_kernel(const AfiWgradGemm p, int ntile_m, int ntile_n, int kper) {
+__global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiWgradGemm p, int ntile_m, int ntile_n, int kper) {
     constexpr int BK = AFI_BK;
+    constexpr int NT = 64 * WM * WN;                      // 256 threads (4 waves) or 512 (8 waves: the 256x256 tile)
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
-    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per block");
     static_assert(MI == 1 || MI == 2 || MI == 4, "vector fragment reads");
     static_assert(NI == 1 || NI == 2 || NI == 4, "vector fragment reads");
     constexpr int A_F4 = BM / 4, B_F4 = BN / 4;
-    constexpr int A_LOADS = (BK * A_F4) / 256, B_LOADS = (BK * B_F4) / 256;
+    constexpr int A_LOADS = (BK * A_F4) / NT, B_LOADS = (BK * B_F4) / NT;
     static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small");
-    constexpr int A_RPP = 256 / A_F4, B_RPP = 256 / B_F4;  // k-rows (pixels) covered per load pass
+    constexpr int A_RPP = NT / A_F4, B_RPP = NT / B_F4;    // k-rows (pixels) covered per load pass
     typedef float fragA __attribute__((ext_vector_type(MI)));
     typedef float fragB __attribute__((ext_vector_type(NI)));
 
@@ -753,7 +754,7 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
     int splitK = p.splitK;
     if (splitK <= 0) {
         splitK = 1;
-        const long long want = 1024;
+        const long long want = (WM * WN == 8) ? 512 : 1024;
         if (tiles < want) splitK = (int)((want + tiles - 1) / tiles);
         const int maxsplit = (int)((P + 8 * AFI_BK - 1) / (8 * AFI_BK));
         if (splitK > maxsplit) splitK = maxsplit;
@@ -763,8 +764,13 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
     kper = ((kper + AFI_BK - 1) / AFI_BK) * AFI_BK;
     splitK = (int)((P + kper - 1) / kper);
     const size_t lds = sizeof(float) * AFI_BK * (BM + BN);
-    ProfScope prof(st, BM == 128 ? 8 : (BM == 64 ? 9 : 10), 2.0 * (double)P * p.Mrows * p.Ncols * p.ntaps);
-    hipLaunchKernelGGL((afi_wgrad_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles, splitK), dim3(256), lds, st, p, ntm, ntn, kper);
+    ProfScope prof(st, BM >= 128 ? 8 : (BM == 64 ? 9 : 10), 2.0 * (double)P * p.Mrows * p.Ncols * p.ntaps);
+    if (lds >= 64 * 1024) {
+        static const hipError_t attr = hipFuncSetAttribute((const void*)afi_wgrad_gemm_kernel<BM, BN, WM, WN>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (attr != hipSuccess) return AFI_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL((afi_wgrad_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles, splitK), dim3(64 * WM * WN), lds, st, p, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -775,5 +781,9 @@ int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st) {
     if ((p.Ncols & 3) || (p.dy_up == 2 && (p.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;   // float4 granularity
     if (p.Mrows <= 32) return launch_wgrad<32, 128, 1, 4>(p, st);
     if (p.Mrows <= 64) return launch_wgrad<64, 128, 2, 2>(p, st);
+    // 256x256 tile / 8 waves (AFI_WGRAD256=1): half the global-load and LDS-read instructions per MFMA, but 226 registers ->
+    // one block (2 waves/SIMD) per CU.  Measured on MI355X: 94.7 vs 106.4 TFLOP/s (D1@P2), so it stays off by default.
+    static const int big = afi_env_int("AFI_WGRAD256", 0);
+    if (big && p.Mrows % 256 == 0 && p.Ncols % 256 == 0 && P >= 16384) return launch_wgrad<256, 256, 2, 4>(p, st);
     return launch_wgrad<128, 128, 2, 2>(p, st);
 }

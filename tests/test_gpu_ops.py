@@ -47,6 +47,7 @@ CONV_CASES = [
     (1, 32, 128, 72, 256),    # exact patch grid
     (1, 16, 192, 100, 168),   # ragged patch grid (13 x 11 patches), Cout not a multiple of 128
     (2, 36, 128, 97, 100),    # > 12 % patch waste: stays on the linear-tile kernel
+    (1, 256, 256, 72, 256),   # large map, 256-multiple channels
 ]
 
 
