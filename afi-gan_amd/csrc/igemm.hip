@@ -152,11 +152,13 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
 
-    // XCD-aware tile map: blocks b and b+8 share an XCD; give each XCD a contiguous run of tiles
+    // XCD-aware tile map: blocks b and b+8 share an XCD (its private L2).  Each XCD owns `chunk` consecutive M tiles and
+    // walks them M-FASTEST for one N tile at a time, so the ~96 blocks resident on an XCD stream the SAME weight tile
+    // (L2 hits) while each reads its own activation patch once per channel chunk.  (N-fastest order made every block pull
+    // its 4.7 MB weight panel through the fabric: FETCH_SIZE 54 GB per step for this kernel vs ~6 GB algorithmic.)
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int t = xcd * chunk + jb;
-    if (t >= ntiles) return;
-    const int tile_m = t / ntile_n, tile_n = t - tile_m * ntile_n;
+    const int tile_n = jb / chunk, tile_m = xcd * chunk + (jb - tile_n * chunk);
+    if (tile_n >= ntile_n || tile_m * ntile_n >= ntiles) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W;
     const long long M = (long long)p.N * HW;
@@ -477,7 +479,14 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiW
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
 
-    int t = blockIdx.x;
+    // XCD-aware order (bijective remap): blocks b, b+8, ... share an XCD, so give each XCD a contiguous run of logical ids;
+    // in that run taps are fastest, then ci tiles: the blocks that re-read one dY tile (9 taps x N tiles) and overlapping X
+    // rows sit behind the same L2 instead of pulling 8 copies through the fabric
+    int t;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
     const int tap = t % p.ntaps; t /= p.ntaps;             // taps fastest: the 9 blocks of one (m, n) tile share dY and most of X in L2
     const int tile_n = t % ntile_n; const int tile_m = t / ntile_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
@@ -682,7 +691,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const int ntm = HALO ? p.N * afi_cdiv(p.H, AFI_HALO_TY) * afi_cdiv(p.W, AFI_HALO_TX) : afi_cdiv(M, BM);
     const int ntn = afi_cdiv(p.Ncols, BN);
     const int ntiles = ntm * ntn;
-    const int chunk = afi_cdiv(ntiles, 8);
+    const int chunk = afi_cdiv(ntm, 8);                           // M tiles per XCD; grid = 8 XCDs x chunk x ntn
     const size_t lds = sizeof(float) * AFI_NBUF * ((HALO ? AFI_HALO_PIX : BM) * (BK + 4) + (B_RC ? BK * BN : BN * (BK + 4))) + sizeof(int) * 3 * BM;
     const int kind = (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
@@ -706,7 +715,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
             q.splitK = afi_cdiv(nK, kper);                // no empty splits
         }
     }
-    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO>), dim3(chunk * 8, q.splitK), dim3(256), lds, st, q, ntn, ntiles, chunk);
+    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO>), dim3(chunk * ntn * 8, q.splitK), dim3(256), lds, st, q, ntn, ntiles, chunk);
     if (q.splitK > 1) {
         const long long items = M * (((p.Ncols + 3) & ~3) >> 2);
         long long g = (items + 255) / 256; if (g > 2048) g = 2048;
@@ -725,7 +734,8 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     if (b_rc && (p.Ncols & 3)) return AFI_ERR_UNSUPPORTED;       // RC weight rows are read as float4 along n
     if (!b_rc && (p.Ck & 3)) return AFI_ERR_UNSUPPORTED;         // KC weight rows are read as float4 along c
     // tile choice: fill the N side first (weights are shared by every block), shrink M tiles for small maps
-    const bool smallM = M <= 64 * 256;                           // fewer than 256 128-row tiles: use 64-row tiles
+    static const int small_thr = afi_env_int("AFI_SMALLM", 64 * 256);
+    const bool smallM = M <= small_thr;                          // fewer than 256 128-row tiles: use 64-row tiles
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work
     static const int halo_on = afi_env_int("AFI_HALO", 1);
     const long long padded = (long long)p.N * afi_cdiv(p.H, AFI_HALO_TY) * AFI_HALO_TY * afi_cdiv(p.W, AFI_HALO_TX) * AFI_HALO_TX;

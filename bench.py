@@ -275,8 +275,19 @@ def main():
     dom = kinds[0]
     gemm_ms = sum(r["ms_total"] for r in kinds)
     gemm_flop = sum(r["flop_total"] for r in kinds)
+    # HBM traffic of the dominant kernel cannot be read live (PMC counters need their own rocprofv3 passes): report the
+    # committed measurement of the same command when there is one (profiles/r01/traffic_dominant_kernel.json), else null
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01", "traffic_dominant_kernel.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "source": "profiles/r01/traffic_dominant_kernel.json "
+                       "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; FETCH x2 per the gfx950 correction)"}
+        except (OSError, ValueError, KeyError):
+            traffic = None
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
+                "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
                 "share_of_step_time": dom["ms_total"] / (elapsed * 1e3),
                 "all_gemm_kernels": {"tflops": gemm_flop / (gemm_ms * 1e-3) / 1e12, "frac": gemm_flop / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                      "share_of_step_time": gemm_ms / (elapsed * 1e3)},
