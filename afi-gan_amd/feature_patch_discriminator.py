@@ -71,7 +71,8 @@ class _DiscriminatorFn(torch.autograd.Function):
         N, H, W = ctx.shape
         lib = _lib.load()
         prm, _ = net._param_struct(weights, already_packed=True)
-        grads = [torch.zeros_like(w) for w in weights]
+        need = ctx.needs_input_grad[2:]
+        grads = [torch.zeros_like(w) if n else None for w, n in zip(weights, need)]
         gst, _ = net._param_struct(grads, already_packed=True, grads=True)
         dlogits = dlogits.contiguous()
         dx = ops.new_pixel_major(N, net.F[0], H, W, dlogits.device) if ctx.x_needs_grad else None
@@ -116,6 +117,8 @@ class _PatchDiscriminatorNet(nn.Module):
 
         def nxt(kind):
             t = next(it)
+            if t is None:               # gradient not wanted: NULL pointer, the library skips it
+                return None
             if not already_packed:
                 t = t.detach()
                 t = ops.ohwi(t) if kind == "ohwi" else t.contiguous()

@@ -98,7 +98,10 @@ class _GeneratorFn(torch.autograd.Function):
         lib = _lib.load()
         dout = dout if ops.is_dense_pm(dout) else ops.pixel_major(dout.contiguous())
         prm, _ = gen._param_struct(weights, already_packed=True)
-        grads = [torch.zeros_like(w) for w in weights]          # zeros_like keeps the [O][kh][kw][I] memory layout
+        # only the parameters that require a gradient get one (MODEL.AFI_FREEZE, fpn_sr.py:67-69, freezes them all: the
+        # library then skips every weight-gradient GEMM); zeros_like keeps the [O][kh][kw][I] memory layout
+        need = ctx.needs_input_grad[2:]
+        grads = [torch.zeros_like(w) if n else None for w, n in zip(weights, need)]
         gst, _ = gen._param_struct(grads, already_packed=True)
         dx = ops.new_pixel_major(N, gen.in_channels, H, W, dout.device) if ctx.x_needs_grad else None
         sc_floats = lib.afi_generator_bwd_ws_floats(gen.in_channels, gen.growth_rate, gen.n_residual_dense_blocks, N, H, W)
@@ -154,6 +157,8 @@ class Generator(nn.Module):
 
         def nxt(kind):
             t = next(it)
+            if t is None:               # gradient not wanted: a NULL pointer makes the library skip that weight gradient
+                return None
             if not already_packed:
                 t = t.detach()
                 t = ops.ohwi(t) if kind == "ohwi" else t.contiguous()

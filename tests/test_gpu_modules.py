@@ -218,3 +218,47 @@ def test_generator_large_map_halo_path(amd):
     assert _rel(out, ref) < 1e-3 and _rel(xg.grad, xr.grad) < 1e-3
     for k, p in G.named_parameters():
         assert _rel(_logical(p.grad), pr[k].grad) < 1e-3, k
+
+
+def test_frozen_generator_inside_a_graph(amd):
+    """MODEL.AFI_FREEZE (fpn_sr.py:67-69): every G parameter has requires_grad=False but the input still needs its gradient
+    (stage 3: prev_features come from the trainable FPN).  Also a partially frozen generator."""
+    C, g = 16, 4
+    gp = orc.closed_form_generator_params(C, 3, g)
+    G = amd.Generator(in_channels=C, n_residual_dense_blocks=3, growth_rate=g).cuda()
+    G.load_state_dict(gp)
+    for p in G.parameters():
+        p.requires_grad = False
+    x = torch.randn((2, C, 6, 9), generator=torch.Generator().manual_seed(2))
+    xg = x.cuda().requires_grad_(True)
+    (G(xg * 1.5) ** 2).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    (orc.generator_forward(xr * 1.5, gp) ** 2).sum().backward()
+    assert _rel(xg.grad, xr.grad) < 1e-3
+    assert all(p.grad is None for p in G.parameters())
+    # un-freeze only the last conv
+    w9 = G.Generators[0][4][0].weight
+    w9.requires_grad = True
+    xg.grad = None
+    (G(xg) ** 2).sum().backward()
+    pr = {k: v.clone().requires_grad_(k == "Generators.0.4.0.weight") for k, v in gp.items()}
+    xr2 = x.clone().requires_grad_(True)
+    (orc.generator_forward(xr2, pr) ** 2).sum().backward()
+    assert _rel(_logical(w9.grad), pr["Generators.0.4.0.weight"].grad) < 1e-3
+    assert _rel(xg.grad, xr2.grad) < 1e-3
+    assert sum(p.grad is not None for p in G.parameters()) == 1
+
+
+def test_error_paths(amd):
+    G = amd.Generator(in_channels=16, growth_rate=4).cuda()
+    with pytest.raises(amd.AfiError):
+        G(torch.zeros(1, 8, 4, 4, device="cuda"))                 # wrong channel count
+    with pytest.raises(amd.AfiError):
+        G(torch.zeros(1, 16, 4, 4, device="cuda", dtype=torch.float16))
+    D = amd.Discriminator(in_filters=16).cuda().eval()
+    x = torch.randn(1, 16, 5, 5, device="cuda", requires_grad=True)
+    with pytest.raises(amd.AfiError, match="train-mode"):
+        D(x).sum().backward()                                     # eval-mode backward is not part of the path
+    # degenerate spatial sizes still work (1x1 map -> 2x2)
+    out = G(torch.randn(1, 16, 1, 1, device="cuda"))
+    assert tuple(out.shape) == (1, 16, 2, 2) and torch.isfinite(out).all()
