@@ -62,6 +62,9 @@ SIGNATURES = {
     "afi_conv3x3_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, _i, _vp]),
     "afi_conv3x3_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, View, _vp]),
     "afi_conv3x3_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_conv1x1_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, View, _f, _i, _vp]),
+    "afi_conv1x1_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, _vp]),
+    "afi_conv1x1_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "afi_convT6s2_pack_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_unpack_wgrad": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp]),

@@ -157,6 +157,29 @@ int afi_conv3x3_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout
     return afi_launch_wgrad_gemm(conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha), (hipStream_t)stream);
 }
 
+int afi_conv1x1_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
+                    float beta, afi_view_t r1, float r1_scale, int lrelu, void* stream) {
+    AfiPixGemm g = pix_default(N, H, W);
+    g.ntaps = 1; g.Ck = Cin; g.Ncols = Cout; g.CoutPhase = Cout;
+    g.A = V(x); g.B = w; g.b_sRow = Cin; g.b_sTap = 0;
+    g.O = V(out); g.bias = bias; g.alpha = alpha; g.beta = beta; g.lrelu = lrelu;
+    if (r1.p) { g.R1 = V(r1); g.r1s = r1_scale; g.r1_lo = 0; g.r1_hi = Cout; }
+    return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
+}
+int afi_conv1x1_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
+                      void* stream) {
+    AfiPixGemm g = pix_default(N, H, W);
+    g.ntaps = 1; g.a_sgn = -1; g.Ck = Cout; g.Ncols = Cin; g.CoutPhase = Cin;
+    g.A = V(dy); g.B = w; g.b_sRow = Cin; g.b_sTap = 0;
+    g.O = V(dx); g.alpha = alpha; g.beta = beta;
+    return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
+}
+int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream) {
+    AfiWgradGemm g = conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha);
+    g.ntaps = 1; g.dw_sRow = Cin; g.dw_sTap = 0;
+    return afi_launch_wgrad_gemm(g, (hipStream_t)stream);
+}
+
 int afi_convT6s2_pack_weight(const float* w, float* wp, int Cin, int Cout, void* stream) {
     return afi_launch_convT_pack(w, wp, Cin, Cout, (hipStream_t)stream);
 }

@@ -124,6 +124,48 @@ def conv3x3_wgrad(dy, x, dw=None, alpha=1.0):
     return dw
 
 
+def conv1x1_fwd(x, w, bias=None, add=None, add_scale=1.0, alpha=1.0, out=None):
+    """out = alpha*conv1x1(x, w) + bias + add_scale*add;  w: [Cout, Cin] or [Cout, Cin, 1, 1]."""
+    _check_cuda(x, w, bias, add, out)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    w2 = w.reshape(Cout, Cin).contiguous()
+    if out is None:
+        out = new_pixel_major(N, Cout, H, W, x.device)
+    call("afi_conv1x1_fwd", view_of(x), N, H, W, Cin, _p(w2), _p(bias), Cout, view_of(out), float(alpha), 0.0,
+         view_of(add) if add is not None else _NULL_VIEW, float(add_scale), 0, stream_ptr())
+    return out
+
+
+def conv1x1_dgrad(dy, w, dx=None, alpha=1.0, beta=0.0):
+    _check_cuda(dy, w, dx)
+    N, Cout, H, W = dy.shape
+    Cin = w.shape[1]
+    w2 = w.reshape(Cout, Cin).contiguous()
+    if dx is None:
+        dx = new_pixel_major(N, Cin, H, W, dy.device)
+    call("afi_conv1x1_dgrad", view_of(dy), N, H, W, Cout, _p(w2), Cin, view_of(dx), float(alpha), float(beta), stream_ptr())
+    return dx
+
+
+def conv1x1_wgrad(dy, x, alpha=1.0):
+    _check_cuda(dy, x)
+    N, Cout, H, W = dy.shape
+    Cin = x.shape[1]
+    dw = torch.zeros((Cout, Cin), device=dy.device, dtype=torch.float32)
+    call("afi_conv1x1_wgrad", view_of(dy), view_of(x), N, H, W, Cout, Cin, _p(dw), float(alpha), stream_ptr())
+    return dw
+
+
+def bias_grad(dy):
+    """Column sums of a dense pixel-major gradient: d/d bias of a conv."""
+    assert is_dense_pm(dy)
+    N, C_, H, W = dy.shape
+    db = torch.zeros(C_, device=dy.device, dtype=torch.float32)
+    colsum_accum(dy.permute(0, 2, 3, 1).reshape(-1, C_), db)
+    return db
+
+
 def convT_pack(w_iohw):
     Cin, Cout = w_iohw.shape[:2]
     w_iohw = w_iohw.contiguous()

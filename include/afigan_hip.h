@@ -112,6 +112,14 @@ int afi_conv3x3_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float*
 /* dw[Cout][3][3][Cin] += alpha * sum_pix dy (x) x */
 int afi_conv3x3_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
 
+/* 1x1 convs of the AFI FPN lateral merge (fpn_sr.py:79-81,152-153), w [Cout][Cin]:
+ * out = act(alpha*conv1x1(x, w) + bias + beta*out + r1_scale*r1)   -- r1 = the up-sampled top-down feature (or NULL) */
+int afi_conv1x1_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out,
+                    float alpha, float beta, afi_view_t r1_or_null, float r1_scale, int lrelu, void* stream);
+int afi_conv1x1_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
+                      void* stream);
+int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
+
 /* ConvTranspose2d(k=6,s=2,p=2) (generator_rdb.py:101-105) on the packed weight wp[4*Cout][3][3][Cin] */
 int afi_convT6s2_pack_weight(const float* w_iohw, float* wp, int Cin, int Cout, void* stream);
 int afi_convT6s2_unpack_wgrad(const float* dwp, float* dw_iohw, int Cin, int Cout, void* stream);   /* dw += */

@@ -14,6 +14,10 @@ so exactly those names are provided as stand-in modules in sys.modules (SURVEY.m
   detectron2.layers.get_norm("BN")  -> nn.BatchNorm2d
   detectron2.layers.ShapeSpec, detectron2.utils.registry.Registry -> inert placeholders
   fvcore.nn.weight_init.c2_msra_fill -> kaiming_normal_(fan_out, relu) + zero bias
+For the FPN fixture afigan/modeling/backbone/fpn_sr.py is loaded the same way; its extra module-top
+imports get inert stand-ins too (detectron2 Backbone = nn.Module, BACKBONE_REGISTRY.register = identity,
+build_resnet_backbone / build_resnest_backbone = unused stubs, c2_xavier_fill = kaiming_uniform_(a=1) + zero bias,
+get_norm("") = None) and the already-loaded reference generator is registered under its package name.
 Only arrays (inputs / expected outputs) are written; no reference source or bytecode is copied.
 The stage-1 trainer (stage1_trainer.py) is not importable (deep detectron2 imports), so its
 run_step lines 336-433 are replayed here against the imported Generator / Discriminator.
@@ -81,9 +85,38 @@ def install_shims():
         if m.bias is not None:
             nn.init.constant_(m.bias, 0)
 
+    def get_norm_any(norm, ch):
+        if norm == "":
+            return None
+        assert norm == "BN"
+        return nn.BatchNorm2d(ch)
+
+    def c2_xavier_fill(m):
+        nn.init.kaiming_uniform_(m.weight, a=1)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+    # extra stand-ins needed only by afigan/modeling/backbone/fpn_sr.py (its module-top imports)
+    modeling = types.ModuleType("detectron2.modeling")
+    backbone = types.ModuleType("detectron2.modeling.backbone")
+    bbuild = types.ModuleType("detectron2.modeling.backbone.build")
+    bresnet = types.ModuleType("detectron2.modeling.backbone.resnet")
+
+    class Backbone(nn.Module):
+        pass
+
+    class _Reg:
+        def register(self, obj=None):
+            return obj if obj is not None else (lambda f: f)
+
+    backbone.Backbone = Backbone
+    bbuild.BACKBONE_REGISTRY = _Reg()
+    bresnet.build_resnet_backbone = lambda *a, **k: None
+    d2.modeling, modeling.backbone, backbone.build, backbone.resnet = modeling, backbone, bbuild, bresnet
+    wi.c2_xavier_fill = c2_xavier_fill
     layers.Conv2d = Conv2d
     layers.ConvTranspose2d = nn.ConvTranspose2d
-    layers.get_norm = get_norm
+    layers.get_norm = get_norm_any
     layers.ShapeSpec = ShapeSpec
     registry.Registry = Registry
     wi.c2_msra_fill = c2_msra_fill
@@ -91,7 +124,8 @@ def install_shims():
     fv.nn, fvnn.weight_init = fvnn, wi
     for name, mod in [("detectron2", d2), ("detectron2.layers", layers), ("detectron2.utils", utils),
                       ("detectron2.utils.registry", registry), ("fvcore", fv), ("fvcore.nn", fvnn),
-                      ("fvcore.nn.weight_init", wi)]:
+                      ("fvcore.nn.weight_init", wi), ("detectron2.modeling", modeling), ("detectron2.modeling.backbone", backbone),
+                      ("detectron2.modeling.backbone.build", bbuild), ("detectron2.modeling.backbone.resnet", bresnet)]:
         sys.modules[name] = mod
 
 
@@ -129,6 +163,58 @@ def main():
     install_shims()
     G_rdb = load_ref("afigan/modeling/feat_interpol/generator_rdb.py", "ref_generator_rdb")
     D_mod = load_ref("afigan/modeling/feat_interpol/feature_patch_discriminator.py", "ref_discriminator")
+
+    # ---------------- FPN_AFIGAN (fpn_sr.py): the top-down merge around G, SURVEY 8f row 1 ----------------
+    # fpn_sr.py also imports two modules of the reference's own package; register the already-loaded generator under its
+    # package name and an inert stand-in for the ResNeSt builder (not on this path) so the file loads by path.
+    for name in ("afigan", "afigan.modeling", "afigan.modeling.backbone", "afigan.modeling.feat_interpol"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    resnest = types.ModuleType("afigan.modeling.backbone.resnest")
+    resnest.build_resnest_backbone = lambda *a, **k: None
+    sys.modules["afigan.modeling.backbone.resnest"] = resnest
+    sys.modules["afigan.modeling.feat_interpol.generator_rdb"] = G_rdb
+    sys.modules["afigan.modeling.feat_interpol"].generator_rdb = G_rdb
+    fpn_mod = load_ref("afigan/modeling/backbone/fpn_sr.py", "ref_fpn_sr")
+    Backbone = sys.modules["detectron2.modeling.backbone"].Backbone
+
+    class ShapeSpec_:
+        def __init__(self, channels, stride):
+            self.channels, self.stride = channels, stride
+
+    class BottomUp(Backbone):
+        def output_shape(self):
+            return {f"res{i + 2}": ShapeSpec_(c, s) for i, (c, s) in enumerate(zip([8, 12, 16, 20], [4, 8, 16, 32]))}
+
+        def forward(self, feats):
+            return feats
+
+    class Cfg:
+        class MODEL:
+            AFI_FREEZE = False
+
+    for fuse in ("sum", "avg"):
+        fpn = fpn_mod.FPN_AFIGAN(BottomUp(), ["res2", "res3", "res4", "res5"], 256, norm="", top_block=fpn_mod.LastLevelMaxPool(),
+                                 fuse_type=fuse, cfg=Cfg)
+        sd = {}
+        for k, v in fpn.state_dict().items():
+            if k.startswith("srf_module."):
+                continue
+            sd[k] = orc.closed_form_tensor(k, v.shape, 0.05 if k.endswith("bias") else (6.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5 / 3 ** 0.5)
+        sd.update({"srf_module." + k: v for k, v in orc.closed_form_generator_params().items()})
+        fpn.load_state_dict(sd, strict=True)
+        gen = torch.Generator().manual_seed(31)
+        feats = {f"res{i + 2}": torch.randn((1, c, 2 * 2 ** (3 - i), 3 * 2 ** (3 - i)), generator=gen).requires_grad_(True)
+                 for i, c in enumerate([8, 12, 16, 20])}
+        out = fpn(feats)
+        sum((o * o).mean() for o in out.values()).backward()
+        fx = {"seed": np.array([31])}
+        for k, o in out.items():
+            fx["out/" + k] = o.detach().numpy() if k != "p2" else o.detach()[:, ::4].numpy()
+        for k, f in feats.items():
+            fx["dfeat/" + k] = f.grad.numpy()
+        fx.update(grads_digest({k: p.grad for k, p in fpn.named_parameters()}))
+        np.savez_compressed(os.path.join(HERE, f"fpn_{fuse}.npz"), **fx)
+        print("fpn", fuse, {k: tuple(v.shape) for k, v in out.items()})
 
     # ---------------- G-small: full tensors, reference default init ----------------
     for tag, shape in (("a", (2, 16, 5, 7)), ("b", (1, 16, 7, 11))):

@@ -1,0 +1,113 @@
+"""GPU parity of the AFI feature-pyramid merge (afi-gan_amd/fpn_sr.py) against the CPU oracle's
+restatement of fpn_sr.py:127-165: outputs p2..p6, gradients w.r.t. the bottom-up features, the lateral / output convs
+and the interpolator.  Bar: 1e-3 relative fp32."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afigan_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import afigan_amd
+    assert torch.cuda.is_available()
+    return afigan_amd
+
+
+class _BottomUp(nn.Module):
+    """Stand-in bottom-up network: hands back the feature maps it is given (res2..res5) and reports their shapes."""
+
+    def __init__(self, chans, strides):
+        super().__init__()
+        self.chans, self.strides = chans, strides
+
+    def output_shape(self):
+        from afigan_amd.fpn_sr import ShapeSpec
+        return {f"res{i + 2}": ShapeSpec(c, s) for i, (c, s) in enumerate(zip(self.chans, self.strides))}
+
+    def forward(self, feats):
+        return feats
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("fuse_type", ["sum", "avg"])
+def test_fpn_afigan_matches_oracle(amd, fuse_type):
+    chans, strides, C = [8, 12, 16, 20], [4, 8, 16, 32], 32
+    N, H5, W5 = 2, 2, 3
+    bu = _BottomUp(chans, strides)
+    fpn = amd.FPN_AFIGAN(bu, ["res2", "res3", "res4", "res5"], C, norm="", top_block=amd.LastLevelMaxPool(), fuse_type=fuse_type).cuda()
+    assert set(k.split(".")[0] for k in fpn.state_dict()) == {"srf_module"} | {f"fpn_lateral{s}" for s in (2, 3, 4, 5)} | {f"fpn_output{s}" for s in (2, 3, 4, 5)}
+    assert fpn.size_divisibility == 32 and list(fpn.output_shape()) == ["p2", "p3", "p4", "p5", "p6"]
+    gen = torch.Generator().manual_seed(5)
+    with torch.no_grad():                            # non-trivial biases, generator weights large enough to matter
+        for k, v in fpn.state_dict().items():
+            if k.endswith("bias"):
+                v.copy_(orc.closed_form_tensor(k, v.shape, 0.05))
+        fpn.srf_module.load_state_dict(orc.closed_form_generator_params(C, 3, 32))
+    feats = {f"res{i + 2}": torch.randn((N, c, H5 * 2 ** (3 - i), W5 * 2 ** (3 - i)), generator=gen) for i, c in enumerate(chans)}
+    fg = {k: v.cuda().requires_grad_(True) for k, v in feats.items()}
+    out = fpn(fg)
+    loss = sum((o * o).mean() for o in out.values())
+    loss.backward()
+
+    pr = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in fpn.state_dict().items()}
+    fr = [feats[f"res{i + 2}"].clone().requires_grad_(True) for i in range(4)]
+    ref = orc.fpn_afigan_forward(fr, [2, 3, 4, 5], pr, fuse_type=fuse_type)
+    sum((o * o).mean() for o in ref.values()).backward()
+    assert list(out) == list(ref)
+    for k in ref:
+        assert _rel(out[k], ref[k]) < 1e-3, k
+    for i in range(4):
+        assert _rel(fg[f"res{i + 2}"].grad, fr[i].grad) < 1e-3, i
+    for k, p in fpn.named_parameters():
+        assert p.grad is not None, k
+        assert _rel(p.grad.contiguous(), pr[k].grad) < 1e-3, k
+
+
+def test_fpn_afigan_frozen_interpolator(amd):
+    class Cfg:
+        class MODEL:
+            AFI_FREEZE = True
+    bu = _BottomUp([8, 8], [4, 8])
+    fpn = amd.FPN_AFIGAN(bu, ["res2", "res3"], 32, top_block=None, cfg=Cfg).cuda()
+    assert all(not p.requires_grad for p in fpn.srf_module.parameters())
+    feats = {"res2": torch.randn(1, 8, 8, 12, device="cuda"), "res3": torch.randn(1, 8, 4, 6, device="cuda")}
+    out = fpn(feats)
+    sum(o.sum() for o in out.values()).backward()
+    assert all(p.grad is None for p in fpn.srf_module.parameters())
+    assert fpn.fpn_lateral3.weight.grad is not None and list(out) == ["p2", "p3"]
+
+
+@pytest.mark.parametrize("fuse", ["sum", "avg"])
+def test_fpn_afigan_vs_reference_fixture(amd, golden_dir, fuse):
+    """256-channel FPN merge against the fixture captured from the imported reference FPN_AFIGAN."""
+    import numpy as np
+    from test_oracle_golden import _fpn_params_and_feats
+    fx = dict(np.load(f"{golden_dir}/fpn_{fuse}.npz"))
+    p, feats = _fpn_params_and_feats(fx)
+    bu = _BottomUp([8, 12, 16, 20], [4, 8, 16, 32])
+    fpn = amd.FPN_AFIGAN(bu, ["res2", "res3", "res4", "res5"], 256, top_block=amd.LastLevelMaxPool(), fuse_type=fuse).cuda()
+    assert set(fpn.state_dict()) == set(p)
+    fpn.load_state_dict(p, strict=True)
+    fg = {f"res{i + 2}": f.cuda().requires_grad_(True) for i, f in enumerate(feats)}
+    out = fpn(fg)
+    for k, o in out.items():
+        ref = fx["out/" + k]
+        got = o.detach().cpu().numpy() if k != "p2" else o.detach().cpu()[:, ::4].numpy()
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), k
+    sum((o * o).mean() for o in out.values()).backward()
+    for i in range(4):
+        ref = fx[f"dfeat/res{i + 2}"]
+        assert np.abs(fg[f"res{i + 2}"].grad.cpu().numpy() - ref).max() <= 1e-3 * np.abs(ref).max(), i
+    for k, q in fpn.named_parameters():
+        f = q.grad.detach().contiguous().reshape(-1).double().cpu()
+        rd = fx["gd/" + k]
+        assert abs(f.norm().item() - rd[1]) <= 1e-3 * rd[1] + 1e-12, k
