@@ -142,23 +142,27 @@ const char* afi_status_string(int s) {
 // ------------------------------------------------------------------------------------------------ per-op
 int afi_conv3x3_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
                     float beta, int lrelu, void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;     // float4 granularity of loads and of the epilogue stores
     AfiPixGemm g = conv_fwd_desc(V(x), N, H, W, Cin, w, bias, Cout, V(out));
     g.alpha = alpha; g.beta = beta; g.lrelu = lrelu;
     return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
 }
 int afi_conv3x3_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
                       afi_view_t z, void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = conv_dgrad_desc(V(dy), N, H, W, Cout, w, Cin, V(dx));
     g.alpha = alpha; g.beta = beta;
     if (z.p) { g.Z = V(z); g.z_lo = 0; g.z_hi = Cin; }
     return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
 }
 int afi_conv3x3_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     return afi_launch_wgrad_gemm(conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha), (hipStream_t)stream);
 }
 
 int afi_conv1x1_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
                     float beta, afi_view_t r1, float r1_scale, int lrelu, void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = pix_default(N, H, W);
     g.ntaps = 1; g.Ck = Cin; g.Ncols = Cout; g.CoutPhase = Cout;
     g.A = V(x); g.B = w; g.b_sRow = Cin; g.b_sTap = 0;
@@ -168,6 +172,7 @@ int afi_conv1x1_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, 
 }
 int afi_conv1x1_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
                       void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = pix_default(N, H, W);
     g.ntaps = 1; g.a_sgn = -1; g.Ck = Cout; g.Ncols = Cin; g.CoutPhase = Cin;
     g.A = V(dy); g.B = w; g.b_sRow = Cin; g.b_sTap = 0;
@@ -175,6 +180,7 @@ int afi_conv1x1_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float*
     return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
 }
 int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiWgradGemm g = conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha);
     g.ntaps = 1; g.dw_sRow = Cin; g.dw_sTap = 0;
     return afi_launch_wgrad_gemm(g, (hipStream_t)stream);
@@ -208,19 +214,19 @@ static AfiWgradGemm convT_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W,
 }
 int afi_convT6s2_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* wp, const float* bias, int Cout, afi_view_t out, int lrelu,
                      void* stream) {
-    if (Cout & 3) return AFI_ERR_UNSUPPORTED;
+    if ((Cout & 3) || (Cin & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = convT_fwd_desc(V(x), N, H, W, Cin, wp, bias, Cout, V(out));
     g.lrelu = lrelu;
     return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
 }
 int afi_convT6s2_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* wp, int Cin, afi_view_t dx, afi_view_t z, void* stream) {
-    if (Cout & 3) return AFI_ERR_UNSUPPORTED;
+    if ((Cout & 3) || (Cin & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = convT_dgrad_desc(V(dy), N, H, W, Cout, wp, Cin, V(dx));
     if (z.p) { g.Z = V(z); g.z_lo = 0; g.z_hi = Cin; }
     return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
 }
 int afi_convT6s2_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dwp, float alpha, void* stream) {
-    if (Cout & 3) return AFI_ERR_UNSUPPORTED;
+    if ((Cout & 3) || (Cin & 3)) return AFI_ERR_UNSUPPORTED;
     return afi_launch_wgrad_gemm(convT_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dwp, alpha), (hipStream_t)stream);
 }
 

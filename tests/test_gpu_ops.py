@@ -191,3 +191,35 @@ def test_layout_roundtrip(amd):
     pm = ops.pixel_major(x)
     assert pm.stride(1) == 1 and torch.equal(pm, x)
     assert torch.equal(ops.to_nchw_contiguous(pm), x)
+
+
+def test_unsupported_channel_counts_are_refused(amd):
+    """Channel counts must be multiples of 4 (float4 granularity): refused by the binding's view check or, for raw callers,
+    by AFI_ERR_UNSUPPORTED from the C-ABI -- never silently computed."""
+    import ctypes as C
+    from afigan_amd import _lib
+    ops = amd.ops
+    with pytest.raises(amd.AfiError):
+        ops.conv3x3_fwd(_pm(_rand(1, 6, 5, 5)), _rand(8, 6, 3, 3).cuda())
+    with pytest.raises(amd.AfiError):
+        ops.conv3x3_fwd(_pm(_rand(1, 8, 5, 5)), _rand(6, 8, 3, 3).cuda())
+    with pytest.raises(amd.AfiError):
+        ops.conv1x1_fwd(_pm(_rand(1, 8, 5, 5)), _rand(6, 8).cuda())
+    x, out = _pm(_rand(1, 8, 5, 5)), _pm(_rand(1, 8, 5, 5))
+    w = _rand(6, 8, 3, 3).cuda()
+    st = _lib.load().afi_conv3x3_fwd(ops.view_of(x), 1, 5, 5, 8, C.c_void_p(w.data_ptr()), None, 6, ops.view_of(out), 1.0, 0.0, 0,
+                                    ops.stream_ptr())
+    assert st == 2 and b"unsupported" in _lib.load().afi_status_string(st)
+
+
+def test_conv1x1_fwd_dgrad_wgrad(amd):
+    ops = amd.ops
+    x, w, b = _rand(2, 20, 9, 11, seed=1), _rand(12, 20, 1, 1, seed=2) * 0.2, _rand(12, seed=3)
+    add, dy = _rand(2, 12, 9, 11, seed=4), _rand(2, 12, 9, 11, seed=5)
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xg, wg, b) + add
+    ref.backward(dy)
+    _close(ops.conv1x1_fwd(_pm(x), w.cuda(), b.cuda(), add=_pm(add)), ref, what="1x1 fwd + add")
+    _close(ops.conv1x1_dgrad(_pm(dy), w.cuda().reshape(12, 20)), xg.grad, what="1x1 dgrad")
+    _close(ops.conv1x1_wgrad(_pm(dy), _pm(x)).reshape(12, 20, 1, 1), wg.grad, what="1x1 wgrad")
+    _close(ops.bias_grad(_pm(dy)), dy.sum(dim=(0, 2, 3)), tol=1e-4, what="bias grad")
