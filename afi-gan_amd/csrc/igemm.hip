@@ -28,15 +28,7 @@
 
 #define AFI_BK 32
 #define AFI_LDK (AFI_BK + 4)
-#ifndef AFI_NBUF
-#define AFI_NBUF 1
-#endif
-#ifndef AFI_GATHER_MODE
-#define AFI_GATHER_MODE 0
-#endif
-#ifndef AFI_GATHER_AT
-#define AFI_GATHER_AT 1      // k-step of the stage after which the next stage's gather is issued (mode 0)
-#endif
+
 
 // 16 bytes of zeros: masked lanes of the branch-free gathers read these instead of selecting after the load, so no
 // instruction depends on a global load until the registers are written to LDS a stage later
@@ -143,10 +135,9 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
     constexpr int B_TILE = B_RC ? BK * BN : BN * LDK;     // floats per B stage buffer
     constexpr int STAGE = A_TILE + B_TILE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // NBUF stage buffers; buffer b: A at smem + b*STAGE, B right behind it.  Measured on MI355X (D1@P2, 512->1024):
-    // 1 buffer / 2 barriers per stage / 3 blocks per CU = 130 TFLOP/s;  2 buffers / 1 barrier / 2 blocks per CU = 120.
-    constexpr int NBUF = AFI_NBUF;
-    int* rowtab = (int*)(smem + NBUF * STAGE);            // [3][BM]: img, y, x of each tile row
+    // one stage buffer: A at smem, B right behind it (double-buffering with one barrier per stage was measured slower: it
+    // costs a third of the resident blocks)
+    int* rowtab = (int*)(smem + STAGE);                   // [3][BM]: img, y, x of each tile row
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -283,9 +274,8 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
             }
         }
     };
-    static_assert(AFI_GATHER_MODE == 0 || A_SLOTS + B_LOADS <= BK / 2 - 1, "one load slot per MFMA group");
-    auto stage_store = [&](int buf, int tap_of_regs) {
-        float* As = smem + buf * STAGE;
+    auto stage_store = [&](int tap_of_regs) {
+        float* As = smem;
         float* Bs = As + A_TILE;
         if constexpr (HALO) {
             if (tap_of_regs == 0) {                        // (uniform) the registers hold a fresh halo
@@ -313,8 +303,8 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    auto read_frags = [&](int buf, int s, int tap, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
-        const float* As = smem + buf * STAGE;
+    auto read_frags = [&](int s, int tap, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
+        const float* As = smem;
         const float* Bs = As + A_TILE;
         if constexpr (HALO) {
             // tile row m = 32*blk + lr is patch pixel (m / 16, m % 16); tap (dy, dx) reads halo pixel (+1 + sgn*dy, +1 + sgn*dx)
@@ -346,41 +336,20 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
             for (int ni = 0; ni < NI; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
     };
-    // One stage out of LDS buffer `buf`; with `gather` the next stage's global loads are issued inside it.
-    // AFI_GATHER_MODE 0 (default): the whole gather (scalar setup + A_LOADS+B_LOADS loads) sits between the 2nd and 3rd
-    //   k-step and hipcc schedules freely.   Mode 1: fragment reads one k-step ahead (two register sets) and one load per
-    //   MFMA group, pinned by sched_barrier.   Measured on MI355X, D1@P2 512->1024 fwd, TFLOP/s at 3 / 1 blocks per CU:
-    //   mode 0: 129.7 / 106.2      mode 1: 123.5 / 115.2   -- mode 1 shortens one wave's bubble but slows co-resident waves.
-    auto compute_stage = [&](int buf, bool gather, bool more, int tap) {
-        if constexpr (AFI_GATHER_MODE == 0) {
+    // One stage out of LDS; the next stage's gather (scalar setup + all its loads) is issued between the 2nd and 3rd k-step,
+    // i.e. in the middle of the stage's 64 MFMAs per wave.  (Pinning one load behind every MFMA group with sched_barrier
+    // shortens a lone wave's bubble but was slower at 3 blocks per CU; moving the issue point changes nothing: DESIGN.md.)
+    auto compute_stage = [&](bool more, int tap) {
 #pragma unroll
-            for (int s = 0; s < BK / 8; ++s) {
-                f32x4 fa[MI], fb[NI];
-                read_frags(buf, s, tap, fa, fb);
+        for (int s = 0; s < BK / 8; ++s) {
+            f32x4 fa[MI], fb[NI];
+            read_frags(s, tap, fa, fb);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mfma_group(fa, fb, j);
-                if (gather && s == AFI_GATHER_AT) {
-                    stage_setup(more);
+            for (int j = 0; j < 4; ++j) mfma_group(fa, fb, j);
+            if (s == 1) {
+                stage_setup(more);
 #pragma unroll
-                    for (int slot = 0; slot < A_SLOTS + B_LOADS; ++slot) load_one(slot);
-                }
-            }
-        } else {
-            f32x4 fa[2][MI], fb[2][NI];
-            read_frags(buf, 0, tap, fa[0], fb[0]);
-#pragma unroll
-            for (int s = 0; s < BK / 8; ++s) {
-                if (s + 1 < BK / 8) read_frags(buf, s + 1, tap, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    mfma_group(fa[s & 1], fb[s & 1], j);
-                    if (gather) {
-                        const int slot = s * 4 + j - 1;          // slot -1: the scalar address setup of the next stage
-                        if (slot == -1) stage_setup(more);
-                        else if (slot < A_SLOTS + B_LOADS) load_one(slot);
-                        if (slot < A_SLOTS + B_LOADS) __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+                for (int slot = 0; slot < A_SLOTS + B_LOADS; ++slot) load_one(slot);
             }
         }
     };
@@ -391,41 +360,23 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
         stage_advance();
     };
 
-    if constexpr (NBUF == 2) {
-        // Software pipeline, one barrier per stage: while stage kc is multiplied out of LDS buffer kc&1, the registers
-        // holding stage kc+1 (loaded during stage kc-1) are written to the other buffer and the gather of stage kc+2 is issued.
-        static_assert(!HALO, "the halo variant is single-buffered");
-        prefetch();
-        stage_store(0, 0);
-        if (nK > 1) prefetch();
+    // registers -> LDS, barrier, the stage's MFMAs with the next stage's gather issued in their middle, barrier
+    int c_tap = kc0 % p.ntaps;                             // tap of the stage about to be multiplied (== of the registers' data)
+    prefetch();
+    for (int kc = 0; kc < nK; ++kc) {
+        stage_store(c_tap);
         __syncthreads();
-        for (int kc = 0; kc < nK; ++kc) {
-            const int cur = kc & 1;
-            if (kc + 1 < nK) stage_store(cur ^ 1, 0);
-            if (kc + 2 < nK) prefetch();
-            compute_stage(cur, false, false, 0);
-            __syncthreads();
-        }
-    } else {
-        // one LDS buffer: registers -> LDS, barrier, MFMAs of the stage with the next stage's gather issued in their middle
-        // (address math and loads overlap the matrix pipe), barrier.
-        int c_tap = kc0 % p.ntaps;                         // tap of the stage about to be multiplied (== of the registers' data)
-        prefetch();
-        for (int kc = 0; kc < nK; ++kc) {
-            stage_store(0, c_tap);
-            __syncthreads();
-            compute_stage(0, true, kc + 1 < nK, c_tap);   // no branch: past the last stage every lane reads afi_zeros
-            stage_advance();
-            if (++c_tap == p.ntaps) c_tap = 0;
-            __syncthreads();
-        }
+        compute_stage(kc + 1 < nK, c_tap);                 // no branch: past the last stage every lane reads afi_zeros
+        stage_advance();
+        if (++c_tap == p.ntaps) c_tap = 0;
+        __syncthreads();
     }
 
     // ---- epilogue: accumulators -> LDS (32 tile rows per wave row at a time) -> float4 rows, so every global access of
     //      the epilogue (store, residual / mask / bilinear reads) is a contiguous 16 B per lane, 512 B per 32 lanes ----
     constexpr int LDC = BN + 4;
     constexpr int C_F4 = BN / 4;
-    static_assert(WM * 32 * LDC <= NBUF * STAGE, "C staging tile must fit in the operand tiles");
+    static_assert(WM * 32 * LDC <= STAGE, "C staging tile must fit in the operand tiles");
     float* Cs = smem;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -692,7 +643,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const int ntn = afi_cdiv(p.Ncols, BN);
     const int ntiles = ntm * ntn;
     const int chunk = afi_cdiv(ntm, 8);                           // M tiles per XCD; grid = 8 XCDs x chunk x ntn
-    const size_t lds = sizeof(float) * AFI_NBUF * ((HALO ? AFI_HALO_PIX : BM) * (BK + 4) + (B_RC ? BK * BN : BN * (BK + 4))) + sizeof(int) * 3 * BM;
+    const size_t lds = sizeof(float) * ((HALO ? AFI_HALO_PIX : BM) * (BK + 4) + (B_RC ? BK * BN : BN * (BK + 4))) + sizeof(int) * 3 * BM;
     const int kind = (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
@@ -725,8 +676,6 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
 }
 
 int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
-    // BK = 64 stages for the 128x128 tile are instantiable (AFI_BK64=1) but measured slower on MI355X: 2 blocks/CU, 124 vs 127 TFLOP/s
-    static const int bk64 = afi_env_int("AFI_BK64", 0);
     const AfiPixGemm& p = p_in;
     const long long M = (long long)p.N * p.H * p.W;
     if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
@@ -734,8 +683,7 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     if (b_rc && (p.Ncols & 3)) return AFI_ERR_UNSUPPORTED;       // RC weight rows are read as float4 along n
     if (!b_rc && (p.Ck & 3)) return AFI_ERR_UNSUPPORTED;         // KC weight rows are read as float4 along c
     // tile choice: fill the N side first (weights are shared by every block), shrink M tiles for small maps
-    static const int small_thr = afi_env_int("AFI_SMALLM", 64 * 256);
-    const bool smallM = M <= small_thr;                          // fewer than 256 128-row tiles: use 64-row tiles
+    const bool smallM = M <= 64 * 256;                           // <= 16 K pixels: 64x64 tiles (measured 99 vs 87 TFLOP/s at P4)
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work
     static const int halo_on = afi_env_int("AFI_HALO", 1);
     const long long padded = (long long)p.N * afi_cdiv(p.H, AFI_HALO_TY) * AFI_HALO_TY * afi_cdiv(p.W, AFI_HALO_TX) * AFI_HALO_TX;
@@ -745,13 +693,13 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
         if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, false>(p, st) : launch_pix<128, 64, 2, 2, false>(p, st);
         if (smallM) return launch_pix<64, 64, 2, 2, false>(p, st);
         if (halo) return launch_pix<128, 128, 2, 2, false, 32, true>(p, st);
-        return (bk64 && p.Ck % 64 == 0) ? launch_pix<128, 128, 2, 2, false, 64>(p, st) : launch_pix<128, 128, 2, 2, false>(p, st);
+        return launch_pix<128, 128, 2, 2, false>(p, st);
     } else {
         if (p.Ncols <= 32) return launch_pix<128, 32, 4, 1, true>(p, st);
         if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, true>(p, st) : launch_pix<128, 64, 2, 2, true>(p, st);
         if (smallM) return launch_pix<64, 64, 2, 2, true>(p, st);
         if (halo) return launch_pix<128, 128, 2, 2, true, 32, true>(p, st);
-        return (bk64 && p.Ck % 64 == 0) ? launch_pix<128, 128, 2, 2, true, 64>(p, st) : launch_pix<128, 128, 2, 2, true>(p, st);
+        return launch_pix<128, 128, 2, 2, true>(p, st);
     }
 }
 
@@ -764,7 +712,7 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
     int splitK = p.splitK;
     if (splitK <= 0) {
         splitK = 1;
-        const long long want = (WM * WN == 8) ? 512 : 1024;
+        const long long want = 1024;
         if (tiles < want) splitK = (int)((want + tiles - 1) / tiles);
         const int maxsplit = (int)((P + 8 * AFI_BK - 1) / (8 * AFI_BK));
         if (splitK > maxsplit) splitK = maxsplit;
@@ -791,9 +739,5 @@ int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st) {
     if ((p.Ncols & 3) || (p.dy_up == 2 && (p.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;   // float4 granularity
     if (p.Mrows <= 32) return launch_wgrad<32, 128, 1, 4>(p, st);
     if (p.Mrows <= 64) return launch_wgrad<64, 128, 2, 2>(p, st);
-    // 256x256 tile / 8 waves (AFI_WGRAD256=1): half the global-load and LDS-read instructions per MFMA, but 226 registers ->
-    // one block (2 waves/SIMD) per CU.  Measured on MI355X: 94.7 vs 106.4 TFLOP/s (D1@P2), so it stays off by default.
-    static const int big = afi_env_int("AFI_WGRAD256", 0);
-    if (big && p.Mrows % 256 == 0 && p.Ncols % 256 == 0 && P >= 16384) return launch_wgrad<256, 256, 2, 4>(p, st);
     return launch_wgrad<128, 128, 2, 2>(p, st);
 }
