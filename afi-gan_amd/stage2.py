@@ -1,0 +1,125 @@
+"""Adversarial terms of stage-2 training on MI355X -- SURVEY.md section 8(f) row 2.
+
+The reference's stage-2 step (afigan/engine/stage2_trainer.py:279-384) is a detectron2 detector step plus, per pyramid level,
+  * a D step:   real = F.interpolate(guide_p, scale_factor=0.5) (nearest), fake = the AFI detector's FPN feature, detached
+                (:299-342), with its own optimizer, and
+  * G-side losses added to the detector's loss dict:  g_loss_p = 1e-3 * BCE(D(fake).detach(), 1) + L1(fake, real)  (:344-364),
+    whose L1 gradient flows back into the detector through autograd.
+This module provides exactly those two pieces on the HIP kernels; the detector itself (detectron2 glue) stays where it is.
+The nearest x0.5 down-sampling is a strided VIEW of the guide feature (even rows / columns): the kernels take strides, no copy.
+"""
+import ctypes as C
+from typing import Dict, Sequence
+
+import torch
+
+from . import _lib, ops
+from ._lib import call
+from .feature_patch_discriminator import Discriminator
+from .stage1 import Stage1Step, _FlatOptim, allreduce_sum_, warmup_multistep_lr
+
+
+def nearest_half(x: torch.Tensor) -> torch.Tensor:
+    """F.interpolate(x, scale_factor=0.5) (mode "nearest", stage2_trainer.py:302) as a zero-copy view."""
+    H, W = x.shape[2] // 2, x.shape[3] // 2
+    return x[:, :, 0:2 * H:2, 0:2 * W:2]
+
+
+class _L1CropFn(torch.autograd.Function):
+    """F.l1_loss(a[..., :h, :w], b[..., :h, :w]) over the common extent (stage2_trainer.py:358 with _reshape_feature), one HIP
+    pass producing the loss and d loss / d a."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ap, bp = ops.pixel_major(a.detach()), ops.pixel_major(b.detach())
+        loss = torch.zeros(1, device=a.device, dtype=torch.float32)
+        da = ops.l1_crop(ap, bp, loss, want_grad=a.requires_grad)
+        ctx.save_for_backward(da) if da is not None else None
+        ctx.has = da is not None
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.has:
+            return None, None
+        (da,) = ctx.saved_tensors
+        return da * g, None
+
+
+def l1_loss_common(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _L1CropFn.apply(a, b)
+
+
+class Stage2Adversarial:
+    """D step + generator-side loss terms of one stage-2 iteration for a Discriminator living on this GPU."""
+
+    def __init__(self, D: Discriminator, base_lr: float = 1e-2, momentum: float = 0.9, weight_decay: float = 1e-4,
+                 weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (120000, 160000), lr_gamma: float = 0.1,
+                 warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2, process_group=None):
+        self.D, self.dnet = D, D.Discriminators[0]
+        self.base_lr, self.momentum = base_lr, momentum
+        self.sched = (tuple(lr_steps), lr_gamma, warmup_factor, warmup_iters)
+        self.first_level = first_level
+        self.pg = process_group
+        self.distributed = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+            torch.distributed.get_world_size(process_group) > 1
+        self.world = torch.distributed.get_world_size(process_group) if self.distributed else 1
+        names = {id(p): n for n, p in D.named_parameters()}
+        self.order = self.dnet._ordered_params()
+        self.opt = _FlatOptim([(names[id(p)], p) for p in self.order], weight_decay, weight_decay_norm)
+        self._prm, _ = self.dnet._param_struct(self.order)
+        self._grad, _ = self.dnet._param_struct([p.grad for p in self.order], already_packed=True, grads=True)
+        self._helper = Stage1Step.__new__(Stage1Step)          # reuse the raw D forward/backward plumbing
+        self._helper.dnet, self._helper._dprm, self._helper._dgrad = self.dnet, self._prm, self._grad
+        self._helper._lib, self._helper._buf = _lib.load(), {}
+        self.iter = 0
+        self.losses = None
+        self._names = []
+
+    def d_step(self, guide_feats: Sequence[torch.Tensor], fpn_feats: Sequence[torch.Tensor]):
+        """stage2_trainer.py:306-342: BCE(D(real),1) + BCE(D(fake.detach()),0) over the levels, backward, D optimizer step."""
+        if not self.D.training:
+            raise AssertionError("[Stage2Adversarial] D was changed to eval mode!")
+        h = self._helper
+        dev = fpn_feats[0].device
+        names = [f"d_loss_p{self.first_level + i}" for i in range(len(fpn_feats))]
+        if self.losses is None or self._names != names:
+            self.losses, self._names = torch.zeros(len(names), device=dev), names
+        self.losses.zero_()
+        self.opt.zero_grad()
+        for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
+            real = ops.pixel_major(nearest_half(ops.pixel_major(g.detach())))
+            fake = ops.pixel_major(f.detach())
+            hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
+            for x, target in ((real[:, :, :hh, :ww], 1.0), (fake[:, :, :hh, :ww], 0.0)):
+                logits, dws = h._d_forward(x, "d_ws")
+                dz = h._scratch("dlogits", logits.numel(), dev)
+                call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * hh * ww, target, 1.0,
+                     C.c_void_p(self.losses.data_ptr() + 4 * i), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
+                h._d_backward(x, dws, dz)
+        if self.distributed:
+            allreduce_sum_(self.opt.flat_grad, self.pg)
+        lr = warmup_multistep_lr(self.base_lr, self.iter, *self.sched)
+        self.opt.step(lr, self.momentum, gscale=1.0 / self.world)
+        self.iter += 1
+
+    def g_losses(self, guide_feats: Sequence[torch.Tensor], fpn_feats: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """stage2_trainer.py:344-364: {g_loss_p{lv}: 1e-3 * adv + content}; `content` carries gradient into fpn_feats."""
+        h = self._helper
+        out = {}
+        for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
+            lv = self.first_level + i
+            real = nearest_half(ops.pixel_major(g.detach()))
+            fake = ops.pixel_major(f.detach())
+            hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
+            adv = torch.zeros(1, device=f.device)
+            logits, _ = h._d_forward(fake[:, :, :hh, :ww], "d_ws")                       # fake first, then real (:350-354)
+            call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), f.shape[0] * hh * ww, 1.0, 1.0, C.c_void_p(adv.data_ptr()),
+                 0.0, C.c_void_p(None), ops.stream_ptr())
+            h._d_forward(real[:, :, :hh, :ww], "d_ws")                                   # only its BN side effects matter (Q2)
+            content = l1_loss_common(f, real)
+            out[f"g_loss_p{lv}"] = adv.reshape(()) * 1e-3 + content
+        return out
+
+    def d_metrics(self) -> Dict[str, float]:
+        return dict(zip(self._names, self.losses.detach().cpu().tolist()))

@@ -382,6 +382,56 @@ def main():
     np.savez_compressed(os.path.join(HERE, "stage1_step.npz"), **fx)
     print("stage1 step", {k: v.item() for k, v in d_loss.items()}, {k: v.item() for k, v in g_loss.items()})
 
+    # ---------------- stage-2 adversarial terms replay: stage2_trainer.py:299-364 ----------------
+    D = D_mod.Discriminator()
+    D.load_state_dict(orc.closed_form_discriminator_params(), strict=True)
+    D.train()
+    gen = torch.Generator().manual_seed(41)
+    guide = [torch.randn((2, 256, 26, 42), generator=gen), torch.randn((2, 256, 13, 21), generator=gen)]     # hr_feature_ p-levels
+    fpn = [torch.randn((2, 256, 13, 21), generator=gen).requires_grad_(True),                                # upsampled_feature_ p-levels
+           torch.randn((2, 256, 7, 11), generator=gen).requires_grad_(True)]
+    D_opt = make_opt(D.Discriminators[0])
+
+    def reshape_feature(t, size):      # stage2_trainer.py _reshape_feature == stage-1's crop
+        return reshape_stage1(t, size)
+
+    hr_features = [F.interpolate(g, scale_factor=0.5) for g in guide]                                        # :302
+    fx = {"seed": np.array([41]), "lr": np.array([base_lr]), "wd": np.array([wd]), "mom": np.array([mom])}
+    d_loss = {}
+    for p_lv, (hr_f, up_f) in enumerate(zip(hr_features, fpn), 2):
+        hr = reshape_feature(hr_f, up_f.size())
+        up = reshape_feature(up_f, hr.size())
+        logit_real = D.Discriminators[0](hr)
+        logit_fake = D.Discriminators[0](up.detach())
+        d_loss[f"d_loss_p{p_lv}"] = crit(logit_real, torch.ones(logit_real.size())) + crit(logit_fake, torch.zeros(logit_fake.size()))
+        fx[f"crop_p{p_lv}"] = np.array(list(up.shape))
+    D_opt.zero_grad()
+    sum(d_loss.values()).backward()
+    fx.update({k: np.array([v.item()]) for k, v in d_loss.items()})
+    fx.update({"D" + k: v for k, v in grads_digest({k: p.grad for k, p in D.named_parameters()}).items()})
+    D_opt.step()
+    fx.update({"Dw_after/" + k: tensor_digest(p)[0] for k, p in D.named_parameters()})
+    g_loss = {}
+    for p_lv, (hr_f, up_f) in enumerate(zip(hr_features, fpn), 2):
+        hr = reshape_feature(hr_f, up_f.size())
+        up = reshape_feature(up_f, hr.size())
+        logit_fake = D.Discriminators[0](up).detach()
+        logit_real = D.Discriminators[0](hr)
+        adv = crit(logit_fake, torch.ones(logit_real.size()))
+        content = F.l1_loss(up, hr)
+        g_loss[f"g_loss_p{p_lv}"] = adv * 1e-3 + content
+        fx[f"adv_loss_p{p_lv}"] = np.array([adv.item()])
+        fx[f"content_loss_p{p_lv}"] = np.array([content.item()])
+    sum(g_loss.values()).backward()
+    fx.update({k: np.array([v.item()]) for k, v in g_loss.items()})
+    for i, f in enumerate(fpn):
+        fx[f"dfpn_{i}"] = f.grad.numpy()[:, ::8]
+    for k, v in D.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            fx["Dbuf_after/" + k] = v.numpy()
+    np.savez_compressed(os.path.join(HERE, "stage2_adv.npz"), **fx)
+    print("stage2 adv", {k: v.item() for k, v in d_loss.items()}, {k: v.item() for k, v in g_loss.items()})
+
 
 if __name__ == "__main__":
     main()
