@@ -97,8 +97,18 @@ __global__ __launch_bounds__(256) void afi_pix_splitk_epilogue_kernel(const AfiP
     for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
         const long long m = it / C_F4;
         const int col = (int)(it - m * C_F4) * 4;
+        // fixed summation order ks = 0, 1, 2, ... (bit-reproducible); the loads of four slabs are issued together so the
+        // (latency-bound) pass does not serialise one L2 round trip per slab
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < p.splitK; ++ks) v += *(const f32x4*)(p.partial + ((long long)ks * M + m) * ldp + col);
+        const float* src = p.partial + m * ldp + col;
+        const long long slab = M * ldp;
+        int ks = 0;
+        for (; ks + 4 <= p.splitK; ks += 4) {
+            const f32x4 t0 = *(const f32x4*)(src + (ks + 0) * slab), t1 = *(const f32x4*)(src + (ks + 1) * slab);
+            const f32x4 t2 = *(const f32x4*)(src + (ks + 2) * slab), t3 = *(const f32x4*)(src + (ks + 3) * slab);
+            v += t0; v += t1; v += t2; v += t3;
+        }
+        for (; ks < p.splitK; ++ks) v += *(const f32x4*)(src + ks * slab);
         const int img = (int)(m / HW);
         const int rem = (int)(m - (long long)img * HW);
         const int y = rem / p.W, x = rem - y * p.W;
