@@ -752,5 +752,7 @@ int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st) {
     if ((p.Ncols & 3) || (p.dy_up == 2 && (p.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;   // float4 granularity
     if (p.Mrows <= 32) return launch_wgrad<32, 128, 1, 4>(p, st);
     if (p.Mrows <= 64) return launch_wgrad<64, 128, 2, 2>(p, st);
-    return launch_wgrad<128, 128, 2, 2>(p, st);
+    // 4 waves side by side (each 128 rows x 32 columns): the dY fragment is one un-fusable ds_read_b128 per k-row; with the
+    // 2x2 layout hipcc fuses pairs of ds_read_b64 into ds_read2st64_b64, which runs at half the LDS rate (107.9 vs 106.9 TFLOP/s)
+    return launch_wgrad<128, 128, 1, 4>(p, st);
 }
