@@ -65,6 +65,10 @@ SIGNATURES = {
     "afi_conv1x1_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, View, _f, _i, _vp]),
     "afi_conv1x1_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, _vp]),
     "afi_conv1x1_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_conv3x3s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, View, _f, View, _f, _vp]),
+    "afi_conv3x3s2_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, _vp]),
+    "afi_conv3x3s2_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_relu_bwd": (_i, [_vp, _vp, _vp, _ll, _f, _vp]),
     "afi_convT6s2_pack_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_unpack_wgrad": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp]),

@@ -36,6 +36,10 @@ struct AfiPixGemm {
     AfiView A;
     int a_sgn;          // +1 forward, -1 dgrad
     int a_up;           // 1, or 2 for convT dgrad (A is [N, 2H, 2W])
+    // generic-tap form (gtap = 1; stride-2 conv forward and the four parity phases of its dgrad): tap t reads grid position
+    // (y*a_stride + tap_dy[t], x*a_stride + tap_dx[t]), valid inside [0, aH) x [0, aW), with weight tap tap_w[t]
+    int gtap, a_stride, aH, aW;
+    signed char tap_dy[12], tap_dx[12], tap_w[12];
     // B (weights).  KC form (b_rc = 0): row n at  B + n*b_sRow + tap*b_sTap + c           (k contiguous)
     //               RC form (b_rc = 1): row k at  B + (kphase*Ck + c)*b_sRow + tap*b_sTap + n  (n contiguous)
     const float* B;
@@ -44,12 +48,15 @@ struct AfiPixGemm {
     // pixel (y*o_up + (phase>>1), x*o_up + (phase&1))
     AfiView O;
     int o_up;           // 1, or 2 for convT forward (O is [N, 2H, 2W])
+    int oH, oW;         // rows whose output pixel falls outside [0, oH) x [0, oW) are not stored (odd sizes in the stride-2 dgrad)
     int CoutPhase;      // == Ncols when o_up == 1
     // epilogue: v = alpha*acc + bias[ch] + beta*O_old + r1s*R1 + r2s*R2 ; lrelu ; * lrelu'(Z)
+    //   with r2_post: v = post_scale * act(alpha*acc + bias + ...) [-> O2 if set] + r2s*R2   (PAFPN: inter + relu(conv))
     float alpha, beta;
     const float* bias;  // indexed by channel (col % CoutPhase); may be null
     AfiView R1; float r1s; int r1_lo, r1_hi;   // applied for channels in [r1_lo, r1_hi); null p = off
     AfiView R2; float r2s; int r2_lo, r2_hi;
+    int r2_post; float post_scale; int pad0_; AfiView O2;
     int r1_bilinear;    // R1 is a low-res [N, H/2, W/2] tensor, added as its bilinear x2 up-sampling
     int lrelu;          // activation on v: 0 none, 1 LeakyReLU(0.2), 2 ReLU
     AfiView Z; int z_lo, z_hi;                 // multiply by (Z > 0 ? 1 : 0.2) for channels in [z_lo, z_hi)
@@ -64,7 +71,8 @@ struct AfiWgradGemm {
     int Mrows;          // co' count (4*Cout for convT)
     int Ncols;          // ci count
     AfiView DY; int dy_up; int CoutPhase;      // dY gather (pixel-shuffled when dy_up == 2)
-    AfiView X;                                  // input activations, gathered at (y+dy, x+dx)
+    AfiView X;                                  // input activations, gathered at (y*x_stride+dy, x*x_stride+dx) inside [0,xH) x [0,xW)
+    int x_stride, xH, xW;
     float* DW; long long dw_sRow, dw_sTap;      // dW + co'*dw_sRow + tap*dw_sTap + ci
     float alpha;
     int splitK;

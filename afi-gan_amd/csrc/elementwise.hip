@@ -469,6 +469,22 @@ int afi_launch_scale(float* p, long long n, float s, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
+// out = scale * g * (act > 0): gradient through an (in-place) ReLU whose OUTPUT was kept (pafpn_sr.py:178)
+__global__ void afi_relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ act, float* __restrict__ out, long long n4, float s) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        const f32x4 gv = ((const f32x4*)g)[i], av = ((const f32x4*)act)[i];
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = av[j] > 0.f ? s * gv[j] : 0.f;
+        ((f32x4*)out)[i] = o;
+    }
+}
+int afi_launch_relu_bwd(const float* g, const float* act, float* out, long long n, float s, hipStream_t st) {
+    if (n <= 0 || (n & 3)) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_relu_bwd_kernel, dim3(afi_ew_grid(n >> 2)), dim3(256), 0, st, g, act, out, n >> 2, s);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // ---------------------------------------------------------------- small helpers
 // *out += alpha * sum(v[0..n))
 __global__ __launch_bounds__(256) void afi_sum_accum_kernel(const float* __restrict__ v, long long n, float alpha, float* __restrict__ out) {

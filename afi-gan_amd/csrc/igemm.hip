@@ -47,10 +47,13 @@ __device__ __forceinline__ void afi_bil_idx(int o, int L, int& i0, int& i1, floa
 
 // Fused epilogue of one float4 of accumulators (4 consecutive output columns of one GEMM row):
 //   v = alpha*acc + bias + beta*O_old + r1s*R1 (direct or bilinear x2) + r2s*R2 ; activation ; * lrelu'(Z) ; (pixel-shuffle) store
+// POST (generic-tap kernels only): the post-activation form  out = post_scale * act(...) + r2s * R2, act(...) -> O2
+template <bool POST = false>
 __device__ __forceinline__ void afi_epilogue_store(const AfiPixGemm& p, int img, int y, int x, int col, f32x4 accv) {
     int phase = 0, ch = col;
     if (p.o_up == 2) { phase = col / p.CoutPhase; ch = col - phase * p.CoutPhase; }
     const int yo = y * p.o_up + (phase >> 1), xo = x * p.o_up + (phase & 1);
+    if (yo >= p.oH || xo >= p.oW) return;
     float* dst = p.O.p + (long long)img * p.O.sN + (long long)yo * p.O.sH + (long long)xo * p.O.sW + ch;
     f32x4 v = p.alpha * accv;
     if (p.bias) v += *(const f32x4*)(p.bias + ch);
@@ -71,7 +74,7 @@ __device__ __forceinline__ void afi_epilogue_store(const AfiPixGemm& p, int img,
             v += p.r1s * *(const f32x4*)(p.R1.p + (long long)img * p.R1.sN + (long long)yo * p.R1.sH + (long long)xo * p.R1.sW + ch);
         }
     }
-    if (p.R2.p && ch >= p.r2_lo && ch < p.r2_hi)
+    if ((!POST || !p.r2_post) && p.R2.p && ch >= p.r2_lo && ch < p.r2_hi)
         v += p.r2s * *(const f32x4*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch);
     if (p.lrelu) {
         const float slope = (p.lrelu == 1) ? AFI_LRELU_SLOPE : 0.f;
@@ -83,11 +86,17 @@ __device__ __forceinline__ void afi_epilogue_store(const AfiPixGemm& p, int img,
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= (z[j] > 0.f ? 1.f : AFI_LRELU_SLOPE);
     }
+    if (POST && p.r2_post) {                              // out = post_scale * act(...) + r2s * R2; the activated value goes to O2
+        if (p.O2.p) *(f32x4*)(p.O2.p + (long long)img * p.O2.sN + (long long)yo * p.O2.sH + (long long)xo * p.O2.sW + ch) = v;
+        v *= p.post_scale;
+        if (p.R2.p) v += p.r2s * *(const f32x4*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch);
+    }
     *(f32x4*)dst = v;
 }
 
 // Second pass of the split-K form (small maps: too few tiles to fill 256 CUs): sum the per-split partial slabs in a FIXED
 // order (bit-reproducible, no atomics, no memset) and apply the fused epilogue.  partial: [splitK][M][ldp].
+template <bool POST>
 __global__ __launch_bounds__(256) void afi_pix_splitk_epilogue_kernel(const AfiPixGemm p) {
     const int HW = p.H * p.W;
     const long long M = (long long)p.N * HW;
@@ -112,7 +121,7 @@ __global__ __launch_bounds__(256) void afi_pix_splitk_epilogue_kernel(const AfiP
         const int img = (int)(m / HW);
         const int rem = (int)(m - (long long)img * HW);
         const int y = rem / p.W, x = rem - y * p.W;
-        afi_epilogue_store(p, img, y, x, col, v);
+        afi_epilogue_store<POST>(p, img, y, x, col, v);
     }
 }
 
@@ -123,22 +132,24 @@ __global__ __launch_bounds__(256) void afi_pix_splitk_epilogue_kernel(const AfiP
 #define AFI_HALO_TY 8
 #define AFI_HALO_TX 16
 #define AFI_HALO_PIX ((AFI_HALO_TY + 2) * (AFI_HALO_TX + 2))
-template <int BM, int BN, int WM, int WN, bool B_RC, int BK, bool HALO = false>
-__global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p, int ntile_n, int ntiles, int chunk) {
+template <int BM, int BN, int WM, int WN, bool B_RC, int BK, bool HALO = false, bool GTAP = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_gemm_kernel(const AfiPixGemm p, int ntile_n, int ntiles, int chunk) {
     constexpr int LDK = BK + 4;                           // K-contiguous LDS rows: +16 B pad -> conflict-free ds_read_b128
     static_assert(!HALO || (BM == AFI_HALO_TY * AFI_HALO_TX && BK == 32), "halo variant: 8x16 patch, 32-channel chunks");
-    constexpr int H_LOADS = (AFI_HALO_PIX * (BK / 4) + 255) / 256;   // float4 loads per thread per halo (6)
+    static_assert(!(HALO && GTAP), "the halo variant is the plain stride-1 3x3 gather");
+    constexpr int NT = 64 * WM * WN;                      // 256 threads (4 waves) or 512 (8 waves)
+    constexpr int H_LOADS = (AFI_HALO_PIX * (BK / 4) + NT - 1) / NT;   // float4 loads per thread per halo (6)
     constexpr int HW_ = AFI_HALO_TX + 2;                  // halo row pitch in pixels
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
-    static_assert(WM * WN == 4, "4 waves per block");
+    static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 waves per block");
     static_assert(MI >= 1 && NI >= 1, "tile too small for the wave layout");
     constexpr int K_F4 = BK / 4;                          // KC: float4 per row of a stage
-    constexpr int K_RPP = 256 / K_F4;                     // KC: rows covered per load pass
+    constexpr int K_RPP = NT / K_F4;                      // KC: rows covered per load pass
     constexpr int A_LOADS = BM / K_RPP;                   // float4 loads per thread per stage (A, KC)
     constexpr int B_F4 = BN / 4;                          // RC: float4 per k-row
-    constexpr int B_LOADS = B_RC ? (BK * B_F4) / 256 : BN / K_RPP;
+    constexpr int B_LOADS = B_RC ? (BK * B_F4) / NT : BN / K_RPP;
     static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small");
-    constexpr int B_ROWS_PER_PASS = 256 / B_F4;           // RC
+    constexpr int B_ROWS_PER_PASS = NT / B_F4;            // RC
 
     constexpr int A_SLOTS = HALO ? H_LOADS : A_LOADS;     // A-side load slots (registers) per thread
     constexpr int A_TILE = (HALO ? AFI_HALO_PIX : BM) * LDK;   // floats per A stage buffer
@@ -205,7 +216,12 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
         const int img = rowtab[r], y = rowtab[BM + r], x = rowtab[2 * BM + r];
         unsigned m = 0;
         if (img >= 0) {
-            if (p.ntaps == 9) {
+            if constexpr (GTAP) {
+                for (int t = 0; t < p.ntaps; ++t) {
+                    const int yy = y * p.a_stride + p.tap_dy[t], xx = x * p.a_stride + p.tap_dx[t];
+                    if ((unsigned)yy < (unsigned)p.aH && (unsigned)xx < (unsigned)p.aW) m |= 1u << t;
+                }
+            } else if (p.ntaps == 9) {
 #pragma unroll
                 for (int t9 = 0; t9 < 9; ++t9) {
                     const int yy = y + p.a_sgn * (t9 / 3 - 1), xx = x + p.a_sgn * (t9 % 3 - 1);
@@ -216,7 +232,8 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
             }
         }
         a_mask[i] = m;
-        a_off[i] = (long long)(img < 0 ? 0 : img) * p.A.sN + (long long)(y * p.a_up) * p.A.sH + (long long)(x * p.a_up) * p.A.sW + 4 * aq;
+        const int cm = GTAP ? p.a_up * p.a_stride : p.a_up;   // coordinate multiplier
+        a_off[i] = (long long)(img < 0 ? 0 : img) * p.A.sN + (long long)(y * cm) * p.A.sH + (long long)(x * cm) * p.A.sW + 4 * aq;
     }
     const int Ck4 = (p.Ck + 3) & ~3;
     const int cchunks = (p.Ck + BK - 1) / BK;
@@ -236,10 +253,11 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
     // a wave issues in order, so a monolithic block of address arithmetic would leave the matrix pipe idle behind it,
     // whereas ~10 VALU instructions + 1 load fit in the 256-cycle shadow of each group of four 32x32x2 MFMAs.
     int k_tap = kc0 % p.ntaps, k_kph = (kc0 / p.ntaps) % p.nKphase, k_c0 = (kc0 / (p.ntaps * p.nKphase)) * BK;   // NEXT stage to gather
-    long long k_delta = 0; bool k_cok = false; bool k_more = true;
+    long long k_delta = 0; bool k_cok = false; bool k_more = true; int k_wtap = k_tap;
     auto stage_setup = [&](bool more) {                  // scalar per-stage part of the addresses
         int dy = 0, dx = 0;
-        if (p.ntaps == 9) { dy = k_tap / 3 - 1; dx = k_tap - (k_tap / 3) * 3 - 1; }
+        if constexpr (GTAP) { dy = p.tap_dy[k_tap]; dx = p.tap_dx[k_tap]; k_wtap = p.tap_w[k_tap]; }   // table offsets are final (the launcher requires a_sgn == +1)
+        else { if (p.ntaps == 9) { dy = k_tap / 3 - 1; dx = k_tap - (k_tap / 3) * 3 - 1; } k_wtap = k_tap; }
         k_delta = (long long)(dy * p.a_sgn * p.a_up + (k_kph >> 1)) * p.A.sH + (long long)(dx * p.a_sgn * p.a_up + (k_kph & 1)) * p.A.sW + k_c0;
         k_cok = more && (k_c0 + 4 * aq) < Ck4;
         k_more = more;
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
             if constexpr (HALO) {
                 if (k_tap == 0) {                          // (uniform) a new channel chunk starts: fetch its halo once
                     // halo pixel hp = (tid + 256 i) / 8 of the 10x18 halo, float4 column aq (256 % 8 == 0)
-                    const int hp = (tid + 256 * i) / K_F4;
+                    const int hp = (tid + NT * i) / K_F4;
                     const int y = patch_y0 - 1 + hp / HW_, x = patch_x0 - 1 + hp % HW_;
                     const bool ok = k_cok && hp < AFI_HALO_PIX && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
                     const float* src = ok ? p.A.p + ((long long)patch_img * p.A.sN + (long long)y * p.A.sH + (long long)x * p.A.sW + 4 * aq + k_c0)
@@ -273,13 +291,13 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
             if constexpr (!B_RC) {
                 const int n = n0 + ar + K_RPP * i;
                 const bool ok = k_cok && n < p.Ncols;
-                const float* src = ok ? p.B + ((long long)n * p.b_sRow + (long long)k_tap * p.b_sTap + k_c0 + 4 * aq) : afi_zeros;
+                const float* src = ok ? p.B + ((long long)n * p.b_sRow + (long long)k_wtap * p.b_sTap + k_c0 + 4 * aq) : afi_zeros;
                 b_reg[i] = *(const f32x4*)src;
             } else {
                 const int c = k_c0 + b_kr + B_ROWS_PER_PASS * i;
                 const int n = n0 + 4 * b_cq;
                 const bool ok = k_more && c < p.Ck && n < p.Ncols;
-                const float* src = ok ? p.B + ((long long)(k_kph * p.Ck + c) * p.b_sRow + (long long)k_tap * p.b_sTap + n) : afi_zeros;
+                const float* src = ok ? p.B + ((long long)(k_kph * p.Ck + c) * p.b_sRow + (long long)k_wtap * p.b_sTap + n) : afi_zeros;
                 b_reg[i] = *(const f32x4*)src;
             }
         }
@@ -291,7 +309,7 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
             if (tap_of_regs == 0) {                        // (uniform) the registers hold a fresh halo
 #pragma unroll
                 for (int i = 0; i < H_LOADS; ++i)
-                    if (tid + 256 * i < AFI_HALO_PIX * K_F4) *(f32x4*)(As + ((tid + 256 * i) / K_F4) * LDK + 4 * aq) = a_reg[i];
+                    if (tid + NT * i < AFI_HALO_PIX * K_F4) *(f32x4*)(As + ((tid + NT * i) / K_F4) * LDK + 4 * aq) = a_reg[i];
             }
         } else
 #pragma unroll
@@ -399,7 +417,7 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
             for (int r = 0; r < 16; ++r)
                 Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + (wn * NI + ni) * 32 + lr] = acc[mi][ni][r];
         __syncthreads();
-        for (int item = tid; item < WM * 32 * C_F4; item += 256) {
+        for (int item = tid; item < WM * 32 * C_F4; item += NT) {
             const int rloc = item / C_F4, c4 = item - rloc * C_F4;
             const int rl = ((rloc >> 5) * MI + mi) * 32 + (rloc & 31);
             const int img = rowtab[rl];
@@ -410,7 +428,7 @@ __global__ __launch_bounds__(256, 3) void afi_pix_gemm_kernel(const AfiPixGemm p
                 const int ldp = (p.Ncols + 3) & ~3;
                 *(f32x4*)(p.partial + ((long long)blockIdx.y * M + (m0 + rl)) * ldp + col) = accv;
             } else {
-                afi_epilogue_store(p, img, rowtab[BM + rl], rowtab[2 * BM + rl], col, accv);
+                afi_epilogue_store<GTAP>(p, img, rowtab[BM + rl], rowtab[2 * BM + rl], col, accv);
             }
         }
         if (mi + 1 < MI) __syncthreads();
@@ -477,7 +495,8 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiW
     const long long a_eH = (long long)p.dy_up * p.DY.sH, a_eW = (long long)p.dy_up * p.DY.sW;
     const int adv_y = BK / p.W, adv_x = BK - adv_y * p.W;
     const long long a_adv = adv_y * a_eH + adv_x * a_eW, a_wrapx = a_eH - p.W * a_eW, a_wrapy = p.DY.sN - p.H * a_eH;
-    const long long b_adv = adv_y * p.X.sH + adv_x * p.X.sW, b_wrapx = p.X.sH - p.W * p.X.sW, b_wrapy = p.X.sN - p.H * p.X.sH;
+    const long long b_eH = (long long)p.x_stride * p.X.sH, b_eW = (long long)p.x_stride * p.X.sW;   // stride-2 conv: X is [N, xH, xW]
+    const long long b_adv = adv_y * b_eH + adv_x * b_eW, b_wrapx = b_eH - p.W * b_eW, b_wrapy = p.X.sN - p.H * b_eH;
 
     long long a_off[A_LOADS], b_off[B_LOADS];
     int ay[A_LOADS], ax[A_LOADS], by[B_LOADS], bx[B_LOADS];
@@ -493,7 +512,7 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiW
         const long long pix = k_begin + b_kr + B_RPP * i;
         const int n = (int)(pix / HW); const int rem = (int)(pix - (long long)n * HW);
         by[i] = rem / p.W; bx[i] = rem - by[i] * p.W;
-        b_off[i] = (long long)n * p.X.sN + (long long)(by[i] + dy) * p.X.sH + (long long)(bx[i] + dx) * p.X.sW + b_col;
+        b_off[i] = (long long)n * p.X.sN + by[i] * b_eH + dy * p.X.sH + bx[i] * b_eW + dx * p.X.sW + b_col;
     }
     long long k_pix = k_begin;                             // first pixel of the NEXT stage to gather
 
@@ -510,8 +529,8 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiW
         }
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i) {
-            const int yy = by[i] + dy, xx = bx[i] + dx;
-            const bool ok = more && b_col_ok && (k_pix + b_kr + B_RPP * i < k_end) && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            const int yy = by[i] * p.x_stride + dy, xx = bx[i] * p.x_stride + dx;
+            const bool ok = more && b_col_ok && (k_pix + b_kr + B_RPP * i < k_end) && (unsigned)yy < (unsigned)p.xH && (unsigned)xx < (unsigned)p.xW;
             const float* src = ok ? p.X.p + b_off[i] : afi_zeros;
             b_reg[i] = *(const f32x4*)src;
             bx[i] += adv_x; by[i] += adv_y; b_off[i] += b_adv;
@@ -649,7 +668,7 @@ static int afi_env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-template <int BM, int BN, int WM, int WN, bool B_RC, int BK = AFI_BK, bool HALO = false>
+template <int BM, int BN, int WM, int WN, bool B_RC, int BK = AFI_BK, bool HALO = false, bool GTAP = false>
 static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const long long M = (long long)p.N * p.H * p.W;
     const int ntm = HALO ? p.N * afi_cdiv(p.H, AFI_HALO_TY) * afi_cdiv(p.W, AFI_HALO_TX) : afi_cdiv(M, BM);
@@ -660,7 +679,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const int kind = (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
-        static const hipError_t attr = hipFuncSetAttribute((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO>,
+        static const hipError_t attr = hipFuncSetAttribute((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO, GTAP>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (attr != hipSuccess) return AFI_ERR_LAUNCH;
     }
@@ -679,11 +698,11 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
             q.splitK = afi_cdiv(nK, kper);                // no empty splits
         }
     }
-    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO>), dim3(chunk * ntn * 8, q.splitK), dim3(256), lds, st, q, ntn, ntiles, chunk);
+    hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO, GTAP>), dim3(chunk * ntn * 8, q.splitK), dim3(64 * WM * WN), lds, st, q, ntn, ntiles, chunk);
     if (q.splitK > 1) {
         const long long items = M * (((p.Ncols + 3) & ~3) >> 2);
         long long g = (items + 255) / 256; if (g > 2048) g = 2048;
-        hipLaunchKernelGGL(afi_pix_splitk_epilogue_kernel, dim3((unsigned)g), dim3(256), 0, st, q);
+        hipLaunchKernelGGL(afi_pix_splitk_epilogue_kernel<GTAP>, dim3((unsigned)g), dim3(256), 0, st, q);
     }
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
@@ -692,9 +711,16 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     const AfiPixGemm& p = p_in;
     const long long M = (long long)p.N * p.H * p.W;
     if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
-    if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;
     if (b_rc && (p.Ncols & 3)) return AFI_ERR_UNSUPPORTED;       // RC weight rows are read as float4 along n
     if (!b_rc && (p.Ck & 3)) return AFI_ERR_UNSUPPORTED;         // KC weight rows are read as float4 along c
+    if (p.gtap) {
+        // generic tap table (stride-2 conv forward / its dgrad phases): 1..9 taps with final offsets, two tile shapes
+        if (p.ntaps < 1 || p.ntaps > 9 || p.a_sgn != 1 || p.nKphase != 1 || (p.a_stride != 1 && p.a_stride != 2)) return AFI_ERR_BAD_ARG;
+        const bool small = M <= 64 * 256 || p.Ncols <= 64;
+        if (!b_rc) return small ? launch_pix<64, 64, 2, 2, false, AFI_BK, false, true>(p, st) : launch_pix<128, 128, 2, 2, false, AFI_BK, false, true>(p, st);
+        return small ? launch_pix<64, 64, 2, 2, true, AFI_BK, false, true>(p, st) : launch_pix<128, 128, 2, 2, true, AFI_BK, false, true>(p, st);
+    }
+    if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;
     // tile choice: fill the N side first (weights are shared by every block), shrink M tiles for small maps
     const bool smallM = M <= 64 * 256;                           // <= 16 K pixels: 64x64 tiles (measured 99 vs 87 TFLOP/s at P4)
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work

@@ -27,6 +27,7 @@ int afi_launch_bce_logits(const float* z, long long n, float target, float lscal
 int afi_launch_l1(AfiView a, AfiView b, int N, int h, int w, int C, int Ha, int Wa, float lscale, float* loss, float gscale, float* da,
                   hipStream_t st);
 int afi_launch_bilinear2x_fwd(AfiView x, int N, int H, int W, int C, float beta, float* out, hipStream_t st);
+int afi_launch_relu_bwd(const float* g, const float* act, float* out, long long n, float s, hipStream_t st);
 int afi_launch_bilinear2x_bwd(const float* dout, int N, int H, int W, int C, float beta, float* dx, hipStream_t st);
 int afi_launch_sgd(const void* descs_dev, int ntensors, long long max_n, float lr, float mom, float gscale, hipStream_t st);
 int afi_launch_scale(float* p, long long n, float s, hipStream_t st);
@@ -93,6 +94,7 @@ static AfiPixGemm pix_default(int N, int H, int W) {
     g.N = N; g.H = H; g.W = W;
     g.ntaps = 9; g.nKphase = 1; g.a_sgn = 1; g.a_up = 1; g.o_up = 1;
     g.alpha = 1.f; g.beta = 0.f; g.r1s = 1.f; g.r2s = 1.f;
+    g.a_stride = 1; g.aH = H; g.aW = W; g.oH = g.oW = 1 << 30; g.post_scale = 1.f;
     return g;
 }
 
@@ -120,6 +122,7 @@ static AfiWgradGemm conv_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W, 
     g.Mrows = Cout; g.Ncols = Cin;
     g.DY = dy; g.dy_up = 1; g.CoutPhase = Cout;
     g.X = x; g.DW = dw; g.dw_sRow = 9LL * Cin; g.dw_sTap = Cin;
+    g.x_stride = 1; g.xH = H; g.xW = W;
     g.alpha = alpha; g.splitK = 0;
     return g;
 }
@@ -184,6 +187,66 @@ int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout
     AfiWgradGemm g = conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha);
     g.ntaps = 1; g.dw_sRow = Cin; g.dw_sTap = 0;
     return afi_launch_wgrad_gemm(g, (hipStream_t)stream);
+}
+
+// ---- Conv2d(k=3, stride=2, padding=1): the PAFPN bottom-up downsample (pafpn_sr.py:105-117,178-183) ----
+// forward: rows are the Ho x Wo output pixels (Ho = ceil(Hi/2)), tap t reads x[2y + t/3 - 1][2x + t%3 - 1]
+int afi_conv3x3s2_fwd(afi_view_t x, int N, int Hi, int Wi, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, int act,
+                      afi_view_t act_out, float post_scale, afi_view_t r, float r_scale, void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
+    if (Hi < 1 || Wi < 1) return AFI_ERR_BAD_ARG;
+    const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
+    AfiPixGemm g = conv_fwd_desc(V(x), N, Ho, Wo, Cin, w, bias, Cout, V(out));
+    g.gtap = 1; g.a_stride = 2; g.aH = Hi; g.aW = Wi;
+    for (int t = 0; t < 9; ++t) { g.tap_dy[t] = (signed char)(t / 3 - 1); g.tap_dx[t] = (signed char)(t % 3 - 1); g.tap_w[t] = (signed char)t; }
+    g.lrelu = act; g.r2_post = 1; g.post_scale = post_scale;
+    if (act_out.p) g.O2 = V(act_out);
+    if (r.p) { g.R2 = V(r); g.r2s = r_scale; g.r2_lo = 0; g.r2_hi = Cout; }
+    return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
+}
+// data gradient: input pixel (2m + py, 2n + px) only sees the taps of matching parity -- ky = 1 for py = 0 (dy row m), ky = 0 / 2
+// for py = 1 (dy rows m+1 / m) -- so dx is four GEMMs over the Ho x Wo grid with 1, 2, 2 and 4 taps (9 in total: no wasted
+// MFMA work, unlike a stride-1 dgrad over a zero-stuffed dy which would do 4x), each storing its parity phase of dx.
+int afi_conv3x3s2_dgrad(afi_view_t dy, int N, int Hi, int Wi, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
+                        void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
+    if (Hi < 1 || Wi < 1) return AFI_ERR_BAD_ARG;
+    const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        if (Hi - py <= 0 || Wi - px <= 0) continue;
+        AfiPixGemm g = pix_default(N, Ho, Wo);
+        g.Ck = Cout; g.Ncols = Cin; g.CoutPhase = Cin;
+        g.A = V(dy); g.B = w; g.b_sRow = 9LL * Cin; g.b_sTap = Cin;
+        g.gtap = 1;
+        int nt = 0;
+        for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+            for (int ix = 0; ix < (px ? 2 : 1); ++ix) {
+                const int ky = py ? (iy ? 2 : 0) : 1, kx = px ? (ix ? 2 : 0) : 1;
+                g.tap_dy[nt] = (signed char)(py && !iy ? 1 : 0);
+                g.tap_dx[nt] = (signed char)(px && !ix ? 1 : 0);
+                g.tap_w[nt] = (signed char)(ky * 3 + kx);
+                ++nt;
+            }
+        g.ntaps = nt;
+        AfiView o = V(dx);
+        o.p += py * o.sH + px * o.sW;
+        g.O = o; g.o_up = 2; g.oH = Hi - py; g.oW = Wi - px;
+        g.alpha = alpha; g.beta = beta;
+        const int rc = afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
+        if (rc != AFI_OK) return rc;
+    }
+    return AFI_OK;
+}
+int afi_conv3x3s2_wgrad(afi_view_t dy, afi_view_t x, int N, int Hi, int Wi, int Cout, int Cin, float* dw, float alpha, void* stream) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
+    if (Hi < 1 || Wi < 1) return AFI_ERR_BAD_ARG;
+    AfiWgradGemm g = conv_wgrad_desc(V(dy), V(x), N, (Hi + 1) / 2, (Wi + 1) / 2, Cout, Cin, dw, alpha);
+    g.x_stride = 2; g.xH = Hi; g.xW = Wi;
+    return afi_launch_wgrad_gemm(g, (hipStream_t)stream);
+}
+int afi_relu_bwd(const float* g, const float* act, float* out, long long n, float scale, void* stream) {
+    return afi_launch_relu_bwd(g, act, out, n, scale, (hipStream_t)stream);
 }
 
 int afi_convT6s2_pack_weight(const float* w, float* wp, int Cin, int Cout, void* stream) {

@@ -124,6 +124,61 @@ def conv3x3_wgrad(dy, x, dw=None, alpha=1.0):
     return dw
 
 
+def conv3x3s2_fwd(x, w, bias=None, act=0, add=None, add_scale=1.0, post_scale=1.0, keep_act=False):
+    """Conv2d(k3, s2, p1) with the fused PAFPN merge:  a = act(conv(x, w) + bias);  out = post_scale*a + add_scale*add.
+    act: 0 none, 1 LeakyReLU(0.2), 2 ReLU.  Returns out, or (out, a) with keep_act (a is what the ReLU backward needs)."""
+    _check_cuda(x, w, bias, add)
+    N, Cin, Hi, Wi = x.shape
+    Cout = w.shape[0]
+    w = ohwi(w)
+    Ho, Wo = (Hi + 1) // 2, (Wi + 1) // 2
+    if add is not None and tuple(add.shape) != (N, Cout, Ho, Wo):
+        raise _lib.AfiError(f"conv3x3s2_fwd: residual shape {tuple(add.shape)} != {(N, Cout, Ho, Wo)}")
+    out = new_pixel_major(N, Cout, Ho, Wo, x.device)
+    a = new_pixel_major(N, Cout, Ho, Wo, x.device) if keep_act else None
+    call("afi_conv3x3s2_fwd", view_of(x), N, Hi, Wi, Cin, _p(w), _p(bias), Cout, view_of(out), int(act),
+         view_of(a) if a is not None else _NULL_VIEW, float(post_scale), view_of(add) if add is not None else _NULL_VIEW,
+         float(add_scale), stream_ptr())
+    return (out, a) if keep_act else out
+
+
+def conv3x3s2_dgrad(dy, w, in_hw, dx=None, alpha=1.0, beta=0.0):
+    """dx [N,Cin,Hi,Wi] = alpha * (data gradient of Conv2d(k3,s2,p1)) + beta*dx;  in_hw = (Hi, Wi) of the conv's input."""
+    _check_cuda(dy, w, dx)
+    N, Cout, Ho, Wo = dy.shape
+    Hi, Wi = in_hw
+    if ((Hi + 1) // 2, (Wi + 1) // 2) != (Ho, Wo):
+        raise _lib.AfiError(f"conv3x3s2_dgrad: dy {Ho}x{Wo} is not the stride-2 output of {Hi}x{Wi}")
+    Cin = w.shape[1]
+    w = ohwi(w)
+    if dx is None:
+        dx = new_pixel_major(N, Cin, Hi, Wi, dy.device)
+    call("afi_conv3x3s2_dgrad", view_of(dy), N, Hi, Wi, Cout, _p(w), Cin, view_of(dx), float(alpha), float(beta), stream_ptr())
+    return dx
+
+
+def conv3x3s2_wgrad(dy, x, dw=None, alpha=1.0):
+    _check_cuda(dy, x, dw)
+    N, Cout, Ho, Wo = dy.shape
+    _, Cin, Hi, Wi = x.shape
+    if ((Hi + 1) // 2, (Wi + 1) // 2) != (Ho, Wo):
+        raise _lib.AfiError(f"conv3x3s2_wgrad: dy {Ho}x{Wo} is not the stride-2 output of {Hi}x{Wi}")
+    if dw is None:
+        dw = new_ohwi(Cout, Cin, 3, 3, dy.device)
+    assert dw.permute(0, 2, 3, 1).is_contiguous()
+    call("afi_conv3x3s2_wgrad", view_of(dy), view_of(x), N, Hi, Wi, Cout, Cin, _p(dw), float(alpha), stream_ptr())
+    return dw
+
+
+def relu_bwd(g, act, scale=1.0):
+    """scale * g * (act > 0) for dense pixel-major g / act of the same shape."""
+    _check_cuda(g, act)
+    assert is_dense_pm(g) and is_dense_pm(act) and g.shape == act.shape
+    out = new_pixel_major(*g.shape, g.device)
+    call("afi_relu_bwd", _p(g), _p(act), _p(out), g.numel(), float(scale), stream_ptr())
+    return out
+
+
 def conv1x1_fwd(x, w, bias=None, add=None, add_scale=1.0, alpha=1.0, out=None):
     """out = alpha*conv1x1(x, w) + bias + add_scale*add;  w: [Cout, Cin] or [Cout, Cin, 1, 1]."""
     _check_cuda(x, w, bias, add, out)

@@ -120,6 +120,22 @@ int afi_conv1x1_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float*
                       void* stream);
 int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
 
+/* Conv2d(k=3, stride=2, padding=1) on [N,Hi,Wi,Cin] -> [N,Ho,Wo,Cout], Ho = ceil(Hi/2): the PAFPN bottom-up downsample conv
+ * with its fused merge (pafpn_sr.py:105-117,177-183):
+ *   a = act(conv(x,w) + bias)            -> act_out (or NULL; kept for the ReLU backward)
+ *   out = post_scale*a + r_scale*r       (r NULL = no residual)
+ * dgrad: dx[N,Hi,Wi,Cin] = alpha*conv^T(dy) + beta*dx, run as four parity-phase GEMMs (9 taps in total).
+ * wgrad: dw[Cout][3][3][Cin] += alpha * sum_pix dy (x) x. */
+int afi_conv3x3s2_fwd(afi_view_t x, int N, int Hi, int Wi, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
+                      afi_view_t out, int act, afi_view_t act_out_or_null, float post_scale, afi_view_t r_or_null, float r_scale,
+                      void* stream);
+int afi_conv3x3s2_dgrad(afi_view_t dy /*[N,Ho,Wo,Cout]*/, int N, int Hi, int Wi, int Cout, const float* w_ohwi, int Cin,
+                        afi_view_t dx, float alpha, float beta, void* stream);
+int afi_conv3x3s2_wgrad(afi_view_t dy, afi_view_t x /*[N,Hi,Wi,Cin]*/, int N, int Hi, int Wi, int Cout, int Cin, float* dw,
+                        float alpha, void* stream);
+/* out[i] = scale * g[i] * (act[i] > 0): gradient through the ReLU of pafpn_sr.py:178 from its kept output (n % 4 == 0) */
+int afi_relu_bwd(const float* g, const float* act, float* out, long long n, float scale, void* stream);
+
 /* ConvTranspose2d(k=6,s=2,p=2) (generator_rdb.py:101-105) on the packed weight wp[4*Cout][3][3][Cin] */
 int afi_convT6s2_pack_weight(const float* w_iohw, float* wp, int Cin, int Cout, void* stream);
 int afi_convT6s2_unpack_wgrad(const float* dwp, float* dw_iohw, int Cin, int Cout, void* stream);   /* dw += */

@@ -223,3 +223,42 @@ def test_conv1x1_fwd_dgrad_wgrad(amd):
     _close(ops.conv1x1_dgrad(_pm(dy), w.cuda().reshape(12, 20)), xg.grad, what="1x1 dgrad")
     _close(ops.conv1x1_wgrad(_pm(dy), _pm(x)).reshape(12, 20, 1, 1), wg.grad, what="1x1 wgrad")
     _close(ops.bias_grad(_pm(dy)), dy.sum(dim=(0, 2, 3)), tol=1e-4, what="bias grad")
+
+
+S2_CASES = [
+    # N, Cin, Cout, Hi, Wi   (odd and even sizes: Ho = ceil(Hi/2); the dgrad's odd phases must not write past the input)
+    (1, 16, 16, 5, 7),
+    (2, 20, 8, 8, 6),
+    (1, 32, 64, 13, 21),
+    (2, 36, 12, 1, 9),        # single input row
+    (1, 64, 160, 34, 41),
+    (2, 256, 256, 50, 84),    # PAFPN P4 -> P5 at config-2 size
+    (1, 128, 256, 200, 336),  # large map: 128x128 tiles (M = 16800 output pixels)
+    (1, 32, 128, 271, 259),   # large odd map
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,Hi,Wi", S2_CASES)
+def test_conv3x3_stride2(amd, N, Cin, Cout, Hi, Wi):
+    """Conv2d(k3, s2, p1) forward (+ fused ReLU / post-activation residual), dgrad (four parity-phase GEMMs) and wgrad
+    against torch-CPU fp32 (pafpn_sr.py:105-117,177-183)."""
+    ops = amd.ops
+    x, w, b = _rand(N, Cin, Hi, Wi, seed=1), _rand(Cout, Cin, 3, 3, seed=2) * 0.1, _rand(Cout, seed=3)
+    Ho, Wo = (Hi + 1) // 2, (Wi + 1) // 2
+    dy, inter = _rand(N, Cout, Ho, Wo, seed=4), _rand(N, Cout, Ho, Wo, seed=5)
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xg, wg, b, 2, 1)
+    assert ref.shape == (N, Cout, Ho, Wo)
+    ref.backward(dy)
+    xd, wd, bd, dyd = _pm(x), w.cuda(), b.cuda(), _pm(dy)
+    _close(ops.conv3x3s2_fwd(xd, wd, bd), ref, what="fwd")
+    out, act = ops.conv3x3s2_fwd(xd, wd, bd, act=2, add=_pm(inter), add_scale=0.5, post_scale=0.5, keep_act=True)
+    _close(act, F.relu(ref), what="relu output")
+    _close(out, 0.5 * inter + 0.5 * F.relu(ref), what="fused merge (avg)")
+    _close(ops.conv3x3s2_dgrad(dyd, wd, (Hi, Wi)), xg.grad, what="dgrad")
+    _close(ops.conv3x3s2_wgrad(dyd, xd), wg.grad, what="wgrad")
+    old = _rand(N, Cin, Hi, Wi, seed=6)
+    got = ops.conv3x3s2_dgrad(dyd, wd, (Hi, Wi), dx=_pm(old).clone(memory_format=torch.preserve_format), alpha=0.5, beta=1.0)
+    _close(got, old + 0.5 * xg.grad, what="dgrad accumulate")
+    g = ops.relu_bwd(dyd, act, scale=0.5)
+    _close(g, 0.5 * dy * (act.cpu() > 0).float(), what="relu bwd")              # mask of the kept activation itself
