@@ -4,6 +4,7 @@ Drop-in surface (same names / signatures / state_dict keys as the reference modu
   * ``Generator``      <- afigan/modeling/feat_interpol/generator_rdb.py:73
   * ``Discriminator``  <- afigan/modeling/feat_interpol/feature_patch_discriminator.py:16
   * ``Stage1Step``     <- the G+D iteration of afigan/engine/stage1_trainer.py:305-435
+  * ``FPN_AFIGAN`` / ``PAFPN_AFIGAN`` <- afigan/modeling/backbone/fpn_sr.py:20, pafpn_sr.py:20 (the callers of G in stages 2/3)
 All forward/backward math runs in hand-written HIP kernels for gfx950 behind the C-ABI of
 ``include/afigan_hip.h`` (libafigan_hip.so).  There is no CPU / eager fallback.
 """
@@ -17,6 +18,7 @@ from .generator_rdb import Generator  # noqa: E402
 from .feature_patch_discriminator import Discriminator  # noqa: E402
 from .stage1 import Stage1Step, warmup_multistep_lr  # noqa: E402
 from .fpn_sr import FPN_AFIGAN, LastLevelMaxPool  # noqa: E402
+from .pafpn_sr import PAFPN_AFIGAN  # noqa: E402
 from .stage2 import Stage2Adversarial, l1_loss_common, nearest_half  # noqa: E402
 
-__all__ = ["Generator", "Discriminator", "Stage1Step", "warmup_multistep_lr", "FPN_AFIGAN", "LastLevelMaxPool", "Stage2Adversarial", "l1_loss_common", "nearest_half", "ops", "AfiError"]
+__all__ = ["Generator", "Discriminator", "Stage1Step", "warmup_multistep_lr", "FPN_AFIGAN", "PAFPN_AFIGAN", "LastLevelMaxPool", "Stage2Adversarial", "l1_loss_common", "nearest_half", "ops", "AfiError"]

@@ -14,7 +14,7 @@ so exactly those names are provided as stand-in modules in sys.modules (SURVEY.m
   detectron2.layers.get_norm("BN")  -> nn.BatchNorm2d
   detectron2.layers.ShapeSpec, detectron2.utils.registry.Registry -> inert placeholders
   fvcore.nn.weight_init.c2_msra_fill -> kaiming_normal_(fan_out, relu) + zero bias
-For the FPN fixture afigan/modeling/backbone/fpn_sr.py is loaded the same way; its extra module-top
+For the FPN / PAFPN fixtures afigan/modeling/backbone/{fpn_sr,pafpn_sr}.py are loaded the same way; their extra module-top
 imports get inert stand-ins too (detectron2 Backbone = nn.Module, BACKBONE_REGISTRY.register = identity,
 build_resnet_backbone / build_resnest_backbone = unused stubs, c2_xavier_fill = kaiming_uniform_(a=1) + zero bias,
 get_norm("") = None) and the already-loaded reference generator is registered under its package name.
@@ -215,6 +215,32 @@ def main():
         fx.update(grads_digest({k: p.grad for k, p in fpn.named_parameters()}))
         np.savez_compressed(os.path.join(HERE, f"fpn_{fuse}.npz"), **fx)
         print("fpn", fuse, {k: tuple(v.shape) for k, v in out.items()})
+
+    # ---------------- PAFPN_AFIGAN (pafpn_sr.py): top-down AFI merge + bottom-up path aggregation, SURVEY 8f row 1 ----------------
+    pafpn_mod = load_ref("afigan/modeling/backbone/pafpn_sr.py", "ref_pafpn_sr")
+    for fuse in ("sum", "avg"):
+        pafpn = pafpn_mod.PAFPN_AFIGAN(BottomUp(), ["res2", "res3", "res4", "res5"], 256, norm="",
+                                       top_block=pafpn_mod.LastLevelMaxPool(), fuse_type=fuse, cfg=Cfg)
+        sd = {}
+        for k, v in pafpn.state_dict().items():
+            if k.startswith("srf_module."):
+                continue
+            sd[k] = orc.closed_form_tensor(k, v.shape, 0.05 if k.endswith("bias") else (6.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5 / 3 ** 0.5)
+        sd.update({"srf_module." + k: v for k, v in orc.closed_form_generator_params().items()})
+        pafpn.load_state_dict(sd, strict=True)
+        gen = torch.Generator().manual_seed(33)
+        feats = {f"res{i + 2}": torch.randn((1, c, 2 * 2 ** (3 - i), 3 * 2 ** (3 - i)), generator=gen).requires_grad_(True)
+                 for i, c in enumerate([8, 12, 16, 20])}
+        out = pafpn(feats)
+        sum((o * o).mean() for o in out.values()).backward()
+        fx = {"seed": np.array([33])}
+        for k, o in out.items():
+            fx["out/" + k] = o.detach().numpy() if k != "p2" else o.detach()[:, ::4].numpy()
+        for k, f in feats.items():
+            fx["dfeat/" + k] = f.grad.numpy()
+        fx.update(grads_digest({k: p.grad for k, p in pafpn.named_parameters()}))
+        np.savez_compressed(os.path.join(HERE, f"pafpn_{fuse}.npz"), **fx)
+        print("pafpn", fuse, {k: tuple(v.shape) for k, v in out.items()}, sorted(k for k in sd if not k.startswith("srf_module."))[:6])
 
     # ---------------- G-small: full tensors, reference default init ----------------
     for tag, shape in (("a", (2, 16, 5, 7)), ("b", (1, 16, 7, 11))):

@@ -32,6 +32,29 @@ def test_reference_import_paths_and_signatures():
     assert sum(p.numel() for p in d.parameters()) == 15_352_321
 
 
+def test_backbone_import_paths_and_state_dict_names():
+    """afigan.modeling.backbone.{fpn_sr,pafpn_sr} resolve to the HIP-backed pyramids with the reference's parameter names
+    (fpn_sr.py:96-97; pafpn_sr.py:96-97,116) -- construction only, no compute."""
+    _amd()
+    from afigan.modeling.backbone import fpn_sr, pafpn_sr
+    from afigan_amd.fpn_sr import ShapeSpec
+
+    class BottomUp(torch.nn.Module):
+        def output_shape(self):
+            return {f"res{i + 2}": ShapeSpec(c, s) for i, (c, s) in enumerate(zip([256, 512, 1024, 2048], [4, 8, 16, 32]))}
+
+    feats = ["res2", "res3", "res4", "res5"]
+    fpn = fpn_sr.FPN_AFIGAN(BottomUp(), feats, 256, top_block=fpn_sr.LastLevelMaxPool())
+    pa = pafpn_sr.PAFPN_AFIGAN(BottomUp(), feats, 256, top_block=pafpn_sr.LastLevelMaxPool())
+    heads = lambda m: {k.split(".")[0] for k in m.state_dict()}
+    assert heads(fpn) == {"srf_module"} | {f"fpn_lateral{s}" for s in range(2, 6)} | {f"fpn_output{s}" for s in range(2, 6)}
+    assert heads(pa) == ({"srf_module"} | {f"fpn_lateral{s}" for s in range(2, 6)} | {f"pafpn_output{s}" for s in range(2, 6)}
+                         | {f"pafpn_downsample{s}" for s in range(3, 6)})
+    assert tuple(pa.state_dict()["pafpn_downsample3.weight"].shape) == (256, 256, 3, 3)
+    assert tuple(pa.state_dict()["fpn_lateral5.weight"].shape) == (256, 2048, 1, 1)
+    assert list(pa.output_shape()) == ["p2", "p3", "p4", "p5", "p6"] and pa.size_divisibility == 32
+
+
 @pytest.mark.parametrize("n_rdb", [2, 3])
 def test_state_dict_contract(n_rdb):
     amd = _amd()

@@ -186,6 +186,45 @@ def test_fpn_merge_matches_reference(golden_dir, fuse):
     _check_digests(fx, {k: v.grad for k, v in p.items()}, rtol=5e-4)
 
 
+def _pafpn_params_and_feats(fx):
+    """Closed-form PAFPN weights (the recipe of make_golden.py) + the seeded bottom-up features."""
+    p = {}
+    chans = [8, 12, 16, 20]
+    for i, c in enumerate(chans):
+        s_ = i + 2
+        names = [(f"fpn_lateral{s_}.weight", (256, c, 1, 1)), (f"fpn_lateral{s_}.bias", (256,)),
+                 (f"pafpn_output{s_}.weight", (256, 256, 3, 3)), (f"pafpn_output{s_}.bias", (256,))]
+        if i > 0:
+            names += [(f"pafpn_downsample{s_}.weight", (256, 256, 3, 3)), (f"pafpn_downsample{s_}.bias", (256,))]
+        for name, shape in names:
+            scale = 0.05 if name.endswith("bias") else (6.0 / (shape[1] * shape[2] * shape[3])) ** 0.5 / 3 ** 0.5
+            p[name] = orc.closed_form_tensor(name, shape, scale)
+    p.update({"srf_module." + k: v for k, v in orc.closed_form_generator_params().items()})
+    gen = torch.Generator().manual_seed(int(fx["seed"][0]))
+    feats = [torch.randn((1, c, 2 * 2 ** (3 - i), 3 * 2 ** (3 - i)), generator=gen) for i, c in enumerate(chans)]
+    return p, feats
+
+
+@pytest.mark.parametrize("fuse", ["sum", "avg"])
+def test_pafpn_matches_reference(golden_dir, fuse):
+    """oracle.pafpn_afigan_forward vs the imported reference PAFPN_AFIGAN (pafpn_sr.py:147-193)."""
+    fx = _load(golden_dir, f"pafpn_{fuse}.npz")
+    p, feats = _pafpn_params_and_feats(fx)
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    feats = [f.requires_grad_(True) for f in feats]
+    out = orc.pafpn_afigan_forward(feats, [2, 3, 4, 5], p, fuse_type=fuse)
+    assert list(out) == ["p2", "p3", "p4", "p5", "p6"]
+    for k, o in out.items():
+        ref = fx["out/" + k]
+        got = o.detach().numpy() if k != "p2" else o.detach()[:, ::4].numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=k)
+    sum((o * o).mean() for o in out.values()).backward()
+    for i, f in enumerate(feats):
+        ref = fx[f"dfeat/res{i + 2}"]
+        np.testing.assert_allclose(f.grad.numpy(), ref, rtol=0, atol=1e-4 * np.abs(ref).max(), err_msg=f"res{i + 2}")
+    _check_digests(fx, {k: v.grad for k, v in p.items()}, rtol=5e-4)
+
+
 def _stage2_inputs(fx):
     gen = torch.Generator().manual_seed(int(fx["seed"][0]))
     guide = [torch.randn((2, 256, 26, 42), generator=gen), torch.randn((2, 256, 13, 21), generator=gen)]
