@@ -107,10 +107,11 @@ def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
             "frac_of_fp32_mfma_peak": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
 
-def fpn_bench(amd, torch, iters=10, warmup=3):
+def fpn_bench(amd, torch, iters=10, warmup=3, pafpn=False):
     """the AFI top-down merge of FPN_AFIGAN (fpn_sr.py:127-165) at stage-3 size, one 800x1344 image:
     res2..res5 = 200x336x256, 100x168x512, 50x84x1024, 25x42x2048 -> p2..p6, forward + backward through the module
-    (autograd path: three interpolator calls, fused lateral+add GEMMs, 3x3 output convs, all channels_last)."""
+    (autograd path: three interpolator calls, fused lateral+add GEMMs, 3x3 output convs, all channels_last).
+    pafpn=True: PAFPN_AFIGAN (pafpn_sr.py:147-193), i.e. the same plus the three stride-2 downsample+merge GEMMs."""
     from afigan_amd.fpn_sr import ShapeSpec
 
     class BottomUp(torch.nn.Module):
@@ -121,7 +122,8 @@ def fpn_bench(amd, torch, iters=10, warmup=3):
             return feats
 
     torch.manual_seed(0)
-    fpn = amd.FPN_AFIGAN(BottomUp(), ["res2", "res3", "res4", "res5"], 256, top_block=amd.LastLevelMaxPool()).cuda()
+    cls = amd.PAFPN_AFIGAN if pafpn else amd.FPN_AFIGAN
+    fpn = cls(BottomUp(), ["res2", "res3", "res4", "res5"], 256, top_block=amd.LastLevelMaxPool()).cuda()
     shapes = [(256, 200, 336), (512, 100, 168), (1024, 50, 84), (2048, 25, 42)]
     feats = {f"res{i + 2}": torch.randn((1, c, h, w), device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
              for i, (c, h, w) in enumerate(shapes)}
@@ -144,8 +146,9 @@ def fpn_bench(amd, torch, iters=10, warmup=3):
     g_px = 25 * 42 + 50 * 84 + 100 * 168
     lat = sum(h * w * c for c, h, w in shapes) * 256 * 2
     outc = sum(h * w for _, h, w in shapes) * 256 * 2304 * 2
-    flop = 3 * (g_px * G_FWD_FLOP_PER_INPX + lat + outc)
-    return {"workload": "FPN_AFIGAN top-down merge fwd+bwd, 1 image 800x1344, R-50 feature shapes", "ms": dt * 1e3, "images_per_s": 1.0 / dt,
+    down = sum(h * w for _, h, w in shapes[1:]) * 256 * 2304 * 2 if pafpn else 0
+    flop = 3 * (g_px * G_FWD_FLOP_PER_INPX + lat + outc + down)
+    return {"workload": ("PAFPN_AFIGAN top-down + bottom-up" if pafpn else "FPN_AFIGAN top-down merge") + " fwd+bwd, 1 image 800x1344, R-50 feature shapes", "ms": dt * 1e3, "images_per_s": 1.0 / dt,
             "algorithmic_tflop": flop / 1e12, "tflops": flop / dt / 1e12, "frac_of_fp32_mfma_peak": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
 
@@ -363,6 +366,7 @@ def main():
     if not args.no_interp:
         log("FPN_AFIGAN top-down merge (SURVEY 8f row 1)")
         line["fpn_topdown"] = fpn_bench(amd, torch)
+        line["pafpn"] = fpn_bench(amd, torch, pafpn=True)
     log("CPU baseline (oracle) on the host cores")
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, B)

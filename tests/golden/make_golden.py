@@ -129,6 +129,23 @@ def install_shims():
         sys.modules[name] = mod
 
 
+def checkpoint_remap_cases():
+    """Key sets (name -> shape) for the stage hand-off fixture; shared with tests/test_host_logic.py.
+    case -> (model keys, checkpoint keys, reference method name)."""
+    g = {k: (2,) + tuple(min(d, 3) for d in shp[1:]) for k, shp in orc.generator_param_shapes(256, 3, 32).items()}   # tiny stand-in shapes
+    det = {"backbone.srf_module." + k: v for k, v in g.items()}
+    det.update({"backbone.fpn_lateral2.weight": (2, 3), "backbone.fpn_output2.weight": (2, 3), "backbone.bottom_up.stem.conv1.weight": (2, 3),
+                "roi_heads.box_head.fc1.weight": (4, 3), "proposal_generator.rpn_head.conv.weight": (2, 2)})
+    stage1 = dict(g)
+    stage1["Generators.0.4.0.bias"] = (5,)                          # shape mismatch: must be skipped
+    stage1["iteration_marker"] = (1,)                               # matches nothing
+    stage2 = {k: v for k, v in det.items()}
+    stage2["backbone.bottom_up.stem.conv1.weight"] = (2, 3)         # same name and shape, but not an srf_module tensor: dropped
+    stage2["backbone.srf_module.Generators.0.2.0.weight"] = (7, 7)  # shape mismatch inside srf_module
+    return {"af_extractor": (det, stage1, "align_and_update_state_dicts_AFExtractor"),
+            "target_detector": (det, stage2, "align_and_update_state_dicts_TargetDetector")}
+
+
 def load_ref(relpath, name):
     spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
     mod = importlib.util.module_from_spec(spec)
@@ -457,6 +474,30 @@ def main():
             fx["Dbuf_after/" + k] = v.numpy()
     np.savez_compressed(os.path.join(HERE, "stage2_adv.npz"), **fx)
     print("stage2 adv", {k: v.item() for k, v in d_loss.items()}, {k: v.item() for k, v in g_loss.items()})
+
+    # ---------------- stage hand-off key remapping: afigan/engine/checkpoint.py:64-258 ----------------
+    # The module's top imports (fvcore Checkpointer / PathManager, detectron2 comm / c2_model_loading) get inert stand-ins;
+    # the two align_and_update_state_dicts_* methods only use `self` to reach convert_AFI_names / remain_only_AFI_names.
+    import json
+    for name, attrs in (("fvcore.common", {}), ("fvcore.common.checkpoint", {"Checkpointer": type("Checkpointer", (), {})}),
+                        ("fvcore.common.file_io", {"PathManager": object}), ("detectron2.utils.comm", {"is_main_process": lambda: True}),
+                        ("detectron2.checkpoint", {}), ("detectron2.checkpoint.c2_model_loading", {"align_and_update_state_dicts": None})):
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    ck_mod = load_ref("afigan/engine/checkpoint.py", "ref_checkpoint")
+    ck = object.__new__(ck_mod.AF_DetectionCheckpointer)
+    cases = {}
+    for case, (model_shapes, ckpt_shapes, method) in checkpoint_remap_cases().items():
+        model_sd = {k: torch.full(shape, -1.0) for k, shape in model_shapes.items()}
+        ckpt_sd = {k: torch.full(shape, float(i)) for i, (k, shape) in enumerate(sorted(ckpt_shapes.items()))}
+        getattr(ck, method)(model_sd, ckpt_sd)
+        order = sorted(ckpt_shapes)
+        cases[case] = {k: (order[int(v.reshape(-1)[0].item())] if v.reshape(-1)[0].item() >= 0 else None) for k, v in model_sd.items()}
+    with open(os.path.join(HERE, "checkpoint_remap.json"), "w") as f:
+        json.dump(cases, f, indent=1, sort_keys=True)
+    print("checkpoint remap", {k: sum(v is not None for v in c.values()) for k, c in cases.items()})
 
 
 if __name__ == "__main__":

@@ -172,3 +172,62 @@ def test_data_parallel_allreduce_world2_gloo(tmp_path):
         assert torch.allclose(r0[k], mean, rtol=1e-6, atol=1e-8), k
         assert torch.equal(r0[k], r1[k]), k
     assert not torch.equal(r0["__shard_grads"]["Generators.0.0.0.weight"], r1["__shard_grads"]["Generators.0.0.0.weight"])
+
+
+def test_checkpoint_remap_matches_reference(golden_dir):
+    """afigan_amd.checkpoint vs the key matching captured from the reference's AF_DetectionCheckpointer
+    (afigan/engine/checkpoint.py:64-258): stage-1 `Generators.*` -> `backbone.srf_module.Generators.*`, stage-2 -> stage-3
+    hands over only `srf_module` tensors, shape mismatches are skipped."""
+    import importlib.util
+    import json
+    _amd()
+    from afigan_amd import checkpoint as ck
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(golden_dir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)                       # defines the shared key sets; touches nothing of /root/reference on import
+    want = json.load(open(os.path.join(golden_dir, "checkpoint_remap.json")))
+    for case, (model_shapes, ckpt_shapes, _method) in mg.checkpoint_remap_cases().items():
+        model_sd = {k: torch.full(shape, -1.0) for k, shape in model_shapes.items()}
+        order = sorted(ckpt_shapes)
+        ckpt_sd = {k: torch.full(ckpt_shapes[k], float(i)) for i, k in enumerate(order)}
+        prep = ck.convert_afi_names if case == "af_extractor" else ck.remain_only_afi_names
+        renamed, new_to_old = prep(ckpt_sd)
+        matched = ck.align_and_update(model_sd, renamed)
+        got = {k: (order[int(v.reshape(-1)[0].item())] if v.reshape(-1)[0].item() >= 0 else None) for k, v in model_sd.items()}
+        assert got == want[case], case
+        assert {new_to_old[c]: m for c, m in matched.items()} == {v: k for k, v in want[case].items() if v is not None}
+    # one checkpoint key feeding two model keys is an error, as in the reference
+    with pytest.raises(ValueError):
+        ck.align_and_update({"a.w": torch.zeros(1), "b.w": torch.zeros(1)}, {"w": torch.ones(1)})
+
+
+def test_stage1_weights_load_into_afi_backbone():
+    """load_af_extractor_weights: a stage-1 Generator state dict lands in FPN_AFIGAN.srf_module of a wrapped detector."""
+    amd = _amd()
+    from afigan_amd import checkpoint as ck
+    from afigan_amd.fpn_sr import ShapeSpec
+
+    class BottomUp(torch.nn.Module):
+        def output_shape(self):
+            return {"res2": ShapeSpec(8, 4), "res3": ShapeSpec(8, 8)}
+
+    class Detector(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = amd.FPN_AFIGAN(BottomUp(), ["res2", "res3"], 256, top_block=None)
+
+    det = Detector()
+    g = amd.Generator(n_residual_dense_blocks=3)
+    with torch.no_grad():
+        for p in g.parameters():
+            p.fill_(0.25)
+    before = det.backbone.fpn_lateral2.weight.clone()
+    matched = ck.load_af_extractor_weights(det, {"model": g.state_dict()})
+    assert len(matched) == len(g.state_dict()) == 23
+    assert all(bool((p == 0.25).all()) for p in det.backbone.srf_module.parameters())
+    assert torch.equal(det.backbone.fpn_lateral2.weight, before)
+    # stage 2 -> stage 3: only srf_module tensors travel
+    det2 = Detector()
+    matched2 = ck.load_target_detector_weights(det2, det.state_dict())
+    assert len(matched2) == 23 and all(bool((p == 0.25).all()) for p in det2.backbone.srf_module.parameters())
+    assert not torch.equal(det2.backbone.fpn_lateral2.weight, det.backbone.fpn_lateral2.weight)

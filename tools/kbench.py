@@ -17,7 +17,7 @@ def t(fn, iters=10, warm=3):
 cases = [("D2@P3", 2, 100, 168, 1024, 1024), ("D1@P2", 2, 200, 336, 512, 1024), ("D0@P2", 2, 200, 336, 256, 512), ("G0@lrP2", 2, 104, 168, 256, 256),
          ("RDBc1@lrP2", 2, 104, 168, 256, 32), ("RDBc5@lrP2", 2, 104, 168, 384, 256), ("D2@P4", 2, 50, 84, 1024, 1024), ("G9@cfg1", 1, 50, 68, 256, 256), ("G0@cfg1", 1, 25, 34, 256, 256)]
 which = sys.argv[1:] or ["fwd", "dgrad", "wgrad"]
-for name, N, H, W, Ci, Co in cases:
+for name, N, H, W, Ci, Co in (cases if set(which) & {"fwd", "dgrad", "wgrad"} else []):
     x = ops.new_pixel_major(N, Ci, H, W, "cuda"); x.normal_()
     w = ops.new_ohwi(Co, Ci, 3, 3, "cuda", zero=False); w.normal_(0, 0.02)
     dy = ops.new_pixel_major(N, Co, H, W, "cuda"); dy.normal_()
@@ -28,3 +28,19 @@ for name, N, H, W, Ci, Co in cases:
     if "dgrad" in which: ms = t(lambda: ops.conv3x3_dgrad(dy, w, dx=dx)); r.append(f"dgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
     if "wgrad" in which: ms = t(lambda: ops.conv3x3_wgrad(dy, x, dw=dw)); r.append(f"wgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
     print(f"{name:12s} N{N} {H}x{W} {Ci}->{Co}: " + " | ".join(r), flush=True)
+
+# stride-2 3x3 conv (PAFPN bottom-up): input sizes of P2 -> P3, P3 -> P4 at the config-2 / 800x1344 image sizes
+if "s2" in which:
+    for name, N, Hi, Wi, Ci, Co in [("PA ds3", 2, 200, 336, 256, 256), ("PA ds4", 2, 100, 168, 256, 256), ("PA ds5", 2, 50, 84, 256, 256)]:
+        Ho, Wo = (Hi + 1) // 2, (Wi + 1) // 2
+        x = ops.new_pixel_major(N, Ci, Hi, Wi, "cuda"); x.normal_()
+        w = ops.new_ohwi(Co, Ci, 3, 3, "cuda", zero=False); w.normal_(0, 0.02)
+        dy = ops.new_pixel_major(N, Co, Ho, Wo, "cuda"); dy.normal_()
+        inter = ops.new_pixel_major(N, Co, Ho, Wo, "cuda"); inter.normal_()
+        dx = ops.new_pixel_major(N, Ci, Hi, Wi, "cuda"); dw = ops.new_ohwi(Co, Ci, 3, 3, "cuda")
+        fl = 2.0 * N * Ho * Wo * Ci * Co * 9
+        r = []
+        ms = t(lambda: ops.conv3x3s2_fwd(x, w, None, act=2, add=inter, keep_act=True)); r.append(f"fwd {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+        ms = t(lambda: ops.conv3x3s2_dgrad(dy, w, (Hi, Wi), dx=dx)); r.append(f"dgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+        ms = t(lambda: ops.conv3x3s2_wgrad(dy, x, dw=dw)); r.append(f"wgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+        print(f"{name:12s} N{N} {Hi}x{Wi}->{Ho}x{Wo} {Ci}->{Co}: " + " | ".join(r), flush=True)
