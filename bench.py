@@ -80,9 +80,11 @@ def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
     t0 = time.perf_counter()
     for _ in range(iters):
         one()
+    t_enq = (time.perf_counter() - t0) / iters             # host time to enqueue one iteration (no sync)
     torch.cuda.synchronize()
     dt_eager = dt = (time.perf_counter() - t0) / iters
     mode = "eager"
+    dt_graph = None
     if graph:
         try:
             g = torch.cuda.CUDAGraph()
@@ -103,6 +105,7 @@ def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
     out_px = N * 4 * H * W
     flop = 3 * G_FWD_FLOP_PER_INPX * N * H * W
     return {"shape": f"{N}x256x{H}x{W}->{N}x256x{2 * H}x{2 * W}", "launch": mode, "ms": dt * 1e3, "ms_eager": dt_eager * 1e3,
+            "ms_graph": None if dt_graph is None else dt_graph * 1e3, "ms_host_enqueue": t_enq * 1e3,
             "out_mpix_per_s": out_px / dt / 1e6, "in_mpix_per_s": out_px / 4 / dt / 1e6, "tflops": flop / dt / 1e12,
             "frac_of_fp32_mfma_peak": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 

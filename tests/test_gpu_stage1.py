@@ -115,6 +115,47 @@ def test_stage1_small_ragged_vs_oracle(amd, reuse):
     assert all(np.isfinite(v) for v in step.metrics().values())
 
 
+def test_stage1_trajectory_four_iterations_vs_oracle(amd):
+    """Four consecutive iterations with the LR warm-up and a decay step inside the window, momentum and weight decay
+    (stage1_trainer.py:110-125,336-433): per-iteration losses and the final weights / BN running statistics follow the
+    oracle's trajectory, i.e. the optimizer state, the schedule and the buffer updates carry over correctly between steps."""
+    C, g = 16, 4
+    gp = orc.closed_form_generator_params(C, 3, g)
+    dp = orc.closed_form_discriminator_params(C)
+    G = amd.Generator(in_channels=C, n_residual_dense_blocks=3, growth_rate=g).cuda()
+    D = amd.Discriminator(in_filters=C).cuda()
+    G.load_state_dict(gp); D.load_state_dict(dp)
+    gen = torch.Generator().manual_seed(11)
+    sched = dict(lr_steps=(3,), lr_gamma=0.5, warmup_factor=0.1, warmup_iters=2)
+    step = amd.Stage1Step(G, D, base_lr=0.02, **sched)
+    g_bufs, d_bufs_m = {}, {}
+    for it in range(4):
+        lr_f = [torch.randn((2, C, 7, 11), generator=gen), torch.randn((2, C, 4, 6), generator=gen)]
+        hr_f = [torch.randn((2, C, 13, 21), generator=gen), torch.randn((2, C, 8, 12), generator=gen)]
+        step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
+        m = step.metrics()
+        lr = orc.warmup_multistep_lr(0.02, it, steps=(3,), gamma=0.5, warmup_factor=0.1, warmup_iters=2)
+        d_losses, d_grads, d_bufs = orc.stage1_d_phase(gp, dp, lr_f, hr_f, first_level=2)
+        dparams = {k: v for k, v in dp.items() if k in d_grads}
+        orc.sgd_momentum_step(dparams, d_grads, d_bufs_m, lr=lr)
+        dp = dict(dp); dp.update(dparams); dp.update(d_bufs)
+        g_losses, g_grads, d_bufs2 = orc.stage1_g_phase(gp, dp, lr_f, hr_f, first_level=2)
+        dp.update(d_bufs2)
+        gparams = dict(gp)
+        orc.sgd_momentum_step(gparams, g_grads, g_bufs, lr=lr)
+        gp = gparams
+        for k, v in list(d_losses.items()) + list(g_losses.items()):
+            assert abs(m[k] - v) <= 2e-3 * abs(v), (it, k, m[k], v)
+    for k, p in G.named_parameters():
+        assert ((p.detach().cpu() - gp[k]).abs().max() / gp[k].abs().max()).item() < 1e-3, k
+    sd = D.state_dict()
+    for k, v in dp.items():
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v) == 4 * 4 * 2, k                      # 4 D forwards per level per iteration (Q2)
+        else:
+            assert ((sd[k].cpu() - v).abs().max() / (v.abs().max() + 1e-30)).item() < 2e-3, k
+
+
 def _dp_gpu_worker(rank, world, port, tmp):
     """Two ranks share the one GPU of the test box and talk over gloo (RCCL needs one GPU per rank): exercises the real
     distributed code path of Stage1Step (broadcast, flat-buffer all-reduce, fused SGD with 1/world) on the HIP kernels."""
