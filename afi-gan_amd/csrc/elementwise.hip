@@ -161,14 +161,35 @@ __global__ __launch_bounds__(256) void afi_colred_partial_kernel(const float* __
     }
 }
 
+// Sum the per-chunk partials [chunks][2][C] of one channel: a 256-thread block owns 32 channels, 8 threads per channel take
+// every 8th chunk (independent loads in flight) and are combined through LDS in a fixed order (bit-reproducible).  The serial
+// one-thread-per-channel loop this replaces cost ~35 us per call (256 dependent L2 round trips), ~90 calls per stage-1 step.
+#define AFI_FIN_CH 32
+__device__ __forceinline__ bool afi_chunk_sums(const float* __restrict__ partial, int chunks, int C, bool two, int& c, float& s0, float& s1) {
+    __shared__ float red[2][8][AFI_FIN_CH];
+    const int cl = threadIdx.x & (AFI_FIN_CH - 1), ln = threadIdx.x / AFI_FIN_CH;
+    c = blockIdx.x * AFI_FIN_CH + cl;
+    float a0 = 0.f, a1 = 0.f;
+    if (c < C)
+        for (int i = ln; i < chunks; i += 8) {
+            a0 += partial[(long long)i * 2 * C + c];
+            if (two) a1 += partial[(long long)i * 2 * C + C + c];
+        }
+    red[0][ln][cl] = a0; red[1][ln][cl] = a1;
+    __syncthreads();
+    if (ln != 0 || c >= C) return false;
+    s0 = 0.f; s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0 += red[0][j][cl]; s1 += red[1][j][cl]; }
+    return true;
+}
+
 // BatchNorm statistics finalize: mean / invstd for this call + running-stat update (momentum 0.1, unbiased var)
 __global__ void afi_bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, const float* __restrict__ x0, long long P, int C,
                                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
                                              float* __restrict__ running_mean, float* __restrict__ running_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s0 = 0.f, s1 = 0.f;
-    for (int i = 0; i < chunks; ++i) { s0 += partial[(long long)i * 2 * C + c]; s1 += partial[(long long)i * 2 * C + C + c]; }
+    int c; float s0, s1;
+    if (!afi_chunk_sums(partial, chunks, C, true, c, s0, s1)) return;
     const float inv_n = 1.f / (float)P;
     const float d = s0 * inv_n;                     // mean - K
     const float m = x0[c] + d;
@@ -205,10 +226,8 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
 // BatchNorm backward finalize: dgamma += sum g*xhat ; dbeta += sum g ; stash the two sums for the apply pass
 __global__ void afi_bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float gscale,
                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s0 = 0.f, s1 = 0.f;
-    for (int i = 0; i < chunks; ++i) { s0 += partial[(long long)i * 2 * C + c]; s1 += partial[(long long)i * 2 * C + C + c]; }
+    int c; float s0, s1;
+    if (!afi_chunk_sums(partial, chunks, C, true, c, s0, s1)) return;
     sums[c] = s0; sums[C + c] = s1;
     if (dbeta) dbeta[c] += gscale * s0;
     if (dgamma) dgamma[c] += gscale * s1;
@@ -231,10 +250,8 @@ __global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float
 }
 // bias gradient finalize: db += alpha * sum
 __global__ void afi_colsum_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float alpha, float* __restrict__ db) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s0 = 0.f;
-    for (int i = 0; i < chunks; ++i) s0 += partial[(long long)i * 2 * C + c];
+    int c; float s0, s1;
+    if (!afi_chunk_sums(partial, chunks, C, false, c, s0, s1)) return;
     db[c] += alpha * s0;
 }
 
@@ -260,7 +277,7 @@ int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* 
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     hipLaunchKernelGGL((afi_colred_partial_kernel<0>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, (long long)C, rpc, scratch);
-    hipLaunchKernelGGL(afi_bn_stats_finalize_kernel, dim3(afi_cdiv(C, 256)), dim3(256), 0, st, scratch, chunks, x, P, C, mean, invstd,
+    hipLaunchKernelGGL(afi_bn_stats_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, x, P, C, mean, invstd,
                        var_out, running_mean, running_var);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
@@ -276,7 +293,7 @@ int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* me
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     float* sums = scratch + (long long)AFI_RED_MAX_CHUNKS * 2 * C;
     hipLaunchKernelGGL((afi_colred_partial_kernel<1>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch);
-    hipLaunchKernelGGL(afi_bn_bwd_finalize_kernel, dim3(afi_cdiv(C, 256)), dim3(256), 0, st, scratch, chunks, C, gscale, dgamma, dbeta, sums);
+    hipLaunchKernelGGL(afi_bn_bwd_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, C, gscale, dgamma, dbeta, sums);
     hipLaunchKernelGGL(afi_bn_bwd_apply_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
@@ -285,7 +302,7 @@ int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, fl
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     hipLaunchKernelGGL((afi_colred_partial_kernel<2>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, (const float*)nullptr, g,
                        (const float*)nullptr, (const float*)nullptr, P, C, ld, rpc, scratch);
-    hipLaunchKernelGGL(afi_colsum_finalize_kernel, dim3(afi_cdiv(C, 256)), dim3(256), 0, st, scratch, chunks, C, alpha, db);
+    hipLaunchKernelGGL(afi_colsum_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, C, alpha, db);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

@@ -4,10 +4,10 @@ set -e
 P=${1:?usage: make_r01.sh gpurun_out/prof_dir}
 D=profiles/r01
 mkdir -p $D
-cp $P/trace/runc/*_kernel_stats.csv $D/kernel_stats_bench_steps3_warmup0.csv
+cp $(find $P/trace -name "*kernel_stats.csv" | head -1) $D/kernel_stats_bench_steps3_warmup0.csv
 grep '^{' $P/bench_trace.log > $D/bench_line_under_rocprof_steps3_warmup0.json
-python profiles/summarize_pmc.py $P/pmc_fetch/runc/*_counter_collection.csv $P/pmc_write/runc/*_counter_collection.csv > $D/pmc_hbm_fetch_write_steps1.csv
-python profiles/summarize_pmc.py $P/pmc_sq/runc/*_counter_collection.csv > $D/pmc_sq_steps1.csv
+python profiles/summarize_pmc.py $(find $P/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $P/pmc_write -name "*counter_collection.csv" | head -1) > $D/pmc_hbm_fetch_write_steps1.csv
+python profiles/summarize_pmc.py $(find $P/pmc_sq -name "*counter_collection.csv" | head -1) > $D/pmc_sq_steps1.csv
 python - <<'PY'
 import json, csv
 rows = list(csv.DictReader(open('profiles/r01/pmc_hbm_fetch_write_steps1.csv')))
