@@ -363,10 +363,11 @@ def main():
         "losses_last_step": {k: round(v, 5) for k, v in metrics.items()},
     }
     log("AF-interpolator micro-benchmark")
-    if not args.no_interp:
+    micro = not args.no_interp and world == 1             # single-GPU metrics: reported on the N=1 line only
+    if micro:
         line["af_interpolator"] = {"metric": "AF-interpolator fwd+bwd feature-Mpix/s (256ch P5->P4)",
                                    "cfg1": interp_bench(amd, torch, 1, 25, 34), "batch16": interp_bench(amd, torch, 16, 25, 34, iters=20, warmup=5)}
-    if not args.no_interp:
+    if micro:
         log("FPN_AFIGAN top-down merge (SURVEY 8f row 1)")
         line["fpn_topdown"] = fpn_bench(amd, torch)
         line["pafpn"] = fpn_bench(amd, torch, pafpn=True)
