@@ -87,6 +87,7 @@ SIGNATURES = {
     "afi_scale_inplace": (_i, [_vp, _ll, _f, _vp]),
     "afi_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "afi_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "afi_set_op_scratch": (_i, [_vp, _ll]),
     "afi_profile_enable": (_i, [_i]),
     "afi_profile_num_kinds": (_i, []),
     "afi_profile_kind_name": (C.c_char_p, [_i]),

@@ -61,7 +61,7 @@ struct AfiPixGemm {
     int lrelu;          // activation on v: 0 none, 1 LeakyReLU(0.2), 2 ReLU
     AfiView Z; int z_lo, z_hi;                 // multiply by (Z > 0 ? 1 : 0.2) for channels in [z_lo, z_hi)
     // split-K scratch (optional): [splitK][M][roundup4(Ncols)] partial slabs; the launcher picks splitK and fills it in
-    float* partial; long long partial_floats; int splitK;
+    float* partial; long long partial_floats; int splitK; int kper;   // kper: K stages per split (set by the launcher)
 };
 
 // Parameters of the weight-gradient GEMM:  dW[co'][tap][ci] += alpha * sum_pix dY[pix][co'] * X[pix+tap][ci]

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_
     const int cchunks = (p.Ck + BK - 1) / BK;
     const int nK_total = p.ntaps * p.nKphase * cchunks;
     // split-K (blockIdx.y): this block multiplies stages [kc0, kc0 + nK) and leaves the raw partial tile in its slab
-    const int kper = (nK_total + p.splitK - 1) / p.splitK;
+    const int kper = p.kper;
     const int kc0 = blockIdx.y * kper;
     const int nK = min(kper, nK_total - kc0);
     if (nK <= 0) return;                                  // (uniform) cannot happen with the launcher's splitK choice
@@ -426,7 +426,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_
             const f32x4 accv = *(const f32x4*)(Cs + rloc * LDC + 4 * c4);
             if (p.splitK > 1) {
                 const int ldp = (p.Ncols + 3) & ~3;
-                *(f32x4*)(p.partial + ((long long)blockIdx.y * M + (m0 + rl)) * ldp + col) = accv;
+                // slab row = the pixel's linear index (the halo variant's tile rows are patch-major, not linear)
+                const long long mrow = HALO ? ((long long)img * p.H + rowtab[BM + rl]) * p.W + rowtab[2 * BM + rl] : (long long)(m0 + rl);
+                *(f32x4*)(p.partial + ((long long)blockIdx.y * M + mrow) * ldp + col) = accv;
             } else {
                 afi_epilogue_store<GTAP>(p, img, rowtab[BM + rl], rowtab[2 * BM + rl], col, accv);
             }
@@ -688,6 +690,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     AfiPixGemm q = p;
     q.splitK = 1;
     const int nK = p.ntaps * p.nKphase * afi_cdiv(p.Ck, BK);
+    q.kper = nK;
     if (!HALO && p.partial && ntiles < 512) {
         int sk = afi_cdiv(1024, ntiles);
         if (sk > nK / 4) sk = nK / 4;
@@ -696,7 +699,20 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
         if (sk > 1) {
             const int kper = afi_cdiv(nK, sk);
             q.splitK = afi_cdiv(nK, kper);                // no empty splits
+            q.kper = kper;
         }
+    }
+    // split-K for MID-SIZE maps on the 128x128 tiles (0.5 .. 6 tiles per CU): whole tiles quantise badly onto 256 CUs x 3
+    // resident blocks (546 tiles = 2.13 per CU run as long as 3 per CU: 93 of the kernel's 130 TFLOP/s; 264 tiles: 62), so cut
+    // every tile's K range in 3-4 so the dispatcher has small pieces to balance with.  Measured (fwd, incl. the reduction
+    // pass): 264 tiles 62 -> 85 TFLOP/s, 546: 93 -> 109, 1050: 104 -> 115; from ~1500 tiles on it only costs slab traffic.
+    if (BM == 128 && BN == 128 && q.splitK == 1 && p.partial && ntiles >= 128 && ntiles < 1536) {
+        int kper = afi_cdiv(nK, ntiles < 768 ? 4 : 3);
+        if (HALO) kper = afi_cdiv(kper, 9) * 9;            // a split must start on a channel-chunk boundary (the halo is fetched at tap 0)
+        if (kper < 9) kper = 9;
+        const int sk = afi_cdiv(nK, kper);
+        const long long slab = M * ((p.Ncols + 3) & ~3);
+        if (sk > 1 && slab * sk <= p.partial_floats) { q.splitK = sk; q.kper = kper; }
     }
     hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO, GTAP>), dim3(chunk * ntn * 8, q.splitK), dim3(64 * WM * WN), lds, st, q, ntn, ntiles, chunk);
     if (q.splitK > 1) {
@@ -707,8 +723,18 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
+// Optional split-K scratch for the per-op entry points (the whole-net calls carve theirs out of the caller's workspace)
+namespace { float* g_op_scratch = nullptr; long long g_op_scratch_floats = 0; }
+extern "C" int afi_set_op_scratch(float* p, long long floats) {
+    if (floats < 0 || (floats > 0 && !p)) return AFI_ERR_BAD_ARG;
+    g_op_scratch = floats > 0 ? p : nullptr;
+    g_op_scratch_floats = floats > 0 ? floats : 0;
+    return AFI_OK;
+}
+
 int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
-    const AfiPixGemm& p = p_in;
+    AfiPixGemm p = p_in;
+    if (!p.partial && g_op_scratch) { p.partial = g_op_scratch; p.partial_floats = g_op_scratch_floats; }
     const long long M = (long long)p.N * p.H * p.W;
     if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
     if (b_rc && (p.Ncols & 3)) return AFI_ERR_UNSUPPORTED;       // RC weight rows are read as float4 along n

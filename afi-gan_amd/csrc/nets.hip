@@ -6,6 +6,7 @@
 
 #include "../../include/afigan_hip.h"
 #include "afi_common.h"
+#include <initializer_list>
 
 // ---- launchers implemented in igemm.hip / elementwise.hip
 int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st);
@@ -335,11 +336,18 @@ int afi_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, void* str
 
 // ------------------------------------------------------------------------------------------------ generator
 // forward workspace layout (floats):  [Wp 36*C*C][buf_r : n_rdb x P*L][t : P*C][a7 : P*C][u : 4P*C]     L = C + 4G
-// split-K scratch shared by the small-map GEMMs of one call: room for 16 slabs of the largest layer, capped at 18 MB
-static long long part_floats(long long max_mn) {
+// split-K scratch shared by the GEMMs of one call (they run one after the other on the caller's stream): small maps get
+// room for 16 slabs of the largest layer, capped at 18 MB; mid-size maps (< 1536 tiles of 128x128, launch_pix's second rule)
+// 4 slabs of the largest layer (at most 4 x 25 M floats = 400 MB)
+static long long part_floats(std::initializer_list<long long> layer_mn) {   // M x Ncols of every GEMM output of the call
     const long long cap = 4608LL * 1024;
-    const long long want = 16 * max_mn;
-    return align4(want < cap ? want : cap);
+    long long want = 0;
+    for (long long mn : layer_mn) {
+        const long long small = 16 * mn < cap ? 16 * mn : cap;
+        if (small > want) want = small;
+        if (mn < 1536LL * 128 * 128 && 4 * mn > want) want = 4 * mn;
+    }
+    return align4(want);
 }
 struct GenWs {
     long long P, L;
@@ -354,7 +362,7 @@ static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_t = o; o += align4(w.P * C);
     w.o_a7 = o; o += align4(w.P * C);
     w.o_u = o; o += align4(4 * w.P * C);
-    w.n_part = part_floats(4 * w.P * C);
+    w.n_part = part_floats({w.P * C, 4 * w.P * C});
     w.o_part = o; o += w.n_part;
     w.total = o;
     return w;
@@ -376,7 +384,7 @@ static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_db1 = o;
     w.o_dwp = o; o += align4(36LL * C * C);
     w.o_red = o; o += align4(afi_reduce_scratch_floats(C));
-    w.n_part = part_floats(4 * P * C);
+    w.n_part = part_floats({P * C, P * L, 4 * P * C});
     w.o_part = o; o += w.n_part;
     w.total = o;
     return w;
@@ -573,7 +581,7 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
         w.o_invstd[n] = o; o += align4(F[n + 1]);
     }
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));
-    w.n_part = part_floats(w.P * fmax);
+    w.n_part = part_floats({w.P * F[1], w.P * F[2], w.P * F[3]});
     w.o_part = o; o += w.n_part;
     w.total = o;
     return w;
@@ -590,7 +598,7 @@ static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     w.o_dd9 = o; o += align4(P * 16);
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));       // BatchNorm backward (main stream)
     w.o_red2 = o; o += align4(afi_reduce_scratch_floats(fmax));      // bias column sums (side stream)
-    w.n_part = part_floats(P * fmax);
+    w.n_part = part_floats({P * F[0], P * F[1], P * F[2], P * F[3]});
     w.o_part = o; o += w.n_part;
     w.total = o;
     return w;

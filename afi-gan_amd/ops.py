@@ -89,8 +89,27 @@ def _p(t):
 
 
 # ------------------------------------------------------------------------------------------------ convs
+_OP_SCRATCH = {}
+OP_SCRATCH_FLOATS = 100 * 1024 * 1024          # 400 MB: 4 slabs of the largest map that is split (1536 tiles of 128x128)
+
+
+def _ensure_op_scratch(device):
+    """Split-K scratch for the per-op conv calls (include/afigan_hip.h: afi_set_op_scratch): one buffer per device, registered
+    once; all per-op calls of this package are issued on the current stream, one after the other."""
+    key = torch.device(device).index or 0
+    buf = _OP_SCRATCH.get(key)
+    if buf is None:
+        buf = torch.empty(OP_SCRATCH_FLOATS, device=device, dtype=torch.float32)
+        _OP_SCRATCH[key] = buf
+    if _OP_SCRATCH.get("registered") != key:
+        call("afi_set_op_scratch", C.c_void_p(buf.data_ptr()), buf.numel())
+        _OP_SCRATCH["registered"] = key
+    return buf
+
+
 def conv3x3_fwd(x, w, bias=None, lrelu=False, out=None, alpha=1.0, beta=0.0):
     _check_cuda(x, w, bias, out)
+    _ensure_op_scratch(x.device)
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     w = ohwi(w)
@@ -103,6 +122,7 @@ def conv3x3_fwd(x, w, bias=None, lrelu=False, out=None, alpha=1.0, beta=0.0):
 
 def conv3x3_dgrad(dy, w, dx=None, alpha=1.0, beta=0.0, z=None):
     _check_cuda(dy, w, dx, z)
+    _ensure_op_scratch(dy.device)
     N, Cout, H, W = dy.shape
     Cin = w.shape[1]
     w = ohwi(w)
@@ -128,6 +148,7 @@ def conv3x3s2_fwd(x, w, bias=None, act=0, add=None, add_scale=1.0, post_scale=1.
     """Conv2d(k3, s2, p1) with the fused PAFPN merge:  a = act(conv(x, w) + bias);  out = post_scale*a + add_scale*add.
     act: 0 none, 1 LeakyReLU(0.2), 2 ReLU.  Returns out, or (out, a) with keep_act (a is what the ReLU backward needs)."""
     _check_cuda(x, w, bias, add)
+    _ensure_op_scratch(x.device)
     N, Cin, Hi, Wi = x.shape
     Cout = w.shape[0]
     w = ohwi(w)
@@ -145,6 +166,7 @@ def conv3x3s2_fwd(x, w, bias=None, act=0, add=None, add_scale=1.0, post_scale=1.
 def conv3x3s2_dgrad(dy, w, in_hw, dx=None, alpha=1.0, beta=0.0):
     """dx [N,Cin,Hi,Wi] = alpha * (data gradient of Conv2d(k3,s2,p1)) + beta*dx;  in_hw = (Hi, Wi) of the conv's input."""
     _check_cuda(dy, w, dx)
+    _ensure_op_scratch(dy.device)
     N, Cout, Ho, Wo = dy.shape
     Hi, Wi = in_hw
     if ((Hi + 1) // 2, (Wi + 1) // 2) != (Ho, Wo):
@@ -182,6 +204,7 @@ def relu_bwd(g, act, scale=1.0):
 def conv1x1_fwd(x, w, bias=None, add=None, add_scale=1.0, alpha=1.0, out=None):
     """out = alpha*conv1x1(x, w) + bias + add_scale*add;  w: [Cout, Cin] or [Cout, Cin, 1, 1]."""
     _check_cuda(x, w, bias, add, out)
+    _ensure_op_scratch(x.device)
     N, Cin, H, W = x.shape
     Cout = w.shape[0]
     w2 = w.reshape(Cout, Cin).contiguous()
@@ -194,6 +217,7 @@ def conv1x1_fwd(x, w, bias=None, add=None, add_scale=1.0, alpha=1.0, out=None):
 
 def conv1x1_dgrad(dy, w, dx=None, alpha=1.0, beta=0.0):
     _check_cuda(dy, w, dx)
+    _ensure_op_scratch(dy.device)
     N, Cout, H, W = dy.shape
     Cin = w.shape[1]
     w2 = w.reshape(Cout, Cin).contiguous()

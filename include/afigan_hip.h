@@ -179,6 +179,13 @@ int afi_scale_inplace(float* p, long long n, float s, void* stream);
 int afi_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, void* stream);
 int afi_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, void* stream);
 
+/* Optional caller-owned scratch for the PER-OP convolution entry points (afi_conv3x3_*, afi_conv1x1_*, afi_conv3x3s2_*,
+ * afi_convT6s2_*): with it, small and mid-size maps (< 6 tiles of 128x128 per CU) run split-K with a deterministic second
+ * pass.  One buffer per process: it serves the launches of ONE stream at a time (the whole-net entry points do not use it,
+ * they carve their split-K scratch out of the workspace they are given).  floats == 0 unregisters.  256 MB covers every
+ * shape that is split. */
+int afi_set_op_scratch(float* scratch, long long floats);
+
 /* ------------------------------------------------------------------ measurement support (bench.py)
  * When enabled, every MFMA GEMM launch is bracketed by two hipEvents recorded on the launch stream.
  * afi_profile_get(kind, out): out[0] launches, out[1] total ms, out[2] total algorithmic FLOP of that kernel since
