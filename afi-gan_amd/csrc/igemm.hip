@@ -780,6 +780,23 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
         const long long want = 1024;
         if (tiles < want) splitK = (int)((want + tiles - 1) / tiles);
         const int maxsplit = (int)((P + 8 * AFI_BK - 1) / (8 * AFI_BK));
+        // Balance: the split is free here (partial sums meet in atomics), so pick the one whose block count fills whole
+        // rounds of the chip's resident slots (256 CUs x 3 blocks): 2-6 rounds, best fill, fewest splits on ties.  "Cover the chip
+        // ~4x" alone left 1.4-1.5 rounds for every big layer (D1: 288 tiles x 4 = 1152 blocks on 768 slots).
+        static const int bal = afi_env_int("AFI_WG_BAL", 1);
+        if (bal && BM == 128) {
+            const long long slots = 768;
+            double best = -1.0; int best_s = 0;
+            for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {
+                const long long blocks = tiles * s2;
+                if (blocks < 2 * slots) continue;
+                if (blocks > 6 * slots) break;
+                const long long rounds = (blocks + slots - 1) / slots;
+                const double fill = (double)blocks / (double)(rounds * slots);
+                if (fill > best + 1e-3) { best = fill; best_s = s2; }
+            }
+            if (best_s > 0) splitK = best_s;
+        }
         if (splitK > maxsplit) splitK = maxsplit;
         if (splitK < 1) splitK = 1;
     }
