@@ -619,10 +619,11 @@ struct ProfState {
     size_t used = 0;
 } g_prof;
 const char* kKindNames[] = {
-    "pix_gemm<128x128,KC> (conv fwd)", "pix_gemm<128x64,KC>", "pix_gemm<128x32,KC>", "pix_gemm<64x64,KC>",
-    "pix_gemm<128x128,RC> (conv dgrad)", "pix_gemm<128x64,RC>", "pix_gemm<128x32,RC>", "pix_gemm<64x64,RC>",
-    "wgrad_gemm<128x128>", "wgrad_gemm<64x128>", "wgrad_gemm<32x128>"};
-constexpr int kNumKinds = 11;
+    "pix_gemm<128x128,KC,linear> (conv fwd, mid-size / ragged maps)", "pix_gemm<128x64,KC>", "pix_gemm<128x32,KC>", "pix_gemm<64x64,KC>",
+    "pix_gemm<128x128,RC,linear> (conv dgrad, mid-size / ragged maps)", "pix_gemm<128x64,RC>", "pix_gemm<128x32,RC>", "pix_gemm<64x64,RC>",
+    "wgrad_gemm<128x128>", "wgrad_gemm<64x128>", "wgrad_gemm<32x128>",
+    "pix_gemm<128x128,KC,halo> (conv fwd)", "pix_gemm<128x128,RC,halo> (conv dgrad)"};   // one kind per kernel instantiation, as rocprofv3 lists them
+constexpr int kNumKinds = 13;
 hipEvent_t prof_event() {
     if (g_prof.used == g_prof.pool.size()) {
         hipEvent_t e;
@@ -678,7 +679,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const int ntiles = ntm * ntn;
     const int chunk = afi_cdiv(ntm, 8);                           // M tiles per XCD; grid = 8 XCDs x chunk x ntn
     const size_t lds = sizeof(float) * ((HALO ? AFI_HALO_PIX : BM) * (BK + 4) + (B_RC ? BK * BN : BN * (BK + 4))) + sizeof(int) * 3 * BM;
-    const int kind = (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
+    const int kind = HALO ? (B_RC ? 12 : 11) : (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
         static const hipError_t attr = hipFuncSetAttribute((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO, GTAP>,
@@ -748,7 +749,7 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     }
     if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;
     // tile choice: fill the N side first (weights are shared by every block), shrink M tiles for small maps
-    const bool smallM = M <= 64 * 256;                           // <= 16 K pixels: 64x64 tiles (measured 99 vs 87 TFLOP/s at P4)
+    const bool smallM = M <= 2048;                               // tiny maps: 64x64 tiles; above, 128x128 tiles + the mid-size split-K win (D fwd+bwd at P4: 7.46 -> 7.04 ms)
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work
     static const int halo_on = afi_env_int("AFI_HALO", 1);
     const long long padded = (long long)p.N * afi_cdiv(p.H, AFI_HALO_TY) * AFI_HALO_TY * afi_cdiv(p.W, AFI_HALO_TX) * AFI_HALO_TX;
