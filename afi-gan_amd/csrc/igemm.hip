@@ -749,7 +749,8 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     }
     if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;
     // tile choice: fill the N side first (weights are shared by every block), shrink M tiles for small maps
-    const bool smallM = M <= 2048;                               // tiny maps: 64x64 tiles; above, 128x128 tiles + the mid-size split-K win (D fwd+bwd at P4: 7.46 -> 7.04 ms)
+    // tiny problems (< 128 tiles of 128x128): 64x64 tiles; from there on 128x128 tiles + the mid-size split-K (D fwd+bwd at P4: 7.46 -> 7.04 ms)
+    const bool smallM = (long long)afi_cdiv(M, 128) * afi_cdiv(p.Ncols, 128) < 128;
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work
     static const int halo_on = afi_env_int("AFI_HALO", 1);
     const long long padded = (long long)p.N * afi_cdiv(p.H, AFI_HALO_TY) * AFI_HALO_TY * afi_cdiv(p.W, AFI_HALO_TX) * AFI_HALO_TX;
