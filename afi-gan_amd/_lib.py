@@ -92,6 +92,7 @@ SIGNATURES = {
     "afi_profile_num_kinds": (_i, []),
     "afi_profile_kind_name": (C.c_char_p, [_i]),
     "afi_profile_get": (_i, [_i, C.POINTER(C.c_double)]),
+    "afi_profile_dump": (_i, [C.c_char_p]),
 }
 
 _lib = None

@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiW
 // ------------------------------------------------------------------------------------------------
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int kind; double flops; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops; long long m; int n, k, split; };
 struct ProfState {
     bool on = false;
     std::vector<ProfRec> recs;
@@ -634,11 +634,12 @@ hipEvent_t prof_event() {
 }
 struct ProfScope {
     hipStream_t st; int kind; double flops; hipEvent_t a{};
-    ProfScope(hipStream_t s, int k, double f) : st(s), kind(k), flops(f) {
+    long long m = 0; int n = 0, k = 0, split = 1;         // GEMM shape of the launch (rows, columns, K; split-K factor), for afi_profile_dump
+    ProfScope(hipStream_t s, int kd, double f) : st(s), kind(kd), flops(f) {
         if (g_prof.on) { a = prof_event(); (void)hipEventRecord(a, st); }
     }
     ~ProfScope() {
-        if (g_prof.on) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops}); }
+        if (g_prof.on) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops, m, n, k, split}); }
     }
 };
 }  // namespace
@@ -663,6 +664,21 @@ extern "C" int afi_profile_get(int kind, double* out) {
     return AFI_OK;
 }
 
+// one CSV line per recorded launch: kind,rows,cols,k,split,ms,tflops  (analysis aid: which shapes fill a kind's bucket)
+#include <stdio.h>
+extern "C" int afi_profile_dump(const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) return AFI_ERR_BAD_ARG;
+    fprintf(f, "kind,rows,cols,k,split,ms,tflops\n");
+    for (const ProfRec& r : g_prof.recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { fclose(f); return AFI_ERR_LAUNCH; }
+        fprintf(f, "\"%s\",%lld,%d,%d,%d,%.4f,%.2f\n", kKindNames[r.kind], r.m, r.n, r.k, r.split, ms, ms > 0.f ? r.flops / (ms * 1e-3) / 1e12 : 0.0);
+    }
+    fclose(f);
+    return AFI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
@@ -681,6 +697,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const size_t lds = sizeof(float) * ((HALO ? AFI_HALO_PIX : BM) * (BK + 4) + (B_RC ? BK * BN : BN * (BK + 4))) + sizeof(int) * 3 * BM;
     const int kind = HALO ? (B_RC ? 12 : 11) : (B_RC ? 4 : 0) + (BM == 64 ? 3 : (BN == 128 ? 0 : (BN == 64 ? 1 : 2)));
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
+    prof.m = M; prof.n = p.Ncols; prof.k = p.ntaps * p.nKphase * p.Ck;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
         static const hipError_t attr = hipFuncSetAttribute((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO, GTAP>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -715,6 +732,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
         const long long slab = M * ((p.Ncols + 3) & ~3);
         if (sk > 1 && slab * sk <= p.partial_floats) { q.splitK = sk; q.kper = kper; }
     }
+    prof.split = q.splitK;
     hipLaunchKernelGGL((afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO, GTAP>), dim3(chunk * ntn * 8, q.splitK), dim3(64 * WM * WN), lds, st, q, ntn, ntiles, chunk);
     if (q.splitK > 1) {
         const long long items = M * (((p.Ncols + 3) & ~3) >> 2);
@@ -807,6 +825,7 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
     splitK = (int)((P + kper - 1) / kper);
     const size_t lds = sizeof(float) * AFI_BK * (BM + BN);
     ProfScope prof(st, BM >= 128 ? 8 : (BM == 64 ? 9 : 10), 2.0 * (double)P * p.Mrows * p.Ncols * p.ntaps);
+    prof.m = (long long)p.Mrows * p.ntaps; prof.n = p.Ncols; prof.k = (int)(P > 2147483647LL ? 2147483647LL : P); prof.split = splitK;
     if (lds >= 64 * 1024) {
         static const hipError_t attr = hipFuncSetAttribute((const void*)afi_wgrad_gemm_kernel<BM, BN, WM, WN>,
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -254,6 +254,7 @@ def convT_pack(w_iohw):
 
 
 def convT_fwd(x, wp, bias, Cout, lrelu=False):
+    _ensure_op_scratch(x.device)
     N, Cin, H, W = x.shape
     out = new_pixel_major(N, Cout, 2 * H, 2 * W, x.device)
     call("afi_convT6s2_fwd", view_of(x), N, H, W, Cin, _p(wp), _p(bias), Cout, view_of(out), int(lrelu), stream_ptr())
@@ -261,6 +262,7 @@ def convT_fwd(x, wp, bias, Cout, lrelu=False):
 
 
 def convT_dgrad(dy, wp, Cin, z=None):
+    _ensure_op_scratch(dy.device)
     N, Cout, H2, W2 = dy.shape
     H, W = H2 // 2, W2 // 2
     dx = new_pixel_major(N, Cin, H, W, dy.device)

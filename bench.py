@@ -299,6 +299,8 @@ def main():
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
     if rank == 0:
         lib.afi_profile_enable(0)
+        if os.environ.get("AFI_PROFILE_DUMP"):            # per-launch CSV (shape, split, ms) for offline analysis
+            lib.afi_profile_dump(os.environ["AFI_PROFILE_DUMP"].encode())
     metrics = step.metrics()                      # also the finite-loss check (_detect_anomaly)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)

@@ -194,6 +194,8 @@ int afi_profile_enable(int on);
 int afi_profile_num_kinds(void);
 const char* afi_profile_kind_name(int kind);
 int afi_profile_get(int kind, double* out3);
+/* one CSV line per recorded launch (kind, GEMM rows, columns, K, split-K factor, ms, TFLOP/s) */
+int afi_profile_dump(const char* path);
 
 #ifdef __cplusplus
 }

@@ -44,3 +44,17 @@ if "s2" in which:
         ms = t(lambda: ops.conv3x3s2_dgrad(dy, w, (Hi, Wi), dx=dx)); r.append(f"dgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
         ms = t(lambda: ops.conv3x3s2_wgrad(dy, x, dw=dw)); r.append(f"wgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
         print(f"{name:12s} N{N} {Hi}x{Wi}->{Ho}x{Wo} {Ci}->{Co}: " + " | ".join(r), flush=True)
+
+# ConvTranspose2d(k6, s2, p2) of the generator (4-phase 3x3 form): forward, data gradient (4 K-phases, stride-2 gather), weight gradient
+if "convT" in which:
+    for name, N, H, W, C_ in [("GT@lrP2", 2, 104, 168, 256), ("GT@lrP3", 2, 52, 84, 256), ("GT@cfg1", 1, 25, 34, 256)]:
+        x = ops.new_pixel_major(N, C_, H, W, "cuda"); x.normal_()
+        w = torch.randn(C_, C_, 6, 6, device="cuda") * 0.02
+        wp = ops.convT_pack(w)
+        dy = ops.new_pixel_major(N, C_, 2 * H, 2 * W, "cuda"); dy.normal_()
+        fl = 2.0 * N * H * W * C_ * C_ * 36
+        r = []
+        ms = t(lambda: ops.convT_fwd(x, wp, None, C_)); r.append(f"fwd {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+        ms = t(lambda: ops.convT_dgrad(dy, wp, C_)); r.append(f"dgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+        ms = t(lambda: ops.convT_wgrad(dy, x)); r.append(f"wgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
+        print(f"{name:12s} N{N} {H}x{W} {C_}->{C_}: " + " | ".join(r), flush=True)
