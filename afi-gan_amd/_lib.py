@@ -6,6 +6,11 @@ fallback: if the HIP library is missing or a call returns a non-zero status, an 
 import ctypes as C
 import os
 
+# torch FIRST: the ROCm wheel ships its own libamdhip64.so; importing torch before dlopen()ing libafigan_hip.so makes the
+# library's HIP dependency resolve to the runtime torch already loaded.  The other order maps a second HIP runtime into the
+# process, and every launch on one of torch's streams then fails ("HIP kernel launch failed" on the first call).
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFI_LIB_PATH") or os.path.join(_HERE, "csrc", "libafigan_hip.so")   # override: A/B kernel builds
 

@@ -184,4 +184,13 @@ class Generator(nn.Module):
         ops._check_cuda(features)
         if features.dim() != 4 or features.shape[1] != self.in_channels:
             raise _lib.AfiError(f"expected [N,{self.in_channels},H,W], got {tuple(features.shape)}")
+        if features.numel() == 0:
+            # empty batch / empty map (detectron2's Conv2d wrapper and torch >= 1.5 convs return an empty output of the right
+            # shape): nothing to launch; the zero-weighted parameter sum keeps every parameter in the autograd graph with a
+            # zero gradient, as the reference's empty-input path does for DDP
+            N, C_, H, W = features.shape
+            out = features.new_zeros((N, C_, 2 * H, 2 * W))
+            if torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in self.parameters())):
+                out = out + features.sum() * 0.0 + sum(p.reshape(-1)[0] for p in self.parameters() if p.requires_grad) * 0.0
+            return out
         return _GeneratorFn.apply(features, self, *self._ordered_params())

@@ -249,6 +249,21 @@ def test_frozen_generator_inside_a_graph(amd):
     assert sum(p.grad is not None for p in G.parameters()) == 1
 
 
+def test_generator_empty_batch(amd):
+    """N = 0 (a rank whose shard has no image / an empty proposal-level map): an empty output of the right shape, no launch,
+    zero gradients for every parameter (what the reference's conv stack returns for empty inputs)."""
+    G = amd.Generator(in_channels=16, n_residual_dense_blocks=2, growth_rate=4).cuda()
+    x = torch.zeros((0, 16, 5, 7), device="cuda", requires_grad=True)
+    out = G(x)
+    assert tuple(out.shape) == (0, 16, 10, 14)
+    out.sum().backward()
+    assert x.grad is not None and tuple(x.grad.shape) == (0, 16, 5, 7)
+    for k, p in G.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().sum()) == 0.0, k
+    with torch.no_grad():
+        assert tuple(G(torch.zeros((2, 16, 0, 7), device="cuda")).shape) == (2, 16, 0, 14)
+
+
 def test_error_paths(amd):
     G = amd.Generator(in_channels=16, growth_rate=4).cuda()
     with pytest.raises(amd.AfiError):
