@@ -74,6 +74,9 @@ SIGNATURES = {
     "afi_conv3x3s2_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, _vp]),
     "afi_conv3x3s2_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "afi_relu_bwd": (_i, [_vp, _vp, _vp, _ll, _f, _vp]),
+    "afi_dwconv3x3_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "afi_maxpool3s2_same_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp]),
+    "afi_fuse_swish_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_convT6s2_pack_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_unpack_wgrad": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp]),

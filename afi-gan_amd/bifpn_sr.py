@@ -1,0 +1,236 @@
+"""BiFPN with the AF interpolator as its up-sampler, inference path, on MI355X -- SURVEY.md section 8(f) row 4.
+
+Mirrors ``BiFPN_AFIGAN`` of the reference (afigan/modeling/backbone/bifpn_sr.py:203-733) for what the reference ships it
+for: an INFERENCE config (configs/inference/AFI-GAN_cascade_rcnn_swint_BiFPN_ST.yaml).  Same constructor arguments, the
+``srf_module`` attribute, the same state_dict (546 tensors + the interpolator's 23: ``before_bifpn.*``,
+``BiFPNLayer_{0..6}_conv{3..6}_up / conv{4..7}_down.{depthwise,pointwise,norm}.*``, ``BiFPNLayer_{l}_p{k}_w{1,2}``), and
+``forward(x) -> {"p3".."p7"}`` with every quirk of the hard-wired seven-layer forward (raw fusion weights, first-lateral
+skips, zero-padded "static_same" max-pool; see oracle/afigan_oracle.py:bifpn_afigan_forward).
+
+Per BiFPN node, in channels_last on this package's kernels:
+
+    fused = swish(w0 * a + w1 * b (+ w2 * c))          one HBM pass, weights read on the device (afi_fuse_swish_fwd)
+    dw    = depthwise3x3(fused)                        one HBM pass                             (afi_dwconv3x3_fwd)
+    out   = pointwise1x1(dw) with the eval-mode norm   ONE fp32-MFMA GEMM: the BatchNorm affine is folded into its weights
+            folded in                                  and bias                                 (afi_conv1x1_fwd)
+
+plus 28 interpolator forwards (one HIP call each) and the zero-padded 3x3/2 max-pools.  The forward has no host
+synchronisation, so it can be captured into a hipGraph (``bench.py`` measures both); training mode raises: the reference
+has no training recipe for this backbone, and the backward of these pieces is not built.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+from .fpn_sr import ShapeSpec
+from .generator_rdb import Generator
+
+__all__ = ["BiFPN_AFIGAN", "LastLevelP6P7"]
+
+_MOM, _EPS = 0.01, 1e-3                                       # bifpn_sr.py:279-280
+
+
+class _SeparableConv(nn.Module):
+    """Parameter tree of SeparableConv2d (bifpn_layers/wrappers.py:172-199): depthwise 3x3 (no bias), pointwise 1x1 + bias, norm."""
+
+    def __init__(self, cin, cout, norm):
+        super().__init__()
+        self.depthwise = nn.Conv2d(cin, cin, 3, groups=cin, bias=False)
+        self.pointwise = nn.Conv2d(cin, cout, 1)
+        self.norm = _make_norm(norm, cout, eps=_EPS, momentum=_MOM)
+
+    def forward(self, *a, **k):
+        raise _lib.AfiError("BiFPN nodes run fused inside BiFPN_AFIGAN.forward")
+
+
+def _make_norm(norm, ch, eps=1e-5, momentum=0.1):
+    if norm == "":
+        return None
+    if norm not in ("BN", "SyncBN"):
+        raise _lib.AfiError(f'norm "{norm}" is not supported on the BiFPN inference path (BN / SyncBN / "")')
+    bn = nn.BatchNorm2d(ch, eps=eps, momentum=momentum)      # eval-mode SyncBN == BN; same state_dict entries
+    return bn
+
+
+def _lateral(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, 1), nn.BatchNorm2d(cout, momentum=_MOM, eps=_EPS))
+
+
+class _ResampleFeature(nn.Module):                            # bifpn_sr.py:745-756
+    def __init__(self, cin, cout, norm):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 1)
+        nn.init.kaiming_uniform_(self.conv.weight, a=1)
+        nn.init.zeros_(self.conv.bias)
+        n = _make_norm(norm, cout)
+        if n is not None:
+            self.norm = n
+
+
+class LastLevelP6P7(nn.Module):
+    """P6 = maxpool(norm(conv1x1(C5))), P7 = maxpool(P6)   (bifpn_sr.py:773-789)."""
+
+    def __init__(self, in_channels, out_channels, norm=""):
+        super().__init__()
+        self.num_levels = 2
+        self.p6 = _ResampleFeature(in_channels, out_channels, norm)
+
+
+class _BeforeBiFPN(nn.Module):                                # bifpn_sr.py:159-201
+    def __init__(self, out_channels, in_channels, top_block):
+        super().__init__()
+        self.lateral3 = _lateral(in_channels[0], out_channels)
+        self.lateral4 = _lateral(in_channels[1], out_channels)
+        self.lateral5 = _lateral(in_channels[2], out_channels)
+        self.top_block = top_block
+        self.p4_skip = _lateral(in_channels[1], out_channels)
+        self.p5_skip = _lateral(in_channels[2], out_channels)
+
+
+def _fold(conv, bn):
+    """1x1 conv followed by an eval-mode BatchNorm as one weight / bias pair:  s = gamma / sqrt(var + eps)."""
+    w = conv.weight.detach().reshape(conv.weight.shape[0], -1)
+    b = conv.bias.detach() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is None:
+        return w.contiguous(), b.contiguous()
+    s = bn.weight.detach() * torch.rsqrt(bn.running_var.detach() + bn.eps)
+    return (w * s[:, None]).contiguous(), ((b - bn.running_mean.detach()) * s + bn.bias.detach()).contiguous()
+
+
+class BiFPN_AFIGAN(nn.Module):
+    N_LAYERS = 7                                              # hard-wired in the reference (its fpn_repeat argument is unused)
+
+    def __init__(self, bottom_up, in_features, out_channels, fpn_repeat=7, norm="SyncBN", top_block=None, fuse_type="sum", cfg=None):
+        super().__init__()
+        assert fuse_type in {"avg", "sum"}
+        if top_block is None or getattr(top_block, "num_levels", 0) != 2:
+            raise _lib.AfiError("BiFPN_AFIGAN needs the two-level top block (LastLevelP6P7), as build_swint_bifpn_sr_backbone passes")
+        in_strides = [bottom_up._out_feature_strides[f] for f in in_features]
+        in_channels = [bottom_up._out_feature_channels[f] for f in in_features]
+        if len(in_features) != 3:
+            raise _lib.AfiError("BiFPN_AFIGAN takes three bottom-up features (stage3, stage4, stage5)")
+        self.in_features, self.bottom_up, self.cfg = in_features, bottom_up, cfg
+        self._out_feature_strides = {f"p{int(math.log2(s))}": s for s in in_strides}
+        last_stage = int(math.log2(in_strides[-1]))
+        for s in range(last_stage, last_stage + top_block.num_levels):
+            in_strides.append(2 ** (s + 1))
+            self._out_feature_strides[f"p{s + 1}"] = 2 ** (s + 1)
+        for i, s in enumerate(in_strides[1:], 1):
+            assert s == 2 * in_strides[i - 1], f"Strides {s} {in_strides[i - 1]} are not log2 contiguous"
+        self.before_bifpn = _BeforeBiFPN(out_channels, in_channels, top_block)
+        self.srf_module = Generator(in_channels=out_channels, n_residual_dense_blocks=3)       # bifpn_sr.py:270
+        if getattr(getattr(cfg, "MODEL", None), "AFI_FREEZE", False):
+            for p in self.srf_module.parameters():
+                p.requires_grad = False
+        for l in range(self.N_LAYERS):
+            for lv in (6, 5, 4, 3):
+                setattr(self, f"BiFPNLayer_{l}_conv{lv}_up", _SeparableConv(out_channels, out_channels, norm))
+            for lv in (4, 5, 6, 7):
+                setattr(self, f"BiFPNLayer_{l}_conv{lv}_down", _SeparableConv(out_channels, out_channels, norm))
+            for lv in (6, 5, 4, 3):
+                setattr(self, f"BiFPNLayer_{l}_p{lv}_w1", nn.Parameter(torch.ones(2)))
+            for lv, n in ((4, 3), (5, 3), (6, 3), (7, 2)):
+                setattr(self, f"BiFPNLayer_{l}_p{lv}_w2", nn.Parameter(torch.ones(n)))
+        self._out_features = list(self._out_feature_strides.keys())
+        self._out_feature_channels = {k: out_channels for k in self._out_features}
+        self._size_divisibility = self._out_feature_strides[self._out_features[-1]]
+        self._fuse_type = fuse_type
+        self._folded, self._folded_key = None, None
+
+    @property
+    def size_divisibility(self):
+        return self._size_divisibility
+
+    def output_shape(self):
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]) for n in self._out_features}
+
+    # ------------------------------------------------------------------------------------------------ folded inference weights
+    def _fingerprint(self):
+        return tuple(t._version for t in self.state_dict(keep_vars=True).values()) + (str(next(self.parameters()).device),)
+
+    def _prepare(self):
+        """Eval-mode constants, rebuilt only when a parameter / buffer changed: BatchNorm folded into the 1x1 convs, depthwise
+        weights repacked tap-major."""
+        key = self._fingerprint()
+        if self._folded is not None and self._folded_key == key:
+            return self._folded
+        f = {}
+        bb = self.before_bifpn
+        for name in ("lateral3", "lateral4", "lateral5", "p4_skip", "p5_skip"):
+            seq = getattr(bb, name)
+            f[name] = _fold(seq[0], seq[1])
+        p6 = bb.top_block.p6
+        f["p6"] = _fold(p6.conv, getattr(p6, "norm", None))
+        for l in range(self.N_LAYERS):
+            for tag in [f"conv{lv}_up" for lv in (6, 5, 4, 3)] + [f"conv{lv}_down" for lv in (4, 5, 6, 7)]:
+                m = getattr(self, f"BiFPNLayer_{l}_{tag}")
+                cdw = m.depthwise.weight.shape[0]
+                dw = m.depthwise.weight.detach().reshape(cdw, 9).t().contiguous()
+                f[(l, tag)] = (dw,) + _fold(m.pointwise, m.norm)
+        self._folded, self._folded_key = f, key
+        return f
+
+    # ------------------------------------------------------------------------------------------------ forward (inference)
+    def forward(self, x):
+        if self.training:
+            raise _lib.AfiError("BiFPN_AFIGAN is an inference-only path in this build (the reference ships it in an inference config only): "
+                                "call .eval() first")
+        with torch.no_grad():
+            f = self._prepare()
+            bottom_up_features = self.bottom_up(x)
+            c3, c4, c5 = [ops.pixel_major(bottom_up_features[k]) for k in self.in_features]
+
+            def lat(t, name):
+                w, b = f[name]
+                return ops.conv1x1_fwd(t, w, b)
+
+            def node(tag, layer, w, a, b, c=None):
+                dw, pw, pb = f[(layer, tag)]
+                return ops.conv1x1_fwd(ops.dwconv3x3(ops.fuse_swish(w.detach(), a, b, c), dw), pw, pb)
+
+            c4_skip, c5_skip = lat(c4, "p4_skip"), lat(c5, "p5_skip")
+            c6 = ops.maxpool3s2_same(lat(c5, "p6"))
+            c7 = ops.maxpool3s2_same(c6)
+            lateral = (lat(c3, "lateral3"), lat(c4, "lateral4"), lat(c5, "lateral5"), c6, c7)
+            G = self.srf_module
+            feats = lateral
+            for l in range(self.N_LAYERS):
+                p3_in, p4_in, p5_in, p6_in, p7_in = feats
+                W = lambda name: getattr(self, f"BiFPNLayer_{l}_{name}")          # noqa: E731
+                p6_up = node("conv6_up", l, W("p6_w1"), p6_in, G(p7_in))
+                p5_up = node("conv5_up", l, W("p5_w1"), p5_in, G(p6_up))
+                p4_up = node("conv4_up", l, W("p4_w1"), p4_in, G(p5_up))
+                p3_up = node("conv3_up", l, W("p3_w1"), p3_in, G(p4_up))
+                s4, s5 = (c4_skip, c5_skip) if l == 0 else (lateral[1], lateral[2])
+                p4_out = node("conv4_down", l, W("p4_w2"), s4, p4_up, ops.maxpool3s2_same(p3_up))
+                p5_out = node("conv5_down", l, W("p5_w2"), s5, p5_up, ops.maxpool3s2_same(p4_out))
+                p6_out = node("conv6_down", l, W("p6_w2"), lateral[3], p6_up, ops.maxpool3s2_same(p5_out))
+                p7_out = node("conv7_down", l, W("p7_w2"), lateral[4], ops.maxpool3s2_same(p6_out))
+                feats = (p3_up, p4_out, p5_out, p6_out, p7_out)
+            assert len(self._out_features) == len(feats)
+            return dict(zip(self._out_features, feats))
+
+
+def _register_with_detectron2():
+    """With detectron2 and the reference's Swin builder importable, register build_swint_bifpn_sr_backbone (bifpn_sr.py:791-817)."""
+    try:
+        from detectron2.modeling import BACKBONE_REGISTRY
+        from afigan.modeling.backbone.swin_transformer import build_swint_backbone
+    except Exception:
+        return False
+
+    @BACKBONE_REGISTRY.register()
+    def build_swint_bifpn_sr_backbone(cfg, input_shape):
+        bottom_up = build_swint_backbone(cfg, input_shape)
+        in_features = cfg.MODEL.BIFPN.IN_FEATURES
+        cin = bottom_up.output_shape()[in_features[-1]].channels
+        return BiFPN_AFIGAN(bottom_up=bottom_up, in_features=in_features, out_channels=cfg.MODEL.BIFPN.OUT_CHANNELS,
+                            fpn_repeat=cfg.MODEL.BIFPN.FPN_REPEAT, norm=cfg.MODEL.BIFPN.NORM,
+                            top_block=LastLevelP6P7(cin, cfg.MODEL.BIFPN.OUT_CHANNELS, cfg.MODEL.BIFPN.NORM),
+                            fuse_type=cfg.MODEL.BIFPN.FUSE_TYPE, cfg=cfg)
+    return True
+
+
+DETECTRON2_REGISTERED = _register_with_detectron2()

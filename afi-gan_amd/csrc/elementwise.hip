@@ -516,6 +516,77 @@ int afi_launch_relu_bwd(const float* g, const float* act, float* out, long long 
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------- BiFPN inference pieces (bifpn_sr.py:569-733, bifpn_layers/wrappers.py)
+// depthwise 3x3, stride 1, zero pad 1 ("static_same" of SeparableConv2d.depthwise, no bias): one thread = one pixel x 4 channels.
+// w: [9][C] (tap-major repack of torch's [C][1][3][3]).  HBM-bound: x is read once from HBM (the 9 taps hit L2), out written once.
+__global__ void afi_dwconv3x3_kernel(const AfiView x, int N, int H, int W, int C, const float* __restrict__ w, float* __restrict__ out) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4; long long r = i / C4;
+        const int xx = (int)(r % W); r /= W; const int yy = (int)(r % H); const int n = (int)(r / H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int y2 = yy + t / 3 - 1, x2 = xx + t % 3 - 1;
+            if ((unsigned)y2 < (unsigned)H && (unsigned)x2 < (unsigned)W)
+                acc += *(const f32x4*)(x.p + (long long)n * x.sN + (long long)y2 * x.sH + (long long)x2 * x.sW + c) * *(const f32x4*)(w + t * C + c);
+        }
+        *(f32x4*)(out + i * 4) = acc;
+    }
+}
+int afi_launch_dwconv3x3(AfiView x, int N, int H, int W, int C, const float* w, float* out, hipStream_t st) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return AFI_ERR_BAD_ARG;
+    if (C & 3) return AFI_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(afi_dwconv3x3_kernel, dim3(afi_ew_grid((long long)N * H * W * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, w, out);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// MaxPool2d(3, 2, "static_same"): F.pad(0 left/top, 1 right/bottom, ZEROS) then max_pool2d(3, 2): out[oy][ox] = max over rows
+// 2oy..2oy+2, cols 2ox..2ox+2 where positions == H / == W count as 0.0 (the zero pad takes part in the max), Ho = (H-2)/2 + 1.
+__global__ void afi_maxpool3s2_same_kernel(const AfiView x, int N, int H, int W, int C, int Ho, int Wo, float* __restrict__ out) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4; long long r = i / C4;
+        const int ox = (int)(r % Wo); r /= Wo; const int oy = (int)(r % Ho); const int n = (int)(r / Ho);
+        f32x4 m = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int y2 = 2 * oy + t / 3, x2 = 2 * ox + t % 3;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};                  // the pad row / column
+            if (y2 < H && x2 < W) v = *(const f32x4*)(x.p + (long long)n * x.sN + (long long)y2 * x.sH + (long long)x2 * x.sW + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) m[j] = fmaxf(m[j], v[j]);
+        }
+        *(f32x4*)(out + i * 4) = m;
+    }
+}
+int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out, hipStream_t st) {
+    if (N <= 0 || H < 2 || W < 2 || C <= 0) return AFI_ERR_BAD_ARG;
+    if (C & 3) return AFI_ERR_UNSUPPORTED;
+    const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
+    hipLaunchKernelGGL(afi_maxpool3s2_same_kernel, dim3(afi_ew_grid((long long)N * Ho * Wo * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Ho, Wo, out);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// out = swish(w[0]*a + w[1]*b (+ w[2]*c)),  swish(v) = v * sigmoid(v)  (BiFPN "_attention" with the RAW fusion weights, then
+// MemoryEfficientSwish: bifpn_sr.py:535-563, activations.py).  w: DEVICE pointer to the 2 or 3 weights (no host sync).
+__global__ void afi_fuse_swish_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c,
+                                      const float* __restrict__ w, float* __restrict__ out, long long n4) {
+    const float w0 = w[0], w1 = w[1], w2 = c ? w[2] : 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        f32x4 v = w0 * ((const f32x4*)a)[i] + w1 * ((const f32x4*)b)[i];
+        if (c) v += w2 * ((const f32x4*)c)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.f + __expf(-v[j]));
+        ((f32x4*)out)[i] = v;
+    }
+}
+int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st) {
+    if (n <= 0 || (n & 3) || !a || !b || !w || !out) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_fuse_swish_kernel, dim3(afi_ew_grid(n >> 2)), dim3(256), 0, st, a, b, c, w, out, n >> 2);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // ---------------------------------------------------------------- small helpers
 // *out += alpha * sum(v[0..n))
 __global__ __launch_bounds__(256) void afi_sum_accum_kernel(const float* __restrict__ v, long long n, float alpha, float* __restrict__ out) {

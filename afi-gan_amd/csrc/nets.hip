@@ -29,6 +29,9 @@ int afi_launch_l1(AfiView a, AfiView b, int N, int h, int w, int C, int Ha, int 
                   hipStream_t st);
 int afi_launch_bilinear2x_fwd(AfiView x, int N, int H, int W, int C, float beta, float* out, hipStream_t st);
 int afi_launch_relu_bwd(const float* g, const float* act, float* out, long long n, float s, hipStream_t st);
+int afi_launch_dwconv3x3(AfiView x, int N, int H, int W, int C, const float* w, float* out, hipStream_t st);
+int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out, hipStream_t st);
+int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st);
 int afi_launch_bilinear2x_bwd(const float* dout, int N, int H, int W, int C, float beta, float* dx, hipStream_t st);
 int afi_launch_sgd(const void* descs_dev, int ntensors, long long max_n, float lr, float mom, float gscale, hipStream_t st);
 int afi_launch_scale(float* p, long long n, float s, hipStream_t st);
@@ -248,6 +251,17 @@ int afi_conv3x3s2_wgrad(afi_view_t dy, afi_view_t x, int N, int Hi, int Wi, int 
 }
 int afi_relu_bwd(const float* g, const float* act, float* out, long long n, float scale, void* stream) {
     return afi_launch_relu_bwd(g, act, out, n, scale, (hipStream_t)stream);
+}
+
+// ---- BiFPN inference pieces (bifpn_sr.py; forward only: the reference ships BiFPN in an inference config only) ----
+int afi_dwconv3x3_fwd(afi_view_t x, int N, int H, int W, int C, const float* w9c, float* out, void* stream) {
+    return afi_launch_dwconv3x3(V(x), N, H, W, C, w9c, out, (hipStream_t)stream);
+}
+int afi_maxpool3s2_same_fwd(afi_view_t x, int N, int H, int W, int C, float* out, void* stream) {
+    return afi_launch_maxpool3s2_same(V(x), N, H, W, C, out, (hipStream_t)stream);
+}
+int afi_fuse_swish_fwd(const float* a, const float* b, const float* c_or_null, const float* w_dev, float* out, long long n, void* stream) {
+    return afi_launch_fuse_swish(a, b, c_or_null, w_dev, out, n, (hipStream_t)stream);
 }
 
 int afi_convT6s2_pack_weight(const float* w, float* wp, int Cin, int Cout, void* stream) {

@@ -282,6 +282,36 @@ def convT_wgrad(dy, x):
     return dw
 
 
+# ------------------------------------------------------------------------------------------------ BiFPN inference pieces
+def dwconv3x3(x, w9c):
+    """Depthwise 3x3 (stride 1, zero pad 1, no bias); w9c: [9, C] tap-major weights (see bifpn_sr.pack_depthwise)."""
+    _check_cuda(x, w9c)
+    N, C_, H, W = x.shape
+    assert tuple(w9c.shape) == (9, C_) and w9c.is_contiguous()
+    out = new_pixel_major(N, C_, H, W, x.device)
+    call("afi_dwconv3x3_fwd", view_of(x), N, H, W, C_, _p(w9c), _p(out), stream_ptr())
+    return out
+
+
+def maxpool3s2_same(x):
+    """MaxPool2d(3, 2, padding_mode="static_same") of bifpn_layers/wrappers.py (zero pad right/bottom)."""
+    _check_cuda(x)
+    N, C_, H, W = x.shape
+    out = new_pixel_major(N, C_, (H - 2) // 2 + 1, (W - 2) // 2 + 1, x.device)
+    call("afi_maxpool3s2_same_fwd", view_of(x), N, H, W, C_, _p(out), stream_ptr())
+    return out
+
+
+def fuse_swish(w, a, b, c=None):
+    """swish(w[0]*a + w[1]*b (+ w[2]*c)) for dense pixel-major tensors of one shape; w: device tensor with 2 or 3 weights."""
+    _check_cuda(w, a, b, c)
+    assert is_dense_pm(a) and is_dense_pm(b) and a.shape == b.shape and (c is None or (is_dense_pm(c) and c.shape == a.shape))
+    assert w.numel() == (2 if c is None else 3) and w.is_contiguous()
+    out = new_pixel_major(*a.shape, a.device)
+    call("afi_fuse_swish_fwd", _p(a), _p(b), _p(c), _p(w), _p(out), a.numel(), stream_ptr())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ bandwidth ops
 def bilinear2x(x, out=None, beta=0.0):
     N, C_, H, W = x.shape

@@ -1,1 +1,1 @@
-from . import fpn_sr, pafpn_sr  # noqa: F401
+from . import fpn_sr, pafpn_sr, bifpn_sr  # noqa: F401

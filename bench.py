@@ -155,6 +155,49 @@ def fpn_bench(amd, torch, iters=10, warmup=3, pafpn=False):
             "algorithmic_tflop": flop / 1e12, "tflops": flop / dt / 1e12, "frac_of_fp32_mfma_peak": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
 
 
+def bifpn_bench(amd, torch, iters=10, warmup=3):
+    """BiFPN_AFIGAN inference forward (bifpn_sr.py:569-733) for one 896x1408 image (size_divisibility 128),
+    Swin-L stage3..5 feature shapes: 7 BiFPN layers, 56 fused separable-conv nodes, 28 interpolator forwards on 7x11 .. 56x88
+    maps -- the launch-bound regime; timed eagerly and as one hipGraph replay."""
+    class BottomUp(torch.nn.Module):
+        _out_feature_strides = {"stage3": 8, "stage4": 16, "stage5": 32}
+        _out_feature_channels = {"stage3": 384, "stage4": 768, "stage5": 1536}
+
+        def forward(self, feats):
+            return feats
+
+    torch.manual_seed(0)
+    net = amd.BiFPN_AFIGAN(BottomUp(), ["stage3", "stage4", "stage5"], 256, 7, norm="SyncBN", top_block=amd.LastLevelP6P7(1536, 256, "SyncBN")).cuda().eval()
+    feats = {f"stage{i + 3}": torch.randn((1, c, 112 // 2 ** i, 176 // 2 ** i), device="cuda").contiguous(memory_format=torch.channels_last)
+             for i, c in enumerate([384, 768, 1536])}
+
+    def timed(fn):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters
+
+    dt_eager = timed(lambda: net(feats))
+    dt_graph = None
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            net(feats)
+        dt_graph = timed(g.replay)
+    except Exception as e:
+        log(f"  hipGraph capture unavailable: {type(e).__name__}: {e}")
+    g_px = sum(7 * (7 * 2 ** i) * (11 * 2 ** i) for i in range(4))               # 7 layers x (p7, p6, p5, p4 inputs)
+    flop = g_px * G_FWD_FLOP_PER_INPX
+    best = min(dt_eager, dt_graph) if dt_graph else dt_eager
+    return {"workload": "BiFPN_AFIGAN inference forward, 1 image 896x1408, Swin-L stage3..5 shapes (28 interpolator calls)",
+            "ms_eager": dt_eager * 1e3, "ms_hipgraph": None if dt_graph is None else dt_graph * 1e3, "images_per_s": 1.0 / best,
+            "interpolator_tflop": flop / 1e12, "interpolator_tflops_lower_bound": flop / best / 1e12}
+
+
 def host_cores():
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box exposes 256 logical
     CPUs but grants 16; running 256 OpenMP threads against a 16-CPU quota throttles to a crawl)."""
@@ -373,6 +416,7 @@ def main():
         log("FPN_AFIGAN top-down merge (SURVEY 8f row 1)")
         line["fpn_topdown"] = fpn_bench(amd, torch)
         line["pafpn"] = fpn_bench(amd, torch, pafpn=True)
+        line["bifpn_inference"] = bifpn_bench(amd, torch)
     log("CPU baseline (oracle) on the host cores")
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, B)

@@ -136,6 +136,17 @@ int afi_conv3x3s2_wgrad(afi_view_t dy, afi_view_t x /*[N,Hi,Wi,Cin]*/, int N, in
 /* out[i] = scale * g[i] * (act[i] > 0): gradient through the ReLU of pafpn_sr.py:178 from its kept output (n % 4 == 0) */
 int afi_relu_bwd(const float* g, const float* act, float* out, long long n, float scale, void* stream);
 
+/* BiFPN_AFIGAN inference pieces around the interpolator (bifpn_sr.py:531-733, bifpn_layers/wrappers.py:172-252, activations.py):
+ *   afi_dwconv3x3_fwd        SeparableConv2d.depthwise: 3x3, stride 1, zero pad 1, no bias; w9c = [9][C] (tap-major)
+ *   afi_maxpool3s2_same_fwd  MaxPool2d(3, 2, "static_same"): zero pad right/bottom by 1 (the zeros take part in the max),
+ *                            out dense [N, (H-2)/2+1, (W-2)/2+1, C]
+ *   afi_fuse_swish_fwd       out = swish(w[0]*a + w[1]*b (+ w[2]*c)); a, b, c, out dense and equal-sized, w a DEVICE pointer
+ * The pointwise 1x1 conv (+ folded eval-mode norm) is afi_conv1x1_fwd. */
+int afi_dwconv3x3_fwd(afi_view_t x, int N, int H, int W, int C, const float* w9c, float* out, void* stream);
+int afi_maxpool3s2_same_fwd(afi_view_t x, int N, int H, int W, int C, float* out, void* stream);
+int afi_fuse_swish_fwd(const float* a, const float* b, const float* c_or_null, const float* w_dev, float* out, long long n,
+                       void* stream);
+
 /* ConvTranspose2d(k=6,s=2,p=2) (generator_rdb.py:101-105) on the packed weight wp[4*Cout][3][3][Cin] */
 int afi_convT6s2_pack_weight(const float* w_iohw, float* wp, int Cin, int Cout, void* stream);
 int afi_convT6s2_unpack_wgrad(const float* dwp, float* dw_iohw, int Cin, int Cout, void* stream);   /* dw += */

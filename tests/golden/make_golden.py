@@ -146,6 +146,26 @@ def checkpoint_remap_cases():
             "target_detector": (det, stage2, "align_and_update_state_dicts_TargetDetector")}
 
 
+def bifpn_closed_form(name, like):
+    """Closed-form value of one BiFPN_AFIGAN state-dict entry (shared with tests/test_oracle_golden.py).  Scales are chosen for
+    a per-node gain near 1 so that seven stacked BiFPN layers keep O(1) activations: conv weights with std 1/sqrt(fan_in),
+    small biases, BatchNorm affine 1 +- 0.17 / shift +- 0.17, running_var in [0.5, 1.5], raw fusion weights in [0.3, 0.6]."""
+    shape = tuple(like.shape)
+    if name.endswith("num_batches_tracked"):
+        return torch.tensor(3, dtype=torch.long)
+    if name.endswith("running_var"):
+        return 1.0 + orc.closed_form_tensor(name, shape, 0.5 / 3 ** 0.5)
+    if name.endswith("running_mean"):
+        return orc.closed_form_tensor(name, shape, 0.1)
+    if "_w1" in name or "_w2" in name:                                      # the raw fusion weights (bifpn_sr.py:535-563)
+        return 0.45 + orc.closed_form_tensor(name, shape, 0.15 / 3 ** 0.5)
+    if len(shape) == 1:                                                     # BatchNorm affine and conv biases
+        is_norm_w = name.endswith("weight")
+        return (1.0 if is_norm_w else 0.0) + orc.closed_form_tensor(name, shape, 0.1)
+    fan_in = shape[1] * shape[2] * shape[3]
+    return orc.closed_form_tensor(name, shape, 1.0 / fan_in ** 0.5)
+
+
 def load_ref(relpath, name):
     spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
     mod = importlib.util.module_from_spec(spec)
@@ -258,6 +278,54 @@ def main():
         fx.update(grads_digest({k: p.grad for k, p in pafpn.named_parameters()}))
         np.savez_compressed(os.path.join(HERE, f"pafpn_{fuse}.npz"), **fx)
         print("pafpn", fuse, {k: tuple(v.shape) for k, v in out.items()}, sorted(k for k in sd if not k.startswith("srf_module."))[:6])
+
+    # ---------------- BiFPN_AFIGAN (bifpn_sr.py), inference: 7 hard-wired BiFPN layers, 28 interpolator calls, SURVEY 8f row 4 ----------------
+    # The reference ships BiFPN only in an inference config (configs/inference/...BiFPN_ST.yaml), so the fixture is an eval-mode
+    # forward.  Its own helper package afigan/modeling/bifpn_layers/{wrappers,activations}.py is loaded by path too (it needs
+    # detectron2.layers.batch_norm.get_norm -> the BN stand-in; eval-mode SyncBN == BN), the Swin builder gets an inert stub.
+    bn_mod = types.ModuleType("detectron2.layers.batch_norm")
+    bn_mod.get_norm = sys.modules["detectron2.layers"].get_norm
+    sys.modules["detectron2.layers.batch_norm"] = bn_mod
+    swin = types.ModuleType("afigan.modeling.backbone.swin_transformer")
+    swin.build_swint_backbone = lambda *a, **k: None
+    sys.modules["afigan.modeling.backbone.swin_transformer"] = swin
+    wr = load_ref("afigan/modeling/bifpn_layers/wrappers.py", "afigan.modeling.bifpn_layers.wrappers")
+    ac = load_ref("afigan/modeling/bifpn_layers/activations.py", "afigan.modeling.bifpn_layers.activations")
+    bl = types.ModuleType("afigan.modeling.bifpn_layers")
+    for k in ("Conv2d", "SeparableConv2d", "MaxPool2d"):
+        setattr(bl, k, getattr(wr, k))
+    bl.MemoryEfficientSwish, bl.Swish = ac.MemoryEfficientSwish, ac.Swish
+    sys.modules["afigan.modeling.bifpn_layers"] = bl
+    bifpn_mod = load_ref("afigan/modeling/backbone/bifpn_sr.py", "ref_bifpn_sr")
+
+    class BottomUp3(Backbone):
+        _out_feature_strides = {"stage3": 8, "stage4": 16, "stage5": 32}
+        _out_feature_channels = {"stage3": 8, "stage4": 12, "stage5": 16}
+
+        def forward(self, feats):
+            return feats
+
+    bifpn = bifpn_mod.BiFPN_AFIGAN(BottomUp3(), ["stage3", "stage4", "stage5"], 256, 7, norm="BN",
+                                   top_block=bifpn_mod.LastLevelP6P7(16, 256, "BN"), fuse_type="sum", cfg=Cfg)
+    sd = {}
+    for k, v in bifpn.state_dict().items():
+        if k.startswith("srf_module."):
+            continue
+        sd[k] = bifpn_closed_form(k, v)
+    sd.update({"srf_module." + k: v for k, v in orc.closed_form_generator_params().items()})
+    bifpn.load_state_dict(sd, strict=True)
+    bifpn.eval()
+    gen = torch.Generator().manual_seed(35)
+    feats = {f"stage{i + 3}": torch.randn((1, c, 16 // 2 ** i, 32 // 2 ** i), generator=gen) for i, c in enumerate([8, 12, 16])}
+    with torch.no_grad():
+        out = bifpn(feats)
+    fx = {"seed": np.array([35])}
+    for k, o in out.items():
+        fx["out/" + k] = o.numpy()
+    fx["n_params"] = np.array([len(sd)])
+    fx["state_dict_contract"] = np.array([f"{k}:{list(v.shape)}" for k, v in bifpn.state_dict().items() if not k.startswith("srf_module.")])
+    np.savez_compressed(os.path.join(HERE, "bifpn_eval.npz"), **fx)
+    print("bifpn", {k: tuple(v.shape) for k, v in out.items()}, len(sd), "tensors")
 
     # ---------------- G-small: full tensors, reference default init ----------------
     for tag, shape in (("a", (2, 16, 5, 7)), ("b", (1, 16, 7, 11))):

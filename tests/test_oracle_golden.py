@@ -225,6 +225,39 @@ def test_pafpn_matches_reference(golden_dir, fuse):
     _check_digests(fx, {k: v.grad for k, v in p.items()}, rtol=5e-4)
 
 
+def _bifpn_params_and_feats(fx):
+    """BiFPN state dict from the fixture's name:shape contract + the closed-form recipe of make_golden.py, and the seeded inputs."""
+    import importlib.util
+    import json
+    import os
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    p = {}
+    for entry in fx["state_dict_contract"]:
+        name, shape = str(entry).rsplit(":", 1)
+        shape = tuple(json.loads(shape))
+        p[name] = mg.bifpn_closed_form(name, torch.empty(shape))
+    p.update({"srf_module." + k: v for k, v in orc.closed_form_generator_params().items()})
+    gen = torch.Generator().manual_seed(int(fx["seed"][0]))
+    feats = [torch.randn((1, c, 16 // 2 ** i, 32 // 2 ** i), generator=gen) for i, c in enumerate([8, 12, 16])]
+    return p, feats
+
+
+def test_bifpn_eval_matches_reference(golden_dir):
+    """oracle.bifpn_afigan_forward vs the imported reference BiFPN_AFIGAN in eval mode (bifpn_sr.py:569-733): 7 layers, 28
+    interpolator calls, the quirks of the hard-wired forward (raw fusion weights, first-lateral skips, zero-padded max-pool)."""
+    fx = _load(golden_dir, "bifpn_eval.npz")
+    p, feats = _bifpn_params_and_feats(fx)
+    assert len(p) == int(fx["n_params"][0])
+    with torch.no_grad():
+        out = orc.bifpn_afigan_forward(feats, p)
+    assert list(out) == ["p3", "p4", "p5", "p6", "p7"]
+    for k, o in out.items():
+        ref = fx["out/" + k]
+        np.testing.assert_allclose(o.numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=k)
+
+
 def _stage2_inputs(fx):
     gen = torch.Generator().manual_seed(int(fx["seed"][0]))
     guide = [torch.randn((2, 256, 26, 42), generator=gen), torch.randn((2, 256, 13, 21), generator=gen)]
