@@ -202,6 +202,48 @@ def test_discriminator_large_map_halo_path(amd):
         assert l2(_logical(p.grad), pr[k].grad) < 3e-3, k
 
 
+def test_mid_size_maps_split_k_paths_full_channels(amd):
+    """Real channel counts on a mid-size ragged map (1x256x50x84 for D, 1x256x26x42 -> 52x84 for G): the 128x128 tiles with
+    the mid-size split-K rule (linear and halo variants, dgrad included) and the balanced wgrad split, against the oracle."""
+    dp = orc.closed_form_discriminator_params()
+    D = amd.Discriminator().cuda()
+    D.load_state_dict(dp)
+    D.train()
+    x = torch.randn((1, 256, 50, 84), generator=torch.Generator().manual_seed(12))
+    xg = x.cuda().requires_grad_(True)
+    logits = D(xg)
+    (logits * logits).mean().backward()
+    pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in dp.items()}
+    xr = x.clone().requires_grad_(True)
+    lref, _ = orc.discriminator_forward(xr, pr, training=True)
+    (lref * lref).mean().backward()
+    assert _rel(logits, lref) < 1e-3
+
+    def l2(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return ((a - b).norm() / b.norm()).item()
+    assert l2(xg.grad, xr.grad) < 3e-3
+    for k, p in D.named_parameters():
+        if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3"):
+            continue
+        assert l2(_logical(p.grad), pr[k].grad) < 3e-3, k
+
+    gp = orc.closed_form_generator_params()
+    G = amd.Generator(n_residual_dense_blocks=3).cuda()
+    G.load_state_dict(gp)
+    z = torch.randn((1, 256, 26, 42), generator=torch.Generator().manual_seed(13))
+    zg = z.cuda().requires_grad_(True)
+    out = G(zg)
+    out.sum().backward()
+    qr = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
+    zr = z.clone().requires_grad_(True)
+    ref = orc.generator_forward(zr, qr)
+    ref.sum().backward()
+    assert _rel(out, ref) < 1e-3 and _rel(zg.grad, zr.grad) < 1e-3
+    for k, p in G.named_parameters():
+        assert _rel(_logical(p.grad), qr[k].grad) < 1e-3, k
+
+
 def test_generator_large_map_halo_path(amd):
     C, g = 128, 32
     gp = orc.closed_form_generator_params(C, 2, g)

@@ -36,12 +36,14 @@ def test_pafpn_afigan_matches_oracle(amd, fuse_type):
     feats = {f"res{i + 2}": torch.randn((N, c, H5 * 2 ** (3 - i), W5 * 2 ** (3 - i)), generator=gen) for i, c in enumerate(chans)}
     fg = {k: v.cuda().requires_grad_(True) for k, v in feats.items()}
     out = net(fg)
-    sum((o * o).mean() for o in out.values()).backward()
+    # <out, R> with fixed random R: O(1) gradients (see tests/test_gpu_fpn.py)
+    R = {k: torch.randn(o.shape, generator=torch.Generator().manual_seed(100 + i)) for i, (k, o) in enumerate(out.items())}
+    sum((o * R[k].cuda()).sum() for k, o in out.items()).backward()
 
     pr = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in net.state_dict().items()}
     fr = [feats[f"res{i + 2}"].clone().requires_grad_(True) for i in range(4)]
     ref = orc.pafpn_afigan_forward(fr, [2, 3, 4, 5], pr, fuse_type=fuse_type)
-    sum((o * o).mean() for o in ref.values()).backward()
+    sum((o * R[k]).sum() for k, o in ref.items()).backward()
     assert list(out) == list(ref)
     for k in ref:
         assert _rel(out[k], ref[k]) < 1e-3, k
