@@ -198,6 +198,41 @@ def bifpn_bench(amd, torch, iters=10, warmup=3):
             "interpolator_tflop": flop / 1e12, "interpolator_tflops_lower_bound": flop / best / 1e12}
 
 
+def stage2_bench(amd, torch, iters=5, warmup=2):
+    """the AFI-specific part of one stage-2 iteration (stage2_trainer.py:299-364) for a per-GPU batch of two
+    images: guide features at full size (P2..P6 of 800x1344), the AFI detector's FPN features at half size (416x672 input);
+    D step (real = nearest-half of the guide feature, fake = FPN feature) + generator-side losses with their backward into the
+    FPN features.  The detector itself is detectron2 glue and not part of it."""
+    D = amd.Discriminator().cuda()
+    adv = amd.Stage2Adversarial(D, base_lr=1e-3)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    guide = [torch.randn((2, 256, h, w), device="cuda", generator=g).contiguous(memory_format=torch.channels_last)
+             for h, w in [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]]
+    fpn = [torch.randn((2, 256, h, w), device="cuda", generator=g).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+           for h, w in [(104, 168), (52, 84), (26, 42), (13, 21), (7, 11)]]
+
+    def one():
+        adv.d_step(guide, fpn)
+        losses = adv.g_losses(guide, fpn)
+        sum(v for k, v in losses.items() if k.startswith("g_loss")).backward()
+        for f in fpn:
+            f.grad = None
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    px = sum(min(gh // 2, fh) * min(gw // 2, fw) for (gh, gw), (fh, fw) in zip([(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)],
+                                                                                [(104, 168), (52, 84), (26, 42), (13, 21), (7, 11)]))
+    flop = 2 * px * (2 * D_FWDBWD_DETACHED_FLOP_PER_PX + 2 * D_FWD_FLOP_PER_PX)      # D step: 2 fwd+bwd; G side: 2 fwd (no D gradient: Q1)
+    return {"workload": "stage-2 adversarial terms (D step + generator-side losses), batch 2, FPN features of 416x672 inputs",
+            "ms": dt * 1e3, "images_per_s": 2.0 / dt, "algorithmic_tflop": flop / 1e12, "tflops": flop / dt / 1e12}
+
+
 def host_cores():
     """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota (the GPU box exposes 256 logical
     CPUs but grants 16; running 256 OpenMP threads against a 16-CPU quota throttles to a crawl)."""
@@ -417,6 +452,7 @@ def main():
         line["fpn_topdown"] = fpn_bench(amd, torch)
         line["pafpn"] = fpn_bench(amd, torch, pafpn=True)
         line["bifpn_inference"] = bifpn_bench(amd, torch)
+        line["stage2_adversarial"] = stage2_bench(amd, torch)
     log("CPU baseline (oracle) on the host cores")
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, B)
