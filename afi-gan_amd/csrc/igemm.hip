@@ -175,6 +175,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_
     const int HW = p.H * p.W;
     const long long M = (long long)p.N * HW;
     int patch_img = 0, patch_y0 = 0, patch_x0 = 0;        // HALO: image and origin of this block's 8x16 patch
+    const long long b_img = (HALO || p.b_sImg == 0) ? 0 : (long long)(m0 / HW) * p.b_sImg;   // per-image weights: the launcher guarantees a tile stays inside one image
 
     // decode the tile's rows once (shared by the A gather and the epilogue)
     if constexpr (HALO) {
@@ -291,13 +292,13 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_
             if constexpr (!B_RC) {
                 const int n = n0 + ar + K_RPP * i;
                 const bool ok = k_cok && n < p.Ncols;
-                const float* src = ok ? p.B + ((long long)n * p.b_sRow + (long long)k_wtap * p.b_sTap + k_c0 + 4 * aq) : afi_zeros;
+                const float* src = ok ? p.B + (b_img + (long long)n * p.b_sRow + (long long)k_wtap * p.b_sTap + k_c0 + 4 * aq) : afi_zeros;
                 b_reg[i] = *(const f32x4*)src;
             } else {
                 const int c = k_c0 + b_kr + B_ROWS_PER_PASS * i;
                 const int n = n0 + 4 * b_cq;
                 const bool ok = k_more && c < p.Ck && n < p.Ncols;
-                const float* src = ok ? p.B + ((long long)(k_kph * p.Ck + c) * p.b_sRow + (long long)k_wtap * p.b_sTap + n) : afi_zeros;
+                const float* src = ok ? p.B + (b_img + (long long)(k_kph * p.Ck + c) * p.b_sRow + (long long)k_wtap * p.b_sTap + n) : afi_zeros;
                 b_reg[i] = *(const f32x4*)src;
             }
         }
@@ -756,6 +757,7 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     if (!p.partial && g_op_scratch) { p.partial = g_op_scratch; p.partial_floats = g_op_scratch_floats; }
     const long long M = (long long)p.N * p.H * p.W;
     if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
+    if (p.b_sImg != 0 && ((long long)p.H * p.W) % 128 != 0) return AFI_ERR_BAD_ARG;   // per-image weights: tiles must not straddle images
     if (b_rc && (p.Ncols & 3)) return AFI_ERR_UNSUPPORTED;       // RC weight rows are read as float4 along n
     if (!b_rc && (p.Ck & 3)) return AFI_ERR_UNSUPPORTED;         // KC weight rows are read as float4 along c
     if (p.gtap) {

@@ -1,0 +1,173 @@
+// Winograd F(2x2, 3x3) transforms around the batched 1x1 MFMA GEMM (large maps, many channels).
+//
+// A 3x3 / stride-1 / pad-1 correlation over a 2x2 output tile costs 16 multiplies per (cin, cout) pair in the transformed
+// domain instead of 36:   Y = A^T [ (G g G^T) (.) (B^T d B) ] A   (Lavin & Gray, 2016).  Per layer:
+//
+//   U[a][n][k]  = G g G^T          weight transform      (afi_wino_weight_kernel; once per call, weights are small)
+//   V[a][t][k]  = B^T d B          input transform       (afi_wino_input_kernel;  HBM-bound: reads X, writes 4x its volume)
+//   M[a][t][n]  = sum_k V[a][t][k] * U[a][n][k]          16 independent GEMMs = ONE launch of the pixel GEMM (ntaps = 1,
+//                                                         "images" = the 16 transform points, per-image weight stride)
+//   Y           = A^T M A (+ bias, * LeakyReLU'(Z))      output transform (afi_wino_output_kernel; HBM-bound)
+//
+// a = 4*i + j indexes the 4x4 transform points, t the 2x2 output tiles (N * ceil(H/2) * ceil(W/2), padded to a multiple of
+// 128 so a GEMM tile never straddles two transform points), k the input and n the output channels.  The matrix-core work
+// drops 2.25x; the price is ~10 GB of transform traffic for the largest layer (2 x 200 x 336 x 1024 -> 1024), ~2.2 ms next
+// to 8.3 ms of GEMM instead of 18.6 ms of direct convolution.  fp32 throughout; the transform constants are 0, +-1, +-1/2,
+// so the result differs from the direct kernel by a few ulp of the accumulated sum (tests hold it to the same 1e-3 bar).
+#include "afi_common.h"
+
+static unsigned wino_grid(long long work_items) {
+    long long g = (work_items + 255) / 256;
+    if (g > 8192) g = 8192;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+// ---------------------------------------------------------------- weights: w [O][3][3][I] (memory order) -> U
+// mode 0 (forward):   U[a][o][i] from g[ky][kx] = w[o][ky][kx][i]            GEMM columns = O, K = I
+// mode 1 (data grad): U[a][i][o] from g[ky][kx] = w[o][2-ky][2-kx][i]        GEMM columns = I, K = O  (flipped taps, swapped roles)
+__global__ void afi_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I, int mode) {
+    const long long total = (long long)O * I;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % I), o = (int)(e / I);
+        float g[3][3];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int tt = mode ? 8 - t : t;
+            g[t / 3][t % 3] = w[((long long)o * 9 + tt) * I + i];
+        }
+        float a[4][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            a[0][j] = g[0][j];
+            a[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+            a[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+            a[3][j] = g[2][j];
+        }
+        const long long plane = (long long)O * I;
+        const long long off = mode ? (long long)i * O + o : (long long)o * I + i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u0 = a[r][0], u1 = 0.5f * (a[r][0] + a[r][1] + a[r][2]), u2 = 0.5f * (a[r][0] - a[r][1] + a[r][2]), u3 = a[r][2];
+            U[(4 * r + 0) * plane + off] = u0;
+            U[(4 * r + 1) * plane + off] = u1;
+            U[(4 * r + 2) * plane + off] = u2;
+            U[(4 * r + 3) * plane + off] = u3;
+        }
+    }
+}
+int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st) {
+    if (O <= 0 || I <= 0) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino_weight_kernel, dim3(wino_grid((long long)O * I)), dim3(256), 0, st, w, U, O, I, mode);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- input: X (view, [N][H][W][C]) -> V [16][Tpad][C]
+// thread = (tile, channel quad); the 4x4 patch starts at (2*ty - 1, 2*tx - 1), zeros outside the image
+__global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T,
+                                                             long long Tpad, float* __restrict__ Vout) {
+    const int C4 = C >> 2;
+    const long long total = Tpad * C4;
+    const long long plane = Tpad * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        const long long t = e / C4;
+        float* dst = Vout + t * C + c;
+        if (t >= T) {                                        // padding tiles: zeros (their GEMM rows are never read back)
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < 16; ++a) *(f32x4*)(dst + a * plane) = z;
+            continue;
+        }
+        const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
+        const float* base = x.p + (long long)n * x.sN + c;
+        f32x4 d[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = 2 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = 2 * tx - 1 + j;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW);
+                d[i][j] = v;
+            }
+        }
+        f32x4 s[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                        // B^T d
+            s[0][j] = d[0][j] - d[2][j];
+            s[1][j] = d[1][j] + d[2][j];
+            s[2][j] = d[2][j] - d[1][j];
+            s[3][j] = d[1][j] - d[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                        // (B^T d) B
+            *(f32x4*)(dst + (4 * i + 0) * plane) = s[i][0] - s[i][2];
+            *(f32x4*)(dst + (4 * i + 1) * plane) = s[i][1] + s[i][2];
+            *(f32x4*)(dst + (4 * i + 2) * plane) = s[i][2] - s[i][1];
+            *(f32x4*)(dst + (4 * i + 3) * plane) = s[i][1] - s[i][3];
+        }
+    }
+}
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
+    const long long T = (long long)N * Th * Tw;
+    if (Tpad < T) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino_input_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- output: M [16][Tpad][C] -> Y (view), 2x2 pixels per tile
+// y = alpha * (A^T m A) + bias[c];  then * (Z > 0 ? 1 : 0.2) when a mask tensor is given (the LeakyReLU' of the dgrad chain)
+__global__ __launch_bounds__(256) void afi_wino_output_kernel(const float* __restrict__ Min, long long Tpad, int N, int H, int W, int C, int Th, int Tw,
+                                                              long long T, const float* __restrict__ bias, float alpha, const AfiView out, const AfiView z) {
+    const int C4 = C >> 2;
+    const long long total = T * C4;
+    const long long plane = Tpad * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        const long long t = e / C4;
+        const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
+        const float* src = Min + t * C + c;
+        f32x4 m[4][4];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) m[a >> 2][a & 3] = *(const f32x4*)(src + a * plane);
+        f32x4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                        // A^T m
+            s[0][j] = m[0][j] + m[1][j] + m[2][j];
+            s[1][j] = m[1][j] - m[2][j] - m[3][j];
+        }
+        f32x4 b = {0.f, 0.f, 0.f, 0.f};
+        if (bias) b = *(const f32x4*)(bias + c);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int yy = 2 * ty + i;
+            if (yy >= H) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int xx = 2 * tx + j;
+                if (xx >= W) continue;
+                f32x4 v = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
+                v = alpha * v + b;
+                if (z.p) {
+                    const f32x4 zz = *(const f32x4*)(z.p + (long long)n * z.sN + (long long)yy * z.sH + (long long)xx * z.sW + c);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] *= (zz[q] > 0.f ? 1.f : AFI_LRELU_SLOPE);
+                }
+                *(f32x4*)(out.p + (long long)n * out.sN + (long long)yy * out.sH + (long long)xx * out.sW + c) = v;
+            }
+        }
+    }
+}
+int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, int C, const float* bias, float alpha, AfiView out, AfiView z,
+                           hipStream_t st) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
+    const long long T = (long long)N * Th * Tw;
+    if (Tpad < T) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino_output_kernel, dim3(wino_grid(T * (C >> 2))), dim3(256), 0, st, M, Tpad, N, H, W, C, Th, Tw, T, bias, alpha, out, z);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}

@@ -144,6 +144,33 @@ def conv3x3_wgrad(dy, x, dw=None, alpha=1.0):
     return dw
 
 
+def conv3x3_wino_fwd(x, w, bias=None):
+    """3x3 conv in Winograd F(2x2,3x3) form (large maps, many channels): out = conv(x, w) + bias."""
+    _check_cuda(x, w, bias)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    w = ohwi(w)
+    n = _lib.load().afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout)
+    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    out = new_pixel_major(N, Cout, H, W, x.device)
+    call("afi_conv3x3_wino_fwd", view_of(x), N, H, W, Cin, _p(w), _p(bias), Cout, view_of(out), _p(ws), n, stream_ptr())
+    return out
+
+
+def conv3x3_wino_dgrad(dy, w, z=None):
+    """Data gradient of the 3x3 conv in Winograd form: dx = conv^T(dy) [* lrelu'(z)]."""
+    _check_cuda(dy, w, z)
+    N, Cout, H, W = dy.shape
+    Cin = w.shape[1]
+    w = ohwi(w)
+    n = _lib.load().afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout)
+    ws = torch.empty(n, device=dy.device, dtype=torch.float32)
+    dx = new_pixel_major(N, Cin, H, W, dy.device)
+    call("afi_conv3x3_wino_dgrad", view_of(dy), N, H, W, Cout, _p(w), Cin, view_of(dx), view_of(z) if z is not None else _NULL_VIEW,
+         _p(ws), n, stream_ptr())
+    return dx
+
+
 def conv3x3s2_fwd(x, w, bias=None, act=0, add=None, add_scale=1.0, post_scale=1.0, keep_act=False):
     """Conv2d(k3, s2, p1) with the fused PAFPN merge:  a = act(conv(x, w) + bias);  out = post_scale*a + add_scale*add.
     act: 0 none, 1 LeakyReLU(0.2), 2 ReLU.  Returns out, or (out, a) with keep_act (a is what the ReLU backward needs)."""

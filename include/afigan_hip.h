@@ -120,6 +120,16 @@ int afi_conv1x1_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float*
                       void* stream);
 int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
 
+/* The same 3x3 / stride-1 / pad-1 conv in Winograd F(2x2,3x3) form (2.25x fewer matrix-core FLOPs; large maps with many
+ * channels): weight + input transforms, one batched 1x1 GEMM over the 16 transform points, output transform with the
+ * epilogue.  fwd: out = conv(x, w) + bias.  dgrad: dx = conv^T(dy) * lrelu'(z) (z NULL = no mask).  ws from
+ * afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout) (the same size serves both directions). */
+long long afi_conv3x3_wino_ws_floats(int N, int H, int W, int Cin, int Cout);
+int afi_conv3x3_wino_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
+                         afi_view_t out, float* ws, long long ws_floats, void* stream);
+int afi_conv3x3_wino_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w_ohwi, int Cin, afi_view_t dx,
+                           afi_view_t z_or_null, float* ws, long long ws_floats, void* stream);
+
 /* Conv2d(k=3, stride=2, padding=1) on [N,Hi,Wi,Cin] -> [N,Ho,Wo,Cout], Ho = ceil(Hi/2): the PAFPN bottom-up downsample conv
  * with its fused merge (pafpn_sr.py:105-117,177-183):
  *   a = act(conv(x,w) + bias)            -> act_out (or NULL; kept for the ReLU backward)

@@ -262,3 +262,33 @@ def test_conv3x3_stride2(amd, N, Cin, Cout, Hi, Wi):
     _close(got, old + 0.5 * xg.grad, what="dgrad accumulate")
     g = ops.relu_bwd(dyd, act, scale=0.5)
     _close(g, 0.5 * dy * (act.cpu() > 0).float(), what="relu bwd")              # mask of the kept activation itself
+
+
+WINO_CASES = [
+    # N, Cin, Cout, H, W  (odd sizes: the last tile row / column is half empty; Tpad rounds the tile count up to 128)
+    (1, 16, 16, 5, 7),
+    (2, 20, 8, 8, 6),
+    (1, 32, 64, 13, 21),
+    (2, 256, 128, 50, 84),
+    (1, 64, 160, 33, 41),
+    (1, 128, 256, 101, 169),
+]
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W", WINO_CASES)
+def test_conv3x3_winograd_fwd_dgrad(amd, N, Cin, Cout, H, W):
+    """Winograd F(2x2,3x3) form of the 3x3 conv (forward + bias, data gradient with the LeakyReLU' mask, a cropped-view input)
+    against torch-CPU fp32; same 1e-3 bar as the direct kernels (measured ~1e-6)."""
+    ops = amd.ops
+    x, w, b = _rand(N, Cin, H, W, seed=1), _rand(Cout, Cin, 3, 3, seed=2) * 0.1, _rand(Cout, seed=3)
+    dy, z = _rand(N, Cout, H, W, seed=4), _rand(N, Cin, H, W, seed=5)
+    xg = x.clone().requires_grad_(True)
+    ref = F.conv2d(xg, w, b, 1, 1)
+    ref.backward(dy)
+    _close(ops.conv3x3_wino_fwd(_pm(x), w.cuda(), b.cuda()), ref, tol=1e-4, what="wino fwd")
+    _close(ops.conv3x3_wino_dgrad(_pm(dy), w.cuda()), xg.grad, tol=1e-4, what="wino dgrad")
+    mask = torch.where(z > 0, torch.ones_like(z), torch.full_like(z, 0.2))
+    _close(ops.conv3x3_wino_dgrad(_pm(dy), w.cuda(), z=_pm(z)), xg.grad * mask, tol=1e-4, what="wino dgrad + mask")
+    big = _rand(N, Cin, H + 3, W + 2, seed=6)
+    refc = F.conv2d(big[:, :, :H, :W], w, None, 1, 1)
+    _close(ops.conv3x3_wino_fwd(_pm(big)[:, :, :H, :W], w.cuda()), refc, tol=1e-4, what="wino fwd, cropped view in")

@@ -58,3 +58,18 @@ if "convT" in which:
         ms = t(lambda: ops.convT_dgrad(dy, wp, C_)); r.append(f"dgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
         ms = t(lambda: ops.convT_wgrad(dy, x)); r.append(f"wgrad {ms:8.3f} ms {fl/ms/1e9:6.1f} TF")
         print(f"{name:12s} N{N} {H}x{W} {C_}->{C_}: " + " | ".join(r), flush=True)
+
+# Winograd F(2x2,3x3) form vs the direct kernels on the big discriminator layers
+if "wino" in which:
+    for name, N, H, W, Ci, Co in [("D2@P2", 2, 200, 336, 1024, 1024), ("D1@P2", 2, 200, 336, 512, 1024), ("D0@P2", 2, 200, 336, 256, 512), ("D2@P3", 2, 100, 168, 1024, 1024),
+                                  ("D1@P3", 2, 100, 168, 512, 1024), ("D2@P4", 2, 50, 84, 1024, 1024), ("G0@lrP2", 2, 104, 168, 256, 256)]:
+        x = ops.new_pixel_major(N, Ci, H, W, "cuda"); x.normal_()
+        w = ops.new_ohwi(Co, Ci, 3, 3, "cuda", zero=False); w.normal_(0, 0.02)
+        dy = ops.new_pixel_major(N, Co, H, W, "cuda"); dy.normal_()
+        fl = 2.0 * N * H * W * Ci * Co * 9
+        r = []
+        ms = t(lambda: ops.conv3x3_fwd(x, w, None), iters=5); r.append(f"direct fwd {ms:7.3f} ms")
+        ms = t(lambda: ops.conv3x3_wino_fwd(x, w, None), iters=5); r.append(f"wino fwd {ms:7.3f} ms ({fl/ms/1e9:6.1f} eff TF)")
+        ms = t(lambda: ops.conv3x3_dgrad(dy, w), iters=5); r.append(f"direct dgrad {ms:7.3f} ms")
+        ms = t(lambda: ops.conv3x3_wino_dgrad(dy, w), iters=5); r.append(f"wino dgrad {ms:7.3f} ms ({fl/ms/1e9:6.1f} eff TF)")
+        print(f"{name:8s} N{N} {H}x{W} {Ci}->{Co}: " + " | ".join(r), flush=True)
