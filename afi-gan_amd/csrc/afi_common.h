@@ -75,6 +75,7 @@ struct AfiWgradGemm {
     AfiView X;                                  // input activations, gathered at (y*x_stride+dy, x*x_stride+dx) inside [0,xH) x [0,xW)
     int x_stride, xH, xW;
     float* DW; long long dw_sRow, dw_sTap;      // dW + co'*dw_sRow + tap*dw_sTap + ci
+    long long dy_sTap, x_sTap;                  // ntaps == 16 (Winograd transform points): operand planes, DY + tap*dy_sTap, X + tap*x_sTap
     float alpha;
     int splitK;
 };

@@ -508,14 +508,14 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiW
         const long long pix = k_begin + a_kr + A_RPP * i;
         const int n = (int)(pix / HW); const int rem = (int)(pix - (long long)n * HW);
         ay[i] = rem / p.W; ax[i] = rem - ay[i] * p.W;
-        a_off[i] = (long long)n * p.DY.sN + ay[i] * a_eH + ax[i] * a_eW + (a_ph >> 1) * p.DY.sH + (a_ph & 1) * p.DY.sW + a_ch;
+        a_off[i] = (long long)n * p.DY.sN + ay[i] * a_eH + ax[i] * a_eW + (a_ph >> 1) * p.DY.sH + (a_ph & 1) * p.DY.sW + a_ch + (long long)tap * p.dy_sTap;
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
         const long long pix = k_begin + b_kr + B_RPP * i;
         const int n = (int)(pix / HW); const int rem = (int)(pix - (long long)n * HW);
         by[i] = rem / p.W; bx[i] = rem - by[i] * p.W;
-        b_off[i] = (long long)n * p.X.sN + by[i] * b_eH + dy * p.X.sH + bx[i] * b_eW + dx * p.X.sW + b_col;
+        b_off[i] = (long long)n * p.X.sN + by[i] * b_eH + dy * p.X.sH + bx[i] * b_eW + dx * p.X.sW + b_col + (long long)tap * p.x_sTap;
     }
     long long k_pix = k_begin;                             // first pixel of the NEXT stage to gather
 
@@ -840,7 +840,7 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st) {
     const long long P = (long long)p.N * p.H * p.W;
     if (P <= 0 || p.Mrows <= 0 || p.Ncols <= 0) return AFI_ERR_BAD_ARG;
-    if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_BAD_ARG;
+    if (p.ntaps != 1 && p.ntaps != 9 && p.ntaps != 16) return AFI_ERR_BAD_ARG;     // 16: the Winograd transform points (no spatial shift, operand planes)
     if ((p.Ncols & 3) || (p.dy_up == 2 && (p.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;   // float4 granularity
     if (p.Mrows <= 32) return launch_wgrad<32, 128, 1, 4>(p, st);
     if (p.Mrows <= 64) return launch_wgrad<64, 128, 2, 2>(p, st);

@@ -35,6 +35,8 @@ int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out
 int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st);
 int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
 int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st);
+int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st);
+int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
 int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, int C, const float* bias, float alpha, AfiView out, AfiView z,
                            hipStream_t st);
 int afi_launch_bilinear2x_bwd(const float* dout, int N, int H, int W, int C, float beta, float* dx, hipStream_t st);
@@ -165,6 +167,31 @@ static int wino_conv(int mode, AfiView in, int N, int H, int W, int K, const flo
     return afi_launch_wino_output(Mb, Tpad, N, H, W, Nc, bias, 1.f, out, z, st);
 }
 
+// weight gradient in Winograd F(3x3,2x2) form: dW[Cout][3][3][Cin] += alpha * sum_pix dy (x) x.  Same workspace layout as wino_conv
+// with K = Cin, Nc = Cout:  [dU 16*Cin*Cout][V 16*Tpad*Cin][Q 16*Tpad*Cout].
+static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws, long long ws_floats,
+                      hipStream_t st) {
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
+    if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
+    const long long Tpad = wino_tpad(N, H, W);
+    float* dU = ws;
+    float* Vb = dU + align4(16LL * Cin * Cout);
+    float* Qb = Vb + align4(16 * Tpad * Cin);
+    if (hipMemsetAsync(dU, 0, sizeof(float) * 16 * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
+    AFI_TRY(afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st));
+    AFI_TRY(afi_launch_wino_dy(dy, N, H, W, Cout, Tpad, Qb, st));
+    AfiWgradGemm g;
+    memset(&g, 0, sizeof(g));
+    g.N = 1; g.H = 1; g.W = (int)Tpad; g.ntaps = 16;
+    g.Mrows = Cout; g.Ncols = Cin;
+    g.DY = AfiView{Qb, 0, 0, Cout}; g.dy_up = 1; g.CoutPhase = Cout; g.dy_sTap = Tpad * Cout;
+    g.X = AfiView{Vb, 0, 0, Cin}; g.x_stride = 1; g.xH = 1; g.xW = (int)Tpad; g.x_sTap = Tpad * Cin;
+    g.DW = dU; g.dw_sRow = Cin; g.dw_sTap = (long long)Cout * Cin;
+    g.alpha = 1.f; g.splitK = 0;
+    AFI_TRY(afi_launch_wgrad_gemm(g, st));
+    return afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
+}
+
 // Winograd or direct for a 3x3 conv of the discriminator: from ~1 K pixels on the 2.25x fewer matrix-core FLOPs win over the
 // transform traffic (measured: 2x336x200 1024->1024 18.8 -> 11.8 ms, 2x84x50 1.38 -> 0.72 ms).  AFI_WINO=0 switches it off.
 static bool use_wino(long long P) {
@@ -225,6 +252,12 @@ int afi_conv3x3_wino_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const f
                            long long ws_floats, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || !ws) return AFI_ERR_BAD_ARG;
     return wino_conv(1, V(dy), N, H, W, Cout, w, Cin, nullptr, V(dx), z.p ? V(z) : null_view(), ws, ws_floats, nullptr, 0, (hipStream_t)stream);
+}
+
+int afi_conv3x3_wino_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws,
+                           long long ws_floats, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || !ws || !dw) return AFI_ERR_BAD_ARG;
+    return wino_wgrad(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha, ws, ws_floats, (hipStream_t)stream);
 }
 
 int afi_conv1x1_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
@@ -663,7 +696,7 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     return w;
 }
 long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W) { return disc_ws(F, N, H, W).total; }
-struct DiscBwdWs { long long o_g[3], o_dd9, o_red, o_red2, o_part, n_part, o_wino, n_wino, total; };
+struct DiscBwdWs { long long o_g[3], o_dd9, o_red, o_red2, o_part, n_part, o_wino, n_wino, o_wino2, total; };
 static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     DiscBwdWs w;
     const long long P = (long long)N * H * W;
@@ -677,7 +710,8 @@ static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     w.n_part = part_floats({P * F[0], P * F[1], P * F[2], P * F[3]});
     w.o_part = o; o += w.n_part;
     w.n_wino = disc_wino_floats(F, N, H, W);
-    w.o_wino = o; o += w.n_wino;
+    w.o_wino = o; o += w.n_wino;                          // data-gradient chain (main stream)
+    w.o_wino2 = o; o += w.n_wino;                         // weight gradients (they may run on the side stream beside it)
     w.total = o;
     return w;
 }
@@ -785,7 +819,8 @@ int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t*
         if (gr->b[n]) AFI_TRY(afi_launch_colsum_accum(g_, P, co, co, 1.f, gr->b[n], red2, sd));
         AfiView gy = dense_view(g_, H, W, co);
         AfiView xin = (n == 0) ? V(xv) : dense_view(ws + l.o_y[n - 1], H, W, ci);
-        if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
+        if (gr->w[n] && s.n_wino > 0) AFI_TRY(wino_wgrad(gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd));
+        else if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0 && s.n_wino > 0) {
             AFI_TRY(wino_conv(1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), xin, scratch + s.o_wino,
                               s.n_wino, part_, part_n_, st));

@@ -171,3 +171,92 @@ int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, 
     hipLaunchKernelGGL(afi_wino_output_kernel, dim3(wino_grid(T * (C >> 2))), dim3(256), 0, st, M, Tpad, N, H, W, C, Th, Tw, T, bias, alpha, out, z);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
+
+// ================================================================ weight gradient: F(3x3, 2x2)
+//   dW[ky][kx] = sum_tiles sum_{i,j<2} dY[2ty+i][2tx+j] * X[2ty-1+i+ky][2tx-1+j+kx]
+// is a correlation of the SAME 4x4 input patch with the tile's 2x2 block of dY: with the interpolation points of F(2,3) it
+// needs 16 products per (co, ci) and tile instead of 36, and B^T is the same matrix, so V = B^T d B is shared with the forward:
+//   Q[a][t][co] = G' dy G'^T                     (afi_wino_dy_kernel;  G' = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]])
+//   dU[a][co][ci] = sum_t Q[a][t][co] * V[a][t][ci]     16 GEMMs with K = tiles: ONE launch of the weight-gradient kernel
+//   dW[co][ky][kx][ci] += A'^T dU A'             (afi_wino_dw_kernel;  A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]])
+__global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
+                                                          float* __restrict__ Q) {
+    const int C4 = C >> 2;
+    const long long total = Tpad * C4;
+    const long long plane = Tpad * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        const long long t = e / C4;
+        float* dst = Q + t * C + c;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (t >= T) {
+#pragma unroll
+            for (int a = 0; a < 16; ++a) *(f32x4*)(dst + a * plane) = zero;
+            continue;
+        }
+        const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
+        const float* base = dy.p + (long long)n * dy.sN + c;
+        f32x4 d[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int yy = 2 * ty + i, xx = 2 * tx + j;
+                d[i][j] = (yy < H && xx < W) ? *(const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW) : zero;
+            }
+        f32x4 a[4][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            a[0][j] = d[0][j];
+            a[1][j] = 0.5f * (d[0][j] + d[1][j]);
+            a[2][j] = 0.5f * (d[0][j] - d[1][j]);
+            a[3][j] = d[1][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *(f32x4*)(dst + (4 * i + 0) * plane) = a[i][0];
+            *(f32x4*)(dst + (4 * i + 1) * plane) = 0.5f * (a[i][0] + a[i][1]);
+            *(f32x4*)(dst + (4 * i + 2) * plane) = 0.5f * (a[i][0] - a[i][1]);
+            *(f32x4*)(dst + (4 * i + 3) * plane) = a[i][1];
+        }
+    }
+}
+int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
+    const long long T = (long long)N * Th * Tw;
+    if (Tpad < T) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino_dy_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// dW[o][ky][kx][i] += alpha * (A'^T dU A')[ky][kx]  with dU [16][O][I]
+__global__ void afi_wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dW, int O, int I, float alpha) {
+    const long long total = (long long)O * I;
+    const long long plane = total;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % I), o = (int)(e / I);
+        float m[4][4];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) m[a >> 2][a & 3] = dU[a * plane + e];
+        float s[3][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = m[0][j] + m[1][j] + m[2][j];
+            s[1][j] = m[1][j] - m[2][j];
+            s[2][j] = m[1][j] + m[2][j] - m[3][j];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float* dst = dW + ((long long)o * 9 + 3 * k) * I + i;
+            dst[0] += alpha * (s[k][0] + s[k][1] + s[k][2]);
+            dst[I] += alpha * (s[k][1] - s[k][2]);
+            dst[2 * I] += alpha * (s[k][1] + s[k][2] - s[k][3]);
+        }
+    }
+}
+int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st) {
+    if (O <= 0 || I <= 0) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino_dw_kernel, dim3(wino_grid((long long)O * I)), dim3(256), 0, st, dU, dW, O, I, alpha);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}

@@ -171,6 +171,20 @@ def conv3x3_wino_dgrad(dy, w, z=None):
     return dx
 
 
+def conv3x3_wino_wgrad(dy, x, dw=None, alpha=1.0):
+    """Weight gradient of the 3x3 conv in Winograd F(3x3,2x2) form; accumulates into dw ([Cout,Cin,3,3] with OHWI memory)."""
+    _check_cuda(dy, x, dw)
+    N, Cout, H, W = dy.shape
+    Cin = x.shape[1]
+    if dw is None:
+        dw = new_ohwi(Cout, Cin, 3, 3, dy.device)
+    assert dw.permute(0, 2, 3, 1).is_contiguous()
+    n = _lib.load().afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout)
+    ws = torch.empty(n, device=dy.device, dtype=torch.float32)
+    call("afi_conv3x3_wino_wgrad", view_of(dy), view_of(x), N, H, W, Cout, Cin, _p(dw), float(alpha), _p(ws), n, stream_ptr())
+    return dw
+
+
 def conv3x3s2_fwd(x, w, bias=None, act=0, add=None, add_scale=1.0, post_scale=1.0, keep_act=False):
     """Conv2d(k3, s2, p1) with the fused PAFPN merge:  a = act(conv(x, w) + bias);  out = post_scale*a + add_scale*add.
     act: 0 none, 1 LeakyReLU(0.2), 2 ReLU.  Returns out, or (out, a) with keep_act (a is what the ReLU backward needs)."""

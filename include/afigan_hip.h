@@ -130,6 +130,11 @@ int afi_conv3x3_wino_fwd(afi_view_t x, int N, int H, int W, int Cin, const float
 int afi_conv3x3_wino_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w_ohwi, int Cin, afi_view_t dx,
                            afi_view_t z_or_null, float* ws, long long ws_floats, void* stream);
 
+/* weight gradient of the same conv in Winograd F(3x3,2x2) form (shares the input transform with the forward):
+ * dw[Cout][3][3][Cin] += alpha * sum_pix dy (x) x */
+int afi_conv3x3_wino_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws,
+                           long long ws_floats, void* stream);
+
 /* Conv2d(k=3, stride=2, padding=1) on [N,Hi,Wi,Cin] -> [N,Ho,Wo,Cout], Ho = ceil(Hi/2): the PAFPN bottom-up downsample conv
  * with its fused merge (pafpn_sr.py:105-117,177-183):
  *   a = act(conv(x,w) + bias)            -> act_out (or NULL; kept for the ReLU backward)

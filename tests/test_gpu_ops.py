@@ -292,3 +292,10 @@ def test_conv3x3_winograd_fwd_dgrad(amd, N, Cin, Cout, H, W):
     big = _rand(N, Cin, H + 3, W + 2, seed=6)
     refc = F.conv2d(big[:, :, :H, :W], w, None, 1, 1)
     _close(ops.conv3x3_wino_fwd(_pm(big)[:, :, :H, :W], w.cuda()), refc, tol=1e-4, what="wino fwd, cropped view in")
+    # weight gradient, F(3x3,2x2): accumulates into an existing buffer
+    wg = w.clone().requires_grad_(True)
+    F.conv2d(x, wg, None, 1, 1).backward(dy)
+    _close(ops.conv3x3_wino_wgrad(_pm(dy), _pm(x)), wg.grad, tol=1e-4, what="wino wgrad")
+    old = _rand(Cout, Cin, 3, 3, seed=7)
+    dw0 = ops.ohwi(old.cuda()).clone(memory_format=torch.preserve_format)
+    _close(ops.conv3x3_wino_wgrad(_pm(dy), _pm(x), dw=dw0, alpha=0.5), old + 0.5 * wg.grad, tol=1e-4, what="wino wgrad accumulate")

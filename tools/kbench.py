@@ -72,4 +72,7 @@ if "wino" in which:
         ms = t(lambda: ops.conv3x3_wino_fwd(x, w, None), iters=5); r.append(f"wino fwd {ms:7.3f} ms ({fl/ms/1e9:6.1f} eff TF)")
         ms = t(lambda: ops.conv3x3_dgrad(dy, w), iters=5); r.append(f"direct dgrad {ms:7.3f} ms")
         ms = t(lambda: ops.conv3x3_wino_dgrad(dy, w), iters=5); r.append(f"wino dgrad {ms:7.3f} ms ({fl/ms/1e9:6.1f} eff TF)")
+        dw = ops.new_ohwi(Co, Ci, 3, 3, "cuda")
+        ms = t(lambda: ops.conv3x3_wgrad(dy, x, dw=dw), iters=5); r.append(f"direct wgrad {ms:7.3f} ms")
+        ms = t(lambda: ops.conv3x3_wino_wgrad(dy, x, dw=dw), iters=5); r.append(f"wino wgrad {ms:7.3f} ms ({fl/ms/1e9:6.1f} eff TF)")
         print(f"{name:8s} N{N} {H}x{W} {Ci}->{Co}: " + " | ".join(r), flush=True)
