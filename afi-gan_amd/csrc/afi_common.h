@@ -44,6 +44,7 @@ struct AfiPixGemm {
     //               RC form (b_rc = 1): row k at  B + (kphase*Ck + c)*b_sRow + tap*b_sTap + n  (n contiguous)
     const float* B;
     long long b_sRow, b_sTap;
+    int n_fastest;      // tile walk: 0 = M fastest per N tile (weight panel stationary in L2), 1 = N fastest per M tile (A tile stationary)
     long long b_sImg;   // weight stride per GEMM "image" (Winograd: one weight matrix per transform point); 0 = shared weights
     // output: column col -> phase = col / CoutPhase, channel = col % CoutPhase;
     // pixel (y*o_up + (phase>>1), x*o_up + (phase&1))

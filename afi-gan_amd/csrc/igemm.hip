@@ -169,7 +169,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_
     // (L2 hits) while each reads its own activation patch once per channel chunk.  (N-fastest order made every block pull
     // its 4.7 MB weight panel through the fabric: FETCH_SIZE 54 GB per step for this kernel vs ~6 GB algorithmic.)
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int tile_n = jb / chunk, tile_m = xcd * chunk + (jb - tile_n * chunk);
+    // n_fastest (short-K GEMMs with small weight panels, i.e. the batched Winograd GEMM: a 128-column panel is K*512 B): walk the
+    // N tiles of one M tile back to back instead, so the A tile is read from HBM once and re-used from L2 by its N tiles
+    const int tile_n = p.n_fastest ? jb % ntile_n : jb / chunk;
+    const int tile_m = xcd * chunk + (p.n_fastest ? jb / ntile_n : jb - tile_n * chunk);
     if (tile_n >= ntile_n || tile_m * ntile_n >= ntiles) return;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int HW = p.H * p.W;

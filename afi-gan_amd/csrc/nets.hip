@@ -161,6 +161,7 @@ static int wino_conv(int mode, AfiView in, int N, int H, int W, int K, const flo
     g.ntaps = 1; g.Ck = K; g.Ncols = Nc; g.CoutPhase = Nc;
     g.A = AfiView{Vb, Tpad * K, 0, K};
     g.B = U; g.b_sRow = K; g.b_sTap = 0; g.b_sImg = (long long)K * Nc;
+    g.n_fastest = 1;                                       // A tile (128 x K) stationary in L2 across its N tiles: +5 % on the big layers
     g.O = AfiView{Mb, Tpad * Nc, 0, Nc};
     g.partial = part; g.partial_floats = part_floats;
     AFI_TRY(afi_launch_pix_gemm(g, 0, st));
