@@ -623,7 +623,7 @@ struct ProfState {
     size_t used = 0;
 } g_prof;
 const char* kKindNames[] = {
-    "pix_gemm<128x128,KC,linear> (conv fwd, mid-size / ragged maps)", "pix_gemm<128x64,KC>", "pix_gemm<128x32,KC>", "pix_gemm<64x64,KC>",
+    "pix_gemm<128x128,KC,linear> (batched Winograd GEMM; also 1x1 and ragged-map convs)", "pix_gemm<128x64,KC>", "pix_gemm<128x32,KC>", "pix_gemm<64x64,KC>",
     "pix_gemm<128x128,RC,linear> (conv dgrad, mid-size / ragged maps)", "pix_gemm<128x64,RC>", "pix_gemm<128x32,RC>", "pix_gemm<64x64,RC>",
     "wgrad_gemm<128x128>", "wgrad_gemm<64x128>", "wgrad_gemm<32x128>",
     "pix_gemm<128x128,KC,halo> (conv fwd)", "pix_gemm<128x128,RC,halo> (conv dgrad)"};   // one kind per kernel instantiation, as rocprofv3 lists them
