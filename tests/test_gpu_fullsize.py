@@ -1,5 +1,6 @@
 """Parity at BASELINE.json's full sizes (configs[1]: per-GPU batch 2, P2 = 200x336) where the whole-tensor oracle would
-take minutes: the three dominant kernels (forward, data gradient, weight gradient of D's 512 -> 1024 conv at P2, and the
+take minutes: the three dominant kernels (forward, data gradient, weight gradient of D's 512 -> 1024 conv at P2 in both the
+direct and the Winograd form, and the
 generator's 256 -> 256 convs on the 208x336 up-sampled map) are checked
 
   * against an fp64 CPU evaluation of the defining sums at a few hundred sampled outputs (borders and tile seams included),
@@ -29,8 +30,9 @@ def _sample_positions(rng, N, H, W, n):
     return pos
 
 
+@pytest.mark.parametrize("algo", ["direct", "winograd"])
 @pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 512, 1024, 200, 336), (2, 256, 256, 208, 336)])
-def test_conv3x3_full_size_sampled_fp64_and_properties(amd, N, Cin, Cout, H, W):
+def test_conv3x3_full_size_sampled_fp64_and_properties(amd, N, Cin, Cout, H, W, algo):
     ops = amd.ops
     rng = np.random.default_rng(0)
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -40,9 +42,14 @@ def test_conv3x3_full_size_sampled_fp64_and_properties(amd, N, Cin, Cout, H, W):
     w = ops.new_ohwi(Cout, Cin, 3, 3, "cuda", zero=False); w.normal_(0, 0.02, generator=g)
     b = torch.randn(Cout, device="cuda", generator=g)
 
-    out = ops.conv3x3_fwd(x, w, b)
-    dx = ops.conv3x3_dgrad(dy, w)
-    dw = ops.conv3x3_wgrad(dy, x)
+    if algo == "winograd":
+        out = ops.conv3x3_wino_fwd(x, w, b)
+        dx = ops.conv3x3_wino_dgrad(dy, w)
+        dw = ops.conv3x3_wino_wgrad(dy, x)
+    else:
+        out = ops.conv3x3_fwd(x, w, b)
+        dx = ops.conv3x3_dgrad(dy, w)
+        dw = ops.conv3x3_wgrad(dy, x)
     xc, wc, bc, dyc = x.cpu().double(), w.cpu().double(), b.cpu().double(), dy.cpu().double()   # logical NCHW / OIHW views
     oc, dxc, dwc = out.cpu().double(), dx.cpu().double(), dw.cpu().double()
     xp = torch.nn.functional.pad(xc, (1, 1, 1, 1))
@@ -64,15 +71,16 @@ def test_conv3x3_full_size_sampled_fp64_and_properties(amd, N, Cin, Cout, H, W):
         ref = (dyc[:, co] * xp[:, ci, ky:ky + H, kx:kx + W]).sum().item()
         assert abs(dwc[co, ci, ky, kx].item() - ref) <= 1e-3 * scale_dw, ("wgrad", co, ci, ky, kx)
 
+    fwd = ops.conv3x3_wino_fwd if algo == "winograd" else ops.conv3x3_fwd
     # ---- linearity of the forward kernel at full size ----
     mix = ops.new_pixel_major(N, Cin, H, W, "cuda")
     torch.add(x * 0.75, y2, alpha=-1.25, out=mix)
-    lhs = ops.conv3x3_fwd(mix, w, None)
-    rhs = 0.75 * ops.conv3x3_fwd(x, w, None) - 1.25 * ops.conv3x3_fwd(y2, w, None)
+    lhs = fwd(mix, w, None)
+    rhs = 0.75 * fwd(x, w, None) - 1.25 * fwd(y2, w, None)
     assert ((lhs - rhs).abs().max() / rhs.abs().max()).item() < 1e-3
 
     # ---- adjoint identities (the three kernels agree with each other on every element, not only on samples) ----
-    o0 = ops.conv3x3_fwd(x, w, None)
+    o0 = fwd(x, w, None)
     s_fwd = (o0.double() * dy.double()).sum().item()
     s_dgrad = (x.double() * dx.double()).sum().item()
     s_wgrad = (w.double() * dw.double()).sum().item()
