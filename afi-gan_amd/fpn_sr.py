@@ -53,6 +53,12 @@ class _LateralMergeFn(torch.autograd.Function):
         return dfeat, dw, db, dtd
 
 
+def _winograd_pays(x, cout):
+    """Large maps with many channels: the Winograd F(2x2,3x3) form of the 3x3 conv (csrc/winograd.hip) beats the direct kernel."""
+    n, cin, h, w = x.shape
+    return n * h * w >= 4096 and cin >= 128 and cout >= 128
+
+
 class _Conv3x3Fn(torch.autograd.Function):
     """p = conv3x3(prev, w) + b   (fpn_sr.py:145,158)."""
 
@@ -60,7 +66,9 @@ class _Conv3x3Fn(torch.autograd.Function):
     def forward(ctx, x, w, b):
         xp = ops.pixel_major(x.detach())
         wk = ops.ohwi(w.detach())
-        out = ops.conv3x3_fwd(xp, wk, b.detach() if b is not None else None)
+        ctx.wino = _winograd_pays(xp, wk.shape[0])
+        fwd = ops.conv3x3_wino_fwd if ctx.wino else ops.conv3x3_fwd
+        out = fwd(xp, wk, b.detach() if b is not None else None)
         ctx.save_for_backward(xp, wk)
         ctx.has_bias = b is not None
         return out
@@ -70,8 +78,9 @@ class _Conv3x3Fn(torch.autograd.Function):
         xp, wk = ctx.saved_tensors
         dy = _dense_pm(dy)
         need = ctx.needs_input_grad
-        dx = ops.conv3x3_dgrad(dy, wk) if need[0] else None
-        dw = ops.conv3x3_wgrad(dy, xp) if need[1] else None
+        dgrad, wgrad = (ops.conv3x3_wino_dgrad, ops.conv3x3_wino_wgrad) if ctx.wino else (ops.conv3x3_dgrad, ops.conv3x3_wgrad)
+        dx = dgrad(dy, wk) if need[0] else None
+        dw = wgrad(dy, xp) if need[1] else None
         db = ops.bias_grad(dy) if (ctx.has_bias and need[2]) else None
         return dx, dw, db
 
