@@ -35,6 +35,7 @@ int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out
 int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st);
 int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
 int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st);
+int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
 int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st);
 int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
 int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, int C, const float* bias, float alpha, AfiView out, AfiView z,
@@ -166,6 +167,37 @@ static int wino_conv(int mode, AfiView in, int N, int H, int W, int K, const flo
     g.partial = part; g.partial_floats = part_floats;
     AFI_TRY(afi_launch_pix_gemm(g, 0, st));
     return afi_launch_wino_output(Mb, Tpad, N, H, W, Nc, bias, 1.f, out, z, st);
+}
+
+// Any 3x3 / stride-1 conv DESCRIPTOR of the pixel GEMM (forward, b_rc = 0, or data gradient, b_rc = 1) run in Winograd form: the
+// batched GEMM writes M, the output transform applies the descriptor's own epilogue.  Eligible: 9 taps, one K phase, no up-sampled
+// gather, dense [rows][3][3][K-or-N] weights, >= 128 channels on both sides, >= 1024 pixels.
+static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
+    static const int on = getenv("AFI_WINO_G") ? atoi(getenv("AFI_WINO_G")) : 1;
+    if (!on || g.ntaps != 9 || g.nKphase != 1 || g.a_up != 1 || g.gtap || g.r2_post) return false;
+    if (g.Ck < 128 || g.Ncols < 128 || (g.Ck & 3) || (g.Ncols & 3)) return false;
+    if ((long long)g.N * g.H * g.W < 1024) return false;
+    const int I = b_rc ? g.Ncols : g.Ck;                   // innermost weight dimension of w[O][3][3][I]
+    return g.b_sTap == I && g.b_sRow == 9LL * I && g.a_sgn == (b_rc ? -1 : 1);
+}
+static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st) {
+    const int K = g.Ck, Nc = g.Ncols;
+    if (ws_floats < wino_ws_floats(g.N, g.H, g.W, K, Nc)) return AFI_ERR_WORKSPACE;
+    const long long Tpad = wino_tpad(g.N, g.H, g.W);
+    float* U = ws;
+    float* Vb = U + align4(16LL * K * Nc);
+    float* Mb = Vb + align4(16 * Tpad * K);
+    AFI_TRY(afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
+    AFI_TRY(afi_launch_wino_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
+    AfiPixGemm q = pix_default(16, 1, (int)Tpad);
+    q.ntaps = 1; q.Ck = K; q.Ncols = Nc; q.CoutPhase = Nc;
+    q.A = AfiView{Vb, Tpad * K, 0, K};
+    q.B = U; q.b_sRow = K; q.b_sTap = 0; q.b_sImg = (long long)K * Nc;
+    q.n_fastest = 1;
+    q.O = AfiView{Mb, Tpad * Nc, 0, Nc};
+    q.partial = part; q.partial_floats = part_floats;
+    AFI_TRY(afi_launch_pix_gemm(q, 0, st));
+    return afi_launch_wino_output_epi(Mb, Tpad, g, st);
 }
 
 // weight gradient in Winograd F(3x3,2x2) form: dW[Cout][3][3][Cin] += alpha * sum_pix dy (x) x.  Same workspace layout as wino_conv
@@ -457,9 +489,20 @@ static long long part_floats(std::initializer_list<long long> layer_mn) {   // M
     }
     return align4(want);
 }
+// Winograd scratch of one interpolator call: the largest of its eligible convs (C->C and L->C on the low-res grid, the
+// conv-transpose as C->4C, C->C on the hi-res grid); 0 when nothing is eligible (small maps / few channels)
+static long long gen_wino_floats(int C, int L, int N, int H, int W) {
+    static const int on = getenv("AFI_WINO_G") ? atoi(getenv("AFI_WINO_G")) : 1;
+    if (!on || C < 128) return 0;
+    long long m = 0;
+    auto upd = [&](long long v) { if (v > m) m = v; };
+    if ((long long)N * H * W >= 1024) { upd(wino_ws_floats(N, H, W, C, C)); upd(wino_ws_floats(N, H, W, L, C)); upd(wino_ws_floats(N, H, W, C, 4 * C)); }
+    if (4LL * N * H * W >= 1024) upd(wino_ws_floats(N, 2 * H, 2 * W, C, C));
+    return m;
+}
 struct GenWs {
     long long P, L;
-    long long o_wp, o_buf, o_t, o_a7, o_u, o_part, n_part, total;
+    long long o_wp, o_buf, o_t, o_a7, o_u, o_part, n_part, o_wino, n_wino, total;
 };
 static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenWs w;
@@ -472,6 +515,8 @@ static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_u = o; o += align4(4 * w.P * C);
     w.n_part = part_floats({w.P * C, 4 * w.P * C});
     w.o_part = o; o += w.n_part;
+    w.n_wino = gen_wino_floats(C, (int)w.L, N, H, W);
+    w.o_wino = o; o += w.n_wino;
     w.total = o;
     return w;
 }
@@ -479,7 +524,7 @@ long long afi_generator_fwd_ws_floats(int C, int G, int n_rdb, int N, int H, int
 
 // backward scratch layout: [dU 4P*C][gA P*C][gB P*C][dBuf0 P*L][dBuf1 P*L][dWp 36*C*C][red]
 struct GenBwdWs {
-    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_red, o_part, n_part, total;
+    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_red, o_part, n_part, o_wino, n_wino, o_wino2, total;
 };
 static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenBwdWs w;
@@ -494,6 +539,9 @@ static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_red = o; o += align4(afi_reduce_scratch_floats(C));
     w.n_part = part_floats({P * C, P * L, 4 * P * C});
     w.o_part = o; o += w.n_part;
+    w.n_wino = gen_wino_floats(C, (int)L, N, H, W);
+    w.o_wino = o; o += w.n_wino;                          // data-gradient chain (main stream)
+    w.o_wino2 = o; o += w.n_wino;                         // weight gradients (side stream on small maps)
     w.total = o;
     return w;
 }
@@ -515,7 +563,11 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
     hipStream_t st = (hipStream_t)stream;
     float* const part_ = ws + l.o_part;
     const long long part_n_ = l.n_part;
-    auto PG = [&](AfiPixGemm g, int b_rc) { g.partial = part_; g.partial_floats = part_n_; return afi_launch_pix_gemm(g, b_rc, st); };
+    auto PG = [&](AfiPixGemm g, int b_rc) {
+        if (l.n_wino > 0 && wino_eligible(g, b_rc)) return wino_run(g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st);
+        g.partial = part_; g.partial_floats = part_n_;
+        return afi_launch_pix_gemm(g, b_rc, st);
+    };
     const int L = (int)l.L;
     const float rs = prm->residual_scale;
     float* wp = ws + l.o_wp;
@@ -578,7 +630,17 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     hipStream_t st = (hipStream_t)stream;
     float* const part_ = scratch + s.o_part;
     const long long part_n_ = s.n_part;
-    auto PG = [&](AfiPixGemm g, int b_rc) { g.partial = part_; g.partial_floats = part_n_; return afi_launch_pix_gemm(g, b_rc, st); };
+    auto PG = [&](AfiPixGemm g, int b_rc) {
+        if (s.n_wino > 0 && wino_eligible(g, b_rc)) return wino_run(g, b_rc, scratch + s.o_wino, s.n_wino, part_, part_n_, st);
+        g.partial = part_; g.partial_floats = part_n_;
+        return afi_launch_pix_gemm(g, b_rc, st);
+    };
+    // weight gradient of a 3x3 conv: Winograd F(3x3,2x2) when both channel counts and the map are large enough, else direct
+    auto WG = [&](AfiView dyv, AfiView xin, int n_, int h_, int w_, int co, int ci, float* dw, float alpha, hipStream_t s_) {
+        if (s.n_wino > 0 && co >= 128 && ci >= 128 && (long long)n_ * h_ * w_ >= 1024)
+            return wino_wgrad(dyv, xin, n_, h_, w_, co, ci, dw, alpha, scratch + s.o_wino2, s.n_wino, s_);
+        return afi_launch_wgrad_gemm(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha), s_);
+    };
     const int L = (int)l.L;
     const long long P = l.P;
     const float rs = prm->residual_scale;
@@ -597,7 +659,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     hipStream_t sd = fk.side;                              // weight / bias gradients
 
     // ---- final conv (generator_rdb.py:107-108)
-    if (gr->w9) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dOut, u, N, 2 * H, 2 * W, C, C, gr->w9, 1.f), sd));
+    if (gr->w9) AFI_TRY(WG(dOut, u, N, 2 * H, 2 * W, C, C, gr->w9, 1.f, sd));
     if (gr->b9) AFI_TRY(afi_launch_colsum_accum(dout, 4 * P, C, C, 1.f, gr->b9, red, sd));
     {
         AfiPixGemm g = conv_dgrad_desc(dOut, N, 2 * H, 2 * W, C, prm->w9, C, dU);
@@ -619,7 +681,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     }
     // ---- trunk conv (:97-99): gA = d(pre-activation of a7)
     fk.after_main();                                       // gA is complete
-    if (gr->w7) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gA, t, N, H, W, C, C, gr->w7, 1.f), sd));
+    if (gr->w7) AFI_TRY(WG(gA, t, N, H, W, C, C, gr->w7, 1.f, sd));
     if (gr->b7) AFI_TRY(afi_launch_colsum_accum(gA.p, P, C, C, 1.f, gr->b7, red, sd));
     AFI_TRY(PG(conv_dgrad_desc(gA, N, H, W, C, prm->w7, C, gB), 1));    // gB = dT
     // ---- ResidualInResidual (:27-30) and the RDB chain (:64-71), last block first
@@ -629,7 +691,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
         AfiView b = buf(r), d = dBuf(r);
         // conv5: out = x + rs*conv5(cat)
         fk.after_main();                                   // Gt is complete
-        if (gr->rdb_w[r][4]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(Gt, b, N, H, W, C, L, gr->rdb_w[r][4], rs * gs), sd));
+        if (gr->rdb_w[r][4]) AFI_TRY(WG(Gt, b, N, H, W, C, L, gr->rdb_w[r][4], rs * gs, sd));
         {
             AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->rdb_w[r][4], L, d);
             g.alpha = rs * gs;
@@ -655,7 +717,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     }
     // ---- head conv (:91-93): Gt[0:C] = d(pre-activation of a0)
     fk.after_main();
-    if (gr->w0) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(Gt, x, N, H, W, C, C, gr->w0, 1.f), sd));
+    if (gr->w0) AFI_TRY(WG(Gt, x, N, H, W, C, C, gr->w0, 1.f, sd));
     if (gr->b0) AFI_TRY(afi_launch_colsum_accum(Gt.p, P, C, L, 1.f, gr->b0, red, sd));
     if (dx) {
         AFI_TRY(afi_launch_bilinear2x_bwd(dout, N, H, W, C, 0.f, dx, st));           // skip path (:125)

@@ -15,6 +15,7 @@
 // to 8.3 ms of GEMM instead of 18.6 ms of direct convolution.  fp32 throughout; the transform constants are 0, +-1, +-1/2,
 // so the result differs from the direct kernel by a few ulp of the accumulated sum (tests hold it to the same 1e-3 bar).
 #include "afi_common.h"
+#include "afi_epilogue.h"
 
 static unsigned wino_grid(long long work_items) {
     long long g = (work_items + 255) / 256;
@@ -169,6 +170,52 @@ int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, 
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
     hipLaunchKernelGGL(afi_wino_output_kernel, dim3(wino_grid(T * (C >> 2))), dim3(256), 0, st, M, Tpad, N, H, W, C, Th, Tw, T, bias, alpha, out, z);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---------------------------------------------------------------- output with the pixel GEMM's full epilogue
+// Same transform, but each output float4 goes through afi_epilogue_store with the conv's own descriptor: bias, alpha / beta,
+// LeakyReLU, the two residual adds with channel ranges, the bilinear x2 skip, the pixel-shuffle store of the conv-transpose
+// (columns = 4 phases x Cout) and the LeakyReLU' mask -- so any 3x3 / stride-1 conv of the interpolator can take this path.
+__global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* __restrict__ Min, long long Tpad, int Th, int Tw, long long T,
+                                                                  const AfiPixGemm p) {
+    const int C = p.Ncols, C4 = C >> 2;
+    const long long total = T * C4;
+    const long long plane = Tpad * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        const long long t = e / C4;
+        const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
+        const float* src = Min + t * C + c;
+        f32x4 m[4][4];
+#pragma unroll
+        for (int a = 0; a < 16; ++a) m[a >> 2][a & 3] = *(const f32x4*)(src + a * plane);
+        f32x4 s[2][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[0][j] = m[0][j] + m[1][j] + m[2][j];
+            s[1][j] = m[1][j] - m[2][j] - m[3][j];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int yy = 2 * ty + i;
+            if (yy >= p.H) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int xx = 2 * tx + j;
+                if (xx >= p.W) continue;
+                const f32x4 v = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
+                afi_epilogue_store(p, n, yy, xx, c, v);
+            }
+        }
+    }
+}
+int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st) {
+    if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.Ncols <= 0 || (p.Ncols & 3)) return AFI_ERR_BAD_ARG;
+    const int Th = (p.H + 1) / 2, Tw = (p.W + 1) / 2;
+    const long long T = (long long)p.N * Th * Tw;
+    if (Tpad < T) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino_output_epi_kernel, dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
