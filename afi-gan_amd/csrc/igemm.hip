@@ -785,7 +785,7 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st) {
     const long long P = (long long)p.N * p.H * p.W;
     if (P <= 0 || p.Mrows <= 0 || p.Ncols <= 0) return AFI_ERR_BAD_ARG;
-    if (p.ntaps != 1 && p.ntaps != 9 && p.ntaps != 16) return AFI_ERR_BAD_ARG;     // 16: the Winograd transform points (no spatial shift, operand planes)
+    if (p.ntaps != 1 && p.ntaps != 9 && p.ntaps != 16 && p.ntaps != 36) return AFI_ERR_BAD_ARG;     // 16 / 36: Winograd transform points (no spatial shift, operand planes)
     if ((p.Ncols & 3) || (p.dy_up == 2 && (p.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;   // float4 granularity
     if (p.Mrows <= 32) return launch_wgrad<32, 128, 1, 4>(p, st);
     if (p.Mrows <= 64) return launch_wgrad<64, 128, 2, 2>(p, st);

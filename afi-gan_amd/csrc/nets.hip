@@ -36,6 +36,11 @@ int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const 
 int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
 int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st);
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st);
+int afi_launch_wino4_weight(const float* w, float* U, int O, int I, hipStream_t st);
+int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
+int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st);
+int afi_launch_wino4_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
 int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st);
 int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
 int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, int C, const float* bias, float alpha, AfiView out, AfiView z,
@@ -143,32 +148,15 @@ static AfiWgradGemm conv_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W, 
 //      the 16 transform points, output transform with the conv's epilogue.  mode 0 = forward (K = Cin, columns = Cout),
 //      mode 1 = data gradient (K = Cout, columns = Cin, flipped taps).  ws: [U 16*K*Nc][V 16*Tpad*K][M 16*Tpad*Nc].
 static long long wino_tpad(int N, int H, int W) { return (((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + 127) / 128) * 128; }
+static long long wino4_tpad(int N, int H, int W) { return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4) + 127) / 128) * 128; }
+static bool wino_f4() { static const int on = getenv("AFI_WINO_F4") ? atoi(getenv("AFI_WINO_F4")) : 1; return on != 0; }
+// one size for both tilings: F(2x2,3x3) = 16 transform points over 2x2 tiles, F(4x4,3x3) = 36 points over 4x4 tiles
 static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
-    const long long Tpad = wino_tpad(N, H, W);
-    return align4(16LL * K * Nc) + align4(16 * Tpad * K) + align4(16 * Tpad * Nc);
+    const long long T2 = wino_tpad(N, H, W), T4 = wino4_tpad(N, H, W);
+    const long long a = align4(16LL * K * Nc) + align4(16 * T2 * K) + align4(16 * T2 * Nc);
+    const long long b = align4(36LL * K * Nc) + align4(36 * T4 * K) + align4(36 * T4 * Nc);
+    return a > b ? a : b;
 }
-static int wino_conv(int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
-                     float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st) {
-    if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
-    if (ws_floats < wino_ws_floats(N, H, W, K, Nc)) return AFI_ERR_WORKSPACE;
-    const long long Tpad = wino_tpad(N, H, W);
-    float* U = ws;
-    float* Vb = U + align4(16LL * K * Nc);
-    float* Mb = Vb + align4(16 * Tpad * K);
-    // weights: forward w[Cout = Nc][3][3][Cin = K]; data gradient w[Cout = K][3][3][Cin = Nc]
-    AFI_TRY(afi_launch_wino_weight(w, U, mode ? K : Nc, mode ? Nc : K, mode, st));
-    AFI_TRY(afi_launch_wino_input(in, N, H, W, K, Tpad, Vb, st));
-    AfiPixGemm g = pix_default(16, 1, (int)Tpad);
-    g.ntaps = 1; g.Ck = K; g.Ncols = Nc; g.CoutPhase = Nc;
-    g.A = AfiView{Vb, Tpad * K, 0, K};
-    g.B = U; g.b_sRow = K; g.b_sTap = 0; g.b_sImg = (long long)K * Nc;
-    g.n_fastest = 1;                                       // A tile (128 x K) stationary in L2 across its N tiles: +5 % on the big layers
-    g.O = AfiView{Mb, Tpad * Nc, 0, Nc};
-    g.partial = part; g.partial_floats = part_floats;
-    AFI_TRY(afi_launch_pix_gemm(g, 0, st));
-    return afi_launch_wino_output(Mb, Tpad, N, H, W, Nc, bias, 1.f, out, z, st);
-}
-
 // Any 3x3 / stride-1 conv DESCRIPTOR of the pixel GEMM (forward, b_rc = 0, or data gradient, b_rc = 1) run in Winograd form: the
 // batched GEMM writes M, the output transform applies the descriptor's own epilogue.  Eligible: 9 taps, one K phase, no up-sampled
 // gather, dense [rows][3][3][K-or-N] weights, >= 128 channels on both sides, >= 1024 pixels.
@@ -183,13 +171,21 @@ static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
 static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st) {
     const int K = g.Ck, Nc = g.Ncols;
     if (ws_floats < wino_ws_floats(g.N, g.H, g.W, K, Nc)) return AFI_ERR_WORKSPACE;
-    const long long Tpad = wino_tpad(g.N, g.H, g.W);
+    // data gradients take F(4x4,3x3) (their error does not decide a LeakyReLU mask); forwards stay on F(2x2,3x3)
+    const bool f4 = b_rc && wino_f4() && (long long)g.N * g.H * g.W >= 8192;     // small maps: too few 4x4 tiles to fill the chip
+    const int np = f4 ? 36 : 16;
+    const long long Tpad = f4 ? wino4_tpad(g.N, g.H, g.W) : wino_tpad(g.N, g.H, g.W);
     float* U = ws;
-    float* Vb = U + align4(16LL * K * Nc);
-    float* Mb = Vb + align4(16 * Tpad * K);
-    AFI_TRY(afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
-    AFI_TRY(afi_launch_wino_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
-    AfiPixGemm q = pix_default(16, 1, (int)Tpad);
+    float* Vb = U + align4((long long)np * K * Nc);
+    float* Mb = Vb + align4(np * Tpad * K);
+    if (f4) {
+        AFI_TRY(afi_launch_wino4_weight(g.B, U, K, Nc, st));
+        AFI_TRY(afi_launch_wino4_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
+    } else {
+        AFI_TRY(afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
+        AFI_TRY(afi_launch_wino_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
+    }
+    AfiPixGemm q = pix_default(np, 1, (int)Tpad);
     q.ntaps = 1; q.Ck = K; q.Ncols = Nc; q.CoutPhase = Nc;
     q.A = AfiView{Vb, Tpad * K, 0, K};
     q.B = U; q.b_sRow = K; q.b_sTap = 0; q.b_sImg = (long long)K * Nc;
@@ -197,7 +193,16 @@ static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_float
     q.O = AfiView{Mb, Tpad * Nc, 0, Nc};
     q.partial = part; q.partial_floats = part_floats;
     AFI_TRY(afi_launch_pix_gemm(q, 0, st));
-    return afi_launch_wino_output_epi(Mb, Tpad, g, st);
+    return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
+}
+
+// forward (mode 0: out = conv(in, w) + bias) or data gradient (mode 1: out = conv^T(in, w) * lrelu'(z)) by descriptor
+static int wino_conv(int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
+                     float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st) {
+    if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
+    AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
+    if (mode && z.p) { g.Z = z; g.z_lo = 0; g.z_hi = Nc; }
+    return wino_run(g, mode, ws, ws_floats, part, part_floats, st);
 }
 
 // weight gradient in Winograd F(3x3,2x2) form: dW[Cout][3][3][Cin] += alpha * sum_pix dy (x) x.  Same workspace layout as wino_conv
@@ -206,23 +211,30 @@ static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int 
                       hipStream_t st) {
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
-    const long long Tpad = wino_tpad(N, H, W);
+    const bool f4 = wino_f4() && (long long)N * H * W >= 8192;   // F(3x3,4x4): 36 transform points over 4x4 blocks of dY
+    const int np = f4 ? 36 : 16;
+    const long long Tpad = f4 ? wino4_tpad(N, H, W) : wino_tpad(N, H, W);
     float* dU = ws;
-    float* Vb = dU + align4(16LL * Cin * Cout);
-    float* Qb = Vb + align4(16 * Tpad * Cin);
-    if (hipMemsetAsync(dU, 0, sizeof(float) * 16 * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
-    AFI_TRY(afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st));
-    AFI_TRY(afi_launch_wino_dy(dy, N, H, W, Cout, Tpad, Qb, st));
+    float* Vb = dU + align4((long long)np * Cin * Cout);
+    float* Qb = Vb + align4(np * Tpad * Cin);
+    if (hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
+    if (f4) {
+        AFI_TRY(afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st));
+        AFI_TRY(afi_launch_wino4_dy(dy, N, H, W, Cout, Tpad, Qb, st));
+    } else {
+        AFI_TRY(afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st));
+        AFI_TRY(afi_launch_wino_dy(dy, N, H, W, Cout, Tpad, Qb, st));
+    }
     AfiWgradGemm g;
     memset(&g, 0, sizeof(g));
-    g.N = 1; g.H = 1; g.W = (int)Tpad; g.ntaps = 16;
+    g.N = 1; g.H = 1; g.W = (int)Tpad; g.ntaps = np;
     g.Mrows = Cout; g.Ncols = Cin;
     g.DY = AfiView{Qb, 0, 0, Cout}; g.dy_up = 1; g.CoutPhase = Cout; g.dy_sTap = Tpad * Cout;
     g.X = AfiView{Vb, 0, 0, Cin}; g.x_stride = 1; g.xH = 1; g.xW = (int)Tpad; g.x_sTap = Tpad * Cin;
     g.DW = dU; g.dw_sRow = Cin; g.dw_sTap = (long long)Cout * Cin;
     g.alpha = 1.f; g.splitK = 0;
     AFI_TRY(afi_launch_wgrad_gemm(g, st));
-    return afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
+    return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
 }
 
 // Winograd or direct for a 3x3 conv of the discriminator: from ~1 K pixels on the 2.25x fewer matrix-core FLOPs win over the

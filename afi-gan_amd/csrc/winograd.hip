@@ -307,3 +307,253 @@ int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hi
     hipLaunchKernelGGL(afi_wino_dw_kernel, dim3(wino_grid((long long)O * I)), dim3(256), 0, st, dU, dW, O, I, alpha);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
+
+// ================================================================ F(4x4, 3x3) / F(3x3, 4x4): data and weight gradients
+// 36 products per (cin, cout) pair and 4x4 output tile instead of 144 (4x fewer matrix-core FLOPs than direct, 1.78x fewer than
+// F(2x2)) and 2.25x (not 4x) transform traffic.  Interpolation points {0, +-1, +-2, inf}: the fp32 result is accurate to ~3e-5
+// of the output scale (vs ~1e-6 for F(2x2)), which is fine for gradients but would flip LeakyReLU masks behind a BatchNorm
+// ~30x more often than fp32 rounding does -- so the FORWARD convs stay on F(2x2) and only the two backward GEMMs, whose
+// errors do not pass through a mask decision, use this form.
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]           (weights, data gradient)
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]                                 (4x4 outputs)
+//   G'  = [1/4 0 0 0; -1/6(1 1 1 1); -1/6(1 -1 1 -1); 1/24(1 2 4 8); 1/24(1 -2 4 -8); 0 0 0 1]     (4x4 block of dY, weight gradient)
+//   A'^T= [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1]                                                 (3x3 weight taps)
+template <typename T>
+__device__ __forceinline__ void wino4_bt(T& d0, T& d1, T& d2, T& d3, T& d4, T& d5) {      // in place: B^T d
+    const T t0 = 4.f * d0 - 5.f * d2 + d4;
+    const T t1 = -4.f * (d1 + d2) + d3 + d4;
+    const T t2 = 4.f * (d1 - d2) - d3 + d4;
+    const T t3 = -2.f * d1 - d2 + 2.f * d3 + d4;
+    const T t4 = 2.f * d1 - d2 - 2.f * d3 + d4;
+    const T t5 = 4.f * d1 - 5.f * d3 + d5;
+    d0 = t0; d1 = t1; d2 = t2; d3 = t3; d4 = t4; d5 = t5;
+}
+
+// input: X (view) -> V [36][Tpad][C]; the 6x6 patch of tile (ty, tx) starts at (4*ty - 1, 4*tx - 1)
+__global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
+                                                              float* __restrict__ Vout) {
+    const int C4 = C >> 2;
+    const long long total = Tpad * C4;
+    const long long plane = Tpad * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        const long long t = e / C4;
+        float* dst = Vout + t * C + c;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (t >= T) {
+#pragma unroll
+            for (int a = 0; a < 36; ++a) *(f32x4*)(dst + a * plane) = zero;
+            continue;
+        }
+        const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
+        const float* base = x.p + (long long)n * x.sN + c;
+        f32x4 d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int yy = 4 * ty - 1 + i;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int xx = 4 * tx - 1 + j;
+                d[i][j] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW) : zero;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wino4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);      // columns
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {                                                                   // rows, stored at once
+            wino4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *(f32x4*)(dst + (6 * i + j) * plane) = d[i][j];
+        }
+    }
+}
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
+    const long long T = (long long)N * Th * Tw;
+    if (Tpad < T) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino4_input_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// weights for the data gradient: U[a][i][o] = G g' G^T with g'[ky][kx] = w[o][2-ky][2-kx][i]   (36 planes).
+// A 32 x 32 (o, i) tile per 1024-thread block: w is read with i fastest (its memory order), each plane is transposed through
+// LDS and written with o fastest (U's order) -- both sides coalesced (the direct form wrote with a stride of O floats).
+__global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I) {
+    __shared__ float tile[32][33];
+    const int ti = threadIdx.x, to = threadIdx.y;
+    const int i = blockIdx.x * 32 + ti, o = blockIdx.y * 32 + to;
+    const bool ok = i < I && o < O;
+    float g[3][3];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ok ? w[((long long)o * 9 + (8 - t)) * I + i] : 0.f;
+    float a[6][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float g0 = g[0][j], g1 = g[1][j], g2 = g[2][j];
+        a[0][j] = 0.25f * g0;
+        a[1][j] = (-1.f / 6.f) * (g0 + g1 + g2);
+        a[2][j] = (-1.f / 6.f) * (g0 - g1 + g2);
+        a[3][j] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+        a[4][j] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+        a[5][j] = g2;
+    }
+    const long long plane = (long long)O * I;
+    const int oi = blockIdx.x * 32 + to, oo = blockIdx.y * 32 + ti;      // transposed roles for the store: ti walks o
+    const bool ok2 = oi < I && oo < O;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        const float a0 = a[r][0], a1 = a[r][1], a2 = a[r][2];
+        float u[6];
+        u[0] = 0.25f * a0;
+        u[1] = (-1.f / 6.f) * (a0 + a1 + a2);
+        u[2] = (-1.f / 6.f) * (a0 - a1 + a2);
+        u[3] = (1.f / 24.f) * a0 + (1.f / 12.f) * a1 + (1.f / 6.f) * a2;
+        u[4] = (1.f / 24.f) * a0 - (1.f / 12.f) * a1 + (1.f / 6.f) * a2;
+        u[5] = a2;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            __syncthreads();
+            tile[to][ti] = u[c];                             // [o][i]
+            __syncthreads();
+            if (ok2) U[(6 * r + c) * plane + (long long)oi * O + oo] = tile[ti][to];
+        }
+    }
+}
+int afi_launch_wino4_weight(const float* w, float* U, int O, int I, hipStream_t st) {
+    if (O <= 0 || I <= 0) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino4_weight_kernel, dim3((I + 31) / 32, (O + 31) / 32), dim3(32, 32), 0, st, w, U, O, I);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// output: M [36][Tpad][C] -> 4x4 pixels per tile through the descriptor's epilogue
+__global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* __restrict__ Min, long long Tpad, int Th, int Tw, long long T,
+                                                                   const AfiPixGemm p) {
+    const int C = p.Ncols, C4 = C >> 2;
+    const long long total = T * C4;
+    const long long plane = Tpad * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        const long long t = e / C4;
+        const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
+        const float* src = Min + t * C + c;
+        f32x4 s[4][6];                                       // A^T m, accumulated row by row of m
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x4 m0 = *(const f32x4*)(src + (0 * 6 + j) * plane), m1 = *(const f32x4*)(src + (1 * 6 + j) * plane);
+            const f32x4 m2 = *(const f32x4*)(src + (2 * 6 + j) * plane), m3 = *(const f32x4*)(src + (3 * 6 + j) * plane);
+            const f32x4 m4 = *(const f32x4*)(src + (4 * 6 + j) * plane), m5 = *(const f32x4*)(src + (5 * 6 + j) * plane);
+            const f32x4 p12 = m1 + m2, d12 = m1 - m2, p34 = m3 + m4, d34 = m3 - m4;
+            s[0][j] = m0 + p12 + p34;
+            s[1][j] = d12 + 2.f * d34;
+            s[2][j] = p12 + 4.f * p34;
+            s[3][j] = d12 + 8.f * d34 + m5;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = 4 * ty + i;
+            if (yy >= p.H) continue;
+            const f32x4 p12 = s[i][1] + s[i][2], d12 = s[i][1] - s[i][2], p34 = s[i][3] + s[i][4], d34 = s[i][3] - s[i][4];
+            const f32x4 y0 = s[i][0] + p12 + p34, y1 = d12 + 2.f * d34, y2 = p12 + 4.f * p34, y3 = d12 + 8.f * d34 + s[i][5];
+            const int xx = 4 * tx;
+            if (xx < p.W) afi_epilogue_store(p, n, yy, xx, c, y0);
+            if (xx + 1 < p.W) afi_epilogue_store(p, n, yy, xx + 1, c, y1);
+            if (xx + 2 < p.W) afi_epilogue_store(p, n, yy, xx + 2, c, y2);
+            if (xx + 3 < p.W) afi_epilogue_store(p, n, yy, xx + 3, c, y3);
+        }
+    }
+}
+int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st) {
+    if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.Ncols <= 0 || (p.Ncols & 3)) return AFI_ERR_BAD_ARG;
+    const int Th = (p.H + 3) / 4, Tw = (p.W + 3) / 4;
+    const long long T = (long long)p.N * Th * Tw;
+    if (Tpad < T) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino4_output_epi_kernel, dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// weight gradient: Q[a][t][co] = G' e G'^T for the 4x4 block e of dY of tile t
+__global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
+                                                           float* __restrict__ Q) {
+    const int C4 = C >> 2;
+    const long long total = Tpad * C4;
+    const long long plane = Tpad * C;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        const long long t = e / C4;
+        float* dst = Q + t * C + c;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        if (t >= T) {
+#pragma unroll
+            for (int a = 0; a < 36; ++a) *(f32x4*)(dst + a * plane) = zero;
+            continue;
+        }
+        const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
+        const float* base = dy.p + (long long)n * dy.sN + c;
+        f32x4 a[6][4];                                       // G' e (columns of e)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yy = 4 * ty + i, xx = 4 * tx + j;
+                v[i] = (yy < H && xx < W) ? *(const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW) : zero;
+            }
+            a[0][j] = 0.25f * v[0];
+            a[1][j] = (-1.f / 6.f) * (v[0] + v[1] + v[2] + v[3]);
+            a[2][j] = (-1.f / 6.f) * (v[0] - v[1] + v[2] - v[3]);
+            a[3][j] = (1.f / 24.f) * v[0] + (1.f / 12.f) * v[1] + (1.f / 6.f) * v[2] + (1.f / 3.f) * v[3];
+            a[4][j] = (1.f / 24.f) * v[0] - (1.f / 12.f) * v[1] + (1.f / 6.f) * v[2] - (1.f / 3.f) * v[3];
+            a[5][j] = v[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x4 v0 = a[i][0], v1 = a[i][1], v2 = a[i][2], v3 = a[i][3];
+            *(f32x4*)(dst + (6 * i + 0) * plane) = 0.25f * v0;
+            *(f32x4*)(dst + (6 * i + 1) * plane) = (-1.f / 6.f) * (v0 + v1 + v2 + v3);
+            *(f32x4*)(dst + (6 * i + 2) * plane) = (-1.f / 6.f) * (v0 - v1 + v2 - v3);
+            *(f32x4*)(dst + (6 * i + 3) * plane) = (1.f / 24.f) * v0 + (1.f / 12.f) * v1 + (1.f / 6.f) * v2 + (1.f / 3.f) * v3;
+            *(f32x4*)(dst + (6 * i + 4) * plane) = (1.f / 24.f) * v0 - (1.f / 12.f) * v1 + (1.f / 6.f) * v2 - (1.f / 3.f) * v3;
+            *(f32x4*)(dst + (6 * i + 5) * plane) = v3;
+        }
+    }
+}
+int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
+    const long long T = (long long)N * Th * Tw;
+    if (Tpad < T) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino4_dy_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// dW[o][ky][kx][i] += alpha * (A'^T dU A')[ky][kx]  with dU [36][O][I]
+__global__ void afi_wino4_dw_kernel(const float* __restrict__ dU, float* __restrict__ dW, int O, int I, float alpha) {
+    const long long total = (long long)O * I;
+    const long long plane = total;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(e % I), o = (int)(e / I);
+        float s[3][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const float m0 = dU[(0 * 6 + j) * plane + e], m1 = dU[(1 * 6 + j) * plane + e], m2 = dU[(2 * 6 + j) * plane + e];
+            const float m3 = dU[(3 * 6 + j) * plane + e], m4 = dU[(4 * 6 + j) * plane + e], m5 = dU[(5 * 6 + j) * plane + e];
+            s[0][j] = m0 + m1 + m2 + m3 + m4;
+            s[1][j] = (m1 - m2) + 2.f * (m3 - m4);
+            s[2][j] = (m1 + m2) + 4.f * (m3 + m4) + m5;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float* dst = dW + ((long long)o * 9 + 3 * k) * I + i;
+            dst[0] += alpha * (s[k][0] + s[k][1] + s[k][2] + s[k][3] + s[k][4]);
+            dst[I] += alpha * ((s[k][1] - s[k][2]) + 2.f * (s[k][3] - s[k][4]));
+            dst[2 * I] += alpha * ((s[k][1] + s[k][2]) + 4.f * (s[k][3] + s[k][4]) + s[k][5]);
+        }
+    }
+}
+int afi_launch_wino4_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st) {
+    if (O <= 0 || I <= 0) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_wino4_dw_kernel, dim3(wino_grid((long long)O * I)), dim3(256), 0, st, dU, dW, O, I, alpha);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}

@@ -449,6 +449,15 @@ def main():
     log("AF-interpolator micro-benchmark")
     micro = not args.no_interp and world == 1             # single-GPU metrics: reported on the N=1 line only
     if micro:
+        # release the stage-1 engine first: with its tens of GB of workspaces mapped, every kernel launch of the small-map
+        # legs cost the host ~16 us instead of ~5 us and the (launch-bound) config-1 leg measured the host, not the GPU
+        del step, G, D
+        if guide is not None:
+            del guide
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
         line["af_interpolator"] = {"metric": "AF-interpolator fwd+bwd feature-Mpix/s (256ch P5->P4)",
                                    "cfg1": interp_bench(amd, torch, 1, 25, 34), "batch16": interp_bench(amd, torch, 16, 25, 34, iters=20, warmup=5)}
     if micro:
