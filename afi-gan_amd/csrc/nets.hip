@@ -37,7 +37,7 @@ int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hip
 int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st);
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
 int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st);
-int afi_launch_wino4_weight(const float* w, float* U, int O, int I, hipStream_t st);
+int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
 int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st);
 int afi_launch_wino4_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
@@ -168,18 +168,20 @@ static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
     const int I = b_rc ? g.Ncols : g.Ck;                   // innermost weight dimension of w[O][3][3][I]
     return g.b_sTap == I && g.b_sRow == 9LL * I && g.a_sgn == (b_rc ? -1 : 1);
 }
-static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st) {
+static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st,
+                    bool fwd_f4 = false) {
     const int K = g.Ck, Nc = g.Ncols;
     if (ws_floats < wino_ws_floats(g.N, g.H, g.W, K, Nc)) return AFI_ERR_WORKSPACE;
     // data gradients take F(4x4,3x3) (their error does not decide a LeakyReLU mask); forwards stay on F(2x2,3x3)
-    const bool f4 = b_rc && wino_f4() && (long long)g.N * g.H * g.W >= 8192;     // small maps: too few 4x4 tiles to fill the chip
+    // fwd_f4: a forward whose activations feed no backward pass (its masks decide no gradient) may take F(4x4) too
+    const bool f4 = (b_rc || fwd_f4) && wino_f4() && (long long)g.N * g.H * g.W >= 8192;     // small maps: too few 4x4 tiles to fill the chip
     const int np = f4 ? 36 : 16;
     const long long Tpad = f4 ? wino4_tpad(g.N, g.H, g.W) : wino_tpad(g.N, g.H, g.W);
     float* U = ws;
     float* Vb = U + align4((long long)np * K * Nc);
     float* Mb = Vb + align4(np * Tpad * K);
     if (f4) {
-        AFI_TRY(afi_launch_wino4_weight(g.B, U, K, Nc, st));
+        AFI_TRY(afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
         AFI_TRY(afi_launch_wino4_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
     } else {
         AFI_TRY(afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
@@ -198,11 +200,11 @@ static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_float
 
 // forward (mode 0: out = conv(in, w) + bias) or data gradient (mode 1: out = conv^T(in, w) * lrelu'(z)) by descriptor
 static int wino_conv(int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
-                     float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st) {
+                     float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
     if (mode && z.p) { g.Z = z; g.z_lo = 0; g.z_hi = Nc; }
-    return wino_run(g, mode, ws, ws_floats, part, part_floats, st);
+    return wino_run(g, mode, ws, ws_floats, part, part_floats, st, fwd_f4);
 }
 
 // weight gradient in Winograd F(3x3,2x2) form: dW[Cout][3][3][Cin] += alpha * sum_pix dy (x) x.  Same workspace layout as wino_conv
@@ -820,7 +822,7 @@ int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, in
         float* mean = ws + l.o_mean[n]; float* invstd = ws + l.o_invstd[n];
         if (l.n_wino > 0) {
             AFI_TRY(wino_conv(0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
-                              part_n_, st));
+                              part_n_, st, /*fwd_f4=*/training != 1));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }

@@ -380,14 +380,14 @@ int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad
 // weights for the data gradient: U[a][i][o] = G g' G^T with g'[ky][kx] = w[o][2-ky][2-kx][i]   (36 planes).
 // A 32 x 32 (o, i) tile per 1024-thread block: w is read with i fastest (its memory order), each plane is transposed through
 // LDS and written with o fastest (U's order) -- both sides coalesced (the direct form wrote with a stride of O floats).
-__global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I) {
+__global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I, int mode) {
     __shared__ float tile[32][33];
     const int ti = threadIdx.x, to = threadIdx.y;
     const int i = blockIdx.x * 32 + ti, o = blockIdx.y * 32 + to;
     const bool ok = i < I && o < O;
     float g[3][3];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ok ? w[((long long)o * 9 + (8 - t)) * I + i] : 0.f;
+    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ok ? w[((long long)o * 9 + (mode ? 8 - t : t)) * I + i] : 0.f;   // mode 0: forward (no flip)
     float a[6][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -412,6 +412,12 @@ __global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __r
         u[3] = (1.f / 24.f) * a0 + (1.f / 12.f) * a1 + (1.f / 6.f) * a2;
         u[4] = (1.f / 24.f) * a0 - (1.f / 12.f) * a1 + (1.f / 6.f) * a2;
         u[5] = a2;
+        if (!mode) {                                         // forward: U[a][o][i], the thread's own (o, i): already coalesced
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (ok) U[(6 * r + c) * plane + (long long)o * I + i] = u[c];
+            continue;
+        }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             __syncthreads();
@@ -421,9 +427,9 @@ __global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __r
         }
     }
 }
-int afi_launch_wino4_weight(const float* w, float* U, int O, int I, hipStream_t st) {
+int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st) {
     if (O <= 0 || I <= 0) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino4_weight_kernel, dim3((I + 31) / 32, (O + 31) / 32), dim3(32, 32), 0, st, w, U, O, I);
+    hipLaunchKernelGGL(afi_wino4_weight_kernel, dim3((I + 31) / 32, (O + 31) / 32), dim3(32, 32), 0, st, w, U, O, I, mode);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

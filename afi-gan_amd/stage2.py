@@ -113,10 +113,10 @@ class Stage2Adversarial:
             fake = ops.pixel_major(f.detach())
             hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
             adv = torch.zeros(1, device=f.device)
-            logits, _ = h._d_forward(fake[:, :, :hh, :ww], "d_ws")                       # fake first, then real (:350-354)
+            logits, _ = h._d_forward(fake[:, :, :hh, :ww], "d_ws", backward_follows=False)   # fake first, then real (:350-354)
             call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), f.shape[0] * hh * ww, 1.0, 1.0, C.c_void_p(adv.data_ptr()),
                  0.0, C.c_void_p(None), ops.stream_ptr())
-            h._d_forward(real[:, :, :hh, :ww], "d_ws")                                   # only its BN side effects matter (Q2)
+            h._d_forward(real[:, :, :hh, :ww], "d_ws", backward_follows=False)           # only its BN side effects matter (Q2)
             content = l1_loss_common(f, real)
             out[f"g_loss_p{lv}"] = adv.reshape(()) * 1e-3 + content
         return out

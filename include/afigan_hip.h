@@ -92,7 +92,10 @@ long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W);
 long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W);
 
 /* logits[N,H,W] (dense) = Discriminators[0](x).  training != 0: batch statistics, running stats advance once,
- * num_batches_tracked += 1 (torch BatchNorm2d train mode);  training == 0: running statistics. */
+ * num_batches_tracked += 1 (torch BatchNorm2d train mode);  training == 0: running statistics.
+ * training == 1: afi_discriminator_bwd may follow on this workspace (the forward convs then keep the Winograd tiling whose
+ * rounding does not disturb LeakyReLU mask decisions);  training == 2: train-mode statistics and logits only, no backward
+ * will follow (stage-1 G phase, stage-2 generator-side terms): the convs may take the cheaper F(4x4,3x3) tiling, as in eval. */
 int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t x, int N, int H, int W, float* logits, int training,
                           float* ws, long long ws_floats, void* stream);
 /* Backward (training-mode forward only).  grads: += targets (w, b, gamma, beta, w3, b3; other fields ignored).
