@@ -417,8 +417,17 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiW
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     }
-    const int tap = t % p.ntaps; t /= p.ntaps;             // taps fastest: the 9 blocks of one (m, n) tile share dY and most of X in L2
-    const int tile_n = t % ntile_n; const int tile_m = t / ntile_n;
+    int tap, tile_n, tile_m;
+    if (p.ntaps <= 9) {
+        tap = t % p.ntaps; t /= p.ntaps;                   // taps fastest: the 9 blocks of one (m, n) tile share dY and most of X in L2
+        tile_n = t % ntile_n; tile_m = t / ntile_n;
+    } else {
+        // Winograd planes share nothing with each other; inside a plane the N tiles of an M tile share the dY-side tile and the M
+        // tiles of an N tile the X-side tile: planes slowest, so an XCD's run of blocks works through whole planes out of its L2
+        // (planes fastest had every block stream both of its operand tiles from HBM: ~20 GB per launch on the largest layer)
+        tile_n = t % ntile_n; t /= ntile_n;
+        tile_m = t % ntile_m; tap = t / ntile_m;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     int dy = 0, dx = 0;
     if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
