@@ -35,7 +35,7 @@ def test_host_only_queries():
     # saved activations of one generator call: packed conv-transpose weight, the RDB dense buffers, t, a7 and the 2x map
     saved = 36 * C * C + R * P * (C + 4 * G) + 2 * P * C + 4 * P * C
     got = lib.afi_generator_fwd_ws_floats(C, G, R, 1, 25, 34)
-    assert saved < got <= 3 * saved                             # + split-K slabs and the transient Winograd buffers
+    assert saved < got <= 8 * saved                             # + split-K slabs and the transient Winograd buffers
     assert lib.afi_generator_fwd_ws_floats(C, G, R, 2, 25, 34) > got          # grows with the batch
     small = lib.afi_generator_fwd_ws_floats(16, 4, 3, 1, 5, 7)               # no Winograd / big slabs for tiny shapes
     assert small < 64 * 1024
