@@ -893,7 +893,11 @@ int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t*
         AFI_TRY(afi_launch_bn_bwd(g_, c, g_, ws + l.o_mean[n], ws + l.o_invstd[n], prm->gamma[n], gr->gamma[n], gr->beta[n], 1.f, P, co,
                                   red, st));          // in place: g_ = d(conv output)
         fk.after_main();                              // g_ = d(conv output) is complete
-        if (gr->b[n]) AFI_TRY(afi_launch_colsum_accum(g_, P, co, co, 1.f, gr->b[n], red2, sd));
+        // d(loss)/d(bias) of a conv that feeds a train-mode BatchNorm is EXACTLY zero: g_ = BN backward's dx, whose sum over the pixels
+        // of a channel vanishes identically (the BN output does not change when a constant is added to its input).  The reference
+        // accumulates the fp32 rounding noise of that sum (~1e-7 of |g|); adding nothing to gr->b[n] is the exact value and saves a
+        // full HBM pass over g_ per layer.  (Eval-mode BN has no backward here; the bias of the last conv is handled above.)
+        (void)red2;
         AfiView gy = dense_view(g_, H, W, co);
         AfiView xin = (n == 0) ? V(xv) : dense_view(ws + l.o_y[n - 1], H, W, ci);
         if (gr->w[n] && s.n_wino > 0) AFI_TRY(wino_wgrad(gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd));
