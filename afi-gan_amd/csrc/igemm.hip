@@ -384,6 +384,115 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Plain batched "NT" GEMM for the Winograd planes:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k]   (both operands K-contiguous),
+// every dimension tile-aligned (rows per plane % 128 == 0, N % 128 == 0, K % 32 == 0): no row table, no tap masks, no bounds
+// checks, no zero page, one 64-bit base per operand: 136 registers and a leaner instruction stream than the general kernel
+// (+4-5 % on the Winograd GEMMs).
+// Same tile, LDS layout, fragment order and MFMA loop as afi_pix_gemm_kernel<128,128,2,2,KC>.
+// ------------------------------------------------------------------------------------------------
+struct AfiGemmNT {
+    const float* A; const float* B; float* C;
+    long long rows_per_plane;                              // rows of one plane (multiple of 128)
+    int planes, N, K;                                      // B plane stride = N*K, C row pitch = N
+};
+template <int PF>
+__global__ __launch_bounds__(256, 3) void afi_gemm_nt_kernel(const AfiGemmNT p, int ntile_n, int ntile_m, int chunk) {
+    constexpr int BM = 128, BN = 128, BK = AFI_BK, LDK = BK + 4, WN = 2, MI = 2, NI = 2;
+    constexpr int A_TILE = BM * LDK, B_TILE = BN * LDK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    // N tiles of one M tile back to back (the A tile stays in L2 for them); each XCD owns `chunk` consecutive M tiles
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile_n = jb % ntile_n, tile_m = xcd * chunk + jb / ntile_n;
+    if (tile_m >= ntile_m) return;
+    const long long m0 = (long long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int plane = (int)(m0 / p.rows_per_plane);
+    const int aq = tid & 7, ar = tid >> 3;                 // float4 column, first row (32 rows per pass, 4 passes)
+    const float* a_base = p.A + (m0 + ar) * p.K + 4 * aq;
+    const float* b_base = p.B + ((long long)plane * p.N + n0 + ar) * p.K + 4 * aq;
+    const long long pass = 32LL * p.K;
+    const int nK = p.K / BK;
+
+    // A (the HBM stream) is kept PF stages ahead in PF register sets; B (weights, L2-resident) one stage ahead in one set
+    f32x4 a_reg[PF][4], b_reg[4];
+    auto issue_a = [&](int set, int kc) {                  // past the end: re-read the last stage, never used
+        const int k0 = (kc < nK ? kc : nK - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_reg[set][i] = *(const f32x4*)(a_base + i * pass + k0);
+    };
+    auto issue_b = [&](int kc) {
+        const int k0 = (kc < nK ? kc : nK - 1) * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b_reg[i] = *(const f32x4*)(b_base + i * pass + k0);
+    };
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    float* As = smem;
+    float* Bs = smem + A_TILE;
+#pragma unroll
+    for (int d = 0; d < PF; ++d) issue_a(d, d);
+    issue_b(0);
+    for (int kc = 0; kc < nK; kc += PF) {
+#pragma unroll
+        for (int d = 0; d < PF; ++d) {
+            if (PF > 1 && kc + d >= nK) break;             // (uniform)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(As + (ar + 32 * i) * LDK + 4 * aq) = a_reg[d][i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + (ar + 32 * i) * LDK + 4 * aq) = b_reg[i];
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < BK / 8; ++s) {
+                f32x4 fa[MI], fb[NI];
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const f32x4*)(As + ((wm * MI + mi) * 32 + lr) * LDK + s * 8 + lh * 4);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) fb[ni] = *(const f32x4*)(Bs + ((wn * NI + ni) * 32 + lr) * LDK + s * 8 + lh * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                if (s == 1) { issue_a(d, kc + d + PF); issue_b(kc + d + 1); }   // refill in the middle of the stage's MFMAs
+            }
+            __syncthreads();
+        }
+    }
+    // epilogue: accumulators -> LDS -> float4 rows of C
+    constexpr int LDC = BN + 4, C_F4 = BN / 4;
+    float* Cs = smem;
+    float* c_base = p.C + m0 * p.N + n0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + (wn * NI + ni) * 32 + lr] = acc[mi][ni][r];
+        __syncthreads();
+        for (int item = tid; item < 2 * 32 * C_F4; item += 256) {
+            const int rloc = item / C_F4, c4 = item - rloc * C_F4;
+            const int rl = ((rloc >> 5) * MI + mi) * 32 + (rloc & 31);
+            *(f32x4*)(c_base + (long long)rl * p.N + 4 * c4) = *(const f32x4*)(Cs + rloc * LDC + 4 * c4);
+        }
+        if (mi + 1 < MI) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient: both operands are pixel-major, i.e. "RC" for a GEMM whose K runs over pixels
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
@@ -704,6 +813,21 @@ extern "C" int afi_set_op_scratch(float* p, long long floats) {
     g_op_scratch = floats > 0 ? p : nullptr;
     g_op_scratch_floats = floats > 0 ? floats : 0;
     return AFI_OK;
+}
+
+// batched NT GEMM of the Winograd planes; returns AFI_ERR_UNSUPPORTED when a dimension is not tile-aligned (caller falls back)
+int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, hipStream_t st) {
+    if (planes <= 0 || rows_per_plane <= 0 || N <= 0 || K <= 0) return AFI_ERR_BAD_ARG;
+    if ((rows_per_plane % 128) || (N % 128) || (K % AFI_BK)) return AFI_ERR_UNSUPPORTED;
+    AfiGemmNT g{A, B, C, rows_per_plane, planes, N, K};
+    const long long M = rows_per_plane * planes;
+    const int ntm = (int)(M / 128), ntn = N / 128, chunk = afi_cdiv(ntm, 8);
+    const size_t lds = sizeof(float) * 2 * 128 * (AFI_BK + 4);
+    ProfScope prof(st, 0, 2.0 * (double)M * N * K);
+    prof.m = M; prof.n = N; prof.k = K;
+    // (two register sets for the A stream, PF = 2, spill under the 168-register cap of 3 blocks per CU: 95 instead of 262 TFLOP/s)
+    hipLaunchKernelGGL((afi_gemm_nt_kernel<1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ntn, ntm, chunk);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
 int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {

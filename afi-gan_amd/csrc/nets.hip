@@ -11,6 +11,7 @@
 
 // ---- launchers implemented in igemm.hip / elementwise.hip
 int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st);
+int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, hipStream_t st);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
@@ -186,6 +187,12 @@ static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_float
     } else {
         AFI_TRY(afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
         AFI_TRY(afi_launch_wino_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
+    }
+    {   // tile-aligned shapes (every layer of the reference nets): the plain batched NT GEMM
+        static const int fast = getenv("AFI_GEMM_NT") ? atoi(getenv("AFI_GEMM_NT")) : 1;
+        const int rc = fast ? afi_launch_gemm_nt(Vb, U, Mb, np, Tpad, Nc, K, st) : AFI_ERR_UNSUPPORTED;
+        if (rc == AFI_OK) return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
+        if (rc != AFI_ERR_UNSUPPORTED) return rc;
     }
     AfiPixGemm q = pix_default(np, 1, (int)Tpad);
     q.ntaps = 1; q.Ck = K; q.Ncols = Nc; q.CoutPhase = Nc;
