@@ -683,11 +683,12 @@ struct ProfState {
     size_t used = 0;
 } g_prof;
 const char* kKindNames[] = {
-    "pix_gemm<128x128,KC,linear> (batched Winograd GEMM; also 1x1 and ragged-map convs)", "pix_gemm<128x64,KC>", "pix_gemm<128x32,KC>", "pix_gemm<64x64,KC>",
+    "pix_gemm<128x128,KC,linear> (1x1 / ragged-map / non-aligned Winograd GEMMs)", "pix_gemm<128x64,KC>", "pix_gemm<128x32,KC>", "pix_gemm<64x64,KC>",
     "pix_gemm<128x128,RC,linear> (conv dgrad, mid-size / ragged maps)", "pix_gemm<128x64,RC>", "pix_gemm<128x32,RC>", "pix_gemm<64x64,RC>",
     "wgrad_gemm<128x128>", "wgrad_gemm<64x128>", "wgrad_gemm<32x128>",
-    "pix_gemm<128x128,KC,halo> (conv fwd)", "pix_gemm<128x128,RC,halo> (conv dgrad)"};   // one kind per kernel instantiation, as rocprofv3 lists them
-constexpr int kNumKinds = 13;
+    "pix_gemm<128x128,KC,halo> (conv fwd)", "pix_gemm<128x128,RC,halo> (conv dgrad)",
+    "gemm_nt<128x128> (batched Winograd GEMM)"};          // one kind per kernel instantiation, as rocprofv3 lists them
+constexpr int kNumKinds = 14;
 hipEvent_t prof_event() {
     if (g_prof.used == g_prof.pool.size()) {
         hipEvent_t e;
@@ -823,7 +824,7 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
     const long long M = rows_per_plane * planes;
     const int ntm = (int)(M / 128), ntn = N / 128, chunk = afi_cdiv(ntm, 8);
     const size_t lds = sizeof(float) * 2 * 128 * (AFI_BK + 4);
-    ProfScope prof(st, 0, 2.0 * (double)M * N * K);
+    ProfScope prof(st, 13, 2.0 * (double)M * N * K);
     prof.m = M; prof.n = N; prof.k = K;
     // (two register sets for the A stream, PF = 2, spill under the 168-register cap of 3 blocks per CU: 95 instead of 262 TFLOP/s)
     hipLaunchKernelGGL((afi_gemm_nt_kernel<1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ntn, ntm, chunk);

@@ -12,7 +12,7 @@ python - <<'PY'
 import json, csv
 rows = list(csv.DictReader(open('profiles/r01/pmc_hbm_fetch_write_steps1.csv')))
 d = json.loads(open('profiles/r01/bench_line_under_rocprof_steps3_warmup0.json').read())
-dom = max((x for x in rows if 'afi_pix_gemm_kernel<128, 128, 2, 2, false' in x['kernel']), key=lambda x: float(x['FETCH_SIZE_sum']))
+dom = max((x for x in rows if ('afi_pix_gemm_kernel<128, 128, 2, 2, false' in x['kernel'] or 'afi_gemm_nt_kernel' in x['kernel'])), key=lambda x: float(x['FETCH_SIZE_sum']))
 fetch = float(dom['FETCH_SIZE_per_dispatch']) * 1024 * 2
 write = float(dom['WRITE_SIZE_per_dispatch']) * 1024
 out = {"kernel": dom['kernel'], "dispatches_in_pass": int(dom['dispatches']),
