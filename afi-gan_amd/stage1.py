@@ -53,6 +53,8 @@ def broadcast_module_state_(modules, src: int = 0, group=None) -> None:
     parameters and buffers."""
     for m in modules:
         for t in m.state_dict().values():
+            if t.dim() == 4 and not t.is_contiguous() and t.permute(0, 2, 3, 1).is_contiguous():
+                t = t.permute(0, 2, 3, 1)                # [O,I,kh,kw] parameters live as [O][kh][kw][I]: hand RCCL the dense view
             torch.distributed.broadcast(t, src=src, group=group)
 
 
