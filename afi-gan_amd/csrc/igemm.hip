@@ -671,6 +671,93 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_gemm_kernel(const AfiW
 }
 
 // ------------------------------------------------------------------------------------------------
+// Plain batched "TN" GEMM for the Winograd weight gradient:  dU[g][m][n] += sum_k Q[g][k][m] * V[g][k][n]   (both operands
+// row-major over k, i.e. the layout of afi_wgrad_gemm_kernel's LDS tiles), every dimension tile-aligned.  Same tile (128x128,
+// four waves side by side), interleaved vector fragment reads and MFMA loop as afi_wgrad_gemm_kernel<128,128,1,4>, without its
+// per-load pixel bookkeeping (y / x tracking, row and image wraps, tap bounds, zero page).
+// ------------------------------------------------------------------------------------------------
+struct AfiGemmTN {
+    const float* Q; const float* V; float* dU;
+    long long rows_per_plane;                              // K of one plane (multiple of 32)
+    int planes, M, N;
+};
+__global__ __launch_bounds__(256) void afi_gemm_tn_kernel(const AfiGemmTN p, int ntile_m, int ntile_n, int kper) {
+    constexpr int BM = 128, BN = 128, BK = AFI_BK, MI = 4, NI = 1;
+    typedef float fragA __attribute__((ext_vector_type(MI)));
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [BK][BM]
+    float* Bs = smem + BK * BM;       // [BK][BN]
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    int t;
+    {   // contiguous run of logical ids per XCD; planes slowest, N tiles fastest (operand tiles of a plane re-used out of L2)
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tile_n = t % ntile_n; t /= ntile_n;
+    const int tile_m = t % ntile_m; const int plane = t / ntile_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long long k_begin = (long long)blockIdx.y * kper;
+    const long long k_end = (k_begin + kper < p.rows_per_plane) ? k_begin + kper : p.rows_per_plane;
+    if (k_begin >= k_end) return;
+    const int nK = (int)((k_end - k_begin) / BK);          // kper and rows_per_plane are multiples of BK
+    const int cq = tid & 31, kr = tid >> 5;                // float4 column, first k row (8 rows per pass, 4 passes)
+    const float* a_base = p.Q + ((long long)plane * p.rows_per_plane + k_begin + kr) * p.M + m0 + 4 * cq;
+    const float* b_base = p.V + ((long long)plane * p.rows_per_plane + k_begin + kr) * p.N + n0 + 4 * cq;
+    const long long a_pass = 8LL * p.M, b_pass = 8LL * p.N, a_stage = (long long)BK * p.M, b_stage = (long long)BK * p.N;
+    f32x4 a_reg[4], b_reg[4];
+    int k_next = 0;
+    auto prefetch = [&]() {                                // past the end: re-read the last stage (never used)
+        const int kc = k_next < nK ? k_next : nK - 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_reg[i] = *(const f32x4*)(a_base + kc * a_stage + i * a_pass);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b_reg[i] = *(const f32x4*)(b_base + kc * b_stage + i * b_pass);
+        ++k_next;
+    };
+    f32x16 acc[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+    const float* a_rd = As + MI * lr;
+    const float* b_rd = Bs + wn * 32 + lr;
+    prefetch();
+    for (int kc = 0; kc < nK; ++kc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(As + (kr + 8 * i) * BM + 4 * cq) = a_reg[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + (kr + 8 * i) * BN + 4 * cq) = b_reg[i];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BK / 8; ++s) {
+            fragA a[4]; float b[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                a[j] = *(const fragA*)(a_rd + (s * 8 + lh * 4 + j) * BM);
+                b[j] = b_rd[(s * 8 + lh * 4 + j) * BN];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j][mi], b[j], acc[mi], 0, 0, 0);
+            if (s == 1) prefetch();
+        }
+        __syncthreads();
+    }
+    const bool use_atomic = gridDim.y > 1;
+    float* out = p.dU + (long long)plane * p.M * p.N;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
+            float* dst = out + (long long)row * p.N + n0 + wn * 32 + lr;
+            if (use_atomic) atomicAdd(dst, acc[mi][r]); else *dst += acc[mi][r];
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)
 // ------------------------------------------------------------------------------------------------
 #include <vector>
@@ -687,8 +774,8 @@ const char* kKindNames[] = {
     "pix_gemm<128x128,RC,linear> (conv dgrad, mid-size / ragged maps)", "pix_gemm<128x64,RC>", "pix_gemm<128x32,RC>", "pix_gemm<64x64,RC>",
     "wgrad_gemm<128x128>", "wgrad_gemm<64x128>", "wgrad_gemm<32x128>",
     "pix_gemm<128x128,KC,halo> (conv fwd)", "pix_gemm<128x128,RC,halo> (conv dgrad)",
-    "gemm_nt<128x128> (batched Winograd GEMM)"};          // one kind per kernel instantiation, as rocprofv3 lists them
-constexpr int kNumKinds = 14;
+    "gemm_nt<128x128> (batched Winograd GEMM)", "gemm_tn<128x128> (Winograd weight-gradient GEMM)"};   // one kind per kernel, as rocprofv3 lists them
+constexpr int kNumKinds = 15;
 hipEvent_t prof_event() {
     if (g_prof.used == g_prof.pool.size()) {
         hipEvent_t e;
@@ -913,6 +1000,36 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
         if (attr != hipSuccess) return AFI_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((afi_wgrad_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles, splitK), dim3(64 * WM * WN), lds, st, p, ntm, ntn, kper);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// batched TN GEMM of the Winograd weight gradient; AFI_ERR_UNSUPPORTED when a dimension is not tile-aligned (caller falls back)
+int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st) {
+    if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0) return AFI_ERR_BAD_ARG;
+    if ((rows_per_plane % AFI_BK) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
+    const int ntm = M / 128, ntn = N / 128;
+    const long long tiles = (long long)ntm * ntn * planes;
+    // split the K range so the block count fills whole rounds of the 768 resident-block slots (2..6 rounds), >= 8 stages per block
+    int splitK = 1;
+    {
+        const int maxsplit = (int)(rows_per_plane / (8 * AFI_BK)) > 0 ? (int)(rows_per_plane / (8 * AFI_BK)) : 1;
+        double best = -1.0;
+        for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {
+            const long long blocks = tiles * s2;
+            if (blocks < 2 * 768 && s2 < maxsplit) continue;
+            if (blocks > 6 * 768 && best >= 0.0) break;
+            const long long rounds = (blocks + 767) / 768;
+            const double fill = (double)blocks / (double)(rounds * 768);
+            if (fill > best + 1e-3) { best = fill; splitK = s2; }
+        }
+    }
+    int kper = (int)((rows_per_plane + splitK - 1) / splitK);
+    kper = ((kper + AFI_BK - 1) / AFI_BK) * AFI_BK;
+    splitK = (int)((rows_per_plane + kper - 1) / kper);
+    AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
+    ProfScope prof(st, 14, 2.0 * (double)rows_per_plane * planes * M * N);
+    prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
+    hipLaunchKernelGGL(afi_gemm_tn_kernel, dim3((unsigned)tiles, splitK), dim3(256), sizeof(float) * AFI_BK * 256, st, g, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

@@ -11,6 +11,7 @@
 
 // ---- launchers implemented in igemm.hip / elementwise.hip
 int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st);
+int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st);
 int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, hipStream_t st);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
@@ -233,6 +234,12 @@ static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int 
     } else {
         AFI_TRY(afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st));
         AFI_TRY(afi_launch_wino_dy(dy, N, H, W, Cout, Tpad, Qb, st));
+    }
+    {   // tile-aligned shapes: the plain batched TN GEMM
+        static const int fast = getenv("AFI_GEMM_TN") ? atoi(getenv("AFI_GEMM_TN")) : 1;
+        const int rc = fast ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st) : AFI_ERR_UNSUPPORTED;
+        if (rc == AFI_OK) return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
+        if (rc != AFI_ERR_UNSUPPORTED) return rc;
     }
     AfiWgradGemm g;
     memset(&g, 0, sizeof(g));
