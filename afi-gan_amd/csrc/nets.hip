@@ -151,6 +151,9 @@ static AfiWgradGemm conv_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W, 
 //      mode 1 = data gradient (K = Cout, columns = Cin, flipped taps).  ws: [U 16*K*Nc][V 16*Tpad*K][M 16*Tpad*Nc].
 static long long wino_tpad(int N, int H, int W) { return (((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + 127) / 128) * 128; }
 static long long wino4_tpad(int N, int H, int W) { return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4) + 127) / 128) * 128; }
+// AFI_WINO_D_F4=1: F(4x4) tiles also for the forwards a backward follows (faster; its ~3e-5 rounding moves ~30x more activations
+// across the LeakyReLU kink than an F(2x2)/direct forward does -- DESIGN.md "Winograd" has the measurement).  Off by default.
+static bool wino_d_f4() { static const int on = getenv("AFI_WINO_D_F4") ? atoi(getenv("AFI_WINO_D_F4")) : 0; return on != 0; }
 static bool wino_f4() { static const int on = getenv("AFI_WINO_F4") ? atoi(getenv("AFI_WINO_F4")) : 1; return on != 0; }
 // one size for both tilings: F(2x2,3x3) = 16 transform points over 2x2 tiles, F(4x4,3x3) = 36 points over 4x4 tiles
 static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
@@ -836,7 +839,7 @@ int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, in
         float* mean = ws + l.o_mean[n]; float* invstd = ws + l.o_invstd[n];
         if (l.n_wino > 0) {
             AFI_TRY(wino_conv(0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
-                              part_n_, st, /*fwd_f4=*/training != 1));
+                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4()));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }

@@ -56,7 +56,8 @@ class _DiscriminatorFn(torch.autograd.Function):
         ws = torch.empty(ws_floats, device=x.device, dtype=torch.float32)
         logits = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
         # 0 eval; 1 train mode with a backward to come; 2 train-mode statistics only (no input of this call needs a gradient)
-        mode = 0 if not net.training else (1 if (torch.is_grad_enabled() and any(ctx.needs_input_grad)) else 2)
+        # (needs_input_grad is all-False under no_grad; grad mode itself is always off inside Function.forward)
+        mode = 0 if not net.training else (1 if any(ctx.needs_input_grad) else 2)
         call("afi_discriminator_fwd", C.byref(prm), ops.view_of(xp), N, H, W, C.c_void_p(logits.data_ptr()), mode,
              C.c_void_p(ws.data_ptr()), ws_floats, ops.stream_ptr())
         ctx.net, ctx.shape, ctx.x_needs_grad, ctx.was_training = net, (N, H, W), x.requires_grad, net.training
