@@ -81,6 +81,9 @@ SIGNATURES = {
     "afi_dwconv3x3_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _vp]),
     "afi_maxpool3s2_same_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp]),
     "afi_fuse_swish_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "afi_resize_bilinear_u8_ws_bytes": (_ll, [_i, _i, _i, _i, _i]),
+    "afi_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _ll, _vp]),
+    "afi_normalize_pad_u8": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_pack_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_unpack_wgrad": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp]),

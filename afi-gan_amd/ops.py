@@ -353,6 +353,56 @@ def fuse_swish(w, a, b, c=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ dual-scale data path
+def _check_u8(t):
+    if not t.is_cuda:
+        raise _lib.AfiError("the dual-scale data path runs on the GPU only (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.uint8 or not t.is_contiguous():
+        raise _lib.AfiError(f"expected a contiguous uint8 tensor, got {t.dtype}, contiguous={t.is_contiguous()}")
+
+
+def resize_bilinear_u8(img_hwc, new_h, new_w, hflip=False, chw=True):
+    """ResizeTransform.apply_image (Pillow BILINEAR, bit-exact) + the shared HFlipTransform for a uint8 [H,W,C] or [H,W]
+    device tensor; returns uint8 [C,new_h,new_w] (chw, the DatasetMapper tensor layout) or [new_h,new_w,C]."""
+    _check_u8(img_hwc)
+    squeeze = img_hwc.dim() == 2
+    H0, W0 = img_hwc.shape[:2]
+    Cn = 1 if squeeze else img_hwc.shape[2]
+    new_h, new_w = int(new_h), int(new_w)
+    lib = _lib.load()
+    ws_bytes = lib.afi_resize_bilinear_u8_ws_bytes(H0, W0, Cn, new_h, new_w)
+    if ws_bytes < 0:
+        raise _lib.AfiError(f"afi_resize_bilinear_u8: unsupported shape {tuple(img_hwc.shape)} -> {(new_h, new_w)}")
+    ws = torch.empty(ws_bytes, device=img_hwc.device, dtype=torch.uint8)
+    out = torch.empty((Cn, new_h, new_w) if chw else (new_h, new_w, Cn), device=img_hwc.device, dtype=torch.uint8)
+    call("afi_resize_bilinear_u8", _p(img_hwc), H0, W0, Cn, _p(out), new_h, new_w, int(bool(hflip)), int(bool(chw)), _p(ws), ws_bytes,
+         stream_ptr())
+    if squeeze:
+        out = out[0] if chw else out[..., 0]
+    return out
+
+
+def normalize_pad(images_chw, pixel_mean, pixel_std, size_divisibility=0):
+    """RCNN_FPN_only.forward's `(x - mean) / std` per image + ImageList.from_tensors (rcnn_only.py:36-39): a list of uint8
+    [C,H,W] device tensors -> fp32 [N,C,Hp,Wp], zero-padded bottom/right to the batch maximum rounded up to size_divisibility."""
+    assert len(images_chw) > 0
+    for t in images_chw:
+        _check_u8(t)
+    Cn = images_chw[0].shape[0]
+    hm = max(t.shape[1] for t in images_chw)
+    wm = max(t.shape[2] for t in images_chw)
+    if size_divisibility > 0:
+        hm = -(-hm // size_divisibility) * size_divisibility
+        wm = -(-wm // size_divisibility) * size_divisibility
+    mean = (C.c_float * Cn)(*[float(v) for v in pixel_mean])
+    std = (C.c_float * Cn)(*[float(v) for v in pixel_std])
+    out = torch.empty((len(images_chw), Cn, hm, wm), device=images_chw[0].device, dtype=torch.float32)
+    for n, t in enumerate(images_chw):
+        assert t.shape[0] == Cn
+        call("afi_normalize_pad_u8", _p(t), Cn, t.shape[1], t.shape[2], mean, std, _p(out[n]), hm, wm, stream_ptr())
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ bandwidth ops
 def bilinear2x(x, out=None, beta=0.0):
     N, C_, H, W = x.shape

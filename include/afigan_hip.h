@@ -208,6 +208,22 @@ int afi_scale_inplace(float* p, long long n, float s, void* stream);
 int afi_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, void* stream);
 int afi_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, void* stream);
 
+/* ------------------------------------------------------------------ dual-scale data path
+ * afi_resize_bilinear_u8: what ResizeTransform.apply_image does to a uint8 image under the reference's DatasetMapper
+ * (afigan/engine/dataset_mapper.py:85-107; target sizes from afigan/engine/transform_gen.py:198-217 for `image` and
+ * :542-543 for `image_x0.5`): Pillow's antialiased BILINEAR resample, bit-exact (22-bit fixed-point coefficients, horizontal
+ * pass rounded to uint8, then vertical pass), followed by the shared HFlipTransform when `hflip` != 0.
+ *   src [H0][W0][C] uint8 (C = 1 or 3: Pillow modes L / RGB), dst [H1][W1][C] (out_chw == 0) or [C][H1][W1] (out_chw != 0, the mapper's tensor layout),
+ *   ws  >= afi_resize_bilinear_u8_ws_bytes(...) bytes of device scratch (coefficient tables + the intermediate image).
+ * afi_normalize_pad_u8: RCNN_FPN_only.forward's per-image normaliser and ImageList.from_tensors padding
+ * (afigan/modeling/meta_arch/rcnn_only.py:36-39): out[c][y][x] = (img[c][y][x] - mean[c]) / std[c] in fp32 for y < H, x < W and
+ * 0 up to Hp x Wp; img is [C][H][W] uint8 on the device, mean/std are HOST arrays of C floats, out is one [C][Hp][Wp] slot of the batch. */
+long long afi_resize_bilinear_u8_ws_bytes(int H0, int W0, int C, int H1, int W1);
+int afi_resize_bilinear_u8(const unsigned char* src, int H0, int W0, int C, unsigned char* dst, int H1, int W1, int hflip,
+                           int out_chw, void* ws, long long ws_bytes, void* stream);
+int afi_normalize_pad_u8(const unsigned char* img_chw, int C, int H, int W, const float* mean, const float* std_,
+                         float* out, int Hp, int Wp, void* stream);
+
 /* Optional caller-owned scratch for the PER-OP convolution entry points (afi_conv3x3_*, afi_conv1x1_*, afi_conv3x3s2_*,
  * afi_convT6s2_*): with it, small and mid-size maps (< 6 tiles of 128x128 per CU) run split-K with a deterministic second
  * pass.  One buffer per process: it serves the launches of ONE stream at a time (the whole-net entry points do not use it,
