@@ -21,5 +21,6 @@ from .fpn_sr import FPN_AFIGAN, LastLevelMaxPool  # noqa: E402
 from .pafpn_sr import PAFPN_AFIGAN  # noqa: E402
 from .bifpn_sr import BiFPN_AFIGAN, LastLevelP6P7  # noqa: E402
 from .stage2 import Stage2Adversarial, l1_loss_common, nearest_half  # noqa: E402
+from .dual_scale import DualScaleMapper, preprocess_images  # noqa: E402
 
-__all__ = ["Generator", "Discriminator", "Stage1Step", "warmup_multistep_lr", "FPN_AFIGAN", "PAFPN_AFIGAN", "BiFPN_AFIGAN", "LastLevelP6P7", "LastLevelMaxPool", "Stage2Adversarial", "l1_loss_common", "nearest_half", "ops", "AfiError"]
+__all__ = ["Generator", "Discriminator", "Stage1Step", "warmup_multistep_lr", "FPN_AFIGAN", "PAFPN_AFIGAN", "BiFPN_AFIGAN", "LastLevelP6P7", "LastLevelMaxPool", "Stage2Adversarial", "l1_loss_common", "nearest_half", "DualScaleMapper", "preprocess_images", "ops", "AfiError"]

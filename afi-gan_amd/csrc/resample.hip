@@ -5,7 +5,8 @@
 // The resize reproduces, bit for bit, what detectron2's ResizeTransform.apply_image runs for uint8 images:
 // Pillow's ImagingResample with the BILINEAR filter -- a triangle filter whose support grows with the down-scale factor,
 // coefficients computed in double precision and rounded to 22-bit fixed point, a horizontal pass rounded to uint8, then a
-// vertical pass.  Byte work, HBM/launch bound: three small kernels (coefficients, horizontal, vertical + flip + CHW store).
+// vertical pass.  Byte work, HBM/launch bound: two launches per SAMPLE -- the coefficient tables of all four axes, then one fused
+// kernel that produces `image` and `image_x0.5` from the source (both passes, flip and CHW store; no intermediate image in memory).
 // The coefficient kernel runs the same IEEE double operations, in the same order, as the C code it mirrors: contraction into
 // FMAs is switched off for this file.
 #pragma clang fp contract(off)
@@ -20,16 +21,16 @@ __device__ __forceinline__ int afi_rs_clip8(int s) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// one thread per output column (first outW threads) or output row (next outH): bounds[i] = {first source index, tap count},
-// kk[i][0..ks) = fixed-point weights (zero beyond the tap count)
-__global__ void afi_resample_coeffs_kernel(int inW, int outW, int ksW, int* __restrict__ bW, int* __restrict__ kW,
-                                           int inH, int outH, int ksH, int* __restrict__ bH, int* __restrict__ kH) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int in_size, out_size, ks, xx;
-    int* b; int* kk;
-    if (i < outW) { in_size = inW; out_size = outW; ks = ksW; xx = i; b = bW; kk = kW; }
-    else if (i < outW + outH) { in_size = inH; out_size = outH; ks = ksH; xx = i - outW; b = bH; kk = kH; }
-    else return;
+// Coefficient tables of up to four axes in one launch.  One thread per output index of an axis:
+// bounds[i] = {first source index, tap count}, kk[i][0..ks) = fixed-point weights (zero beyond the tap count).
+struct AfiRsAxis { int in_size, out_size, ks; int* bounds; int* kk; };
+struct AfiRsAxes { AfiRsAxis a[4]; int n; };
+__global__ void afi_resample_coeffs_kernel(AfiRsAxes ax) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int which = 0;
+    while (which < ax.n && i >= ax.a[which].out_size) { i -= ax.a[which].out_size; ++which; }
+    if (which >= ax.n) return;
+    const int in_size = ax.a[which].in_size, out_size = ax.a[which].out_size, ks = ax.a[which].ks, xx = i;
     const double scale = (double)((float)in_size - 0.0f) / out_size;
     const double filterscale = scale < 1.0 ? 1.0 : scale;
     const double support = 1.0 * filterscale;
@@ -46,7 +47,7 @@ __global__ void afi_resample_coeffs_kernel(int inW, int outW, int ksW, int* __re
         if (a < 0.0) a = -a;
         ww += a < 1.0 ? 1.0 - a : 0.0;
     }
-    int* k = kk + (long long)xx * ks;
+    int* k = ax.a[which].kk + (long long)xx * ks;
     for (int x = 0; x < ks; ++x) {
         double v = 0.0;
         if (x < xmax) {
@@ -57,57 +58,51 @@ __global__ void afi_resample_coeffs_kernel(int inW, int outW, int ksW, int* __re
         }
         k[x] = v < 0 ? (int)(-0.5 + v * (double)(1 << AFI_RS_PRECISION_BITS)) : (int)(0.5 + v * (double)(1 << AFI_RS_PRECISION_BITS));
     }
-    b[2 * xx] = xmin;
-    b[2 * xx + 1] = xmax;
+    ax.a[which].bounds[2 * xx] = xmin;
+    ax.a[which].bounds[2 * xx + 1] = xmax;
 }
 
-// horizontal pass: tmp[y][xx][c] = clip8(sum_x src[y][xmin + x][c] * k[x])
+// Both passes in one kernel, for up to two target sizes of one source image.  Per output pixel the few intermediate pixels its
+// vertical taps need are recomputed from the source -- each rounded to uint8 exactly as Pillow's horizontal pass stores them --
+// so the intermediate image never exists in memory: the source (L2-resident) is read, the result written once.
+// Optional horizontal flip and HWC / CHW store are part of the same write.
+struct AfiRsTarget { unsigned char* dst; int H1, W1, ksw, ksh, hflip; const int* bw; const int* kw; const int* bh; const int* kh; };
+struct AfiRsTargets { AfiRsTarget t[2]; int n; };
 template <int C>
-__global__ void afi_resample_h_kernel(const unsigned char* __restrict__ src, int H0, int W0, unsigned char* __restrict__ tmp, int W1,
-                                      const int* __restrict__ bounds, const int* __restrict__ kk, int ks) {
-    const long long total = (long long)H0 * W1;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int y = (int)(idx / W1), xx = (int)(idx - (long long)y * W1);
-        const int xmin = bounds[2 * xx], xmax = bounds[2 * xx + 1];
-        const int* k = kk + (long long)xx * ks;
-        const unsigned char* p = src + ((long long)y * W0 + xmin) * C;
-        int s[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) s[c] = 1 << (AFI_RS_PRECISION_BITS - 1);
-        for (int x = 0; x < xmax; ++x) {
-            const int kx = k[x];
-#pragma unroll
-            for (int c = 0; c < C; ++c) s[c] += (int)p[x * C + c] * kx;
-        }
-#pragma unroll
-        for (int c = 0; c < C; ++c) tmp[idx * C + c] = (unsigned char)afi_rs_clip8(s[c]);
-    }
-}
-
-// vertical pass + optional horizontal flip + HWC or CHW store
-template <int C>
-__global__ void afi_resample_v_kernel(const unsigned char* __restrict__ tmp, int W1, unsigned char* __restrict__ dst, int H1,
-                                      const int* __restrict__ bounds, const int* __restrict__ kk, int ks, int hflip, int chw) {
-    const long long total = (long long)H1 * W1;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int yy = (int)(idx / W1), x = (int)(idx - (long long)yy * W1);
-        const int ymin = bounds[2 * yy], ymax = bounds[2 * yy + 1];
-        const int* k = kk + (long long)yy * ks;
-        const unsigned char* p = tmp + ((long long)ymin * W1 + x) * C;
-        const long long pitch = (long long)W1 * C;
+__global__ void afi_resample_fused_kernel(const unsigned char* __restrict__ src, int W0, AfiRsTargets tg, int chw) {
+    const long long n0 = (long long)tg.t[0].H1 * tg.t[0].W1;
+    const long long total = n0 + (tg.n > 1 ? (long long)tg.t[1].H1 * tg.t[1].W1 : 0);
+    for (long long gi = (long long)blockIdx.x * blockDim.x + threadIdx.x; gi < total; gi += (long long)gridDim.x * blockDim.x) {
+        const int w = gi >= n0;
+        const AfiRsTarget& t = tg.t[w];
+        const long long idx = gi - (w ? n0 : 0);
+        const int yy = (int)(idx / t.W1), xx = (int)(idx - (long long)yy * t.W1);
+        const int xmin = t.bw[2 * xx], xmax = t.bw[2 * xx + 1];
+        const int ymin = t.bh[2 * yy], ymax = t.bh[2 * yy + 1];
+        const int* kx = t.kw + (long long)xx * t.ksw;
+        const int* ky = t.kh + (long long)yy * t.ksh;
         int s[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) s[c] = 1 << (AFI_RS_PRECISION_BITS - 1);
         for (int y = 0; y < ymax; ++y) {
-            const int ky = k[y];
+            const unsigned char* p = src + ((long long)(ymin + y) * W0 + xmin) * C;
+            int h[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) s[c] += (int)p[y * pitch + c] * ky;
+            for (int c = 0; c < C; ++c) h[c] = 1 << (AFI_RS_PRECISION_BITS - 1);
+            for (int x = 0; x < xmax; ++x) {
+                const int k = kx[x];
+#pragma unroll
+                for (int c = 0; c < C; ++c) h[c] += (int)p[x * C + c] * k;
+            }
+            const int k = ky[y];
+#pragma unroll
+            for (int c = 0; c < C; ++c) s[c] += afi_rs_clip8(h[c]) * k;
         }
-        const int xo = hflip ? W1 - 1 - x : x;
+        const int xo = t.hflip ? t.W1 - 1 - xx : xx;
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const long long o = chw ? ((long long)c * H1 + yy) * W1 + xo : ((long long)yy * W1 + xo) * C + c;
-            dst[o] = (unsigned char)afi_rs_clip8(s[c]);
+            const long long o = chw ? ((long long)c * t.H1 + yy) * t.W1 + xo : ((long long)yy * t.W1 + xo) * C + c;
+            t.dst[o] = (unsigned char)afi_rs_clip8(s[c]);
         }
     }
 }
@@ -133,8 +128,9 @@ static int afi_rs_ksize(int in_size, int out_size) {
     return (int)ceil(scale) * 2 + 1;
 }
 static long long afi_rs_align(long long b) { return (b + 255) & ~255LL; }
-struct AfiRsWs { long long o_bw, o_kw, o_bh, o_kh, o_tmp, total; int ksw, ksh; };
-static AfiRsWs afi_rs_ws(int H0, int W0, int C, int H1, int W1) {
+// workspace of one target: [bounds W][kk W][bounds H][kk H]
+struct AfiRsWs { long long o_bw, o_kw, o_bh, o_kh, total; int ksw, ksh; };
+static AfiRsWs afi_rs_ws(int H0, int W0, int H1, int W1) {
     AfiRsWs w;
     w.ksw = afi_rs_ksize(W0, W1); w.ksh = afi_rs_ksize(H0, H1);
     long long o = 0;
@@ -142,7 +138,6 @@ static AfiRsWs afi_rs_ws(int H0, int W0, int C, int H1, int W1) {
     w.o_kw = o; o += afi_rs_align(4LL * W1 * w.ksw);
     w.o_bh = o; o += afi_rs_align(8LL * H1);
     w.o_kh = o; o += afi_rs_align(4LL * H1 * w.ksh);
-    w.o_tmp = o; o += afi_rs_align((long long)H0 * W1 * C);
     w.total = o;
     return w;
 }
@@ -152,34 +147,61 @@ static unsigned afi_rs_grid(long long items) {
     if (g < 1) g = 1;
     return (unsigned)g;
 }
+static bool afi_rs_shape_ok(int H0, int W0, int H1, int W1) {
+    // Pillow keeps its accumulators in 32 bits too; its own limit on the tap count is far beyond any image size used here
+    return H0 > 0 && W0 > 0 && H1 > 0 && W1 > 0 && (long long)H0 * W0 < (1LL << 31) && (long long)H1 * W1 < (1LL << 31);
+}
+// n = 1 or 2 targets of one source
+static int afi_rs_run(const unsigned char* src, int H0, int W0, int C, int n, unsigned char* const dst[2], const int H1[2], const int W1[2],
+                      const int hflip[2], int out_chw, void* ws, long long ws_bytes, hipStream_t st) {
+    if (!src || !ws) return AFI_ERR_BAD_ARG;
+    if (C != 1 && C != 3) return AFI_ERR_UNSUPPORTED;      // Pillow modes "L" and "RGB"; "LA"/"RGBA" resize premultiplied, not this path
+    AfiRsAxes ax; ax.n = 2 * n;
+    AfiRsTargets tg; tg.n = n;
+    long long off = 0, outs = 0, pix = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!dst[i]) return AFI_ERR_BAD_ARG;
+        if (!afi_rs_shape_ok(H0, W0, H1[i], W1[i])) return AFI_ERR_UNSUPPORTED;
+        const AfiRsWs l = afi_rs_ws(H0, W0, H1[i], W1[i]);
+        if (ws_bytes < off + l.total) return AFI_ERR_WORKSPACE;
+        char* base = (char*)ws + off;
+        int* bw = (int*)(base + l.o_bw); int* kw = (int*)(base + l.o_kw);
+        int* bh = (int*)(base + l.o_bh); int* kh = (int*)(base + l.o_kh);
+        ax.a[2 * i] = AfiRsAxis{W0, W1[i], l.ksw, bw, kw};
+        ax.a[2 * i + 1] = AfiRsAxis{H0, H1[i], l.ksh, bh, kh};
+        tg.t[i] = AfiRsTarget{dst[i], H1[i], W1[i], l.ksw, l.ksh, hflip[i], bw, kw, bh, kh};
+        off += l.total; outs += W1[i] + H1[i]; pix += (long long)H1[i] * W1[i];
+    }
+    for (int i = n; i < 2; ++i) tg.t[i] = tg.t[0];
+    for (int i = 2 * n; i < 4; ++i) ax.a[i] = ax.a[0];
+    hipLaunchKernelGGL(afi_resample_coeffs_kernel, dim3((unsigned)((outs + 255) / 256)), dim3(256), 0, st, ax);
+    if (C == 1) hipLaunchKernelGGL((afi_resample_fused_kernel<1>), dim3(afi_rs_grid(pix)), dim3(256), 0, st, src, W0, tg, out_chw);
+    else        hipLaunchKernelGGL((afi_resample_fused_kernel<3>), dim3(afi_rs_grid(pix)), dim3(256), 0, st, src, W0, tg, out_chw);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
 
 long long afi_resize_bilinear_u8_ws_bytes(int H0, int W0, int C, int H1, int W1) {
-    if (H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0 || (C != 1 && C != 3)) return -1;
-    return afi_rs_ws(H0, W0, C, H1, W1).total;
+    if (!afi_rs_shape_ok(H0, W0, H1, W1) || (C != 1 && C != 3)) return -1;
+    return afi_rs_ws(H0, W0, H1, W1).total;
 }
 
 int afi_resize_bilinear_u8(const unsigned char* src, int H0, int W0, int C, unsigned char* dst, int H1, int W1, int hflip,
-                                      int out_chw, void* ws, long long ws_bytes, void* stream) {
-    if (!src || !dst || !ws || H0 <= 0 || W0 <= 0 || H1 <= 0 || W1 <= 0) return AFI_ERR_BAD_ARG;
-    if (C != 1 && C != 3) return AFI_ERR_UNSUPPORTED;      // Pillow modes "L" and "RGB"; "LA"/"RGBA" resize premultiplied, not this path
-    // Pillow keeps the accumulators in 32 bits too; its own limit on the tap count is far beyond any image size used here
-    if ((long long)H0 * W0 >= (1LL << 31) || (long long)H1 * W1 >= (1LL << 31)) return AFI_ERR_UNSUPPORTED;
-    const AfiRsWs l = afi_rs_ws(H0, W0, C, H1, W1);
-    if (ws_bytes < l.total) return AFI_ERR_WORKSPACE;
-    hipStream_t st = (hipStream_t)stream;
-    char* base = (char*)ws;
-    int* bw = (int*)(base + l.o_bw); int* kw = (int*)(base + l.o_kw);
-    int* bh = (int*)(base + l.o_bh); int* kh = (int*)(base + l.o_kh);
-    unsigned char* tmp = (unsigned char*)(base + l.o_tmp);
-    hipLaunchKernelGGL(afi_resample_coeffs_kernel, dim3((W1 + H1 + 255) / 256), dim3(256), 0, st, W0, W1, l.ksw, bw, kw, H0, H1, l.ksh, bh, kh);
-    const unsigned gh = afi_rs_grid((long long)H0 * W1), gv = afi_rs_grid((long long)H1 * W1);
-#define AFI_RS_LAUNCH(CC)                                                                                                          \
-    hipLaunchKernelGGL((afi_resample_h_kernel<CC>), dim3(gh), dim3(256), 0, st, src, H0, W0, tmp, W1, (const int*)bw, (const int*)kw, l.ksw); \
-    hipLaunchKernelGGL((afi_resample_v_kernel<CC>), dim3(gv), dim3(256), 0, st, (const unsigned char*)tmp, W1, dst, H1, (const int*)bh,       \
-                       (const int*)kh, l.ksh, hflip, out_chw)
-    if (C == 1) { AFI_RS_LAUNCH(1); } else { AFI_RS_LAUNCH(3); }
-#undef AFI_RS_LAUNCH
-    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+                           int out_chw, void* ws, long long ws_bytes, void* stream) {
+    unsigned char* const d[2] = {dst, nullptr};
+    const int h[2] = {H1, 0}, w[2] = {W1, 0}, f[2] = {hflip, 0};
+    return afi_rs_run(src, H0, W0, C, 1, d, h, w, f, out_chw, ws, ws_bytes, (hipStream_t)stream);
+}
+
+long long afi_dual_scale_u8_ws_bytes(int H0, int W0, int C, int H1, int W1, int H2, int W2) {
+    const long long a = afi_resize_bilinear_u8_ws_bytes(H0, W0, C, H1, W1), b = afi_resize_bilinear_u8_ws_bytes(H0, W0, C, H2, W2);
+    return a < 0 || b < 0 ? -1 : a + b;
+}
+
+int afi_dual_scale_u8(const unsigned char* src, int H0, int W0, int C, unsigned char* image, int H1, int W1, int hflip,
+                      unsigned char* image_r, int H2, int W2, int hflip_r, int out_chw, void* ws, long long ws_bytes, void* stream) {
+    unsigned char* const d[2] = {image, image_r};
+    const int h[2] = {H1, H2}, w[2] = {W1, W2}, f[2] = {hflip, hflip_r};
+    return afi_rs_run(src, H0, W0, C, 2, d, h, w, f, out_chw, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int afi_normalize_pad_u8(const unsigned char* img_chw, int C, int H, int W, const float* mean, const float* std_,

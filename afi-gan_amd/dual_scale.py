@@ -122,10 +122,9 @@ class DualScaleMapper:
         if size == 0:
             raise _lib.AfiError("short-edge size 0 (NoOpTransform) is not supported on the dual-scale path")
         new_h, new_w = shortest_edge_size(h, w, size, self.max_size)
-        d["image"] = ops.resize_bilinear_u8(img, new_h, new_w, hflip=flip, chw=True)
         ratio = self.scale_ratio[0]
         rh, rw = int(new_h * ratio), int(new_w * ratio)
-        image_r = ops.resize_bilinear_u8(img, rh, rw, hflip=flip_r, chw=True)
+        d["image"], image_r = ops.dual_scale_u8(img, (new_h, new_w), (rh, rw), hflip=flip, hflip_r=flip_r, chw=True)
         shp = d["image"].shape
         d[f"width_x{ratio}"], d[f"heigth_x{ratio}"] = int(shp[1] * ratio), int(shp[2] * ratio)      # sic, dataset_mapper.py:121-122
         if not self.is_train:

@@ -382,6 +382,26 @@ def resize_bilinear_u8(img_hwc, new_h, new_w, hflip=False, chw=True):
     return out
 
 
+def dual_scale_u8(img_hwc, size, size_r, hflip=False, hflip_r=False, chw=True):
+    """Both images of one DatasetMapper sample in two launches: `image` = resize(img, size) and `image_x0.5` =
+    resize(img, size_r), each from the ORIGINAL uint8 [H,W,3] device tensor (dataset_mapper.py:103-105), each with its flip flag."""
+    _check_u8(img_hwc)
+    if img_hwc.dim() != 3:
+        raise _lib.AfiError(f"expected a uint8 HWC image, got shape {tuple(img_hwc.shape)}")
+    H0, W0, Cn = img_hwc.shape
+    (H1, W1), (H2, W2) = (int(v) for v in size), (int(v) for v in size_r)
+    lib = _lib.load()
+    ws_bytes = lib.afi_dual_scale_u8_ws_bytes(H0, W0, Cn, H1, W1, H2, W2)
+    if ws_bytes < 0:
+        raise _lib.AfiError(f"afi_dual_scale_u8: unsupported shape {tuple(img_hwc.shape)} -> {(H1, W1)}, {(H2, W2)}")
+    ws = torch.empty(ws_bytes, device=img_hwc.device, dtype=torch.uint8)
+    out = torch.empty((Cn, H1, W1) if chw else (H1, W1, Cn), device=img_hwc.device, dtype=torch.uint8)
+    out_r = torch.empty((Cn, H2, W2) if chw else (H2, W2, Cn), device=img_hwc.device, dtype=torch.uint8)
+    call("afi_dual_scale_u8", _p(img_hwc), H0, W0, Cn, _p(out), H1, W1, int(bool(hflip)), _p(out_r), H2, W2, int(bool(hflip_r)),
+         int(bool(chw)), _p(ws), ws_bytes, stream_ptr())
+    return out, out_r
+
+
 def normalize_pad(images_chw, pixel_mean, pixel_std, size_divisibility=0):
     """RCNN_FPN_only.forward's `(x - mean) / std` per image + ImageList.from_tensors (rcnn_only.py:36-39): a list of uint8
     [C,H,W] device tensors -> fp32 [N,C,Hp,Wp], zero-padded bottom/right to the batch maximum rounded up to size_divisibility."""

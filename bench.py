@@ -15,6 +15,7 @@ Extra objects on the line:
   cpu_baseline  -- the CPU oracle (kind "port": oracle/afigan_oracle.py, a PyTorch-CPU restatement pinned to the reference's
                    outputs) timed on this host on a bounded sample of the same workload (levels P3..P6 only), scaled to images/s.
   af_interpolator -- BASELINE metric 1: Generator fwd+bwd feature-Mpix/s on 1x256x25x34 -> 1x256x50x68 (and batch 16).
+  fpn_topdown / pafpn / bifpn_inference / stage2_adversarial / dual_scale_data_path -- the SURVEY 8(f) rows, N = 1 only.
 """
 import argparse
 import ctypes as C
@@ -466,6 +467,8 @@ def main():
         line["pafpn"] = fpn_bench(amd, torch, pafpn=True)
         line["bifpn_inference"] = bifpn_bench(amd, torch)
         line["stage2_adversarial"] = stage2_bench(amd, torch)
+        from tools import dual_scale_bench                       # the mapper's uint8 resize pair + normalise/pad
+        line["dual_scale_data_path"] = dual_scale_bench.run(iters=100, warm=10, cpu_iters=3)
     log("CPU baseline (oracle) on the host cores")
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, B)

@@ -214,13 +214,18 @@ int afi_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, void* str
  * :542-543 for `image_x0.5`): Pillow's antialiased BILINEAR resample, bit-exact (22-bit fixed-point coefficients, horizontal
  * pass rounded to uint8, then vertical pass), followed by the shared HFlipTransform when `hflip` != 0.
  *   src [H0][W0][C] uint8 (C = 1 or 3: Pillow modes L / RGB), dst [H1][W1][C] (out_chw == 0) or [C][H1][W1] (out_chw != 0, the mapper's tensor layout),
- *   ws  >= afi_resize_bilinear_u8_ws_bytes(...) bytes of device scratch (coefficient tables + the intermediate image).
+ *   ws  >= afi_resize_bilinear_u8_ws_bytes(...) bytes of device scratch (the coefficient tables).
  * afi_normalize_pad_u8: RCNN_FPN_only.forward's per-image normaliser and ImageList.from_tensors padding
  * (afigan/modeling/meta_arch/rcnn_only.py:36-39): out[c][y][x] = (img[c][y][x] - mean[c]) / std[c] in fp32 for y < H, x < W and
  * 0 up to Hp x Wp; img is [C][H][W] uint8 on the device, mean/std are HOST arrays of C floats, out is one [C][Hp][Wp] slot of the batch. */
+/* afi_dual_scale_u8: both images of one sample in two launches -- `image` [H1,W1] and `image_x0.5` [H2,W2], each resized from
+ * the same ORIGINAL src (dataset_mapper.py:103-105) with its own flip flag (equal when the flip is shared, transform_gen.py:546-554). */
 long long afi_resize_bilinear_u8_ws_bytes(int H0, int W0, int C, int H1, int W1);
 int afi_resize_bilinear_u8(const unsigned char* src, int H0, int W0, int C, unsigned char* dst, int H1, int W1, int hflip,
                            int out_chw, void* ws, long long ws_bytes, void* stream);
+long long afi_dual_scale_u8_ws_bytes(int H0, int W0, int C, int H1, int W1, int H2, int W2);
+int afi_dual_scale_u8(const unsigned char* src, int H0, int W0, int C, unsigned char* image, int H1, int W1, int hflip,
+                      unsigned char* image_r, int H2, int W2, int hflip_r, int out_chw, void* ws, long long ws_bytes, void* stream);
 int afi_normalize_pad_u8(const unsigned char* img_chw, int C, int H, int W, const float* mean, const float* std_,
                          float* out, int Hp, int Wp, void* stream);
 
