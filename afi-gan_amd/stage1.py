@@ -21,6 +21,7 @@ MI355X-first differences in HOW (results are the reference's):
     gathers per iteration (stage1_trainer.py:459,465).
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -113,6 +114,8 @@ class Stage1Step:
         self.lr_steps, self.lr_gamma, self.warmup_factor, self.warmup_iters = tuple(lr_steps), lr_gamma, warmup_factor, warmup_iters
         self.first_level = first_level
         self.reuse_g = reuse_generator_forward
+        self.overlap_d = os.environ.get("AFI_D_OVERLAP", "0") != "0"
+        self._bstream = None
         self.iter = 0
         self.pg = process_group
         if distributed is None:
@@ -230,11 +233,25 @@ class Stage1Step:
             trs.append((tr, ws))
             tr_c, hr_c = self._crop_pair(tr, hrs[i])                                  # :345-346
             for x, target, key in ((hr_c, 1.0, "d_ws"), (tr_c, 0.0, "d_ws")):        # :349-353, :355-359
+                if self.overlap_d:
+                    key = f"d_ws_{i}_{int(target)}"                                   # lives until its backward has run
                 logits, dws = self._d_forward(x, key)
-                dz = self._scratch("dlogits", logits.numel(), dev)
+                dz = self._scratch("dlogits" + (key if self.overlap_d else ""), logits.numel(), dev)
                 call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], target, 1.0,
                      C.c_void_p(lptr + 4 * (3 * i)), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
-                self._d_backward(x, dws, dz)                                         # :375 (accumulates into the flat grads)
+                if self.overlap_d:
+                    # all forwards stay in order on the caller's stream (BatchNorm running statistics), all backwards in
+                    # order on a second one (gradient accumulation): same results, and a backward's GEMMs run beside the
+                    # next forward's bandwidth-bound transforms / BatchNorm passes
+                    if self._bstream is None:
+                        self._bstream = torch.cuda.Stream(device=dev)
+                    self._bstream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._bstream):
+                        self._d_backward(x, dws, dz)
+                else:
+                    self._d_backward(x, dws, dz)                                     # :375 (accumulates into the flat grads)
+        if self.overlap_d and self._bstream is not None:
+            torch.cuda.current_stream().wait_stream(self._bstream)
         self._allreduce(self.d_opt)
         self.d_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :381
 
