@@ -386,7 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_
 // ------------------------------------------------------------------------------------------------
 // Plain batched "NT" GEMM for the Winograd planes:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k]   (both operands K-contiguous),
 // every dimension tile-aligned (rows per plane % 128 == 0, N % 128 == 0, K % 32 == 0): no row table, no tap masks, no bounds
-// checks, no zero page, one 64-bit base per operand: 136 registers and a leaner instruction stream than the general kernel
+// checks, no zero page, one 64-bit base per operand: a leaner instruction stream than the general kernel, which leaves room for a second fragment register set (152 registers)
 // (+4-5 % on the Winograd GEMMs).
 // Same tile, LDS layout, fragment order and MFMA loop as afi_pix_gemm_kernel<128,128,2,2,KC>.
 // ------------------------------------------------------------------------------------------------
@@ -449,13 +449,18 @@ __global__ __launch_bounds__(256, 3) void afi_gemm_nt_kernel(const AfiGemmNT p, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) *(f32x4*)(Bs + (ar + 32 * i) * LDK + 4 * aq) = b_reg[i];
             __syncthreads();
+            // fragments of slice s+1 are read from LDS while the 16 MFMAs of slice s issue (two register sets: 152 registers, +1.2 %)
+            f32x4 fa[2][MI], fb[2][NI];
+            auto frag = [&](int set, int s) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) fa[set][mi] = *(const f32x4*)(As + ((wm * MI + mi) * 32 + lr) * LDK + s * 8 + lh * 4);
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) fb[set][ni] = *(const f32x4*)(Bs + ((wn * NI + ni) * 32 + lr) * LDK + s * 8 + lh * 4);
+            };
+            frag(0, 0);
 #pragma unroll
             for (int s = 0; s < BK / 8; ++s) {
-                f32x4 fa[MI], fb[NI];
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) fa[mi] = *(const f32x4*)(As + ((wm * MI + mi) * 32 + lr) * LDK + s * 8 + lh * 4);
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) fb[ni] = *(const f32x4*)(Bs + ((wn * NI + ni) * 32 + lr) * LDK + s * 8 + lh * 4);
+                if (s + 1 < BK / 8) frag((s + 1) & 1, s + 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     __builtin_amdgcn_s_setprio(1);
@@ -463,7 +468,7 @@ __global__ __launch_bounds__(256, 3) void afi_gemm_nt_kernel(const AfiGemmNT p, 
                     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi][j], fb[ni][j], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][mi][j], fb[s & 1][ni][j], acc[mi][ni], 0, 0, 0);
                     __builtin_amdgcn_s_setprio(0);
                 }
                 if (s == 1) { issue_a(d, kc + d + PF); issue_b(kc + d + 1); }   // refill in the middle of the stage's MFMAs
