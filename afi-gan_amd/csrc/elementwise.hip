@@ -211,15 +211,34 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
                                           long long P, int C) {
     const long long total4 = P * C / 4;
     const int C4 = C / 4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        f32x4 v = *(const f32x4*)(x + i * 4);
-        const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
-        const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto apply = [](f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
         v = (v - mu) * is * ga + be;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * AFI_LRELU_SLOPE;
-        *(f32x4*)(y + i * 4) = v;
+        return v;
+    };
+    if (stride % C4 == 0) {
+        // a thread stays on one channel group: its four parameter vectors are loaded once, and four independent 16-B loads are
+        // kept in flight per thread (a streaming kernel needs ~37 KB outstanding per CU to cover the HBM latency)
+        const int c = (int)(i % C4) * 4;
+        const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c);
+        const f32x4 ga = *(const f32x4*)(gamma + c), be = *(const f32x4*)(beta + c);
+        for (; i + 3 * stride < total4; i += 4 * stride) {
+            f32x4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(x + (i + u * stride) * 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *(f32x4*)(y + (i + u * stride) * 4) = apply(v[u], mu, is, ga, be);
+        }
+        for (; i < total4; i += stride) *(f32x4*)(y + i * 4) = apply(*(const f32x4*)(x + i * 4), mu, is, ga, be);
+        return;
+    }
+    for (; i < total4; i += stride) {
+        const int c = (int)(i % C4) * 4;
+        *(f32x4*)(y + i * 4) = apply(*(const f32x4*)(x + i * 4), *(const f32x4*)(mean + c), *(const f32x4*)(invstd + c),
+                                     *(const f32x4*)(gamma + c), *(const f32x4*)(beta + c));
     }
 }
 
@@ -239,13 +258,30 @@ __global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float
     const long long total4 = P * C / 4;
     const int C4 = C / 4;
     const float inv_n = 1.f / (float)P;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long long)gridDim.x * blockDim.x) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    auto apply = [inv_n](f32x4 gv, f32x4 xv, f32x4 mu, f32x4 is, f32x4 ga, f32x4 sg, f32x4 sgx) {
+        const f32x4 xh = (xv - mu) * is;
+        return ga * is * (gv - sg * inv_n - xh * (sgx * inv_n));
+    };
+    if (stride % C4 == 0) {          // one channel group per thread: parameters hoisted, two element pairs in flight (see bn_apply)
         const int c = (int)(i % C4) * 4;
-        const f32x4 gv = *(const f32x4*)(g + i * 4), xv = *(const f32x4*)(x + i * 4);
         const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c), ga = *(const f32x4*)(gamma + c);
         const f32x4 sg = *(const f32x4*)(sums + c), sgx = *(const f32x4*)(sums + C + c);
-        const f32x4 xh = (xv - mu) * is;
-        *(f32x4*)(dx + i * 4) = ga * is * (gv - sg * inv_n - xh * (sgx * inv_n));
+        for (; i + stride < total4; i += 2 * stride) {
+            const f32x4 g0 = *(const f32x4*)(g + i * 4), x0 = *(const f32x4*)(x + i * 4);
+            const f32x4 g1 = *(const f32x4*)(g + (i + stride) * 4), x1 = *(const f32x4*)(x + (i + stride) * 4);
+            *(f32x4*)(dx + i * 4) = apply(g0, x0, mu, is, ga, sg, sgx);
+            *(f32x4*)(dx + (i + stride) * 4) = apply(g1, x1, mu, is, ga, sg, sgx);
+        }
+        for (; i < total4; i += stride)
+            *(f32x4*)(dx + i * 4) = apply(*(const f32x4*)(g + i * 4), *(const f32x4*)(x + i * 4), mu, is, ga, sg, sgx);
+        return;
+    }
+    for (; i < total4; i += stride) {
+        const int c = (int)(i % C4) * 4;
+        *(f32x4*)(dx + i * 4) = apply(*(const f32x4*)(g + i * 4), *(const f32x4*)(x + i * 4), *(const f32x4*)(mean + c), *(const f32x4*)(invstd + c),
+                                      *(const f32x4*)(gamma + c), *(const f32x4*)(sums + c), *(const f32x4*)(sums + C + c));
     }
 }
 // bias gradient finalize: db += alpha * sum
