@@ -75,7 +75,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         lib = _lib.load()
         prm, _ = net._param_struct(weights, already_packed=True)
         need = ctx.needs_input_grad[2:]
-        grads = [torch.zeros_like(w) if n else None for w, n in zip(weights, need)]
+        grads = ops.zeros_like_many(weights, need)
         gst, _ = net._param_struct(grads, already_packed=True, grads=True)
         dlogits = dlogits.contiguous()
         dx = ops.new_pixel_major(N, net.F[0], H, W, dlogits.device) if ctx.x_needs_grad else None

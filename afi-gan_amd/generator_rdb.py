@@ -101,7 +101,7 @@ class _GeneratorFn(torch.autograd.Function):
         # only the parameters that require a gradient get one (MODEL.AFI_FREEZE, fpn_sr.py:67-69, freezes them all: the
         # library then skips every weight-gradient GEMM); zeros_like keeps the [O][kh][kw][I] memory layout
         need = ctx.needs_input_grad[2:]
-        grads = [torch.zeros_like(w) if n else None for w, n in zip(weights, need)]
+        grads = ops.zeros_like_many(weights, need)
         gst, _ = gen._param_struct(grads, already_packed=True)
         dx = ops.new_pixel_major(N, gen.in_channels, H, W, dout.device) if ctx.x_needs_grad else None
         sc_floats = lib.afi_generator_bwd_ws_floats(gen.in_channels, gen.growth_rate, gen.n_residual_dense_blocks, N, H, W)

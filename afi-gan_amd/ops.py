@@ -88,6 +88,35 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
 
 
+def _dense(t):
+    """sizes/strides describe a permutation of a contiguous block (what zeros_like can reproduce exactly)"""
+    expect = 1
+    for size, stride in sorted(((sz, st) for sz, st in zip(t.size(), t.stride()) if sz != 1), key=lambda p: p[1]):
+        if stride != expect:
+            return False
+        expect *= size
+    return True
+
+
+def zeros_like_many(tensors, need):
+    """``[torch.zeros_like(t) if n else None ...]`` out of ONE zero-filled allocation (one fill kernel instead of one per
+    tensor: 23 launches per interpolator backward otherwise).  Each result keeps its tensor's sizes and strides (the
+    [O][kh][kw][I] weight layout) and starts 16-byte aligned."""
+    offs, total = [], 0
+    for t, n in zip(tensors, need):
+        if n:
+            assert t.dtype == torch.float32 and _dense(t), (t.dtype, t.size(), t.stride())
+            offs.append(total)
+            total += (t.numel() + 3) & ~3
+        else:
+            offs.append(None)
+    if total == 0:
+        return [None] * len(offs)
+    ref = next(t for t, n in zip(tensors, need) if n)
+    flat = torch.zeros(total, device=ref.device, dtype=torch.float32)
+    return [flat.as_strided(t.size(), t.stride(), o) if o is not None else None for t, o in zip(tensors, offs)]
+
+
 # ------------------------------------------------------------------------------------------------ convs
 _OP_SCRATCH = {}
 OP_SCRATCH_FLOATS = 100 * 1024 * 1024          # 400 MB: 4 slabs of the largest map that is split (1536 tiles of 128x128)
