@@ -17,15 +17,18 @@ import torch.nn.functional as F
 from . import ops
 
 
-def _kaiming(shape, fan_out):
-    return torch.randn(shape) * math.sqrt(2.0 / fan_out)
+def _kaiming(shape, fan_in, gain=1.0):
+    """He init on fan_in (variance-preserving through ReLU): with the residual branches damped (gain 0.25 on their last conv) the
+    random-init pyramid stays O(1), like a trained guide's features -- the stage-1 step then trains stably for as many iterations
+    as a bench run asks for (an unnormalised harness with features ~1e5 drives the interpolator to NaN within ~25 iterations)."""
+    return torch.randn(shape) * (gain * math.sqrt(2.0 / fan_in))
 
 
 class _Conv1x1(nn.Module):
-    def __init__(self, cin, cout, stride=1, relu=False):
+    def __init__(self, cin, cout, stride=1, relu=False, gain=1.0):
         super().__init__()
         self.stride, self.relu = stride, relu
-        self.register_buffer("w", _kaiming((cin, cout), cout))          # [Cin, Cout] (frozen-BN scale folded in)
+        self.register_buffer("w", _kaiming((cin, cout), cin, gain))     # [Cin, Cout] (frozen-BN scale folded in)
         self.register_buffer("b", torch.zeros(cout))
 
     def forward(self, x):                                               # x: [N,C,H,W] pixel-major
@@ -42,7 +45,7 @@ class _Conv3x3(nn.Module):
     def __init__(self, cin, cout, relu=False):
         super().__init__()
         self.relu = relu
-        self.register_buffer("w", _kaiming((cout, 3, 3, cin), cout * 9).permute(0, 3, 1, 2))   # memory [Cout][3][3][Cin]
+        self.register_buffer("w", _kaiming((cout, 3, 3, cin), cin * 9).permute(0, 3, 1, 2))    # memory [Cout][3][3][Cin]
         self.register_buffer("b", torch.zeros(cout))
 
     def forward(self, x):
@@ -54,7 +57,7 @@ class _Bottleneck(nn.Module):
         super().__init__()
         self.c1 = _Conv1x1(cin, mid, stride, relu=True)                 # detectron2 STRIDE_IN_1X1 = True
         self.c2 = _Conv3x3(mid, mid, relu=True)
-        self.c3 = _Conv1x1(mid, cout)
+        self.c3 = _Conv1x1(mid, cout, gain=0.25)
         self.short = _Conv1x1(cin, cout, stride) if (cin != cout or stride != 1) else None
 
     def forward(self, x):
@@ -68,21 +71,21 @@ class GuideR50FPN(nn.Module):
 
     def __init__(self, out_channels=256):
         super().__init__()
-        self.register_buffer("stem_w", _kaiming((3 * 49, 64), 64 * 49))
+        self.register_buffer("stem_w", _kaiming((3 * 49, 64), 3 * 49))
         self.register_buffer("stem_b", torch.zeros(64))
         cfg = [(64, 64, 256, 3, 1), (256, 128, 512, 4, 2), (512, 256, 1024, 6, 2), (1024, 512, 2048, 3, 2)]
         self.stages = nn.ModuleList()
         for cin, mid, cout, n, stride in cfg:
             blocks = [_Bottleneck(cin, mid, cout, stride)] + [_Bottleneck(cout, mid, cout, 1) for _ in range(n - 1)]
             self.stages.append(nn.Sequential(*blocks))
-        self.lateral = nn.ModuleList([_Conv1x1(c, out_channels) for c in (256, 512, 1024, 2048)])
+        self.lateral = nn.ModuleList([_Conv1x1(c, out_channels, gain=0.1) for c in (256, 512, 1024, 2048)])   # pyramid std ~1
         self.output = nn.ModuleList([_Conv3x3(out_channels, out_channels) for _ in range(4)])
         self.register_buffer("pixel_mean", torch.tensor([103.53, 116.28, 123.675]).view(1, 3, 1, 1))
         self.eval()
 
     @torch.no_grad()
     def forward(self, images):
-        x = images - self.pixel_mean
+        x = (images - self.pixel_mean) * (1.0 / 58.0)          # harness only: unit-scale input (a trained guide absorbs the 0..255 range)
         H, W = x.shape[-2:]
         ph, pw = (32 - H % 32) % 32, (32 - W % 32) % 32
         if ph or pw:
