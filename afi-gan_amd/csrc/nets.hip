@@ -173,6 +173,39 @@ static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
     const int I = b_rc ? g.Ncols : g.Ck;                   // innermost weight dimension of w[O][3][3][I]
     return g.b_sTap == I && g.b_sRow == 9LL * I && g.a_sgn == (b_rc ? -1 : 1);
 }
+// Optional caller-owned cache of transformed weights (afi_set_wino_weight_cache): within one phase of a training step the same
+// weights meet up to ten calls (five pyramid levels x real / fake), so their U = G g G^T is computed once and found again by
+// (weight pointer, tiling, direction).  The caller invalidates it whenever weights change; one stream at a time, like the op scratch.
+namespace {
+struct WinoWeightCache {
+    float* buf = nullptr;
+    long long floats = 0, used = 0;
+    struct Entry { const float* w; int f4, mode, O, I; long long off; } e[64];
+    int n = 0;
+} g_wcache;
+// returns the slot for this transform and whether it already holds it; nullptr when there is no cache or no room left
+float* wino_wcache_slot(const float* w, int f4, int mode, int O, int I, long long need, bool& hit) {
+    hit = false;
+    if (!g_wcache.buf) return nullptr;
+    for (int i = 0; i < g_wcache.n; ++i) {
+        const WinoWeightCache::Entry& e = g_wcache.e[i];
+        if (e.w == w && e.f4 == f4 && e.mode == mode && e.O == O && e.I == I) { hit = true; return g_wcache.buf + e.off; }
+    }
+    if (g_wcache.n == 64 || g_wcache.used + need > g_wcache.floats) return nullptr;
+    g_wcache.e[g_wcache.n++] = WinoWeightCache::Entry{w, f4, mode, O, I, g_wcache.used};
+    float* slot = g_wcache.buf + g_wcache.used;
+    g_wcache.used += need;
+    return slot;
+}
+}  // namespace
+int afi_set_wino_weight_cache(float* buf, long long floats) {
+    if (floats < 0 || (floats > 0 && !buf)) return AFI_ERR_BAD_ARG;
+    g_wcache.buf = floats > 0 ? buf : nullptr;
+    g_wcache.floats = floats; g_wcache.used = 0; g_wcache.n = 0;
+    return AFI_OK;
+}
+int afi_wino_weight_cache_invalidate(void) { g_wcache.used = 0; g_wcache.n = 0; return AFI_OK; }
+
 static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st,
                     bool fwd_f4 = false) {
     const int K = g.Ck, Nc = g.Ncols;
@@ -185,11 +218,13 @@ static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_float
     float* U = ws;
     float* Vb = U + align4((long long)np * K * Nc);
     float* Mb = Vb + align4(np * Tpad * K);
+    bool have_u = false;
+    if (float* slot = wino_wcache_slot(g.B, f4, b_rc, b_rc ? K : Nc, b_rc ? Nc : K, align4((long long)np * K * Nc), have_u)) U = slot;
     if (f4) {
-        AFI_TRY(afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
+        if (!have_u) AFI_TRY(afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
         AFI_TRY(afi_launch_wino4_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
     } else {
-        AFI_TRY(afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
+        if (!have_u) AFI_TRY(afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
         AFI_TRY(afi_launch_wino_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
     }
     {   // tile-aligned shapes (every layer of the reference nets): the plain batched NT GEMM

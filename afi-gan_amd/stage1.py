@@ -224,7 +224,19 @@ class Stage1Step:
         self.losses.zero_()
         lptr = self.losses.data_ptr()
         lr_now = self.lr_at(self.iter)
+        # transformed conv weights are shared by the calls of a phase (weights only change at the two optimizer steps)
+        if os.environ.get("AFI_WINO_WCACHE", "1") != "0":
+            wcache = self._scratch("wino_wcache", self.WINO_WCACHE_FLOATS, dev)
+            call("afi_set_wino_weight_cache", C.c_void_p(wcache.data_ptr()), self.WINO_WCACHE_FLOATS)
+        try:
+            self._run_phases(nlev, lrs, hrs, lptr, lr_now, dev)
+        finally:
+            call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
+        self.iter += 1
 
+    WINO_WCACHE_FLOATS = 140 * 1024 * 1024
+
+    def _run_phases(self, nlev, lrs, hrs, lptr, lr_now, dev):
         # ---------------- D phase (stage1_trainer.py:334-381)
         self.d_opt.zero_grad()                                                       # :374
         trs = []
@@ -254,6 +266,7 @@ class Stage1Step:
             torch.cuda.current_stream().wait_stream(self._bstream)
         self._allreduce(self.d_opt)
         self.d_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :381
+        call("afi_wino_weight_cache_invalidate")                                     # D's weights moved
 
         # ---------------- G phase (:384-433)
         self.g_opt.zero_grad()                                                       # :426
@@ -281,7 +294,6 @@ class Stage1Step:
                  ops.stream_ptr())                                                   # :427
         self._allreduce(self.g_opt)
         self.g_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :433
-        self.iter += 1
 
     def metrics(self, check_finite: bool = True) -> Dict[str, float]:
         """Loss values of the last step (one device sync).  g_loss_p = 1e-3*adv + content (stage1_trainer.py:411)."""

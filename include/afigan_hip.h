@@ -236,6 +236,15 @@ int afi_normalize_pad_u8(const unsigned char* img_chw, int C, int H, int W, cons
  * shape that is split. */
 int afi_set_op_scratch(float* scratch, long long floats);
 
+/* Optional caller-owned cache for the Winograd-transformed weights of the 3x3 convs (whole-net and per-op entry points alike).
+ * Within one phase of a training step the same weights serve up to ten calls (stage1_trainer.py:336-433: five levels x real /
+ * fake); with a cache registered each (weight pointer, tiling, direction) is transformed once and re-used until
+ * afi_wino_weight_cache_invalidate() -- which the caller MUST issue whenever weight values change (optimizer step, load, broadcast).
+ * afi_set_wino_weight_cache also invalidates; floats == 0 unregisters.  One buffer per process, one stream at a time.
+ * 140 M floats hold every transform of the reference's G and D. */
+int afi_set_wino_weight_cache(float* buf, long long floats);
+int afi_wino_weight_cache_invalidate(void);
+
 /* ------------------------------------------------------------------ measurement support (bench.py)
  * When enabled, every MFMA GEMM launch is bracketed by two hipEvents recorded on the launch stream.
  * afi_profile_get(kind, out): out[0] launches, out[1] total ms, out[2] total algorithmic FLOP of that kernel since
