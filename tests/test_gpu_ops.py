@@ -299,3 +299,29 @@ def test_conv3x3_winograd_fwd_dgrad(amd, N, Cin, Cout, H, W):
     old = _rand(Cout, Cin, 3, 3, seed=7)
     dw0 = ops.ohwi(old.cuda()).clone(memory_format=torch.preserve_format)
     _close(ops.conv3x3_wino_wgrad(_pm(dy), _pm(x), dw=dw0, alpha=0.5), old + 0.5 * wg.grad, tol=1e-4, what="wino wgrad accumulate")
+
+
+def test_wino_weight_cache_semantics(amd):
+    """afi_set_wino_weight_cache: a transform is computed on first use and re-used until the caller invalidates -- a weight
+    change WITHOUT an invalidation is (by contract) not seen, WITH one it is; unregistering restores the per-call transform."""
+    import ctypes as C
+    from afigan_amd import _lib
+    ops = amd.ops
+    x, w = _rand(1, 128, 40, 44, seed=11), _rand(128, 128, 3, 3, seed=12) * 0.1
+    wd = ops.ohwi(w.cuda()).clone(memory_format=torch.preserve_format)      # one device buffer = one cache key
+    ref1 = F.conv2d(x, w, None, 1, 1)
+    cache = torch.empty(8 * 1024 * 1024, device="cuda", dtype=torch.float32)
+    _lib.call("afi_set_wino_weight_cache", C.c_void_p(cache.data_ptr()), cache.numel())
+    try:
+        _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="first use fills the cache")
+        _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="second use hits it")
+        wd.mul_(2.0)                                                        # weights move, cache not told
+        _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="stale by contract until invalidated")
+        _lib.call("afi_wino_weight_cache_invalidate")
+        _close(ops.conv3x3_wino_fwd(_pm(x), wd), 2.0 * ref1, tol=1e-4, what="after invalidation")
+        _close(ops.conv3x3_wino_dgrad(_pm(ref1), wd), torch.autograd.grad(F.conv2d(xg := x.clone().requires_grad_(True), 2.0 * w, None, 1, 1), xg, ref1)[0],
+               tol=1e-4, what="the data-gradient transform has its own entry")
+    finally:
+        _lib.call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
+    wd.mul_(0.5)
+    _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="unregistered: transformed per call")
