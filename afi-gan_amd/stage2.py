@@ -8,7 +8,9 @@ The reference's stage-2 step (afigan/engine/stage2_trainer.py:279-384) is a dete
 This module provides exactly those two pieces on the HIP kernels; the detector itself (detectron2 glue) stays where it is.
 The nearest x0.5 down-sampling is a strided VIEW of the guide feature (even rows / columns): the kernels take strides, no copy.
 """
+import contextlib
 import ctypes as C
+import os
 from typing import Dict, Sequence
 
 import torch
@@ -50,6 +52,21 @@ def l1_loss_common(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     return _L1CropFn.apply(a, b)
 
 
+@contextlib.contextmanager
+def _wino_weight_cache(helper, device):
+    """Transformed conv weights shared by the calls of one phase (include/afigan_hip.h: afi_set_wino_weight_cache); registered for
+    the duration of the phase only, during which D's weights do not change."""
+    if os.environ.get("AFI_WINO_WCACHE", "1") == "0":
+        yield
+        return
+    buf = helper._scratch("wino_wcache", Stage1Step.WINO_WCACHE_FLOATS, device)
+    call("afi_set_wino_weight_cache", C.c_void_p(buf.data_ptr()), Stage1Step.WINO_WCACHE_FLOATS)
+    try:
+        yield
+    finally:
+        call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
+
+
 class Stage2Adversarial:
     """D step + generator-side loss terms of one stage-2 iteration for a Discriminator living on this GPU."""
 
@@ -87,16 +104,17 @@ class Stage2Adversarial:
             self.losses, self._names = torch.zeros(len(names), device=dev), names
         self.losses.zero_()
         self.opt.zero_grad()
-        for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
-            real = ops.pixel_major(nearest_half(ops.pixel_major(g.detach())))
-            fake = ops.pixel_major(f.detach())
-            hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
-            for x, target in ((real[:, :, :hh, :ww], 1.0), (fake[:, :, :hh, :ww], 0.0)):
-                logits, dws = h._d_forward(x, "d_ws")
-                dz = h._scratch("dlogits", logits.numel(), dev)
-                call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * hh * ww, target, 1.0,
-                     C.c_void_p(self.losses.data_ptr() + 4 * i), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
-                h._d_backward(x, dws, dz)
+        with _wino_weight_cache(h, dev):                   # D's weights are fixed until the optimizer step below
+            for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
+                real = ops.pixel_major(nearest_half(ops.pixel_major(g.detach())))
+                fake = ops.pixel_major(f.detach())
+                hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
+                for x, target in ((real[:, :, :hh, :ww], 1.0), (fake[:, :, :hh, :ww], 0.0)):
+                    logits, dws = h._d_forward(x, "d_ws")
+                    dz = h._scratch("dlogits", logits.numel(), dev)
+                    call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * hh * ww, target, 1.0,
+                         C.c_void_p(self.losses.data_ptr() + 4 * i), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
+                    h._d_backward(x, dws, dz)
         if self.distributed:
             allreduce_sum_(self.opt.flat_grad, self.pg)
         lr = warmup_multistep_lr(self.base_lr, self.iter, *self.sched)
@@ -107,18 +125,19 @@ class Stage2Adversarial:
         """stage2_trainer.py:344-364: {g_loss_p{lv}: 1e-3 * adv + content}; `content` carries gradient into fpn_feats."""
         h = self._helper
         out = {}
-        for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
-            lv = self.first_level + i
-            real = nearest_half(ops.pixel_major(g.detach()))
-            fake = ops.pixel_major(f.detach())
-            hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
-            adv = torch.zeros(1, device=f.device)
-            logits, _ = h._d_forward(fake[:, :, :hh, :ww], "d_ws", backward_follows=False)   # fake first, then real (:350-354)
-            call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), f.shape[0] * hh * ww, 1.0, 1.0, C.c_void_p(adv.data_ptr()),
-                 0.0, C.c_void_p(None), ops.stream_ptr())
-            h._d_forward(real[:, :, :hh, :ww], "d_ws", backward_follows=False)           # only its BN side effects matter (Q2)
-            content = l1_loss_common(f, real)
-            out[f"g_loss_p{lv}"] = adv.reshape(()) * 1e-3 + content
+        with _wino_weight_cache(h, fpn_feats[0].device):
+            for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
+                lv = self.first_level + i
+                real = nearest_half(ops.pixel_major(g.detach()))
+                fake = ops.pixel_major(f.detach())
+                hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
+                adv = torch.zeros(1, device=f.device)
+                logits, _ = h._d_forward(fake[:, :, :hh, :ww], "d_ws", backward_follows=False)   # fake first, then real (:350-354)
+                call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), f.shape[0] * hh * ww, 1.0, 1.0, C.c_void_p(adv.data_ptr()),
+                     0.0, C.c_void_p(None), ops.stream_ptr())
+                h._d_forward(real[:, :, :hh, :ww], "d_ws", backward_follows=False)           # only its BN side effects matter (Q2)
+                content = l1_loss_common(f, real)
+                out[f"g_loss_p{lv}"] = adv.reshape(()) * 1e-3 + content
         return out
 
     def d_metrics(self) -> Dict[str, float]:
