@@ -174,6 +174,14 @@ class BiFPN_AFIGAN(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ forward (inference)
     def forward(self, x):
+        # the interpolator runs several times on one set of weights: their transformed / packed forms are computed once
+        first = next(iter(x.values())) if isinstance(x, dict) else x
+        if not first.is_cuda:
+            return self._forward_impl(x)
+        with ops.weight_transform_cache(first.device):
+            return self._forward_impl(x)
+
+    def _forward_impl(self, x):
         if self.training:
             raise _lib.AfiError("BiFPN_AFIGAN is an inference-only path in this build (the reference ships it in an inference config only): "
                                 "call .eval() first")

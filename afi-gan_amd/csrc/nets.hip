@@ -642,7 +642,16 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
     AfiView t = dense_view(ws + l.o_t, H, W, C), a7 = dense_view(ws + l.o_a7, H, W, C);
     AfiView u = dense_view(ws + l.o_u, 2 * H, 2 * W, C);
 
-    AFI_TRY(afi_launch_convT_pack(prm->wT, wp, C, C, st));
+    {   // packed conv-transpose weight: from the caller's weight cache when one is registered (BiFPN: 28 calls on one set of weights)
+        bool hit = false;
+        const long long wp_floats = 36LL * C * C;
+        if (float* slot = wino_wcache_slot(prm->wT, /*tag: convT pack*/ 2, 0, C, C, align4(wp_floats), hit)) {
+            if (!hit) AFI_TRY(afi_launch_convT_pack(prm->wT, slot, C, C, st));
+            if (hipMemcpyAsync(wp, slot, sizeof(float) * wp_floats, hipMemcpyDeviceToDevice, st) != hipSuccess) return AFI_ERR_LAUNCH;
+        } else {
+            AFI_TRY(afi_launch_convT_pack(prm->wT, wp, C, C, st));
+        }
+    }
     {   // head conv + LReLU (generator_rdb.py:91-93) -> channels [0,C) of RDB 0's dense buffer
         AfiPixGemm g = conv_fwd_desc(x, N, H, W, C, prm->w0, prm->b0, C, buf(0));
         g.lrelu = 1;

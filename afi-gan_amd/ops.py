@@ -4,7 +4,9 @@ All tensors are logically NCHW (what detectron2 hands around) but 
 ``stride(1) == 1`` (torch.channels_last, or any crop / channel slice of such a tensor).  ``pixel_major`` converts an
 NCHW-contiguous tensor with the library's own transpose kernel.
 """
+import contextlib
 import ctypes as C
+import os
 
 import torch
 
@@ -96,6 +98,28 @@ def _dense(t):
             return False
         expect *= size
     return True
+
+
+_WCACHE = {}
+
+
+@contextlib.contextmanager
+def weight_transform_cache(device, floats=32 * 1024 * 1024):
+    """Register a buffer for transformed / packed conv weights (afi_set_wino_weight_cache) for the duration of a block in which
+    weight VALUES do not change -- e.g. one backbone forward, where the interpolator runs 3 (FPN) to 28 (BiFPN) times on one set
+    of weights.  Not re-entrant; one stream at a time (include/afigan_hip.h)."""
+    if os.environ.get("AFI_WINO_WCACHE", "1") == "0":
+        yield
+        return
+    key = (torch.device(device).index, floats)
+    buf = _WCACHE.get(key)
+    if buf is None:
+        buf = _WCACHE[key] = torch.empty(floats, device=device, dtype=torch.float32)
+    call("afi_set_wino_weight_cache", _p(buf), floats)
+    try:
+        yield
+    finally:
+        call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
 
 
 def zeros_like_many(tensors, need):

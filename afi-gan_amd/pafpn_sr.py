@@ -114,6 +114,14 @@ class PAFPN_AFIGAN(nn.Module):
         return self._size_divisibility
 
     def forward(self, x):
+        # the interpolator runs several times on one set of weights: their transformed / packed forms are computed once
+        first = next(iter(x.values())) if isinstance(x, dict) else x
+        if not first.is_cuda:
+            return self._forward_impl(x)
+        with ops.weight_transform_cache(first.device):
+            return self._forward_impl(x)
+
+    def _forward_impl(self, x):
         bottom_up_features = self.bottom_up(x)
         feats = [bottom_up_features[f] for f in self.in_features[::-1]]
         fs = 0.5 if self._fuse_type == "avg" else 1.0
