@@ -83,6 +83,8 @@ SIGNATURES = {
     "afi_fuse_swish_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_resize_bilinear_u8_ws_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "afi_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _ll, _vp]),
+    "afi_set_wino_wgrad_accum": (_i, [_vp, _ll]),
+    "afi_wino_wgrad_flush": (_i, [_vp]),
     "afi_set_wino_weight_cache": (_i, [_vp, _ll]),
     "afi_wino_weight_cache_invalidate": (_i, []),
     "afi_dual_scale_u8_ws_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),

@@ -253,6 +253,52 @@ static int wino_conv(int mode, AfiView in, int N, int H, int W, int K, const flo
     return wino_run(g, mode, ws, ws_floats, part, part_floats, st, fwd_f4);
 }
 
+// Optional caller-owned accumulator for the transform-domain weight gradients (afi_set_wino_wgrad_accum): dW = A'^T dU A' is linear
+// in dU, so the calls of one phase that add into the same dW (five levels x real / fake) can sum their dU and transform ONCE, at
+// afi_wino_wgrad_flush(), instead of zero-filling a dU and transforming it per call.
+namespace {
+struct WinoWgradAccum {
+    float* buf = nullptr;
+    long long floats = 0, used = 0;
+    struct Entry { float* dw; int f4, O, I; float alpha; long long off; } e[64];
+    int n = 0;
+} g_wgacc;
+float* wino_wgacc_slot(float* dw, int f4, int O, int I, float alpha, long long need, bool& fresh) {
+    fresh = false;
+    if (!g_wgacc.buf) { fresh = true; return nullptr; }
+    for (int i = 0; i < g_wgacc.n; ++i) {
+        const WinoWgradAccum::Entry& e = g_wgacc.e[i];
+        if (e.dw == dw && e.f4 == f4 && e.O == O && e.I == I) {
+            if (e.alpha == alpha) return g_wgacc.buf + e.off;
+            fresh = true;                                  // another scale for the same target: this call goes the per-call way
+            return nullptr;
+        }
+    }
+    if (g_wgacc.n == 64 || g_wgacc.used + need > g_wgacc.floats) { fresh = true; return nullptr; }
+    g_wgacc.e[g_wgacc.n++] = WinoWgradAccum::Entry{dw, f4, O, I, alpha, g_wgacc.used};
+    float* slot = g_wgacc.buf + g_wgacc.used;
+    g_wgacc.used += need;
+    fresh = true;
+    return slot;
+}
+}  // namespace
+int afi_wino_wgrad_flush(void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = AFI_OK;
+    for (int i = 0; i < g_wgacc.n && rc == AFI_OK; ++i) {
+        const WinoWgradAccum::Entry& e = g_wgacc.e[i];
+        rc = e.f4 ? afi_launch_wino4_dw(g_wgacc.buf + e.off, e.dw, e.O, e.I, e.alpha, st) : afi_launch_wino_dw(g_wgacc.buf + e.off, e.dw, e.O, e.I, e.alpha, st);
+    }
+    g_wgacc.n = 0; g_wgacc.used = 0;
+    return rc;
+}
+int afi_set_wino_wgrad_accum(float* buf, long long floats) {
+    if (floats < 0 || (floats > 0 && !buf) || g_wgacc.n != 0) return AFI_ERR_BAD_ARG;      // pending sums must be flushed first
+    g_wgacc.buf = floats > 0 ? buf : nullptr;
+    g_wgacc.floats = floats; g_wgacc.used = 0;
+    return AFI_OK;
+}
+
 // weight gradient in Winograd F(3x3,2x2) form: dW[Cout][3][3][Cin] += alpha * sum_pix dy (x) x.  Same workspace layout as wino_conv
 // with K = Cin, Nc = Cout:  [dU 16*Cin*Cout][V 16*Tpad*Cin][Q 16*Tpad*Cout].
 static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws, long long ws_floats,
@@ -265,7 +311,9 @@ static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int 
     float* dU = ws;
     float* Vb = dU + align4((long long)np * Cin * Cout);
     float* Qb = Vb + align4(np * Tpad * Cin);
-    if (hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
+    bool fresh = true, accum = false;
+    if (float* slot = wino_wgacc_slot(dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
+    if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
     if (f4) {
         AFI_TRY(afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st));
         AFI_TRY(afi_launch_wino4_dy(dy, N, H, W, Cout, Tpad, Qb, st));
@@ -276,7 +324,10 @@ static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int 
     {   // tile-aligned shapes: the plain batched TN GEMM
         static const int fast = getenv("AFI_GEMM_TN") ? atoi(getenv("AFI_GEMM_TN")) : 1;
         const int rc = fast ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st) : AFI_ERR_UNSUPPORTED;
-        if (rc == AFI_OK) return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
+        if (rc == AFI_OK) {
+            if (accum) return AFI_OK;                      // transformed at afi_wino_wgrad_flush()
+            return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
+        }
         if (rc != AFI_ERR_UNSUPPORTED) return rc;
     }
     AfiWgradGemm g;
@@ -288,6 +339,7 @@ static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int 
     g.DW = dU; g.dw_sRow = Cin; g.dw_sTap = (long long)Cout * Cin;
     g.alpha = 1.f; g.splitK = 0;
     AFI_TRY(afi_launch_wgrad_gemm(g, st));
+    if (accum) return AFI_OK;
     return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
 }
 

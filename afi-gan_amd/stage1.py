@@ -228,13 +228,20 @@ class Stage1Step:
         if os.environ.get("AFI_WINO_WCACHE", "1") != "0":
             wcache = self._scratch("wino_wcache", self.WINO_WCACHE_FLOATS, dev)
             call("afi_set_wino_weight_cache", C.c_void_p(wcache.data_ptr()), self.WINO_WCACHE_FLOATS)
+            # ... and the transform-domain weight-gradient sums of a phase are transformed back once, before its all-reduce
+            if os.environ.get("AFI_WINO_WGACC", "1") != "0":
+                wgacc = self._scratch("wino_wgacc", self.WINO_WGACC_FLOATS, dev)
+                call("afi_set_wino_wgrad_accum", C.c_void_p(wgacc.data_ptr()), self.WINO_WGACC_FLOATS)
         try:
             self._run_phases(nlev, lrs, hrs, lptr, lr_now, dev)
         finally:
+            call("afi_wino_wgrad_flush", ops.stream_ptr())       # (nothing pending unless a phase raised)
+            call("afi_set_wino_wgrad_accum", C.c_void_p(None), 0)
             call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
         self.iter += 1
 
     WINO_WCACHE_FLOATS = 140 * 1024 * 1024
+    WINO_WGACC_FLOATS = 100 * 1024 * 1024
 
     def _run_phases(self, nlev, lrs, hrs, lptr, lr_now, dev):
         # ---------------- D phase (stage1_trainer.py:334-381)
@@ -264,6 +271,7 @@ class Stage1Step:
                     self._d_backward(x, dws, dz)                                     # :375 (accumulates into the flat grads)
         if self.overlap_d and self._bstream is not None:
             torch.cuda.current_stream().wait_stream(self._bstream)
+        call("afi_wino_wgrad_flush", ops.stream_ptr())
         self._allreduce(self.d_opt)
         self.d_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :381
         call("afi_wino_weight_cache_invalidate")                                     # D's weights moved
@@ -292,6 +300,7 @@ class Stage1Step:
             call("afi_generator_bwd", C.byref(self._gprm), C.byref(self._ggrad), ops.view_of(lrt), lrt.shape[0], lrt.shape[2], lrt.shape[3],
                  C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n,
                  ops.stream_ptr())                                                   # :427
+        call("afi_wino_wgrad_flush", ops.stream_ptr())
         self._allreduce(self.g_opt)
         self.g_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :433
 

@@ -245,6 +245,14 @@ int afi_set_op_scratch(float* scratch, long long floats);
 int afi_set_wino_weight_cache(float* buf, long long floats);
 int afi_wino_weight_cache_invalidate(void);
 
+/* Optional caller-owned accumulator for the Winograd weight gradients.  While one is registered, every Winograd weight-gradient
+ * call adds its transform-domain sum dU into a slot keyed by its dW target instead of zero-filling and transforming per call; the
+ * caller MUST call afi_wino_wgrad_flush(stream) -- dW += alpha * A'^T dU A' for every slot, then the slots are released -- before
+ * it reads the gradients (all-reduce, optimizer step), on a stream ordered after the calls that accumulated.  Registering or
+ * unregistering with sums pending is refused (AFI_ERR_BAD_ARG).  100 M floats hold every slot of the reference's G and D. */
+int afi_set_wino_wgrad_accum(float* buf, long long floats);
+int afi_wino_wgrad_flush(void* stream);
+
 /* ------------------------------------------------------------------ measurement support (bench.py)
  * When enabled, every MFMA GEMM launch is bracketed by two hipEvents recorded on the launch stream.
  * afi_profile_get(kind, out): out[0] launches, out[1] total ms, out[2] total algorithmic FLOP of that kernel since

@@ -325,3 +325,31 @@ def test_wino_weight_cache_semantics(amd):
         _lib.call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
     wd.mul_(0.5)
     _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="unregistered: transformed per call")
+
+
+def test_wino_wgrad_accumulator_semantics(amd):
+    """afi_set_wino_wgrad_accum: calls adding into one dW sum their transform-domain gradients; dW is untouched until
+    afi_wino_wgrad_flush, after which it holds the same total as per-call transforms (both tilings)."""
+    import ctypes as C
+    from afigan_amd import _lib
+    ops = amd.ops
+    for (N, Ci, Co, H, W) in [(2, 128, 256, 50, 84), (2, 256, 128, 100, 168)]:           # F(3x3,2x2) and F(3x3,4x4)
+        xs = [_rand(N, Ci, H, W, seed=20 + i) for i in range(3)]
+        dys = [_rand(N, Co, H, W, seed=30 + i) for i in range(3)]
+        w = torch.zeros(Co, Ci, 3, 3, requires_grad=True)
+        ref = sum(torch.autograd.grad(F.conv2d(x, w, None, 1, 1), w, dy)[0] for x, dy in zip(xs, dys))
+        acc = torch.empty(16 * 1024 * 1024, device="cuda", dtype=torch.float32)
+        dw = ops.new_ohwi(Co, Ci, 3, 3, "cuda")
+        _lib.call("afi_set_wino_wgrad_accum", C.c_void_p(acc.data_ptr()), acc.numel())
+        try:
+            for x, dy in zip(xs, dys):
+                ops.conv3x3_wino_wgrad(_pm(dy), _pm(x), dw=dw)
+            assert float(dw.abs().max()) == 0.0                                           # nothing lands before the flush
+            with pytest.raises(_lib.AfiError):                                            # pending sums: refuse to drop them
+                _lib.call("afi_set_wino_wgrad_accum", C.c_void_p(None), 0)
+        finally:
+            _lib.call("afi_wino_wgrad_flush", ops.stream_ptr())
+            _lib.call("afi_set_wino_wgrad_accum", C.c_void_p(None), 0)
+        _close(dw, ref, tol=1e-4, what="accumulated wgrad after flush")
+        ops.conv3x3_wino_wgrad(_pm(dys[0]), _pm(xs[0]), dw=dw)                            # unregistered again: per call, dw +=
+        _close(dw, ref + torch.autograd.grad(F.conv2d(xs[0], w, None, 1, 1), w, dys[0])[0], tol=1e-4, what="per-call path after unregistering")

@@ -209,3 +209,31 @@ def test_stage1_data_parallel_two_ranks_one_gpu(amd, tmp_path):
         got = r0["g_sum"][k]
         assert ((got - want).abs().max() / want.abs().max()).item() < 1e-4, k
         assert torch.equal(r0["g_sum"][k], r1["g_sum"][k]), k
+
+
+def test_stage1_phase_caches_do_not_change_the_gradients(amd, monkeypatch):
+    """The per-phase weight-transform cache and the transform-domain weight-gradient accumulator (afi_set_wino_weight_cache /
+    afi_set_wino_wgrad_accum + afi_wino_wgrad_flush) are pure re-orderings: one step on a mid-size two-level pyramid (both
+    Winograd tilings active: 2x64x96 -> F(4x4), 2x32x48 -> F(2x2)) yields the same flat gradient buffers with and without them,
+    and two steps (weights moved in between: the caches must have been invalidated) the same losses."""
+    def run(wcache, wgacc):
+        monkeypatch.setenv("AFI_WINO_WCACHE", wcache)
+        monkeypatch.setenv("AFI_WINO_WGACC", wgacc)
+        torch.manual_seed(0)
+        G = amd.Generator(n_residual_dense_blocks=3).cuda()
+        D = amd.Discriminator().cuda()
+        step = amd.Stage1Step(G, D, base_lr=0.05, warmup_iters=0)
+        gen = torch.Generator(device="cuda").manual_seed(3)
+        hrs = [torch.randn((2, 256, 64, 96), device="cuda", generator=gen), torch.randn((2, 256, 32, 48), device="cuda", generator=gen)]
+        lrs = [torch.randn((2, 256, 33, 49), device="cuda", generator=gen), torch.randn((2, 256, 16, 24), device="cuda", generator=gen)]
+        step.run_step(lrs, hrs)
+        grads = (step.d_opt.flat_grad.detach().clone(), step.g_opt.flat_grad.detach().clone())
+        step.run_step(lrs, hrs)
+        return grads, step.metrics()
+    (d0, g0), m0 = run("0", "0")
+    for mode in (("1", "0"), ("1", "1")):
+        (d1, g1), m1 = run(*mode)
+        assert float((d1 - d0).norm() / d0.norm()) < 1e-5, mode       # fp32 atomics reorder sums; nothing else may differ
+        assert float((g1 - g0).norm() / g0.norm()) < 1e-5, mode
+        for k, v in m0.items():
+            assert abs(m1[k] - v) <= 2e-4 * abs(v) + 1e-6, (mode, k, m1[k], v)
