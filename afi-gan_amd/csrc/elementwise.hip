@@ -187,7 +187,9 @@ __device__ __forceinline__ bool afi_chunk_sums(const float* __restrict__ partial
 // BatchNorm statistics finalize: mean / invstd for this call + running-stat update (momentum 0.1, unbiased var)
 __global__ void afi_bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, const float* __restrict__ x0, long long P, int C,
                                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
-                                             float* __restrict__ running_mean, float* __restrict__ running_var) {
+                                             float* __restrict__ running_mean, float* __restrict__ running_var,
+                                             long long* __restrict__ num_batches_tracked) {
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;     // torch BatchNorm2d train mode
     int c; float s0, s1;
     if (!afi_chunk_sums(partial, chunks, C, true, c, s0, s1)) return;
     const float inv_n = 1.f / (float)P;
@@ -308,13 +310,13 @@ static unsigned afi_ew_grid(long long work_items) {
 }
 
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out,
-                        float* running_mean, float* running_var, float* scratch, hipStream_t st) {
+                        float* running_mean, float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked) {
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     hipLaunchKernelGGL((afi_colred_partial_kernel<0>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, (long long)C, rpc, scratch);
     hipLaunchKernelGGL(afi_bn_stats_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, x, P, C, mean, invstd,
-                       var_out, running_mean, running_var);
+                       var_out, running_mean, running_var, num_batches_tracked);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,

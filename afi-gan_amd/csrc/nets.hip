@@ -19,7 +19,7 @@ int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hi
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
 int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st);
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
-                        float* running_var, float* scratch, hipStream_t st);
+                        float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked = nullptr);
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                               long long P, int C, hipStream_t st);
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
@@ -940,8 +940,8 @@ int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, in
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
         if (training) {
-            AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st));
-            if (prm->num_batches_tracked[n]) AFI_TRY(afi_launch_inc_i64(prm->num_batches_tracked[n], st));
+            AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st,
+                                        prm->num_batches_tracked[n]));      // the counter ticks inside the statistics finalizer
             AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
         } else {
             AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
