@@ -56,8 +56,9 @@ class _DiscriminatorFn(torch.autograd.Function):
         ws = torch.empty(ws_floats, device=x.device, dtype=torch.float32)
         logits = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
         # 0 eval; 1 train mode with a backward to come; 2 train-mode statistics only (no input of this call needs a gradient)
-        # (needs_input_grad is all-False under no_grad; grad mode itself is always off inside Function.forward)
-        mode = 0 if not net.training else (1 if any(ctx.needs_input_grad) else 2)
+        # net._grad_mode: torch.is_grad_enabled() as the module's forward saw it (inside Function.forward it is always off, and
+        # needs_input_grad still reports requires_grad under no_grad)
+        mode = 0 if not net.training else (1 if (net._grad_mode and any(ctx.needs_input_grad)) else 2)
         call("afi_discriminator_fwd", C.byref(prm), ops.view_of(xp), N, H, W, C.c_void_p(logits.data_ptr()), mode,
              C.c_void_p(ws.data_ptr()), ws_floats, ops.stream_ptr())
         ctx.net, ctx.shape, ctx.x_needs_grad, ctx.was_training = net, (N, H, W), x.requires_grad, net.training
@@ -144,6 +145,7 @@ class _PatchDiscriminatorNet(nn.Module):
         ops._check_cuda(feature)
         if feature.dim() != 4 or feature.shape[1] != self.F[0]:
             raise _lib.AfiError(f"expected [N,{self.F[0]},H,W], got {tuple(feature.shape)}")
+        self._grad_mode = torch.is_grad_enabled()
         return _DiscriminatorFn.apply(feature, self, *self._ordered_params())
 
 
