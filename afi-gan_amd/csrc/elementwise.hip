@@ -230,7 +230,7 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
         for (; i + 3 * stride < total4; i += 4 * stride) {
             f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(x + (i + u * stride) * 4);
+            for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load((const f32x4*)(x + (i + u * stride) * 4));
 #pragma unroll
             for (int u = 0; u < 4; ++u) *(f32x4*)(y + (i + u * stride) * 4) = apply(v[u], mu, is, ga, be);
         }
@@ -271,8 +271,8 @@ __global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float
         const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c), ga = *(const f32x4*)(gamma + c);
         const f32x4 sg = *(const f32x4*)(sums + c), sgx = *(const f32x4*)(sums + C + c);
         for (; i + stride < total4; i += 2 * stride) {
-            const f32x4 g0 = *(const f32x4*)(g + i * 4), x0 = *(const f32x4*)(x + i * 4);
-            const f32x4 g1 = *(const f32x4*)(g + (i + stride) * 4), x1 = *(const f32x4*)(x + (i + stride) * 4);
+            const f32x4 g0 = __builtin_nontemporal_load((const f32x4*)(g + i * 4)), x0 = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
+            const f32x4 g1 = __builtin_nontemporal_load((const f32x4*)(g + (i + stride) * 4)), x1 = __builtin_nontemporal_load((const f32x4*)(x + (i + stride) * 4));
             *(f32x4*)(dx + i * 4) = apply(g0, x0, mu, is, ga, sg, sgx);
             *(f32x4*)(dx + (i + stride) * 4) = apply(g1, x1, mu, is, ga, sg, sgx);
         }

