@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int yy = 4 * ty + i, xx = 4 * tx + j;
-                v[i] = (yy < H && xx < W) ? *(const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW) : zero;
+                v[i] = (yy < H && xx < W) ? __builtin_nontemporal_load((const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW)) : zero;
             }
             a[0][j] = 0.25f * v[0];
             a[1][j] = (-1.f / 6.f) * (v[0] + v[1] + v[2] + v[3]);
