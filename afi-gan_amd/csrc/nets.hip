@@ -36,14 +36,14 @@ int afi_launch_dwconv3x3(AfiView x, int N, int H, int W, int C, const float* w, 
 int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out, hipStream_t st);
 int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st);
 int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
-int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st);
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0);
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
-int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st);
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0);
 int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
-int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st);
+int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0);
 int afi_launch_wino4_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
-int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st);
+int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0);
 int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
 int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, int C, const float* bias, float alpha, AfiView out, AfiView z,
                            hipStream_t st);
@@ -167,7 +167,13 @@ static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
 // gather, dense [rows][3][3][K-or-N] weights, >= 128 channels on both sides, >= 1024 pixels.
 static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
     static const int on = getenv("AFI_WINO_G") ? atoi(getenv("AFI_WINO_G")) : 1;
-    if (!on || g.ntaps != 9 || g.nKphase != 1 || g.a_up != 1 || g.gtap || g.r2_post) return false;
+    if (!on || g.ntaps != 9 || g.gtap || g.r2_post) return false;
+    // plain 3x3 conv / its data gradient, or the data gradient of the 4-phase conv-transpose (its A operand is the hi-res
+    // gradient read as four phase views: each phase is one channel block of a 3x3 data gradient with 4*Cout channels)
+    const bool phases = g.nKphase == 4 && g.a_up == 2 && b_rc;
+    if (!phases && (g.nKphase != 1 || g.a_up != 1)) return false;
+    static const int convt = getenv("AFI_WINO_CONVT") ? atoi(getenv("AFI_WINO_CONVT")) : 1;
+    if (phases && !convt) return false;
     if (g.Ck < 128 || g.Ncols < 128 || (g.Ck & 3) || (g.Ncols & 3)) return false;
     if ((long long)g.N * g.H * g.W < 1024) return false;
     const int I = b_rc ? g.Ncols : g.Ck;                   // innermost weight dimension of w[O][3][3][I]
@@ -208,7 +214,8 @@ int afi_wino_weight_cache_invalidate(void) { g_wcache.used = 0; g_wcache.n = 0; 
 
 static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st,
                     bool fwd_f4 = false) {
-    const int K = g.Ck, Nc = g.Ncols;
+    const int nph = g.nKphase;                             // 1, or 4 phase views of a pixel-shuffled A (conv-transpose data gradient)
+    const int K = g.Ck * nph, Nc = g.Ncols;
     if (ws_floats < wino_ws_floats(g.N, g.H, g.W, K, Nc)) return AFI_ERR_WORKSPACE;
     // data gradients take F(4x4,3x3) (their error does not decide a LeakyReLU mask); forwards stay on F(2x2,3x3)
     // fwd_f4: a forward whose activations feed no backward pass (its masks decide no gradient) may take F(4x4) too
@@ -220,12 +227,13 @@ static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_float
     float* Mb = Vb + align4(np * Tpad * K);
     bool have_u = false;
     if (float* slot = wino_wcache_slot(g.B, f4, b_rc, b_rc ? K : Nc, b_rc ? Nc : K, align4((long long)np * K * Nc), have_u)) U = slot;
-    if (f4) {
-        if (!have_u) AFI_TRY(afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
-        AFI_TRY(afi_launch_wino4_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
-    } else {
-        if (!have_u) AFI_TRY(afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
-        AFI_TRY(afi_launch_wino_input(g.A, g.N, g.H, g.W, K, Tpad, Vb, st));
+    if (!have_u) AFI_TRY(f4 ? afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st)
+                            : afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
+    for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
+        AfiView a = g.A;
+        if (nph == 4) { a.p += (ph >> 1) * g.A.sH + (ph & 1) * g.A.sW; a.sH *= 2; a.sW *= 2; }
+        AFI_TRY(f4 ? afi_launch_wino4_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K)
+                   : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K));
     }
     {   // tile-aligned shapes (every layer of the reference nets): the plain batched NT GEMM
         static const int fast = getenv("AFI_GEMM_NT") ? atoi(getenv("AFI_GEMM_NT")) : 1;
@@ -301,8 +309,11 @@ int afi_set_wino_wgrad_accum(float* buf, long long floats) {
 
 // weight gradient in Winograd F(3x3,2x2) form: dW[Cout][3][3][Cin] += alpha * sum_pix dy (x) x.  Same workspace layout as wino_conv
 // with K = Cin, Nc = Cout:  [dU 16*Cin*Cout][V 16*Tpad*Cin][Q 16*Tpad*Cout].
+// dy_phases = 4: dy is the hi-res gradient of a 4-phase conv-transpose; its phase views fill the four channel blocks of Q and
+// dw is the packed weight gradient [4*CoutPhase][3][3][Cin] (Cout = 4*CoutPhase).  accumulate = false keeps the call out of the
+// phase accumulator (its dw is a per-call scratch that is unpacked right away).
 static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws, long long ws_floats,
-                      hipStream_t st) {
+                      hipStream_t st, int dy_phases = 1, bool accumulate = true) {
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
     const bool f4 = wino_f4() && (long long)N * H * W >= 8192;   // F(3x3,4x4): 36 transform points over 4x4 blocks of dY
@@ -312,14 +323,15 @@ static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int 
     float* Vb = dU + align4((long long)np * Cin * Cout);
     float* Qb = Vb + align4(np * Tpad * Cin);
     bool fresh = true, accum = false;
-    if (float* slot = wino_wgacc_slot(dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
+    if (accumulate)
+        if (float* slot = wino_wgacc_slot(dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
     if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
-    if (f4) {
-        AFI_TRY(afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st));
-        AFI_TRY(afi_launch_wino4_dy(dy, N, H, W, Cout, Tpad, Qb, st));
-    } else {
-        AFI_TRY(afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st));
-        AFI_TRY(afi_launch_wino_dy(dy, N, H, W, Cout, Tpad, Qb, st));
+    AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st) : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st));
+    const int cph = Cout / dy_phases;
+    for (int ph = 0; ph < dy_phases; ++ph) {
+        AfiView d = dy;
+        if (dy_phases == 4) { d.p += (ph >> 1) * dy.sH + (ph & 1) * dy.sW; d.sH *= 2; d.sW *= 2; }
+        AFI_TRY(f4 ? afi_launch_wino4_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout) : afi_launch_wino_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout));
     }
     {   // tile-aligned shapes: the plain batched TN GEMM
         static const int fast = getenv("AFI_GEMM_TN") ? atoi(getenv("AFI_GEMM_TN")) : 1;
@@ -797,7 +809,12 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     fk.after_main();                                       // dU is complete
     if (gr->wT) {
         if (hipMemsetAsync(dwp, 0, sizeof(float) * 36LL * C * C, sd) != hipSuccess) return AFI_ERR_LAUNCH;
-        AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));
+        static const int convt = getenv("AFI_WINO_CONVT") ? atoi(getenv("AFI_WINO_CONVT")) : 1;
+        if (convt && s.n_wino > 0 && C >= 128 && P >= 1024) {    // the four phases as channel blocks of one Winograd weight gradient
+            AFI_TRY(wino_wgrad(dU, a7, N, H, W, 4 * C, C, dwp, 1.f, scratch + s.o_wino2, s.n_wino, sd, /*dy_phases=*/4, /*accumulate=*/false));
+        } else {
+            AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));
+        }
         AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd));
     }
     if (gr->bT) AFI_TRY(afi_launch_colsum_accum(dU.p, 4 * P, C, C, 1.f, gr->bT, red, sd));

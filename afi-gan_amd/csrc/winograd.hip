@@ -66,14 +66,14 @@ int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hip
 // ---------------------------------------------------------------- input: X (view, [N][H][W][C]) -> V [16][Tpad][C]
 // thread = (tile, channel quad); the 4x4 patch starts at (2*ty - 1, 2*tx - 1), zeros outside the image
 __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T,
-                                                             long long Tpad, float* __restrict__ Vout) {
+                                                             long long Tpad, float* __restrict__ Vout, long long ldo) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
-    const long long plane = Tpad * C;
+    const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
-        float* dst = Vout + t * C + c;
+        float* dst = Vout + t * ldo + c;
         if (t >= T) {                                        // padding tiles: zeros (their GEMM rows are never read back)
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -111,12 +111,12 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
         }
     }
 }
-int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st) {
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino_input_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V);
+    hipLaunchKernelGGL(afi_wino_input_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -227,14 +227,14 @@ int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm&
 //   dU[a][co][ci] = sum_t Q[a][t][co] * V[a][t][ci]     16 GEMMs with K = tiles: ONE launch of the weight-gradient kernel
 //   dW[co][ky][kx][ci] += A'^T dU A'             (afi_wino_dw_kernel;  A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]])
 __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                          float* __restrict__ Q) {
+                                                          float* __restrict__ Q, long long ldo) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
-    const long long plane = Tpad * C;
+    const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
-        float* dst = Q + t * C + c;
+        float* dst = Q + t * ldo + c;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (t >= T) {
 #pragma unroll
@@ -268,12 +268,12 @@ __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int 
         }
     }
 }
-int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st) {
+int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino_dy_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q);
+    hipLaunchKernelGGL(afi_wino_dy_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -332,14 +332,14 @@ __device__ __forceinline__ void wino4_bt(T& d0, T& d1, T& d2, T& d3, T& d4, T& d
 
 // input: X (view) -> V [36][Tpad][C]; the 6x6 patch of tile (ty, tx) starts at (4*ty - 1, 4*tx - 1)
 __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                              float* __restrict__ Vout) {
+                                                              float* __restrict__ Vout, long long ldo) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
-    const long long plane = Tpad * C;
+    const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
-        float* dst = Vout + t * C + c;
+        float* dst = Vout + t * ldo + c;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (t >= T) {
 #pragma unroll
@@ -368,12 +368,12 @@ __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, i
         }
     }
 }
-int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st) {
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino4_input_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V);
+    hipLaunchKernelGGL(afi_wino4_input_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -482,14 +482,14 @@ int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm
 
 // weight gradient: Q[a][t][co] = G' e G'^T for the 4x4 block e of dY of tile t
 __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                           float* __restrict__ Q) {
+                                                           float* __restrict__ Q, long long ldo) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
-    const long long plane = Tpad * C;
+    const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
-        float* dst = Q + t * C + c;
+        float* dst = Q + t * ldo + c;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (t >= T) {
 #pragma unroll
@@ -526,12 +526,12 @@ __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int
         }
     }
 }
-int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st) {
+int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino4_dy_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q);
+    hipLaunchKernelGGL(afi_wino4_dy_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
