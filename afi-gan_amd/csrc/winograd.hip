@@ -17,6 +17,10 @@
 #include "afi_common.h"
 #include "afi_epilogue.h"
 
+static bool afi_epilogue_is_simple_host(const AfiPixGemm& p) {
+    return p.o_up == 1 && p.beta == 0.f && !p.R1.p && !p.R2.p && !p.lrelu && !p.r2_post && p.oH >= p.H && p.oW >= p.W &&
+           (!p.Z.p || (p.z_lo == 0 && p.z_hi >= p.Ncols));
+}
 static unsigned wino_grid(long long work_items) {
     long long g = (work_items + 255) / 256;
     if (g > 8192) g = 8192;
@@ -177,6 +181,7 @@ int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, 
 // Same transform, but each output float4 goes through afi_epilogue_store with the conv's own descriptor: bias, alpha / beta,
 // LeakyReLU, the two residual adds with channel ranges, the bilinear x2 skip, the pixel-shuffle store of the conv-transpose
 // (columns = 4 phases x Cout) and the LeakyReLU' mask -- so any 3x3 / stride-1 conv of the interpolator can take this path.
+template <bool SIMPLE>
 __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* __restrict__ Min, long long Tpad, int Th, int Tw, long long T,
                                                                   const AfiPixGemm p) {
     const int C = p.Ncols, C4 = C >> 2;
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* _
                 const int xx = 2 * tx + j;
                 if (xx >= p.W) continue;
                 const f32x4 v = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
-                afi_epilogue_store(p, n, yy, xx, c, v);
+                if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx, c, v); else afi_epilogue_store(p, n, yy, xx, c, v);
             }
         }
     }
@@ -215,7 +220,8 @@ int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm&
     const int Th = (p.H + 1) / 2, Tw = (p.W + 1) / 2;
     const long long T = (long long)p.N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino_output_epi_kernel, dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
+    if (afi_epilogue_is_simple_host(p)) hipLaunchKernelGGL((afi_wino_output_epi_kernel<true>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
+    else hipLaunchKernelGGL((afi_wino_output_epi_kernel<false>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -434,6 +440,7 @@ int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hi
 }
 
 // output: M [36][Tpad][C] -> 4x4 pixels per tile through the descriptor's epilogue
+template <bool SIMPLE>
 __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* __restrict__ Min, long long Tpad, int Th, int Tw, long long T,
                                                                    const AfiPixGemm p) {
     const int C = p.Ncols, C4 = C >> 2;
@@ -464,10 +471,10 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
             const f32x4 p12 = s[i][1] + s[i][2], d12 = s[i][1] - s[i][2], p34 = s[i][3] + s[i][4], d34 = s[i][3] - s[i][4];
             const f32x4 y0 = s[i][0] + p12 + p34, y1 = d12 + 2.f * d34, y2 = p12 + 4.f * p34, y3 = d12 + 8.f * d34 + s[i][5];
             const int xx = 4 * tx;
-            if (xx < p.W) afi_epilogue_store(p, n, yy, xx, c, y0);
-            if (xx + 1 < p.W) afi_epilogue_store(p, n, yy, xx + 1, c, y1);
-            if (xx + 2 < p.W) afi_epilogue_store(p, n, yy, xx + 2, c, y2);
-            if (xx + 3 < p.W) afi_epilogue_store(p, n, yy, xx + 3, c, y3);
+            if (xx < p.W) { if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx, c, y0); else afi_epilogue_store(p, n, yy, xx, c, y0); }
+            if (xx + 1 < p.W) { if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx + 1, c, y1); else afi_epilogue_store(p, n, yy, xx + 1, c, y1); }
+            if (xx + 2 < p.W) { if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx + 2, c, y2); else afi_epilogue_store(p, n, yy, xx + 2, c, y2); }
+            if (xx + 3 < p.W) { if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx + 3, c, y3); else afi_epilogue_store(p, n, yy, xx + 3, c, y3); }
         }
     }
 }
@@ -476,7 +483,8 @@ int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm
     const int Th = (p.H + 3) / 4, Tw = (p.W + 3) / 4;
     const long long T = (long long)p.N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino4_output_epi_kernel, dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
+    if (afi_epilogue_is_simple_host(p)) hipLaunchKernelGGL((afi_wino4_output_epi_kernel<true>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
+    else hipLaunchKernelGGL((afi_wino4_output_epi_kernel<false>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
