@@ -72,6 +72,7 @@ SIGNATURES = {
     "afi_conv1x1_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "afi_conv3x3_wino_ws_floats": (_ll, [_i] * 5),
     "afi_conv3x3_wino_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _vp, _ll, _vp]),
+    "afi_conv3x3_wino_infer": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp, _ll, _vp]),
     "afi_conv3x3_wino_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, View, _vp, _ll, _vp]),
     "afi_conv3x3_wino_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp, _ll, _vp]),
     "afi_conv3x3s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, View, _f, View, _f, _vp]),

@@ -62,17 +62,22 @@ __device__ __forceinline__ void afi_epilogue_store(const AfiPixGemm& p, int img,
     *(f32x4*)dst = v;
 }
 
-// The common case of the big Winograd convs (D forward: bias only; D / G data gradients: the LeakyReLU' mask over every channel):
-// no beta, residuals, activation or pixel shuffle.  A lean body keeps the 16 inlined copies in an output transform small
+// The common case of the big Winograd convs (D forward: bias only; D / G data gradients: the LeakyReLU' mask over every channel;
+// plain conv + activation): no beta, residuals or pixel shuffle.  A lean body keeps the 16 inlined copies in an output transform small
 // (the general one above makes that kernel ~5500 instructions long).
 __device__ __forceinline__ bool afi_epilogue_is_simple(const AfiPixGemm& p) {
-    return p.o_up == 1 && p.beta == 0.f && !p.R1.p && !p.R2.p && !p.lrelu && !p.r2_post && p.oH >= p.H && p.oW >= p.W &&
+    return p.o_up == 1 && p.beta == 0.f && !p.R1.p && !p.R2.p && !p.r2_post && p.oH >= p.H && p.oW >= p.W &&
            (!p.Z.p || (p.z_lo == 0 && p.z_hi >= p.Ncols));
 }
 __device__ __forceinline__ void afi_epilogue_store_simple(const AfiPixGemm& p, int img, int y, int x, int col, f32x4 accv) {
     const long long pix = (long long)img * p.O.sN + (long long)y * p.O.sH + (long long)x * p.O.sW + col;
     f32x4 v = p.alpha * accv;
     if (p.bias) v += *(const f32x4*)(p.bias + col);
+    if (p.lrelu) {
+        const float slope = (p.lrelu == 1) ? AFI_LRELU_SLOPE : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+    }
     if (p.Z.p) {
         const f32x4 z = *(const f32x4*)(p.Z.p + (long long)img * p.Z.sN + (long long)y * p.Z.sH + (long long)x * p.Z.sW + col);
 #pragma unroll

@@ -411,6 +411,14 @@ int afi_conv3x3_wino_fwd(afi_view_t x, int N, int H, int W, int Cin, const float
     if (N <= 0 || H <= 0 || W <= 0 || !ws) return AFI_ERR_BAD_ARG;
     return wino_conv(0, V(x), N, H, W, Cin, w, Cout, bias, V(out), null_view(), ws, ws_floats, nullptr, 0, (hipStream_t)stream);
 }
+int afi_conv3x3_wino_infer(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, int act,
+                           float* ws, long long ws_floats, void* stream) {
+    if (N <= 0 || H <= 0 || W <= 0 || !ws || act < 0 || act > 2) return AFI_ERR_BAD_ARG;
+    if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
+    AfiPixGemm g = conv_fwd_desc(V(x), N, H, W, Cin, w, bias, Cout, V(out));
+    g.lrelu = act;
+    return wino_run(g, 0, ws, ws_floats, nullptr, 0, (hipStream_t)stream, /*fwd_f4=*/true);
+}
 int afi_conv3x3_wino_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, afi_view_t z, float* ws,
                            long long ws_floats, void* stream) {
     if (N <= 0 || H <= 0 || W <= 0 || !ws) return AFI_ERR_BAD_ARG;

@@ -18,7 +18,7 @@
 #include "afi_epilogue.h"
 
 static bool afi_epilogue_is_simple_host(const AfiPixGemm& p) {
-    return p.o_up == 1 && p.beta == 0.f && !p.R1.p && !p.R2.p && !p.lrelu && !p.r2_post && p.oH >= p.H && p.oW >= p.W &&
+    return p.o_up == 1 && p.beta == 0.f && !p.R1.p && !p.R2.p && !p.r2_post && p.oH >= p.H && p.oW >= p.W &&
            (!p.Z.p || (p.z_lo == 0 && p.z_hi >= p.Ncols));
 }
 static unsigned wino_grid(long long work_items) {

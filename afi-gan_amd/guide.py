@@ -5,8 +5,8 @@ contains the same work as stage1_trainer.py:320-321 (two guide forwards per iter
 
 To keep a fresh GPU box from spending minutes in MIOpen's just-in-time kernel builds, the guide avoids MIOpen entirely:
 1x1 convs are plain GEMMs on the pixel-major tensor (torch.matmul -> hipBLASLt), the 7x7 stem is unfold + GEMM, every 3x3
-conv (stride 1 under detectron2's STRIDE_IN_1X1=True) runs on this package's own fp32-MFMA conv kernel with a fused
-bias + ReLU epilogue, and the frozen BatchNorms are folded into weights / biases at construction.
+conv (stride 1 under detectron2's STRIDE_IN_1X1=True) runs on this package's own fp32-MFMA conv kernels with a fused
+bias + ReLU epilogue (the >= 128-channel ones in the inference Winograd form, afi_conv3x3_wino_infer), and the frozen BatchNorms are folded into weights / biases at construction.
 """
 import math
 
@@ -49,6 +49,9 @@ class _Conv3x3(nn.Module):
         self.register_buffer("b", torch.zeros(cout))
 
     def forward(self, x):
+        N, C, H, W = x.shape
+        if C >= 128 and self.w.shape[0] >= 128 and N * H * W >= 1024:      # frozen inference net: the Winograd form, F(4x4) on big maps
+            return ops.conv3x3_wino_infer(x, self.w, self.b, act=2 if self.relu else 0)
         return ops.conv3x3_fwd(x, self.w, self.b, lrelu=2 if self.relu else 0)
 
 

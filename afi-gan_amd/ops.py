@@ -210,6 +210,19 @@ def conv3x3_wino_fwd(x, w, bias=None):
     return out
 
 
+def conv3x3_wino_infer(x, w, bias=None, act=0):
+    """act(conv3x3(x, w) + bias) for inference (no backward): Winograd, F(4x4) tiles on maps of >= 8192 pixels.  act: 0 / 1 LeakyReLU / 2 ReLU."""
+    _check_cuda(x, w, bias)
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    w = ohwi(w)
+    n = _lib.load().afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout)
+    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    out = new_pixel_major(N, Cout, H, W, x.device)
+    call("afi_conv3x3_wino_infer", view_of(x), N, H, W, Cin, _p(w), _p(bias), Cout, view_of(out), int(act), _p(ws), n, stream_ptr())
+    return out
+
+
 def conv3x3_wino_dgrad(dy, w, z=None):
     """Data gradient of the 3x3 conv in Winograd form: dx = conv^T(dy) [* lrelu'(z)]."""
     _check_cuda(dy, w, z)

@@ -130,6 +130,10 @@ int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout
 long long afi_conv3x3_wino_ws_floats(int N, int H, int W, int Cin, int Cout);
 int afi_conv3x3_wino_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
                          afi_view_t out, float* ws, long long ws_floats, void* stream);
+/* inference form: out = act(conv + bias), act 0 none / 1 LeakyReLU(0.2) / 2 ReLU; no backward will follow, so maps of >= 8192 pixels
+ * take the F(4x4,3x3) tiling (4x fewer multiplies, ~3e-5 relative rounding) */
+int afi_conv3x3_wino_infer(afi_view_t x, int N, int H, int W, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
+                           afi_view_t out, int act, float* ws, long long ws_floats, void* stream);
 int afi_conv3x3_wino_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w_ohwi, int Cin, afi_view_t dx,
                            afi_view_t z_or_null, float* ws, long long ws_floats, void* stream);
 

@@ -353,3 +353,15 @@ def test_wino_wgrad_accumulator_semantics(amd):
         _close(dw, ref, tol=1e-4, what="accumulated wgrad after flush")
         ops.conv3x3_wino_wgrad(_pm(dys[0]), _pm(xs[0]), dw=dw)                            # unregistered again: per call, dw +=
         _close(dw, ref + torch.autograd.grad(F.conv2d(xs[0], w, None, 1, 1), w, dys[0])[0], tol=1e-4, what="per-call path after unregistering")
+
+
+@pytest.mark.parametrize("N,Cin,Cout,H,W,act", [(1, 128, 128, 40, 44, 2), (2, 128, 256, 72, 100, 2), (1, 256, 128, 100, 168, 1), (1, 128, 128, 96, 100, 0)])
+def test_conv3x3_winograd_inference_form(amd, N, Cin, Cout, H, W, act):
+    """afi_conv3x3_wino_infer: act(conv + bias) with the F(4x4) tiling from 8192 pixels on (its rounding is ~3e-5 of the output
+    scale, the F(2x2) tiling's ~1e-6): against torch-CPU fp32."""
+    ops = amd.ops
+    x, w, b = _rand(N, Cin, H, W, seed=41), _rand(Cout, Cin, 3, 3, seed=42) * 0.05, _rand(Cout, seed=43)
+    ref = F.conv2d(x, w, b, 1, 1)
+    ref = F.relu(ref) if act == 2 else (F.leaky_relu(ref, 0.2) if act == 1 else ref)
+    out = ops.conv3x3_wino_infer(_pm(x), w.cuda(), b.cuda(), act=act)
+    _close(out, ref, tol=3e-4 if N * H * W >= 8192 else 1e-4, what="wino inference conv")
