@@ -1,5 +1,5 @@
 set -e
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r01q; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r01r; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o runc -- $B --steps 3 --warmup 0 --no-interp --no-cpu-baseline > $O/bench_trace.log 2>&1
