@@ -507,13 +507,20 @@ __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int
         const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
         const float* base = dy.p + (long long)n * dy.sN + c;
         f32x4 a[6][4];                                       // G' e (columns of e)
+        const bool interior = 4 * ty + 3 < H && 4 * tx + 3 < W;    // whole 4x4 block inside the map: unconditional loads
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 v[4];
+            if (interior) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int yy = 4 * ty + i, xx = 4 * tx + j;
-                v[i] = (yy < H && xx < W) ? __builtin_nontemporal_load((const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW)) : zero;
+                for (int i = 0; i < 4; ++i)
+                    v[i] = __builtin_nontemporal_load((const f32x4*)(base + (long long)(4 * ty + i) * dy.sH + (long long)(4 * tx + j) * dy.sW));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int yy = 4 * ty + i, xx = 4 * tx + j;
+                    v[i] = (yy < H && xx < W) ? __builtin_nontemporal_load((const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW)) : zero;
+                }
             }
             a[0][j] = 0.25f * v[0];
             a[1][j] = (-1.f / 6.f) * (v[0] + v[1] + v[2] + v[3]);
