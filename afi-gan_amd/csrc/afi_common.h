@@ -81,4 +81,7 @@ struct AfiWgradGemm {
     int splitK;
 };
 
+// one bias-gradient problem of afi_launch_colsum_group: db[c] += alpha * sum_rows g[row*ld + c], c < C
+struct AfiColsumProb { const float* g; float* db; long long P, ld; int C; float alpha; };
+
 static inline int afi_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -71,7 +71,7 @@ int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hi
 // are contiguous (W is contiguous along the 36 taps of one (ci, co), Wp along ci): a direct gather ran at ~0.6 TB/s (33 us for
 // the 256x256 layer, on the critical path of every generator forward), the tiled form is bandwidth-bound.
 #define AFI_CT_CI 32
-#define AFI_CT_CO 8
+#define AFI_CT_CO 2                                          // 8 -> 2: 1024 blocks for the 256x256 layer (the pass is latency-bound: 21 / 28 us with 256 blocks)
 #define AFI_CT_LD (AFI_CT_CO * 36 + 1)
 template <bool UNPACK>
 __global__ __launch_bounds__(256) void afi_convT_repack_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cin, int Cout) {
@@ -81,6 +81,7 @@ __global__ __launch_bounds__(256) void afi_convT_repack_kernel(const float* __re
     // packed side: thread -> (ci lane, row), row = (phase, co_l, tap)
     auto packed_pass = [&](auto&& f) {
         const int ci = tid & (AFI_CT_CI - 1);
+#pragma unroll 3
         for (int row = tid / AFI_CT_CI; row < 4 * AFI_CT_CO * 9; row += 256 / AFI_CT_CI) {
             const int tap = row % 9, r = row / 9, co_l = r % AFI_CT_CO, phase = r / AFI_CT_CO;
             const int a = phase >> 1, c = phase & 1, dy = tap / 3 - 1, dx = tap % 3 - 1;
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256) void afi_convT_repack_kernel(const float* __re
     };
     // torch side: thread -> consecutive floats of the 8*36-float run of one ci
     auto torch_pass = [&](auto&& f) {
+#pragma unroll 3
         for (int i = tid; i < AFI_CT_CI * AFI_CT_CO * 36; i += 256) {
             const int ci = i / (AFI_CT_CO * 36), j = i - ci * (AFI_CT_CO * 36);
             if (ci0 + ci < Cin && co0 + j / 36 < Cout) f(T[ci][j], ((long long)(ci0 + ci) * Cout + co0) * 36 + j);

@@ -14,6 +14,8 @@ int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st);
 int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st);
 int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, hipStream_t st);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
+int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // smallmap.hip
+int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st);
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
@@ -782,11 +784,31 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
         g.partial = part_; g.partial_floats = part_n_;
         return afi_launch_pix_gemm(g, b_rc, st);
     };
+    // Small maps (config-1 sizes): every weight / bias gradient is DEFERRED to the end of the pass and runs as ONE grouped launch
+    // per tile shape (csrc/smallmap.hip: whole dW tiles per block, no split over pixels, no atomics, no zero-fill), instead of one
+    // 7 .. 36-tile launch per layer on a side stream.  All their operands (dOut, dU, gA, gB, the per-block gradient buffers and the
+    // saved activations) stay alive until the call returns.  AFI_WG_GROUP=0 restores the per-layer launches.
+    static const int wg_group = getenv("AFI_WG_GROUP") ? atoi(getenv("AFI_WG_GROUP")) : 1;
+    const bool grouped = wg_group && 4 * l.P <= kSideStreamMaxPixels;
+    AfiWgradGemm wg_wide[12], wg_narrow[4 * AFI_MAX_RDB];
+    AfiColsumProb cs[8];
+    int n_wide = 0, n_narrow = 0, n_cs = 0;
+    bool n_wide_has_convT = false;
+    auto defer = [&](const AfiWgradGemm& g) {
+        if (g.Mrows <= 32 && n_narrow < 4 * AFI_MAX_RDB) { wg_narrow[n_narrow++] = g; return AFI_OK; }
+        if (g.Mrows > 32 && n_wide < 12) { wg_wide[n_wide++] = g; return AFI_OK; }
+        return afi_launch_wgrad_gemm(g, (hipStream_t)stream);       // table full (unusual shapes): launch it on its own
+    };
     // weight gradient of a 3x3 conv: Winograd F(3x3,2x2) when both channel counts and the map are large enough, else direct
     auto WG = [&](AfiView dyv, AfiView xin, int n_, int h_, int w_, int co, int ci, float* dw, float alpha, hipStream_t s_) {
+        if (grouped) return defer(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha));
         if (s.n_wino > 0 && co >= 128 && ci >= 128 && (long long)n_ * h_ * w_ >= 1024)
             return wino_wgrad(dyv, xin, n_, h_, w_, co, ci, dw, alpha, scratch + s.o_wino2, s.n_wino, s_);
         return afi_launch_wgrad_gemm(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha), s_);
+    };
+    auto CS = [&](const float* g, long long rows, int Cc, long long ld, float* db, hipStream_t s_) {
+        if (grouped) { cs[n_cs++] = AfiColsumProb{g, db, rows, ld, Cc, 1.f}; return AFI_OK; }
+        return afi_launch_colsum_accum(g, rows, Cc, ld, 1.f, db, scratch + s.o_red, s_);
     };
     const int L = (int)l.L;
     const long long P = l.P;
@@ -801,40 +823,59 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     AfiView gA = dense_view(scratch + s.o_ga, H, W, C), gB = dense_view(scratch + s.o_gb, H, W, C);
     auto dBuf = [&](int r) { return dense_view(scratch + s.o_db0 + (long long)r * P * L, H, W, L); };
     float* dwp = scratch + s.o_dwp;
-    float* red = scratch + s.o_red;                        // column-sum scratch: used on the side stream only
-    Fork fk(st, 4 * P <= kSideStreamMaxPixels);
+    // grouped form: the deferred problems are flushed onto the side stream at a few points of the chain (after the hi-res pair, after
+    // each dense block, at the end), so the grouped launches run beside the data-gradient chain and fill the matrix-pipe time its
+    // launch-bound small kernels leave idle.  AFI_WG_OVERLAP=0 keeps everything on the caller's stream (one flush at the end).
+    static const int wg_overlap = getenv("AFI_WG_OVERLAP") ? atoi(getenv("AFI_WG_OVERLAP")) : 1;
+    Fork fk(st, 4 * P <= kSideStreamMaxPixels && (!grouped || wg_overlap));
     hipStream_t sd = fk.side;                              // weight / bias gradients
+    bool unpack_pending = false;
+    auto flush = [&](bool last) {                          // launch what has been deferred so far (its operands are complete on `st`)
+        if (!grouped || (!last && !fk.on)) return AFI_OK;
+        if (n_wide + n_narrow + n_cs == 0 && !(last && unpack_pending)) return AFI_OK;
+        fk.after_main();
+        AFI_TRY(afi_launch_wgrad_group(wg_wide, n_wide, 1, sd));
+        AFI_TRY(afi_launch_wgrad_group(wg_narrow, n_narrow, 0, sd));
+        AFI_TRY(afi_launch_colsum_group(cs, n_cs, sd));
+        if (unpack_pending && gr->wT && n_wide_has_convT) { AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd)); unpack_pending = false; }
+        n_wide = n_narrow = n_cs = 0; n_wide_has_convT = false;
+        return AFI_OK;
+    };
 
     // ---- final conv (generator_rdb.py:107-108)
     if (gr->w9) AFI_TRY(WG(dOut, u, N, 2 * H, 2 * W, C, C, gr->w9, 1.f, sd));
-    if (gr->b9) AFI_TRY(afi_launch_colsum_accum(dout, 4 * P, C, C, 1.f, gr->b9, red, sd));
+    if (gr->b9) AFI_TRY(CS(dout, 4 * P, C, C, gr->b9, sd));
     {
         AfiPixGemm g = conv_dgrad_desc(dOut, N, 2 * H, 2 * W, C, prm->w9, C, dU);
         g.Z = u; g.z_lo = 0; g.z_hi = C;                       // through the LReLU after the conv-transpose
         AFI_TRY(PG(g, 1));
     }
     // ---- conv-transpose (:101-105)
-    fk.after_main();                                       // dU is complete
+    if (!grouped) fk.after_main();                                       // dU is complete
     if (gr->wT) {
         if (hipMemsetAsync(dwp, 0, sizeof(float) * 36LL * C * C, sd) != hipSuccess) return AFI_ERR_LAUNCH;
         static const int convt = getenv("AFI_WINO_CONVT") ? atoi(getenv("AFI_WINO_CONVT")) : 1;
-        if (convt && s.n_wino > 0 && C >= 128 && P >= 1024) {    // the four phases as channel blocks of one Winograd weight gradient
+        if (grouped) {
+            AFI_TRY(defer(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f)));
+            n_wide_has_convT = true; unpack_pending = true;
+        } else if (convt && s.n_wino > 0 && C >= 128 && P >= 1024) {    // the four phases as channel blocks of one Winograd weight gradient
             AFI_TRY(wino_wgrad(dU, a7, N, H, W, 4 * C, C, dwp, 1.f, scratch + s.o_wino2, s.n_wino, sd, /*dy_phases=*/4, /*accumulate=*/false));
         } else {
             AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));
         }
-        AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd));
+        if (!grouped) AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd));
     }
-    if (gr->bT) AFI_TRY(afi_launch_colsum_accum(dU.p, 4 * P, C, C, 1.f, gr->bT, red, sd));
+    if (gr->bT) AFI_TRY(CS(dU.p, 4 * P, C, C, gr->bT, sd));
     {
         AfiPixGemm g = convT_dgrad_desc(dU, N, H, W, C, wp, C, gA);
         g.Z = a7; g.z_lo = 0; g.z_hi = C;
         AFI_TRY(PG(g, 1));
     }
     // ---- trunk conv (:97-99): gA = d(pre-activation of a7)
-    fk.after_main();                                       // gA is complete
+    if (!grouped) fk.after_main();                                       // gA is complete
     if (gr->w7) AFI_TRY(WG(gA, t, N, H, W, C, C, gr->w7, 1.f, sd));
-    if (gr->b7) AFI_TRY(afi_launch_colsum_accum(gA.p, P, C, C, 1.f, gr->b7, red, sd));
+    if (gr->b7) AFI_TRY(CS(gA.p, P, C, C, gr->b7, sd));
+    AFI_TRY(flush(false));                                 // final conv, conv-transpose and trunk gradients: all their operands exist now
     AFI_TRY(PG(conv_dgrad_desc(gA, N, H, W, C, prm->w7, C, gB), 1));    // gB = dT
     // ---- ResidualInResidual (:27-30) and the RDB chain (:64-71), last block first
     AfiView Gt = gB;        // incoming gradient tensor, true gradient = gs * Gt
@@ -842,7 +883,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     for (int r = R - 1; r >= 0; --r) {
         AfiView b = buf(r), d = dBuf(r);
         // conv5: out = x + rs*conv5(cat)
-        fk.after_main();                                   // Gt is complete
+        if (!grouped) fk.after_main();                                   // Gt is complete
         if (gr->rdb_w[r][4]) AFI_TRY(WG(Gt, b, N, H, W, C, L, gr->rdb_w[r][4], rs * gs, sd));
         {
             AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->rdb_w[r][4], L, d);
@@ -854,8 +895,11 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
         for (int k = 4; k >= 1; --k) {
             const int cin = C + (k - 1) * G;
             AfiView dyk = ch_off(d, cin);                               // d(pre-activation of conv_k), G channels
-            fk.after_main();                               // dyk's slice was finalised by the previous dgrad
-            if (gr->rdb_w[r][k - 1]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dyk, b, N, H, W, G, cin, gr->rdb_w[r][k - 1], 1.f), sd));
+            if (!grouped) fk.after_main();                               // dyk's slice was finalised by the previous dgrad
+            if (gr->rdb_w[r][k - 1]) {
+                const AfiWgradGemm wd = conv_wgrad_desc(dyk, b, N, H, W, G, cin, gr->rdb_w[r][k - 1], 1.f);
+                AFI_TRY(grouped ? defer(wd) : afi_launch_wgrad_gemm(wd, sd));
+            }
             AfiPixGemm g = conv_dgrad_desc(dyk, N, H, W, G, prm->rdb_w[r][k - 1], cin, d);
             g.beta = 1.f;                                               // dense connections: accumulate
             if (k >= 2) { g.Z = b; g.z_lo = cin - G; g.z_hi = cin; }    // conv_{k-1}'s slice becomes final
@@ -865,18 +909,20 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
             }
             AFI_TRY(PG(g, 1));
         }
+        AFI_TRY(flush(false));                                          // this block's five weight gradients
         Gt = d; gs = 1.f;                                               // channels [0,C) of d = gradient w.r.t. the block input
     }
     // ---- head conv (:91-93): Gt[0:C] = d(pre-activation of a0)
-    fk.after_main();
+    if (!grouped) fk.after_main();
     if (gr->w0) AFI_TRY(WG(Gt, x, N, H, W, C, C, gr->w0, 1.f, sd));
-    if (gr->b0) AFI_TRY(afi_launch_colsum_accum(Gt.p, P, C, L, 1.f, gr->b0, red, sd));
+    if (gr->b0) AFI_TRY(CS(Gt.p, P, C, L, gr->b0, sd));
     if (dx) {
         AFI_TRY(afi_launch_bilinear2x_bwd(dout, N, H, W, C, 0.f, dx, st));           // skip path (:125)
         AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->w0, C, dense_view(dx, H, W, C));
         g.beta = 1.f;
         AFI_TRY(PG(g, 1));
     }
+    AFI_TRY(flush(true));                                  // head conv (and, without the side stream, everything deferred so far)
     fk.join();
     return AFI_OK;
 }

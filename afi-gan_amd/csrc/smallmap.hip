@@ -1,0 +1,848 @@
+// Small-map schedule of the AF interpolator (SURVEY 8a rows 2-9 at config-1 sizes: 1 x 256 x 25 x 34 -> 50 x 68).
+//
+// At 850 .. 3400 pixels a 3x3 conv is a GEMM with M = 850, N = 32 .. 1024, K = 2304 .. 9216: 7 .. 56 output tiles for 256 CUs,
+// so whole tiles cannot fill the chip and a fixed split-K quantises badly (56 tiles x 5 splits = 280 blocks = 1.09 per CU).
+// This file holds the three pieces of the small-map schedule:
+//
+//   afi_pix_gemm_sk_kernel   STREAM-K form of the pixel GEMM (same descriptor, gather, LDS layout and MFMA loop as
+//                            afi_pix_gemm_kernel): the work is the list of (tile, K-stage) units; each of G persistent blocks
+//                            takes an equal contiguous run of units, so every CU carries the same number of MFMAs whatever the
+//                            shape; a block whose run ends inside a tile leaves a raw partial tile in a slab.  Blocks reach their
+//                            prologue / MFMA / store phases at different times (runs start at arbitrary stages), which removes the
+//                            lock-step of the one-tile-per-block split-K grid, where all blocks load, multiply and store together.
+//   afi_pix_sk_reduce_kernel sums a tile's slabs in a FIXED order (bit-reproducible, no atomics) and applies the fused epilogue.
+//   afi_wgrad_group_kernel   every weight gradient of one backward pass (19 convs, 23 parameter tensors) in ONE launch: the blocks
+//                            walk a table of AfiWgradGemm problems, each block owns a whole dW tile (all pixels), so there are no
+//                            atomics, no zero-fills, and the grid fills the chip (the per-layer launches were 7 .. 36 tiles each).
+//   afi_colsum_group_kernel  the bias gradients of the same pass in one launch.
+#include "afi_common.h"
+
+#define AFI_BK 32
+// zero page of the branch-free gathers.  EXTERNAL linkage and non-const on purpose: with internal linkage hipcc proves the array is
+// never written, folds loads from it to 0.0f, and turns every `ok ? ptr : zeros` address select into an exec-masked branch around
+// the load plus `s_waitcnt vmcnt(0)` (seen in the ISA: the K loop then waits for the loads it has just issued, 2x its matrix time)
+__device__ __attribute__((aligned(16))) float afi_zeros_smallmap[4] = {0.f, 0.f, 0.f, 0.f};
+#define afi_zeros afi_zeros_smallmap
+
+#include "afi_epilogue.h"
+#include "afi_wgrad_body.h"
+#include <stdlib.h>
+#include <stdio.h>
+#include <vector>
+
+// stream-K partition: unit = one BK-deep K stage of one tile; tile t owns units [t*nK, (t+1)*nK); logical block b owns
+// [b*U/G, (b+1)*U/G).  G <= U, so no block is empty and the blocks that touch a tile are consecutive.  The launcher prefers a G
+// for which every block's run is one equal slice of ONE tile (q = U/G divides nK): then a block is a single segment.
+// Everything is 32-bit (small maps: U * G < 2^31) and the two divisions per row go through host-made reciprocals: at one or two
+// waves per SIMD every VALU instruction of the prologue costs 4+ cycles in which the matrix pipe idles.
+struct AfiSkArgs {
+    int ntile_m, ntile_n;      // tiles of BM x BN (tile id = tile_n * ntile_m + tile_m: M fastest, a weight panel stays in L2)
+    int nK;                    // K stages per tile = ntaps * nKphase * ceil(Ck / 32)
+    int G;                     // logical blocks == gridDim.x
+    int U;                     // ntile_m * ntile_n * nK
+    int bm, bn;                // tile shape (for the reduction pass)
+    int M, HW;                 // pixels, pixels per image
+    unsigned rcp_HW, rcp_W, rcp_taps;   // floor(2^32 / d) + 1: n / d == umulhi(n, rcp) for n * d < 2^32 (d == 1: see afi_udiv)
+    int kph_shift;             // log2(nKphase)   (1 or 4 phases)
+    unsigned long long* dbg;   // diagnostic build only (AFI_SK_DIAG): [G][10] cycle stamps per block; production launches pass nullptr and compile no stamp
+};
+__device__ __forceinline__ unsigned afi_udiv(unsigned n, unsigned d, unsigned rcp) { return d == 1 ? n : __umulhi(n, rcp); }
+// the block that owns unit x: the largest b with b*U/G <= x
+__device__ __forceinline__ int afi_sk_owner(int x, int G, int U) { return (int)(((unsigned)(x + 1) * (unsigned)G + (unsigned)U - 1u) / (unsigned)U) - 1; }
+
+#define AFI_STAMP(i) do { if constexpr (DIAG) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + (i)] = t_; } } while (0)
+template <int BM, int BN, int WM, int WN, bool B_RC, bool DIAG = false>
+__global__ __launch_bounds__(256, 3) void afi_pix_gemm_sk_kernel(const AfiPixGemm p, const AfiSkArgs sk) {
+    constexpr int BK = AFI_BK, LDK = BK + 4, NT = 256, D = 3;
+    constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
+    static_assert(WM * WN == 4 && MI == 1 && NI == 1, "4 waves, one 32x32 accumulator block each");
+    constexpr int K_F4 = BK / 4, K_RPP = NT / K_F4;       // KC operands: float4 per row of a stage, rows per load pass
+    constexpr int A_LOADS = BM / K_RPP;
+    constexpr int B_F4 = BN / 4;
+    constexpr int B_LOADS = B_RC ? (BK * B_F4) / NT : BN / K_RPP;
+    static_assert(A_LOADS >= 1 && B_LOADS >= 1, "tile too small");
+    constexpr int B_ROWS_PER_PASS = NT / B_F4;
+    constexpr int A_TILE = BM * LDK, B_TILE = B_RC ? BK * BN : BN * LDK, STAGE = A_TILE + B_TILE;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // two stage buffers: ONE barrier per stage
+
+    if constexpr (DIAG) { if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + 6] = __builtin_amdgcn_s_memrealtime(); }
+    AFI_STAMP(0);
+    bool first_seg = true;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int M = sk.M, HW = sk.HW;
+    const int Ck4 = (p.Ck + 3) & ~3;
+    const int ldp = (p.Ncols + 3) & ~3;
+    const int aq = tid % K_F4, ar = tid / K_F4;           // KC: float4 column, first row
+    const int b_cq = tid % B_F4, b_kr = tid / B_F4;       // RC: float4 column, first k-row
+    // the zero page's address, made opaque: knowing it, hipcc loads the page ONCE, keeps it as the default value of every gather and
+    // wraps the real loads in exec-masked branches behind `s_waitcnt vmcnt(0)` (seen in the ISA) -- the prefetch depth was gone
+    typedef const __attribute__((address_space(1))) float gfloat;      // keeps the gathers global_load (a generic pointer would make them flat_load)
+    typedef const __attribute__((address_space(1))) f32x4 gf32x4;
+    gfloat* zpage = (gfloat*)afi_zeros;
+    asm volatile("" : "+v"(zpage));
+
+    // blocks b and b + 8 share an XCD: give each XCD a contiguous range of logical blocks, i.e. of tiles (weight panels and
+    // neighbouring activation rows then meet in one L2); bijective for any G
+    int lb;
+    {
+        const int q8 = sk.G >> 3, r8 = sk.G & 7, xcd = blockIdx.x & 7;
+        lb = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (int)(blockIdx.x >> 3);
+    }
+    int u = (int)((unsigned)lb * (unsigned)sk.U / (unsigned)sk.G);
+    const int u_end = (int)((unsigned)(lb + 1) * (unsigned)sk.U / (unsigned)sk.G);
+
+    while (u < u_end) {                                    // (uniform) one segment = the part of this block's run inside one tile
+        const int t = (int)((unsigned)u / (unsigned)sk.nK);
+        const int kc0 = u - t * sk.nK;
+        const int nK = min(sk.nK - kc0, u_end - u);
+        const int tile_n = (int)((unsigned)t / (unsigned)sk.ntile_m), tile_m = t - tile_n * sk.ntile_m;
+        const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+        // ---- loader state: each thread decodes the rows IT gathers (no row table, no barrier): centre offset + 9-bit tap mask
+        long long a_off[A_LOADS]; unsigned a_mask[A_LOADS];
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) {
+            const int m = m0 + ar + K_RPP * i;
+            const unsigned img = afi_udiv((unsigned)m, (unsigned)HW, sk.rcp_HW);
+            const int rem = m - (int)img * HW;
+            const int y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W), x = rem - y * p.W;
+            unsigned mk = 1u;
+            if (p.ntaps == 9) {
+                const unsigned cm = ((unsigned)(x - p.a_sgn) < (unsigned)p.W ? 1u : 0u) | 2u | ((unsigned)(x + p.a_sgn) < (unsigned)p.W ? 4u : 0u);
+                mk = ((unsigned)(y - p.a_sgn) < (unsigned)p.H ? cm : 0u) | (cm << 3) | ((unsigned)(y + p.a_sgn) < (unsigned)p.H ? (cm << 6) : 0u);
+            }
+            a_mask[i] = m < M ? mk : 0u;
+            a_off[i] = (long long)(m < M ? (int)img : 0) * p.A.sN + (long long)(y * p.a_up) * p.A.sH + (long long)(x * p.a_up) * p.A.sW + 4 * aq;
+        }
+        long long b_off[B_LOADS]; unsigned b_okm[B_LOADS], b_tail[B_LOADS];
+        const int tail_c0 = (p.Ck / BK) * BK;              // first channel of a partial last chunk (== Ck rounded down: no partial chunk -> never reached with valid lanes masked)
+        const unsigned a_tail = (tail_c0 + 4 * aq) < Ck4 ? 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i) {
+            if constexpr (!B_RC) {
+                const int n = n0 + ar + K_RPP * i;
+                b_okm[i] = n < p.Ncols ? 1u : 0u; b_tail[i] = 1u;
+                b_off[i] = (long long)n * p.b_sRow + 4 * aq;
+            } else {
+                const int n = n0 + 4 * b_cq;
+                b_okm[i] = n < p.Ncols ? 1u : 0u;
+                b_tail[i] = (tail_c0 + b_kr + B_ROWS_PER_PASS * i) < p.Ck ? 1u : 0u;
+                b_off[i] = (long long)(b_kr + B_ROWS_PER_PASS * i) * p.b_sRow + n;
+            }
+        }
+
+        // D register sets: a stage's gather is issued D stages before it is written to LDS.  At these sizes nearly every load is the
+        // first touch of its line in this XCD's L2 (served by the Infinity Cache: ~2000 cycles under load, measured with cycle stamps),
+        // i.e. two stages' worth of MFMAs; one set in flight left the loop at 2x its matrix time
+        f32x4 a_reg[D][A_LOADS], b_reg[D][B_LOADS];
+        // K order: channel chunk outermost, then phase, tap innermost (the taps of one chunk re-read the same pixels: L2 / L1 hits)
+        const int kq = (int)afi_udiv((unsigned)kc0, (unsigned)p.ntaps, sk.rcp_taps);
+        int k_tap = kc0 - kq * p.ntaps, k_kph = kq & (p.nKphase - 1), k_c0 = (kq >> sk.kph_shift) * BK;   // NEXT stage to gather
+        auto stage_advance = [&]() {
+            if (++k_tap == p.ntaps) {
+                k_tap = 0;
+                if (++k_kph == p.nKphase) { k_kph = 0; k_c0 += BK; }
+            }
+        };
+        // Validity is kept as integer bit masks and every gather is ONE address select + ONE load: a bool && chain with a uniform and
+        // a per-lane part makes hipcc build if/else around the loads, both arms writing the same registers behind `s_waitcnt vmcnt(0)`
+        // (which drains the whole prefetch ring).  Only the last channel chunk can be partial: tail_c0 / *_tail describe it.
+        auto load_all = [&](int set, bool more) {          // gather of stage (k_c0, k_kph, k_tap); !more: past the segment's end, every lane reads the zero page
+            int dy = 0, dx = 0;
+            if (p.ntaps == 9) { dy = k_tap / 3 - 1; dx = k_tap - (k_tap / 3) * 3 - 1; }
+            const long long a_delta = (long long)(dy * p.a_sgn * p.a_up + (k_kph >> 1)) * p.A.sH + (long long)(dx * p.a_sgn * p.a_up + (k_kph & 1)) * p.A.sW + k_c0;
+            const bool is_tail = k_c0 >= tail_c0;          // (uniform)
+            // `more` goes through a VGPR: the loads must be issued UNCONDITIONALLY (a uniform branch around them makes the number of
+            // loads in flight path-dependent, and hipcc then falls back from counted vmcnt(N) waits to vmcnt(0) at every LDS store)
+            unsigned mm = more ? 1u : 0u;
+            asm volatile("" : "+v"(mm));
+            const unsigned ta = (is_tail ? a_tail : 1u) & mm;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) {
+                const unsigned ok = (a_mask[i] >> k_tap) & ta;
+                gfloat* src = ok ? (gfloat*)(p.A.p + (a_off[i] + a_delta)) : zpage;   // branch-free: masked lanes read zeros
+                a_reg[set][i] = *(gf32x4*)src;
+            }
+            if constexpr (!B_RC) {
+                const long long b_delta = (long long)k_tap * p.b_sTap + k_c0;
+#pragma unroll
+                for (int i = 0; i < B_LOADS; ++i) {
+                    const unsigned ok = b_okm[i] & ta;
+                    gfloat* src = ok ? (gfloat*)(p.B + (b_off[i] + b_delta)) : zpage;
+                    b_reg[set][i] = *(gf32x4*)src;
+                }
+            } else {
+                const long long b_delta = (long long)(k_kph * p.Ck + k_c0) * p.b_sRow + (long long)k_tap * p.b_sTap;
+#pragma unroll
+                for (int i = 0; i < B_LOADS; ++i) {
+                    const unsigned ok = b_okm[i] & (is_tail ? b_tail[i] : 1u) & mm;
+                    gfloat* src = ok ? (gfloat*)(p.B + (b_off[i] + b_delta)) : zpage;
+                    b_reg[set][i] = *(gf32x4*)src;
+                }
+            }
+        };
+        auto stage_store = [&](int set, int buf) {
+            float* As = smem + buf * STAGE;
+            float* Bs = As + A_TILE;
+#pragma unroll
+            for (int i = 0; i < A_LOADS; ++i) *(f32x4*)(As + (ar + K_RPP * i) * LDK + 4 * aq) = a_reg[set][i];
+            if constexpr (!B_RC) {
+#pragma unroll
+                for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (ar + K_RPP * i) * LDK + 4 * aq) = b_reg[set][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < B_LOADS; ++i) *(f32x4*)(Bs + (b_kr + B_ROWS_PER_PASS * i) * BN + 4 * b_cq) = b_reg[set][i];
+            }
+        };
+
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+        // double-buffered LDS, D register sets:  stage k's MFMAs read buffer k & 1;  behind them the registers of stage k+1 (gathered D
+        // stages earlier) go to the other buffer, the gather of stage k+1+D is issued into the freed set, ONE barrier closes the stage
+        if (first_seg) AFI_STAMP(1);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { load_all(d, d < nK); stage_advance(); }
+        if (first_seg) AFI_STAMP(2);
+        stage_store(0, 0);
+        load_all(0, D < nK); stage_advance();
+        __syncthreads();
+        if (first_seg) AFI_STAMP(3);
+        for (int kb = 0; kb < nK; kb += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int kc = kb + d;
+                if (kc >= nK) break;                       // (uniform)
+                const float* As = smem + (kc & 1) * STAGE;
+                const float* Bs = As + A_TILE;
+                // two fragment register sets: slice s+1 is read from LDS while the MFMAs of slice s issue
+                f32x4 fa[2], fb[2];
+                auto frag = [&](int set, int s) {
+                    fa[set] = *(const f32x4*)(As + (wm * 32 + lr) * LDK + s * 8 + lh * 4);
+                    if constexpr (!B_RC) {
+                        fb[set] = *(const f32x4*)(Bs + (wn * 32 + lr) * LDK + s * 8 + lh * 4);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fb[set][j] = Bs[(s * 8 + lh * 4 + j) * BN + wn * 32 + lr];
+                    }
+                };
+                frag(0, 0);
+#pragma unroll
+                for (int s = 0; s < BK / 8; ++s) {
+                    if (s + 1 < BK / 8) frag((s + 1) & 1, s + 1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][j], fb[s & 1][j], acc, 0, 0, 0);
+                    // behind the first k-slice's MFMAs (in their shadow, not after the last one): next stage -> other buffer, refill the set
+                    if (s == 0) {                          // (compile time) unconditional, also behind the last stage: its store lands in the idle buffer
+                        stage_store((d + 1) % D, (kc + 1) & 1);
+                        load_all((d + 1) % D, kc + 1 + D < nK); stage_advance();
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        if (first_seg) AFI_STAMP(4);
+
+        const int tile_first = t * sk.nK;
+        const bool whole = (kc0 == 0 && nK == sk.nK);      // (uniform) this block multiplied the tile's whole K range: fused epilogue, no slab
+        if (!whole) {
+            // partial tile: straight from the accumulators into this block's slab (a lane holds one column, 16 rows: every store
+            // instruction writes two 128-B row segments; the slab layout is ours, the reduction pass reads it back as float4 rows)
+            const int slot = lb - afi_sk_owner(tile_first, sk.G, sk.U);
+            float* slab = p.partial + (long long)slot * M * ldp;
+            // each wave turns its own 32x32 block through a private LDS patch into float4 rows (no block barrier: the loop's last
+            // barrier freed the stage buffers, and a wave's LDS instructions execute in order)
+            float* Cw = smem + wave * (32 * LDK);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cw[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDK + lr] = acc[r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int item = lane + 64 * i, rl = item >> 3, c4 = item & 7;
+                const int m = m0 + wm * 32 + rl, col = n0 + wn * 32 + 4 * c4;
+                if (m < M && col < ldp) *(f32x4*)(slab + (long long)m * ldp + col) = *(const f32x4*)(Cw + rl * LDK + 4 * c4);
+            }
+            __syncthreads();                                // the next segment's prologue refills the stage buffers
+        } else {
+            // whole tile: accumulators -> LDS -> float4 rows -> fused epilogue (the last barrier of the loop freed both buffers)
+            constexpr int LDC = BN + 4, C_F4 = BN / 4;
+            static_assert(BM * LDC <= 2 * STAGE, "C staging tile must fit in the operand buffers");
+            float* Cs = smem;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + wn * 32 + lr] = acc[r];
+            __syncthreads();
+            for (int item = tid; item < BM * C_F4; item += NT) {
+                const int rl = item / C_F4, c4 = item - rl * C_F4;
+                const int m = m0 + rl, col = n0 + 4 * c4;
+                if (m >= M || col >= p.Ncols) continue;
+                const unsigned img = afi_udiv((unsigned)m, (unsigned)HW, sk.rcp_HW);
+                const int rem = m - (int)img * HW;
+                const int y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W), x = rem - y * p.W;
+                afi_epilogue_store<false>(p, (int)img, y, x, col, *(const f32x4*)(Cs + rl * LDC + 4 * c4));
+            }
+            __syncthreads();
+        }
+        if (first_seg) AFI_STAMP(5);
+        first_seg = false;
+        u += nK;
+    }
+    AFI_STAMP(8);
+    if constexpr (DIAG) { if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + 7] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+// Second pass: element (m, col) belongs to tile (m / bm, col / bn); its slabs are those of the consecutive blocks that own the
+// tile's units, summed in block order, then the fused epilogue (bias, activation, residuals, bilinear skip, mask, pixel shuffle).
+__global__ __launch_bounds__(256) void afi_pix_sk_reduce_kernel(const AfiPixGemm p, const AfiSkArgs sk, unsigned rcp_cf4, unsigned rcp_bm, unsigned rcp_bn) {
+    const int M = sk.M, HW = sk.HW;
+    const int ldp = (p.Ncols + 3) & ~3;
+    const int C_F4 = ldp >> 2;
+    const int total = M * C_F4;
+    const long long slab = (long long)M * ldp;
+    for (int it = (int)blockIdx.x * 256 + (int)threadIdx.x; it < total; it += (int)gridDim.x * 256) {
+        const int m = (int)afi_udiv((unsigned)it, (unsigned)C_F4, rcp_cf4);
+        const int col = (it - m * C_F4) * 4;
+        const int t = (int)afi_udiv((unsigned)col, (unsigned)sk.bn, rcp_bn) * sk.ntile_m + (int)afi_udiv((unsigned)m, (unsigned)sk.bm, rcp_bm);
+        const int b0 = afi_sk_owner(t * sk.nK, sk.G, sk.U), b1 = afi_sk_owner(t * sk.nK + sk.nK - 1, sk.G, sk.U);
+        const int nparts = b1 - b0 + 1;
+        const float* src = p.partial + (long long)m * ldp + col;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        int ks = 0;
+        for (; ks + 4 <= nparts; ks += 4) {               // four slabs in flight (the pass is latency-bound), fixed order of the adds
+            const f32x4 t0 = *(const f32x4*)(src + (ks + 0) * slab), t1 = *(const f32x4*)(src + (ks + 1) * slab);
+            const f32x4 t2 = *(const f32x4*)(src + (ks + 2) * slab), t3 = *(const f32x4*)(src + (ks + 3) * slab);
+            v += t0; v += t1; v += t2; v += t3;
+        }
+        for (; ks < nparts; ++ks) v += *(const f32x4*)(src + ks * slab);
+        const unsigned img = afi_udiv((unsigned)m, (unsigned)HW, sk.rcp_HW);
+        const int rem = m - (int)img * HW;
+        const int y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W), x = rem - y * p.W;
+        afi_epilogue_store<false>(p, (int)img, y, x, col, v);
+    }
+}
+
+static int sk_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+static unsigned sk_rcp(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ULL << 32) / d) + 1u; }
+
+template <int BM, int BN, int WM, int WN, bool B_RC>
+static int launch_sk(const AfiPixGemm& p, hipStream_t st) {
+    static const int bpc = sk_env_int("AFI_SK_BPC", 2);          // persistent blocks per CU
+    static const int minq = sk_env_int("AFI_SK_MINQ", 4);        // at least this many K stages per block
+    const long long M = (long long)p.N * p.H * p.W;
+    AfiSkArgs sk;
+    sk.ntile_m = afi_cdiv(M, BM); sk.ntile_n = afi_cdiv(p.Ncols, BN);
+    sk.nK = p.ntaps * p.nKphase * afi_cdiv(p.Ck, AFI_BK);
+    const long long U = (long long)sk.ntile_m * sk.ntile_n * sk.nK;
+    const long long Gcap = 256LL * bpc;
+    if (U * Gcap >= (1LL << 31) || M * (long long)p.H * p.W >= (1LL << 32) || M * (((p.Ncols + 3) & ~3) >> 2) >= (1LL << 31)) return AFI_ERR_UNSUPPORTED;   // 32-bit index math
+    sk.U = (int)U; sk.bm = BM; sk.bn = BN; sk.M = (int)M; sk.HW = p.H * p.W;
+    sk.rcp_HW = sk_rcp((unsigned)sk.HW); sk.rcp_W = sk_rcp((unsigned)p.W); sk.rcp_taps = sk_rcp((unsigned)p.ntaps);
+    sk.kph_shift = p.nKphase == 4 ? 2 : 0;
+    if (p.nKphase != 1 && p.nKphase != 4) return AFI_ERR_UNSUPPORTED;
+    const long long slab = M * ((p.Ncols + 3) & ~3);
+    const long long ntiles = (long long)sk.ntile_m * sk.ntile_n;
+    long long G;
+    if (sk.nK <= 16 || ntiles >= Gcap) {
+        G = ntiles;                                       // short K or enough tiles: whole tiles, fused epilogue, no second pass
+    } else {
+        // equal slices of ONE tile per block where a divisor of nK fits: splits = the largest s with s | nK, ntiles * s <= Gcap and
+        // nK / s >= minq; otherwise the general stream-K partition with G = Gcap
+        int best = 1;
+        for (int s2 = 1; s2 <= sk.nK; ++s2)
+            if (sk.nK % s2 == 0 && ntiles * s2 <= Gcap && sk.nK / s2 >= minq) best = s2;
+        G = ntiles * best;
+        if (G * 10 < Gcap * 8) {                          // the best divisor leaves > 20 % of the block slots empty: general partition
+            G = Gcap;
+            if (G > U / minq) G = U / minq;
+            if (G < ntiles) G = ntiles;
+        }
+        for (;;) {                                        // the slabs of the most-shared tile must fit the caller's scratch
+            const long long qmin = U / G;                 // fewest units a block owns
+            const long long smax = (sk.nK + qmin - 1) / qmin + 1;
+            if (G <= ntiles || smax * slab <= p.partial_floats) break;
+            G -= (G - ntiles) > 8 ? 8 : (G - ntiles);
+        }
+    }
+    sk.G = (int)G;
+    const bool second_pass = G > ntiles;
+    if (second_pass && (!p.partial || p.partial_floats <= 0)) return AFI_ERR_UNSUPPORTED;
+    const size_t lds = sizeof(float) * 2 * (BM * (AFI_BK + 4) + (B_RC ? AFI_BK * BN : BN * (AFI_BK + 4)));
+    sk.dbg = nullptr;
+    static const char* diag = getenv("AFI_SK_DIAG");          // diagnostic: dump per-block cycle stamps of every launch (synchronises!)
+    if (diag) {
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, sizeof(unsigned long long) * 10 * G) != hipSuccess) return AFI_ERR_LAUNCH;
+        (void)hipMemset(d, 0, sizeof(unsigned long long) * 10 * G);
+        sk.dbg = d;
+        hipLaunchKernelGGL((afi_pix_gemm_sk_kernel<BM, BN, WM, WN, B_RC, true>), dim3((unsigned)G), dim3(256), lds, st, p, sk);
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(10 * G);
+        (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * 10 * G, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        FILE* f = fopen(diag, "a");
+        if (f) {
+            unsigned long long r0 = ~0ULL, r1 = 0;
+            for (long long b = 0; b < G; ++b) { if (h[b * 10 + 6] < r0) r0 = h[b * 10 + 6]; if (h[b * 10 + 7] > r1) r1 = h[b * 10 + 7]; }
+            fprintf(f, "launch BM=%d BN=%d rc=%d M=%lld N=%d nK=%d G=%lld U=%lld span_us=%.2f\n", BM, BN, (int)B_RC, M, p.Ncols, sk.nK, G, U, (r1 - r0) * 0.01);
+            for (long long b = 0; b < G; b += (G > 64 ? G / 32 : 1)) {
+                const unsigned long long* e = &h[b * 10];
+                fprintf(f, "  blk %4lld start_us %.2f end_us %.2f | cyc: decode %lld issue %lld firstdata %lld loop %lld epi %lld | clk_MHz %.0f\n", b, (e[6] - r0) * 0.01, (e[7] - r0) * 0.01,
+                        (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]), (long long)(e[5] - e[4]),
+                        (e[7] > e[6]) ? (double)(e[8] - e[0]) / ((e[7] - e[6]) * 0.01) : 0.0);
+            }
+            fclose(f);
+        }
+    } else
+    hipLaunchKernelGGL((afi_pix_gemm_sk_kernel<BM, BN, WM, WN, B_RC>), dim3((unsigned)G), dim3(256), lds, st, p, sk);
+    if (second_pass) {
+        const int cf4 = ((p.Ncols + 3) & ~3) >> 2;
+        const long long items = M * cf4;
+        long long g = (items + 255) / 256; if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(afi_pix_sk_reduce_kernel, dim3((unsigned)g), dim3(256), 0, st, p, sk, sk_rcp((unsigned)cf4), sk_rcp((unsigned)BM), sk_rcp((unsigned)BN));
+    }
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+template <bool B_RC> static int launch_wk(const AfiPixGemm& p, hipStream_t st);
+// Small-map form of a pixel GEMM: stream-K / even split-K with a slab reduction for long K, whole tiles with the fused epilogue for
+// short K.  AFI_ERR_UNSUPPORTED = "not this path" (the caller falls back to the tiled kernels).
+int afi_launch_pix_gemm_sk(const AfiPixGemm& p, int b_rc, hipStream_t st) {
+    static const int on = sk_env_int("AFI_SK", 1);
+    if (!on || p.gtap || p.b_sImg != 0) return AFI_ERR_UNSUPPORTED;
+    if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_UNSUPPORTED;
+    static const int wk_on = sk_env_int("AFI_WK", 1);      // K split inside the block (no second pass); AFI_WK=0: the stream-K form
+    if (wk_on) {
+        const int rc = b_rc ? launch_wk<true>(p, st) : launch_wk<false>(p, st);
+        if (rc != AFI_ERR_UNSUPPORTED) return rc;
+    }
+    if (p.Ncols <= 32) return b_rc ? launch_sk<128, 32, 4, 1, true>(p, st) : launch_sk<128, 32, 4, 1, false>(p, st);
+    return b_rc ? launch_sk<64, 64, 2, 2, true>(p, st) : launch_sk<64, 64, 2, 2, false>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// afi_pix_gemm_wk_kernel: the small-map pixel GEMM with the K split INSIDE the block.
+//   One block = one 32 x 32 output tile = 8 waves (two per SIMD); wave w multiplies the tile's K stages [w*nK/8, (w+1)*nK/8) into its
+//   own 32x32 accumulator block; the eight partial blocks meet in LDS and the fused epilogue stores the tile.  850 x 256 outputs are
+//   216 tiles, so the grid fills the chip with whole tiles and there is NO cross-block reduction: no slabs, no second launch (the
+//   stream-K form above needs one, 5 us each at these sizes: 24 launches per interpolator forward + backward).
+//   Each wave stages its OWN operand slices (32 rows x 32 k of A and of B) through a private LDS patch, so the K loop has no
+//   block barrier at all: global -> registers (two sets in flight) -> LDS -> all fragments of a stage in registers (two sets) ->
+//   16 MFMAs; a wave's LDS instructions execute in order, which is all the synchronisation the loop needs.
+//   Price: no operand sharing between waves, i.e. 2x the L2 -> CU traffic of a 64x64 tile (32 B/clk/CU at the matrix-pipe rate).
+struct AfiWkArgs {
+    int ntile_m, ntile_n, nK;  // tiles of 32 x 32 (tile id = tile_n * ntile_m + tile_m), K stages per tile
+    int M, HW;
+    unsigned rcp_HW, rcp_W, rcp_taps, rcp_ntm;
+    int kph_shift;
+    unsigned long long* dbg;   // diagnostic build only
+};
+// Fused epilogue with every optional operand loaded UP FRONT (address select to the zero page when a term is off, its scale then 0):
+// the generic afi_epilogue_store reads O_old, R1, R2 and Z one after the other behind uniform branches, i.e. up to four memory
+// latencies in a row -- 3 us at the end of a kernel whose whole K loop takes 1.5 us.  Same arithmetic, same order of the adds.
+typedef const __attribute__((address_space(1))) float afi_gfloat;
+typedef const __attribute__((address_space(1))) f32x4 afi_gf32x4;
+__device__ __forceinline__ void afi_epilogue_store_fast(const AfiPixGemm& p, int img, int y, int x, int col, f32x4 accv, afi_gfloat* zpage) {
+    int phase = 0, ch = col;
+    if (p.o_up == 2) { phase = col / p.CoutPhase; ch = col - phase * p.CoutPhase; }
+    const int yo = y * p.o_up + (phase >> 1), xo = x * p.o_up + (phase & 1);
+    if (yo >= p.oH || xo >= p.oW) return;
+    float* dst = p.O.p + (long long)img * p.O.sN + (long long)yo * p.O.sH + (long long)xo * p.O.sW + ch;
+    const bool use_old = p.beta != 0.f;
+    const bool use_r1 = p.R1.p && !p.r1_bilinear && ch >= p.r1_lo && ch < p.r1_hi;
+    const bool use_r2 = p.R2.p && ch >= p.r2_lo && ch < p.r2_hi;
+    const bool use_z = p.Z.p && ch >= p.z_lo && ch < p.z_hi;
+    afi_gfloat* a_b = p.bias ? (afi_gfloat*)(p.bias + ch) : zpage;
+    afi_gfloat* a_o = use_old ? (afi_gfloat*)dst : zpage;
+    afi_gfloat* a_1 = use_r1 ? (afi_gfloat*)(p.R1.p + (long long)img * p.R1.sN + (long long)yo * p.R1.sH + (long long)xo * p.R1.sW + ch) : zpage;
+    afi_gfloat* a_2 = use_r2 ? (afi_gfloat*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch) : zpage;
+    afi_gfloat* a_z = use_z ? (afi_gfloat*)(p.Z.p + (long long)img * p.Z.sN + (long long)yo * p.Z.sH + (long long)xo * p.Z.sW + ch) : zpage;
+    const f32x4 bv = *(afi_gf32x4*)a_b, ov = *(afi_gf32x4*)a_o, r1 = *(afi_gf32x4*)a_1, r2 = *(afi_gf32x4*)a_2, zv = *(afi_gf32x4*)a_z;
+    f32x4 v = p.alpha * accv;
+    v += bv;
+    if (use_old) v += p.beta * ov;
+    if (use_r1) v += p.r1s * r1;
+    if (p.R1.p && p.r1_bilinear && ch >= p.r1_lo && ch < p.r1_hi) {      // (uniform) only the interpolator's last conv
+        int by0, by1, bx0, bx1; float ly, lx;
+        afi_bil_idx(y, p.H >> 1, by0, by1, ly); afi_bil_idx(x, p.W >> 1, bx0, bx1, lx);
+        const float* rb = p.R1.p + (long long)img * p.R1.sN + ch;
+        const f32x4 x00 = *(const f32x4*)(rb + (long long)by0 * p.R1.sH + (long long)bx0 * p.R1.sW);
+        const f32x4 x01 = *(const f32x4*)(rb + (long long)by0 * p.R1.sH + (long long)bx1 * p.R1.sW);
+        const f32x4 x10 = *(const f32x4*)(rb + (long long)by1 * p.R1.sH + (long long)bx0 * p.R1.sW);
+        const f32x4 x11 = *(const f32x4*)(rb + (long long)by1 * p.R1.sH + (long long)bx1 * p.R1.sW);
+        const f32x4 top = x00 * (1.f - lx) + x01 * lx;
+        const f32x4 bot = x10 * (1.f - lx) + x11 * lx;
+        v += p.r1s * (top * (1.f - ly) + bot * ly);
+    }
+    if (use_r2) v += p.r2s * r2;
+    if (p.lrelu) {
+        const float slope = (p.lrelu == 1) ? AFI_LRELU_SLOPE : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
+    }
+    if (use_z) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= (zv[j] > 0.f ? 1.f : AFI_LRELU_SLOPE);
+    }
+    *(f32x4*)dst = v;
+}
+
+template <bool B_RC, bool DIAG = false>
+__global__ __launch_bounds__(512, 2) void afi_pix_gemm_wk_kernel(const AfiPixGemm p, const AfiWkArgs sk) {
+    constexpr int BK = AFI_BK, LDK = BK + 4, NW = 8, D = 2;
+    constexpr int A_TILE = 32 * LDK, PATCH = 2 * 32 * LDK;   // per-wave LDS patch: A [32][LDK] + B ([32][LDK] or [32 k][32 n]); >= one 32 x LDK partial tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    if constexpr (DIAG) { if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + 6] = __builtin_amdgcn_s_memrealtime(); }
+    AFI_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int q8 = lane & 7, r8 = lane >> 3;               // staging: float4 column, first row (8 rows per pass, 4 passes)
+    const int M = sk.M, HW = sk.HW;
+    const int Ck4 = (p.Ck + 3) & ~3;
+    // Gathers are raw BUFFER loads: 32-bit byte offsets (the launcher checks both operands stay below 2 GB), one v_add + one
+    // v_cndmask per load, and a masked lane's offset (0xFFFFFFFF) is out of range: the hardware returns zeros without touching memory
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A.p, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFF0, 0x00020000);
+    int lb;
+    {   // XCD-contiguous logical tile ids (bijective for any grid)
+        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = blockIdx.x & 7;
+        lb = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (int)(blockIdx.x >> 3);
+    }
+    const int tile_n = (int)afi_udiv((unsigned)lb, (unsigned)sk.ntile_m, sk.rcp_ntm), tile_m = lb - tile_n * sk.ntile_m;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int kc0 = wave_u * sk.nK / NW, kc1 = (wave_u + 1) * sk.nK / NW;   // this wave's K stages
+    const int nK = kc1 - kc0;
+    float* As = smem + wave_u * PATCH;
+    float* Bs = As + A_TILE;
+
+    // ---- loader state (per lane: 4 rows of A, 4 rows of B): byte offsets, validity as bit masks
+    unsigned a_off[4], a_mask[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r8 + 8 * i;
+        const unsigned img = afi_udiv((unsigned)m, (unsigned)HW, sk.rcp_HW);
+        const int rem = m - (int)img * HW;
+        const int y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W), x = rem - y * p.W;
+        unsigned mk = 1u;
+        if (p.ntaps == 9) {
+            const unsigned cm = ((unsigned)(x - p.a_sgn) < (unsigned)p.W ? 1u : 0u) | 2u | ((unsigned)(x + p.a_sgn) < (unsigned)p.W ? 4u : 0u);
+            mk = ((unsigned)(y - p.a_sgn) < (unsigned)p.H ? cm : 0u) | (cm << 3) | ((unsigned)(y + p.a_sgn) < (unsigned)p.H ? (cm << 6) : 0u);
+        }
+        a_mask[i] = m < M ? mk : 0u;
+        a_off[i] = 4u * (unsigned)((m < M ? (int)img : 0) * (int)p.A.sN + (y * p.a_up) * (int)p.A.sH + (x * p.a_up) * (int)p.A.sW + 4 * q8);
+    }
+    const int tail_c0 = (p.Ck / BK) * BK;                  // first channel of a partial last chunk
+    const unsigned a_tail = (tail_c0 + 4 * q8) < Ck4 ? 1u : 0u;
+    unsigned b_off[4], b_okm[4], b_tail[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (!B_RC) {
+            const int n = n0 + r8 + 8 * i;
+            b_okm[i] = n < p.Ncols ? 1u : 0u; b_tail[i] = 1u;
+            b_off[i] = 4u * (unsigned)(n * (int)p.b_sRow + 4 * q8);
+        } else {
+            const int n = n0 + 4 * q8;
+            b_okm[i] = n < p.Ncols ? 1u : 0u;
+            b_tail[i] = (tail_c0 + r8 + 8 * i) < p.Ck ? 1u : 0u;
+            b_off[i] = 4u * (unsigned)((r8 + 8 * i) * (int)p.b_sRow + n);
+        }
+    }
+    const int kq = (int)afi_udiv((unsigned)kc0, (unsigned)p.ntaps, sk.rcp_taps);
+    int k_tap = kc0 - kq * p.ntaps, k_kph = kq & (p.nKphase - 1), k_c0 = (kq >> sk.kph_shift) * BK;   // NEXT stage to gather
+    auto stage_advance = [&]() {
+        if (++k_tap == p.ntaps) {
+            k_tap = 0;
+            if (++k_kph == p.nKphase) { k_kph = 0; k_c0 += BK; }
+        }
+    };
+    u32x4 a_reg[D][4], b_reg[D][4];
+    auto load_all = [&](int set, bool more) {              // the loads are issued UNCONDITIONALLY (counted vmcnt waits need a path-independent count)
+        int dy = 0, dx = 0;
+        if (p.ntaps == 9) { dy = k_tap / 3 - 1; dx = k_tap - (k_tap / 3) * 3 - 1; }
+        const int a_delta = 4 * ((dy * p.a_sgn * p.a_up + (k_kph >> 1)) * (int)p.A.sH + (dx * p.a_sgn * p.a_up + (k_kph & 1)) * (int)p.A.sW + k_c0);
+        const bool is_tail = k_c0 >= tail_c0;
+        unsigned mm = more ? 1u : 0u;
+        asm volatile("" : "+v"(mm));
+        const unsigned ta = (is_tail ? a_tail : 1u) & mm;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned ok = (a_mask[i] >> k_tap) & ta;
+            a_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_off[i] + (unsigned)a_delta : 0xFFFFFFFFu, 0, 0);
+        }
+        if constexpr (!B_RC) {
+            const int b_delta = 4 * (k_tap * (int)p.b_sTap + k_c0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ok = b_okm[i] & ta;
+                b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ok ? b_off[i] + (unsigned)b_delta : 0xFFFFFFFFu, 0, 0);
+            }
+        } else {
+            const int b_delta = 4 * ((k_kph * p.Ck + k_c0) * (int)p.b_sRow + k_tap * (int)p.b_sTap);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned ok = b_okm[i] & (is_tail ? b_tail[i] : 1u) & mm;
+                b_reg[set][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, ok ? b_off[i] + (unsigned)b_delta : 0xFFFFFFFFu, 0, 0);
+            }
+        }
+    };
+    auto stage_store = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(u32x4*)(As + (r8 + 8 * i) * LDK + 4 * q8) = a_reg[set][i];
+        if constexpr (!B_RC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(Bs + (r8 + 8 * i) * LDK + 4 * q8) = b_reg[set][i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(u32x4*)(Bs + (r8 + 8 * i) * 32 + 4 * q8) = b_reg[set][i];
+        }
+    };
+    f32x4 fa[2][4], fb[2][4];                              // all fragments of a stage, two sets
+    auto read_frags = [&](int set) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            fa[set][s] = *(const f32x4*)(As + lr * LDK + s * 8 + lh * 4);
+            if constexpr (!B_RC) {
+                fb[set][s] = *(const f32x4*)(Bs + lr * LDK + s * 8 + lh * 4);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[set][s][j] = Bs[(s * 8 + lh * 4 + j) * 32 + lr];
+            }
+        }
+    };
+    auto lds_order = [&]() {                               // (lgkmcnt only) a wave's LDS instructions execute in order; this pins the compiler's order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    AFI_STAMP(1);
+#pragma unroll
+    for (int d = 0; d < D; ++d) { load_all(d, d < nK); stage_advance(); }
+    AFI_STAMP(2);
+    stage_store(0);
+    lds_order();
+    read_frags(0);
+    load_all(0, D < nK); stage_advance();
+    AFI_STAMP(3);
+    for (int kb = 0; kb < nK; kb += 2) {
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int kc = kb + d;
+            if (kc >= nK) break;                           // (uniform per wave)
+            // stage kc's fragments are in registers (set d): the patch is free for stage kc+1, whose registers were gathered D stages ago
+            stage_store((d + 1) % D);
+            lds_order();
+            read_frags((d + 1) & 1);
+            load_all((d + 1) % D, kc + 1 + D < nK); stage_advance();
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[d][s][j], fb[d][s][j], acc, 0, 0, 0);
+        }
+    }
+    AFI_STAMP(4);
+    // ---- the eight partial blocks meet in LDS (each wave writes into its own patch), then 256 threads sum and run the fused epilogue
+    lds_order();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDK + lr] = acc[r];
+    __syncthreads();
+    if (tid < 256) {
+        const int rl = tid >> 3, c4 = tid & 7;
+        const int m = m0 + rl, col = n0 + 4 * c4;
+        if (m < M && col < p.Ncols) {
+            afi_gfloat* zpage = (afi_gfloat*)afi_zeros;
+            asm volatile("" : "+v"(zpage));
+            f32x4 v = *(const f32x4*)(smem + rl * LDK + 4 * c4);
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += *(const f32x4*)(smem + w * PATCH + rl * LDK + 4 * c4);     // fixed order: bit-reproducible
+            const unsigned img = afi_udiv((unsigned)m, (unsigned)HW, sk.rcp_HW);
+            const int rem = m - (int)img * HW;
+            const int y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W), x = rem - y * p.W;
+            afi_epilogue_store_fast(p, (int)img, y, x, col, v, zpage);
+        }
+    }
+    AFI_STAMP(5);
+    AFI_STAMP(8);
+    if constexpr (DIAG) { if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + 7] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+template <bool B_RC>
+static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
+    const long long M = (long long)p.N * p.H * p.W;
+    if (p.nKphase != 1 && p.nKphase != 4) return AFI_ERR_UNSUPPORTED;
+    if (M * (long long)p.H * p.W >= (1LL << 32) || M >= (1LL << 30)) return AFI_ERR_UNSUPPORTED;   // 32-bit index math, reciprocal division
+    {   // buffer loads address both operands with 32-bit byte offsets below 2 GB
+        auto ab = [](long long v) { return v < 0 ? -v : v; };
+        const long long a_ext = (ab(p.A.sN) * p.N + ab(p.A.sH) * ((long long)p.H * p.a_up + 2) + ab(p.A.sW) * ((long long)p.W * p.a_up + 2) + p.Ck + 64) * 4;
+        const long long b_rows = B_RC ? (long long)p.nKphase * p.Ck : p.Ncols;
+        const long long b_ext = (ab(p.b_sRow) * (b_rows + 32) + ab(p.b_sTap) * p.ntaps + (B_RC ? p.Ncols : p.Ck) + 64) * 4;
+        if (p.A.sN < 0 || p.A.sH < 0 || p.A.sW < 0 || p.b_sRow < 0 || p.b_sTap < 0 || a_ext >= 0x7FFFFFF0LL || b_ext >= 0x7FFFFFF0LL) return AFI_ERR_UNSUPPORTED;
+    }
+    AfiWkArgs wk;
+    wk.ntile_m = afi_cdiv(M, 32); wk.ntile_n = afi_cdiv(p.Ncols, 32);
+    wk.nK = p.ntaps * p.nKphase * afi_cdiv(p.Ck, AFI_BK);
+    wk.M = (int)M; wk.HW = p.H * p.W;
+    wk.rcp_HW = sk_rcp((unsigned)wk.HW); wk.rcp_W = sk_rcp((unsigned)p.W); wk.rcp_taps = sk_rcp((unsigned)p.ntaps); wk.rcp_ntm = sk_rcp((unsigned)wk.ntile_m);
+    wk.kph_shift = p.nKphase == 4 ? 2 : 0;
+    wk.dbg = nullptr;
+    const long long G = (long long)wk.ntile_m * wk.ntile_n;
+    if (G * wk.ntile_m >= (1LL << 32)) return AFI_ERR_UNSUPPORTED;
+    constexpr int LDK = AFI_BK + 4;
+    const size_t lds = sizeof(float) * 8 * (2 * 32 * LDK);
+    static const char* diag = getenv("AFI_SK_DIAG");
+    if (diag) {
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, sizeof(unsigned long long) * 10 * G) != hipSuccess) return AFI_ERR_LAUNCH;
+        (void)hipMemset(d, 0, sizeof(unsigned long long) * 10 * G);
+        wk.dbg = d;
+        hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(10 * G);
+        (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * 10 * G, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        FILE* f = fopen(diag, "a");
+        if (f) {
+            unsigned long long r0 = ~0ULL, r1 = 0;
+            for (long long b = 0; b < G; ++b) { if (h[b * 10 + 6] < r0) r0 = h[b * 10 + 6]; if (h[b * 10 + 7] > r1) r1 = h[b * 10 + 7]; }
+            fprintf(f, "launch WK rc=%d M=%lld N=%d nK=%d G=%lld span_us=%.2f\n", (int)B_RC, M, p.Ncols, wk.nK, G, (r1 - r0) * 0.01);
+            for (long long b = 0; b < G; b += (G > 64 ? G / 16 : 1)) {
+                const unsigned long long* e = &h[b * 10];
+                fprintf(f, "  blk %4lld start_us %.2f end_us %.2f | cyc: decode %lld issue %lld firstdata %lld loop %lld epi %lld | clk_MHz %.0f\n", b, (e[6] - r0) * 0.01, (e[7] - r0) * 0.01,
+                        (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]), (long long)(e[5] - e[4]),
+                        (e[7] > e[6]) ? (double)(e[8] - e[0]) / ((e[7] - e[6]) * 0.01) : 0.0);
+            }
+            fclose(f);
+        }
+    } else
+    hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped weight gradients: one launch, a table of problems, each block owns a whole dW tile (no split over pixels)
+// ------------------------------------------------------------------------------------------------
+#define AFI_WG_MAXP 20
+struct AfiWgradGroup {
+    int nprob;
+    int blk_start[AFI_WG_MAXP + 1];                        // prefix sums of blocks (ntile_m * ntile_n * ntaps * nsplit) per problem
+    short ntile_m[AFI_WG_MAXP], ntile_n[AFI_WG_MAXP];
+    short nsplit[AFI_WG_MAXP];                             // pixel-range slices per tile (> 1: the partial sums meet in fp32 atomics)
+    int kper[AFI_WG_MAXP];                                 // pixels per slice (multiple of 32)
+    AfiWgradGemm g[AFI_WG_MAXP];
+};
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_group_kernel(const AfiWgradGroup grp) {
+    // bijective XCD remap: blocks b, b+8, .. share an XCD; give each XCD a contiguous run of logical blocks
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    int pi = 0;
+    while (pi + 1 < grp.nprob && t >= grp.blk_start[pi + 1]) ++pi;      // (uniform) <= 20 entries
+    const AfiWgradGemm& p = grp.g[pi];
+    const int ns = grp.nsplit[pi];
+    const int lt = t - grp.blk_start[pi];                  // slices of one tile are adjacent: they share both operand tiles' columns
+    afi_wgrad_gemm_body<BM, BN, WM, WN>(p, grp.ntile_m[pi], grp.ntile_n[pi], grp.kper[pi], lt / ns, lt % ns, ns > 1);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_wgrad_group(const AfiWgradGemm* probs, int n, hipStream_t st) {
+    static const int stages = sk_env_int("AFI_WG_STAGES", 14);    // K stages (of 32 pixels) per block: 850 pixels -> 2 slices, 3400 -> 8
+    AfiWgradGroup grp;
+    int done = 0;
+    while (done < n) {
+        const int cnt = (n - done) < AFI_WG_MAXP ? (n - done) : AFI_WG_MAXP;
+        grp.nprob = cnt;
+        int blocks = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const AfiWgradGemm& g = probs[done + i];
+            if ((g.Ncols & 3) || (g.dy_up == 2 && (g.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;
+            grp.g[i] = g;
+            const long long P = (long long)g.N * g.H * g.W;
+            const int nst = afi_cdiv(P, AFI_BK);
+            int ns = stages > 0 ? afi_cdiv(nst, stages) : 1;
+            if (ns > 64) ns = 64;
+            const int kper = afi_cdiv(nst, ns) * AFI_BK;
+            ns = afi_cdiv(P, kper);                        // no empty slices
+            grp.ntile_m[i] = (short)afi_cdiv(g.Mrows, BM); grp.ntile_n[i] = (short)afi_cdiv(g.Ncols, BN);
+            grp.nsplit[i] = (short)ns; grp.kper[i] = kper;
+            grp.blk_start[i] = blocks;
+            blocks += grp.ntile_m[i] * grp.ntile_n[i] * g.ntaps * ns;
+        }
+        grp.blk_start[cnt] = blocks;
+        for (int i = cnt + 1; i <= AFI_WG_MAXP; ++i) grp.blk_start[i] = blocks;
+        hipLaunchKernelGGL((afi_wgrad_group_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(64 * WM * WN), sizeof(float) * AFI_BK * (BM + BN), st, grp);
+        done += cnt;
+    }
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// wide = 0: problems with <= 32 rows (the RDB growth convs), 32 x 128 tiles; wide = 1: 128 x 128 tiles.  Problems are sorted by
+// the caller, longest pixel range first (the dispatcher hands blocks out in order: long tiles early, short ones fill the tail).
+int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st) {
+    if (n <= 0) return AFI_OK;
+    return wide ? launch_wgrad_group<128, 128, 1, 4>(probs, n, st) : launch_wgrad_group<32, 128, 1, 4>(probs, n, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped bias gradients: db[c] += alpha * sum_rows g[row][c] for up to 8 matrices in one launch (fp32 atomics: a few thousand adds)
+// ------------------------------------------------------------------------------------------------
+#define AFI_CS_MAXP 8
+struct AfiColsumGroup {
+    int nprob;
+    int blk_start[AFI_CS_MAXP + 1];
+    struct { const float* g; float* db; long long P, ld; int C; int rows_per_blk; float alpha; int pad; } d[AFI_CS_MAXP];
+};
+__global__ __launch_bounds__(256) void afi_colsum_group_kernel(const AfiColsumGroup grp) {
+    __shared__ f32x4 red[16][16];
+    int pi = 0;
+    const int b = blockIdx.x;
+    while (pi + 1 < grp.nprob && b >= grp.blk_start[pi + 1]) ++pi;
+    const auto& d = grp.d[pi];
+    const int lbk = b - grp.blk_start[pi];
+    const int ccs = (d.C + 63) / 64;                       // 64-channel column groups
+    const int cg = lbk % ccs, rc = lbk / ccs;
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = cg * 64 + cq * 4;
+    const long long r0 = (long long)rc * d.rows_per_blk;
+    const long long r1 = (r0 + d.rows_per_blk < d.P) ? r0 + d.rows_per_blk : d.P;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < d.C)
+        for (long long r = r0 + rl; r < r1; r += 16) s += *(const f32x4*)(d.g + r * d.ld + c);
+    red[rl][cq] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cc = threadIdx.x >> 2, j = threadIdx.x & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][cc][j];
+        const int ch = cg * 64 + cc * 4 + j;
+        if (ch < d.C) atomicAdd(d.db + ch, d.alpha * v);
+    }
+}
+int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st) {
+    if (n <= 0) return AFI_OK;
+    if (n > AFI_CS_MAXP) return AFI_ERR_BAD_ARG;
+    AfiColsumGroup grp;
+    grp.nprob = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (probs[i].C & 3) return AFI_ERR_UNSUPPORTED;
+        const int rpb = 128;                               // rows per block: 850 rows -> 7 blocks per column group
+        grp.d[i].g = probs[i].g; grp.d[i].db = probs[i].db; grp.d[i].P = probs[i].P; grp.d[i].ld = probs[i].ld;
+        grp.d[i].C = probs[i].C; grp.d[i].rows_per_blk = rpb; grp.d[i].alpha = probs[i].alpha; grp.d[i].pad = 0;
+        grp.blk_start[i] = blocks;
+        blocks += ((probs[i].C + 63) / 64) * afi_cdiv(probs[i].P, rpb);
+    }
+    for (int i = n; i <= AFI_CS_MAXP; ++i) grp.blk_start[i] = blocks;
+    hipLaunchKernelGGL(afi_colsum_group_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grp);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
