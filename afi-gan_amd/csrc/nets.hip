@@ -16,6 +16,7 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
 int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // smallmap.hip
 int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st);
+int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
@@ -731,15 +732,55 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
         g.lrelu = 1;
         AFI_TRY(PG(g, 0));
     }
+    // Small maps: the dense block in COLUMN-BATCHED form.  conv_k reads cat(x, y1 .. y_{k-1}); instead of five convs whose K grows
+    // (and whose four 32-column outputs are 27 tiles each, for 256 CUs), five steps whose source is ONE slice: step 0 multiplies x into
+    // the columns of all five convs in one grouped launch (384 columns, K = 9*C), step j = 1..4 multiplies y_j (32 channels, K = 288)
+    // into the convs that still need it; a conv's slice accumulates in place (beta = 1) and is activated by the step that completes
+    // it.  Same multiply-adds as generator_rdb.py:64-71, summed in another order (fp32 rounding only).  AFI_RDB_BATCH=0: conv by conv.
+    static const int rdb_batch = getenv("AFI_RDB_BATCH") ? atoi(getenv("AFI_RDB_BATCH")) : 1;
+    const bool batched = rdb_batch && l.P < 1024 && 4 * l.P <= kSideStreamMaxPixels;
     for (int r = 0; r < R; ++r) {   // ResidualDenseBlock.forward (generator_rdb.py:64-71); the dense buffer replaces torch.cat
         AfiView b = buf(r);
+        const bool last = (r == R - 1);
+        auto conv5_desc = [&](int c_lo, int nch) {      // conv5 restricted to input channels [c_lo, c_lo + nch)
+            AfiPixGemm g = conv_fwd_desc(ch_off(b, c_lo), N, H, W, nch, prm->rdb_w[r][4] + c_lo, nullptr, C, last ? t : buf(r + 1));
+            g.b_sRow = 9LL * L; g.b_sTap = L;
+            g.alpha = last ? rs * rs : rs;
+            return g;
+        };
+        if (batched) {
+            for (int j = 0; j <= 4; ++j) {              // source slice j: x (j = 0) or y_j
+                const int c_lo = j == 0 ? 0 : C + (j - 1) * G, nch = j == 0 ? C : G;
+                AfiPixGemm probs[5];
+                int n = 0;
+                for (int k = j + 1; k <= 4; ++k) {      // growth conv k, its input channels [c_lo, c_lo + nch)
+                    const int cin = C + (k - 1) * G;
+                    AfiPixGemm g = conv_fwd_desc(ch_off(b, c_lo), N, H, W, nch, prm->rdb_w[r][k - 1] + c_lo, nullptr, G, ch_off(b, cin));
+                    g.b_sRow = 9LL * cin; g.b_sTap = cin;
+                    g.beta = j == 0 ? 0.f : 1.f;
+                    g.lrelu = (k == j + 1) ? 1 : 0;     // this step completes conv_k
+                    probs[n++] = g;
+                }
+                AfiPixGemm g5 = conv5_desc(c_lo, nch);
+                if (j == 0) {                           // residual terms ride on the first step (no activation follows conv5)
+                    g5.R1 = b; g5.r1_lo = 0; g5.r1_hi = C; g5.r1s = last ? rs : 1.f;
+                    if (last) { g5.R2 = buf(0); g5.r2s = 1.f; g5.r2_lo = 0; g5.r2_hi = C; }
+                } else {
+                    g5.beta = 1.f;
+                }
+                probs[n++] = g5;
+                const int rc = afi_launch_pix_gemm_wk_group(probs, n, 0, st);
+                if (rc == AFI_ERR_UNSUPPORTED) { for (int i = 0; i < n; ++i) AFI_TRY(PG(probs[i], 0)); }   // same step, one launch per conv
+                else AFI_TRY(rc);
+            }
+            continue;
+        }
         for (int k = 1; k <= 4; ++k) {
             const int cin = C + (k - 1) * G;
             AfiPixGemm g = conv_fwd_desc(b, N, H, W, cin, prm->rdb_w[r][k - 1], nullptr, G, ch_off(b, cin));
             g.lrelu = 1;
             AFI_TRY(PG(g, 0));
         }
-        const bool last = (r == R - 1);
         AfiPixGemm g = conv_fwd_desc(b, N, H, W, L, prm->rdb_w[r][4], nullptr, C, last ? t : buf(r + 1));
         g.R1 = b; g.r1_lo = 0; g.r1_hi = C;
         if (!last) {            // x + rs * conv5

@@ -493,9 +493,11 @@ __device__ __forceinline__ void afi_epilogue_store_fast(const AfiPixGemm& p, int
     *(f32x4*)dst = v;
 }
 
-template <bool B_RC, bool DIAG = false>
-__global__ __launch_bounds__(512, 2) void afi_pix_gemm_wk_kernel(const AfiPixGemm p, const AfiWkArgs sk) {
-    constexpr int BK = AFI_BK, LDK = BK + 4, NW = 8, D = 2;
+// LEAN: one register set in flight and one fragment set (<= 128 registers): TWO blocks per CU = four waves per SIMD, whose interleaving
+// covers the memory latency instead of the second register set; for grids with more blocks than CUs (N = 384 .. 1024 columns)
+template <bool B_RC, bool LEAN, bool DIAG>
+__device__ __forceinline__ void afi_wk_body(const AfiPixGemm& p, const AfiWkArgs& sk, const int lb) {
+    constexpr int BK = AFI_BK, LDK = BK + 4, NW = 8, D = LEAN ? 1 : 2, FS = LEAN ? 1 : 2;
     constexpr int A_TILE = 32 * LDK, PATCH = 2 * 32 * LDK;   // per-wave LDS patch: A [32][LDK] + B ([32][LDK] or [32 k][32 n]); >= one 32 x LDK partial tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -510,11 +512,6 @@ __global__ __launch_bounds__(512, 2) void afi_pix_gemm_wk_kernel(const AfiPixGem
     // v_cndmask per load, and a masked lane's offset (0xFFFFFFFF) is out of range: the hardware returns zeros without touching memory
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A.p, 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, 0x7FFFFFF0, 0x00020000);
-    int lb;
-    {   // XCD-contiguous logical tile ids (bijective for any grid)
-        const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = blockIdx.x & 7;
-        lb = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (int)(blockIdx.x >> 3);
-    }
     const int tile_n = (int)afi_udiv((unsigned)lb, (unsigned)sk.ntile_m, sk.rcp_ntm), tile_m = lb - tile_n * sk.ntile_m;
     const int m0 = tile_m * 32, n0 = tile_n * 32;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -604,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void afi_pix_gemm_wk_kernel(const AfiPixGem
             for (int i = 0; i < 4; ++i) *(u32x4*)(Bs + (r8 + 8 * i) * 32 + 4 * q8) = b_reg[set][i];
         }
     };
-    f32x4 fa[2][4], fb[2][4];                              // all fragments of a stage, two sets
+    f32x4 fa[FS][4], fb[FS][4];                            // all fragments of a stage (two sets: the next stage's are read under this stage's MFMAs)
     auto read_frags = [&](int set) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -635,20 +632,33 @@ __global__ __launch_bounds__(512, 2) void afi_pix_gemm_wk_kernel(const AfiPixGem
     read_frags(0);
     load_all(0, D < nK); stage_advance();
     AFI_STAMP(3);
-    for (int kb = 0; kb < nK; kb += 2) {
+    if constexpr (!LEAN) {
+        for (int kb = 0; kb < nK; kb += 2) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const int kc = kb + d;
-            if (kc >= nK) break;                           // (uniform per wave)
-            // stage kc's fragments are in registers (set d): the patch is free for stage kc+1, whose registers were gathered D stages ago
-            stage_store((d + 1) % D);
-            lds_order();
-            read_frags((d + 1) & 1);
-            load_all((d + 1) % D, kc + 1 + D < nK); stage_advance();
+            for (int d = 0; d < 2; ++d) {
+                const int kc = kb + d;
+                if (kc >= nK) break;                       // (uniform per wave)
+                // stage kc's fragments are in registers (set d): the patch is free for stage kc+1, whose registers were gathered D stages ago
+                stage_store((d + 1) % D);
+                lds_order();
+                read_frags((d + 1) & 1);
+                load_all((d + 1) % D, kc + 1 + D < nK); stage_advance();
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[d][s][j], fb[d][s][j], acc, 0, 0, 0);
+            }
+        }
+    } else {
+        for (int kc = 0; kc < nK; ++kc) {
+            stage_store(0);                                // stage kc+1 (gathered one stage ago; the other three waves of this SIMD ran meanwhile)
+            load_all(0, kc + 2 < nK); stage_advance();
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[d][s][j], fb[d][s][j], acc, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[0][s][j], fb[0][s][j], acc, 0, 0, 0);
+            lds_order();
+            read_frags(0);
         }
     }
     AFI_STAMP(4);
@@ -677,36 +687,92 @@ __global__ __launch_bounds__(512, 2) void afi_pix_gemm_wk_kernel(const AfiPixGem
     if constexpr (DIAG) { if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + 7] = __builtin_amdgcn_s_memrealtime(); }
 }
 
+__device__ __forceinline__ int afi_xcd_logical_id() {       // XCD-contiguous logical block ids (bijective for any grid)
+    const int nwg = gridDim.x, qq = nwg >> 3, rr = nwg & 7, xcd = blockIdx.x & 7;
+    return (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (int)(blockIdx.x >> 3);
+}
+template <bool B_RC, bool LEAN, bool DIAG = false>
+__global__ __launch_bounds__(512, LEAN ? 4 : 2) void afi_pix_gemm_wk_kernel(const AfiPixGemm p, const AfiWkArgs sk) {
+    afi_wk_body<B_RC, LEAN, DIAG>(p, sk, afi_xcd_logical_id());
+}
+// Several GEMMs that are ready at the same time in ONE launch (the dense block in column-batched form: the contributions of one
+// source slice to every later conv of the block).  Tiles are numbered problem-major; a block finds its problem in a 5-entry table.
+#define AFI_WK_MAXP 5
+struct AfiWkGroup {
+    int nprob;
+    int tile_start[AFI_WK_MAXP + 1];
+    AfiWkArgs wk[AFI_WK_MAXP];
+    AfiPixGemm p[AFI_WK_MAXP];
+};
 template <bool B_RC>
-static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
+__global__ __launch_bounds__(512, 4) void afi_pix_gemm_wk_group_kernel(const AfiWkGroup grp) {
+    const int t = afi_xcd_logical_id();
+    int pi = 0;
+    while (pi + 1 < grp.nprob && t >= grp.tile_start[pi + 1]) ++pi;     // (uniform)
+    afi_wk_body<B_RC, true, false>(grp.p[pi], grp.wk[pi], t - grp.tile_start[pi]);
+}
+
+// fills the kernel's argument block; AFI_ERR_UNSUPPORTED when the problem does not fit the kernel's 32-bit index math
+static int wk_prepare(const AfiPixGemm& p, bool b_rc, AfiWkArgs& wk) {
     const long long M = (long long)p.N * p.H * p.W;
+    if (p.gtap || p.b_sImg != 0 || (p.ntaps != 1 && p.ntaps != 9)) return AFI_ERR_UNSUPPORTED;
     if (p.nKphase != 1 && p.nKphase != 4) return AFI_ERR_UNSUPPORTED;
     if (M * (long long)p.H * p.W >= (1LL << 32) || M >= (1LL << 30)) return AFI_ERR_UNSUPPORTED;   // 32-bit index math, reciprocal division
     {   // buffer loads address both operands with 32-bit byte offsets below 2 GB
         auto ab = [](long long v) { return v < 0 ? -v : v; };
         const long long a_ext = (ab(p.A.sN) * p.N + ab(p.A.sH) * ((long long)p.H * p.a_up + 2) + ab(p.A.sW) * ((long long)p.W * p.a_up + 2) + p.Ck + 64) * 4;
-        const long long b_rows = B_RC ? (long long)p.nKphase * p.Ck : p.Ncols;
-        const long long b_ext = (ab(p.b_sRow) * (b_rows + 32) + ab(p.b_sTap) * p.ntaps + (B_RC ? p.Ncols : p.Ck) + 64) * 4;
+        const long long b_rows = b_rc ? (long long)p.nKphase * p.Ck : p.Ncols;
+        const long long b_ext = (ab(p.b_sRow) * (b_rows + 32) + ab(p.b_sTap) * p.ntaps + (b_rc ? p.Ncols : p.Ck) + 64) * 4;
         if (p.A.sN < 0 || p.A.sH < 0 || p.A.sW < 0 || p.b_sRow < 0 || p.b_sTap < 0 || a_ext >= 0x7FFFFFF0LL || b_ext >= 0x7FFFFFF0LL) return AFI_ERR_UNSUPPORTED;
     }
-    AfiWkArgs wk;
     wk.ntile_m = afi_cdiv(M, 32); wk.ntile_n = afi_cdiv(p.Ncols, 32);
     wk.nK = p.ntaps * p.nKphase * afi_cdiv(p.Ck, AFI_BK);
     wk.M = (int)M; wk.HW = p.H * p.W;
     wk.rcp_HW = sk_rcp((unsigned)wk.HW); wk.rcp_W = sk_rcp((unsigned)p.W); wk.rcp_taps = sk_rcp((unsigned)p.ntaps); wk.rcp_ntm = sk_rcp((unsigned)wk.ntile_m);
     wk.kph_shift = p.nKphase == 4 ? 2 : 0;
     wk.dbg = nullptr;
+    if ((long long)wk.ntile_m * wk.ntile_n * wk.ntile_m >= (1LL << 32)) return AFI_ERR_UNSUPPORTED;
+    return AFI_OK;
+}
+// up to AFI_WK_MAXP simultaneous small-map GEMMs in one launch; validates everything before it launches anything
+int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st) {
+    static const int on = sk_env_int("AFI_SK", 1) && sk_env_int("AFI_WK", 1);
+    if (!on || n < 1 || n > AFI_WK_MAXP) return AFI_ERR_UNSUPPORTED;
+    AfiWkGroup grp;
+    grp.nprob = n;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = wk_prepare(probs[i], b_rc != 0, grp.wk[i]);
+        if (rc != AFI_OK) return rc;
+        grp.p[i] = probs[i];
+        grp.tile_start[i] = tiles;
+        tiles += grp.wk[i].ntile_m * grp.wk[i].ntile_n;
+    }
+    for (int i = n; i <= AFI_WK_MAXP; ++i) grp.tile_start[i] = tiles;
+    const size_t lds = sizeof(float) * 8 * (2 * 32 * (AFI_BK + 4));
+    if (b_rc) hipLaunchKernelGGL((afi_pix_gemm_wk_group_kernel<true>), dim3((unsigned)tiles), dim3(512), lds, st, grp);
+    else hipLaunchKernelGGL((afi_pix_gemm_wk_group_kernel<false>), dim3((unsigned)tiles), dim3(512), lds, st, grp);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+template <bool B_RC>
+static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
+    const long long M = (long long)p.N * p.H * p.W;
+    AfiWkArgs wk;
+    { const int rc = wk_prepare(p, B_RC, wk); if (rc != AFI_OK) return rc; }
     const long long G = (long long)wk.ntile_m * wk.ntile_n;
-    if (G * wk.ntile_m >= (1LL << 32)) return AFI_ERR_UNSUPPORTED;
     constexpr int LDK = AFI_BK + 4;
     const size_t lds = sizeof(float) * 8 * (2 * 32 * LDK);
+    static const int lean_min = sk_env_int("AFI_WK_LEAN_MIN", 1);     // the two-blocks-per-CU variant measured faster at every grid size (1.06 -> 1.01 ms at config 1)
+    const bool lean = G >= lean_min;
     static const char* diag = getenv("AFI_SK_DIAG");
     if (diag) {
         unsigned long long* d = nullptr;
         if (hipMalloc(&d, sizeof(unsigned long long) * 10 * G) != hipSuccess) return AFI_ERR_LAUNCH;
         (void)hipMemset(d, 0, sizeof(unsigned long long) * 10 * G);
         wk.dbg = d;
-        hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
+        if (lean) hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, true, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
+        else hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, false, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
         (void)hipStreamSynchronize(st);
         std::vector<unsigned long long> h(10 * G);
         (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * 10 * G, hipMemcpyDeviceToHost);
@@ -715,7 +781,7 @@ static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
         if (f) {
             unsigned long long r0 = ~0ULL, r1 = 0;
             for (long long b = 0; b < G; ++b) { if (h[b * 10 + 6] < r0) r0 = h[b * 10 + 6]; if (h[b * 10 + 7] > r1) r1 = h[b * 10 + 7]; }
-            fprintf(f, "launch WK rc=%d M=%lld N=%d nK=%d G=%lld span_us=%.2f\n", (int)B_RC, M, p.Ncols, wk.nK, G, (r1 - r0) * 0.01);
+            fprintf(f, "launch WK rc=%d lean=%d M=%lld N=%d nK=%d G=%lld span_us=%.2f\n", (int)B_RC, (int)lean, M, p.Ncols, wk.nK, G, (r1 - r0) * 0.01);
             for (long long b = 0; b < G; b += (G > 64 ? G / 16 : 1)) {
                 const unsigned long long* e = &h[b * 10];
                 fprintf(f, "  blk %4lld start_us %.2f end_us %.2f | cyc: decode %lld issue %lld firstdata %lld loop %lld epi %lld | clk_MHz %.0f\n", b, (e[6] - r0) * 0.01, (e[7] - r0) * 0.01,
@@ -724,8 +790,8 @@ static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
             }
             fclose(f);
         }
-    } else
-    hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
+    } else if (lean) hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
+    else hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, false>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
