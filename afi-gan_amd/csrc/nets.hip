@@ -864,10 +864,11 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     AfiView gA = dense_view(scratch + s.o_ga, H, W, C), gB = dense_view(scratch + s.o_gb, H, W, C);
     auto dBuf = [&](int r) { return dense_view(scratch + s.o_db0 + (long long)r * P * L, H, W, L); };
     float* dwp = scratch + s.o_dwp;
-    // grouped form: the deferred problems are flushed onto the side stream at a few points of the chain (after the hi-res pair, after
-    // each dense block, at the end), so the grouped launches run beside the data-gradient chain and fill the matrix-pipe time its
-    // launch-bound small kernels leave idle.  AFI_WG_OVERLAP=0 keeps everything on the caller's stream (one flush at the end).
-    static const int wg_overlap = getenv("AFI_WG_OVERLAP") ? atoi(getenv("AFI_WG_OVERLAP")) : 1;
+    // grouped form: ONE stream by default (flush at the end).  Flushing the deferred problems onto the side stream after the hi-res pair,
+    // after each dense block and at the end was measured: the grouped launches then run beside the data-gradient chain, every kernel of
+    // which gets slower by about what is gained (1.26 vs 1.19 ms eager, and 1.51 ms replayed from a hipGraph with its six fork/join
+    // edges): the chain's kernels already occupy every CU even where they wait on memory.  AFI_WG_OVERLAP=1 switches it back on.
+    static const int wg_overlap = getenv("AFI_WG_OVERLAP") ? atoi(getenv("AFI_WG_OVERLAP")) : 0;
     Fork fk(st, 4 * P <= kSideStreamMaxPixels && (!grouped || wg_overlap));
     hipStream_t sd = fk.side;                              // weight / bias gradients
     bool unpack_pending = false;
