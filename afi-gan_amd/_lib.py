@@ -62,6 +62,7 @@ SIGNATURES = {
     "afi_generator_bwd": (_i, [_GP, _GP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_discriminator_fwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
     "afi_discriminator_bwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
+    "afi_discriminator_ws_layout": (_i, [C.POINTER(C.c_int), _i, _i, _i, C.POINTER(C.c_longlong)]),
     "afi_discriminator_fwd": (_i, [_DP, View, _i, _i, _i, _vp, _i, _vp, _ll, _vp]),
     "afi_discriminator_bwd": (_i, [_DP, _DP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_conv3x3_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, _i, _vp]),

@@ -4,6 +4,7 @@
 // All of them are float4-vectorised along the contiguous channel dimension of the pixel-major layout;
 // reductions use wavefront shuffles (64 lanes) + one LDS hop per block.
 #include "afi_common.h"
+#include <stdlib.h>
 
 #define AFI_BN_EPS 1e-5f
 #define AFI_BN_MOMENTUM 0.1f
@@ -186,6 +187,71 @@ __device__ __forceinline__ bool afi_chunk_sums(const float* __restrict__ partial
     return true;
 }
 
+// BatchNorm batch statistics in fp64.  The normalised value decides a LeakyReLU mask, and one flipped mask element moves a whole
+// gradient tensor by ~1e-3 (tools/d_parity_probe.py: with identical masks the backward is exact to 2e-6), so the statistics are kept
+// as accurate as torch's CPU path, whose accumulation type for float is double: per-thread sums, the chunk partials, the finalize
+// and 1/sqrt(var + eps) are all fp64 (the one-pass fp32 form measured 0.9-1.6e-6 relative in var, 5-8x the reference's deviation).
+// Shifted by K = x[0][c] so that s1/P - d^2 does not cancel.  The pass stays bandwidth-bound (12 fp64 ops per 16 bytes).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void afi_bn_stats_partial_kernel(const float* __restrict__ x, long long P, int C, long long ld, int rows_per_chunk,
+                                                                   double* __restrict__ partial) {
+    __shared__ f64x4 red[2][8][32];
+    const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 128 + cq * 4;
+    const bool cok = c < C;
+    f64x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
+    if (cok) {
+        const f32x4 k = *(const f32x4*)(x + c);
+        const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+        const long long r1 = (r0 + rows_per_chunk < P) ? r0 + rows_per_chunk : P;
+        for (long long r = r0 + rl; r < r1; r += 8) {
+            const f32x4 v = *(const f32x4*)(x + r * ld + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const double d = (double)v[j] - (double)k[j]; s0[j] += d; s1[j] += d * d; }
+        }
+    }
+    red[0][rl][cq] = s0; red[1][rl][cq] = s1;
+    __syncthreads();
+    if (rl == 0 && cok) {
+#pragma unroll
+        for (int i = 1; i < 8; ++i) { s0 += red[0][i][cq]; s1 += red[1][i][cq]; }
+        double* dst = partial + (long long)blockIdx.y * 2 * C;
+        *(f64x4*)(dst + c) = s0;
+        *(f64x4*)(dst + C + c) = s1;
+    }
+}
+__global__ void afi_bn_stats_finalize64_kernel(const double* __restrict__ partial, int chunks, const float* __restrict__ x0, long long P, int C,
+                                               float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
+                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                               long long* __restrict__ num_batches_tracked) {
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;     // torch BatchNorm2d train mode
+    __shared__ double red[2][8][AFI_FIN_CH];
+    const int cl = threadIdx.x & (AFI_FIN_CH - 1), ln = threadIdx.x / AFI_FIN_CH;
+    const int c = blockIdx.x * AFI_FIN_CH + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int i = ln; i < chunks; i += 8) { a0 += partial[(long long)i * 2 * C + c]; a1 += partial[(long long)i * 2 * C + C + c]; }
+    red[0][ln][cl] = a0; red[1][ln][cl] = a1;
+    __syncthreads();
+    if (ln != 0 || c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s0 += red[0][j][cl]; s1 += red[1][j][cl]; }        // fixed order: bit-reproducible
+    const double inv_n = 1.0 / (double)P;
+    const double d = s0 * inv_n;                    // mean - K
+    const double m = (double)x0[c] + d;
+    double var = s1 * inv_n - d * d;                // biased
+    var = var > 0.0 ? var : 0.0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)AFI_BN_EPS));
+    if (var_out) var_out[c] = (float)var;
+    if (running_mean) {
+        const double unb = var * ((double)P / (double)(P > 1 ? P - 1 : 1));
+        running_mean[c] = (float)((1.0 - (double)AFI_BN_MOMENTUM) * (double)running_mean[c] + (double)AFI_BN_MOMENTUM * m);
+        running_var[c] = (float)((1.0 - (double)AFI_BN_MOMENTUM) * (double)running_var[c] + (double)AFI_BN_MOMENTUM * unb);
+    }
+}
+
 // BatchNorm statistics finalize: mean / invstd for this call + running-stat update (momentum 0.1, unbiased var)
 __global__ void afi_bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, const float* __restrict__ x0, long long P, int C,
                                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
@@ -302,7 +368,7 @@ static void afi_red_geometry(long long P, int& chunks, int& rows_per_chunk) {
     rows_per_chunk = (int)((P + want - 1) / want);
     chunks = (int)((P + rows_per_chunk - 1) / rows_per_chunk);
 }
-extern "C" long long afi_reduce_scratch_floats(int C) { return (long long)AFI_RED_MAX_CHUNKS * 2 * C + 2 * C; }
+extern "C" long long afi_reduce_scratch_floats(int C) { return (long long)AFI_RED_MAX_CHUNKS * 4 * C + 2 * C; }   // partials [chunks][2][C] as fp64 (statistics) or fp32, + [2][C] sums
 
 static unsigned afi_ew_grid(long long work_items) {
     long long g = (work_items + 255) / 256;
@@ -315,6 +381,13 @@ int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* 
                         float* running_mean, float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked) {
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
+    static const int stats64 = getenv("AFI_BN_STATS_F64") ? atoi(getenv("AFI_BN_STATS_F64")) : 1;      // 0: the fp32 one-pass form (A/B only)
+    if (stats64 && (((uintptr_t)scratch) & 7) == 0) {
+        hipLaunchKernelGGL(afi_bn_stats_partial_kernel, dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, P, C, (long long)C, rpc, (double*)scratch);
+        hipLaunchKernelGGL(afi_bn_stats_finalize64_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, (const double*)scratch, chunks, x, P, C, mean,
+                           invstd, var_out, running_mean, running_var, num_batches_tracked);
+        return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL((afi_colred_partial_kernel<0>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, (long long)C, rpc, scratch);
     hipLaunchKernelGGL(afi_bn_stats_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, x, P, C, mean, invstd,
@@ -331,7 +404,7 @@ int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* me
                       float* dgamma, float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st) {
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
-    float* sums = scratch + (long long)AFI_RED_MAX_CHUNKS * 2 * C;
+    float* sums = scratch + (long long)AFI_RED_MAX_CHUNKS * 4 * C;
     hipLaunchKernelGGL((afi_colred_partial_kernel<1>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch);
     hipLaunchKernelGGL(afi_bn_bwd_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, C, gscale, dgamma, dbeta, sums);
     hipLaunchKernelGGL(afi_bn_bwd_apply_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C);

@@ -999,6 +999,14 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     return w;
 }
 long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W) { return disc_ws(F, N, H, W).total; }
+// where the forward keeps what the backward reads (offsets in floats into the forward workspace): 12 entries,
+// conv outputs c[0..2] ([P][F_{n+1}]), activations y[0..2], batch means [F_{n+1}], 1/sqrt(var + eps) [F_{n+1}]
+int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* off12) {
+    if (!F || !off12 || N <= 0 || H <= 0 || W <= 0) return AFI_ERR_BAD_ARG;
+    const DiscWs l = disc_ws(F, N, H, W);
+    for (int n = 0; n < 3; ++n) { off12[n] = l.o_c[n]; off12[3 + n] = l.o_y[n]; off12[6 + n] = l.o_mean[n]; off12[9 + n] = l.o_invstd[n]; }
+    return AFI_OK;
+}
 struct DiscBwdWs { long long o_g[3], o_dd9, o_red, o_red2, o_part, n_part, o_wino, n_wino, o_wino2, total; };
 static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     DiscBwdWs w;

@@ -90,6 +90,10 @@ typedef struct afi_disc_params {
 
 long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W);
 long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W);
+/* Where afi_discriminator_fwd (training != 0) keeps what afi_discriminator_bwd reads, as offsets in floats into the forward
+ * workspace: off12 = { c[0..2] conv outputs [P][F(n+1)], y[0..2] activations, mean[0..2], invstd[0..2] }.  For parity tooling
+ * (tests feed the reference's saved activations to the backward; feature_patch_discriminator.py:35-38) and activation checkpoints. */
+int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* off12);
 
 /* logits[N,H,W] (dense) = Discriminators[0](x).  training != 0: batch statistics, running stats advance once,
  * num_batches_tracked += 1 (torch BatchNorm2d train mode);  training == 0: running statistics.

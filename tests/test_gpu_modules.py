@@ -10,6 +10,12 @@ pytestmark = pytest.mark.gpu
 
 from oracle import afigan_oracle as orc  # noqa: E402
 
+# Discriminator gradients on the library's OWN forward: a LeakyReLU-mask element that flips under fp32 rounding moves a gradient tensor
+# by ~1e-3 relative L2 / ~1e-2 max-norm (torch's own fp32 CPU evaluation of the reference does the same against fp64), so these get
+# their own bars; tests/test_gpu_d_parity.py holds the full backward to 1e-4 max-norm with the reference's masks and bounds the flips.
+D_GRAD_L2_TOL = 3e-3
+D_GRAD_MAXNORM_TOL = 3e-2
+
 
 @pytest.fixture(scope="module")
 def amd():
@@ -120,8 +126,8 @@ def test_discriminator_vs_reference(amd, golden_dir, tag):
     # the mask-free pieces (BN backward, dgrad, wgrad with explicit masks) are held to 1e-3 max-norm in test_gpu_ops.py.
     ref_dx = fx["dx_slice"]
     got_dx = x.grad.cpu()[0, ::16].numpy()
-    assert np.linalg.norm(got_dx - ref_dx) <= 3e-3 * np.linalg.norm(ref_dx)
-    assert np.abs(got_dx - ref_dx).max() < 3e-2 * fx["gd/x"][2]
+    assert np.linalg.norm(got_dx - ref_dx) <= D_GRAD_L2_TOL * np.linalg.norm(ref_dx)
+    assert np.abs(got_dx - ref_dx).max() < D_GRAD_MAXNORM_TOL * fx["gd/x"][2]
     for k, p in D.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3"):
             # bias feeding a train-mode BN: zero gradient up to rounding noise, in the reference too
@@ -130,8 +136,8 @@ def test_discriminator_vs_reference(amd, golden_dir, tag):
             continue
         d, s = _digest(_logical(p.grad))
         rd, rs = fx["gd/" + k], fx["gs/" + k]
-        assert abs(d[1] - rd[1]) <= 3e-3 * rd[1], (k, d, rd)
-        np.testing.assert_allclose(s, rs, rtol=0, atol=3e-2 * rd[2], err_msg=k)
+        assert abs(d[1] - rd[1]) <= D_GRAD_L2_TOL * rd[1], (k, d, rd)
+        np.testing.assert_allclose(s, rs, rtol=0, atol=D_GRAD_MAXNORM_TOL * rd[2], err_msg=k)
     # full tensors against the fp32 CPU oracle, relative L2
     pr = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in dp.items()}
     xr = x.detach().cpu().clone().requires_grad_(True)
@@ -141,11 +147,11 @@ def test_discriminator_vs_reference(amd, golden_dir, tag):
     def l2(a, b):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return ((a - b).norm() / b.norm()).item()
-    assert l2(x.grad, xr.grad) < 3e-3
+    assert l2(x.grad, xr.grad) < D_GRAD_L2_TOL
     for k, p in D.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3"):
             continue
-        assert l2(_logical(p.grad), pr[k].grad) < 3e-3, k
+        assert l2(_logical(p.grad), pr[k].grad) < D_GRAD_L2_TOL, k
 
 
 def test_discriminator_eval_mode_and_buffers(amd):
@@ -195,11 +201,11 @@ def test_discriminator_large_map_halo_path(amd):
     def l2(a, b):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return ((a - b).norm() / b.norm()).item()
-    assert l2(xg.grad, xr.grad) < 3e-3
+    assert l2(xg.grad, xr.grad) < D_GRAD_L2_TOL
     for k, p in D.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3"):
             continue
-        assert l2(_logical(p.grad), pr[k].grad) < 3e-3, k
+        assert l2(_logical(p.grad), pr[k].grad) < D_GRAD_L2_TOL, k
 
 
 def test_mid_size_maps_split_k_paths_full_channels(amd):
@@ -222,11 +228,11 @@ def test_mid_size_maps_split_k_paths_full_channels(amd):
     def l2(a, b):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return ((a - b).norm() / b.norm()).item()
-    assert l2(xg.grad, xr.grad) < 3e-3
+    assert l2(xg.grad, xr.grad) < D_GRAD_L2_TOL
     for k, p in D.named_parameters():
         if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3"):
             continue
-        assert l2(_logical(p.grad), pr[k].grad) < 3e-3, k
+        assert l2(_logical(p.grad), pr[k].grad) < D_GRAD_L2_TOL, k
 
     gp = orc.closed_form_generator_params()
     G = amd.Generator(n_residual_dense_blocks=3).cuda()

@@ -8,6 +8,10 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+# D gradients on the library's own forward: mask-flip noise (~1e-3 L2 per flipped LeakyReLU element); tests/test_gpu_d_parity.py
+D_GRAD_L2_TOL = 3e-3
+D_GRAD_MAXNORM_TOL = 3e-2
+
 from oracle import afigan_oracle as orc  # noqa: E402
 
 
@@ -47,8 +51,8 @@ def test_stage1_step_vs_reference_replay(amd, golden_dir):
             continue                                  # rounding-noise gradients (bias before a train-mode BN)
         d, s = _digest(p.grad)                      # LeakyReLU mask flips: see test_gpu_modules.test_discriminator_vs_reference
         rd, rs = fx["Dgd/" + k], fx["Dgs/" + k]
-        assert abs(d[1] - rd[1]) <= 3e-3 * rd[1], (k, d, rd)
-        np.testing.assert_allclose(s, rs, rtol=0, atol=3e-2 * rd[2], err_msg=k)
+        assert abs(d[1] - rd[1]) <= D_GRAD_L2_TOL * rd[1], (k, d, rd)
+        np.testing.assert_allclose(s, rs, rtol=0, atol=D_GRAD_MAXNORM_TOL * rd[2], err_msg=k)
     for k, p in G.named_parameters():
         d, s = _digest(p.grad)
         rd, rs = fx["Ggd/" + k], fx["Ggs/" + k]
