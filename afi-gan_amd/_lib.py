@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFI_LIB_PATH") or os.path.join(_HERE, "csrc", "libafigan_hip.so")   # override: A/B kernel builds
 
 AFI_MAX_RDB = 8
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class AfiError(RuntimeError):
@@ -56,47 +56,51 @@ _GP, _DP = C.POINTER(GenParams), C.POINTER(DiscParams)
 SIGNATURES = {
     "afi_abi_version": (_i, []),
     "afi_status_string": (C.c_char_p, [_i]),
+    "afi_ctx_create": (_i, [C.POINTER(C.c_void_p)]),
+    "afi_ctx_destroy": (_i, [_vp]),
+    "afi_ctx_set_op_scratch": (_i, [_vp, _vp, _ll]),
+    "afi_ctx_set_wino_weight_cache": (_i, [_vp, _vp, _ll]),
+    "afi_ctx_wino_weight_cache_invalidate": (_i, [_vp]),
+    "afi_ctx_set_wino_wgrad_accum": (_i, [_vp, _vp, _ll]),
+    "afi_ctx_wino_wgrad_flush": (_i, [_vp, _vp]),
+    "afi_ctx_wino_wgrad_discard": (_i, [_vp]),
     "afi_generator_fwd_ws_floats": (_ll, [_i] * 6),
     "afi_generator_bwd_ws_floats": (_ll, [_i] * 6),
-    "afi_generator_fwd": (_i, [_GP, View, _i, _i, _i, View, _vp, _ll, _vp]),
-    "afi_generator_bwd": (_i, [_GP, _GP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "afi_generator_fwd": (_i, [_vp, _GP, View, _i, _i, _i, View, _vp, _ll, _vp]),
+    "afi_generator_bwd": (_i, [_vp, _GP, _GP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_discriminator_fwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
     "afi_discriminator_bwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
     "afi_discriminator_ws_layout": (_i, [C.POINTER(C.c_int), _i, _i, _i, C.POINTER(C.c_longlong)]),
-    "afi_discriminator_fwd": (_i, [_DP, View, _i, _i, _i, _vp, _i, _vp, _ll, _vp]),
-    "afi_discriminator_bwd": (_i, [_DP, _DP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
-    "afi_conv3x3_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, _i, _vp]),
-    "afi_conv3x3_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, View, _vp]),
-    "afi_conv3x3_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
-    "afi_conv1x1_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, View, _f, _i, _vp]),
-    "afi_conv1x1_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, _vp]),
-    "afi_conv1x1_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_discriminator_fwd": (_i, [_vp, _DP, View, _i, _i, _i, _vp, _i, _vp, _ll, _vp]),
+    "afi_discriminator_bwd": (_i, [_vp, _DP, _DP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "afi_conv3x3_fwd": (_i, [_vp, View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, _i, _vp]),
+    "afi_conv3x3_dgrad": (_i, [_vp, View, _i, _i, _i, _i, _vp, _i, View, _f, _f, View, _vp]),
+    "afi_conv3x3_wgrad": (_i, [_vp, View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_conv1x1_fwd": (_i, [_vp, View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, View, _f, _i, _vp]),
+    "afi_conv1x1_dgrad": (_i, [_vp, View, _i, _i, _i, _i, _vp, _i, View, _f, _f, _vp]),
+    "afi_conv1x1_wgrad": (_i, [_vp, View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "afi_conv3x3_wino_ws_floats": (_ll, [_i] * 5),
-    "afi_conv3x3_wino_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _vp, _ll, _vp]),
-    "afi_conv3x3_wino_infer": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp, _ll, _vp]),
-    "afi_conv3x3_wino_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, View, _vp, _ll, _vp]),
-    "afi_conv3x3_wino_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp, _ll, _vp]),
-    "afi_conv3x3s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, View, _f, View, _f, _vp]),
-    "afi_conv3x3s2_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, _f, _f, _vp]),
-    "afi_conv3x3s2_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_conv3x3_wino_fwd": (_i, [_vp, View, _i, _i, _i, _i, _vp, _vp, _i, View, _vp, _ll, _vp]),
+    "afi_conv3x3_wino_infer": (_i, [_vp, View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp, _ll, _vp]),
+    "afi_conv3x3_wino_dgrad": (_i, [_vp, View, _i, _i, _i, _i, _vp, _i, View, View, _vp, _ll, _vp]),
+    "afi_conv3x3_wino_wgrad": (_i, [_vp, View, View, _i, _i, _i, _i, _i, _vp, _f, _vp, _ll, _vp]),
+    "afi_conv3x3s2_fwd": (_i, [_vp, View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, View, _f, View, _f, _vp]),
+    "afi_conv3x3s2_dgrad": (_i, [_vp, View, _i, _i, _i, _i, _vp, _i, View, _f, _f, _vp]),
+    "afi_conv3x3s2_wgrad": (_i, [_vp, View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "afi_relu_bwd": (_i, [_vp, _vp, _vp, _ll, _f, _vp]),
     "afi_dwconv3x3_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _vp]),
     "afi_maxpool3s2_same_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp]),
     "afi_fuse_swish_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_resize_bilinear_u8_ws_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "afi_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _ll, _vp]),
-    "afi_set_wino_wgrad_accum": (_i, [_vp, _ll]),
-    "afi_wino_wgrad_flush": (_i, [_vp]),
-    "afi_set_wino_weight_cache": (_i, [_vp, _ll]),
-    "afi_wino_weight_cache_invalidate": (_i, []),
     "afi_dual_scale_u8_ws_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
     "afi_dual_scale_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _ll, _vp]),
     "afi_normalize_pad_u8": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_pack_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "afi_convT6s2_unpack_wgrad": (_i, [_vp, _vp, _i, _i, _vp]),
-    "afi_convT6s2_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp]),
-    "afi_convT6s2_dgrad": (_i, [View, _i, _i, _i, _i, _vp, _i, View, View, _vp]),
-    "afi_convT6s2_wgrad": (_i, [View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
+    "afi_convT6s2_fwd": (_i, [_vp, View, _i, _i, _i, _i, _vp, _vp, _i, View, _i, _vp]),
+    "afi_convT6s2_dgrad": (_i, [_vp, View, _i, _i, _i, _i, _vp, _i, View, View, _vp]),
+    "afi_convT6s2_wgrad": (_i, [_vp, View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),
     "afi_bilinear2x_add_fwd": (_i, [View, _i, _i, _i, _i, _f, _vp, _vp]),
     "afi_bilinear2x_add_bwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _vp]),
     "afi_reduce_scratch_floats": (_ll, [_i]),
@@ -110,7 +114,6 @@ SIGNATURES = {
     "afi_scale_inplace": (_i, [_vp, _ll, _f, _vp]),
     "afi_nchw_to_nhwc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "afi_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "afi_set_op_scratch": (_i, [_vp, _ll]),
     "afi_profile_enable": (_i, [_i]),
     "afi_profile_num_kinds": (_i, []),
     "afi_profile_kind_name": (C.c_char_p, [_i]),
@@ -146,6 +149,72 @@ def check(status: int, what: str = ""):
         raise AfiError(f"{what or 'afigan_hip call'} failed: status {status} ({msg})")
 
 
+# Entry points whose first argument is the caller-owned afi_ctx_t (include/afigan_hip.h): `call` passes the ACTIVE context of the calling
+# thread -- the one made current by `use_ctx`, else the default context of the current GPU -- so call sites read like the header minus
+# its first argument.  Contexts hold every piece of library state (op scratch, weight-transform cache, weight-gradient accumulator,
+# side stream); nothing in the library is process-global.
+CTX_FIRST = frozenset(n for n, (_, a) in SIGNATURES.items() if n.startswith(("afi_conv", "afi_generator_fwd", "afi_generator_bwd",
+                                                                                 "afi_discriminator_fwd", "afi_discriminator_bwd"))
+                      and not n.endswith(("_ws_floats", "_ws_layout", "pack_weight", "unpack_wgrad")))
+
+
+class Ctx:
+    """afi_ctx_t owned from Python: created on the current GPU, destroyed with the object.  Buffers registered with it are kept alive here."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(load().afi_ctx_create(C.byref(h)), "afi_ctx_create")
+        self.handle = h
+        self.device = torch.cuda.current_device()
+        self.bufs = {}                # name -> tensor registered with the context
+        self.keep = None              # list collecting temporaries that must outlive an open weight-transform-cache block
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.afi_ctx_wino_wgrad_discard(self.handle)
+                _lib.afi_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:             # interpreter shutdown
+            pass
+
+
+import threading  # noqa: E402
+_tls = threading.local()
+_default_ctx = {}
+
+
+def current_ctx() -> "Ctx":
+    stack = getattr(_tls, "stack", None)
+    if stack:
+        return stack[-1]
+    dev = torch.cuda.current_device()
+    key = (threading.get_ident(), dev)
+    cx = _default_ctx.get(key)
+    if cx is None:
+        cx = _default_ctx[key] = Ctx()
+    return cx
+
+
+class use_ctx:
+    """``with use_ctx(cx):`` -- the calls of this thread inside the block run on context `cx` (an engine's own state)."""
+
+    def __init__(self, cx: "Ctx"):
+        self.cx = cx
+
+    def __enter__(self):
+        if not hasattr(_tls, "stack"):
+            _tls.stack = []
+        _tls.stack.append(self.cx)
+        return self.cx
+
+    def __exit__(self, *exc):
+        _tls.stack.pop()
+        return False
+
+
 def call(name: str, *args):
-    """Call an int-status entry point and raise on failure."""
+    """Call an int-status entry point and raise on failure (context-taking entry points get the active context prepended)."""
+    if name in CTX_FIRST:
+        args = (current_ctx().handle,) + args
     check(getattr(load(), name)(*args), name)

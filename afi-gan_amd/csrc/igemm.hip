@@ -614,8 +614,9 @@ const char* kKindNames[] = {
     "wgrad_gemm<128x128>", "wgrad_gemm<64x128>", "wgrad_gemm<32x128>",
     "pix_gemm<128x128,KC,halo> (conv fwd)", "pix_gemm<128x128,RC,halo> (conv dgrad)",
     "gemm_nt<128x128> (batched Winograd GEMM)", "gemm_tn<128x128> (Winograd weight-gradient GEMM)",
-    "pix_gemm_sk (stream-K pixel GEMM + slab reduction, small maps)"};   // one kind per kernel, as rocprofv3 lists them
-constexpr int kNumKinds = 16;
+    "pix_gemm_wk (small-map pixel GEMM, K split inside the block; grouped launches included)",
+    "wgrad_group (grouped weight gradients of a small-map backward pass)"};   // one kind per kernel, as rocprofv3 lists them
+constexpr int kNumKinds = 17;
 hipEvent_t prof_event() {
     if (g_prof.used == g_prof.pool.size()) {
         hipEvent_t e;
@@ -630,8 +631,10 @@ struct ProfScope {
     ProfScope(hipStream_t s, int kd, double f) : st(s), kind(kd), flops(f) {
         if (g_prof.on) { a = prof_event(); (void)hipEventRecord(a, st); }
     }
+    bool live = true;
+    void cancel() { live = false; }                        // nothing was launched under this scope (the caller falls back to another kernel)
     ~ProfScope() {
-        if (g_prof.on) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops, m, n, k, split}); }
+        if (g_prof.on && live) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops, m, n, k, split}); }
     }
 };
 }  // namespace
@@ -734,15 +737,6 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
-// Optional split-K scratch for the per-op entry points (the whole-net calls carve theirs out of the caller's workspace)
-namespace { float* g_op_scratch = nullptr; long long g_op_scratch_floats = 0; }
-extern "C" int afi_set_op_scratch(float* p, long long floats) {
-    if (floats < 0 || (floats > 0 && !p)) return AFI_ERR_BAD_ARG;
-    g_op_scratch = floats > 0 ? p : nullptr;
-    g_op_scratch_floats = floats > 0 ? floats : 0;
-    return AFI_OK;
-}
-
 // batched NT GEMM of the Winograd planes; returns AFI_ERR_UNSUPPORTED when a dimension is not tile-aligned (caller falls back)
 int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, hipStream_t st) {
     if (planes <= 0 || rows_per_plane <= 0 || N <= 0 || K <= 0) return AFI_ERR_BAD_ARG;
@@ -759,9 +753,31 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
 }
 
 int afi_launch_pix_gemm_sk(const AfiPixGemm& p, int b_rc, hipStream_t st);   // smallmap.hip
+int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
+int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);
+// grouped small-map launches, bracketed for the live roofline like every other GEMM launch
+int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st) {
+    double fl = 0.0; long long m = 0; int nn = 0;
+    for (int i = 0; i < n; ++i) {
+        const long long M = (long long)probs[i].N * probs[i].H * probs[i].W;
+        fl += 2.0 * (double)M * probs[i].Ncols * probs[i].ntaps * probs[i].nKphase * probs[i].Ck;
+        m = M; nn += probs[i].Ncols;
+    }
+    ProfScope prof(st, 15, fl);
+    prof.m = m; prof.n = nn; prof.k = n > 0 ? probs[0].ntaps * probs[0].nKphase * probs[0].Ck : 0;
+    const int rc = afi_launch_pix_gemm_wk_group(probs, n, b_rc, st);
+    if (rc == AFI_ERR_UNSUPPORTED) prof.cancel();          // nothing was launched: the caller falls back to one launch per problem
+    return rc;
+}
+int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st) {
+    double fl = 0.0;
+    for (int i = 0; i < n; ++i) fl += 2.0 * (double)probs[i].N * probs[i].H * probs[i].W * probs[i].Mrows * probs[i].Ncols * probs[i].ntaps;
+    ProfScope prof(st, 16, fl);
+    prof.m = n;
+    return afi_launch_wgrad_group(probs, n, wide, st);
+}
 int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     AfiPixGemm p = p_in;
-    if (!p.partial && g_op_scratch) { p.partial = g_op_scratch; p.partial_floats = g_op_scratch_floats; }
     const long long M = (long long)p.N * p.H * p.W;
     if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
     if (p.b_sImg != 0 && ((long long)p.H * p.W) % 128 != 0) return AFI_ERR_BAD_ARG;   // per-image weights: tiles must not straddle images
@@ -786,6 +802,7 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
         prof.m = M; prof.n = p.Ncols; prof.k = p.ntaps * p.nKphase * p.Ck;
         const int rc = afi_launch_pix_gemm_sk(p, b_rc, st);
         if (rc != AFI_ERR_UNSUPPORTED) return rc;
+        prof.cancel();
     }
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work
     static const int halo_on = afi_env_int("AFI_HALO", 1);

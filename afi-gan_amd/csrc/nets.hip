@@ -8,15 +8,16 @@
 #include "../../include/afigan_hip.h"
 #include "afi_common.h"
 #include <initializer_list>
+#include <new>
 
 // ---- launchers implemented in igemm.hip / elementwise.hip
 int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st);
 int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st);
 int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, hipStream_t st);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
-int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // smallmap.hip
+int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // igemm.hip -> smallmap.hip
 int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st);
-int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
+int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
@@ -59,49 +60,84 @@ int afi_launch_invstd(const float* var, float* invstd, int C, hipStream_t st);
 
 #define AFI_TRY(expr) do { int _s = (expr); if (_s != AFI_OK) return _s; } while (0)
 
-// Fork/join onto one cached side stream, used by the backward passes of SMALL maps: the weight-gradient GEMMs and bias
-// column sums do not feed the data-gradient chain, so they run beside it instead of between its links (at config-1 sizes
-// every kernel occupies a fraction of the 256 CUs).  Events come from a small ring created on first use; fork/join only
-// records and waits on events, so the sequence stays capturable in a hipGraph.
+// ---- the caller-owned context (include/afigan_hip.h: afi_ctx_t): every piece of state that outlives one call lives here, nothing is
+//      process-global.  One context serves one stream at a time; two engines in one process use two contexts.
 #include <vector>
 namespace {
-struct SideStream {
+struct SideStream {                                        // fork/join target of the backward passes of small / mid-size maps
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> ring;
     size_t next = 0;
     bool init() {
         if (side) return true;
-        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) return false;
+        if (hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
         ring.resize(128);
         for (auto& e : ring)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
         return true;
     }
+    void destroy() {
+        for (auto& e : ring) if (e) (void)hipEventDestroy(e);
+        ring.clear();
+        if (side) (void)hipStreamDestroy(side);
+        side = nullptr;
+    }
     hipEvent_t ev() { hipEvent_t e = ring[next]; next = (next + 1) % ring.size(); return e; }
 };
-thread_local SideStream g_side;
+struct WinoWeightCache {
+    float* buf = nullptr;
+    long long floats = 0, used = 0;
+    struct Entry { const float* w; int f4, mode, O, I; long long off; } e[64];
+    int n = 0;
+};
+struct WinoWgradAccum {
+    float* buf = nullptr;
+    long long floats = 0, used = 0;
+    struct Entry { float* dw; int f4, O, I; float alpha; long long off; } e[64];
+    int n = 0;
+};
+}  // namespace
+struct afi_ctx {
+    int device = -1;                                       // the device the context was created on; calls on another one are refused
+    float* op_scratch = nullptr; long long op_scratch_floats = 0;
+    WinoWeightCache wcache;
+    WinoWgradAccum wgacc;
+    SideStream side;
+};
+namespace {
+// Fork/join onto the context's side stream (created on first use, on the context's device): the weight-gradient GEMMs and bias column
+// sums do not feed the data-gradient chain, so they run beside it.  Only event record / wait, so the sequence captures into a hipGraph.
+// Without a context (or if the stream cannot be made) everything stays on the caller's stream.  The destructor joins, so an early
+// error return never leaves side-stream work un-joined.
 struct Fork {
-    hipStream_t main, side;
+    afi_ctx* cx; hipStream_t main, side;
     bool on;
-    Fork(hipStream_t m, bool enable) : main(m), side(m), on(false) {
-        if (enable && g_side.init()) { side = g_side.side; on = true; after_main(); }
+    Fork(afi_ctx* c, hipStream_t m, bool enable) : cx(c), main(m), side(m), on(false) {
+        if (enable && cx && cx->side.init()) { side = cx->side.side; on = true; after_main(); }
     }
+    ~Fork() { join(); }
     void after_main() {            // work queued on `side` from here on sees everything already queued on `main`
         if (!on) return;
-        hipEvent_t e = g_side.ev();
-        (void)hipEventRecord(e, main);
-        (void)hipStreamWaitEvent(side, e, 0);
+        hipEvent_t e = cx->side.ev();
+        if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) { on = false; side = main; }
     }
     void join() {                  // `main` continues only after everything queued on `side`
         if (!on) return;
-        hipEvent_t e = g_side.ev();
+        hipEvent_t e = cx->side.ev();
         (void)hipEventRecord(e, side);
         (void)hipStreamWaitEvent(main, e, 0);
+        on = false;
     }
 };
 constexpr long long kSideStreamMaxPixels = 12000;   // above this every GEMM fills the chip on its own (and overlapping kernels only perturb each other)
 }  // namespace
+#define AFI_CTX_CHECK(ctx) do { if (ctx) { int d_ = -1; if (hipGetDevice(&d_) != hipSuccess || d_ != ((afi_ctx*)(ctx))->device) return AFI_ERR_BAD_ARG; } } while (0)
 
+// per-op entry points: split-K slabs come from the context's op scratch (the whole-net calls carve theirs out of their workspace)
+static inline int launch_pix_op(afi_ctx* cx, AfiPixGemm g, int b_rc, hipStream_t st) {
+    if (cx && cx->op_scratch && !g.partial) { g.partial = cx->op_scratch; g.partial_floats = cx->op_scratch_floats; }
+    return afi_launch_pix_gemm(g, b_rc, st);
+}
 static inline AfiView V(afi_view_t v) { return AfiView{v.p, v.sN, v.sH, v.sW}; }
 static inline AfiView dense_view(const float* p, int H, int W, long long ld) {
     return AfiView{const_cast<float*>(p), (long long)H * W * ld, (long long)W * ld, ld};
@@ -182,40 +218,26 @@ static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
     const int I = b_rc ? g.Ncols : g.Ck;                   // innermost weight dimension of w[O][3][3][I]
     return g.b_sTap == I && g.b_sRow == 9LL * I && g.a_sgn == (b_rc ? -1 : 1);
 }
-// Optional caller-owned cache of transformed weights (afi_set_wino_weight_cache): within one phase of a training step the same
-// weights meet up to ten calls (five pyramid levels x real / fake), so their U = G g G^T is computed once and found again by
-// (weight pointer, tiling, direction).  The caller invalidates it whenever weights change; one stream at a time, like the op scratch.
-namespace {
-struct WinoWeightCache {
-    float* buf = nullptr;
-    long long floats = 0, used = 0;
-    struct Entry { const float* w; int f4, mode, O, I; long long off; } e[64];
-    int n = 0;
-} g_wcache;
+// Caller-owned cache of transformed weights (afi_ctx_set_wino_weight_cache): within one phase of a training step the same weights meet
+// up to ten calls (five pyramid levels x real / fake), so their U = G g G^T is computed once and found again by (weight pointer,
+// tiling, direction).  The caller invalidates it whenever weights change and keeps the weight memory alive while it is registered.
 // returns the slot for this transform and whether it already holds it; nullptr when there is no cache or no room left
-float* wino_wcache_slot(const float* w, int f4, int mode, int O, int I, long long need, bool& hit) {
+static float* wino_wcache_slot(afi_ctx* cx, const float* w, int f4, int mode, int O, int I, long long need, bool& hit) {
     hit = false;
-    if (!g_wcache.buf) return nullptr;
-    for (int i = 0; i < g_wcache.n; ++i) {
-        const WinoWeightCache::Entry& e = g_wcache.e[i];
-        if (e.w == w && e.f4 == f4 && e.mode == mode && e.O == O && e.I == I) { hit = true; return g_wcache.buf + e.off; }
+    if (!cx || !cx->wcache.buf) return nullptr;
+    WinoWeightCache& c = cx->wcache;
+    for (int i = 0; i < c.n; ++i) {
+        const WinoWeightCache::Entry& e = c.e[i];
+        if (e.w == w && e.f4 == f4 && e.mode == mode && e.O == O && e.I == I) { hit = true; return c.buf + e.off; }
     }
-    if (g_wcache.n == 64 || g_wcache.used + need > g_wcache.floats) return nullptr;
-    g_wcache.e[g_wcache.n++] = WinoWeightCache::Entry{w, f4, mode, O, I, g_wcache.used};
-    float* slot = g_wcache.buf + g_wcache.used;
-    g_wcache.used += need;
+    if (c.n == 64 || c.used + need > c.floats) return nullptr;
+    c.e[c.n++] = WinoWeightCache::Entry{w, f4, mode, O, I, c.used};
+    float* slot = c.buf + c.used;
+    c.used += need;
     return slot;
 }
-}  // namespace
-int afi_set_wino_weight_cache(float* buf, long long floats) {
-    if (floats < 0 || (floats > 0 && !buf)) return AFI_ERR_BAD_ARG;
-    g_wcache.buf = floats > 0 ? buf : nullptr;
-    g_wcache.floats = floats; g_wcache.used = 0; g_wcache.n = 0;
-    return AFI_OK;
-}
-int afi_wino_weight_cache_invalidate(void) { g_wcache.used = 0; g_wcache.n = 0; return AFI_OK; }
 
-static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st,
+static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st,
                     bool fwd_f4 = false) {
     const int nph = g.nKphase;                             // 1, or 4 phase views of a pixel-shuffled A (conv-transpose data gradient)
     const int K = g.Ck * nph, Nc = g.Ncols;
@@ -229,7 +251,7 @@ static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_float
     float* Vb = U + align4((long long)np * K * Nc);
     float* Mb = Vb + align4(np * Tpad * K);
     bool have_u = false;
-    if (float* slot = wino_wcache_slot(g.B, f4, b_rc, b_rc ? K : Nc, b_rc ? Nc : K, align4((long long)np * K * Nc), have_u)) U = slot;
+    if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc, b_rc ? K : Nc, b_rc ? Nc : K, align4((long long)np * K * Nc), have_u)) U = slot;
     if (!have_u) AFI_TRY(f4 ? afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st)
                             : afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
     for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
@@ -256,58 +278,35 @@ static int wino_run(const AfiPixGemm& g, int b_rc, float* ws, long long ws_float
 }
 
 // forward (mode 0: out = conv(in, w) + bias) or data gradient (mode 1: out = conv^T(in, w) * lrelu'(z)) by descriptor
-static int wino_conv(int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
+static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
                      float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
     if (mode && z.p) { g.Z = z; g.z_lo = 0; g.z_hi = Nc; }
-    return wino_run(g, mode, ws, ws_floats, part, part_floats, st, fwd_f4);
+    return wino_run(cx, g, mode, ws, ws_floats, part, part_floats, st, fwd_f4);
 }
 
-// Optional caller-owned accumulator for the transform-domain weight gradients (afi_set_wino_wgrad_accum): dW = A'^T dU A' is linear
-// in dU, so the calls of one phase that add into the same dW (five levels x real / fake) can sum their dU and transform ONCE, at
-// afi_wino_wgrad_flush(), instead of zero-filling a dU and transforming it per call.
-namespace {
-struct WinoWgradAccum {
-    float* buf = nullptr;
-    long long floats = 0, used = 0;
-    struct Entry { float* dw; int f4, O, I; float alpha; long long off; } e[64];
-    int n = 0;
-} g_wgacc;
-float* wino_wgacc_slot(float* dw, int f4, int O, int I, float alpha, long long need, bool& fresh) {
+// Caller-owned accumulator for the transform-domain weight gradients (afi_ctx_set_wino_wgrad_accum): dW = A'^T dU A' is linear in dU,
+// so the calls of one phase that add into the same dW (five levels x real / fake) can sum their dU and transform ONCE, at
+// afi_ctx_wino_wgrad_flush(), instead of zero-filling a dU and transforming it per call.
+static float* wino_wgacc_slot(afi_ctx* cx, float* dw, int f4, int O, int I, float alpha, long long need, bool& fresh) {
     fresh = false;
-    if (!g_wgacc.buf) { fresh = true; return nullptr; }
-    for (int i = 0; i < g_wgacc.n; ++i) {
-        const WinoWgradAccum::Entry& e = g_wgacc.e[i];
+    if (!cx || !cx->wgacc.buf) { fresh = true; return nullptr; }
+    WinoWgradAccum& a = cx->wgacc;
+    for (int i = 0; i < a.n; ++i) {
+        const WinoWgradAccum::Entry& e = a.e[i];
         if (e.dw == dw && e.f4 == f4 && e.O == O && e.I == I) {
-            if (e.alpha == alpha) return g_wgacc.buf + e.off;
+            if (e.alpha == alpha) return a.buf + e.off;
             fresh = true;                                  // another scale for the same target: this call goes the per-call way
             return nullptr;
         }
     }
-    if (g_wgacc.n == 64 || g_wgacc.used + need > g_wgacc.floats) { fresh = true; return nullptr; }
-    g_wgacc.e[g_wgacc.n++] = WinoWgradAccum::Entry{dw, f4, O, I, alpha, g_wgacc.used};
-    float* slot = g_wgacc.buf + g_wgacc.used;
-    g_wgacc.used += need;
+    if (a.n == 64 || a.used + need > a.floats) { fresh = true; return nullptr; }
+    a.e[a.n++] = WinoWgradAccum::Entry{dw, f4, O, I, alpha, a.used};
+    float* slot = a.buf + a.used;
+    a.used += need;
     fresh = true;
     return slot;
-}
-}  // namespace
-int afi_wino_wgrad_flush(void* stream) {
-    hipStream_t st = (hipStream_t)stream;
-    int rc = AFI_OK;
-    for (int i = 0; i < g_wgacc.n && rc == AFI_OK; ++i) {
-        const WinoWgradAccum::Entry& e = g_wgacc.e[i];
-        rc = e.f4 ? afi_launch_wino4_dw(g_wgacc.buf + e.off, e.dw, e.O, e.I, e.alpha, st) : afi_launch_wino_dw(g_wgacc.buf + e.off, e.dw, e.O, e.I, e.alpha, st);
-    }
-    g_wgacc.n = 0; g_wgacc.used = 0;
-    return rc;
-}
-int afi_set_wino_wgrad_accum(float* buf, long long floats) {
-    if (floats < 0 || (floats > 0 && !buf) || g_wgacc.n != 0) return AFI_ERR_BAD_ARG;      // pending sums must be flushed first
-    g_wgacc.buf = floats > 0 ? buf : nullptr;
-    g_wgacc.floats = floats; g_wgacc.used = 0;
-    return AFI_OK;
 }
 
 // weight gradient in Winograd F(3x3,2x2) form: dW[Cout][3][3][Cin] += alpha * sum_pix dy (x) x.  Same workspace layout as wino_conv
@@ -315,7 +314,7 @@ int afi_set_wino_wgrad_accum(float* buf, long long floats) {
 // dy_phases = 4: dy is the hi-res gradient of a 4-phase conv-transpose; its phase views fill the four channel blocks of Q and
 // dw is the packed weight gradient [4*CoutPhase][3][3][Cin] (Cout = 4*CoutPhase).  accumulate = false keeps the call out of the
 // phase accumulator (its dw is a per-call scratch that is unpacked right away).
-static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws, long long ws_floats,
+static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws, long long ws_floats,
                       hipStream_t st, int dy_phases = 1, bool accumulate = true) {
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
@@ -327,7 +326,7 @@ static int wino_wgrad(AfiView dy, AfiView x, int N, int H, int W, int Cout, int 
     float* Qb = Vb + align4(np * Tpad * Cin);
     bool fresh = true, accum = false;
     if (accumulate)
-        if (float* slot = wino_wgacc_slot(dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
+        if (float* slot = wino_wgacc_slot(cx, dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
     if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
     AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st) : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st));
     const int cph = Cout / dy_phases;
@@ -374,7 +373,7 @@ static long long disc_wino_floats(const int F[4], int N, int H, int W) {
 
 extern "C" {
 
-int afi_abi_version(void) { return 1; }
+int afi_abi_version(void) { return 2; }
 
 const char* afi_status_string(int s) {
     switch (s) {
@@ -387,73 +386,154 @@ const char* afi_status_string(int s) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ context
+int afi_ctx_create(afi_ctx_t** out) {
+    if (!out) return AFI_ERR_BAD_ARG;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return AFI_ERR_LAUNCH;
+    afi_ctx* cx = new (std::nothrow) afi_ctx();
+    if (!cx) return AFI_ERR_WORKSPACE;
+    cx->device = dev;
+    *out = cx;
+    return AFI_OK;
+}
+int afi_ctx_destroy(afi_ctx_t* ctx) {
+    if (!ctx) return AFI_OK;
+    afi_ctx* cx = ctx;
+    if (cx->wgacc.n != 0) return AFI_ERR_BAD_ARG;          // pending weight-gradient sums: flush or discard first
+    cx->side.destroy();
+    delete cx;
+    return AFI_OK;
+}
+int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* p, long long floats) {
+    if (!ctx || floats < 0 || (floats > 0 && !p)) return AFI_ERR_BAD_ARG;
+    ctx->op_scratch = floats > 0 ? p : nullptr;
+    ctx->op_scratch_floats = floats > 0 ? floats : 0;
+    return AFI_OK;
+}
+int afi_ctx_set_wino_weight_cache(afi_ctx_t* ctx, float* buf, long long floats) {
+    if (!ctx || floats < 0 || (floats > 0 && !buf)) return AFI_ERR_BAD_ARG;
+    ctx->wcache.buf = floats > 0 ? buf : nullptr;
+    ctx->wcache.floats = floats; ctx->wcache.used = 0; ctx->wcache.n = 0;
+    return AFI_OK;
+}
+int afi_ctx_wino_weight_cache_invalidate(afi_ctx_t* ctx) {
+    if (!ctx) return AFI_ERR_BAD_ARG;
+    ctx->wcache.used = 0; ctx->wcache.n = 0;
+    return AFI_OK;
+}
+int afi_ctx_set_wino_wgrad_accum(afi_ctx_t* ctx, float* buf, long long floats) {
+    if (!ctx || floats < 0 || (floats > 0 && !buf) || ctx->wgacc.n != 0) return AFI_ERR_BAD_ARG;      // pending sums must be flushed first
+    ctx->wgacc.buf = floats > 0 ? buf : nullptr;
+    ctx->wgacc.floats = floats; ctx->wgacc.used = 0;
+    return AFI_OK;
+}
+int afi_ctx_wino_wgrad_flush(afi_ctx_t* ctx, void* stream) {
+    if (!ctx) return AFI_ERR_BAD_ARG;
+    AFI_CTX_CHECK(ctx);
+    hipStream_t st = (hipStream_t)stream;
+    WinoWgradAccum& a = ctx->wgacc;
+    int rc = AFI_OK;
+    for (int i = 0; i < a.n && rc == AFI_OK; ++i) {
+        const WinoWgradAccum::Entry& e = a.e[i];
+        rc = e.f4 ? afi_launch_wino4_dw(a.buf + e.off, e.dw, e.O, e.I, e.alpha, st) : afi_launch_wino_dw(a.buf + e.off, e.dw, e.O, e.I, e.alpha, st);
+    }
+    a.n = 0; a.used = 0;
+    return rc;
+}
+int afi_ctx_wino_wgrad_discard(afi_ctx_t* ctx) {           // error path: drop the pending sums instead of adding partial ones into dW
+    if (!ctx) return AFI_ERR_BAD_ARG;
+    ctx->wgacc.n = 0; ctx->wgacc.used = 0;
+    return AFI_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ per-op
-int afi_conv3x3_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
+int afi_conv3x3_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
                     float beta, int lrelu, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;     // float4 granularity of loads and of the epilogue stores
     AfiPixGemm g = conv_fwd_desc(V(x), N, H, W, Cin, w, bias, Cout, V(out));
     g.alpha = alpha; g.beta = beta; g.lrelu = lrelu;
-    return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
+    return launch_pix_op(cx, g, 0, (hipStream_t)stream);
 }
-int afi_conv3x3_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
+int afi_conv3x3_dgrad(afi_ctx_t* ctx, afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
                       afi_view_t z, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = conv_dgrad_desc(V(dy), N, H, W, Cout, w, Cin, V(dx));
     g.alpha = alpha; g.beta = beta;
     if (z.p) { g.Z = V(z); g.z_lo = 0; g.z_hi = Cin; }
-    return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
+    return launch_pix_op(cx, g, 1, (hipStream_t)stream);
 }
-int afi_conv3x3_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream) {
+int afi_conv3x3_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     return afi_launch_wgrad_gemm(conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha), (hipStream_t)stream);
 }
 
 long long afi_conv3x3_wino_ws_floats(int N, int H, int W, int Cin, int Cout) { return wino_ws_floats(N, H, W, Cin, Cout); }
-int afi_conv3x3_wino_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float* ws,
+int afi_conv3x3_wino_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float* ws,
                          long long ws_floats, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if (N <= 0 || H <= 0 || W <= 0 || !ws) return AFI_ERR_BAD_ARG;
-    return wino_conv(0, V(x), N, H, W, Cin, w, Cout, bias, V(out), null_view(), ws, ws_floats, nullptr, 0, (hipStream_t)stream);
+    return wino_conv(cx, 0, V(x), N, H, W, Cin, w, Cout, bias, V(out), null_view(), ws, ws_floats, nullptr, 0, (hipStream_t)stream);
 }
-int afi_conv3x3_wino_infer(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, int act,
+int afi_conv3x3_wino_infer(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, int act,
                            float* ws, long long ws_floats, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if (N <= 0 || H <= 0 || W <= 0 || !ws || act < 0 || act > 2) return AFI_ERR_BAD_ARG;
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = conv_fwd_desc(V(x), N, H, W, Cin, w, bias, Cout, V(out));
     g.lrelu = act;
-    return wino_run(g, 0, ws, ws_floats, nullptr, 0, (hipStream_t)stream, /*fwd_f4=*/true);
+    return wino_run(cx, g, 0, ws, ws_floats, nullptr, 0, (hipStream_t)stream, /*fwd_f4=*/true);
 }
-int afi_conv3x3_wino_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, afi_view_t z, float* ws,
+int afi_conv3x3_wino_dgrad(afi_ctx_t* ctx, afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, afi_view_t z, float* ws,
                            long long ws_floats, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if (N <= 0 || H <= 0 || W <= 0 || !ws) return AFI_ERR_BAD_ARG;
-    return wino_conv(1, V(dy), N, H, W, Cout, w, Cin, nullptr, V(dx), z.p ? V(z) : null_view(), ws, ws_floats, nullptr, 0, (hipStream_t)stream);
+    return wino_conv(cx, 1, V(dy), N, H, W, Cout, w, Cin, nullptr, V(dx), z.p ? V(z) : null_view(), ws, ws_floats, nullptr, 0, (hipStream_t)stream);
 }
 
-int afi_conv3x3_wino_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws,
+int afi_conv3x3_wino_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws,
                            long long ws_floats, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if (N <= 0 || H <= 0 || W <= 0 || !ws || !dw) return AFI_ERR_BAD_ARG;
-    return wino_wgrad(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha, ws, ws_floats, (hipStream_t)stream);
+    return wino_wgrad(cx, V(dy), V(x), N, H, W, Cout, Cin, dw, alpha, ws, ws_floats, (hipStream_t)stream);
 }
 
-int afi_conv1x1_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
+int afi_conv1x1_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, float alpha,
                     float beta, afi_view_t r1, float r1_scale, int lrelu, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = pix_default(N, H, W);
     g.ntaps = 1; g.Ck = Cin; g.Ncols = Cout; g.CoutPhase = Cout;
     g.A = V(x); g.B = w; g.b_sRow = Cin; g.b_sTap = 0;
     g.O = V(out); g.bias = bias; g.alpha = alpha; g.beta = beta; g.lrelu = lrelu;
     if (r1.p) { g.R1 = V(r1); g.r1s = r1_scale; g.r1_lo = 0; g.r1_hi = Cout; }
-    return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
+    return launch_pix_op(cx, g, 0, (hipStream_t)stream);
 }
-int afi_conv1x1_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
+int afi_conv1x1_dgrad(afi_ctx_t* ctx, afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
                       void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = pix_default(N, H, W);
     g.ntaps = 1; g.a_sgn = -1; g.Ck = Cout; g.Ncols = Cin; g.CoutPhase = Cin;
     g.A = V(dy); g.B = w; g.b_sRow = Cin; g.b_sTap = 0;
     g.O = V(dx); g.alpha = alpha; g.beta = beta;
-    return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
+    return launch_pix_op(cx, g, 1, (hipStream_t)stream);
 }
-int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream) {
+int afi_conv1x1_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiWgradGemm g = conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha);
     g.ntaps = 1; g.dw_sRow = Cin; g.dw_sTap = 0;
@@ -462,8 +542,10 @@ int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout
 
 // ---- Conv2d(k=3, stride=2, padding=1): the PAFPN bottom-up downsample (pafpn_sr.py:105-117,178-183) ----
 // forward: rows are the Ho x Wo output pixels (Ho = ceil(Hi/2)), tap t reads x[2y + t/3 - 1][2x + t%3 - 1]
-int afi_conv3x3s2_fwd(afi_view_t x, int N, int Hi, int Wi, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, int act,
+int afi_conv3x3s2_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int Hi, int Wi, int Cin, const float* w, const float* bias, int Cout, afi_view_t out, int act,
                       afi_view_t act_out, float post_scale, afi_view_t r, float r_scale, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (Hi < 1 || Wi < 1) return AFI_ERR_BAD_ARG;
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
@@ -473,13 +555,15 @@ int afi_conv3x3s2_fwd(afi_view_t x, int N, int Hi, int Wi, int Cin, const float*
     g.lrelu = act; g.r2_post = 1; g.post_scale = post_scale;
     if (act_out.p) g.O2 = V(act_out);
     if (r.p) { g.R2 = V(r); g.r2s = r_scale; g.r2_lo = 0; g.r2_hi = Cout; }
-    return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
+    return launch_pix_op(cx, g, 0, (hipStream_t)stream);
 }
 // data gradient: input pixel (2m + py, 2n + px) only sees the taps of matching parity -- ky = 1 for py = 0 (dy row m), ky = 0 / 2
 // for py = 1 (dy rows m+1 / m) -- so dx is four GEMMs over the Ho x Wo grid with 1, 2, 2 and 4 taps (9 in total: no wasted
 // MFMA work, unlike a stride-1 dgrad over a zero-stuffed dy which would do 4x), each storing its parity phase of dx.
-int afi_conv3x3s2_dgrad(afi_view_t dy, int N, int Hi, int Wi, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
+int afi_conv3x3s2_dgrad(afi_ctx_t* ctx, afi_view_t dy, int N, int Hi, int Wi, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
                         void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (Hi < 1 || Wi < 1) return AFI_ERR_BAD_ARG;
     const int Ho = (Hi + 1) / 2, Wo = (Wi + 1) / 2;
@@ -504,12 +588,14 @@ int afi_conv3x3s2_dgrad(afi_view_t dy, int N, int Hi, int Wi, int Cout, const fl
         o.p += py * o.sH + px * o.sW;
         g.O = o; g.o_up = 2; g.oH = Hi - py; g.oW = Wi - px;
         g.alpha = alpha; g.beta = beta;
-        const int rc = afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
+        const int rc = launch_pix_op(cx, g, 1, (hipStream_t)stream);
         if (rc != AFI_OK) return rc;
     }
     return AFI_OK;
 }
-int afi_conv3x3s2_wgrad(afi_view_t dy, afi_view_t x, int N, int Hi, int Wi, int Cout, int Cin, float* dw, float alpha, void* stream) {
+int afi_conv3x3s2_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int Hi, int Wi, int Cout, int Cin, float* dw, float alpha, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (Hi < 1 || Wi < 1) return AFI_ERR_BAD_ARG;
     AfiWgradGemm g = conv_wgrad_desc(V(dy), V(x), N, (Hi + 1) / 2, (Wi + 1) / 2, Cout, Cin, dw, alpha);
@@ -557,20 +643,26 @@ static AfiWgradGemm convT_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W,
     g.dy_up = 2; g.CoutPhase = Cout;
     return g;
 }
-int afi_convT6s2_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* wp, const float* bias, int Cout, afi_view_t out, int lrelu,
+int afi_convT6s2_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* wp, const float* bias, int Cout, afi_view_t out, int lrelu,
                      void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cout & 3) || (Cin & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = convT_fwd_desc(V(x), N, H, W, Cin, wp, bias, Cout, V(out));
     g.lrelu = lrelu;
-    return afi_launch_pix_gemm(g, 0, (hipStream_t)stream);
+    return launch_pix_op(cx, g, 0, (hipStream_t)stream);
 }
-int afi_convT6s2_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* wp, int Cin, afi_view_t dx, afi_view_t z, void* stream) {
+int afi_convT6s2_dgrad(afi_ctx_t* ctx, afi_view_t dy, int N, int H, int W, int Cout, const float* wp, int Cin, afi_view_t dx, afi_view_t z, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cout & 3) || (Cin & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = convT_dgrad_desc(V(dy), N, H, W, Cout, wp, Cin, V(dx));
     if (z.p) { g.Z = V(z); g.z_lo = 0; g.z_hi = Cin; }
-    return afi_launch_pix_gemm(g, 1, (hipStream_t)stream);
+    return launch_pix_op(cx, g, 1, (hipStream_t)stream);
 }
-int afi_convT6s2_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dwp, float alpha, void* stream) {
+int afi_convT6s2_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dwp, float alpha, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     if ((Cout & 3) || (Cin & 3)) return AFI_ERR_UNSUPPORTED;
     return afi_launch_wgrad_gemm(convT_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dwp, alpha), (hipStream_t)stream);
 }
@@ -694,8 +786,10 @@ static int gen_check(const afi_gen_params_t* p) {
     return AFI_OK;
 }
 
-int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, int W, afi_view_t outv, float* ws, long long ws_floats,
+int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv, int N, int H, int W, afi_view_t outv, float* ws, long long ws_floats,
                       void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     AFI_TRY(gen_check(prm));
     if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || !outv.p) return AFI_ERR_BAD_ARG;
     const int C = prm->C, G = prm->G, R = prm->n_rdb;
@@ -705,7 +799,7 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
     float* const part_ = ws + l.o_part;
     const long long part_n_ = l.n_part;
     auto PG = [&](AfiPixGemm g, int b_rc) {
-        if (l.n_wino > 0 && wino_eligible(g, b_rc)) return wino_run(g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st);
+        if (l.n_wino > 0 && wino_eligible(g, b_rc)) return wino_run(cx, g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st);
         g.partial = part_; g.partial_floats = part_n_;
         return afi_launch_pix_gemm(g, b_rc, st);
     };
@@ -720,7 +814,7 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
     {   // packed conv-transpose weight: from the caller's weight cache when one is registered (BiFPN: 28 calls on one set of weights)
         bool hit = false;
         const long long wp_floats = 36LL * C * C;
-        if (float* slot = wino_wcache_slot(prm->wT, /*tag: convT pack*/ 2, 0, C, C, align4(wp_floats), hit)) {
+        if (float* slot = wino_wcache_slot(cx, prm->wT, /*tag: convT pack*/ 2, 0, C, C, align4(wp_floats), hit)) {
             if (!hit) AFI_TRY(afi_launch_convT_pack(prm->wT, slot, C, C, st));
             if (hipMemcpyAsync(wp, slot, sizeof(float) * wp_floats, hipMemcpyDeviceToDevice, st) != hipSuccess) return AFI_ERR_LAUNCH;
         } else {
@@ -769,7 +863,7 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
                     g5.beta = 1.f;
                 }
                 probs[n++] = g5;
-                const int rc = afi_launch_pix_gemm_wk_group(probs, n, 0, st);
+                const int rc = afi_launch_pix_gemm_group(probs, n, 0, st);
                 if (rc == AFI_ERR_UNSUPPORTED) { for (int i = 0; i < n; ++i) AFI_TRY(PG(probs[i], 0)); }   // same step, one launch per conv
                 else AFI_TRY(rc);
             }
@@ -809,8 +903,10 @@ int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t xv, int N, int H, 
     return AFI_OK;
 }
 
-int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
+int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
                       const float* dout, float* dx, float* scratch, long long scratch_floats, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     AFI_TRY(gen_check(prm));
     if (!gr || N <= 0 || H <= 0 || W <= 0 || !ws || !dout || !scratch) return AFI_ERR_BAD_ARG;
     const int C = prm->C, G = prm->G, R = prm->n_rdb;
@@ -821,7 +917,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     float* const part_ = scratch + s.o_part;
     const long long part_n_ = s.n_part;
     auto PG = [&](AfiPixGemm g, int b_rc) {
-        if (s.n_wino > 0 && wino_eligible(g, b_rc)) return wino_run(g, b_rc, scratch + s.o_wino, s.n_wino, part_, part_n_, st);
+        if (s.n_wino > 0 && wino_eligible(g, b_rc)) return wino_run(cx, g, b_rc, scratch + s.o_wino, s.n_wino, part_, part_n_, st);
         g.partial = part_; g.partial_floats = part_n_;
         return afi_launch_pix_gemm(g, b_rc, st);
     };
@@ -844,7 +940,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     auto WG = [&](AfiView dyv, AfiView xin, int n_, int h_, int w_, int co, int ci, float* dw, float alpha, hipStream_t s_) {
         if (grouped) return defer(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha));
         if (s.n_wino > 0 && co >= 128 && ci >= 128 && (long long)n_ * h_ * w_ >= 1024)
-            return wino_wgrad(dyv, xin, n_, h_, w_, co, ci, dw, alpha, scratch + s.o_wino2, s.n_wino, s_);
+            return wino_wgrad(cx, dyv, xin, n_, h_, w_, co, ci, dw, alpha, scratch + s.o_wino2, s.n_wino, s_);
         return afi_launch_wgrad_gemm(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha), s_);
     };
     auto CS = [&](const float* g, long long rows, int Cc, long long ld, float* db, hipStream_t s_) {
@@ -869,15 +965,15 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
     // which gets slower by about what is gained (1.26 vs 1.19 ms eager, and 1.51 ms replayed from a hipGraph with its six fork/join
     // edges): the chain's kernels already occupy every CU even where they wait on memory.  AFI_WG_OVERLAP=1 switches it back on.
     static const int wg_overlap = getenv("AFI_WG_OVERLAP") ? atoi(getenv("AFI_WG_OVERLAP")) : 0;
-    Fork fk(st, 4 * P <= kSideStreamMaxPixels && (!grouped || wg_overlap));
+    Fork fk(cx, st, 4 * P <= kSideStreamMaxPixels && (!grouped || wg_overlap));
     hipStream_t sd = fk.side;                              // weight / bias gradients
     bool unpack_pending = false;
     auto flush = [&](bool last) {                          // launch what has been deferred so far (its operands are complete on `st`)
         if (!grouped || (!last && !fk.on)) return AFI_OK;
         if (n_wide + n_narrow + n_cs == 0 && !(last && unpack_pending)) return AFI_OK;
         fk.after_main();
-        AFI_TRY(afi_launch_wgrad_group(wg_wide, n_wide, 1, sd));
-        AFI_TRY(afi_launch_wgrad_group(wg_narrow, n_narrow, 0, sd));
+        AFI_TRY(afi_launch_wgrad_gemm_group(wg_wide, n_wide, 1, sd));
+        AFI_TRY(afi_launch_wgrad_gemm_group(wg_narrow, n_narrow, 0, sd));
         AFI_TRY(afi_launch_colsum_group(cs, n_cs, sd));
         if (unpack_pending && gr->wT && n_wide_has_convT) { AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd)); unpack_pending = false; }
         n_wide = n_narrow = n_cs = 0; n_wide_has_convT = false;
@@ -901,7 +997,7 @@ int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* gr, a
             AFI_TRY(defer(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f)));
             n_wide_has_convT = true; unpack_pending = true;
         } else if (convt && s.n_wino > 0 && C >= 128 && P >= 1024) {    // the four phases as channel blocks of one Winograd weight gradient
-            AFI_TRY(wino_wgrad(dU, a7, N, H, W, 4 * C, C, dwp, 1.f, scratch + s.o_wino2, s.n_wino, sd, /*dy_phases=*/4, /*accumulate=*/false));
+            AFI_TRY(wino_wgrad(cx, dU, a7, N, H, W, 4 * C, C, dwp, 1.f, scratch + s.o_wino2, s.n_wino, sd, /*dy_phases=*/4, /*accumulate=*/false));
         } else {
             AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));
         }
@@ -1037,8 +1133,10 @@ static int disc_check(const afi_disc_params_t* p) {
     return AFI_OK;
 }
 
-int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, int H, int W, float* logits, int training, float* ws,
+int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv, int N, int H, int W, float* logits, int training, float* ws,
                           long long ws_floats, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     AFI_TRY(disc_check(prm));
     if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || !logits) return AFI_ERR_BAD_ARG;
     const DiscWs l = disc_ws(prm->F, N, H, W);
@@ -1055,7 +1153,7 @@ int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, in
         float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];
         float* mean = ws + l.o_mean[n]; float* invstd = ws + l.o_invstd[n];
         if (l.n_wino > 0) {
-            AFI_TRY(wino_conv(0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
+            AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
                               part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4()));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
@@ -1083,8 +1181,10 @@ int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t xv, int N, in
     return AFI_OK;
 }
 
-int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
+int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
                           const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream) {
+    afi_ctx* cx = ctx; (void)cx;
+    AFI_CTX_CHECK(ctx);
     AFI_TRY(disc_check(prm));
     if (!gr || N <= 0 || H <= 0 || W <= 0 || !ws || !dlogits || !scratch) return AFI_ERR_BAD_ARG;
     const DiscWs l = disc_ws(prm->F, N, H, W);
@@ -1098,7 +1198,7 @@ int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t*
     float* red = scratch + s.o_red;
     float* red2 = scratch + s.o_red2;
     float* dd9 = scratch + s.o_dd9;
-    Fork fk(st, P <= kSideStreamMaxPixels);
+    Fork fk(cx, st, P <= kSideStreamMaxPixels);
     hipStream_t sd = fk.side;                              // weight / bias gradients run beside the data-gradient chain
     const int F3 = prm->F[3];
     // ---- last conv
@@ -1134,17 +1234,17 @@ int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t*
         (void)red2;
         AfiView gy = dense_view(g_, H, W, co);
         AfiView xin = (n == 0) ? V(xv) : dense_view(ws + l.o_y[n - 1], H, W, ci);
-        if (gr->w[n] && s.n_wino > 0) AFI_TRY(wino_wgrad(gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd));
+        if (gr->w[n] && s.n_wino > 0) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd));
         else if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0 && s.n_wino > 0) {
-            AFI_TRY(wino_conv(1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), xin, scratch + s.o_wino,
+            AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), xin, scratch + s.o_wino,
                               s.n_wino, part_, part_n_, st));
         } else if (n > 0) {
             AfiPixGemm g = conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(scratch + s.o_g[n - 1], H, W, ci));
             g.Z = xin; g.z_lo = 0; g.z_hi = ci;
             AFI_TRY(PG(g, 1));
         } else if (dx && s.n_wino > 0) {
-            AFI_TRY(wino_conv(1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(dx, H, W, ci), null_view(), scratch + s.o_wino, s.n_wino, part_,
+            AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(dx, H, W, ci), null_view(), scratch + s.o_wino, s.n_wino, part_,
                               part_n_, st));
         } else if (dx) {
             AFI_TRY(PG(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(dx, H, W, ci)), 1));

@@ -125,7 +125,7 @@ class _PatchDiscriminatorNet(nn.Module):
                 return None
             if not already_packed:
                 t = t.detach()
-                t = ops.ohwi(t) if kind == "ohwi" else t.contiguous()
+                t = ops.ohwi(t) if kind == "ohwi" else (t if t.is_contiguous() else ops.keep_alive(t.contiguous()))
             keep.append(t)
             return t.data_ptr()
 

@@ -78,7 +78,7 @@ def ohwi(w: torch.Tensor) -> torch.Tensor:
     """[O,I,kh,kw] weight whose memory is [O][kh][kw][I] (what the kernels read); copies only if it is not already."""
     if w.permute(0, 2, 3, 1).is_contiguous():
         return w
-    return w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return keep_alive(w.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2))
 
 
 def new_ohwi(O, I, kh, kw, device, zero=True) -> torch.Tensor:
@@ -100,26 +100,37 @@ def _dense(t):
     return True
 
 
-_WCACHE = {}
-
-
 @contextlib.contextmanager
 def weight_transform_cache(device, floats=32 * 1024 * 1024):
-    """Register a buffer for transformed / packed conv weights (afi_set_wino_weight_cache) for the duration of a block in which
-    weight VALUES do not change -- e.g. one backbone forward, where the interpolator runs 3 (FPN) to 28 (BiFPN) times on one set
-    of weights.  Not re-entrant; one stream at a time (include/afigan_hip.h)."""
+    """Register a buffer for transformed / packed conv weights (afi_ctx_set_wino_weight_cache) with the active context for the duration
+    of a block in which weight VALUES do not change -- e.g. one backbone forward, where the interpolator runs 3 (FPN) to 28 (BiFPN) times
+    on one set of weights.  The cache is keyed by weight ADDRESS, so every temporary weight copy made inside the block (``ohwi`` of a
+    parameter that is not stored in the kernels' layout, ``.contiguous()`` of a bias) is kept alive until the block exits: a freed
+    temporary's address could otherwise be handed to another same-shaped weight and hit the first one's transform.  Not re-entrant."""
     if os.environ.get("AFI_WINO_WCACHE", "1") == "0":
         yield
         return
-    key = (torch.device(device).index, floats)
-    buf = _WCACHE.get(key)
-    if buf is None:
-        buf = _WCACHE[key] = torch.empty(floats, device=device, dtype=torch.float32)
-    call("afi_set_wino_weight_cache", _p(buf), floats)
+    cx = _lib.current_ctx()
+    buf = cx.bufs.get("wcache")
+    if buf is None or buf.numel() < floats:
+        buf = cx.bufs["wcache"] = torch.empty(floats, device=device, dtype=torch.float32)
+    if cx.keep is not None:
+        raise _lib.AfiError("weight_transform_cache is not re-entrant")
+    cx.keep = []
+    call("afi_ctx_set_wino_weight_cache", cx.handle, _p(buf), floats)
     try:
         yield
     finally:
-        call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
+        call("afi_ctx_set_wino_weight_cache", cx.handle, C.c_void_p(None), 0)
+        cx.keep = None
+
+
+def keep_alive(t: torch.Tensor) -> torch.Tensor:
+    """Hold a temporary until the open weight_transform_cache block (if any) exits; returns it."""
+    cx = _lib.current_ctx()
+    if cx.keep is not None:
+        cx.keep.append(t)
+    return t
 
 
 def zeros_like_many(tensors, need):
@@ -142,21 +153,17 @@ def zeros_like_many(tensors, need):
 
 
 # ------------------------------------------------------------------------------------------------ convs
-_OP_SCRATCH = {}
 OP_SCRATCH_FLOATS = 100 * 1024 * 1024          # 400 MB: 4 slabs of the largest map that is split (1536 tiles of 128x128)
 
 
 def _ensure_op_scratch(device):
-    """Split-K scratch for the per-op conv calls (include/afigan_hip.h: afi_set_op_scratch): one buffer per device, registered
-    once; all per-op calls of this package are issued on the current stream, one after the other."""
-    key = torch.device(device).index or 0
-    buf = _OP_SCRATCH.get(key)
+    """Split-K scratch for the per-op conv calls (include/afigan_hip.h: afi_ctx_set_op_scratch): one buffer per context, registered
+    once; all per-op calls of a context are issued on one stream, one after the other."""
+    cx = _lib.current_ctx()
+    buf = cx.bufs.get("op_scratch")
     if buf is None:
-        buf = torch.empty(OP_SCRATCH_FLOATS, device=device, dtype=torch.float32)
-        _OP_SCRATCH[key] = buf
-    if _OP_SCRATCH.get("registered") != key:
-        call("afi_set_op_scratch", C.c_void_p(buf.data_ptr()), buf.numel())
-        _OP_SCRATCH["registered"] = key
+        buf = cx.bufs["op_scratch"] = torch.empty(OP_SCRATCH_FLOATS, device=device, dtype=torch.float32)
+        call("afi_ctx_set_op_scratch", cx.handle, C.c_void_p(buf.data_ptr()), buf.numel())
     return buf
 
 

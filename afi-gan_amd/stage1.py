@@ -143,6 +143,8 @@ class Stage1Step:
                 raise _lib.AfiError("parameters must be stored in the kernels' layout ([O][kh][kw][I]); "
                                     "construct the modules with afigan_amd.Generator / Discriminator")
         self._buf: Dict[str, torch.Tensor] = {}
+        self.ctx = _lib.Ctx()          # this engine's own library state (weight-transform cache, gradient accumulator, side stream)
+        self.after_allreduce = None
         self.losses = None
         self._loss_names: List[str] = []
 
@@ -202,6 +204,8 @@ class Stage1Step:
         call and the optimizer step ``param.grad`` holds the SUM over ranks."""
         if self.distributed:
             allreduce_sum_(opt.flat_grad, self.pg)
+        if self.after_allreduce is not None:       # observation point for tests: `opt.flat_grad` holds the SUM over ranks here
+            self.after_allreduce("D" if opt is self.d_opt else "G", opt)
 
     # ------------------------------------------------------------------------------------------------ the step
     def run_step(self, lr_features: Sequence[torch.Tensor], hr_features: Sequence[torch.Tensor]):
@@ -225,19 +229,26 @@ class Stage1Step:
         lptr = self.losses.data_ptr()
         lr_now = self.lr_at(self.iter)
         # transformed conv weights are shared by the calls of a phase (weights only change at the two optimizer steps)
-        if os.environ.get("AFI_WINO_WCACHE", "1") != "0":
-            wcache = self._scratch("wino_wcache", self.WINO_WCACHE_FLOATS, dev)
-            call("afi_set_wino_weight_cache", C.c_void_p(wcache.data_ptr()), self.WINO_WCACHE_FLOATS)
-            # ... and the transform-domain weight-gradient sums of a phase are transformed back once, before its all-reduce
-            if os.environ.get("AFI_WINO_WGACC", "1") != "0":
-                wgacc = self._scratch("wino_wgacc", self.WINO_WGACC_FLOATS, dev)
-                call("afi_set_wino_wgrad_accum", C.c_void_p(wgacc.data_ptr()), self.WINO_WGACC_FLOATS)
-        try:
-            self._run_phases(nlev, lrs, hrs, lptr, lr_now, dev)
-        finally:
-            call("afi_wino_wgrad_flush", ops.stream_ptr())       # (nothing pending unless a phase raised)
-            call("afi_set_wino_wgrad_accum", C.c_void_p(None), 0)
-            call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
+        cx = self.ctx
+        with _lib.use_ctx(cx):
+            use_cache = os.environ.get("AFI_WINO_WCACHE", "1") != "0"
+            if use_cache:
+                wcache = self._scratch("wino_wcache", self.WINO_WCACHE_FLOATS, dev)
+                call("afi_ctx_set_wino_weight_cache", cx.handle, C.c_void_p(wcache.data_ptr()), self.WINO_WCACHE_FLOATS)
+                # ... and the transform-domain weight-gradient sums of a phase are transformed back once, before its all-reduce
+                if os.environ.get("AFI_WINO_WGACC", "1") != "0":
+                    wgacc = self._scratch("wino_wgacc", self.WINO_WGACC_FLOATS, dev)
+                    call("afi_ctx_set_wino_wgrad_accum", cx.handle, C.c_void_p(wgacc.data_ptr()), self.WINO_WGACC_FLOATS)
+            try:
+                self._run_phases(nlev, lrs, hrs, lptr, lr_now, dev)
+            except BaseException:
+                # a phase failed: drop its partial transform-domain sums (never add them into param.grad) and let the first error out
+                self._lib.afi_ctx_wino_wgrad_discard(cx.handle)
+                self._lib.afi_ctx_set_wino_wgrad_accum(cx.handle, None, 0)
+                self._lib.afi_ctx_set_wino_weight_cache(cx.handle, None, 0)
+                raise
+            call("afi_ctx_set_wino_wgrad_accum", cx.handle, C.c_void_p(None), 0)        # (both phases flushed their sums)
+            call("afi_ctx_set_wino_weight_cache", cx.handle, C.c_void_p(None), 0)
         self.iter += 1
 
     WINO_WCACHE_FLOATS = 140 * 1024 * 1024
@@ -271,10 +282,10 @@ class Stage1Step:
                     self._d_backward(x, dws, dz)                                     # :375 (accumulates into the flat grads)
         if self.overlap_d and self._bstream is not None:
             torch.cuda.current_stream().wait_stream(self._bstream)
-        call("afi_wino_wgrad_flush", ops.stream_ptr())
+        call("afi_ctx_wino_wgrad_flush", self.ctx.handle, ops.stream_ptr())
         self._allreduce(self.d_opt)
         self.d_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :381
-        call("afi_wino_weight_cache_invalidate")                                     # D's weights moved
+        call("afi_ctx_wino_weight_cache_invalidate", self.ctx.handle)                # D's weights moved
 
         # ---------------- G phase (:384-433)
         self.g_opt.zero_grad()                                                       # :426
@@ -300,7 +311,7 @@ class Stage1Step:
             call("afi_generator_bwd", C.byref(self._gprm), C.byref(self._ggrad), ops.view_of(lrt), lrt.shape[0], lrt.shape[2], lrt.shape[3],
                  C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n,
                  ops.stream_ptr())                                                   # :427
-        call("afi_wino_wgrad_flush", ops.stream_ptr())
+        call("afi_ctx_wino_wgrad_flush", self.ctx.handle, ops.stream_ptr())
         self._allreduce(self.g_opt)
         self.g_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :433
 

@@ -54,17 +54,18 @@ def l1_loss_common(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 @contextlib.contextmanager
 def _wino_weight_cache(helper, device):
-    """Transformed conv weights shared by the calls of one phase (include/afigan_hip.h: afi_set_wino_weight_cache); registered for
-    the duration of the phase only, during which D's weights do not change."""
-    if os.environ.get("AFI_WINO_WCACHE", "1") == "0":
-        yield
-        return
-    buf = helper._scratch("wino_wcache", Stage1Step.WINO_WCACHE_FLOATS, device)
-    call("afi_set_wino_weight_cache", C.c_void_p(buf.data_ptr()), Stage1Step.WINO_WCACHE_FLOATS)
-    try:
-        yield
-    finally:
-        call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
+    """Transformed conv weights shared by the calls of one phase (include/afigan_hip.h: afi_ctx_set_wino_weight_cache), on this engine's
+    own context; registered for the duration of the phase only, during which D's weights do not change."""
+    with _lib.use_ctx(helper.ctx):
+        if os.environ.get("AFI_WINO_WCACHE", "1") == "0":
+            yield
+            return
+        buf = helper._scratch("wino_wcache", Stage1Step.WINO_WCACHE_FLOATS, device)
+        call("afi_ctx_set_wino_weight_cache", helper.ctx.handle, C.c_void_p(buf.data_ptr()), Stage1Step.WINO_WCACHE_FLOATS)
+        try:
+            yield
+        finally:
+            call("afi_ctx_set_wino_weight_cache", helper.ctx.handle, C.c_void_p(None), 0)
 
 
 class Stage2Adversarial:
@@ -89,6 +90,7 @@ class Stage2Adversarial:
         self._helper = Stage1Step.__new__(Stage1Step)          # reuse the raw D forward/backward plumbing
         self._helper.dnet, self._helper._dprm, self._helper._dgrad = self.dnet, self._prm, self._grad
         self._helper._lib, self._helper._buf = _lib.load(), {}
+        self._helper.ctx = _lib.Ctx()
         self.iter = 0
         self.losses = None
         self._names = []

@@ -105,7 +105,30 @@ def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
             log(f"  hipGraph capture unavailable: {type(e).__name__}: {e}")
     out_px = N * 4 * H * W
     flop = 3 * G_FWD_FLOP_PER_INPX * N * H * W
-    return {"shape": f"{N}x256x{H}x{W}->{N}x256x{2 * H}x{2 * W}", "launch": mode, "ms": dt * 1e3, "ms_eager": dt_eager * 1e3,
+    # live roofline of this workload's dominant kernel: a short run with the library's HIP-event brackets on (not the timed run above:
+    # the brackets add two event records per launch)
+    lib.afi_profile_enable(1)
+    prof_iters = 20
+    for _ in range(prof_iters):
+        one()
+    torch.cuda.synchronize()
+    lib.afi_profile_enable(0)
+    kinds = []
+    for k in range(lib.afi_profile_num_kinds()):
+        out3 = (C.c_double * 3)()
+        _lib.check(lib.afi_profile_get(k, out3), "afi_profile_get")
+        if out3[0] > 0:
+            kinds.append({"kernel": lib.afi_profile_kind_name(k).decode(), "launches_per_iter": out3[0] / prof_iters, "us_per_iter": out3[1] * 1e3 / prof_iters,
+                          "avg_launch_us": out3[1] * 1e3 / out3[0], "tflops": out3[2] / (out3[1] * 1e-3) / 1e12 if out3[1] > 0 else 0.0})
+    kinds.sort(key=lambda r: -r["us_per_iter"])
+    roof = None
+    if kinds:
+        d0 = kinds[0]
+        roof = {"bound": "mfma", "kernel": d0["kernel"], "achieved": d0["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": d0["tflops"] / PEAK_FP32_MFMA_TFLOPS, "launches": d0["launches_per_iter"], "avg_launch_us": d0["avg_launch_us"],
+                "gemm_launches_per_iter": sum(r["launches_per_iter"] for r in kinds), "gemm_us_per_iter": sum(r["us_per_iter"] for r in kinds),
+                "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in kinds], "traffic": None}
+    return {"roofline": roof, "shape": f"{N}x256x{H}x{W}->{N}x256x{2 * H}x{2 * W}", "launch": mode, "ms": dt * 1e3, "ms_eager": dt_eager * 1e3,
             "ms_graph": None if dt_graph is None else dt_graph * 1e3, "ms_host_enqueue": t_enq * 1e3,
             "out_mpix_per_s": out_px / dt / 1e6, "in_mpix_per_s": out_px / 4 / dt / 1e6, "tflops": flop / dt / 1e12,
             "frac_of_fp32_mfma_peak": flop / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS}
@@ -276,7 +299,7 @@ def cpu_baseline(torch, batch):
     for _ in range(reps):
         orc.generator_forward(x, gq).sum().backward()
     tg = (time.perf_counter() - t1) / reps
-    return {"value": batch * frac / dt, "unit": "images/s", "cores": ncores, "kind": "port",
+    return {"value": batch * frac / dt, "unit": "images/s", "cores": ncores, "kind": "port", "extrapolated": True,
             "sample": f"oracle D+G phases on levels P3..P6 only (batch {batch}; {frac * 100:.2f}% of the pyramid's pixels) took {dt:.2f} s; "
                       f"scaled by the pixel ratio to the full P2..P6 step (guide net excluded)",
             "af_interpolator_out_mpix_per_s": 3400 / tg / 1e6, "af_interpolator_ms": tg * 1e3}
@@ -386,10 +409,18 @@ def main():
     except FloatingPointError as e:               # the reference aborts here too; the timing is still reported, flagged
         log(f"WARNING: {e}")
         metrics, losses_finite = step.metrics(check_finite=False), False
+    params_identical = None
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # data-parallel invariant (stage1_trainer.py:80-89 + the all-reduce): after K steps every rank holds the same G and D weights
+        chk = torch.stack([torch.cat([p.detach().reshape(-1).double() for p in m.parameters()]).sum() for m in (G, D)])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        params_identical = bool(torch.equal(lo, hi))
+        assert params_identical, "parameters differ across ranks after the timed steps (all-reduce / broadcast broken)"
     if rank != 0:
         if dist is not None:
             dist.barrier()
@@ -411,18 +442,28 @@ def main():
     gemm_flop = sum(r["flop_total"] for r in kinds)
     # HBM traffic of the dominant kernel cannot be read live (PMC counters need their own rocprofv3 passes): report the
     # committed measurement of the same command when there is one (profiles/r01/traffic_dominant_kernel.json), else null
+    # (the newest profiles/rNN that holds one; the record names the kernel it was taken on -- a different dominant kernel nulls it)
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01", "traffic_dominant_kernel.json")
-    if os.path.exists(tpath):
+    for rnd in ("r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", rnd, "traffic_dominant_kernel.json")
+        if not os.path.exists(tpath):
+            continue
         try:
             tj = json.load(open(tpath))
-            traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "source": "profiles/r01/traffic_dominant_kernel.json "
+            if tj.get("kernel") and not dom["kernel"].startswith(str(tj["kernel"]).split("<")[0]):
+                break                                      # measured on another kernel: stale
+            traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch"),
+                       "measured_at": tj.get("measured_at"), "source": f"profiles/{rnd}/traffic_dominant_kernel.json "
                        "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; FETCH x2 per the gfx950 correction)"}
         except (OSError, ValueError, KeyError):
             traffic = None
+        break
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
                 "share_of_step_time": dom["ms_total"] / (elapsed * 1e3),
+                # the whole step in EXECUTED matrix-core FLOPs (what the GEMM launches multiplied, Winograd-domain for the big convs)
+                # over wall time and peak: the one <= 1 "achieved roofline" figure of the step
+                "frac_step_executed": gemm_flop / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                 "all_gemm_kernels": {"tflops": gemm_flop / (gemm_ms * 1e-3) / 1e12, "frac": gemm_flop / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                      "share_of_step_time": gemm_ms / (elapsed * 1e3)},
                 "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "flop_total"} for r in kinds]}
@@ -433,6 +474,10 @@ def main():
     flop_img = (2 * D_FWD_FLOP_PER_PX + 2 * D_FWDBWD_DETACHED_FLOP_PER_PX) * hr_px + \
         (2 * G_FWD_FLOP_PER_INPX + 2 * G_FWD_FLOP_PER_INPX - 1_179_648) * lr_px
     n_img = world * B * args.steps
+    # SURVEY 8(d)'s algorithmic (direct-convolution) FLOP count of the step over wall time and peak.  It can pass 1: the big 3x3 convs
+    # run in Winograd form, which executes 2.25x (F(2x2,3x3)) / 4x (F(4x4,3x3)) fewer multiplies than the count assumes
+    roofline["algorithmic_over_peak"] = flop_img * B * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS
+    roofline["winograd_multiply_reduction"] = "2.25x F(2x2,3x3) forwards with a backward behind them, 4x F(4x4,3x3) data / weight gradients and forwards without one"
     line = {
         "metric": "stage1_G+D_step_images_per_s", "value": n_img / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -450,6 +495,7 @@ def main():
         "step_algorithmic_tflops_over_fp32_mfma_peak": flop_img * B * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         "conv_algorithm": "Winograd F(2x2,3x3) fwd/dgrad + F(3x3,2x2) wgrad for the discriminator's 3x3 convs (fp32, exact-f32 MFMA GEMMs); direct implicit GEMM elsewhere",
         "roofline": roofline,
+        "params_identical_across_ranks": params_identical,
         "losses_last_step": {k: round(v, 5) for k, v in metrics.items()}, "losses_finite": losses_finite,
     }
     log("AF-interpolator micro-benchmark")

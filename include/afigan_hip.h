@@ -22,6 +22,7 @@
  *   - "accumulate" outputs (all gradients w.r.t. parameters) are += targets: zero them first, like
  *     optimizer.zero_grad() at stage1_trainer.py:374/426.
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream).
+ *   - `ctx` (first argument of the convolution and whole-network entry points) is the caller's afi_ctx_t or NULL, see below.
  */
 #ifndef AFIGAN_HIP_H
 #define AFIGAN_HIP_H
@@ -49,6 +50,40 @@ typedef struct afi_view {
 int afi_abi_version(void);
 const char* afi_status_string(int status);
 
+/* ------------------------------------------------------------------ caller-owned context
+ * Every piece of library state that outlives one call lives in an afi_ctx_t the caller creates, passes to the entry points that can
+ * use it, and destroys: the split-K scratch of the per-op calls, the cache of transformed / packed weights, the transform-domain
+ * weight-gradient accumulator, and the side stream the backward passes fork their weight gradients onto.  NOTHING is process-global
+ * (the reference's modules keep their state per nn.Module instance; SURVEY 8b: "thread-safe per stream; no global mutable state").
+ *   - One context serves ONE stream at a time on the device that was current when it was created (calls on another device return
+ *     AFI_ERR_BAD_ARG); two engines / threads use two contexts and share nothing.
+ *   - ctx may be NULL in every entry point: no scratch, no caches, no side stream (everything on `stream`, every transform per call).
+ *   - The library never allocates device memory: the three buffers are the caller's and must stay alive and unchanged in meaning while
+ *     registered (floats == 0 unregisters).  The side stream and its events are created on first use and released by afi_ctx_destroy. */
+typedef struct afi_ctx afi_ctx_t;
+int afi_ctx_create(afi_ctx_t** out);
+int afi_ctx_destroy(afi_ctx_t* ctx);                       /* refused (AFI_ERR_BAD_ARG) while weight-gradient sums are pending */
+/* Scratch for the PER-OP convolution entry points (afi_conv3x3_*, afi_conv1x1_*, afi_conv3x3s2_*, afi_convT6s2_*): with it, mid-size maps
+ * (< 6 tiles of 128x128 per CU) run split-K with a deterministic second pass.  256 MB covers every shape that is split.  (The whole-net
+ * entry points carve their split-K scratch out of the workspace they are given.) */
+int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
+/* Cache of the Winograd-transformed (and packed conv-transpose) weights.  Within one phase of a training step the same weights serve up
+ * to ten calls (stage1_trainer.py:336-433: five levels x real / fake); each (weight pointer, tiling, direction) is transformed once and
+ * re-used until afi_ctx_wino_weight_cache_invalidate() -- which the caller MUST issue whenever weight VALUES change (optimizer step,
+ * load, broadcast); the weight MEMORY must stay allocated while entries exist (a freed-and-reused address would alias another weight).
+ * Registering also invalidates.  140 M floats hold every transform of the reference's G and D. */
+int afi_ctx_set_wino_weight_cache(afi_ctx_t* ctx, float* buf, long long floats);
+int afi_ctx_wino_weight_cache_invalidate(afi_ctx_t* ctx);
+/* Accumulator for the Winograd weight gradients.  While one is registered, every Winograd weight-gradient call adds its transform-domain
+ * sum dU into a slot keyed by its dW target instead of zero-filling and transforming per call; the caller MUST call
+ * afi_ctx_wino_wgrad_flush(ctx, stream) -- dW += alpha * A'^T dU A' for every slot, then the slots are released -- before it reads the
+ * gradients (all-reduce, optimizer step), on a stream ordered after the calls that accumulated; after a failed phase
+ * afi_ctx_wino_wgrad_discard drops the pending sums instead.  (Un)registering with sums pending is refused.  100 M floats hold every
+ * slot of the reference's G and D. */
+int afi_ctx_set_wino_wgrad_accum(afi_ctx_t* ctx, float* buf, long long floats);
+int afi_ctx_wino_wgrad_flush(afi_ctx_t* ctx, void* stream);
+int afi_ctx_wino_wgrad_discard(afi_ctx_t* ctx);
+
 /* ------------------------------------------------------------------ whole-network entry points */
 
 /* Parameters of Generator.Generators[0]  (generator_rdb.py:87-108; state_dict names in SURVEY.md 8b). */
@@ -70,12 +105,12 @@ long long afi_generator_fwd_ws_floats(int C, int G, int n_rdb, int N, int H, int
 long long afi_generator_bwd_ws_floats(int C, int G, int n_rdb, int N, int H, int W);
 
 /* out[N,2H,2W,C] = bilinear_x2(x) + Generators[0](x)      (Generator.forward, generator_rdb.py:123-130) */
-int afi_generator_fwd(const afi_gen_params_t* prm, afi_view_t x, int N, int H, int W, afi_view_t out,
+int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t x, int N, int H, int W, afi_view_t out,
                       float* ws, long long ws_floats, void* stream);
 /* Backward of the above.  `ws` is the forward workspace (unchanged since the forward), `dout` a DENSE
  * [N,2H,2W,C] gradient, `grads` the += targets laid out like the params (any pointer may be NULL to skip),
  * `dx` a DENSE [N,H,W,C] buffer or NULL when the input needs no gradient (stage 1: lr features are detached). */
-int afi_generator_bwd(const afi_gen_params_t* prm, const afi_gen_params_t* grads, afi_view_t x, int N, int H, int W,
+int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen_params_t* grads, afi_view_t x, int N, int H, int W,
                       const float* ws, const float* dout, float* dx, float* scratch, long long scratch_floats, void* stream);
 
 /* Parameters of Discriminator.Discriminators[0] (feature_patch_discriminator.py:32-41). */
@@ -100,50 +135,50 @@ int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* 
  * training == 1: afi_discriminator_bwd may follow on this workspace (the forward convs then keep the Winograd tiling whose
  * rounding does not disturb LeakyReLU mask decisions);  training == 2: train-mode statistics and logits only, no backward
  * will follow (stage-1 G phase, stage-2 generator-side terms): the convs may take the cheaper F(4x4,3x3) tiling, as in eval. */
-int afi_discriminator_fwd(const afi_disc_params_t* prm, afi_view_t x, int N, int H, int W, float* logits, int training,
+int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t x, int N, int H, int W, float* logits, int training,
                           float* ws, long long ws_floats, void* stream);
 /* Backward (training-mode forward only).  grads: += targets (w, b, gamma, beta, w3, b3; other fields ignored).
  * dx: DENSE [N,H,W,F0] or NULL (both reference loops feed detached inputs). */
-int afi_discriminator_bwd(const afi_disc_params_t* prm, const afi_disc_params_t* grads, afi_view_t x, int N, int H, int W,
+int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* grads, afi_view_t x, int N, int H, int W,
                           const float* ws, const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream);
 
 /* ------------------------------------------------------------------ per-op entry points (also used by the tests) */
 
 /* out[.., c_out] = act(alpha*conv3x3(x, w) + bias + beta*out);  w [Cout][3][3][Cin]  (generator_rdb.py:39-55,91-99,107)
  * lrelu: 0 = no activation, 1 = LeakyReLU(0.2), 2 = ReLU (used by the bench harness's guide network only) */
-int afi_conv3x3_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
+int afi_conv3x3_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout,
                     afi_view_t out, float alpha, float beta, int lrelu, void* stream);
 /* dx = alpha*conv3x3^T(dy, w) + beta*dx, optionally times lrelu'(z) (z = the activation that produced x) */
-int afi_conv3x3_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx,
+int afi_conv3x3_dgrad(afi_ctx_t* ctx, afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx,
                       float alpha, float beta, afi_view_t z_or_null, void* stream);
 /* dw[Cout][3][3][Cin] += alpha * sum_pix dy (x) x */
-int afi_conv3x3_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
+int afi_conv3x3_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
 
 /* 1x1 convs of the AFI FPN lateral merge (fpn_sr.py:79-81,152-153), w [Cout][Cin]:
  * out = act(alpha*conv1x1(x, w) + bias + beta*out + r1_scale*r1)   -- r1 = the up-sampled top-down feature (or NULL) */
-int afi_conv1x1_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out,
+int afi_conv1x1_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* w, const float* bias, int Cout, afi_view_t out,
                     float alpha, float beta, afi_view_t r1_or_null, float r1_scale, int lrelu, void* stream);
-int afi_conv1x1_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
+int afi_conv1x1_dgrad(afi_ctx_t* ctx, afi_view_t dy, int N, int H, int W, int Cout, const float* w, int Cin, afi_view_t dx, float alpha, float beta,
                       void* stream);
-int afi_conv1x1_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
+int afi_conv1x1_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, void* stream);
 
 /* The same 3x3 / stride-1 / pad-1 conv in Winograd F(2x2,3x3) form (2.25x fewer matrix-core FLOPs; large maps with many
  * channels): weight + input transforms, one batched 1x1 GEMM over the 16 transform points, output transform with the
  * epilogue.  fwd: out = conv(x, w) + bias.  dgrad: dx = conv^T(dy) * lrelu'(z) (z NULL = no mask).  ws from
  * afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout) (the same size serves both directions). */
 long long afi_conv3x3_wino_ws_floats(int N, int H, int W, int Cin, int Cout);
-int afi_conv3x3_wino_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
+int afi_conv3x3_wino_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
                          afi_view_t out, float* ws, long long ws_floats, void* stream);
 /* inference form: out = act(conv + bias), act 0 none / 1 LeakyReLU(0.2) / 2 ReLU; no backward will follow, so maps of >= 8192 pixels
  * take the F(4x4,3x3) tiling (4x fewer multiplies, ~3e-5 relative rounding) */
-int afi_conv3x3_wino_infer(afi_view_t x, int N, int H, int W, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
+int afi_conv3x3_wino_infer(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
                            afi_view_t out, int act, float* ws, long long ws_floats, void* stream);
-int afi_conv3x3_wino_dgrad(afi_view_t dy, int N, int H, int W, int Cout, const float* w_ohwi, int Cin, afi_view_t dx,
+int afi_conv3x3_wino_dgrad(afi_ctx_t* ctx, afi_view_t dy, int N, int H, int W, int Cout, const float* w_ohwi, int Cin, afi_view_t dx,
                            afi_view_t z_or_null, float* ws, long long ws_floats, void* stream);
 
 /* weight gradient of the same conv in Winograd F(3x3,2x2) form (shares the input transform with the forward):
  * dw[Cout][3][3][Cin] += alpha * sum_pix dy (x) x */
-int afi_conv3x3_wino_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws,
+int afi_conv3x3_wino_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws,
                            long long ws_floats, void* stream);
 
 /* Conv2d(k=3, stride=2, padding=1) on [N,Hi,Wi,Cin] -> [N,Ho,Wo,Cout], Ho = ceil(Hi/2): the PAFPN bottom-up downsample conv
@@ -152,12 +187,12 @@ int afi_conv3x3_wino_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int
  *   out = post_scale*a + r_scale*r       (r NULL = no residual)
  * dgrad: dx[N,Hi,Wi,Cin] = alpha*conv^T(dy) + beta*dx, run as four parity-phase GEMMs (9 taps in total).
  * wgrad: dw[Cout][3][3][Cin] += alpha * sum_pix dy (x) x. */
-int afi_conv3x3s2_fwd(afi_view_t x, int N, int Hi, int Wi, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
+int afi_conv3x3s2_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int Hi, int Wi, int Cin, const float* w_ohwi, const float* bias_or_null, int Cout,
                       afi_view_t out, int act, afi_view_t act_out_or_null, float post_scale, afi_view_t r_or_null, float r_scale,
                       void* stream);
-int afi_conv3x3s2_dgrad(afi_view_t dy /*[N,Ho,Wo,Cout]*/, int N, int Hi, int Wi, int Cout, const float* w_ohwi, int Cin,
+int afi_conv3x3s2_dgrad(afi_ctx_t* ctx, afi_view_t dy /*[N,Ho,Wo,Cout]*/, int N, int Hi, int Wi, int Cout, const float* w_ohwi, int Cin,
                         afi_view_t dx, float alpha, float beta, void* stream);
-int afi_conv3x3s2_wgrad(afi_view_t dy, afi_view_t x /*[N,Hi,Wi,Cin]*/, int N, int Hi, int Wi, int Cout, int Cin, float* dw,
+int afi_conv3x3s2_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x /*[N,Hi,Wi,Cin]*/, int N, int Hi, int Wi, int Cout, int Cin, float* dw,
                         float alpha, void* stream);
 /* out[i] = scale * g[i] * (act[i] > 0): gradient through the ReLU of pafpn_sr.py:178 from its kept output (n % 4 == 0) */
 int afi_relu_bwd(const float* g, const float* act, float* out, long long n, float scale, void* stream);
@@ -176,11 +211,11 @@ int afi_fuse_swish_fwd(const float* a, const float* b, const float* c_or_null, c
 /* ConvTranspose2d(k=6,s=2,p=2) (generator_rdb.py:101-105) on the packed weight wp[4*Cout][3][3][Cin] */
 int afi_convT6s2_pack_weight(const float* w_iohw, float* wp, int Cin, int Cout, void* stream);
 int afi_convT6s2_unpack_wgrad(const float* dwp, float* dw_iohw, int Cin, int Cout, void* stream);   /* dw += */
-int afi_convT6s2_fwd(afi_view_t x, int N, int H, int W, int Cin, const float* wp, const float* bias, int Cout,
+int afi_convT6s2_fwd(afi_ctx_t* ctx, afi_view_t x, int N, int H, int W, int Cin, const float* wp, const float* bias, int Cout,
                      afi_view_t out /*[N,2H,2W,Cout]*/, int lrelu, void* stream);
-int afi_convT6s2_dgrad(afi_view_t dy /*[N,2H,2W,Cout]*/, int N, int H, int W, int Cout, const float* wp, int Cin,
+int afi_convT6s2_dgrad(afi_ctx_t* ctx, afi_view_t dy /*[N,2H,2W,Cout]*/, int N, int H, int W, int Cout, const float* wp, int Cin,
                        afi_view_t dx, afi_view_t z_or_null, void* stream);
-int afi_convT6s2_wgrad(afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dwp, float alpha, void* stream);
+int afi_convT6s2_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H, int W, int Cout, int Cin, float* dwp, float alpha, void* stream);
 
 /* out (dense [N,2H,2W,C]) = beta*out + bilinear_x2(x), align_corners=False (generator_rdb.py:125) */
 int afi_bilinear2x_add_fwd(afi_view_t x, int N, int H, int W, int C, float beta, float* out, void* stream);
@@ -236,30 +271,6 @@ int afi_dual_scale_u8(const unsigned char* src, int H0, int W0, int C, unsigned 
                       unsigned char* image_r, int H2, int W2, int hflip_r, int out_chw, void* ws, long long ws_bytes, void* stream);
 int afi_normalize_pad_u8(const unsigned char* img_chw, int C, int H, int W, const float* mean, const float* std_,
                          float* out, int Hp, int Wp, void* stream);
-
-/* Optional caller-owned scratch for the PER-OP convolution entry points (afi_conv3x3_*, afi_conv1x1_*, afi_conv3x3s2_*,
- * afi_convT6s2_*): with it, small and mid-size maps (< 6 tiles of 128x128 per CU) run split-K with a deterministic second
- * pass.  One buffer per process: it serves the launches of ONE stream at a time (the whole-net entry points do not use it,
- * they carve their split-K scratch out of the workspace they are given).  floats == 0 unregisters.  256 MB covers every
- * shape that is split. */
-int afi_set_op_scratch(float* scratch, long long floats);
-
-/* Optional caller-owned cache for the Winograd-transformed weights of the 3x3 convs (whole-net and per-op entry points alike).
- * Within one phase of a training step the same weights serve up to ten calls (stage1_trainer.py:336-433: five levels x real /
- * fake); with a cache registered each (weight pointer, tiling, direction) is transformed once and re-used until
- * afi_wino_weight_cache_invalidate() -- which the caller MUST issue whenever weight values change (optimizer step, load, broadcast).
- * afi_set_wino_weight_cache also invalidates; floats == 0 unregisters.  One buffer per process, one stream at a time.
- * 140 M floats hold every transform of the reference's G and D. */
-int afi_set_wino_weight_cache(float* buf, long long floats);
-int afi_wino_weight_cache_invalidate(void);
-
-/* Optional caller-owned accumulator for the Winograd weight gradients.  While one is registered, every Winograd weight-gradient
- * call adds its transform-domain sum dU into a slot keyed by its dW target instead of zero-filling and transforming per call; the
- * caller MUST call afi_wino_wgrad_flush(stream) -- dW += alpha * A'^T dU A' for every slot, then the slots are released -- before
- * it reads the gradients (all-reduce, optimizer step), on a stream ordered after the calls that accumulated.  Registering or
- * unregistering with sums pending is refused (AFI_ERR_BAD_ARG).  100 M floats hold every slot of the reference's G and D. */
-int afi_set_wino_wgrad_accum(float* buf, long long floats);
-int afi_wino_wgrad_flush(void* stream);
 
 /* ------------------------------------------------------------------ measurement support (bench.py)
  * When enabled, every MFMA GEMM launch is bracketed by two hipEvents recorded on the launch stream.

@@ -44,6 +44,19 @@ def test_host_only_queries():
     assert lib.afi_discriminator_fwd_ws_floats(F, 1, 50, 68) > 3400 * (2 * 512 + 4 * 1024)
 
 
+def test_context_api_rejects_bad_arguments_without_a_gpu():
+    """afi_ctx_* are host functions: NULL handling is checked here; creation needs a current device and is covered by the GPU tests."""
+    _build()
+    from afigan_amd import _lib
+    lib = _lib.load()
+    assert lib.afi_ctx_create(None) == 1                                   # AFI_ERR_BAD_ARG
+    assert lib.afi_ctx_destroy(None) == 0                                  # destroying nothing is fine
+    for fn in (lib.afi_ctx_wino_weight_cache_invalidate, lib.afi_ctx_wino_wgrad_discard):
+        assert fn(None) == 1
+    assert lib.afi_ctx_set_op_scratch(None, None, 0) == 1 and lib.afi_ctx_set_wino_weight_cache(None, None, 0) == 1
+    assert lib.afi_ctx_set_wino_wgrad_accum(None, None, 0) == 1 and lib.afi_ctx_wino_wgrad_flush(None, None) == 1
+
+
 def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     from afigan_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -325,3 +325,54 @@ def test_error_paths(amd):
     # degenerate spatial sizes still work (1x1 map -> 2x2)
     out = G(torch.randn(1, 16, 1, 1, device="cuda"))
     assert tuple(out.shape) == (1, 16, 2, 2) and torch.isfinite(out).all()
+
+
+def test_weight_cache_with_weights_that_need_a_layout_copy(amd):
+    """the transform cache is keyed by weight ADDRESS.  With parameters that are NOT stored in the kernels' [O][kh][kw][I]
+    layout every call makes temporary copies; under no_grad they used to be freed after the call, and the allocator hands the same
+    address to the next same-shaped weight (w0 / w7 / w9 are all [256,256,3,3]) -- a cache hit on another layer's transform.  Inside a
+    weight_transform_cache block the temporaries are now kept alive until the block exits."""
+    ops = amd.ops
+    torch.manual_seed(3)
+    G = amd.Generator(n_residual_dense_blocks=3).cuda().eval()
+    x = torch.randn((1, 256, 32, 32), generator=torch.Generator().manual_seed(4)).cuda()     # 1024 px: the Winograd path with its cache
+    with torch.no_grad():
+        ref = G(x).clone()
+        G2 = amd.Generator(n_residual_dense_blocks=3).cuda().eval()
+        G2.load_state_dict(G.state_dict())
+        for p in G2.parameters():
+            if p.dim() == 4:
+                p.data = p.data.contiguous()                     # NCHW-contiguous storage: ohwi() has to copy on every call
+        assert not G2.Generators[0][0][0].weight.permute(0, 2, 3, 1).is_contiguous()
+        with ops.weight_transform_cache(x.device):
+            outs = [G2(x).clone() for _ in range(3)]             # FPN / PAFPN run the interpolator 3x inside one block
+    for o in outs:
+        assert _rel(o, ref) < 1e-6
+
+
+def test_two_contexts_keep_their_own_state(amd):
+    """Two engines in one process: each afi_ctx_t has its own weight-transform cache.  Changing a weight's VALUES in place makes the
+    cache of the context that transformed it stale (the documented contract: the caller invalidates) and leaves the other one fresh."""
+    import ctypes as C
+    ops, _lib = amd.ops, amd._lib
+    x = torch.randn((1, 128, 32, 32), generator=torch.Generator().manual_seed(1)).cuda().contiguous(memory_format=torch.channels_last)
+    w = ops.new_ohwi(128, 128, 3, 3, "cuda", zero=False)
+    w.normal_(0, 0.05)
+    a, b = _lib.Ctx(), _lib.Ctx()
+    bufs = [torch.empty(8 * 1024 * 1024, device="cuda") for _ in range(2)]
+    for cx, buf in zip((a, b), bufs):
+        _lib.call("afi_ctx_set_wino_weight_cache", cx.handle, C.c_void_p(buf.data_ptr()), buf.numel())
+    with _lib.use_ctx(a):
+        y_a0 = ops.conv3x3_wino_fwd(x, w, None).clone()          # context a transforms and caches w
+    w.mul_(2.0)                                                  # values change, address does not
+    with _lib.use_ctx(a):
+        y_a1 = ops.conv3x3_wino_fwd(x, w, None).clone()          # stale by contract (no invalidate)
+    with _lib.use_ctx(b):
+        y_b = ops.conv3x3_wino_fwd(x, w, None).clone()           # context b never saw the old values
+    assert torch.equal(y_a1, y_a0)
+    assert _rel(y_b, 2.0 * y_a0) < 1e-5
+    _lib.call("afi_ctx_wino_weight_cache_invalidate", a.handle)
+    with _lib.use_ctx(a):
+        assert _rel(ops.conv3x3_wino_fwd(x, w, None), y_b) < 1e-6
+    for cx in (a, b):
+        _lib.call("afi_ctx_set_wino_weight_cache", cx.handle, C.c_void_p(None), 0)

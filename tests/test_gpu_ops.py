@@ -207,7 +207,7 @@ def test_unsupported_channel_counts_are_refused(amd):
         ops.conv1x1_fwd(_pm(_rand(1, 8, 5, 5)), _rand(6, 8).cuda())
     x, out = _pm(_rand(1, 8, 5, 5)), _pm(_rand(1, 8, 5, 5))
     w = _rand(6, 8, 3, 3).cuda()
-    st = _lib.load().afi_conv3x3_fwd(ops.view_of(x), 1, 5, 5, 8, C.c_void_p(w.data_ptr()), None, 6, ops.view_of(out), 1.0, 0.0, 0,
+    st = _lib.load().afi_conv3x3_fwd(_lib.current_ctx().handle, ops.view_of(x), 1, 5, 5, 8, C.c_void_p(w.data_ptr()), None, 6, ops.view_of(out), 1.0, 0.0, 0,
                                     ops.stream_ptr())
     assert st == 2 and b"unsupported" in _lib.load().afi_status_string(st)
 
@@ -302,7 +302,7 @@ def test_conv3x3_winograd_fwd_dgrad(amd, N, Cin, Cout, H, W):
 
 
 def test_wino_weight_cache_semantics(amd):
-    """afi_set_wino_weight_cache: a transform is computed on first use and re-used until the caller invalidates -- a weight
+    """afi_ctx_set_wino_weight_cache: a transform is computed on first use and re-used until the caller invalidates -- a weight
     change WITHOUT an invalidation is (by contract) not seen, WITH one it is; unregistering restores the per-call transform."""
     import ctypes as C
     from afigan_amd import _lib
@@ -311,25 +311,25 @@ def test_wino_weight_cache_semantics(amd):
     wd = ops.ohwi(w.cuda()).clone(memory_format=torch.preserve_format)      # one device buffer = one cache key
     ref1 = F.conv2d(x, w, None, 1, 1)
     cache = torch.empty(8 * 1024 * 1024, device="cuda", dtype=torch.float32)
-    _lib.call("afi_set_wino_weight_cache", C.c_void_p(cache.data_ptr()), cache.numel())
+    _lib.call("afi_ctx_set_wino_weight_cache", _lib.current_ctx().handle, C.c_void_p(cache.data_ptr()), cache.numel())
     try:
         _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="first use fills the cache")
         _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="second use hits it")
         wd.mul_(2.0)                                                        # weights move, cache not told
         _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="stale by contract until invalidated")
-        _lib.call("afi_wino_weight_cache_invalidate")
+        _lib.call("afi_ctx_wino_weight_cache_invalidate", _lib.current_ctx().handle)
         _close(ops.conv3x3_wino_fwd(_pm(x), wd), 2.0 * ref1, tol=1e-4, what="after invalidation")
         _close(ops.conv3x3_wino_dgrad(_pm(ref1), wd), torch.autograd.grad(F.conv2d(xg := x.clone().requires_grad_(True), 2.0 * w, None, 1, 1), xg, ref1)[0],
                tol=1e-4, what="the data-gradient transform has its own entry")
     finally:
-        _lib.call("afi_set_wino_weight_cache", C.c_void_p(None), 0)
+        _lib.call("afi_ctx_set_wino_weight_cache", _lib.current_ctx().handle, C.c_void_p(None), 0)
     wd.mul_(0.5)
     _close(ops.conv3x3_wino_fwd(_pm(x), wd), ref1, tol=1e-4, what="unregistered: transformed per call")
 
 
 def test_wino_wgrad_accumulator_semantics(amd):
-    """afi_set_wino_wgrad_accum: calls adding into one dW sum their transform-domain gradients; dW is untouched until
-    afi_wino_wgrad_flush, after which it holds the same total as per-call transforms (both tilings)."""
+    """afi_ctx_set_wino_wgrad_accum: calls adding into one dW sum their transform-domain gradients; dW is untouched until
+    afi_ctx_wino_wgrad_flush, after which it holds the same total as per-call transforms (both tilings)."""
     import ctypes as C
     from afigan_amd import _lib
     ops = amd.ops
@@ -340,16 +340,16 @@ def test_wino_wgrad_accumulator_semantics(amd):
         ref = sum(torch.autograd.grad(F.conv2d(x, w, None, 1, 1), w, dy)[0] for x, dy in zip(xs, dys))
         acc = torch.empty(16 * 1024 * 1024, device="cuda", dtype=torch.float32)
         dw = ops.new_ohwi(Co, Ci, 3, 3, "cuda")
-        _lib.call("afi_set_wino_wgrad_accum", C.c_void_p(acc.data_ptr()), acc.numel())
+        _lib.call("afi_ctx_set_wino_wgrad_accum", _lib.current_ctx().handle, C.c_void_p(acc.data_ptr()), acc.numel())
         try:
             for x, dy in zip(xs, dys):
                 ops.conv3x3_wino_wgrad(_pm(dy), _pm(x), dw=dw)
             assert float(dw.abs().max()) == 0.0                                           # nothing lands before the flush
             with pytest.raises(_lib.AfiError):                                            # pending sums: refuse to drop them
-                _lib.call("afi_set_wino_wgrad_accum", C.c_void_p(None), 0)
+                _lib.call("afi_ctx_set_wino_wgrad_accum", _lib.current_ctx().handle, C.c_void_p(None), 0)
         finally:
-            _lib.call("afi_wino_wgrad_flush", ops.stream_ptr())
-            _lib.call("afi_set_wino_wgrad_accum", C.c_void_p(None), 0)
+            _lib.call("afi_ctx_wino_wgrad_flush", _lib.current_ctx().handle, ops.stream_ptr())
+            _lib.call("afi_ctx_set_wino_wgrad_accum", _lib.current_ctx().handle, C.c_void_p(None), 0)
         _close(dw, ref, tol=1e-4, what="accumulated wgrad after flush")
         ops.conv3x3_wino_wgrad(_pm(dys[0]), _pm(xs[0]), dw=dw)                            # unregistered again: per call, dw +=
         _close(dw, ref + torch.autograd.grad(F.conv2d(xs[0], w, None, 1, 1), w, dys[0])[0], tol=1e-4, what="per-call path after unregistering")

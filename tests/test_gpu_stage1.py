@@ -184,12 +184,19 @@ def _dp_gpu_worker(rank, world, port, tmp):
     G1, D1 = copy.deepcopy(G), copy.deepcopy(D)
     solo = amd.Stage1Step(G1, D1, base_lr=0.01, warmup_iters=0, distributed=False)
     solo.run_step(lr_f, hr_f)
+    snap = {}
+    step.after_allreduce = lambda which, opt: snap.__setitem__(which, opt.flat_grad.detach().clone())   # right after the collective
     step.run_step(lr_f, hr_f)
     torch.cuda.synchronize()
     out = {"w0": {k: v.cpu() for k, v in w0.items()},
            "w1": {k: v.detach().cpu() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())},
            "g_sum": {k: p.grad.detach().cpu().clone() for k, p in G.named_parameters()},
            "g_solo": {k: p.grad.detach().cpu().clone() for k, p in G1.named_parameters()},
+           # D: the all-reduced flat gradient buffer, snapshotted before the optimizer step, and this rank's single-process D-phase
+           # gradients from the same broadcast weights (the D phase runs before any weight moves)
+           "d_sum_flat": snap["D"].cpu(), "g_sum_flat": snap["G"].cpu(),
+           "d_solo_flat": solo.d_opt.flat_grad.detach().cpu().clone(),
+           "d_sizes": [({id(q): n for n, q in D.named_parameters()}[id(p)], p.numel()) for p in step.d_order],
            "metrics": step.metrics()}
     torch.save(out, os.path.join(tmp, f"r{rank}.pt"))
     dist.barrier()
@@ -213,11 +220,25 @@ def test_stage1_data_parallel_two_ranks_one_gpu(amd, tmp_path):
         got = r0["g_sum"][k]
         assert ((got - want).abs().max() / want.abs().max()).item() < 1e-4, k
         assert torch.equal(r0["g_sum"][k], r1["g_sum"][k]), k
+    # D: every one of its 14 parameter tensors -- all-reduced gradient == sum of the per-shard single-process gradients (identical
+    # weights and kernels on both sides, so the LeakyReLU masks agree bit for bit and 1e-4 holds)
+    assert torch.equal(r0["d_sum_flat"], r1["d_sum_flat"]) and torch.equal(r0["g_sum_flat"], r1["g_sum_flat"])
+    want, got = r0["d_solo_flat"] + r1["d_solo_flat"], r0["d_sum_flat"]
+    assert len(r0["d_sizes"]) == 14
+    o = 0
+    for k, n in r0["d_sizes"]:
+        w, g = want[o:o + n], got[o:o + n]
+        o += (n + 3) // 4 * 4
+        scale = w.abs().max().item()
+        if k.endswith(".0.bias") and not k.startswith("Discriminators.0.3"):
+            assert scale == 0.0 and g.abs().max().item() == 0.0, k      # bias in front of a train-mode BN: exactly zero
+            continue
+        assert scale > 0 and ((g - w).abs().max() / scale).item() < 1e-4, k
 
 
 def test_stage1_phase_caches_do_not_change_the_gradients(amd, monkeypatch):
-    """The per-phase weight-transform cache and the transform-domain weight-gradient accumulator (afi_set_wino_weight_cache /
-    afi_set_wino_wgrad_accum + afi_wino_wgrad_flush) are pure re-orderings: one step on a mid-size two-level pyramid (both
+    """The per-phase weight-transform cache and the transform-domain weight-gradient accumulator (afi_ctx_set_wino_weight_cache /
+    afi_ctx_set_wino_wgrad_accum + afi_ctx_wino_wgrad_flush) are pure re-orderings: one step on a mid-size two-level pyramid (both
     Winograd tilings active: 2x64x96 -> F(4x4), 2x32x48 -> F(2x2)) yields the same flat gradient buffers with and without them,
     and two steps (weights moved in between: the caches must have been invalidated) the same losses."""
     def run(wcache, wgacc):
