@@ -221,24 +221,23 @@ class BiFPN_AFIGAN(nn.Module):
             return dict(zip(self._out_features, feats))
 
 
-def _register_with_detectron2():
-    """With detectron2 and the reference's Swin builder importable, register build_swint_bifpn_sr_backbone (bifpn_sr.py:791-817)."""
-    try:
-        from detectron2.modeling import BACKBONE_REGISTRY
-        from afigan.modeling.backbone.swin_transformer import build_swint_backbone
-    except Exception:
-        return False
+def build_swint_bifpn_sr_backbone(cfg, input_shape):
+    """bifpn_sr.py:791-817; the Swin bottom-up builder is looked up at call time (registry.bottom_up_builder)."""
+    from .registry import bottom_up_builder
+    bottom_up = bottom_up_builder("swint")(cfg, input_shape)
+    in_features = cfg.MODEL.BIFPN.IN_FEATURES
+    cin = bottom_up.output_shape()[in_features[-1]].channels
+    return BiFPN_AFIGAN(bottom_up=bottom_up, in_features=in_features, out_channels=cfg.MODEL.BIFPN.OUT_CHANNELS,
+                        fpn_repeat=cfg.MODEL.BIFPN.FPN_REPEAT, norm=cfg.MODEL.BIFPN.NORM,
+                        top_block=LastLevelP6P7(cin, cfg.MODEL.BIFPN.OUT_CHANNELS, cfg.MODEL.BIFPN.NORM),
+                        fuse_type=cfg.MODEL.BIFPN.FUSE_TYPE, cfg=cfg)
 
-    @BACKBONE_REGISTRY.register()
-    def build_swint_bifpn_sr_backbone(cfg, input_shape):
-        bottom_up = build_swint_backbone(cfg, input_shape)
-        in_features = cfg.MODEL.BIFPN.IN_FEATURES
-        cin = bottom_up.output_shape()[in_features[-1]].channels
-        return BiFPN_AFIGAN(bottom_up=bottom_up, in_features=in_features, out_channels=cfg.MODEL.BIFPN.OUT_CHANNELS,
-                            fpn_repeat=cfg.MODEL.BIFPN.FPN_REPEAT, norm=cfg.MODEL.BIFPN.NORM,
-                            top_block=LastLevelP6P7(cin, cfg.MODEL.BIFPN.OUT_CHANNELS, cfg.MODEL.BIFPN.NORM),
-                            fuse_type=cfg.MODEL.BIFPN.FUSE_TYPE, cfg=cfg)
+
+def _register():
+    from .registry import BACKBONE_REGISTRY
+    if "build_swint_bifpn_sr_backbone" not in BACKBONE_REGISTRY:
+        BACKBONE_REGISTRY.register(build_swint_bifpn_sr_backbone)
     return True
 
 
-DETECTRON2_REGISTERED = _register_with_detectron2()
+REGISTERED = _register()

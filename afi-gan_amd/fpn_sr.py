@@ -85,18 +85,45 @@ class _Conv3x3Fn(torch.autograd.Function):
         return dx, dw, db
 
 
-class _FpnConv(nn.Module):
-    """Stands where the reference has detectron2 Conv2d (norm == ""): weight [Cout, Cin, k, k] + bias, c2_xavier_fill."""
+def get_norm(norm, out_channels):
+    """detectron2.layers.get_norm for the strings the reference's configs use (fpn_sr.py:74-81 passes cfg.MODEL.FPN.NORM through):
+    "" -> None, "BN", "SyncBN", "FrozenBN" (BatchNorm2d kept in eval mode with frozen affine), "GN" (32 groups)."""
+    if norm is None or norm == "":
+        return None
+    if norm == "BN":
+        return nn.BatchNorm2d(out_channels)
+    if norm == "SyncBN":
+        return nn.SyncBatchNorm(out_channels)
+    if norm == "GN":
+        return nn.GroupNorm(32, out_channels)
+    if norm == "FrozenBN":
+        m = nn.BatchNorm2d(out_channels)
+        for p in m.parameters():
+            p.requires_grad = False
+        m.eval()
+        m.train = lambda mode=True: m                      # stays in eval mode
+        return m
+    raise _lib.AfiError(f'norm "{norm}" is not available without detectron2 (supported: "", "BN", "SyncBN", "FrozenBN", "GN")')
 
-    def __init__(self, cin, cout, k):
+
+class _FpnConv(nn.Module):
+    """Stands where the reference has detectron2 Conv2d: weight [Cout, Cin, k, k], c2_xavier_fill; norm == "" -> bias, fused epilogues;
+    any other norm -> no bias and a `.norm` child applied to the conv's output (Conv2d.forward of detectron2: conv, then norm)."""
+
+    def __init__(self, cin, cout, k, norm=""):
         super().__init__()
         self.k = k
         w = torch.empty(cout, k, k, cin).permute(0, 3, 1, 2) if k == 3 else torch.empty(cout, cin, 1, 1)
         self.weight = nn.Parameter(w)
-        self.bias = nn.Parameter(torch.zeros(cout))
+        self.norm = get_norm(norm, cout)
+        self.bias = nn.Parameter(torch.zeros(cout)) if self.norm is None else None     # fpn_sr.py:76: use_bias = norm == ""
         nn.init.kaiming_uniform_(self.weight, a=1)           # c2_xavier_fill (fvcore): kaiming_uniform_(a=1), zero bias
 
     def forward(self, x, add=None):
+        if self.norm is not None:                          # conv -> norm (torch) -> top-down add: the add cannot ride in the GEMM epilogue
+            y = _LateralMergeFn.apply(x, self.weight, None, None) if self.k == 1 else _Conv3x3Fn.apply(x, self.weight, None)
+            y = self.norm(y)
+            return y if add is None else y + add
         if self.k == 1:
             return _LateralMergeFn.apply(x, self.weight, self.bias, add)
         assert add is None
@@ -123,8 +150,6 @@ class _Cfg:                                                   # minimal stand-in
 class FPN_AFIGAN(nn.Module):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum", cfg=None):
         super().__init__()
-        if norm != "":
-            raise _lib.AfiError('only norm="" (biased convs, the reference yaml default) is implemented on the HIP path')
         assert fuse_type in {"avg", "sum"}
         self.cfg = cfg
         input_shapes = bottom_up.output_shape()
@@ -139,7 +164,7 @@ class FPN_AFIGAN(nn.Module):
         lateral_convs, output_convs = [], []
         for idx, cin in enumerate(in_channels):
             stage = int(math.log2(in_strides[idx]))
-            lat, out = _FpnConv(cin, out_channels, 1), _FpnConv(out_channels, out_channels, 3)
+            lat, out = _FpnConv(cin, out_channels, 1, norm), _FpnConv(out_channels, out_channels, 3, norm)
             self.add_module(f"fpn_lateral{stage}", lat)
             self.add_module(f"fpn_output{stage}", out)
             lateral_convs.append(lat)
@@ -197,20 +222,24 @@ class FPN_AFIGAN(nn.Module):
         return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]) for n in self._out_features}
 
 
-def _register_with_detectron2():
-    """With detectron2 present, register the reference's builder names (fpn_sr.py:201-244) so its yamls resolve here."""
-    try:
-        from detectron2.modeling import BACKBONE_REGISTRY
-        from detectron2.modeling.backbone.resnet import build_resnet_backbone
-    except Exception:
-        return False
-
-    @BACKBONE_REGISTRY.register()
-    def build_resnet_fpn_sr_backbone(cfg, input_shape):
-        bottom_up = build_resnet_backbone(cfg, input_shape)
+def _fpn_from_cfg(kind):
+    def build(cfg, input_shape):
+        from .registry import bottom_up_builder
+        bottom_up = bottom_up_builder(kind)(cfg, input_shape)
         return FPN_AFIGAN(bottom_up=bottom_up, in_features=cfg.MODEL.FPN.IN_FEATURES, out_channels=cfg.MODEL.FPN.OUT_CHANNELS,
                           norm=cfg.MODEL.FPN.NORM, top_block=LastLevelMaxPool(), fuse_type=cfg.MODEL.FPN.FUSE_TYPE, cfg=cfg)
+    return build
+
+
+def _register():
+    """The reference's builder names (fpn_sr.py:201-244) in detectron2's BACKBONE_REGISTRY when it is importable, else in the local one."""
+    from .registry import BACKBONE_REGISTRY
+    for name, kind in (("build_resnet_fpn_sr_backbone", "resnet"), ("build_resnest_fpn_sr_backbone", "resnest")):
+        fn = _fpn_from_cfg(kind)
+        fn.__name__ = fn.__qualname__ = name
+        if name not in BACKBONE_REGISTRY:
+            BACKBONE_REGISTRY.register(fn)
     return True
 
 
-DETECTRON2_REGISTERED = _register_with_detectron2()
+REGISTERED = _register()

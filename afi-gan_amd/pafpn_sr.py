@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .fpn_sr import LastLevelMaxPool, ShapeSpec, _dense_pm, _FpnConv
+from .fpn_sr import LastLevelMaxPool, ShapeSpec, _dense_pm, _FpnConv, get_norm
 from .generator_rdb import Generator
 
 __all__ = ["PAFPN_AFIGAN", "LastLevelMaxPool"]
@@ -54,23 +54,47 @@ class _DownsampleMergeFn(torch.autograd.Function):
 
 
 class _DownsampleConv(nn.Module):
-    """Stands where the reference has detectron2 Conv2d(k3, stride 2, pad 1) (norm == ""): weight + bias, c2_xavier_fill."""
+    """Stands where the reference has detectron2 Conv2d(k3, stride 2, pad 1): weight, c2_xavier_fill; norm == "" -> bias and ONE fused
+    kernel (ReLU + merge in the epilogue); another norm -> no bias, the stride-2 conv alone on the HIP kernel, then norm, ReLU and the
+    merge as torch ops (pafpn_sr.py:103-117,183-188)."""
 
-    def __init__(self, cin, cout):
+    def __init__(self, cin, cout, norm=""):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(cout, 3, 3, cin).permute(0, 3, 1, 2))
-        self.bias = nn.Parameter(torch.zeros(cout))
+        self.norm = get_norm(norm, cout)
+        self.bias = nn.Parameter(torch.zeros(cout)) if self.norm is None else None
         nn.init.kaiming_uniform_(self.weight, a=1)
 
     def forward(self, x, inter, fs):
-        return _DownsampleMergeFn.apply(x, self.weight, self.bias, inter, fs)
+        if self.norm is None:
+            return _DownsampleMergeFn.apply(x, self.weight, self.bias, inter, fs)
+        y = _Conv3x3S2Fn.apply(x, self.weight)
+        return fs * (inter + torch.relu(self.norm(y)))
+
+
+class _Conv3x3S2Fn(torch.autograd.Function):
+    """y = conv3x3_stride2(x, w) without bias / activation (the norm != "" form of the downsample conv)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        xp = ops.pixel_major(x.detach())
+        wk = ops.ohwi(w.detach())
+        out = ops.conv3x3s2_fwd(xp, wk, None, act=0, add=None, add_scale=1.0, post_scale=1.0, keep_act=False)
+        ctx.save_for_backward(xp, wk)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, wk = ctx.saved_tensors
+        dy = _dense_pm(dy)
+        dx = ops.conv3x3s2_dgrad(dy, wk, xp.shape[-2:]) if ctx.needs_input_grad[0] else None
+        dw = ops.conv3x3s2_wgrad(dy, xp) if ctx.needs_input_grad[1] else None
+        return dx, dw
 
 
 class PAFPN_AFIGAN(nn.Module):
     def __init__(self, bottom_up, in_features, out_channels, norm="", top_block=None, fuse_type="sum", cfg=None):
         super().__init__()
-        if norm != "":
-            raise _lib.AfiError('only norm="" (biased convs, the reference yaml default) is implemented on the HIP path')
         assert fuse_type in {"avg", "sum"}
         self.cfg = cfg
         input_shapes = bottom_up.output_shape()
@@ -85,13 +109,13 @@ class PAFPN_AFIGAN(nn.Module):
         lateral_convs, output_convs, downsample_convs = [], [], []
         for idx, cin in enumerate(in_channels):
             stage = int(math.log2(in_strides[idx]))
-            lat, out = _FpnConv(cin, out_channels, 1), _FpnConv(out_channels, out_channels, 3)
+            lat, out = _FpnConv(cin, out_channels, 1, norm), _FpnConv(out_channels, out_channels, 3, norm)
             self.add_module(f"fpn_lateral{stage}", lat)
             self.add_module(f"pafpn_output{stage}", out)
             lateral_convs.append(lat)
             output_convs.append(out)
             if idx > 0:                                                                        # :103-117
-                ds = _DownsampleConv(out_channels, out_channels)
+                ds = _DownsampleConv(out_channels, out_channels, norm)
                 self.add_module(f"pafpn_downsample{stage}", ds)
                 downsample_convs.append(ds)
         self.lateral_convs = lateral_convs[::-1]              # top-down order (low to high resolution): 5 4 3 2
@@ -155,20 +179,24 @@ class PAFPN_AFIGAN(nn.Module):
         return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n]) for n in self._out_features}
 
 
-def _register_with_detectron2():
-    """With detectron2 present, register the reference's builder name (pafpn_sr.py:232-254) so its yamls resolve here."""
-    try:
-        from detectron2.modeling import BACKBONE_REGISTRY
-        from detectron2.modeling.backbone.resnet import build_resnet_backbone
-    except Exception:
-        return False
-
-    @BACKBONE_REGISTRY.register()
-    def build_resnet_pafpn_sr_backbone(cfg, input_shape):
-        bottom_up = build_resnet_backbone(cfg, input_shape)
+def _pafpn_from_cfg(kind):
+    def build(cfg, input_shape):
+        from .registry import bottom_up_builder
+        bottom_up = bottom_up_builder(kind)(cfg, input_shape)
         return PAFPN_AFIGAN(bottom_up=bottom_up, in_features=cfg.MODEL.FPN.IN_FEATURES, out_channels=cfg.MODEL.FPN.OUT_CHANNELS,
                             norm=cfg.MODEL.FPN.NORM, top_block=LastLevelMaxPool(), fuse_type=cfg.MODEL.FPN.FUSE_TYPE, cfg=cfg)
+    return build
+
+
+def _register():
+    """The reference's builder names (pafpn_sr.py:237-280) in detectron2's BACKBONE_REGISTRY when it is importable, else in the local one."""
+    from .registry import BACKBONE_REGISTRY
+    for name, kind in (("build_resnet_pafpn_sr_backbone", "resnet"), ("build_resnest_pafpn_sr_backbone", "resnest")):
+        fn = _pafpn_from_cfg(kind)
+        fn.__name__ = fn.__qualname__ = name
+        if name not in BACKBONE_REGISTRY:
+            BACKBONE_REGISTRY.register(fn)
     return True
 
 
-DETECTRON2_REGISTERED = _register_with_detectron2()
+REGISTERED = _register()

@@ -1,0 +1,2 @@
+
+from . import meta_arch  # noqa: F401,E402

@@ -115,3 +115,46 @@ def test_fpn_afigan_vs_reference_fixture(amd, golden_dir, fuse):
         f = q.grad.detach().contiguous().reshape(-1).double().cpu()
         rd = fx["gd/" + k]
         assert abs(f.norm().item() - rd[1]) <= 1e-3 * rd[1] + 1e-12, k
+
+
+def test_fpn_afigan_with_a_norm_layer(amd):
+    """cfg.MODEL.FPN.NORM != "" (fpn_sr.py:74-81: convs without bias, each followed by get_norm(norm)): the convs stay on the HIP
+    kernels, the norm is torch's; forward and every gradient against a plain torch restatement on the CPU."""
+    import torch.nn.functional as F
+    chans, strides, C = [8, 12, 16, 20], [4, 8, 16, 32], 32
+    bu = _BottomUp(chans, strides)
+    fpn = amd.FPN_AFIGAN(bu, ["res2", "res3", "res4", "res5"], C, norm="GN", top_block=amd.LastLevelMaxPool(), fuse_type="sum").cuda()
+    assert "fpn_lateral2.bias" not in fpn.state_dict() and "fpn_lateral2.norm.weight" in fpn.state_dict()
+    with torch.no_grad():
+        fpn.srf_module.load_state_dict(orc.closed_form_generator_params(C, 3, 32))
+        for k, v in fpn.state_dict().items():
+            if ".norm." in k:
+                v.copy_(1.0 + orc.closed_form_tensor(k, v.shape, 0.2) if k.endswith("weight") else orc.closed_form_tensor(k, v.shape, 0.1))
+    gen = torch.Generator().manual_seed(6)
+    feats = {f"res{i + 2}": torch.randn((2, c, 2 * 2 ** (3 - i), 3 * 2 ** (3 - i)), generator=gen) for i, c in enumerate(chans)}
+    fg = {k: v.cuda().requires_grad_(True) for k, v in feats.items()}
+    out = fpn(fg)
+    R = {k: torch.randn(o.shape, generator=torch.Generator().manual_seed(200 + i)) for i, (k, o) in enumerate(out.items())}
+    sum((o * R[k].cuda()).sum() for k, o in out.items()).backward()
+
+    p = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in fpn.state_dict().items()}
+    fr = {k: v.clone().requires_grad_(True) for k, v in feats.items()}
+    gp = {k[len("srf_module."):]: v for k, v in p.items() if k.startswith("srf_module.")}
+
+    def cn(name, x, pad):
+        y = F.conv2d(x, p[name + ".weight"], None, 1, pad)
+        return F.group_norm(y, 32, p[name + ".norm.weight"], p[name + ".norm.bias"])
+    prev = cn("fpn_lateral5", fr["res5"], 0)
+    res = [cn("fpn_output5", prev, 1)]
+    for s in (4, 3, 2):
+        prev = cn(f"fpn_lateral{s}", fr[f"res{s}"], 0) + orc.generator_forward(prev, gp, 3)
+        res.insert(0, cn(f"fpn_output{s}", prev, 1))
+    res.append(F.max_pool2d(res[-1], kernel_size=1, stride=2, padding=0))
+    ref = dict(zip(["p2", "p3", "p4", "p5", "p6"], res))
+    sum((o * R[k]).sum() for k, o in ref.items()).backward()
+    for k in ref:
+        assert _rel(out[k], ref[k]) < 1e-3, k
+    for k in fr:
+        assert _rel(fg[k].grad, fr[k].grad) < 1e-3, k
+    for k, q in fpn.named_parameters():
+        assert _rel(q.grad.contiguous(), p[k].grad) < 1e-3, k

@@ -231,3 +231,88 @@ def test_stage1_weights_load_into_afi_backbone():
     matched2 = ck.load_target_detector_weights(det2, det.state_dict())
     assert len(matched2) == 23 and all(bool((p == 0.25).all()) for p in det2.backbone.srf_module.parameters())
     assert not torch.equal(det2.backbone.fpn_lateral2.weight, det.backbone.fpn_lateral2.weight)
+
+
+# ------------------------------------------------------------------------------------------------ registry / config surface
+class _FakeBottomUp(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self._shapes = {"res2": (256, 4), "res3": (512, 8), "res4": (1024, 16), "res5": (2048, 32)}
+
+    def output_shape(self):
+        from afigan_amd.fpn_sr import ShapeSpec
+        return {k: ShapeSpec(channels=c, stride=s) for k, (c, s) in self._shapes.items()}
+
+
+def _fake_cfg(norm="", freeze=False):
+    import afigan_amd as amd
+    cfg = amd.get_cfg()
+    cfg.MODEL.FPN.NORM = norm
+    cfg.MODEL.AFI_FREEZE = freeze
+    return cfg
+
+
+def test_registry_names_config_keys_and_builders():
+    """Every builder name of the reference resolves (fpn_sr.py:201,224; pafpn_sr.py:237,260; bifpn_sr.py:791), the guide registry
+    holds RCNN_FPN_only (rcnn_only.py:17), the config keys of defaults.py:5-22 exist with the reference's defaults, and the builder
+    bodies run (bottom-up builder supplied by the test: the backbones themselves are outside this package)."""
+    import afigan_amd as amd
+    from afigan_amd import registry
+    for name in ("build_resnet_fpn_sr_backbone", "build_resnest_fpn_sr_backbone", "build_resnet_pafpn_sr_backbone",
+                 "build_resnest_pafpn_sr_backbone", "build_swint_bifpn_sr_backbone"):
+        assert callable(amd.BACKBONE_REGISTRY.get(name)), name
+    assert amd.GUIDE_ARCH_REGISTRY.get("RCNN_FPN_only") is amd.RCNN_FPN_only
+    cfg = _fake_cfg()
+    assert cfg.MODEL.GUIDE_ARCHITECTURE == "" and cfg.MODEL.GUIDE_WEIGHTS == "" and cfg.MODEL.AFI_GEN_WEIGHTS == ""
+    assert cfg.MODEL.AFI_DIS_WEIGHTS == "" and cfg.MODEL.AF_EXTRACTOR_WEIGHTS == "" and cfg.MODEL.AFI_FREEZE is False
+    assert cfg.MODEL.GUIDE_BACKBONE.NAME == "build_resnet_fpn_backbone" and cfg.MODEL.GUIDE_BACKBONE.FREEZE_AT == 2
+    old = dict(registry._BOTTOM_UP)
+    try:
+        for kind in ("resnet", "resnest"):
+            registry.set_bottom_up_builder(kind, lambda cfg, shape: _FakeBottomUp())
+        for name, cls in (("build_resnet_fpn_sr_backbone", amd.FPN_AFIGAN), ("build_resnest_fpn_sr_backbone", amd.FPN_AFIGAN),
+                          ("build_resnet_pafpn_sr_backbone", amd.PAFPN_AFIGAN), ("build_resnest_pafpn_sr_backbone", amd.PAFPN_AFIGAN)):
+            m = amd.BACKBONE_REGISTRY.get(name)(_fake_cfg(freeze=True), None)
+            assert isinstance(m, cls) and m.size_divisibility == 32
+            assert set(m.output_shape()) == {"p2", "p3", "p4", "p5", "p6"}
+            assert all(not p.requires_grad for p in m.srf_module.parameters())          # MODEL.AFI_FREEZE (fpn_sr.py:67-69)
+        # any get_norm string of the reference's configs: conv without bias + a norm child (fpn_sr.py:74-81)
+        m = amd.BACKBONE_REGISTRY.get("build_resnet_fpn_sr_backbone")(_fake_cfg(norm="GN"), None)
+        assert m.fpn_lateral2.bias is None and isinstance(m.fpn_lateral2.norm, torch.nn.GroupNorm)
+        assert "fpn_output5.norm.weight" in m.state_dict() and "fpn_output5.bias" not in m.state_dict()
+        m = amd.BACKBONE_REGISTRY.get("build_resnet_pafpn_sr_backbone")(_fake_cfg(norm="BN"), None)
+        assert "pafpn_downsample3.norm.running_mean" in m.state_dict() and m.pafpn_downsample3.bias is None
+    finally:
+        registry._BOTTOM_UP.clear()
+        registry._BOTTOM_UP.update(old)
+    # without a bottom-up builder the call fails loudly, naming what is missing
+    if not registry.USING_DETECTRON2_REGISTRY:
+        with pytest.raises(amd.AfiError, match="bottom-up"):
+            amd.BACKBONE_REGISTRY.get("build_swint_bifpn_sr_backbone")(_fake_cfg(), None)
+
+
+def test_builders_register_into_a_detectron2_style_registry(monkeypatch):
+    """What happens with detectron2 installed: the registration functions put the five names into ITS BACKBONE_REGISTRY (here a stand-in
+    object with the same interface, swapped in for the registry module's)."""
+    from afigan_amd import bifpn_sr, fpn_sr, pafpn_sr, registry
+    fake = registry.Registry("BACKBONE")
+    monkeypatch.setattr(registry, "BACKBONE_REGISTRY", fake)
+    assert fpn_sr._register() and pafpn_sr._register() and bifpn_sr._register()
+    assert sorted(fake._obj_map) == ["build_resnest_fpn_sr_backbone", "build_resnest_pafpn_sr_backbone", "build_resnet_fpn_sr_backbone",
+                                     "build_resnet_pafpn_sr_backbone", "build_swint_bifpn_sr_backbone"]
+    assert fpn_sr._register()                                   # idempotent: names already present are left alone
+
+
+def test_reference_import_paths_for_registry_and_config():
+    from afigan.config import get_cfg                           # noqa: F401  (config/config.py:3)
+    from afigan.modeling.meta_arch.build import GUIDE_ARCH_REGISTRY, build_guide_model   # noqa: F401
+    from afigan.modeling.meta_arch.rcnn_only import RCNN_FPN_only
+    assert GUIDE_ARCH_REGISTRY.get("RCNN_FPN_only") is RCNN_FPN_only
+
+
+def test_guide_network_pads_like_imagelist():
+    from afigan_amd.rcnn_only import pad_to_batch
+    a, b = torch.ones(3, 5, 7), 2 * torch.ones(3, 6, 4)
+    out = pad_to_batch([a, b], 4)
+    assert out.shape == (2, 3, 8, 8) and float(out[0, :, :5, :7].min()) == 1.0 and float(out[0, :, 5:].abs().max()) == 0.0
+    assert float(out[1, :, :6, :4].min()) == 2.0 and float(out[1, :, :, 4:].abs().max()) == 0.0
