@@ -450,7 +450,9 @@ def main():
             continue
         try:
             tj = json.load(open(tpath))
-            if tj.get("kernel") and not dom["kernel"].startswith(str(tj["kernel"]).split("<")[0]):
+            same = [t for t in ("gemm_nt", "gemm_tn", "pix_gemm_wk", "pix_gemm", "wgrad") if t in dom["kernel"]][:1] == \
+                   [t for t in ("gemm_nt", "gemm_tn", "pix_gemm_wk", "pix_gemm", "wgrad") if t in str(tj.get("kernel", ""))][:1]
+            if not same:
                 break                                      # measured on another kernel: stale
             traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch"),
                        "measured_at": tj.get("measured_at"), "source": f"profiles/{rnd}/traffic_dominant_kernel.json "
