@@ -13,6 +13,7 @@ import ctypes as C
 import os
 from typing import Dict, Sequence
 
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -144,3 +145,48 @@ class Stage2Adversarial:
 
     def d_metrics(self) -> Dict[str, float]:
         return dict(zip(self._names, self.losses.detach().cpu().tolist()))
+
+
+class Stage2Step:
+    """One stage-2 iteration, ``Multi_Scale_AF_Extractor_Trainer.run_step`` (afigan/engine/stage2_trainer.py:279-384), around the
+    HIP-backed adversarial terms:
+
+        hr_ = feature_model(data, img_dict_name='image')                 frozen guide network, full-size image            (:291)
+        loss_dict, up_ = model(data)                                     AFI detector on `image_x0.5`; its FPN features   (:296)
+        D step on (nearest-half(hr_p), up_p.detach()), D optimizer       Stage2Adversarial.d_step                         (:299-342)
+        loss_dict.update(g_loss_p{2..6})                                 Stage2Adversarial.g_losses (D already stepped)   (:344-364)
+        optimizer.zero_grad(); sum(loss_dict).backward(); optimizer.step()                                                (:366-384)
+
+    `model` is the detector (``GeneralizedRCNN_AFExtractor`` or anything with its contract: training-mode call returns
+    ``(loss_dict, [{"features": {"p2".."p6"}}])``), `feature_model` the guide (``RCNN_FPN_only``: returns ``[{"features": ...}]``),
+    `optimizer` any torch optimizer over the detector's parameters.  Data-parallel wrapping of `model` is the caller's (the reference
+    wraps it in DistributedDataParallel, :75-84; D's gradients are all-reduced inside Stage2Adversarial)."""
+
+    def __init__(self, model, feature_model, D: Discriminator, optimizer, levels: Sequence[int] = (2, 3, 4, 5, 6), **d_kwargs):
+        self.model, self.feature_model, self.optimizer = model, feature_model, optimizer
+        self.levels = tuple(levels)
+        self.adv = Stage2Adversarial(D, first_level=self.levels[0], **d_kwargs)
+        self.last_losses: Dict[str, float] = {}
+
+    def run_step(self, data):
+        if not self.model.training:
+            raise AssertionError("[Stage2Step] model was changed to eval mode!")                       # :283
+        with torch.no_grad():
+            hr_ = self.feature_model(data, img_dict_name="image")                                     # :291 (guide is frozen, eval mode)
+        loss_dict, up_ = self.model(data)                                                             # :296
+        hr = [hr_[0]["features"][f"p{d}"].detach() for d in self.levels]                             # :299-303
+        up = [up_[0]["features"][f"p{d}"] for d in self.levels]
+        self.adv.d_step(hr, up)                                                                       # :305-342
+        d_metrics = self.adv.d_metrics()
+        if not all(np.isfinite(v) for v in d_metrics.values()):                                       # _detect_anomaly (:324)
+            raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.adv.iter}!\nloss_dict = {d_metrics}")
+        loss_dict = dict(loss_dict)
+        loss_dict.update(self.adv.g_losses(hr, up))                                                   # :344-364
+        losses = sum(loss_dict.values())
+        if not torch.isfinite(losses).all():                                                          # :367
+            raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.adv.iter}!\nloss_dict = {loss_dict}")
+        self.optimizer.zero_grad()                                                                    # :377
+        losses.backward()
+        self.optimizer.step()                                                                         # :384
+        self.last_losses = {**d_metrics, **{k: float(v.detach()) for k, v in loss_dict.items()}}
+        return self.last_losses

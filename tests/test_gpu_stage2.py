@@ -91,3 +91,124 @@ def test_stage2_adversarial_vs_reference_fixture(amd, golden_dir):
     for k in sd:
         if "num_batches" in k:
             assert int(sd[k]) == int(fx["Dbuf_after/" + k]) == 8
+
+
+class _TinyBottomUp(torch.nn.Module):
+    """Learned stand-in bottom-up network: average pooling to strides 4..32 and a 1x1 conv per level (plain torch ops)."""
+
+    def __init__(self, chans=(8, 12, 16, 20)):
+        super().__init__()
+        self.chans = chans
+        self.proj = torch.nn.ModuleList([torch.nn.Conv2d(3, c, 1) for c in chans])
+
+    def output_shape(self):
+        from afigan_amd.fpn_sr import ShapeSpec
+        return {f"res{i + 2}": ShapeSpec(c, 4 * 2 ** i) for i, c in enumerate(self.chans)}
+
+    def forward(self, x):
+        return {f"res{i + 2}": p(torch.nn.functional.avg_pool2d(x, 4 * 2 ** i)) for i, p in enumerate(self.proj)}
+
+
+class _FakeRPN(torch.nn.Module):
+    def forward(self, images, features, gt):
+        return [None] * len(images), {"loss_rpn_cls": 0.1 * features["p3"].square().mean(), "loss_rpn_loc": 0.05 * features["p6"].abs().mean()}
+
+
+class _FakeHeads(torch.nn.Module):
+    def forward(self, images, features, proposals, gt):
+        return None, {"loss_cls": 0.2 * features["p2"].square().mean(), "loss_box_reg": 0.1 * features["p4"].abs().mean()}
+
+
+def _stage2_models(amd, C, seed):
+    torch.manual_seed(seed)
+    def fpn():
+        f = amd.FPN_AFIGAN(_TinyBottomUp(), ["res2", "res3", "res4", "res5"], C, top_block=amd.LastLevelMaxPool())
+        f.srf_module.load_state_dict(orc.closed_form_generator_params(C, 3, 32))
+        return f
+    det = amd.GeneralizedRCNN_AFExtractor(backbone=fpn(), proposal_generator=_FakeRPN(), roi_heads=_FakeHeads(),
+                                          pixel_mean=[0.4, 0.5, 0.6], pixel_std=[1.0, 1.1, 0.9], device="cuda")
+
+    class Cfg:
+        class MODEL:
+            DEVICE, PIXEL_MEAN, PIXEL_STD = "cuda", [0.4, 0.5, 0.6], [1.0, 1.1, 0.9]
+            class GUIDE_BACKBONE:
+                NAME = "_test_stage2_guide_backbone"
+        class INPUT:
+            FORMAT = "BGR"
+    guide_fpn = fpn()
+    if Cfg.MODEL.GUIDE_BACKBONE.NAME not in amd.BACKBONE_REGISTRY:
+        def _test_stage2_guide_backbone(cfg, shape):
+            return _stage2_models.guide_fpn
+        amd.BACKBONE_REGISTRY.register(_test_stage2_guide_backbone)
+    _stage2_models.guide_fpn = guide_fpn
+    guide = amd.RCNN_FPN_only(Cfg).eval()
+    D = amd.Discriminator(in_filters=C).cuda()
+    D.load_state_dict(orc.closed_form_discriminator_params(C))
+    return det, guide, D
+
+
+def test_stage2_step_is_the_reference_sequence(amd):
+    """Stage2Step.run_step (stage2_trainer.py:279-384) on a small detector: losses against the oracle evaluated on the detector's own
+    features, and the detector's parameter update against the oracle's feature gradients pushed through the same network."""
+    import copy
+    C, lr_d, lr_g = 32, 0.01, 0.05
+    det, guide, D = _stage2_models(amd, C, 3)
+    det2, D2 = copy.deepcopy(det), copy.deepcopy(D)
+    gen = torch.Generator().manual_seed(21)
+    data = [{"image": torch.rand((3, 128, 192), generator=gen), "image_x0.5": torch.rand((3, 64, 96), generator=gen)},
+            {"image": torch.rand((3, 120, 180), generator=gen), "image_x0.5": torch.rand((3, 60, 90), generator=gen)}]
+    opt = torch.optim.SGD(det.parameters(), lr=lr_g, momentum=0.9)
+    step = amd.Stage2Step(det.train(), guide, D, opt, base_lr=lr_d, warmup_iters=0, lr_steps=())
+    out = step.run_step(data)
+    assert set(out) == {f"d_loss_p{k}" for k in range(2, 7)} | {f"g_loss_p{k}" for k in range(2, 7)} | \
+        {"loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"}
+
+    # the same iteration by hand: HIP features of the untouched copies, the oracle for everything the stage-2 loop adds
+    with torch.no_grad():
+        hr = guide(data, img_dict_name="image")[0]["features"]
+    loss_dict, up_ = det2.train()(data)
+    up = up_[0]["features"]
+    lv = [f"p{k}" for k in range(2, 7)]
+    dp = {k: v.detach().cpu() for k, v in D2.state_dict().items()}
+    hr_c, up_c = [hr[k].detach().cpu().contiguous() for k in lv], [up[k].detach().cpu().contiguous() for k in lv]
+    d_losses, d_grads, d_bufs = orc.stage2_d_phase(dp, hr_c, up_c)
+    for k, v in d_losses.items():
+        assert abs(out[k] - v) <= 1e-3 * abs(v), (k, out[k], v)
+    params = {k: v for k, v in dp.items() if k in d_grads}
+    orc.sgd_momentum_step(params, d_grads, {}, lr=lr_d)
+    for k, p in D.named_parameters():
+        assert ((p.detach().cpu() - params[k]).abs().max() / params[k].abs().max()).item() < 1e-4, k
+    dp2 = dict(dp); dp2.update(params); dp2.update(d_bufs)
+    fr = [f.clone().requires_grad_(True) for f in up_c]
+    ref, _ = orc.stage2_g_losses(dp2, hr_c, fr)
+    g_terms = {k: v for k, v in ref.items() if k.startswith("g_loss")}
+    for k, v in g_terms.items():
+        assert abs(out[k] - v.item()) <= 1e-3 * abs(v.item()), (k, out[k], v.item())
+    for k, v in loss_dict.items():
+        assert abs(out[k] - v.item()) <= 1e-5 * abs(v.item()) + 1e-7, k
+    sum(g_terms.values()).backward()
+    opt2 = torch.optim.SGD(det2.parameters(), lr=lr_g, momentum=0.9)
+    opt2.zero_grad()
+    torch.autograd.backward([sum(loss_dict.values())] + [up[k] for k in lv], [None] + [f.grad.cuda() for f in fr])
+    opt2.step()
+    moved = 0
+    for (k, a), (_, b) in zip(det.named_parameters(), det2.named_parameters()):
+        assert ((a - b).abs().max() / (b.abs().max() + 1e-30)).item() < 2e-4, k
+        moved += 1
+    assert moved > 20 and step.adv.iter == 1
+
+
+def test_stage2_step_refuses_eval_mode_and_nonfinite(amd):
+    det, guide, D = _stage2_models(amd, 32, 4)
+    opt = torch.optim.SGD(det.parameters(), lr=0.01)
+    step = amd.Stage2Step(det.eval(), guide, D, opt)
+    data = [{"image": torch.rand(3, 64, 64), "image_x0.5": torch.rand(3, 32, 32)}]
+    with pytest.raises(AssertionError, match="eval mode"):
+        step.run_step(data)
+    det.train()
+    bad = [{"image": torch.full((3, 64, 64), float("nan")), "image_x0.5": torch.rand(3, 32, 32)}]
+    before = [p.detach().clone() for p in det.parameters()]
+    with pytest.raises(FloatingPointError, match="infinite or NaN"):
+        step.run_step(bad)
+    for a, b in zip(before, det.parameters()):
+        assert torch.equal(a, b)

@@ -316,3 +316,37 @@ def test_guide_network_pads_like_imagelist():
     out = pad_to_batch([a, b], 4)
     assert out.shape == (2, 3, 8, 8) and float(out[0, :, :5, :7].min()) == 1.0 and float(out[0, :, 5:].abs().max()) == 0.0
     assert float(out[1, :, :6, :4].min()) == 2.0 and float(out[1, :, :, 4:].abs().max()) == 0.0
+
+
+def test_af_extractor_contract_on_cpu():
+    """GeneralizedRCNN_AFExtractor (rcnn_extractor.py:41-70): half-size image in, (losses, [{"features"}]) out, zero padding to the
+    backbone's size_divisibility, RPN + ROI-head losses merged."""
+    import torch
+    import afigan_amd as amd
+
+    class BB(torch.nn.Module):
+        size_divisibility = 32
+
+        def forward(self, x):
+            return {"p2": x[:, :1]}
+
+    class RPN(torch.nn.Module):
+        def forward(self, images, features, gt):
+            assert gt is None and images.image_sizes[0] == (40, 50)
+            return [None] * len(images), {"loss_rpn": features["p2"].mean()}
+
+    class Heads(torch.nn.Module):
+        def forward(self, images, features, proposals, gt):
+            return ["inst"] * len(images), {"loss_cls": features["p2"].sum()}
+
+    m = amd.GeneralizedRCNN_AFExtractor(backbone=BB(), proposal_generator=RPN(), roi_heads=Heads(), pixel_mean=[1., 2, 3], pixel_std=[2., 2, 2],
+                                        device="cpu").train()
+    a, b = torch.rand(3, 40, 50), torch.rand(3, 33, 64)
+    losses, res = m([{"image_x0.5": a, "image": None}, {"image_x0.5": b, "image": None}])
+    f = res[0]["features"]["p2"]
+    assert set(losses) == {"loss_rpn", "loss_cls"} and f.shape == (2, 1, 64, 64)
+    assert torch.allclose(f[0, 0, :40, :50], (a[0] - 1) / 2) and float(f[0, 0, 40:].abs().sum()) == 0 and float(f[1, 0, 33:].abs().sum()) == 0
+    assert m.eval()([{"image_x0.5": a}]) == ["inst"]
+    assert amd.META_ARCH_REGISTRY.get("GeneralizedRCNN_AFExtractor") is amd.GeneralizedRCNN_AFExtractor
+    from afigan.modeling.meta_arch import GeneralizedRCNN_AFExtractor as shim
+    assert shim is amd.GeneralizedRCNN_AFExtractor
