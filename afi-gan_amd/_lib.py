@@ -91,6 +91,14 @@ SIGNATURES = {
     "afi_dwconv3x3_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp, _vp]),
     "afi_maxpool3s2_same_fwd": (_i, [View, _i, _i, _i, _i, _vp, _vp]),
     "afi_fuse_swish_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "afi_fuse_swish_bwd_scratch_floats": (_ll, []),
+    "afi_fuse_swish_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _vp, _vp]),
+    "afi_dwconv3x3_wgrad_scratch_floats": (_ll, [_i]),
+    "afi_dwconv3x3_wgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "afi_maxpool3s2_same_fwd_idx": (_i, [View, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "afi_maxpool3s2_same_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "afi_bn_stats_ex": (_i, [_vp, _ll, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "afi_bn_apply_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _f, _vp]),
     "afi_resize_bilinear_u8_ws_bytes": (_ll, [_i, _i, _i, _i, _i]),
     "afi_resize_bilinear_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _ll, _vp]),
     "afi_dual_scale_u8_ws_bytes": (_ll, [_i, _i, _i, _i, _i, _i, _i]),

@@ -1,7 +1,8 @@
-"""BiFPN with the AF interpolator as its up-sampler, inference path, on MI355X -- SURVEY.md section 8(f) row 4.
+"""BiFPN with the AF interpolator as its up-sampler on MI355X -- SURVEY.md section 8(f) row 4.
 
-Mirrors ``BiFPN_AFIGAN`` of the reference (afigan/modeling/backbone/bifpn_sr.py:203-733) for what the reference ships it
-for: an INFERENCE config (configs/inference/AFI-GAN_cascade_rcnn_swint_BiFPN_ST.yaml).  Same constructor arguments, the
+Mirrors ``BiFPN_AFIGAN`` of the reference (afigan/modeling/backbone/bifpn_sr.py:203-733).  The reference ships it in an INFERENCE
+config (configs/inference/AFI-GAN_cascade_rcnn_swint_BiFPN_ST.yaml); the eval-mode forward below is the fast path, and the training-mode
+forward (batch-statistics norms, autograd through every node) is built from the same kernels plus their backward.  Same constructor arguments, the
 ``srf_module`` attribute, the same state_dict (546 tensors + the interpolator's 23: ``before_bifpn.*``,
 ``BiFPNLayer_{0..6}_conv{3..6}_up / conv{4..7}_down.{depthwise,pointwise,norm}.*``, ``BiFPNLayer_{l}_p{k}_w{1,2}``), and
 ``forward(x) -> {"p3".."p7"}`` with every quirk of the hard-wired seven-layer forward (raw fusion weights, first-lateral
@@ -15,8 +16,13 @@ Per BiFPN node, in channels_last on this package's kernels:
             folded in                                  and bias                                 (afi_conv1x1_fwd)
 
 plus 28 interpolator forwards (one HIP call each) and the zero-padded 3x3/2 max-pools.  The forward has no host
-synchronisation, so it can be captured into a hipGraph (``bench.py`` measures both); training mode raises: the reference
-has no training recipe for this backbone, and the backward of these pieces is not built.
+synchronisation, so it can be captured into a hipGraph (``bench.py`` measures both).
+
+In training mode nothing is folded: each piece is a torch.autograd.Function over its HIP forward and backward
+(afi_fuse_swish_bwd, afi_dwconv3x3_fwd with reversed taps + afi_dwconv3x3_wgrad, afi_conv1x1_{dgrad,wgrad}, afi_maxpool3s2_same_bwd,
+the interpolator's own backward), and the norms use batch statistics with the reference's eps / momentum (afi_bn_stats_ex,
+afi_bn_apply_fwd, afi_bn_bwd).  "SyncBN" is taken as per-process BatchNorm: statistics are NOT exchanged between ranks (the reference
+has no multi-GPU training recipe for this backbone; with world_size 1 the two are the same function).
 """
 import math
 
@@ -24,7 +30,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
-from .fpn_sr import ShapeSpec
+from .fpn_sr import ShapeSpec, _dense_pm, _LateralMergeFn
 from .generator_rdb import Generator
 
 __all__ = ["BiFPN_AFIGAN", "LastLevelP6P7"]
@@ -49,8 +55,8 @@ def _make_norm(norm, ch, eps=1e-5, momentum=0.1):
     if norm == "":
         return None
     if norm not in ("BN", "SyncBN"):
-        raise _lib.AfiError(f'norm "{norm}" is not supported on the BiFPN inference path (BN / SyncBN / "")')
-    bn = nn.BatchNorm2d(ch, eps=eps, momentum=momentum)      # eval-mode SyncBN == BN; same state_dict entries
+        raise _lib.AfiError(f'norm "{norm}" is not supported on the BiFPN path (BN / SyncBN / "")')
+    bn = nn.BatchNorm2d(ch, eps=eps, momentum=momentum)      # SyncBN == BN within one process; same state_dict entries
     return bn
 
 
@@ -87,6 +93,95 @@ class _BeforeBiFPN(nn.Module):                                # bifpn_sr.py:159-
         self.top_block = top_block
         self.p4_skip = _lateral(in_channels[1], out_channels)
         self.p5_skip = _lateral(in_channels[2], out_channels)
+
+
+class _FuseSwishFn(torch.autograd.Function):
+    """swish(w[0]*a + w[1]*b (+ w[2]*c)) with the raw fusion weights (bifpn_sr.py:535-563) and its backward."""
+
+    @staticmethod
+    def forward(ctx, w, a, b, c):
+        wd = w.detach().contiguous()
+        a, b = _dense_pm(a.detach()), _dense_pm(b.detach())
+        c = _dense_pm(c.detach()) if c is not None else None
+        ctx.save_for_backward(wd, a, b, c)
+        return ops.fuse_swish(wd, a, b, c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        wd, a, b, c = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dw, da, db, dc = ops.fuse_swish_bwd(wd, a, b, c, _dense_pm(dy), need=need)
+        return dw, da, db, dc
+
+
+class _DepthwiseFn(torch.autograd.Function):
+    """SeparableConv2d.depthwise (3x3, zero pad 1, no bias); weight [C,1,3,3] as torch keeps it."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        C_ = w.shape[0]
+        w9c = w.detach().reshape(C_, 9).t().contiguous()
+        x = _dense_pm(x.detach())
+        ctx.save_for_backward(x, w9c)
+        return ops.dwconv3x3(x, w9c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w9c = ctx.saved_tensors
+        dy = _dense_pm(dy)
+        dx = ops.dwconv3x3(dy, w9c.flip(0).contiguous()) if ctx.needs_input_grad[0] else None      # correlation with the reversed taps
+        dw = ops.dwconv3x3_wgrad(dy, x).t().reshape(-1, 1, 3, 3) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        out, idx = ops.maxpool3s2_same_idx(ops.pixel_major(x.detach()))
+        ctx.save_for_backward(idx)
+        ctx.in_hw = tuple(x.shape[-2:])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        return ops.maxpool3s2_same_bwd(_dense_pm(dy), idx, ctx.in_hw)
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    """BatchNorm2d in training mode on a pixel-major tensor: batch statistics (fp64 accumulation), running buffers updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn):
+        x = _dense_pm(x.detach())
+        N, C_, H, W = x.shape
+        x2d = x.permute(0, 2, 3, 1).reshape(N * H * W, C_)
+        mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+        track = bn.track_running_stats and bn.running_mean is not None
+        mean, invstd = ops.bn_stats_ex(x2d, bn.eps, mom, bn.running_mean if track else None, bn.running_var if track else None,
+                                       bn.num_batches_tracked if track else None)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y = ops.bn_apply(x2d, mean, invstd, g, b)
+        ctx.save_for_backward(x, mean, invstd, g)
+        return y.view(N, H, W, C_).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, invstd, g = ctx.saved_tensors
+        N, C_, H, W = x.shape
+        dy2d = _dense_pm(dy).permute(0, 2, 3, 1).reshape(N * H * W, C_)
+        dgamma, dbeta = torch.zeros_like(g), torch.zeros_like(g)
+        dx = ops.bn_bwd(dy2d, x.permute(0, 2, 3, 1).reshape(N * H * W, C_), mean, invstd, g, dgamma, dbeta)
+        return dx.view(N, H, W, C_).permute(0, 3, 1, 2), dgamma, dbeta, None
+
+
+def _norm_train(x, bn):
+    """A norm layer inside the autograd graph: batch statistics when the layer is in training mode, its running ones otherwise."""
+    if bn is None:
+        return x
+    if bn.training:
+        return _BatchNormTrainFn.apply(x, bn.weight, bn.bias, bn)
+    return torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
 
 
 def _fold(conv, bn):
@@ -181,10 +276,44 @@ class BiFPN_AFIGAN(nn.Module):
         with ops.weight_transform_cache(first.device):
             return self._forward_impl(x)
 
+    def _forward_train(self, x):
+        """The same seven layers with nothing folded, every piece differentiable (see the module docstring)."""
+        bb = self.before_bifpn
+        bottom_up_features = self.bottom_up(x)
+        c3, c4, c5 = [bottom_up_features[k] for k in self.in_features]       # (the Functions below make their own pixel-major copies)
+
+        def lat(t, seq):
+            return _norm_train(_LateralMergeFn.apply(t, seq[0].weight, seq[0].bias, None), seq[1])
+
+        def node(m, w, a, b, c=None):
+            y = _DepthwiseFn.apply(_FuseSwishFn.apply(w, a, b, c), m.depthwise.weight)
+            return _norm_train(_LateralMergeFn.apply(y, m.pointwise.weight, m.pointwise.bias, None), m.norm)
+
+        c4_skip, c5_skip = lat(c4, bb.p4_skip), lat(c5, bb.p5_skip)
+        p6 = bb.top_block.p6
+        c6 = _MaxPoolFn.apply(_norm_train(_LateralMergeFn.apply(c5, p6.conv.weight, p6.conv.bias, None), getattr(p6, "norm", None)))
+        c7 = _MaxPoolFn.apply(c6)
+        lateral = (lat(c3, bb.lateral3), lat(c4, bb.lateral4), lat(c5, bb.lateral5), c6, c7)
+        G = self.srf_module
+        feats = lateral
+        for l in range(self.N_LAYERS):
+            p3_in, p4_in, p5_in, p6_in, p7_in = feats
+            W = lambda name: getattr(self, f"BiFPNLayer_{l}_{name}")          # noqa: E731
+            p6_up = node(W("conv6_up"), W("p6_w1"), p6_in, G(p7_in))
+            p5_up = node(W("conv5_up"), W("p5_w1"), p5_in, G(p6_up))
+            p4_up = node(W("conv4_up"), W("p4_w1"), p4_in, G(p5_up))
+            p3_up = node(W("conv3_up"), W("p3_w1"), p3_in, G(p4_up))
+            s4, s5 = (c4_skip, c5_skip) if l == 0 else (lateral[1], lateral[2])
+            p4_out = node(W("conv4_down"), W("p4_w2"), s4, p4_up, _MaxPoolFn.apply(p3_up))
+            p5_out = node(W("conv5_down"), W("p5_w2"), s5, p5_up, _MaxPoolFn.apply(p4_out))
+            p6_out = node(W("conv6_down"), W("p6_w2"), lateral[3], p6_up, _MaxPoolFn.apply(p5_out))
+            p7_out = node(W("conv7_down"), W("p7_w2"), lateral[4], _MaxPoolFn.apply(p6_out))
+            feats = (p3_up, p4_out, p5_out, p6_out, p7_out)
+        return dict(zip(self._out_features, feats))
+
     def _forward_impl(self, x):
-        if self.training:
-            raise _lib.AfiError("BiFPN_AFIGAN is an inference-only path in this build (the reference ships it in an inference config only): "
-                                "call .eval() first")
+        if self.training or torch.is_grad_enabled() and any(t.requires_grad for t in (x.values() if isinstance(x, dict) else [x])):
+            return self._forward_train(x)
         with torch.no_grad():
             f = self._prepare()
             bottom_up_features = self.bottom_up(x)

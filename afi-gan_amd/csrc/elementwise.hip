@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void afi_bn_stats_partial_kernel(const float* 
 __global__ void afi_bn_stats_finalize64_kernel(const double* __restrict__ partial, int chunks, const float* __restrict__ x0, long long P, int C,
                                                float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
                                                float* __restrict__ running_mean, float* __restrict__ running_var,
-                                               long long* __restrict__ num_batches_tracked) {
+                                               long long* __restrict__ num_batches_tracked, float eps, float momentum) {
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;     // torch BatchNorm2d train mode
     __shared__ double red[2][8][AFI_FIN_CH];
     const int cl = threadIdx.x & (AFI_FIN_CH - 1), ln = threadIdx.x / AFI_FIN_CH;
@@ -243,12 +243,12 @@ __global__ void afi_bn_stats_finalize64_kernel(const double* __restrict__ partia
     double var = s1 * inv_n - d * d;                // biased
     var = var > 0.0 ? var : 0.0;
     mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)AFI_BN_EPS));
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
     if (var_out) var_out[c] = (float)var;
     if (running_mean) {
         const double unb = var * ((double)P / (double)(P > 1 ? P - 1 : 1));
-        running_mean[c] = (float)((1.0 - (double)AFI_BN_MOMENTUM) * (double)running_mean[c] + (double)AFI_BN_MOMENTUM * m);
-        running_var[c] = (float)((1.0 - (double)AFI_BN_MOMENTUM) * (double)running_var[c] + (double)AFI_BN_MOMENTUM * unb);
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
     }
 }
 
@@ -256,7 +256,7 @@ __global__ void afi_bn_stats_finalize64_kernel(const double* __restrict__ partia
 __global__ void afi_bn_stats_finalize_kernel(const float* __restrict__ partial, int chunks, const float* __restrict__ x0, long long P, int C,
                                              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
                                              float* __restrict__ running_mean, float* __restrict__ running_var,
-                                             long long* __restrict__ num_batches_tracked) {
+                                             long long* __restrict__ num_batches_tracked, float eps, float momentum) {
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;     // torch BatchNorm2d train mode
     int c; float s0, s1;
     if (!afi_chunk_sums(partial, chunks, C, true, c, s0, s1)) return;
@@ -266,27 +266,27 @@ __global__ void afi_bn_stats_finalize_kernel(const float* __restrict__ partial, 
     float var = s1 * inv_n - d * d;                 // biased
     var = fmaxf(var, 0.f);
     mean[c] = m;
-    invstd[c] = rsqrtf(var + AFI_BN_EPS);
+    invstd[c] = rsqrtf(var + eps);
     if (var_out) var_out[c] = var;
     if (running_mean) {
         const float unb = var * ((float)P / (float)(P > 1 ? P - 1 : 1));
-        running_mean[c] = (1.f - AFI_BN_MOMENTUM) * running_mean[c] + AFI_BN_MOMENTUM * m;
-        running_var[c] = (1.f - AFI_BN_MOMENTUM) * running_var[c] + AFI_BN_MOMENTUM * unb;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
     }
 }
 
-// y = lrelu((x - mean) * invstd * gamma + beta)
+// y = lrelu_slope((x - mean) * invstd * gamma + beta); slope 1 = the plain affine (BiFPN's norms have no activation behind them)
 __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
                                           const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                          long long P, int C) {
+                                          long long P, int C, float slope) {
     const long long total4 = P * C / 4;
     const int C4 = C / 4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    auto apply = [](f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
+    auto apply = [slope](f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
         v = (v - mu) * is * ga + be;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * AFI_LRELU_SLOPE;
+        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
         return v;
     };
     if (stride % C4 == 0) {
@@ -378,26 +378,29 @@ static unsigned afi_ew_grid(long long work_items) {
 }
 
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out,
-                        float* running_mean, float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked) {
+                        float* running_mean, float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked, float eps,
+                        float momentum) {
+    if (eps < 0.f) eps = AFI_BN_EPS;                        // negative = torch's BatchNorm2d defaults (the discriminator's norms)
+    if (momentum < 0.f) momentum = AFI_BN_MOMENTUM;
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     static const int stats64 = getenv("AFI_BN_STATS_F64") ? atoi(getenv("AFI_BN_STATS_F64")) : 1;      // 0: the fp32 one-pass form (A/B only)
     if (stats64 && (((uintptr_t)scratch) & 7) == 0) {
         hipLaunchKernelGGL(afi_bn_stats_partial_kernel, dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, P, C, (long long)C, rpc, (double*)scratch);
         hipLaunchKernelGGL(afi_bn_stats_finalize64_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, (const double*)scratch, chunks, x, P, C, mean,
-                           invstd, var_out, running_mean, running_var, num_batches_tracked);
+                           invstd, var_out, running_mean, running_var, num_batches_tracked, eps, momentum);
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((afi_colred_partial_kernel<0>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, (long long)C, rpc, scratch);
     hipLaunchKernelGGL(afi_bn_stats_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, x, P, C, mean, invstd,
-                       var_out, running_mean, running_var, num_batches_tracked);
+                       var_out, running_mean, running_var, num_batches_tracked, eps, momentum);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                              long long P, int C, hipStream_t st) {
+                              long long P, int C, hipStream_t st, float slope) {
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_bn_apply_lrelu_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, x, y, mean, invstd, gamma, beta, P, C);
+    hipLaunchKernelGGL(afi_bn_apply_lrelu_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, x, y, mean, invstd, gamma, beta, P, C, slope);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma,

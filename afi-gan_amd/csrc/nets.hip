@@ -23,9 +23,10 @@ int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hi
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
 int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st);
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
-                        float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked = nullptr);
+                        float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked = nullptr, float eps = -1.f,
+                        float momentum = -1.f);
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                              long long P, int C, hipStream_t st);
+                              long long P, int C, hipStream_t st, float slope = AFI_LRELU_SLOPE);
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                       float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st);
 int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st);
@@ -680,6 +681,15 @@ int afi_bn_stats(const float* x, long long P, int C, float* mean, float* invstd,
 int afi_bn_apply_lrelu_fwd(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                            long long P, int C, void* stream) {
     return afi_launch_bn_apply_lrelu(x, y, mean, invstd, gamma, beta, P, C, (hipStream_t)stream);
+}
+int afi_bn_stats_ex(const float* x, long long P, int C, float eps, float momentum, float* mean, float* invstd, float* var, float* rm, float* rv,
+                    long long* nbt, float* scratch, void* stream) {
+    if (eps < 0.f || momentum < 0.f || momentum > 1.f || !x || !mean || !invstd || !scratch || (rm == nullptr) != (rv == nullptr)) return AFI_ERR_BAD_ARG;
+    return afi_launch_bn_stats(x, P, C, mean, invstd, var, rm, rv, scratch, (hipStream_t)stream, nbt, eps, momentum);
+}
+int afi_bn_apply_fwd(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta, long long P, int C,
+                     float slope, void* stream) {
+    return afi_launch_bn_apply_lrelu(x, y, mean, invstd, gamma, beta, P, C, (hipStream_t)stream, slope);
 }
 int afi_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                float* dbeta, long long P, int C, float* scratch, void* stream) {

@@ -426,6 +426,71 @@ def fuse_swish(w, a, b, c=None):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ BiFPN node backward (training mode)
+def fuse_swish_bwd(w, a, b, c, dout, need=(True, True, True, True)):
+    """Backward of fuse_swish: returns (dw, da, db, dc); entries not in `need` (w, a, b, c) come back None."""
+    _check_cuda(w, a, b, c, dout)
+    assert is_dense_pm(dout) and dout.shape == a.shape
+    dev = a.device
+    da = new_pixel_major(*a.shape, dev) if need[1] else None
+    db = new_pixel_major(*a.shape, dev) if need[2] else None
+    dc = new_pixel_major(*a.shape, dev) if (c is not None and need[3]) else None
+    dw = torch.empty_like(w) if need[0] else None
+    scratch = torch.empty(_lib.load().afi_fuse_swish_bwd_scratch_floats(), device=dev, dtype=torch.float32)
+    call("afi_fuse_swish_bwd", _p(a), _p(b), _p(c), _p(w), _p(dout), _p(da), _p(db), _p(dc), _p(dw), a.numel(), _p(scratch), stream_ptr())
+    return dw, da, db, dc
+
+
+def dwconv3x3_wgrad(dy, x):
+    """[9, C] tap-major weight gradient of dwconv3x3 from dense pixel-major dy and x."""
+    _check_cuda(dy, x)
+    assert is_dense_pm(dy) and is_dense_pm(x) and dy.shape == x.shape
+    N, C_, H, W = x.shape
+    dw = torch.empty((9, C_), device=x.device, dtype=torch.float32)
+    scratch = torch.empty(_lib.load().afi_dwconv3x3_wgrad_scratch_floats(C_), device=x.device, dtype=torch.float32)
+    call("afi_dwconv3x3_wgrad", _p(dy), _p(x), N, H, W, C_, _p(dw), _p(scratch), stream_ptr())
+    return dw
+
+
+def maxpool3s2_same_idx(x):
+    """maxpool3s2_same keeping the argmax taps (uint8, [N, Ho, Wo, C]) for maxpool3s2_same_bwd."""
+    _check_cuda(x)
+    N, C_, H, W = x.shape
+    Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
+    out = new_pixel_major(N, C_, Ho, Wo, x.device)
+    idx = torch.empty((N, Ho, Wo, C_), device=x.device, dtype=torch.uint8)
+    call("afi_maxpool3s2_same_fwd_idx", view_of(x), N, H, W, C_, _p(out), _p(idx), stream_ptr())
+    return out, idx
+
+
+def maxpool3s2_same_bwd(dout, idx, in_hw):
+    _check_cuda(dout)
+    if not idx.is_cuda or idx.dtype != torch.uint8 or not idx.is_contiguous():
+        raise _lib.AfiError("idx must be the contiguous uint8 CUDA tensor maxpool3s2_same_idx returned")
+    N, C_ = dout.shape[:2]
+    H, W = in_hw
+    assert is_dense_pm(dout) and tuple(idx.shape) == (N, (H - 2) // 2 + 1, (W - 2) // 2 + 1, C_) and tuple(dout.shape[2:]) == tuple(idx.shape[1:3])
+    dx = new_pixel_major(N, C_, H, W, dout.device)
+    call("afi_maxpool3s2_same_bwd", _p(dout), _p(idx), N, H, W, C_, _p(dx), stream_ptr())
+    return dx
+
+
+def bn_stats_ex(x2d, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    """Train-mode statistics of a dense [P, C] matrix with the norm's own eps / momentum; updates the running buffers in place."""
+    P, C_ = x2d.shape
+    mean, invstd = torch.empty(C_, device=x2d.device), torch.empty(C_, device=x2d.device)
+    call("afi_bn_stats_ex", _p(x2d), P, C_, float(eps), float(momentum), _p(mean), _p(invstd), _p(None), _p(running_mean), _p(running_var),
+         _p(num_batches_tracked), _p(reduce_scratch(C_, x2d.device)), stream_ptr())
+    return mean, invstd
+
+
+def bn_apply(x2d, mean, invstd, gamma, beta, slope=1.0):
+    P, C_ = x2d.shape
+    y = torch.empty_like(x2d)
+    call("afi_bn_apply_fwd", _p(x2d), _p(y), _p(mean), _p(invstd), _p(gamma), _p(beta), P, C_, float(slope), stream_ptr())
+    return y
+
+
 # ------------------------------------------------------------------------------------------------ dual-scale data path
 def _check_u8(t):
     if not t.is_cuda:

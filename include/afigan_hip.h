@@ -208,6 +208,25 @@ int afi_maxpool3s2_same_fwd(afi_view_t x, int N, int H, int W, int C, float* out
 int afi_fuse_swish_fwd(const float* a, const float* b, const float* c_or_null, const float* w_dev, float* out, long long n,
                        void* stream);
 
+/* BiFPN_AFIGAN under autograd (the same node, training mode): the backward of the three pieces above.  No atomics: every reduction is
+ * two-stage in a fixed order.  The depthwise INPUT gradient is afi_dwconv3x3_fwd on dy with the taps reversed (w9c rows 8..0); the
+ * pointwise conv is afi_conv1x1_{dgrad,wgrad}; the train-mode norm is afi_bn_stats_ex + afi_bn_apply_fwd + afi_bn_bwd.
+ *   afi_fuse_swish_bwd           ds = dout * swish'(w.{a,b,c});  d{a,b,c} = w_k * ds (each optional), dw[2 or 3] = sum ds * {a,b,c}
+ *                                (MemoryEfficientSwish.backward, bifpn_layers/activations.py); scratch: afi_fuse_swish_bwd_scratch_floats()
+ *   afi_dwconv3x3_wgrad          dw9c[t][c] = sum_pixels dy[p][c] * x[p + tap t][c]; dy, x dense [N,H,W,C];
+ *                                scratch: afi_dwconv3x3_wgrad_scratch_floats(C)
+ *   afi_maxpool3s2_same_fwd_idx  the forward, also keeping idx[N,Ho,Wo,C] (one byte per element, 4-byte aligned): tap 3*dy+dx of the
+ *                                first maximum in scan order, which is where torch's max_pool2d sends the gradient
+ *   afi_maxpool3s2_same_bwd      dx dense [N,H,W,C] = gather of dout over the windows whose argmax is the element (a window won by the
+ *                                zero pad sends its gradient nowhere, as F.pad's backward drops it) */
+long long afi_fuse_swish_bwd_scratch_floats(void);
+int afi_fuse_swish_bwd(const float* a, const float* b, const float* c_or_null, const float* w_dev, const float* dout, float* da_or_null,
+                       float* db_or_null, float* dc_or_null, float* dw_or_null, long long n, float* scratch, void* stream);
+long long afi_dwconv3x3_wgrad_scratch_floats(int C);
+int afi_dwconv3x3_wgrad(const float* dy, const float* x, int N, int H, int W, int C, float* dw9c, float* scratch, void* stream);
+int afi_maxpool3s2_same_fwd_idx(afi_view_t x, int N, int H, int W, int C, float* out, unsigned char* idx, void* stream);
+int afi_maxpool3s2_same_bwd(const float* dout, const unsigned char* idx, int N, int H, int W, int C, float* dx, void* stream);
+
 /* ConvTranspose2d(k=6,s=2,p=2) (generator_rdb.py:101-105) on the packed weight wp[4*Cout][3][3][Cin] */
 int afi_convT6s2_pack_weight(const float* w_iohw, float* wp, int Cin, int Cout, void* stream);
 int afi_convT6s2_unpack_wgrad(const float* dwp, float* dw_iohw, int Cin, int Cout, void* stream);   /* dw += */
@@ -227,6 +246,14 @@ int afi_bn_stats(const float* x, long long P, int C, float* mean, float* invstd,
                  float* running_mean_or_null, float* running_var_or_null, float* scratch, void* stream);
 int afi_bn_apply_lrelu_fwd(const float* x, float* y, const float* mean, const float* invstd, const float* gamma,
                            const float* beta, long long P, int C, void* stream);
+/* The same two passes for a norm with its own eps / momentum and no activation behind it (BiFPN: eps 1e-3, momentum 0.01,
+ * bifpn_sr.py:279-280): statistics (+ running-stat update and num_batches_tracked += 1 when given), then
+ * y = lrelu_slope((x - mean) * invstd * gamma + beta) with slope 1 = the plain affine.  Backward: afi_bn_bwd. */
+int afi_bn_stats_ex(const float* x, long long P, int C, float eps, float momentum, float* mean, float* invstd, float* var_biased_or_null,
+                    float* running_mean_or_null, float* running_var_or_null, long long* num_batches_tracked_or_null, float* scratch,
+                    void* stream);
+int afi_bn_apply_fwd(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
+                     long long P, int C, float slope, void* stream);
 int afi_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma,
                float* dgamma, float* dbeta, long long P, int C, float* scratch, void* stream);
 /* db[C] += alpha * column sums of the [P][C] matrix g with row stride ld */

@@ -327,6 +327,31 @@ def main():
     np.savez_compressed(os.path.join(HERE, "bifpn_eval.npz"), **fx)
     print("bifpn", {k: tuple(v.shape) for k, v in out.items()}, len(sd), "tensors")
 
+    # BiFPN_AFIGAN in TRAINING mode (batch-statistics norms, autograd through all seven layers): outputs, input gradients, parameter
+    # gradient digests and the running buffers after the step.  norm="BN": nn.SyncBatchNorm has no CPU forward, and within one
+    # process the two compute the same function.
+    bifpn.load_state_dict(sd, strict=True)
+    bifpn.train()
+    gen = torch.Generator().manual_seed(36)
+    feats = {f"stage{i + 3}": torch.randn((2, c, 32 // 2 ** i, 48 // 2 ** i), generator=gen).requires_grad_(True) for i, c in enumerate([8, 12, 16])}
+    out = bifpn(feats)
+    R = {k: torch.randn(o.shape, generator=torch.Generator().manual_seed(200 + i)) for i, (k, o) in enumerate(out.items())}
+    sum((o * R[k]).sum() for k, o in out.items()).backward()
+    fx = {"seed": np.array([36]), "state_dict_contract": fx["state_dict_contract"]}
+    for k, o in out.items():
+        fx["out/" + k] = o.detach().numpy() if k != "p3" else o.detach()[:, ::4].numpy()
+    for k, f in feats.items():
+        fx["dfeat/" + k] = f.grad.numpy()
+    fx.update(grads_digest({k: p.grad for k, p in bifpn.named_parameters() if p.grad is not None}))
+    for k, v in bifpn.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            d, smp = tensor_digest(v)
+            fx["bd/" + k], fx["bs/" + k] = d, smp
+        elif k.endswith("num_batches_tracked"):
+            assert int(v) == 4, (k, int(v))
+    np.savez_compressed(os.path.join(HERE, "bifpn_train.npz"), **fx)
+    print("bifpn train", {k: tuple(v.shape) for k, v in out.items()}, sum(p.grad is not None for p in bifpn.parameters()), "gradients")
+
     # ---------------- G-small: full tensors, reference default init ----------------
     for tag, shape in (("a", (2, 16, 5, 7)), ("b", (1, 16, 7, 11))):
         torch.manual_seed(1234)

@@ -1,6 +1,7 @@
-"""GPU parity of the BiFPN inference path (afi-gan_amd/bifpn_sr.py): the per-op pieces against torch-CPU
-fp32, and the whole seven-layer forward (28 interpolator calls) against the fixture captured from the imported reference
-BiFPN_AFIGAN in eval mode and against the CPU oracle.  Bar: 1e-3 relative fp32."""
+"""GPU parity of the BiFPN path (afi-gan_amd/bifpn_sr.py): the per-op pieces and their backward against torch-CPU
+fp32 / fp64, the whole seven-layer forward (28 interpolator calls) against the fixtures captured from the imported reference
+BiFPN_AFIGAN in eval mode and in training mode (outputs, gradients, running statistics) and against the CPU oracle.
+Bar: 1e-3 relative fp32 (named exceptions below)."""
 import numpy as np
 import pytest
 import torch
@@ -43,6 +44,67 @@ def test_bifpn_pieces(amd, N, C, H, W):
     assert _rel(ops.fuse_swish(w3[:2].contiguous().cuda(), _pm(x), _pm(y)), orc.swish(w3[0] * x + w3[1] * y)) < 1e-5
 
 
+@pytest.mark.parametrize("N,C,H,W", [(1, 16, 5, 7), (2, 256, 14, 22), (1, 64, 2, 4), (1, 32, 113, 97), (2, 8, 6, 6)])
+def test_bifpn_pieces_backward(amd, N, C, H, W):
+    """Backward of the three node pieces against fp64 autograd on the CPU."""
+    ops = amd.ops
+    g = torch.Generator().manual_seed(3)
+    x, y, z = (torch.randn((N, C, H, W), generator=g, dtype=torch.float64).requires_grad_(True) for _ in range(3))
+    # fusion + swish, three and two inputs
+    for n_in in (3, 2):
+        w = torch.tensor([0.4, 1.1, 0.7][:n_in], dtype=torch.float64, requires_grad=True)
+        ins = (x, y, z)[:n_in]
+        out = orc.swish(sum(w[i] * t for i, t in enumerate(ins)))
+        R = torch.randn(out.shape, generator=g, dtype=torch.float64)
+        gr = torch.autograd.grad((out * R).sum(), (w,) + ins)
+        got = ops.fuse_swish_bwd(w.detach().float().cuda(), *[_pm(t.detach().float()) for t in ins], *([None] if n_in == 2 else []), _pm(R.float()))
+        assert _rel(got[0], gr[0].float()) < 1e-4
+        for a, b in zip(got[1:1 + n_in], gr[1:]):
+            assert _rel(a, b.float()) < 1e-5
+        assert n_in == 3 or got[3] is None
+    # depthwise 3x3: input gradient (the forward kernel on reversed taps) and weight gradient
+    wdw = torch.randn((C, 1, 3, 3), generator=g, dtype=torch.float64, requires_grad=True)
+    out = F.conv2d(F.pad(x, (1, 1, 1, 1)), wdw, None, 1, 0, 1, C)
+    R = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    gx, gw = torch.autograd.grad((out * R).sum(), (x, wdw))
+    w9c = wdw.detach().float().reshape(C, 9).t().contiguous().cuda()
+    assert _rel(ops.dwconv3x3(_pm(R.float()), w9c.flip(0).contiguous()), gx.float()) < 1e-5
+    assert _rel(ops.dwconv3x3_wgrad(_pm(R.float()), _pm(x.detach().float())).t().reshape(C, 1, 3, 3), gw.float()) < 1e-5
+    # zero-padded max-pool: same winners as torch (first maximum in scan order, pad included), so the gradient is exact
+    for src in (x.detach().float(), -x.detach().float().abs() - 1.0, torch.zeros((N, C, H, W)), (x.detach().float() * 2).round() / 2):
+        xs = src.clone().requires_grad_(True)
+        ref = orc.maxpool3s2_same(xs)
+        Rm = torch.randn(ref.shape, generator=g)
+        (gxm,) = torch.autograd.grad((ref * Rm).sum(), xs)
+        out, idx = ops.maxpool3s2_same_idx(_pm(src))
+        assert torch.equal(out.cpu(), ref.detach())
+        dx = ops.maxpool3s2_same_bwd(_pm(Rm), idx, (H, W))
+        assert _rel(dx, gxm) < 1e-6
+
+
+def test_bn_train_function(amd):
+    """The training-mode norm used by the BiFPN nodes (eps 1e-3, momentum 0.01) against torch's BatchNorm2d on the CPU."""
+    from afigan_amd.bifpn_sr import _BatchNormTrainFn
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn((2, 32, 9, 7), generator=g) * 3 + 1).requires_grad_(True)
+    ref = torch.nn.BatchNorm2d(32, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(32, generator=g) + 0.5); ref.bias.copy_(torch.randn(32, generator=g))
+        ref.running_mean.copy_(torch.randn(32, generator=g)); ref.running_var.copy_(torch.rand(32, generator=g) + 0.5)
+    import copy
+    bn = copy.deepcopy(ref).cuda()
+    R = torch.randn(x.shape, generator=g)
+    yr = ref(x)
+    (yr * R).sum().backward()
+    xg = _pm(x.detach()).requires_grad_(True)
+    out = _BatchNormTrainFn.apply(xg, bn.weight, bn.bias, bn)
+    (out * R.cuda()).sum().backward()
+    assert _rel(out, yr) < 1e-5 and _rel(xg.grad, x.grad) < 1e-4
+    assert _rel(bn.weight.grad, ref.weight.grad) < 1e-5 and _rel(bn.bias.grad, ref.bias.grad) < 1e-5
+    assert _rel(bn.running_mean, ref.running_mean) < 1e-6 and _rel(bn.running_var, ref.running_var) < 1e-6
+    assert int(bn.num_batches_tracked) == 1
+
+
 class _BottomUp3(torch.nn.Module):
     _out_feature_strides = {"stage3": 8, "stage4": 16, "stage5": 32}
     _out_feature_channels = {"stage3": 8, "stage4": 12, "stage5": 16}
@@ -58,8 +120,6 @@ def test_bifpn_eval_vs_reference_fixture_and_oracle(amd, golden_dir):
     net = amd.BiFPN_AFIGAN(_BottomUp3(), ["stage3", "stage4", "stage5"], 256, 7, norm="BN", top_block=amd.LastLevelP6P7(16, 256, "BN")).cuda()
     assert set(net.state_dict()) == set(p)                                    # the reference's state_dict contract
     net.load_state_dict(p, strict=True)
-    with pytest.raises(amd.AfiError):
-        net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})         # training mode is not built
     net.eval()
     out = net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})
     assert list(out) == ["p3", "p4", "p5", "p6", "p7"] and net.size_divisibility == 128
@@ -74,6 +134,88 @@ def test_bifpn_eval_vs_reference_fixture_and_oracle(amd, golden_dir):
         net.BiFPNLayer_6_conv3_up.norm.bias.add_(0.5)
     out2 = net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})
     assert _rel(out2["p3"], out["p3"] + 0.5) < 1e-5
+
+
+def test_bifpn_train_vs_reference_fixture(amd, golden_dir):
+    """Training mode: batch-statistics norms and autograd through all seven layers against the fixture of the imported reference
+    BiFPN_AFIGAN.train() -- outputs, gradients w.r.t. the bottom-up features and every parameter, running statistics."""
+    from test_oracle_golden import _bifpn_train_case, _check_digests, _digest
+    fx = dict(np.load(f"{golden_dir}/bifpn_train.npz"))
+    p, feats, R = _bifpn_train_case(fx)
+    net = amd.BiFPN_AFIGAN(_BottomUp3(), ["stage3", "stage4", "stage5"], 256, 7, norm="BN", top_block=amd.LastLevelP6P7(16, 256, "BN")).cuda()
+    net.load_state_dict({k: v.detach() for k, v in p.items()}, strict=True)
+    net.train()
+    fg = {f"stage{i + 3}": f.detach().cuda().requires_grad_(True) for i, f in enumerate(feats)}
+    out = net(fg)
+    sum((o * R[k].cuda()).sum() for k, o in out.items()).backward()
+    for k, o in out.items():
+        gold = fx["out/" + k]
+        got = o.detach().cpu().numpy() if k != "p3" else o.detach()[:, ::4].cpu().numpy()
+        assert np.abs(got - gold).max() <= 1e-3 * np.abs(gold).max(), k
+    for k, f in fg.items():
+        gold = fx["dfeat/" + k]
+        assert np.abs(f.grad.cpu().numpy() - gold).max() <= 2e-3 * np.abs(gold).max(), k
+    grads = {k: v.grad.cpu() for k, v in net.named_parameters() if v.grad is not None}
+    assert {k for k in fx if k.startswith("gd/")} == {"gd/" + k for k in grads}
+    # (the conv biases in front of a training-mode norm have an analytically zero gradient: see tests/test_oracle_golden.py)
+    dead = {k for k in grads if not k.startswith("srf_module.") and (k.endswith("pointwise.bias") or k.endswith(".0.bias") or k.endswith("p6.conv.bias"))}
+    for k in dead:
+        assert grads[k].abs().max() <= 1e-4 * grads[k[:-len("bias")] + "weight"].abs().max(), k
+    _check_digests(fx, {k: g for k, g in grads.items() if k not in dead and not k.startswith("srf_module.")}, rtol=2e-3)
+    _check_digests(fx, {k: g for k, g in grads.items() if k.startswith("srf_module.")}, rtol=1e-2)     # sums over 28 calls that cancel
+    sd = net.state_dict()
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == 4, k
+        elif "running" in k:
+            d, s = _digest(sd[k].cpu())
+            assert abs(d[1] - fx["bd/" + k][1]) <= 1e-4 * fx["bd/" + k][1], k
+            np.testing.assert_allclose(s, fx["bs/" + k], rtol=0, atol=1e-4 * fx["bd/" + k][2], err_msg=k)
+
+
+def test_bifpn_train_small_vs_oracle(amd):
+    """A 32-channel BiFPN, no norm on the top block, frozen interpolator: training forward / backward against the oracle."""
+    C = 32
+
+    class Cfg:
+        class MODEL:
+            AFI_FREEZE = True
+    net = amd.BiFPN_AFIGAN(_BottomUp3(), ["stage3", "stage4", "stage5"], C, 7, norm="SyncBN", top_block=amd.LastLevelP6P7(16, C, ""), cfg=Cfg).cuda()
+    from test_oracle_golden import _bifpn_params_and_feats  # noqa: F401  (loads make_golden's closed-form recipe)
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    p = {k: mg.bifpn_closed_form(k, v) for k, v in net.state_dict().items() if not k.startswith("srf_module.")}
+    p.update({"srf_module." + k: v for k, v in orc.closed_form_generator_params(C, 3, 32).items()})
+    net.load_state_dict(p, strict=True)
+    net.train()
+    g = torch.Generator().manual_seed(9)
+    feats = [torch.randn((2, c, 16 // 2 ** i, 48 // 2 ** i), generator=g).requires_grad_(True) for i, c in enumerate([8, 12, 16])]
+    fg = {f"stage{i + 3}": f.detach().cuda().requires_grad_(True) for i, f in enumerate(feats)}
+    out = net(fg)
+    R = {k: torch.randn(o.shape, generator=g) for k, o in out.items()}
+    sum((o * R[k].cuda()).sum() for k, o in out.items()).backward()
+    pr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k and not k.startswith("srf_module.") else v.clone()) for k, v in p.items()}
+    bufs = {}
+    ref = orc.bifpn_afigan_forward(feats, pr, train_buffers=bufs)
+    sum((o * R[k]).sum() for k, o in ref.items()).backward()
+    for k in ref:
+        assert _rel(out[k], ref[k]) < 1e-3, k
+    for i, f in enumerate(feats):
+        assert _rel(fg[f"stage{i + 3}"].grad, f.grad) < 2e-3, i
+    n = 0
+    for k, v in net.named_parameters():
+        if k.startswith("srf_module."):
+            assert v.grad is None
+            continue
+        if k.endswith("pointwise.bias") or k.endswith(".0.bias"):
+            continue                                       # zero gradient behind a training-mode norm
+        assert _rel(v.grad, pr[k].grad) < 2e-3, k
+        n += 1
+    assert n > 200
+    sd = net.state_dict()
+    for k, v in bufs.items():
+        assert _rel(sd[k].float(), v.float()) < 1e-4, k
 
 
 def test_bifpn_hipgraph_capture(amd):

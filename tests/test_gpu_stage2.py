@@ -176,8 +176,11 @@ def test_stage2_step_is_the_reference_sequence(amd):
         assert abs(out[k] - v) <= 1e-3 * abs(v), (k, out[k], v)
     params = {k: v for k, v in dp.items() if k in d_grads}
     orc.sgd_momentum_step(params, d_grads, {}, lr=lr_d)
-    for k, p in D.named_parameters():
-        assert ((p.detach().cpu() - params[k]).abs().max() / params[k].abs().max()).item() < 1e-4, k
+    # D's own parity is tests/test_gpu_d_parity.py's subject (LeakyReLU-mask flips between two fp32 evaluations move a gradient
+    # tensor by up to TOL_OWN_FORWARD_L2 = 3e-3 in L2); here: the UPDATE each parameter received, to that bar, over all of D
+    num = sum(float(((p.detach().cpu() - dp[k]) - (params[k] - dp[k])).square().sum()) for k, p in D.named_parameters())
+    den = sum(float((params[k] - dp[k]).square().sum()) for k, p in D.named_parameters())
+    assert (num / den) ** 0.5 < 3e-3, (num / den) ** 0.5
     dp2 = dict(dp); dp2.update(params); dp2.update(d_bufs)
     fr = [f.clone().requires_grad_(True) for f in up_c]
     ref, _ = orc.stage2_g_losses(dp2, hr_c, fr)
@@ -202,11 +205,11 @@ def test_stage2_step_refuses_eval_mode_and_nonfinite(amd):
     det, guide, D = _stage2_models(amd, 32, 4)
     opt = torch.optim.SGD(det.parameters(), lr=0.01)
     step = amd.Stage2Step(det.eval(), guide, D, opt)
-    data = [{"image": torch.rand(3, 64, 64), "image_x0.5": torch.rand(3, 32, 32)}]
+    data = [{"image": torch.rand(3, 128, 128), "image_x0.5": torch.rand(3, 64, 64)}]
     with pytest.raises(AssertionError, match="eval mode"):
         step.run_step(data)
     det.train()
-    bad = [{"image": torch.full((3, 64, 64), float("nan")), "image_x0.5": torch.rand(3, 32, 32)}]
+    bad = [{"image": torch.full((3, 128, 128), float("nan")), "image_x0.5": torch.rand(3, 64, 64)}]
     before = [p.detach().clone() for p in det.parameters()]
     with pytest.raises(FloatingPointError, match="infinite or NaN"):
         step.run_step(bad)

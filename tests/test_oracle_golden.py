@@ -258,6 +258,56 @@ def test_bifpn_eval_matches_reference(golden_dir):
         np.testing.assert_allclose(o.numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=k)
 
 
+def _bifpn_train_case(fx):
+    """State dict (leaf tensors), the seeded training inputs and the seeded loss weights of tests/golden/bifpn_train.npz."""
+    p, _ = _bifpn_params_and_feats(fx)
+    p = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone()) for k, v in p.items()}
+    gen = torch.Generator().manual_seed(int(fx["seed"][0]))
+    feats = [torch.randn((2, c, 32 // 2 ** i, 48 // 2 ** i), generator=gen).requires_grad_(True) for i, c in enumerate([8, 12, 16])]
+    shapes = {"p3": (2, 256, 32, 48), "p4": (2, 256, 16, 24), "p5": (2, 256, 8, 12), "p6": (2, 256, 4, 6), "p7": (2, 256, 2, 3)}
+    R = {k: torch.randn(sh, generator=torch.Generator().manual_seed(200 + i)) for i, (k, sh) in enumerate(shapes.items())}
+    return p, feats, R
+
+
+def test_bifpn_train_matches_reference(golden_dir):
+    """oracle.bifpn_afigan_forward in TRAINING mode vs the imported reference BiFPN_AFIGAN.train(): outputs, gradients w.r.t. the bottom-up
+    features and every parameter, running statistics after the step."""
+    fx = _load(golden_dir, "bifpn_train.npz")
+    p, feats, R = _bifpn_train_case(fx)
+    bufs = {}
+    out = orc.bifpn_afigan_forward(feats, p, train_buffers=bufs)
+    sum((o * R[k]).sum() for k, o in out.items()).backward()
+    for k, o in out.items():
+        ref = fx["out/" + k]
+        got = o.detach().numpy() if k != "p3" else o.detach()[:, ::4].numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=5e-5 * np.abs(ref).max(), err_msg=k)
+    for i, f in enumerate(feats):
+        ref = fx[f"dfeat/stage{i + 3}"]
+        np.testing.assert_allclose(f.grad.numpy(), ref, rtol=0, atol=5e-4 * np.abs(ref).max(), err_msg=f"stage{i + 3}")
+    grads = {k: v.grad for k, v in p.items() if v.requires_grad and v.grad is not None}
+    assert {k for k in fx if k.startswith("gd/")} == {"gd/" + k for k in grads}
+    # a conv bias in front of a training-mode norm has an analytically ZERO gradient (the norm subtracts the mean): what both sides hold
+    # there is summation round-off, compared against the size of the same conv's weight gradient instead of against each other
+    dead = {k for k in grads if not k.startswith("srf_module.") and (k.endswith("pointwise.bias") or k.endswith(".0.bias") or k.endswith("p6.conv.bias"))}
+    assert len(dead) == 5 + 1 + 7 * 8
+    for k in dead:
+        wk = k[:-len("bias")] + "weight"
+        assert grads[k].abs().max() <= 1e-4 * grads[wk].abs().max() and fx["gd/" + k][2] <= 1e-4 * fx["gd/" + wk][2], k
+    _check_digests(fx, {k: g for k, g in grads.items() if k not in dead and not k.startswith("srf_module.")}, rtol=1e-3)
+    # the interpolator's weight gradients are sums over its 28 calls that cancel to ~1e-4 of their terms: fp32 ordering noise is larger there
+    _check_digests(fx, {k: g for k, g in grads.items() if k.startswith("srf_module.")}, rtol=5e-3)
+    n_buf = 0
+    for k, v in bufs.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 4
+            continue
+        d, s = _digest(v)
+        assert abs(d[1] - fx["bd/" + k][1]) <= 1e-5 * fx["bd/" + k][1], k
+        np.testing.assert_allclose(s, fx["bs/" + k], rtol=0, atol=1e-5 * fx["bd/" + k][2], err_msg=k)
+        n_buf += 1
+    assert n_buf == 2 * (5 + 1 + 7 * 8)
+
+
 def _stage2_inputs(fx):
     gen = torch.Generator().manual_seed(int(fx["seed"][0]))
     guide = [torch.randn((2, 256, 26, 42), generator=gen), torch.randn((2, 256, 13, 21), generator=gen)]
