@@ -9,7 +9,7 @@ All forward/backward math runs in hand-written HIP kernels for gfx950 behind the
 ``include/afigan_hip.h`` (libafigan_hip.so).  There is no CPU / eager fallback.
 """
 from . import _lib
-from ._lib import AfiError
+from ._lib import AfiError, compute_dtype
 
 _lib.load()     # fail loudly at import time when the HIP library is missing
 
@@ -28,4 +28,4 @@ from .rcnn_only import RCNN_FPN_only  # noqa: E402
 from .rcnn_extractor import GeneralizedRCNN_AFExtractor, META_ARCH_REGISTRY  # noqa: E402
 from .config import add_afigan_config, get_cfg  # noqa: E402
 
-__all__ = ["Generator", "Discriminator", "Stage1Step", "warmup_multistep_lr", "FPN_AFIGAN", "PAFPN_AFIGAN", "BiFPN_AFIGAN", "LastLevelP6P7", "LastLevelMaxPool", "Stage2Adversarial", "l1_loss_common", "nearest_half", "DualScaleMapper", "preprocess_images", "ops", "AfiError", "BACKBONE_REGISTRY", "GUIDE_ARCH_REGISTRY", "build_guide_model", "RCNN_FPN_only", "GeneralizedRCNN_AFExtractor", "META_ARCH_REGISTRY", "Stage2Step", "add_afigan_config", "get_cfg"]
+__all__ = ["Generator", "Discriminator", "Stage1Step", "warmup_multistep_lr", "FPN_AFIGAN", "PAFPN_AFIGAN", "BiFPN_AFIGAN", "LastLevelP6P7", "LastLevelMaxPool", "Stage2Adversarial", "l1_loss_common", "nearest_half", "DualScaleMapper", "preprocess_images", "ops", "AfiError", "compute_dtype", "BACKBONE_REGISTRY", "GUIDE_ARCH_REGISTRY", "build_guide_model", "RCNN_FPN_only", "GeneralizedRCNN_AFExtractor", "META_ARCH_REGISTRY", "Stage2Step", "add_afigan_config", "get_cfg"]

@@ -59,6 +59,10 @@ SIGNATURES = {
     "afi_ctx_create": (_i, [C.POINTER(C.c_void_p)]),
     "afi_ctx_destroy": (_i, [_vp]),
     "afi_ctx_set_op_scratch": (_i, [_vp, _vp, _ll]),
+    "afi_ctx_set_compute_dtype": (_i, [_vp, _i]),
+    "afi_ctx_get_compute_dtype": (_i, [_vp]),
+    "afi_gemm_nt": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
+    "afi_gemm_tn": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     "afi_ctx_set_wino_weight_cache": (_i, [_vp, _vp, _ll]),
     "afi_ctx_wino_weight_cache_invalidate": (_i, [_vp]),
     "afi_ctx_set_wino_wgrad_accum": (_i, [_vp, _vp, _ll]),
@@ -166,16 +170,30 @@ CTX_FIRST = frozenset(n for n, (_, a) in SIGNATURES.items() if n.startswith(("af
                       and not n.endswith(("_ws_floats", "_ws_layout", "pack_weight", "unpack_wgrad")))
 
 
-class Ctx:
-    """afi_ctx_t owned from Python: created on the current GPU, destroyed with the object.  Buffers registered with it are kept alive here."""
+DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 3}             # AFI_DTYPE_* of include/afigan_hip.h
 
-    def __init__(self):
+
+class Ctx:
+    """afi_ctx_t owned from Python: created on the current GPU, destroyed with the object.  Buffers registered with it are kept alive here.
+    `dtype`: arithmetic of the Winograd-domain GEMMs run under this context ("fp32" -- the parity path and the default --, "bf16x3",
+    "bf16"; see afi_ctx_set_compute_dtype)."""
+
+    def __init__(self, dtype="fp32"):
         h = C.c_void_p()
         check(load().afi_ctx_create(C.byref(h)), "afi_ctx_create")
         self.handle = h
         self.device = torch.cuda.current_device()
         self.bufs = {}                # name -> tensor registered with the context
         self.keep = None              # list collecting temporaries that must outlive an open weight-transform-cache block
+        self.dtype = "fp32"
+        if dtype != "fp32":
+            self.set_dtype(dtype)
+
+    def set_dtype(self, dtype):
+        if dtype not in DTYPES:
+            raise AfiError(f"compute dtype must be one of {sorted(DTYPES)}, got {dtype!r}")
+        check(load().afi_ctx_set_compute_dtype(self.handle, DTYPES[dtype]), "afi_ctx_set_compute_dtype")
+        self.dtype = dtype
 
     def __del__(self):
         try:
@@ -202,6 +220,25 @@ def current_ctx() -> "Ctx":
     if cx is None:
         cx = _default_ctx[key] = Ctx()
     return cx
+
+
+class compute_dtype:
+    """``with compute_dtype("bf16x3"):`` -- the module-level ops of this thread (Generator / FPN / PAFPN / BiFPN autograd, afigan_amd.ops)
+    run their Winograd-domain GEMMs in that arithmetic inside the block; restored on exit.  Engines with their own context
+    (Stage1Step, Stage2Adversarial) take ``dtype=`` instead."""
+
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.cx = current_ctx()
+        self.prev = self.cx.dtype
+        self.cx.set_dtype(self.dtype)
+        return self.cx
+
+    def __exit__(self, *exc):
+        self.cx.set_dtype(self.prev)
+        return False
 
 
 class use_ctx:

@@ -615,8 +615,10 @@ const char* kKindNames[] = {
     "pix_gemm<128x128,KC,halo> (conv fwd)", "pix_gemm<128x128,RC,halo> (conv dgrad)",
     "gemm_nt<128x128> (batched Winograd GEMM)", "gemm_tn<128x128> (Winograd weight-gradient GEMM)",
     "pix_gemm_wk (small-map pixel GEMM, K split inside the block; grouped launches included)",
-    "wgrad_group (grouped weight gradients of a small-map backward pass)"};   // one kind per kernel, as rocprofv3 lists them
-constexpr int kNumKinds = 17;
+    "wgrad_group (grouped weight gradients of a small-map backward pass)",
+    "gemm_nt_bf16<128x128> (batched Winograd GEMM, bf16 / bf16x3 MFMA, fp32 accumulate)",
+    "gemm_tn_bf16<128x128> (Winograd weight-gradient GEMM, bf16 / bf16x3 MFMA, fp32 accumulate)"};   // one kind per kernel, as rocprofv3 lists them
+constexpr int kNumKinds = 19;
 hipEvent_t prof_event() {
     if (g_prof.used == g_prof.pool.size()) {
         hipEvent_t e;
@@ -749,6 +751,22 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
     prof.m = M; prof.n = N; prof.k = K;
     // (two register sets for the A stream, PF = 2, spill under the 168-register cap of 3 blocks per CU: 95 instead of 262 TFLOP/s)
     hipLaunchKernelGGL((afi_gemm_nt_kernel<1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ntn, ntm, chunk);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+#include "afi_gemm_bf16.h"
+// the same GEMM on the bf16 matrix cores (split = 1: bf16 operands; 3: split-bf16, three MFMAs per k-step); fp32 planes in and out
+int afi_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st) {
+    if (planes <= 0 || rows_per_plane <= 0 || N <= 0 || K <= 0 || (split != 1 && split != 3)) return AFI_ERR_BAD_ARG;
+    if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
+    AfiGemmNT g{A, B, C, rows_per_plane, planes, N, K};
+    const long long M = rows_per_plane * planes;
+    const int ntm = (int)(M / 128), ntn = N / 128, chunk = afi_cdiv(ntm, 8);
+    const size_t lds = afi_gemm_nt_bf16_lds(split);
+    ProfScope prof(st, 17, 2.0 * (double)M * N * K);
+    prof.m = M; prof.n = N; prof.k = K; prof.split = split;
+    if (split == 3) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<3>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ntn, ntm, chunk);
+    else hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ntn, ntm, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -897,6 +915,37 @@ int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, lo
     ProfScope prof(st, 14, 2.0 * (double)rows_per_plane * planes * M * N);
     prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
     hipLaunchKernelGGL(afi_gemm_tn_kernel, dim3((unsigned)tiles, splitK), dim3(256), sizeof(float) * AFI_BK * 256, st, g, ntm, ntn, kper);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st) {
+    if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0 || (split != 1 && split != 3)) return AFI_ERR_BAD_ARG;
+    if ((rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
+    const int ntm = M / 128, ntn = N / 128;
+    const long long tiles = (long long)ntm * ntn * planes;
+    // two resident blocks per CU (512 slots); a stage is ~16x shorter than the fp32 kernel's, so blocks keep >= 16 stages each
+    int splitK = 1;
+    {
+        const int maxsplit = (int)(rows_per_plane / (16 * 32)) > 0 ? (int)(rows_per_plane / (16 * 32)) : 1;
+        double best = -1.0;
+        for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {
+            const long long blocks = tiles * s2;
+            if (blocks < 2 * 512 && s2 < maxsplit) continue;
+            if (blocks > 6 * 512 && best >= 0.0) break;
+            const long long rounds = (blocks + 511) / 512;
+            const double fill = (double)blocks / (double)(rounds * 512);
+            if (fill > best + 1e-3) { best = fill; splitK = s2; }
+        }
+    }
+    int kper = (int)((rows_per_plane + splitK - 1) / splitK);
+    kper = ((kper + 31) / 32) * 32;
+    splitK = (int)((rows_per_plane + kper - 1) / kper);
+    AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
+    ProfScope prof(st, 18, 2.0 * (double)rows_per_plane * planes * M * N);
+    prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
+    const size_t lds = 2u * 2u * (split == 3 ? 2u : 1u) * 8192u;
+    if (split == 3) hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<3>), dim3((unsigned)tiles, splitK), dim3(256), lds, st, g, ntm, ntn, kper);
+    else hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<1>), dim3((unsigned)tiles, splitK), dim3(256), lds, st, g, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

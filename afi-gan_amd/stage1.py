@@ -107,7 +107,7 @@ class Stage1Step:
     def __init__(self, G: Generator, D: Discriminator, base_lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (270000,), lr_gamma: float = 0.1,
                  warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2,
-                 reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None):
+                 reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: str = "fp32"):
         self.G, self.D = G, D
         self.gnet, self.dnet = G, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
@@ -143,7 +143,9 @@ class Stage1Step:
                 raise _lib.AfiError("parameters must be stored in the kernels' layout ([O][kh][kw][I]); "
                                     "construct the modules with afigan_amd.Generator / Discriminator")
         self._buf: Dict[str, torch.Tensor] = {}
-        self.ctx = _lib.Ctx()          # this engine's own library state (weight-transform cache, gradient accumulator, side stream)
+        # this engine's own library state (weight-transform cache, gradient accumulator, side stream) and the arithmetic of its big
+        # convolutions: "fp32" is the reference's and the parity path; "bf16x3" / "bf16" are opt-in (afi_ctx_set_compute_dtype)
+        self.ctx = _lib.Ctx(dtype)
         self.after_allreduce = None
         self.losses = None
         self._loss_names: List[str] = []

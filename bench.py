@@ -28,6 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA", dense
 G_FWD_FLOP_PER_INPX = 19_206_144        # SURVEY.md 8(d) / BASELINE.md section 3
 D_FWD_FLOP_PER_PX = 30_689_280
 D_FWDBWD_DETACHED_FLOP_PER_PX = 89_708_544
@@ -43,6 +44,9 @@ def parse():
     ap.add_argument("--no-interp", action="store_true", help="skip the AF-interpolator micro-benchmark")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse "
                     "the multi-process path with several ranks sharing one GPU)")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16x3", "bf16"],
+                    help="arithmetic of the Winograd-domain GEMMs (afi_ctx_set_compute_dtype).  fp32 = the reference's and the headline; the "
+                         "default run also times the two bf16 settings after the fp32 measurement and reports them under other_dtypes")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
     return ap.parse_args()
@@ -348,7 +352,7 @@ def main():
     G = amd.Generator(n_residual_dense_blocks=3).to(dev)
     D = amd.Discriminator().to(dev)
     G.train(); D.train()
-    step = amd.Stage1Step(G, D, base_lr=1e-3)
+    step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype)
     guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)     # each rank owns a different shard of the global batch
     images = torch.rand((B, 3, 800, 1333), device=dev, generator=gen) * 255.0
@@ -438,6 +442,36 @@ def main():
                           "flop_total": out3[2]})
     kinds.sort(key=lambda r: -r["ms_total"])
     dom = kinds[0]
+    # the opt-in bf16 arithmetic on the same engine, same inputs (N = 1 only; never the headline value): 1 warm-up + the same K steps each
+    other_dtypes = None
+    if world == 1 and args.dtype == "fp32" and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":
+        other_dtypes = {}
+        for dt in ("bf16x3", "bf16"):
+            step.ctx.set_dtype(dt)
+            one_step()
+            torch.cuda.synchronize()
+            lib.afi_profile_enable(1)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            lib.afi_profile_enable(0)
+            gk = []
+            for k in range(lib.afi_profile_num_kinds()):
+                o3 = (C.c_double * 3)()
+                _lib.check(lib.afi_profile_get(k, o3), "afi_profile_get")
+                if o3[0] > 0 and "bf16" in lib.afi_profile_kind_name(k).decode():
+                    gk.append({"kernel": lib.afi_profile_kind_name(k).decode(), "launches": int(o3[0]), "ms_total": round(o3[1], 3),
+                               "tflops": round(o3[2] / (o3[1] * 1e-3) / 1e12, 1), "frac_of_bf16_mfma_peak": round(o3[2] / (o3[1] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)})
+            try:
+                fin = all(v == v and abs(v) != float("inf") for v in step.metrics().values())
+            except FloatingPointError:
+                fin = False
+            other_dtypes[dt] = {"ms_per_step": el / args.steps * 1e3, "images_per_s": B * args.steps / el, "losses_finite": fin, "bf16_gemm_kernels": gk}
+            log(f"dtype {dt}: {el / args.steps * 1e3:.1f} ms/step")
+        step.ctx.set_dtype("fp32")
+
     gemm_ms = sum(r["ms_total"] for r in kinds)
     gemm_flop = sum(r["flop_total"] for r in kinds)
     # HBM traffic of the dominant kernel cannot be read live (PMC counters need their own rocprofv3 passes): report the
@@ -460,8 +494,9 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         break
-    roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
+    dom_peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["kernel"] else PEAK_FP32_MFMA_TFLOPS      # (--dtype bf16x3 / bf16: the dense bf16 MFMA peak)
+    roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": dom_peak, "unit": "TFLOP/s",
+                "frac": dom["tflops"] / dom_peak, "traffic": traffic, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
                 "share_of_step_time": dom["ms_total"] / (elapsed * 1e3),
                 # the whole step in EXECUTED matrix-core FLOPs (what the GEMM launches multiplied, Winograd-domain for the big convs)
                 # over wall time and peak: the one <= 1 "achieved roofline" figure of the step
@@ -483,7 +518,8 @@ def main():
     line = {
         "metric": "stage1_G+D_step_images_per_s", "value": n_img / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 operands, three bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)",
+                                       "bf16": "bf16 (bf16 operands, fp32 accumulate; tensors fp32)"}[args.dtype], "data": "synthetic",
         "backend": (args.backend if world > 1 else None),
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
                                f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",
@@ -497,6 +533,9 @@ def main():
         "step_algorithmic_tflops_over_fp32_mfma_peak": flop_img * B * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
         "conv_algorithm": "Winograd F(2x2,3x3) fwd/dgrad + F(3x3,2x2) wgrad for the discriminator's 3x3 convs (fp32, exact-f32 MFMA GEMMs); direct implicit GEMM elsewhere",
         "roofline": roofline,
+        # opt-in arithmetic of the big convolutions, same engine / inputs / K (afi_ctx_set_compute_dtype; tolerances: tests/test_gpu_bf16.py).
+        # Not the headline: the reference is fp32-only.  Their GEMM kernels are priced against the dense bf16 MFMA peak.
+        "other_dtypes": other_dtypes,
         "params_identical_across_ranks": params_identical,
         "losses_last_step": {k: round(v, 5) for k, v in metrics.items()}, "losses_finite": losses_finite,
     }

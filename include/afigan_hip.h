@@ -67,6 +67,27 @@ int afi_ctx_destroy(afi_ctx_t* ctx);                       /* refused (AFI_ERR_B
  * (< 6 tiles of 128x128 per CU) run split-K with a deterministic second pass.  256 MB covers every shape that is split.  (The whole-net
  * entry points carve their split-K scratch out of the workspace they are given.) */
 int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
+/* Arithmetic of the Winograd-domain GEMMs issued under this context -- every 3x3 / stride-1 convolution with >= 128 channels on both
+ * sides and >= 1024 pixels, forward, data gradient and weight gradient, i.e. >= 95 % of a stage-1 step's FLOPs.  Tensors, transforms,
+ * epilogues, accumulators and every other kernel stay fp32.  The reference is fp32-only (SOLVER.AMP is never read, defaults.py:82), so
+ * this is opt-in and each setting carries its own tolerance (tests/test_gpu_bf16.py):
+ *   AFI_DTYPE_F32     fp32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-3 parity path, the default.
+ *   AFI_DTYPE_BF16X3  operands split x = hi + lo into two bf16 (2^-17), three v_mfma_f32_32x32x16_bf16 per k-step (hi*hi + hi*lo + lo*hi),
+ *                     fp32 accumulate; same tilings as fp32.  Conv outputs within 1e-3 of the fp32 oracle (max-norm).
+ *   AFI_DTYPE_BF16    operands rounded to bf16 (2^-9), one v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate; every convolution on
+ *                     F(2x2,3x3) tiles (F(4x4) transforms do not survive 8-bit operands).  Conv outputs within 2e-2 (max-norm).
+ * Refused while weight-gradient sums are pending. */
+#define AFI_DTYPE_F32 0
+#define AFI_DTYPE_BF16 1
+#define AFI_DTYPE_BF16X3 3
+int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype);
+int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
+/* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over
+ * `planes` groups; rows_per_plane % 128 == 0, N % 128 == 0, K % 32 == 0 (else AFI_ERR_UNSUPPORTED); fp32 in memory for every dtype. */
+int afi_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int dtype, void* stream);
+/* ... and the weight-gradient form  dU[g][m][n] += sum_k Q[g][k][m] * V[g][k][n]  (both operands k-slow; rows_per_plane = K per plane,
+ * % 32 == 0; M % 128 == 0, N % 128 == 0).  Split-K with fp32 atomics: the summation order varies run to run. */
+int afi_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int dtype, void* stream);
 /* Cache of the Winograd-transformed (and packed conv-transpose) weights.  Within one phase of a training step the same weights serve up
  * to ten calls (stage1_trainer.py:336-433: five levels x real / fake); each (weight pointer, tiling, direction) is transformed once and
  * re-used until afi_ctx_wino_weight_cache_invalidate() -- which the caller MUST issue whenever weight VALUES change (optimizer step,

@@ -1,0 +1,151 @@
+"""The opt-in bf16 arithmetic of the Winograd-domain GEMMs (afi_ctx_set_compute_dtype; BASELINE.json configs[4] "bf16"): each setting
+against the fp32 oracle with ITS OWN stated tolerance.  The reference is fp32-only, so fp32 stays the default and the 1e-3 parity path.
+
+    dtype      operands                         GEMM alone (max-norm)   conv3x3 fwd / dgrad / wgrad   generator fwd+bwd, D step
+    fp32       exact fp32 MFMA                  2e-6                    1e-5 .. 1e-4 (other tests)    1e-3 (other tests)
+    bf16x3     x = hi + lo, 3 bf16 MFMAs        2e-5                    2e-4                          1e-3 outputs / input grads; 1e-2 (L2) weight grads
+    bf16       x -> bf16(x), 1 bf16 MFMA        8e-3                    2e-2 (F(2x2) tiles only)      5e-2 outputs / input grads; 1e-1 (L2) weight grads
+"""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import afigan_oracle as orc  # noqa: E402
+
+TOL_GEMM = {"fp32": 2e-6, "bf16x3": 2e-5, "bf16": 8e-3}
+TOL_CONV = {"bf16x3": 2e-4, "bf16": 2e-2}
+TOL_NET = {"bf16x3": 1e-3, "bf16": 5e-2}
+TOL_GRAD_L2 = {"bf16x3": 1e-2, "bf16": 1e-1}
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import afigan_amd
+    assert torch.cuda.is_available()
+    return afigan_amd
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return ((a - b).abs().max() / (b.abs().max() + 1e-300)).item()
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3", "bf16"])
+def test_batched_gemms(amd, dtype):
+    """afi_gemm_nt / afi_gemm_tn (the GEMMs every big 3x3 conv runs on) against fp64, including the last tile of the last plane."""
+    from afigan_amd import _lib
+    lib, dt, st = _lib.load(), _lib.DTYPES[dtype], amd.ops.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for planes, rows, N, K in ((3, 256, 128, 32), (16, 384, 256, 288), (36, 128, 384, 1024)):
+        A = torch.randn((planes, rows, K), device="cuda", generator=g)
+        B = torch.randn((planes, N, K), device="cuda", generator=g)
+        Cm = torch.full((planes, rows, N), float("nan"), device="cuda")
+        _lib.check(lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), planes, rows, N, K, dt, st), "afi_gemm_nt")
+        assert _rel(Cm, torch.bmm(A.double(), B.double().transpose(1, 2))) < TOL_GEMM[dtype], (planes, rows, N, K)
+    for planes, rows, M, N in ((2, 64, 128, 128), (16, 1056, 256, 384), (36, 4096, 128, 256)):
+        Q = torch.randn((planes, rows, M), device="cuda", generator=g)
+        V = torch.randn((planes, rows, N), device="cuda", generator=g)
+        dU = torch.ones((planes, M, N), device="cuda")                        # += semantics
+        _lib.check(lib.afi_gemm_tn(C.c_void_p(Q.data_ptr()), C.c_void_p(V.data_ptr()), C.c_void_p(dU.data_ptr()), planes, rows, M, N, dt, st), "afi_gemm_tn")
+        assert _rel(dU, 1.0 + torch.bmm(Q.double().transpose(1, 2), V.double())) < TOL_GEMM[dtype], (planes, rows, M, N)
+    # shapes the tile-aligned kernels do not take are refused, not mangled
+    assert lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), 1, 100, 128, 32, dt, st) == 2
+    assert lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), 1, 128, 128, 32, 2, st) == 1
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("N,Ci,Co,H,W", [(1, 256, 256, 50, 68), (2, 256, 512, 100, 84), (1, 288, 128, 33, 47)])
+def test_conv3x3_winograd_under_dtype(amd, dtype, N, Ci, Co, H, W):
+    """Forward, data gradient and weight gradient of a 3x3 conv on the Winograd path under the context's dtype, against fp64."""
+    ops = amd.ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((N, Ci, H, W), generator=g, dtype=torch.float64)
+    w = torch.randn((Co, Ci, 3, 3), generator=g, dtype=torch.float64) / (9 * Ci) ** 0.5
+    b = torch.randn(Co, generator=g, dtype=torch.float64)
+    dy = torch.randn((N, Co, H, W), generator=g, dtype=torch.float64)
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv2d(xg, wg, b, padding=1)
+    gx, gw = torch.autograd.grad((y * dy).sum(), (xg, wg))
+    xp, dyp = ops.pixel_major(x.float().cuda()), ops.pixel_major(dy.float().cuda())
+    wk = ops.ohwi(w.float().cuda())
+    with amd.compute_dtype(dtype):
+        out = ops.conv3x3_wino_fwd(xp, wk, b.float().cuda())
+        dx = ops.conv3x3_wino_dgrad(dyp, wk)
+        dw = ops.conv3x3_wino_wgrad(dyp, xp)
+    assert amd._lib.current_ctx().dtype == "fp32"
+    assert _rel(out, y) < TOL_CONV[dtype] and _rel(dx, gx) < TOL_CONV[dtype] and _rel(dw, gw) < TOL_CONV[dtype]
+    # and the setting is not a no-op: bf16 differs from fp32 by more than fp32's own error
+    if dtype == "bf16":
+        assert _rel(out, y) > 1e-4
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+def test_generator_fwd_bwd_under_dtype(amd, dtype):
+    """AF interpolator on a map large enough for the Winograd path (2 x 256 x 52 x 84), forward + full backward, against the oracle."""
+    Cc = 256
+    G = amd.Generator(in_channels=Cc, n_residual_dense_blocks=3).cuda()
+    p = orc.closed_form_generator_params(Cc, 3, 32)
+    G.load_state_dict(p)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn((2, Cc, 52, 84), generator=g)
+    R = torch.randn((2, Cc, 104, 168), generator=g)
+    xr = x.clone().requires_grad_(True)
+    pr = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = orc.generator_forward(xr, pr, 3)
+    (ref * R).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    with amd.compute_dtype(dtype):
+        out = G(xg)
+        (out * R.cuda()).sum().backward()
+    tol = TOL_NET[dtype]
+    assert _rel(out, ref) < tol and _rel(xg.grad, xr.grad) < tol
+    # parameter gradients, L2-relative per tensor: the forward's error (1e-5 of a pre-activation under bf16x3, 4e-3 under bf16) flips
+    # LeakyReLU masks near zero, and each flip moves the gradients behind it by a finite amount (measured: fp32 1e-5 .. 3e-3 on the
+    # tensors whose gradient cancels to 3e-4 of its terms, bf16x3 1.6e-3 .. 5e-3, bf16 5e-2)
+    worst = max(((v.grad.contiguous().cpu().double() - pr[k].grad.double()).norm() / pr[k].grad.double().norm()).item() for k, v in G.named_parameters())
+    assert worst < TOL_GRAD_L2[dtype], worst
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "bf16"])
+def test_stage1_step_under_dtype(amd, dtype):
+    """One stage-1 G+D step with the engine's dtype against the same step in fp32: losses and the parameter updates."""
+    import copy
+    torch.manual_seed(3)
+    G0 = amd.Generator(n_residual_dense_blocks=3).cuda()
+    D0 = amd.Discriminator().cuda()
+    g = torch.Generator().manual_seed(9)
+    hr = [torch.randn((1, 256, 100, 168), generator=g).cuda(), torch.randn((1, 256, 50, 84), generator=g).cuda()]
+    lr = [torch.randn((1, 256, 52, 84), generator=g).cuda(), torch.randn((1, 256, 26, 42), generator=g).cuda()]
+    res = {}
+    for dt in ("fp32", dtype):
+        G, D = copy.deepcopy(G0), copy.deepcopy(D0)
+        step = amd.Stage1Step(G, D, base_lr=0.01, warmup_iters=0, dtype=dt)
+        assert step.ctx.dtype == dt
+        step.run_step(lr, hr)
+        res[dt] = (step.metrics(), [q.detach().clone() for q in list(G.parameters()) + list(D.parameters())], [q.detach().clone() for q in list(G0.parameters()) + list(D0.parameters())])
+    m32, p32, p0 = res["fp32"]
+    m, p, _ = res[dtype]
+    tol = TOL_NET[dtype]
+    for k in m32:
+        assert abs(m[k] - m32[k]) <= tol * abs(m32[k]) + 1e-6, (k, m[k], m32[k])
+    # the update each parameter received, over the whole net, in L2 (a D gradient carries LeakyReLU-mask flips between any two
+    # evaluations -- tests/test_gpu_d_parity.py -- so the bar is that file's TOL_OWN_FORWARD_L2 on top of the dtype's own)
+    num = sum(float(((a - c) - (b - c)).double().square().sum()) for a, b, c in zip(p, p32, p0))
+    den = sum(float((b - c).double().square().sum()) for b, c in zip(p32, p0))
+    assert (num / den) ** 0.5 < 3e-3 + 2 * tol, (num / den) ** 0.5
+
+
+def test_dtype_api_guards(amd):
+    from afigan_amd import _lib
+    cx = _lib.Ctx()
+    with pytest.raises(amd.AfiError):
+        cx.set_dtype("fp16")
+    assert _lib.load().afi_ctx_set_compute_dtype(cx.handle, 2) == 1 and _lib.load().afi_ctx_get_compute_dtype(cx.handle) == 0
+    cx.set_dtype("bf16x3")
+    assert _lib.load().afi_ctx_get_compute_dtype(cx.handle) == 3 and _lib.load().afi_ctx_get_compute_dtype(None) == 0
+    assert _lib.load().afi_ctx_set_compute_dtype(None, 0) == 1
