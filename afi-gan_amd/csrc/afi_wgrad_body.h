@@ -7,8 +7,9 @@
 #endif
 // the including translation unit defines the 16-byte zero page `afi_zeros` (a non-const __device__ array) before this header
 
+// pixel range [k_begin, k_end) of logical tile t; k_begin a multiple of 32.  Ends on a block barrier: may be called again by the same block.
 template <int BM, int BN, int WM, int WN>
-__device__ __forceinline__ void afi_wgrad_gemm_body(const AfiWgradGemm& p, int ntile_m, int ntile_n, int kper, int t, int ksplit, bool use_atomic) {
+__device__ __forceinline__ void afi_wgrad_gemm_range(const AfiWgradGemm& p, int ntile_m, int ntile_n, int t, long long k_begin, long long k_end, bool use_atomic) {
     constexpr int BK = AFI_BK;
     constexpr int NT = 64 * WM * WN;                      // 256 threads (4 waves) or 512 (8 waves: the 256x256 tile)
     constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);
@@ -53,9 +54,6 @@ __device__ __forceinline__ void afi_wgrad_gemm_body(const AfiWgradGemm& p, int n
     if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
 
     const int HW = p.H * p.W;
-    const long long P = (long long)p.N * HW;
-    const long long k_begin = (long long)ksplit * kper;
-    const long long k_end = (k_begin + kper < P) ? k_begin + kper : P;
     if (k_begin >= k_end) return;
     const int nK = (int)((k_end - k_begin + BK - 1) / BK);
 
@@ -183,3 +181,10 @@ __device__ __forceinline__ void afi_wgrad_gemm_body(const AfiWgradGemm& p, int n
         }
 }
 
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void afi_wgrad_gemm_body(const AfiWgradGemm& p, int ntile_m, int ntile_n, int kper, int t, int ksplit, bool use_atomic) {
+    const long long P = (long long)p.N * p.H * p.W;
+    const long long k_begin = (long long)ksplit * kper;
+    const long long k_end = (k_begin + kper < P) ? k_begin + kper : P;
+    afi_wgrad_gemm_range<BM, BN, WM, WN>(p, ntile_m, ntile_n, t, k_begin, k_end, use_atomic);
+}

@@ -820,6 +820,71 @@ __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_group_kernel(const Afi
     afi_wgrad_gemm_body<BM, BN, WM, WN>(p, grp.ntile_m[pi], grp.ntile_n[pi], grp.kper[pi], lt / ns, lt % ns, ns > 1);
 }
 
+// Stream-K form: the (tile, 32-pixel stage) units of all problems are laid end to end and cut into EQUAL runs, one per block, with as
+// many blocks as the chip holds at once.  A block works through its run tile by tile -- at most a partial tile at each end -- and adds
+// a tile it shares with a neighbour by fp32 atomics; tiles it owns alone are stored.  Against "one tile slice per block" (above) this
+// removes the partly filled last round: 1044 slices on 768 slots ran as two rounds (191 us for config 1's backward); equal runs need
+// 14058 stage times / 256 CUs.
+struct AfiWgradGroupSK {
+    int nprob, units_per_block, total_units;
+    int unit_start[AFI_WG_MAXP + 1];                       // prefix sums of units (tiles * stages) per problem
+    short ntile_m[AFI_WG_MAXP], ntile_n[AFI_WG_MAXP];
+    int nst[AFI_WG_MAXP];                                  // 32-pixel stages per tile
+    AfiWgradGemm g[AFI_WG_MAXP];
+};
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_group_sk_kernel(const AfiWgradGroupSK grp) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);      // neighbours in the unit order share an XCD's L2
+    int u = b * grp.units_per_block;
+    int u_end = u + grp.units_per_block;
+    if (u_end > grp.total_units) u_end = grp.total_units;
+    int pi = 0;
+    while (u < u_end) {                                    // (uniform) a run crosses a few tile boundaries at most
+        while (pi + 1 < grp.nprob && u >= grp.unit_start[pi + 1]) ++pi;
+        const AfiWgradGemm& p = grp.g[pi];
+        const int nst = grp.nst[pi];
+        const int lu = u - grp.unit_start[pi];
+        const int tile = lu / nst, s0 = lu - tile * nst;
+        int s1 = s0 + (u_end - u);
+        if (s1 > nst) s1 = nst;
+        const long long P = (long long)p.N * p.H * p.W;
+        const long long k0 = (long long)s0 * AFI_BK, k1 = (long long)s1 * AFI_BK < P ? (long long)s1 * AFI_BK : P;
+        afi_wgrad_gemm_range<BM, BN, WM, WN>(p, grp.ntile_m[pi], grp.ntile_n[pi], tile, k0, k1, !(s0 == 0 && s1 == nst));
+        u += s1 - s0;
+    }
+}
+template <int BM, int BN, int WM, int WN>
+static int launch_wgrad_group_sk(const AfiWgradGemm* probs, int n, hipStream_t st, int bpc) {
+    AfiWgradGroupSK grp;
+    int done = 0;
+    while (done < n) {
+        const int cnt = (n - done) < AFI_WG_MAXP ? (n - done) : AFI_WG_MAXP;
+        grp.nprob = cnt;
+        long long units = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const AfiWgradGemm& g = probs[done + i];
+            if ((g.Ncols & 3) || (g.dy_up == 2 && (g.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;
+            grp.g[i] = g;
+            const long long P = (long long)g.N * g.H * g.W;
+            grp.nst[i] = afi_cdiv(P, AFI_BK);
+            grp.ntile_m[i] = (short)afi_cdiv(g.Mrows, BM); grp.ntile_n[i] = (short)afi_cdiv(g.Ncols, BN);
+            grp.unit_start[i] = (int)units;
+            units += (long long)grp.ntile_m[i] * grp.ntile_n[i] * g.ntaps * grp.nst[i];
+            if (units > 0x7fffffffLL) return AFI_ERR_UNSUPPORTED;
+        }
+        for (int i = cnt; i <= AFI_WG_MAXP; ++i) grp.unit_start[i] = (int)units;
+        int blocks = 256 * bpc;
+        int upb = (int)((units + blocks - 1) / blocks);
+        if (upb < 4) upb = 4;                              // tiny groups: no run shorter than four stages
+        blocks = (int)((units + upb - 1) / upb);
+        grp.units_per_block = upb; grp.total_units = (int)units;
+        hipLaunchKernelGGL((afi_wgrad_group_sk_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(64 * WM * WN), sizeof(float) * AFI_BK * (BM + BN), st, grp);
+        done += cnt;
+    }
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_wgrad_group(const AfiWgradGemm* probs, int n, hipStream_t st) {
     static const int stages = sk_env_int("AFI_WG_STAGES", 14);    // K stages (of 32 pixels) per block: 850 pixels -> 2 slices, 3400 -> 8
@@ -855,6 +920,9 @@ static int launch_wgrad_group(const AfiWgradGemm* probs, int n, hipStream_t st) 
 // the caller, longest pixel range first (the dispatcher hands blocks out in order: long tiles early, short ones fill the tail).
 int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st) {
     if (n <= 0) return AFI_OK;
+    static const int sk = sk_env_int("AFI_WG_SK", 1);      // 0: one tile slice per block (A/B)
+    static const int bpc = sk_env_int("AFI_WG_SK_BPC", 3); // resident blocks per CU the runs are cut for
+    if (sk) return wide ? launch_wgrad_group_sk<128, 128, 1, 4>(probs, n, st, bpc) : launch_wgrad_group_sk<32, 128, 1, 4>(probs, n, st, bpc);
     return wide ? launch_wgrad_group<128, 128, 1, 4>(probs, n, st) : launch_wgrad_group<32, 128, 1, 4>(probs, n, st);
 }
 
