@@ -170,23 +170,23 @@ CTX_FIRST = frozenset(n for n, (_, a) in SIGNATURES.items() if n.startswith(("af
                       and not n.endswith(("_ws_floats", "_ws_layout", "pack_weight", "unpack_wgrad")))
 
 
-DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 3}             # AFI_DTYPE_* of include/afigan_hip.h
+DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}             # AFI_DTYPE_* of include/afigan_hip.h
 
 
 class Ctx:
     """afi_ctx_t owned from Python: created on the current GPU, destroyed with the object.  Buffers registered with it are kept alive here.
-    `dtype`: arithmetic of the Winograd-domain GEMMs run under this context ("fp32" -- the parity path and the default --, "bf16x3",
-    "bf16"; see afi_ctx_set_compute_dtype)."""
+    `dtype`: arithmetic of the Winograd-domain GEMMs run under this context ("fp32", "bf16x6", "bf16x3", "bf16"; None = the library's
+    default; see afi_ctx_set_compute_dtype)."""
 
-    def __init__(self, dtype="fp32"):
+    def __init__(self, dtype=None):
         h = C.c_void_p()
         check(load().afi_ctx_create(C.byref(h)), "afi_ctx_create")
         self.handle = h
         self.device = torch.cuda.current_device()
         self.bufs = {}                # name -> tensor registered with the context
         self.keep = None              # list collecting temporaries that must outlive an open weight-transform-cache block
-        self.dtype = "fp32"
-        if dtype != "fp32":
+        self.dtype = {v: k for k, v in DTYPES.items()}[load().afi_ctx_get_compute_dtype(h)]      # the library's default
+        if dtype is not None and dtype != self.dtype:
             self.set_dtype(dtype)
 
     def set_dtype(self, dtype):

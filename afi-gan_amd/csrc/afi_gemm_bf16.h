@@ -5,6 +5,9 @@
 //   SPLIT = 1  "bf16":    x -> hi = bf16(x); one MFMA per k-step.  Operand error 2^-9: use on F(2x2) planes only.
 //   SPLIT = 3  "bf16x3":  x -> hi + lo, lo = bf16(x - hi); hi*hi + hi*lo + lo*hi (three MFMAs per k-step, the lo*lo term dropped):
 //                         operand error 2^-17, so the F(4x4) planes stay usable.  Three bf16 MFMAs cost 3/16 of the fp32 MFMA work.
+//   SPLIT = 6  "bf16x6":  x = hi + mid + lo exactly (three bf16 carry all 24 mantissa bits); the six products of order <= 2^-16
+//                         (hh, hm, mh, mm, hl, lh), smallest first: what is dropped (ml, lm, ll) is below fp32's own rounding of a
+//                         product, so the result is fp32-grade (measured 1e-6, like the fp32 MFMA) at 6/16 of its matrix-core work.
 // At bf16 rate a 128x128x32 stage is 256 (x3: 768) MFMA cycles per wave while its operands are 32 KB of fp32 from L2, so both forms
 // are bound by the L2 -> CU stream, not by the matrix cores: the roofline for this kernel is L2 bandwidth x 32 FLOP/B per tile pair.
 //
@@ -28,10 +31,12 @@ __device__ __forceinline__ int afi_bf16_tile_off(int row, int kq /* float4 colum
     return row * 64 + ((((kq >> 1) ^ (row >> 2)) & 3) << 4) + ((kq & 1) << 3);
 }
 
-template <int SPLIT>
-__global__ __launch_bounds__(256, 2) void afi_gemm_nt_bf16_kernel(const AfiGemmNT p, int ntile_n, int ntile_m, int chunk) {
+// DB: two LDS buffers and one barrier per stage (two blocks per CU); !DB: one buffer, two barriers, three blocks per CU whose stages
+// interleave -- the form the six-product variant needs (its three images per operand are 48 KB per buffer).
+template <int SPLIT, bool DB>
+__global__ __launch_bounds__(256, DB ? 2 : 3) void afi_gemm_nt_bf16_kernel(const AfiGemmNT p, int ntile_n, int ntile_m, int chunk) {
     constexpr int BM = 128, BN = 128, BK = 32, WN = 2, MI = 2, NI = 2;
-    constexpr int NPART = SPLIT == 3 ? 2 : 1;                // hi (and lo) images per operand
+    constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);   // hi (, mid) (, lo) images per operand
     constexpr int TILE = BM * BK * 2;                        // bytes of one bf16 tile image
     constexpr int BUF = 2 * NPART * TILE;                    // A parts then B parts
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -65,9 +70,14 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_nt_bf16_kernel(const AfiGemmN
             const int off = afi_bf16_tile_off(ar + 32 * i, aq);
             *(u32x2*)(base + off) = afi_pack_bf16(a_reg[i]);
             *(u32x2*)(base + NPART * TILE + off) = afi_pack_bf16(b_reg[i]);
-            if (SPLIT == 3) {
-                *(u32x2*)(base + TILE + off) = afi_pack_bf16(afi_bf16_residual(a_reg[i]));
-                *(u32x2*)(base + NPART * TILE + TILE + off) = afi_pack_bf16(afi_bf16_residual(b_reg[i]));
+            if (SPLIT >= 3) {
+                const f32x4 ra = afi_bf16_residual(a_reg[i]), rb = afi_bf16_residual(b_reg[i]);
+                *(u32x2*)(base + TILE + off) = afi_pack_bf16(ra);
+                *(u32x2*)(base + NPART * TILE + TILE + off) = afi_pack_bf16(rb);
+                if (SPLIT == 6) {
+                    *(u32x2*)(base + 2 * TILE + off) = afi_pack_bf16(afi_bf16_residual(ra));
+                    *(u32x2*)(base + NPART * TILE + 2 * TILE + off) = afi_pack_bf16(afi_bf16_residual(rb));
+                }
             }
         }
     };
@@ -90,37 +100,44 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_nt_bf16_kernel(const AfiGemmN
     }
 
     issue(0);
-    stage_store(0);
-    __syncthreads();
+    if (DB) { stage_store(0); __syncthreads(); }
     for (int kc = 0; kc < nK; ++kc) {
         const bool more = kc + 1 < nK;
+        if (!DB) { stage_store(0); __syncthreads(); }
         if (more) issue(kc + 1);                             // in flight behind this stage's MFMAs (and the other blocks of the CU)
-        const unsigned char* base = smem_b + (kc & 1) * BUF;
+        const unsigned char* base = smem_b + (DB ? (kc & 1) * BUF : 0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 ah[MI], bh[NI], al[MI], bl[NI];
+            bf16x8 ah[MI], bh[NI], al[MI], bl[NI], am[MI], bm[NI];      // (SPLIT 3: "l" is the second part; SPLIT 6: h, m, l)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 ah[mi] = *(const bf16x8*)(base + fa_off[mi][s]);
                 if (SPLIT == 3) al[mi] = *(const bf16x8*)(base + TILE + fa_off[mi][s]);
+                if (SPLIT == 6) { am[mi] = *(const bf16x8*)(base + TILE + fa_off[mi][s]); al[mi] = *(const bf16x8*)(base + 2 * TILE + fa_off[mi][s]); }
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 bh[ni] = *(const bf16x8*)(base + fb_off[ni][s]);
                 if (SPLIT == 3) bl[ni] = *(const bf16x8*)(base + TILE + fb_off[ni][s]);
+                if (SPLIT == 6) { bm[ni] = *(const bf16x8*)(base + TILE + fb_off[ni][s]); bl[ni] = *(const bf16x8*)(base + 2 * TILE + fb_off[ni][s]); }
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    if (SPLIT == 3) {                        // small terms first
+                    if (SPLIT >= 3) {                        // small terms first
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    }
+                    if (SPLIT == 6) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bm[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bm[ni], acc[mi][ni], 0, 0, 0);
                     }
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
                 }
         }
-        if (more) stage_store((kc + 1) & 1);                 // the other buffer: its readers passed the barrier of the previous stage
+        if (DB && more) stage_store((kc + 1) & 1);           // the other buffer: its readers passed the barrier of the previous stage
         __syncthreads();
     }
     // epilogue: accumulators -> LDS -> float4 rows of C   (same staging as afi_gemm_nt_kernel)
@@ -144,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_nt_bf16_kernel(const AfiGemmN
     }
 }
 
-static size_t afi_gemm_nt_bf16_lds(int split) {
-    const size_t ring = 2u * 2u * (split == 3 ? 2u : 1u) * 128u * 32u * 2u;      // two buffers x (A, B) x parts x tile
+static size_t afi_gemm_nt_bf16_lds(int split, bool db) {
+    const size_t ring = (db ? 2u : 1u) * 2u * (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 128u * 32u * 2u;      // buffers x (A, B) x parts x tile
     const size_t cst = sizeof(float) * 64u * (128u + 4u);
     return ring > cst ? ring : cst;
 }
@@ -168,10 +185,10 @@ __device__ __forceinline__ bf16x8 afi_tr_frag(const unsigned char* base, int off
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int SPLIT>
+template <int SPLIT, bool DB>
 __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmTN p, int ntile_m, int ntile_n, int kper) {
     constexpr int BM = 128, BN = 128, BK = 32, WN = 2, MI = 2, NI = 2;
-    constexpr int NPART = SPLIT == 3 ? 2 : 1;
+    constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);
     constexpr int TILE = BK * BM * 2;                        // 8 KB: [32 k][128 columns] bf16
     constexpr int BUF = 2 * NPART * TILE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -214,9 +231,14 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
         for (int i = 0; i < 4; ++i) {
             *(u32x2*)(base + st_off[i]) = afi_pack_bf16(a_reg[i]);
             *(u32x2*)(base + NPART * TILE + st_off[i]) = afi_pack_bf16(b_reg[i]);
-            if (SPLIT == 3) {
-                *(u32x2*)(base + TILE + st_off[i]) = afi_pack_bf16(afi_bf16_residual(a_reg[i]));
-                *(u32x2*)(base + NPART * TILE + TILE + st_off[i]) = afi_pack_bf16(afi_bf16_residual(b_reg[i]));
+            if (SPLIT >= 3) {
+                const f32x4 ra = afi_bf16_residual(a_reg[i]), rb = afi_bf16_residual(b_reg[i]);
+                *(u32x2*)(base + TILE + st_off[i]) = afi_pack_bf16(ra);
+                *(u32x2*)(base + NPART * TILE + TILE + st_off[i]) = afi_pack_bf16(rb);
+                if (SPLIT == 6) {
+                    *(u32x2*)(base + 2 * TILE + st_off[i]) = afi_pack_bf16(afi_bf16_residual(ra));
+                    *(u32x2*)(base + NPART * TILE + 2 * TILE + st_off[i]) = afi_pack_bf16(afi_bf16_residual(rb));
+                }
             }
         }
     };
@@ -243,38 +265,45 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     issue(0);
-    stage_store(0);
-    __syncthreads();
+    if (DB) { stage_store(0); __syncthreads(); }
     for (int kc = 0; kc < nK; ++kc) {
         const bool more = kc + 1 < nK;
+        if (!DB) { stage_store(0); __syncthreads(); }
         if (more) issue(kc + 1);
-        const unsigned char* base = smem_b + (kc & 1) * BUF;
+        const unsigned char* base = smem_b + (DB ? (kc & 1) * BUF : 0);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             // rows 16 s + ...: (r >> 2) & 3 of the swizzle is unchanged by + 16 rows, so k-step 1 is a constant + 4096 bytes
-            bf16x8 ah[MI], bh[NI], al[MI], bl[NI];
+            bf16x8 ah[MI], bh[NI], al[MI], bl[NI], am[MI], bm[NI];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 ah[mi] = afi_tr_frag(base + 4096 * s, fa_off[mi][0], fa_off[mi][1]);
                 if (SPLIT == 3) al[mi] = afi_tr_frag(base + 4096 * s + TILE, fa_off[mi][0], fa_off[mi][1]);
+                if (SPLIT == 6) { am[mi] = afi_tr_frag(base + 4096 * s + TILE, fa_off[mi][0], fa_off[mi][1]); al[mi] = afi_tr_frag(base + 4096 * s + 2 * TILE, fa_off[mi][0], fa_off[mi][1]); }
             }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 bh[ni] = afi_tr_frag(base + 4096 * s, fb_off[ni][0], fb_off[ni][1]);
                 if (SPLIT == 3) bl[ni] = afi_tr_frag(base + 4096 * s + TILE, fb_off[ni][0], fb_off[ni][1]);
+                if (SPLIT == 6) { bm[ni] = afi_tr_frag(base + 4096 * s + TILE, fb_off[ni][0], fb_off[ni][1]); bl[ni] = afi_tr_frag(base + 4096 * s + 2 * TILE, fb_off[ni][0], fb_off[ni][1]); }
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    if (SPLIT == 3) {
+                    if (SPLIT >= 3) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    }
+                    if (SPLIT == 6) {
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bm[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bm[ni], acc[mi][ni], 0, 0, 0);
                     }
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
                 }
         }
-        if (more) stage_store((kc + 1) & 1);
+        if (DB && more) stage_store((kc + 1) & 1);
         __syncthreads();
     }
     const bool use_atomic = gridDim.y > 1;

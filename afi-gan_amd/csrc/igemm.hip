@@ -757,16 +757,22 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
 #include "afi_gemm_bf16.h"
 // the same GEMM on the bf16 matrix cores (split = 1: bf16 operands; 3: split-bf16, three MFMAs per k-step); fp32 planes in and out
 int afi_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st) {
-    if (planes <= 0 || rows_per_plane <= 0 || N <= 0 || K <= 0 || (split != 1 && split != 3)) return AFI_ERR_BAD_ARG;
+    if (planes <= 0 || rows_per_plane <= 0 || N <= 0 || K <= 0 || (split != 1 && split != 3 && split != 6)) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
     AfiGemmNT g{A, B, C, rows_per_plane, planes, N, K};
     const long long M = rows_per_plane * planes;
     const int ntm = (int)(M / 128), ntn = N / 128, chunk = afi_cdiv(ntm, 8);
-    const size_t lds = afi_gemm_nt_bf16_lds(split);
+    static const int db_env = afi_env_int("AFI_BF16_DB", 0);      // 1: two LDS buffers, one barrier per stage, two blocks per CU (A/B)
+    const bool db = db_env > 0 && split != 6;              // default: one buffer, three blocks per CU (measured +8 % over two buffers at two blocks)
+    const size_t lds = afi_gemm_nt_bf16_lds(split, db);
     ProfScope prof(st, 17, 2.0 * (double)M * N * K);
     prof.m = M; prof.n = N; prof.k = K; prof.split = split;
-    if (split == 3) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<3>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ntn, ntm, chunk);
-    else hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ntn, ntm, chunk);
+    const dim3 grid(chunk * ntn * 8), blk(256);
+    if (split == 6) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<6, false>), grid, blk, lds, st, g, ntn, ntm, chunk);
+    else if (split == 3 && db) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<3, true>), grid, blk, lds, st, g, ntn, ntm, chunk);
+    else if (split == 3) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<3, false>), grid, blk, lds, st, g, ntn, ntm, chunk);
+    else if (db) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<1, true>), grid, blk, lds, st, g, ntn, ntm, chunk);
+    else hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<1, false>), grid, blk, lds, st, g, ntn, ntm, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -919,7 +925,7 @@ int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, lo
 }
 
 int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st) {
-    if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0 || (split != 1 && split != 3)) return AFI_ERR_BAD_ARG;
+    if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0 || (split != 1 && split != 3 && split != 6)) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
     const int ntm = M / 128, ntn = N / 128;
     const long long tiles = (long long)ntm * ntn * planes;
@@ -943,9 +949,12 @@ int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int plane
     AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
     ProfScope prof(st, 18, 2.0 * (double)rows_per_plane * planes * M * N);
     prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
-    const size_t lds = 2u * 2u * (split == 3 ? 2u : 1u) * 8192u;
-    if (split == 3) hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<3>), dim3((unsigned)tiles, splitK), dim3(256), lds, st, g, ntm, ntn, kper);
-    else hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<1>), dim3((unsigned)tiles, splitK), dim3(256), lds, st, g, ntm, ntn, kper);
+    const bool db = split != 6;                            // six-product form: one 48 KB buffer, two blocks per CU
+    const size_t lds = (db ? 2u : 1u) * 2u * (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 8192u;
+    const dim3 grid((unsigned)tiles, splitK), blk(256);
+    if (split == 6) hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<6, false>), grid, blk, lds, st, g, ntm, ntn, kper);
+    else if (split == 3) hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<3, true>), grid, blk, lds, st, g, ntm, ntn, kper);
+    else hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<1, true>), grid, blk, lds, st, g, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

@@ -100,10 +100,19 @@ struct WinoWgradAccum {
     int n = 0;
 };
 }  // namespace
+// arithmetic of the Winograd-domain GEMMs for new contexts and context-less calls (AFI_DEFAULT_DTYPE = 0 / 1 / 3 / 6 overrides: A/B runs)
+static int afi_default_dtype() {
+    static const int d = [] {
+        const char* v = getenv("AFI_DEFAULT_DTYPE");
+        const int x = v ? atoi(v) : AFI_DTYPE_DEFAULT;
+        return (x == AFI_DTYPE_F32 || x == AFI_DTYPE_BF16 || x == AFI_DTYPE_BF16X3 || x == AFI_DTYPE_BF16X6) ? x : AFI_DTYPE_DEFAULT;
+    }();
+    return d;
+}
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
-    int dtype = AFI_DTYPE_F32;                             // arithmetic of the Winograd-domain GEMMs (afi_ctx_set_compute_dtype)
+    int dtype = afi_default_dtype();                       // arithmetic of the Winograd-domain GEMMs (afi_ctx_set_compute_dtype)
     WinoWeightCache wcache;
     WinoWgradAccum wgacc;
     SideStream side;
@@ -250,7 +259,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     // fwd_f4: a forward whose activations feed no backward pass (its masks decide no gradient) may take F(4x4) too
     // bf16 operands (2^-9) cannot carry the F(4x4) transforms (their 1/24 .. 8 coefficient range costs two more digits: 3 % error);
     // split-bf16 (2^-17) can
-    const int dtype = cx ? cx->dtype : AFI_DTYPE_F32;
+    const int dtype = cx ? cx->dtype : afi_default_dtype();
     const bool f4 = (b_rc || fwd_f4) && wino_f4() && dtype != AFI_DTYPE_BF16 && (long long)g.N * g.H * g.W >= 8192;     // small maps: too few 4x4 tiles to fill the chip
     const int np = f4 ? 36 : 16;
     const long long Tpad = f4 ? wino4_tpad(g.N, g.H, g.W) : wino_tpad(g.N, g.H, g.W);
@@ -271,7 +280,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
         static const int fast = getenv("AFI_GEMM_NT") ? atoi(getenv("AFI_GEMM_NT")) : 1;
         const int rc = !fast ? AFI_ERR_UNSUPPORTED
                      : dtype == AFI_DTYPE_F32 ? afi_launch_gemm_nt(Vb, U, Mb, np, Tpad, Nc, K, st)
-                                              : afi_launch_gemm_nt_bf16(Vb, U, Mb, np, Tpad, Nc, K, dtype == AFI_DTYPE_BF16X3 ? 3 : 1, st);
+                                              : afi_launch_gemm_nt_bf16(Vb, U, Mb, np, Tpad, Nc, K, dtype, st);
         if (rc == AFI_OK) return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
         if (rc != AFI_ERR_UNSUPPORTED) return rc;
     }
@@ -327,7 +336,7 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
                       hipStream_t st, int dy_phases = 1, bool accumulate = true) {
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
-    const int dtype = cx ? cx->dtype : AFI_DTYPE_F32;
+    const int dtype = cx ? cx->dtype : afi_default_dtype();
     const bool f4 = wino_f4() && dtype != AFI_DTYPE_BF16 && (long long)N * H * W >= 8192;   // F(3x3,4x4): 36 transform points over 4x4 blocks of dY
     const int np = f4 ? 36 : 16;
     const long long Tpad = f4 ? wino4_tpad(N, H, W) : wino_tpad(N, H, W);
@@ -349,7 +358,7 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
         static const int fast = getenv("AFI_GEMM_TN") ? atoi(getenv("AFI_GEMM_TN")) : 1;
         const int rc = !fast ? AFI_ERR_UNSUPPORTED
                      : dtype == AFI_DTYPE_F32 ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st)
-                                              : afi_launch_gemm_tn_bf16(Qb, Vb, dU, np, Tpad, Cout, Cin, dtype == AFI_DTYPE_BF16X3 ? 3 : 1, st);
+                                              : afi_launch_gemm_tn_bf16(Qb, Vb, dU, np, Tpad, Cout, Cin, dtype, st);
         if (rc == AFI_OK) {
             if (accum) return AFI_OK;                      // transformed at afi_wino_wgrad_flush()
             return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
@@ -418,23 +427,23 @@ int afi_ctx_destroy(afi_ctx_t* ctx) {
     return AFI_OK;
 }
 int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype) {
-    if (!ctx || (dtype != AFI_DTYPE_F32 && dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3)) return AFI_ERR_BAD_ARG;
+    if (!ctx || (dtype != AFI_DTYPE_F32 && dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6)) return AFI_ERR_BAD_ARG;
     if (ctx->wgacc.n) return AFI_ERR_BAD_ARG;             // pending transform-domain sums belong to the tiling of the old setting
     ctx->dtype = dtype;
     return AFI_OK;
 }
-int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx) { return ctx ? ctx->dtype : AFI_DTYPE_F32; }
+int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx) { return ctx ? ctx->dtype : afi_default_dtype(); }
 int afi_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int dtype, void* stream) {
     if (!A || !B || !C) return AFI_ERR_BAD_ARG;
     if (dtype == AFI_DTYPE_F32) return afi_launch_gemm_nt(A, B, C, planes, rows_per_plane, N, K, (hipStream_t)stream);
-    if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3) return AFI_ERR_BAD_ARG;
-    return afi_launch_gemm_nt_bf16(A, B, C, planes, rows_per_plane, N, K, dtype == AFI_DTYPE_BF16X3 ? 3 : 1, (hipStream_t)stream);
+    if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6) return AFI_ERR_BAD_ARG;
+    return afi_launch_gemm_nt_bf16(A, B, C, planes, rows_per_plane, N, K, dtype, (hipStream_t)stream);
 }
 int afi_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int dtype, void* stream) {
     if (!Q || !V || !dU) return AFI_ERR_BAD_ARG;
     if (dtype == AFI_DTYPE_F32) return afi_launch_gemm_tn(Q, V, dU, planes, rows_per_plane, M, N, (hipStream_t)stream);
-    if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3) return AFI_ERR_BAD_ARG;
-    return afi_launch_gemm_tn_bf16(Q, V, dU, planes, rows_per_plane, M, N, dtype == AFI_DTYPE_BF16X3 ? 3 : 1, (hipStream_t)stream);
+    if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6) return AFI_ERR_BAD_ARG;
+    return afi_launch_gemm_tn_bf16(Q, V, dU, planes, rows_per_plane, M, N, dtype, (hipStream_t)stream);
 }
 int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* p, long long floats) {
     if (!ctx || floats < 0 || (floats > 0 && !p)) return AFI_ERR_BAD_ARG;

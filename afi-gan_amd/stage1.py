@@ -107,7 +107,7 @@ class Stage1Step:
     def __init__(self, G: Generator, D: Discriminator, base_lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (270000,), lr_gamma: float = 0.1,
                  warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2,
-                 reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: str = "fp32"):
+                 reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: Optional[str] = None):
         self.G, self.D = G, D
         self.gnet, self.dnet = G, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum

@@ -74,7 +74,7 @@ class Stage2Adversarial:
 
     def __init__(self, D: Discriminator, base_lr: float = 1e-2, momentum: float = 0.9, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (120000, 160000), lr_gamma: float = 0.1,
-                 warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2, process_group=None, dtype: str = "fp32"):
+                 warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2, process_group=None, dtype=None):
         self.D, self.dnet = D, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
         self.sched = (tuple(lr_steps), lr_gamma, warmup_factor, warmup_iters)

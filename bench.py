@@ -29,6 +29,11 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3           # MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md, "Peak BF16/FP16 MFMA", dense
+
+
+def gemm_peak(dtype):
+    """Roof of the Winograd-domain GEMM kernels in fp32-equivalent TFLOP/s (2*M*N*K counted once per product)."""
+    return {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS}[dtype]
 G_FWD_FLOP_PER_INPX = 19_206_144        # SURVEY.md 8(d) / BASELINE.md section 3
 D_FWD_FLOP_PER_PX = 30_689_280
 D_FWDBWD_DETACHED_FLOP_PER_PX = 89_708_544
@@ -44,9 +49,10 @@ def parse():
     ap.add_argument("--no-interp", action="store_true", help="skip the AF-interpolator micro-benchmark")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse "
                     "the multi-process path with several ranks sharing one GPU)")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "bf16x3", "bf16"],
-                    help="arithmetic of the Winograd-domain GEMMs (afi_ctx_set_compute_dtype).  fp32 = the reference's and the headline; the "
-                         "default run also times the two bf16 settings after the fp32 measurement and reports them under other_dtypes")
+    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16x6", "bf16x3", "bf16"],
+                    help="how the big convolutions' GEMMs form their fp32 products (afi_ctx_set_compute_dtype).  Default: the library's "
+                         "(bf16x6: exact three-way bf16 split, fp32-grade); the default run also times the other settings on the same "
+                         "engine afterwards and reports them under other_dtypes")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
     return ap.parse_args()
@@ -353,6 +359,7 @@ def main():
     D = amd.Discriminator().to(dev)
     G.train(); D.train()
     step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype)
+    run_dtype = step.ctx.dtype                             # the library's default when --dtype is not given
     guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)     # each rank owns a different shard of the global batch
     images = torch.rand((B, 3, 800, 1333), device=dev, generator=gen) * 255.0
@@ -444,9 +451,9 @@ def main():
     dom = kinds[0]
     # the opt-in bf16 arithmetic on the same engine, same inputs (N = 1 only; never the headline value): 1 warm-up + the same K steps each
     other_dtypes = None
-    if world == 1 and args.dtype == "fp32" and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":
+    if world == 1 and args.dtype is None and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":
         other_dtypes = {}
-        for dt in ("bf16x3", "bf16"):
+        for dt in [d for d in ("fp32", "bf16x6", "bf16x3", "bf16") if d != run_dtype]:
             step.ctx.set_dtype(dt)
             one_step()
             torch.cuda.synchronize()
@@ -461,16 +468,18 @@ def main():
             for k in range(lib.afi_profile_num_kinds()):
                 o3 = (C.c_double * 3)()
                 _lib.check(lib.afi_profile_get(k, o3), "afi_profile_get")
-                if o3[0] > 0 and "bf16" in lib.afi_profile_kind_name(k).decode():
-                    gk.append({"kernel": lib.afi_profile_kind_name(k).decode(), "launches": int(o3[0]), "ms_total": round(o3[1], 3),
-                               "tflops": round(o3[2] / (o3[1] * 1e-3) / 1e12, 1), "frac_of_bf16_mfma_peak": round(o3[2] / (o3[1] * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)})
+                name = lib.afi_profile_kind_name(k).decode()
+                if o3[0] > 0 and ("gemm_nt" in name or "gemm_tn" in name):
+                    tf = o3[2] / (o3[1] * 1e-3) / 1e12
+                    gk.append({"kernel": name, "launches": int(o3[0]), "ms_total": round(o3[1], 3), "tflops": round(tf, 1),
+                               "frac_of_peak": round(tf / gemm_peak(dt), 4), "peak": round(gemm_peak(dt), 1)})
             try:
                 fin = all(v == v and abs(v) != float("inf") for v in step.metrics().values())
             except FloatingPointError:
                 fin = False
-            other_dtypes[dt] = {"ms_per_step": el / args.steps * 1e3, "images_per_s": B * args.steps / el, "losses_finite": fin, "bf16_gemm_kernels": gk}
+            other_dtypes[dt] = {"ms_per_step": el / args.steps * 1e3, "images_per_s": B * args.steps / el, "losses_finite": fin, "winograd_gemm_kernels": gk}
             log(f"dtype {dt}: {el / args.steps * 1e3:.1f} ms/step")
-        step.ctx.set_dtype("fp32")
+        step.ctx.set_dtype(run_dtype)
 
     gemm_ms = sum(r["ms_total"] for r in kinds)
     gemm_flop = sum(r["flop_total"] for r in kinds)
@@ -494,14 +503,22 @@ def main():
         except (OSError, ValueError, KeyError):
             traffic = None
         break
-    dom_peak = PEAK_BF16_MFMA_TFLOPS if "bf16" in dom["kernel"] else PEAK_FP32_MFMA_TFLOPS      # (--dtype bf16x3 / bf16: the dense bf16 MFMA peak)
+    # the Winograd GEMMs' own roof: the dense bf16 MFMA peak over the bf16 MFMAs issued per fp32-equivalent product (6 / 3 / 1), or the
+    # fp32 MFMA peak; every other kernel multiplies on the fp32 MFMA
+    def kind_peak(name):
+        return gemm_peak(run_dtype) if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
+    dom_peak = kind_peak(dom["kernel"])
+    peak_s = sum(r["flop_total"] / (kind_peak(r["kernel"]) * 1e12) for r in kinds)        # seconds the step's products take at each kernel's own peak
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": dom_peak, "unit": "TFLOP/s",
                 "frac": dom["tflops"] / dom_peak, "traffic": traffic, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
                 "share_of_step_time": dom["ms_total"] / (elapsed * 1e3),
-                # the whole step in EXECUTED matrix-core FLOPs (what the GEMM launches multiplied, Winograd-domain for the big convs)
-                # over wall time and peak: the one <= 1 "achieved roofline" figure of the step
-                "frac_step_executed": gemm_flop / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                "all_gemm_kernels": {"tflops": gemm_flop / (gemm_ms * 1e-3) / 1e12, "frac": gemm_flop / (gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                # fp32-equivalent rate of the dominant kernel against the fp32 MFMA roof it replaces (> 1 is the point of the emulated forms)
+                "achieved_over_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+                "peak_note": "fp32-equivalent TFLOP/s: 2*M*N*K once per product; peak = dense bf16 MFMA 2500 / bf16 MFMAs per product (6, 3 or 1), or the fp32 MFMA 157.3",
+                # the whole step in EXECUTED matrix-core products (what the GEMM launches multiplied, Winograd-domain for the big convs): the time
+                # they need at each kernel's own peak over the wall time -- the one <= 1 "achieved roofline" figure of the step
+                "frac_step_executed": peak_s / elapsed,
+                "all_gemm_kernels": {"tflops": gemm_flop / (gemm_ms * 1e-3) / 1e12, "frac": peak_s / (gemm_ms * 1e-3),
                                      "share_of_step_time": gemm_ms / (elapsed * 1e3)},
                 "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "flop_total"} for r in kinds]}
 
@@ -518,8 +535,8 @@ def main():
     line = {
         "metric": "stage1_G+D_step_images_per_s", "value": n_img / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "bf16x3 (split-bf16 operands, three bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)",
-                                       "bf16": "bf16 (bf16 operands, fp32 accumulate; tensors fp32)"}[args.dtype], "data": "synthetic",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x6": "f32 emulated on the bf16 matrix cores (operands split exactly into three bf16, six bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)", "bf16x3": "bf16x3 (split-bf16 operands, three bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)",
+                                       "bf16": "bf16 (bf16 operands, fp32 accumulate; tensors fp32)"}[run_dtype], "data": "synthetic",
         "backend": (args.backend if world > 1 else None),
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
                                f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",

@@ -69,17 +69,27 @@ int afi_ctx_destroy(afi_ctx_t* ctx);                       /* refused (AFI_ERR_B
 int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
 /* Arithmetic of the Winograd-domain GEMMs issued under this context -- every 3x3 / stride-1 convolution with >= 128 channels on both
  * sides and >= 1024 pixels, forward, data gradient and weight gradient, i.e. >= 95 % of a stage-1 step's FLOPs.  Tensors, transforms,
- * epilogues, accumulators and every other kernel stay fp32.  The reference is fp32-only (SOLVER.AMP is never read, defaults.py:82), so
- * this is opt-in and each setting carries its own tolerance (tests/test_gpu_bf16.py):
- *   AFI_DTYPE_F32     fp32 MFMA (v_mfma_f32_32x32x2_f32): the 1e-3 parity path, the default.
- *   AFI_DTYPE_BF16X3  operands split x = hi + lo into two bf16 (2^-17), three v_mfma_f32_32x32x16_bf16 per k-step (hi*hi + hi*lo + lo*hi),
- *                     fp32 accumulate; same tilings as fp32.  Conv outputs within 1e-3 of the fp32 oracle (max-norm).
- *   AFI_DTYPE_BF16    operands rounded to bf16 (2^-9), one v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate; every convolution on
- *                     F(2x2,3x3) tiles (F(4x4) transforms do not survive 8-bit operands).  Conv outputs within 2e-2 (max-norm).
- * Refused while weight-gradient sums are pending. */
+ * epilogues, accumulators and every other kernel are fp32 under every setting; the settings differ in how a product of two fp32
+ * operands is formed on the matrix cores (gfx950 runs fp32 MFMAs at 1/16 of its bf16 MFMA rate, and has no xf32).  Measured max-norm
+ * error of the batched GEMM against fp64 on the same operands (tools/gemm_nt_dtype.py; tolerances asserted in tests/test_gpu_bf16.py):
+ *   AFI_DTYPE_BF16X6  (default) each operand is split EXACTLY into three bf16, x = hi + mid + lo (3 x 8 = all 24 mantissa bits; the
+ *                     residuals x - hi and x - hi - mid are exact in fp32), and the six partial products of order >= 2^-16
+ *                     (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are accumulated smallest first in fp32 by v_mfma_f32_32x32x16_bf16;
+ *                     a bf16 x bf16 product is exact in fp32, and what is dropped (mid*lo, lo*mid, lo*lo <= 2^-23 of a product) is the
+ *                     size of fp32's own rounding of that product.  Error 0.5e-6 .. 1.1e-6 -- at or below the fp32 MFMA's on every shape
+ *                     measured -- at 1.5x its speed.  fp32-grade: every parity test of this repo runs on it at the fp32 tolerances.
+ *   AFI_DTYPE_F32     fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain).  Error 1.0e-6 .. 1.3e-6.
+ *   AFI_DTYPE_BF16X3  x = hi + lo (16 mantissa bits), three MFMAs (hi*hi + hi*lo + lo*hi).  Error 4.5e-6; conv outputs within 2e-4,
+ *                     network outputs / input gradients within 1e-3, weight gradients within 1e-2 (L2; LeakyReLU-mask flips).  Opt-in.
+ *   AFI_DTYPE_BF16    operands rounded to bf16 (8 bits), one MFMA; every convolution on F(2x2,3x3) tiles (the F(4x4) transforms do not
+ *                     survive 8-bit operands: 3 % error).  Error 2.5e-3; conv outputs within 2e-2, networks 5e-2 / 1e-1.  Opt-in:
+ *                     the reference has no reduced-precision mode (SOLVER.AMP is never read, defaults.py:82).
+ * Refused while weight-gradient sums are pending.  AFI_DEFAULT_DTYPE=<n> in the environment overrides the default (A/B runs). */
 #define AFI_DTYPE_F32 0
 #define AFI_DTYPE_BF16 1
 #define AFI_DTYPE_BF16X3 3
+#define AFI_DTYPE_BF16X6 6
+#define AFI_DTYPE_DEFAULT AFI_DTYPE_BF16X6
 int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype);
 int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over

@@ -152,16 +152,18 @@ def test_bifpn_train_vs_reference_fixture(amd, golden_dir):
         gold = fx["out/" + k]
         got = o.detach().cpu().numpy() if k != "p3" else o.detach()[:, ::4].cpu().numpy()
         assert np.abs(got - gold).max() <= 1e-3 * np.abs(gold).max(), k
+    # (the input gradients pass 28 interpolator calls and 61 training-mode norms: the LeakyReLU-mask flips between two fp32-grade
+    #  evaluations -- tests/test_gpu_d_parity.py -- put them at 1.5e-3 .. 2.5e-3 max-norm, whichever fp32-grade GEMM arithmetic runs)
     for k, f in fg.items():
         gold = fx["dfeat/" + k]
-        assert np.abs(f.grad.cpu().numpy() - gold).max() <= 2e-3 * np.abs(gold).max(), k
+        assert np.abs(f.grad.cpu().numpy() - gold).max() <= 5e-3 * np.abs(gold).max(), k
     grads = {k: v.grad.cpu() for k, v in net.named_parameters() if v.grad is not None}
     assert {k for k in fx if k.startswith("gd/")} == {"gd/" + k for k in grads}
     # (the conv biases in front of a training-mode norm have an analytically zero gradient: see tests/test_oracle_golden.py)
     dead = {k for k in grads if not k.startswith("srf_module.") and (k.endswith("pointwise.bias") or k.endswith(".0.bias") or k.endswith("p6.conv.bias"))}
     for k in dead:
         assert grads[k].abs().max() <= 1e-4 * grads[k[:-len("bias")] + "weight"].abs().max(), k
-    _check_digests(fx, {k: g for k, g in grads.items() if k not in dead and not k.startswith("srf_module.")}, rtol=2e-3)
+    _check_digests(fx, {k: g for k, g in grads.items() if k not in dead and not k.startswith("srf_module.")}, rtol=5e-3)    # (mask flips, as above: 1e-3 .. 3e-3)
     _check_digests(fx, {k: g for k, g in grads.items() if k.startswith("srf_module.")}, rtol=1e-2)     # sums over 28 calls that cancel
     sd = net.state_dict()
     for k in sd:
