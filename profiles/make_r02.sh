@@ -6,6 +6,8 @@ D=profiles/r02
 mkdir -p $D
 cp $(find $P/trace -name "*kernel_stats.csv" | head -1) $D/kernel_stats_bench_steps3_warmup0.csv
 grep '^{' $P/bench_trace.log > $D/bench_line_under_rocprof_steps3_warmup0.json
+cp $(find $P/trace_fp32 -name "*kernel_stats.csv" | head -1) $D/kernel_stats_bench_steps3_warmup0_dtype_fp32.csv
+grep '^{' $P/bench_trace_fp32.log > $D/bench_line_under_rocprof_steps3_warmup0_dtype_fp32.json
 grep '^{' $P/bench_default.log > $D/bench_line_default_run.json
 python profiles/summarize_pmc.py $(find $P/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $P/pmc_write -name "*counter_collection.csv" | head -1) > $D/pmc_hbm_fetch_write_steps1.csv
 python profiles/summarize_pmc.py $(find $P/pmc_sq -name "*counter_collection.csv" | head -1) > $D/pmc_sq_steps1.csv
@@ -18,7 +20,7 @@ import json, csv, subprocess
 D = 'profiles/r02'
 rows = list(csv.DictReader(open(f'{D}/pmc_hbm_fetch_write_steps1.csv')))
 d = json.loads(open(f'{D}/bench_line_under_rocprof_steps3_warmup0.json').read())
-dom = max((x for x in rows if 'afi_gemm_nt_kernel' in x['kernel']), key=lambda x: float(x['FETCH_SIZE_sum']))
+dom = max((x for x in rows if 'afi_gemm_nt' in x['kernel']), key=lambda x: float(x['FETCH_SIZE_sum']))
 fetch = float(dom['FETCH_SIZE_per_dispatch']) * 1024 * 2
 write = float(dom['WRITE_SIZE_per_dispatch']) * 1024
 head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
