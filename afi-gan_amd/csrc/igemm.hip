@@ -616,8 +616,8 @@ const char* kKindNames[] = {
     "gemm_nt<128x128> (batched Winograd GEMM)", "gemm_tn<128x128> (Winograd weight-gradient GEMM)",
     "pix_gemm_wk (small-map pixel GEMM, K split inside the block; grouped launches included)",
     "wgrad_group (grouped weight gradients of a small-map backward pass)",
-    "gemm_nt_bf16<128x128> (batched Winograd GEMM, bf16 / bf16x3 MFMA, fp32 accumulate)",
-    "gemm_tn_bf16<128x128> (Winograd weight-gradient GEMM, bf16 / bf16x3 MFMA, fp32 accumulate)"};   // one kind per kernel, as rocprofv3 lists them
+    "gemm_nt_bf16<128x128> (batched Winograd GEMM on the bf16 MFMA: bf16x6 / bf16x3 / bf16 operands, fp32 accumulate)",
+    "gemm_tn_bf16<128x128> (Winograd weight-gradient GEMM on the bf16 MFMA: bf16x6 / bf16x3 / bf16 operands, fp32 accumulate)"};   // one kind per kernel, as rocprofv3 lists them
 constexpr int kNumKinds = 19;
 hipEvent_t prof_event() {
     if (g_prof.used == g_prof.pool.size()) {
