@@ -680,6 +680,21 @@ extern "C" int afi_profile_dump(const char* path) {
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
 #include <stdlib.h>
+// dynamic LDS beyond 64 KB is an opt-in per kernel AND per device (a process may drive several GPUs): done once for each pair
+#include <mutex>
+#include <set>
+#include <utility>
+static bool afi_opt_in_big_lds(const void* fn) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, fn})) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    done.insert({dev, fn});
+    return true;
+}
 static int afi_env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
@@ -696,9 +711,7 @@ static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     ProfScope prof(st, kind, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
     prof.m = M; prof.n = p.Ncols; prof.k = p.ntaps * p.nKphase * p.Ck;
     if (lds > 64 * 1024) {   // beyond the default dynamic-LDS limit: opt in once per instantiation
-        static const hipError_t attr = hipFuncSetAttribute((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO, GTAP>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr != hipSuccess) return AFI_ERR_LAUNCH;
+        if (!afi_opt_in_big_lds((const void*)afi_pix_gemm_kernel<BM, BN, WM, WN, B_RC, BK, HALO, GTAP>)) return AFI_ERR_LAUNCH;
     }
     // split-K for small maps: with fewer tiles than ~2 per CU the serial K loop (72..288 stages of ~0.9 us) is pure latency;
     // spread it over blockIdx.y, keeping >= 4 stages per block and the slabs inside the caller's workspace
@@ -886,9 +899,7 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
     ProfScope prof(st, BM >= 128 ? 8 : (BM == 64 ? 9 : 10), 2.0 * (double)P * p.Mrows * p.Ncols * p.ntaps);
     prof.m = (long long)p.Mrows * p.ntaps; prof.n = p.Ncols; prof.k = (int)(P > 2147483647LL ? 2147483647LL : P); prof.split = splitK;
     if (lds >= 64 * 1024) {
-        static const hipError_t attr = hipFuncSetAttribute((const void*)afi_wgrad_gemm_kernel<BM, BN, WM, WN>,
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (attr != hipSuccess) return AFI_ERR_LAUNCH;
+        if (!afi_opt_in_big_lds((const void*)afi_wgrad_gemm_kernel<BM, BN, WM, WN>)) return AFI_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((afi_wgrad_gemm_kernel<BM, BN, WM, WN>), dim3((unsigned)tiles, splitK), dim3(64 * WM * WN), lds, st, p, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
