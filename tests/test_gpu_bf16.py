@@ -63,6 +63,35 @@ def test_batched_gemms(amd, dtype):
     assert lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), 1, 128, 128, 32, 2, st) == 1
 
 
+@pytest.mark.parametrize("kind", ["normal", "positive_large_mean", "wide_dynamic_range", "tiny_values", "sparse_post_relu"])
+def test_bf16x6_is_fp32_grade_on_hard_operands(amd, kind):
+    """The default arithmetic against the fp32 MFMA kernel on the SAME operands, both measured against fp64: the six-product form must
+    not be worse than fp32's own rounding (bar: 1.5x the fp32 kernel's error + 1e-7), whatever the operands look like."""
+    from afigan_amd import _lib
+    lib, st = _lib.load(), amd.ops.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    planes, rows, N, K = 4, 512, 256, 1024
+    A = torch.randn((planes, rows, K), device="cuda", generator=g)
+    B = torch.randn((planes, N, K), device="cuda", generator=g)
+    if kind == "positive_large_mean":
+        A, B = A.abs() * 3 + 100.0, B.abs() + 10.0                   # no cancellation to hide a bias of the dropped terms
+    elif kind == "wide_dynamic_range":
+        A = A * torch.exp2(torch.randint(-20, 20, A.shape, device="cuda", generator=g).float())
+        B = B * torch.exp2(torch.randint(-12, 12, B.shape, device="cuda", generator=g).float())
+    elif kind == "tiny_values":
+        A, B = A * 1e-18, B * 1e-12                                  # products ~1e-30: far below bf16's precision of 1.0, inside its range
+    elif kind == "sparse_post_relu":
+        A, B = torch.relu(A - 1.0), B * (torch.rand(B.shape, device="cuda", generator=g) < 0.1)
+    ref = torch.bmm(A.double(), B.double().transpose(1, 2))
+    err = {}
+    for dt in ("fp32", "bf16x6"):
+        Cm = torch.empty((planes, rows, N), device="cuda")
+        _lib.check(lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), planes, rows, N, K, _lib.DTYPES[dt], st), "afi_gemm_nt")
+        err[dt] = ((Cm.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err["bf16x6"] <= 1.5 * err["fp32"] + 1e-7, (kind, err)
+    assert err["fp32"] < 5e-6, (kind, err)
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16x6", "bf16x3", "bf16"])
 @pytest.mark.parametrize("N,Ci,Co,H,W", [(1, 256, 256, 50, 68), (2, 256, 512, 100, 84), (1, 288, 128, 33, 47)])
 def test_conv3x3_winograd_under_dtype(amd, dtype, N, Ci, Co, H, W):
