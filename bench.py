@@ -514,7 +514,7 @@ def main():
                 "share_of_step_time": dom["ms_total"] / (elapsed * 1e3),
                 # fp32-equivalent rate of the dominant kernel against the fp32 MFMA roof it replaces (> 1 is the point of the emulated forms)
                 "achieved_over_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                "peak_note": "fp32-equivalent TFLOP/s: 2*M*N*K once per product; peak = dense bf16 MFMA 2500 / bf16 MFMAs per product (6, 3 or 1), or the fp32 MFMA 157.3",
+                "peak_note": "fp32-equivalent TFLOP/s: 2*M*N*K once per product; peak = dense bf16 MFMA 2500 (quoted at 2.4 GHz) / bf16 MFMAs per product (6, 3 or 1), or the fp32 MFMA 157.3.  Under the bf16x6 GEMM the chip holds 1.63 GHz (power-limited; profiles/r02/pmc_sq_steps1.csv: SQ_BUSY_CYCLES), where its matrix pipe is 67 % busy: DESIGN.md 4b",
                 # the whole step in EXECUTED matrix-core products (what the GEMM launches multiplied, Winograd-domain for the big convs): the time
                 # they need at each kernel's own peak over the wall time -- the one <= 1 "achieved roofline" figure of the step
                 "frac_step_executed": peak_s / elapsed,
