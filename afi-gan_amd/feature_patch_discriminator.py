@@ -53,7 +53,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         prm, keep = net._param_struct(params)
         F = (C.c_int * 4)(*net.F)
         ws_floats = lib.afi_discriminator_fwd_ws_floats(F, N, H, W)
-        ws = torch.empty(ws_floats, device=x.device, dtype=torch.float32)
+        ws = ops.new_workspace(ws_floats, x.device)
         logits = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
         # 0 eval; 1 train mode with a backward to come; 2 train-mode statistics only (no input of this call needs a gradient)
         # net._grad_mode: torch.is_grad_enabled() as the module's forward saw it (inside Function.forward it is always off, and
@@ -82,7 +82,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         dx = ops.new_pixel_major(N, net.F[0], H, W, dlogits.device) if ctx.x_needs_grad else None
         F = (C.c_int * 4)(*net.F)
         sc_floats = lib.afi_discriminator_bwd_ws_floats(F, N, H, W)
-        scratch = torch.empty(sc_floats, device=dlogits.device, dtype=torch.float32)
+        scratch = ops.new_workspace(sc_floats, dlogits.device)
         call("afi_discriminator_bwd", C.byref(prm), C.byref(gst), ops.view_of(xp), N, H, W, C.c_void_p(ws.data_ptr()),
              C.c_void_p(dlogits.data_ptr()), C.c_void_p(dx.data_ptr() if dx is not None else None),
              C.c_void_p(scratch.data_ptr()), sc_floats, ops.stream_ptr())

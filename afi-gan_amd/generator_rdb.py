@@ -80,7 +80,7 @@ class _GeneratorFn(torch.autograd.Function):
         lib = _lib.load()
         prm, keep = gen._param_struct(params)
         ws_floats = lib.afi_generator_fwd_ws_floats(gen.in_channels, gen.growth_rate, gen.n_residual_dense_blocks, N, H, W)
-        ws = torch.empty(ws_floats, device=x.device, dtype=torch.float32)
+        ws = ops.new_workspace(ws_floats, x.device)
         out = ops.new_pixel_major(N, Cc, 2 * H, 2 * W, x.device)
         call("afi_generator_fwd", C.byref(prm), ops.view_of(xp), N, H, W, ops.view_of(out), C.c_void_p(ws.data_ptr()), ws_floats,
              ops.stream_ptr())
@@ -105,7 +105,7 @@ class _GeneratorFn(torch.autograd.Function):
         gst, _ = gen._param_struct(grads, already_packed=True)
         dx = ops.new_pixel_major(N, gen.in_channels, H, W, dout.device) if ctx.x_needs_grad else None
         sc_floats = lib.afi_generator_bwd_ws_floats(gen.in_channels, gen.growth_rate, gen.n_residual_dense_blocks, N, H, W)
-        scratch = torch.empty(sc_floats, device=dout.device, dtype=torch.float32)
+        scratch = ops.new_workspace(sc_floats, dout.device)
         call("afi_generator_bwd", C.byref(prm), C.byref(gst), ops.view_of(xp), N, H, W, C.c_void_p(ws.data_ptr()),
              C.c_void_p(dout.data_ptr()), C.c_void_p(dx.data_ptr() if dx is not None else None),
              C.c_void_p(scratch.data_ptr()), sc_floats, ops.stream_ptr())

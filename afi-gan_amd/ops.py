@@ -35,8 +35,21 @@ def is_pixel_major(t: torch.Tensor) -> bool:
         and t.data_ptr() % 16 == 0
 
 
+_POISON = os.environ.get("AFI_POISON_WS", "0") != "0"     # debugging aid: workspaces start as NaN, so a read of memory the library did not
+                                                            # write first shows up in the results instead of depending on what the allocator recycled
+
+
+def new_workspace(floats: int, device) -> torch.Tensor:
+    """Uninitialised fp32 scratch for a library call (NaN-filled under AFI_POISON_WS=1)."""
+    if _POISON:
+        return torch.full((int(floats),), float("nan"), device=device, dtype=torch.float32)
+    return torch.empty(int(floats), device=device, dtype=torch.float32)
+
+
 def new_pixel_major(N, C_, H, W, device, zero=False) -> torch.Tensor:
     """Fresh [N,C,H,W] tensor whose memory is [N][H][W][C]."""
+    if _POISON and not zero:
+        return torch.full((N, H, W, C_), float("nan"), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
     f = torch.zeros if zero else torch.empty
     return f((N, H, W, C_), device=device, dtype=torch.float32).permute(0, 3, 1, 2)
 
@@ -113,7 +126,7 @@ def weight_transform_cache(device, floats=32 * 1024 * 1024):
     cx = _lib.current_ctx()
     buf = cx.bufs.get("wcache")
     if buf is None or buf.numel() < floats:
-        buf = cx.bufs["wcache"] = torch.empty(floats, device=device, dtype=torch.float32)
+        buf = cx.bufs["wcache"] = new_workspace(floats, device)
     if cx.keep is not None:
         raise _lib.AfiError("weight_transform_cache is not re-entrant")
     cx.keep = []
@@ -162,7 +175,7 @@ def _ensure_op_scratch(device):
     cx = _lib.current_ctx()
     buf = cx.bufs.get("op_scratch")
     if buf is None:
-        buf = cx.bufs["op_scratch"] = torch.empty(OP_SCRATCH_FLOATS, device=device, dtype=torch.float32)
+        buf = cx.bufs["op_scratch"] = new_workspace(OP_SCRATCH_FLOATS, device)
         call("afi_ctx_set_op_scratch", cx.handle, C.c_void_p(buf.data_ptr()), buf.numel())
     return buf
 
@@ -211,7 +224,7 @@ def conv3x3_wino_fwd(x, w, bias=None):
     Cout = w.shape[0]
     w = ohwi(w)
     n = _lib.load().afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout)
-    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    ws = new_workspace(n, x.device)
     out = new_pixel_major(N, Cout, H, W, x.device)
     call("afi_conv3x3_wino_fwd", view_of(x), N, H, W, Cin, _p(w), _p(bias), Cout, view_of(out), _p(ws), n, stream_ptr())
     return out
@@ -224,7 +237,7 @@ def conv3x3_wino_infer(x, w, bias=None, act=0):
     Cout = w.shape[0]
     w = ohwi(w)
     n = _lib.load().afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout)
-    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    ws = new_workspace(n, x.device)
     out = new_pixel_major(N, Cout, H, W, x.device)
     call("afi_conv3x3_wino_infer", view_of(x), N, H, W, Cin, _p(w), _p(bias), Cout, view_of(out), int(act), _p(ws), n, stream_ptr())
     return out
@@ -237,7 +250,7 @@ def conv3x3_wino_dgrad(dy, w, z=None):
     Cin = w.shape[1]
     w = ohwi(w)
     n = _lib.load().afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout)
-    ws = torch.empty(n, device=dy.device, dtype=torch.float32)
+    ws = new_workspace(n, dy.device)
     dx = new_pixel_major(N, Cin, H, W, dy.device)
     call("afi_conv3x3_wino_dgrad", view_of(dy), N, H, W, Cout, _p(w), Cin, view_of(dx), view_of(z) if z is not None else _NULL_VIEW,
          _p(ws), n, stream_ptr())
@@ -253,7 +266,7 @@ def conv3x3_wino_wgrad(dy, x, dw=None, alpha=1.0):
         dw = new_ohwi(Cout, Cin, 3, 3, dy.device)
     assert dw.permute(0, 2, 3, 1).is_contiguous()
     n = _lib.load().afi_conv3x3_wino_ws_floats(N, H, W, Cin, Cout)
-    ws = torch.empty(n, device=dy.device, dtype=torch.float32)
+    ws = new_workspace(n, dy.device)
     call("afi_conv3x3_wino_wgrad", view_of(dy), view_of(x), N, H, W, Cout, Cin, _p(dw), float(alpha), _p(ws), n, stream_ptr())
     return dw
 
@@ -436,7 +449,7 @@ def fuse_swish_bwd(w, a, b, c, dout, need=(True, True, True, True)):
     db = new_pixel_major(*a.shape, dev) if need[2] else None
     dc = new_pixel_major(*a.shape, dev) if (c is not None and need[3]) else None
     dw = torch.empty_like(w) if need[0] else None
-    scratch = torch.empty(_lib.load().afi_fuse_swish_bwd_scratch_floats(), device=dev, dtype=torch.float32)
+    scratch = new_workspace(_lib.load().afi_fuse_swish_bwd_scratch_floats(), dev)
     call("afi_fuse_swish_bwd", _p(a), _p(b), _p(c), _p(w), _p(dout), _p(da), _p(db), _p(dc), _p(dw), a.numel(), _p(scratch), stream_ptr())
     return dw, da, db, dc
 
@@ -447,7 +460,7 @@ def dwconv3x3_wgrad(dy, x):
     assert is_dense_pm(dy) and is_dense_pm(x) and dy.shape == x.shape
     N, C_, H, W = x.shape
     dw = torch.empty((9, C_), device=x.device, dtype=torch.float32)
-    scratch = torch.empty(_lib.load().afi_dwconv3x3_wgrad_scratch_floats(C_), device=x.device, dtype=torch.float32)
+    scratch = new_workspace(_lib.load().afi_dwconv3x3_wgrad_scratch_floats(C_), x.device)
     call("afi_dwconv3x3_wgrad", _p(dy), _p(x), N, H, W, C_, _p(dw), _p(scratch), stream_ptr())
     return dw
 
@@ -581,7 +594,7 @@ def bilinear2x_bwd(dout, dx=None, beta=0.0):
 
 
 def reduce_scratch(C_, device):
-    return torch.empty(_lib.load().afi_reduce_scratch_floats(C_), device=device, dtype=torch.float32)
+    return new_workspace(_lib.load().afi_reduce_scratch_floats(C_), device)
 
 
 def bn_stats(x2d, running_mean=None, running_var=None):

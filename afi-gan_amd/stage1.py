@@ -154,7 +154,7 @@ class Stage1Step:
     def _scratch(self, key: str, floats: int, device) -> torch.Tensor:
         t = self._buf.get(key)
         if t is None or t.numel() < floats:
-            t = torch.empty(int(floats), device=device, dtype=torch.float32)
+            t = ops.new_workspace(floats, device)
             self._buf[key] = t
         return t
 
