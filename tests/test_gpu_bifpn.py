@@ -220,6 +220,37 @@ def test_bifpn_train_small_vs_oracle(amd):
         assert _rel(sd[k].float(), v.float()) < 1e-4, k
 
 
+def test_bifpn_eval_mode_with_input_gradients(amd):
+    """eval() with an input that requires grad: the autograd path with the norms on their running statistics -- the folded inference
+    forward's values, and gradients that match the oracle's eval-mode graph."""
+    C = 32
+    net = amd.BiFPN_AFIGAN(_BottomUp3(), ["stage3", "stage4", "stage5"], C, 7, norm="BN", top_block=amd.LastLevelP6P7(16, C, "BN")).cuda()
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(os.path.dirname(__file__), "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+    p = {k: mg.bifpn_closed_form(k, v) for k, v in net.state_dict().items() if not k.startswith("srf_module.")}
+    p.update({"srf_module." + k: v for k, v in orc.closed_form_generator_params(C, 3, 32).items()})
+    net.load_state_dict(p, strict=True)
+    net.eval()
+    g = torch.Generator().manual_seed(12)
+    feats = [torch.randn((1, c, 16 // 2 ** i, 32 // 2 ** i), generator=g) for i, c in enumerate([8, 12, 16])]
+    with torch.no_grad():
+        fast = net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})
+    fg = {f"stage{i + 3}": f.cuda().requires_grad_(True) for i, f in enumerate(feats)}
+    out = net(fg)
+    R = {k: torch.randn(o.shape, generator=g) for k, o in out.items()}
+    sum((o * R[k].cuda()).sum() for k, o in out.items()).backward()
+    fr = [f.clone().requires_grad_(True) for f in feats]
+    ref = orc.bifpn_afigan_forward(fr, p)
+    sum((o * R[k]).sum() for k, o in ref.items()).backward()
+    for k in ref:
+        assert _rel(out[k], fast[k]) < 1e-4 and _rel(out[k], ref[k]) < 1e-3, k
+    for i, f in enumerate(fr):
+        assert _rel(fg[f"stage{i + 3}"].grad, f.grad) < 2e-3, i
+    sd = net.state_dict()
+    assert all(torch.equal(sd[k].cpu(), v) for k, v in p.items() if "running" in k or "num_batches" in k)      # eval: buffers untouched
+
+
 def test_bifpn_hipgraph_capture(amd):
     """The inference forward has no host synchronisation: it captures into a hipGraph and replays bit-identically."""
     net = amd.BiFPN_AFIGAN(_BottomUp3(), ["stage3", "stage4", "stage5"], 256, 7, norm="SyncBN", top_block=amd.LastLevelP6P7(16, 256, "SyncBN")).cuda().eval()
