@@ -544,11 +544,11 @@ def main():
                    "reuse_generator_forward": True},
         "algorithmic_tflop_per_image": flop_img / 1e12,
         "step_tflops_per_gpu": flop_img * B * args.steps / elapsed / 1e12,
-        # direct-convolution FLOP count of the step over the dense fp32 MFMA peak.  The discriminator's 3x3 convs run in
-        # Winograd F(2x2,3x3) / F(3x3,2x2) form, which EXECUTES 2.25x fewer matrix-core FLOPs than this count, so the ratio can pass 1;
-        # `roofline` below is in executed FLOPs of the dominant kernel (the batched Winograd GEMM) and stays under the peak.
+        # direct-convolution FLOP count of the step over the dense fp32 MFMA peak.  The big 3x3 convs run in Winograd form,
+        # which EXECUTES 2.25x / 4x fewer products than this count, so the ratio can pass 1; `roofline` below is in executed products of
+        # the dominant kernel (the batched Winograd GEMM) against that kernel's own roof.
         "step_algorithmic_tflops_over_fp32_mfma_peak": flop_img * B * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-        "conv_algorithm": "Winograd F(2x2,3x3) fwd/dgrad + F(3x3,2x2) wgrad for the discriminator's 3x3 convs (fp32, exact-f32 MFMA GEMMs); direct implicit GEMM elsewhere",
+        "conv_algorithm": "Winograd F(2x2,3x3) forwards that a backward follows, F(4x4,3x3) / F(3x3,4x4) data and weight gradients and forward-only passes, for every 3x3 conv with >= 128 channels on both sides and >= 1024 pixels (fp32 planes; their batched GEMMs in the arithmetic named by `dtype`); direct implicit GEMM on the fp32 MFMA elsewhere",
         "roofline": roofline,
         # opt-in arithmetic of the big convolutions, same engine / inputs / K (afi_ctx_set_compute_dtype; tolerances: tests/test_gpu_bf16.py).
         # Not the headline: the reference is fp32-only.  Their GEMM kernels are priced against the dense bf16 MFMA peak.
