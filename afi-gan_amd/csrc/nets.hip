@@ -217,6 +217,9 @@ static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
 // Any 3x3 / stride-1 conv DESCRIPTOR of the pixel GEMM (forward, b_rc = 0, or data gradient, b_rc = 1) run in Winograd form: the
 // batched GEMM writes M, the output transform applies the descriptor's own epilogue.  Eligible: 9 taps, one K phase, no up-sampled
 // gather, dense [rows][3][3][K-or-N] weights, >= 128 channels on both sides, >= 1024 pixels.
+// below this many pixels a conv of the interpolator stays on the direct small-map kernels.  Scanned with tools/interp_sweep.py
+// (fwd+bwd, 1024 -> 2048): 1x25x42 1.31 -> 1.04 ms, 2x25x34 1.49 -> 1.33 ms; 4096 and up lose from 3400 pixels on.
+static long long wino_g_minpix() { static const long long v = getenv("AFI_G_WINO_MINPIX") ? atoll(getenv("AFI_G_WINO_MINPIX")) : 2048; return v; }
 static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
     static const int on = getenv("AFI_WINO_G") ? atoi(getenv("AFI_WINO_G")) : 1;
     if (!on || g.ntaps != 9 || g.gtap || g.r2_post) return false;
@@ -227,7 +230,7 @@ static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
     static const int convt = getenv("AFI_WINO_CONVT") ? atoi(getenv("AFI_WINO_CONVT")) : 1;
     if (phases && !convt) return false;
     if (g.Ck < 128 || g.Ncols < 128 || (g.Ck & 3) || (g.Ncols & 3)) return false;
-    if ((long long)g.N * g.H * g.W < 1024) return false;
+    if ((long long)g.N * g.H * g.W < wino_g_minpix()) return false;
     const int I = b_rc ? g.Ncols : g.Ck;                   // innermost weight dimension of w[O][3][3][I]
     return g.b_sTap == I && g.b_sRow == 9LL * I && g.a_sgn == (b_rc ? -1 : 1);
 }
@@ -881,7 +884,8 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     // into the convs that still need it; a conv's slice accumulates in place (beta = 1) and is activated by the step that completes
     // it.  Same multiply-adds as generator_rdb.py:64-71, summed in another order (fp32 rounding only).  AFI_RDB_BATCH=0: conv by conv.
     static const int rdb_batch = getenv("AFI_RDB_BATCH") ? atoi(getenv("AFI_RDB_BATCH")) : 1;
-    const bool batched = rdb_batch && l.P < 1024 && 4 * l.P <= kSideStreamMaxPixels;
+    static const long long rdb_batch_maxp = getenv("AFI_RDB_BATCH_MAXP") ? atoll(getenv("AFI_RDB_BATCH_MAXP")) : 2048;
+    const bool batched = rdb_batch && l.P < rdb_batch_maxp;
     for (int r = 0; r < R; ++r) {   // ResidualDenseBlock.forward (generator_rdb.py:64-71); the dense buffer replaces torch.cat
         AfiView b = buf(r);
         const bool last = (r == R - 1);
@@ -975,7 +979,8 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // 7 .. 36-tile launch per layer on a side stream.  All their operands (dOut, dU, gA, gB, the per-block gradient buffers and the
     // saved activations) stay alive until the call returns.  AFI_WG_GROUP=0 restores the per-layer launches.
     static const int wg_group = getenv("AFI_WG_GROUP") ? atoi(getenv("AFI_WG_GROUP")) : 1;
-    const bool grouped = wg_group && 4 * l.P <= kSideStreamMaxPixels;
+    static const long long wg_group_maxp = getenv("AFI_WG_GROUP_MAXP") ? atoll(getenv("AFI_WG_GROUP_MAXP")) : kSideStreamMaxPixels / 4;
+    const bool grouped = wg_group && l.P <= wg_group_maxp;
     AfiWgradGemm wg_wide[12], wg_narrow[4 * AFI_MAX_RDB];
     AfiColsumProb cs[8];
     int n_wide = 0, n_narrow = 0, n_cs = 0;
@@ -988,7 +993,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // weight gradient of a 3x3 conv: Winograd F(3x3,2x2) when both channel counts and the map are large enough, else direct
     auto WG = [&](AfiView dyv, AfiView xin, int n_, int h_, int w_, int co, int ci, float* dw, float alpha, hipStream_t s_) {
         if (grouped) return defer(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha));
-        if (s.n_wino > 0 && co >= 128 && ci >= 128 && (long long)n_ * h_ * w_ >= 1024)
+        if (s.n_wino > 0 && co >= 128 && ci >= 128 && (long long)n_ * h_ * w_ >= wino_g_minpix())
             return wino_wgrad(cx, dyv, xin, n_, h_, w_, co, ci, dw, alpha, scratch + s.o_wino2, s.n_wino, s_);
         return afi_launch_wgrad_gemm(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha), s_);
     };
@@ -1045,7 +1050,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
         if (grouped) {
             AFI_TRY(defer(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f)));
             n_wide_has_convT = true; unpack_pending = true;
-        } else if (convt && s.n_wino > 0 && C >= 128 && P >= 1024) {    // the four phases as channel blocks of one Winograd weight gradient
+        } else if (convt && s.n_wino > 0 && C >= 128 && P >= wino_g_minpix()) {    // the four phases as channel blocks of one Winograd weight gradient
             AFI_TRY(wino_wgrad(cx, dU, a7, N, H, W, 4 * C, C, dwp, 1.f, scratch + s.o_wino2, s.n_wino, sd, /*dy_phases=*/4, /*accumulate=*/false));
         } else {
             AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));

@@ -570,6 +570,12 @@ def main():
         torch.cuda.synchronize()
         line["af_interpolator"] = {"metric": "AF-interpolator fwd+bwd feature-Mpix/s (256ch P5->P4)",
                                    "cfg1": interp_bench(amd, torch, 1, 25, 34), "batch16": interp_bench(amd, torch, 16, 25, 34, iters=20, warmup=5)}
+        # SURVEY 8(d) sweep: batch sizes at the config-1 map, and the stage-3 FPN call-site maps (25x42, 50x84, 100x168) at N = 1
+        sweep = {}
+        for (n_, h_, w_) in ((2, 25, 34), (8, 25, 34), (1, 25, 42), (1, 50, 84), (1, 100, 168)):
+            r_ = interp_bench(amd, torch, n_, h_, w_, iters=20, warmup=5)          # (eager or hipGraph replay, whichever is faster: as cfg1)
+            sweep[f"{n_}x256x{h_}x{w_}"] = {"ms": round(r_["ms"], 4), "out_mpix_per_s": round(r_["out_mpix_per_s"], 3), "tflops": round(r_["tflops"], 1)}
+        line["af_interpolator"]["sweep"] = sweep
     if micro:
         log("FPN_AFIGAN top-down merge (SURVEY 8f row 1)")
         line["fpn_topdown"] = fpn_bench(amd, torch)
