@@ -1,11 +1,12 @@
-"""Per-launch GEMM timings of one config-1 AF-interpolator fwd+bwd (HIP-event brackets of the library): kind, shape, us."""
+"""Per-launch GEMM timings of one AF-interpolator fwd+bwd (HIP-event brackets of the library): kind, shape, us.
+Usage: python tools/cfg1_launches.py [N H W]   (default: config 1, 1 25 34)"""
 import ctypes as C, os, sys, csv, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import afigan_amd as amd
 from afigan_amd import _lib, ops
 lib = _lib.load()
-N, H, W = 1, 25, 34
+N, H, W = (int(v) for v in sys.argv[1:4]) if len(sys.argv) >= 4 else (1, 25, 34)
 G = amd.Generator(n_residual_dense_blocks=3).cuda()
 x = ops.pixel_major(torch.randn(N, 256, H, W).cuda())
 params = G._ordered_params(); prm, keep = G._param_struct(params)
