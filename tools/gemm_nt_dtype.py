@@ -63,5 +63,5 @@ if __name__ == "__main__":
     for cs in cases:
         run(*cs)
     if not a:
-        for cs in [(36, 2816, 512, 256), (36, 2816, 1024, 512), (36, 2816, 1024, 1024), (16, 11264, 256, 256), (36, 704, 128, 288)]:
+        for cs in [(36, 2816, 512, 256), (36, 2816, 1024, 512), (36, 2816, 1024, 1024), (16, 11264, 256, 256)]:
             run_tn(*cs)
