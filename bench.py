@@ -580,6 +580,11 @@ def main():
         log("FPN_AFIGAN top-down merge (SURVEY 8f row 1)")
         line["fpn_topdown"] = fpn_bench(amd, torch)
         line["pafpn"] = fpn_bench(amd, torch, pafpn=True)
+        # BASELINE configs[4] names this pyramid "bf16": the same forward + backward under each arithmetic setting of the big GEMMs
+        line["pafpn"]["ms_by_dtype"] = {}
+        for dt in ("fp32", "bf16x6", "bf16x3", "bf16"):
+            with amd.compute_dtype(dt):
+                line["pafpn"]["ms_by_dtype"][dt] = round(fpn_bench(amd, torch, iters=5, warmup=2, pafpn=True)["ms"], 3)
         line["bifpn_inference"] = bifpn_bench(amd, torch)
         line["stage2_adversarial"] = stage2_bench(amd, torch)
         from tools import dual_scale_bench                       # the mapper's uint8 resize pair + normalise/pad
