@@ -448,26 +448,36 @@ struct AfiWkArgs {
 // latencies in a row -- 3 us at the end of a kernel whose whole K loop takes 1.5 us.  Same arithmetic, same order of the adds.
 typedef const __attribute__((address_space(1))) float afi_gfloat;
 typedef const __attribute__((address_space(1))) f32x4 afi_gf32x4;
-__device__ __forceinline__ void afi_epilogue_store_fast(const AfiPixGemm& p, int img, int y, int x, int col, f32x4 accv, afi_gfloat* zpage) {
+struct AfiEpiPre {                                          // the optional operands of one output float4, loaded ahead of the accumulator
+    float* dst; f32x4 bv, ov, r1, r2, zv; int ch; bool live, use_old, use_r1, use_r2, use_z;
+};
+__device__ __forceinline__ AfiEpiPre afi_epilogue_prefetch(const AfiPixGemm& p, int img, int y, int x, int col, afi_gfloat* zpage) {
+    AfiEpiPre e;
     int phase = 0, ch = col;
     if (p.o_up == 2) { phase = col / p.CoutPhase; ch = col - phase * p.CoutPhase; }
     const int yo = y * p.o_up + (phase >> 1), xo = x * p.o_up + (phase & 1);
-    if (yo >= p.oH || xo >= p.oW) return;
-    float* dst = p.O.p + (long long)img * p.O.sN + (long long)yo * p.O.sH + (long long)xo * p.O.sW + ch;
-    const bool use_old = p.beta != 0.f;
-    const bool use_r1 = p.R1.p && !p.r1_bilinear && ch >= p.r1_lo && ch < p.r1_hi;
-    const bool use_r2 = p.R2.p && ch >= p.r2_lo && ch < p.r2_hi;
-    const bool use_z = p.Z.p && ch >= p.z_lo && ch < p.z_hi;
-    afi_gfloat* a_b = p.bias ? (afi_gfloat*)(p.bias + ch) : zpage;
-    afi_gfloat* a_o = use_old ? (afi_gfloat*)dst : zpage;
-    afi_gfloat* a_1 = use_r1 ? (afi_gfloat*)(p.R1.p + (long long)img * p.R1.sN + (long long)yo * p.R1.sH + (long long)xo * p.R1.sW + ch) : zpage;
-    afi_gfloat* a_2 = use_r2 ? (afi_gfloat*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch) : zpage;
-    afi_gfloat* a_z = use_z ? (afi_gfloat*)(p.Z.p + (long long)img * p.Z.sN + (long long)yo * p.Z.sH + (long long)xo * p.Z.sW + ch) : zpage;
-    const f32x4 bv = *(afi_gf32x4*)a_b, ov = *(afi_gf32x4*)a_o, r1 = *(afi_gf32x4*)a_1, r2 = *(afi_gf32x4*)a_2, zv = *(afi_gf32x4*)a_z;
+    e.ch = ch;
+    e.live = !(yo >= p.oH || xo >= p.oW);
+    e.dst = p.O.p + (long long)img * p.O.sN + (long long)yo * p.O.sH + (long long)xo * p.O.sW + ch;
+    e.use_old = e.live && p.beta != 0.f;
+    e.use_r1 = e.live && p.R1.p && !p.r1_bilinear && ch >= p.r1_lo && ch < p.r1_hi;
+    e.use_r2 = e.live && p.R2.p && ch >= p.r2_lo && ch < p.r2_hi;
+    e.use_z = e.live && p.Z.p && ch >= p.z_lo && ch < p.z_hi;
+    afi_gfloat* a_b = (e.live && p.bias) ? (afi_gfloat*)(p.bias + ch) : zpage;
+    afi_gfloat* a_o = e.use_old ? (afi_gfloat*)e.dst : zpage;
+    afi_gfloat* a_1 = e.use_r1 ? (afi_gfloat*)(p.R1.p + (long long)img * p.R1.sN + (long long)yo * p.R1.sH + (long long)xo * p.R1.sW + ch) : zpage;
+    afi_gfloat* a_2 = e.use_r2 ? (afi_gfloat*)(p.R2.p + (long long)img * p.R2.sN + (long long)yo * p.R2.sH + (long long)xo * p.R2.sW + ch) : zpage;
+    afi_gfloat* a_z = e.use_z ? (afi_gfloat*)(p.Z.p + (long long)img * p.Z.sN + (long long)yo * p.Z.sH + (long long)xo * p.Z.sW + ch) : zpage;
+    e.bv = *(afi_gf32x4*)a_b; e.ov = *(afi_gf32x4*)a_o; e.r1 = *(afi_gf32x4*)a_1; e.r2 = *(afi_gf32x4*)a_2; e.zv = *(afi_gf32x4*)a_z;
+    return e;
+}
+__device__ __forceinline__ void afi_epilogue_finish(const AfiPixGemm& p, const AfiEpiPre& e, int img, int y, int x, f32x4 accv) {
+    if (!e.live) return;
+    const int ch = e.ch;
     f32x4 v = p.alpha * accv;
-    v += bv;
-    if (use_old) v += p.beta * ov;
-    if (use_r1) v += p.r1s * r1;
+    v += e.bv;
+    if (e.use_old) v += p.beta * e.ov;
+    if (e.use_r1) v += p.r1s * e.r1;
     if (p.R1.p && p.r1_bilinear && ch >= p.r1_lo && ch < p.r1_hi) {      // (uniform) only the interpolator's last conv
         int by0, by1, bx0, bx1; float ly, lx;
         afi_bil_idx(y, p.H >> 1, by0, by1, ly); afi_bil_idx(x, p.W >> 1, bx0, bx1, lx);
@@ -480,17 +490,21 @@ __device__ __forceinline__ void afi_epilogue_store_fast(const AfiPixGemm& p, int
         const f32x4 bot = x10 * (1.f - lx) + x11 * lx;
         v += p.r1s * (top * (1.f - ly) + bot * ly);
     }
-    if (use_r2) v += p.r2s * r2;
+    if (e.use_r2) v += p.r2s * e.r2;
     if (p.lrelu) {
         const float slope = (p.lrelu == 1) ? AFI_LRELU_SLOPE : 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
     }
-    if (use_z) {
+    if (e.use_z) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] *= (zv[j] > 0.f ? 1.f : AFI_LRELU_SLOPE);
+        for (int j = 0; j < 4; ++j) v[j] *= (e.zv[j] > 0.f ? 1.f : AFI_LRELU_SLOPE);
     }
-    *(f32x4*)dst = v;
+    *(f32x4*)e.dst = v;
+}
+__device__ __forceinline__ void afi_epilogue_store_fast(const AfiPixGemm& p, int img, int y, int x, int col, f32x4 accv, afi_gfloat* zpage) {
+    const AfiEpiPre e = afi_epilogue_prefetch(p, img, y, x, col, zpage);
+    afi_epilogue_finish(p, e, img, y, x, accv);
 }
 
 // LEAN: one register set in flight and one fragment set (<= 128 registers): TWO blocks per CU = four waves per SIMD, whose interleaving
@@ -664,23 +678,28 @@ __device__ __forceinline__ void afi_wk_body(const AfiPixGemm& p, const AfiWkArgs
     AFI_STAMP(4);
     // ---- the eight partial blocks meet in LDS (each wave writes into its own patch), then 256 threads sum and run the fused epilogue
     lds_order();
+    // the epilogue's own operands (old value, residuals, mask, bias) are requested BEFORE the partial tiles meet in LDS: their global
+    // round trip (~1.5 us) runs under the LDS write, the barrier and the eight partial reads instead of after them
+    const int e_rl = tid >> 3, e_c4 = tid & 7;
+    const int e_m = m0 + e_rl, e_col = n0 + 4 * e_c4;
+    const bool e_on = tid < 256 && e_m < M && e_col < p.Ncols;
+    AfiEpiPre epre; int e_img = 0, e_y = 0, e_x = 0;
+    if (e_on) {
+        afi_gfloat* zpage = (afi_gfloat*)afi_zeros;
+        asm volatile("" : "+v"(zpage));
+        const unsigned img = afi_udiv((unsigned)e_m, (unsigned)HW, sk.rcp_HW);
+        const int rem = e_m - (int)img * HW;
+        e_y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W); e_x = rem - e_y * p.W; e_img = (int)img;
+        epre = afi_epilogue_prefetch(p, e_img, e_y, e_x, e_col, zpage);
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) As[((r & 3) + 8 * (r >> 2) + 4 * lh) * LDK + lr] = acc[r];
     __syncthreads();
-    if (tid < 256) {
-        const int rl = tid >> 3, c4 = tid & 7;
-        const int m = m0 + rl, col = n0 + 4 * c4;
-        if (m < M && col < p.Ncols) {
-            afi_gfloat* zpage = (afi_gfloat*)afi_zeros;
-            asm volatile("" : "+v"(zpage));
-            f32x4 v = *(const f32x4*)(smem + rl * LDK + 4 * c4);
+    if (e_on) {
+        f32x4 v = *(const f32x4*)(smem + e_rl * LDK + 4 * e_c4);
 #pragma unroll
-            for (int w = 1; w < NW; ++w) v += *(const f32x4*)(smem + w * PATCH + rl * LDK + 4 * c4);     // fixed order: bit-reproducible
-            const unsigned img = afi_udiv((unsigned)m, (unsigned)HW, sk.rcp_HW);
-            const int rem = m - (int)img * HW;
-            const int y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W), x = rem - y * p.W;
-            afi_epilogue_store_fast(p, (int)img, y, x, col, v, zpage);
-        }
+        for (int w = 1; w < NW; ++w) v += *(const f32x4*)(smem + w * PATCH + e_rl * LDK + 4 * e_c4);     // fixed order: bit-reproducible
+        afi_epilogue_finish(p, epre, e_img, e_y, e_x, v);
     }
     AFI_STAMP(5);
     AFI_STAMP(8);
