@@ -376,3 +376,38 @@ def test_two_contexts_keep_their_own_state(amd):
         assert _rel(ops.conv3x3_wino_fwd(x, w, None), y_b) < 1e-6
     for cx in (a, b):
         _lib.call("afi_ctx_set_wino_weight_cache", cx.handle, C.c_void_p(None), 0)
+
+
+def test_results_do_not_depend_on_uninitialised_memory(amd, monkeypatch):
+    """Every workspace and output buffer the Python side hands to the library pre-filled with NaN (ops._POISON, = AFI_POISON_WS=1):
+    generator and discriminator forward + backward and one stage-1 step give the same finite results as with recycled memory."""
+    import copy
+    from afigan_amd import ops
+    torch.manual_seed(5)
+    G0 = amd.Generator(in_channels=32, n_residual_dense_blocks=3).cuda()
+    D0 = amd.Discriminator(in_filters=32).cuda()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn((2, 32, 9, 13), generator=g).cuda()
+    h = torch.randn((2, 32, 18, 26), generator=g).cuda()
+    R = torch.randn((2, 32, 18, 26), generator=g).cuda()
+
+    def run():
+        G, D = copy.deepcopy(G0), copy.deepcopy(D0)
+        xg = x.clone().requires_grad_(True)
+        out = G(xg)
+        (out * R).sum().backward()
+        hg = h.clone().requires_grad_(True)
+        logits = D(hg)
+        logits.square().mean().backward()
+        res = [out.detach(), xg.grad, logits.detach(), hg.grad] + [q.grad for q in list(G.parameters()) + list(D.parameters())]
+        step = amd.Stage1Step(copy.deepcopy(G0), copy.deepcopy(D0), base_lr=0.01, warmup_iters=0)
+        step.run_step([x], [h])
+        res += [torch.tensor(sorted(step.metrics().values()))]
+        return [t.detach().float().cpu().clone() for t in res]
+
+    clean = run()
+    monkeypatch.setattr(ops, "_POISON", True)
+    poisoned = run()
+    for a, b in zip(clean, poisoned):
+        assert torch.isfinite(b).all()
+        assert ((a - b).abs().max() / (a.abs().max() + 1e-30)).item() < 1e-4      # (fp32 atomics of the split weight gradients only)
