@@ -498,7 +498,8 @@ def main():
             if not same:
                 break                                      # measured on another kernel: stale
             traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch"),
-                       "measured_at": tj.get("measured_at"), "source": f"profiles/{rnd}/traffic_dominant_kernel.json "
+                       "measured_at": tj.get("measured_at"), "held_clock_ghz": tj.get("held_clock_ghz"), "mfma_busy_at_held_clock": tj.get("mfma_busy_at_held_clock"),
+                       "source": f"profiles/{rnd}/traffic_dominant_kernel.json "
                        "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; FETCH x2 per the gfx950 correction)"}
         except (OSError, ValueError, KeyError):
             traffic = None

@@ -30,6 +30,15 @@ out = {"kernel": dom['kernel'], "dispatches_in_pass": int(dom['dispatches']), "m
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-interp --no-cpu-baseline`; "
                "FETCH_SIZE x2 (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B), both x1024 (KB units); average over the "
                "launches of the dominant kernel in that step"}
+# clock the chip holds under the dominant kernel and its matrix-pipe duty there (SQ pass of the same command): SQ_BUSY_CYCLES is summed over
+# the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+sq = {x['kernel']: x for x in csv.DictReader(open(f'{D}/pmc_sq_steps1.csv'))}.get(dom['kernel'])
+ks_all = {x['Name']: x for x in csv.DictReader(open(f'{D}/kernel_stats_bench_steps3_warmup0.csv'))}
+if sq and dom['kernel'] in ks_all:
+    cyc = float(sq['SQ_BUSY_CYCLES_sum']) / 32 / int(sq['dispatches'])
+    out["held_clock_ghz"] = round(cyc / float(ks_all[dom['kernel']]['AverageNs']), 3)
+    out["mfma_busy_at_held_clock"] = round(float(sq['SQ_VALU_MFMA_BUSY_CYCLES_sum']) / (float(sq['SQ_BUSY_CYCLES_sum']) / 32 * 1024), 4)
+    out["clock_note"] = "SQ_BUSY_CYCLES / 32 shader engines / launches / rocprofv3 average duration; SQ_VALU_MFMA_BUSY_CYCLES / (those cycles x 1024 SIMDs)"
 json.dump(out, open(f'{D}/traffic_dominant_kernel.json', 'w'), indent=1)
 r = d['roofline']
 print('step  live HIP events :', r['kernel'], r['launches'], 'launches, avg', round(r['avg_launch_us'], 1), 'us,', round(r['achieved'], 1), 'TFLOP/s')
