@@ -20,6 +20,7 @@ MI355X-first differences in HOW (results are the reference's):
   * losses stay on the device; ``metrics()`` reads them back (one sync) instead of two ``.item()`` syncs + two pickle
     gathers per iteration (stage1_trainer.py:459,465).
 """
+import contextlib
 import ctypes as C
 import os
 from typing import Dict, List, Optional, Sequence
@@ -114,7 +115,10 @@ class Stage1Step:
         self.lr_steps, self.lr_gamma, self.warmup_factor, self.warmup_iters = tuple(lr_steps), lr_gamma, warmup_factor, warmup_iters
         self.first_level = first_level
         self.reuse_g = reuse_generator_forward
-        self.overlap_d = os.environ.get("AFI_D_OVERLAP", "0") != "0"
+        # D phase on two streams (forwards in order on the caller's, backwards in order on a second one), and in the G phase G's backward
+        # beside the two D forwards per level (the adversarial term carries no gradient): -2.7 % and -2 % of a step now that the big GEMMs
+        # are power-bound and leave room beside the bandwidth-bound passes (129.5 -> 126.4 -> 123.9 ms); AFI_D_OVERLAP=0 / AFI_G_OVERLAP=0
+        self.overlap_d = os.environ.get("AFI_D_OVERLAP", "1") != "0"
         self._bstream = None
         self.iter = 0
         self.pg = process_group
@@ -302,17 +306,28 @@ class Stage1Step:
                 if key == "adv":                                                     # :408, no gradient (Q1)
                     call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], 1.0, 1.0,
                          C.c_void_p(lptr + 4 * (3 * i + 1)), 0.0, C.c_void_p(None), ops.stream_ptr())
-            N, Cc, Ha, Wa = tr.shape
-            da = self._scratch("g_dout", tr.numel(), dev)
-            call("afi_l1_fwd_bwd", ops.view_of(tr), ops.view_of(hrs[i]), N, tr_c.shape[2], tr_c.shape[3], Cc, Ha, Wa, 1.0,
-                 C.c_void_p(lptr + 4 * (3 * i + 2)), 1.0, C.c_void_p(da.data_ptr()), ops.stream_ptr())      # :410
-            lrt = lrs[i]
-            n = self._lib.afi_generator_bwd_ws_floats(self.G.in_channels, self.G.growth_rate, self.G.n_residual_dense_blocks,
-                                                      lrt.shape[0], lrt.shape[2], lrt.shape[3])
-            sc = self._scratch("g_bwd", n, dev)
-            call("afi_generator_bwd", C.byref(self._gprm), C.byref(self._ggrad), ops.view_of(lrt), lrt.shape[0], lrt.shape[2], lrt.shape[3],
-                 C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n,
-                 ops.stream_ptr())                                                   # :427
+            # the adversarial term carries no gradient (Q1): G's backward needs only the L1 term, i.e. nothing the two D forwards above
+            # produce -- with the second stream it runs beside them (in level order; the losses land in their own slots)
+            side = self.overlap_d and self.reuse_g and os.environ.get("AFI_G_OVERLAP", "1") != "0"
+            if side:
+                if self._bstream is None:
+                    self._bstream = torch.cuda.Stream(device=dev)
+                if i == 0:
+                    self._bstream.wait_stream(torch.cuda.current_stream())           # behind the D phase and G's zero_grad
+            with (torch.cuda.stream(self._bstream) if side else contextlib.nullcontext()):
+                N, Cc, Ha, Wa = tr.shape
+                da = self._scratch("g_dout", tr.numel(), dev)
+                call("afi_l1_fwd_bwd", ops.view_of(tr), ops.view_of(hrs[i]), N, tr_c.shape[2], tr_c.shape[3], Cc, Ha, Wa, 1.0,
+                     C.c_void_p(lptr + 4 * (3 * i + 2)), 1.0, C.c_void_p(da.data_ptr()), ops.stream_ptr())      # :410
+                lrt = lrs[i]
+                n = self._lib.afi_generator_bwd_ws_floats(self.G.in_channels, self.G.growth_rate, self.G.n_residual_dense_blocks,
+                                                          lrt.shape[0], lrt.shape[2], lrt.shape[3])
+                sc = self._scratch("g_bwd", n, dev)
+                call("afi_generator_bwd", C.byref(self._gprm), C.byref(self._ggrad), ops.view_of(lrt), lrt.shape[0], lrt.shape[2], lrt.shape[3],
+                     C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n,
+                     ops.stream_ptr())                                               # :427
+        if self.overlap_d and self.reuse_g and self._bstream is not None:
+            torch.cuda.current_stream().wait_stream(self._bstream)
         call("afi_ctx_wino_wgrad_flush", self.ctx.handle, ops.stream_ptr())
         self._allreduce(self.g_opt)
         self.g_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :433

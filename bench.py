@@ -449,6 +449,24 @@ def main():
                           "flop_total": out3[2]})
     kinds.sort(key=lambda r: -r["ms_total"])
     dom = kinds[0]
+    # The timed steps run the D phase (and G's backward) on two streams, so the HIP-event duration of a launch above includes the time it
+    # shares the chip with the other stream's kernels.  The same kernel with the chip to itself: two extra steps with the overlaps off.
+    kernel_alone = None
+    if world == 1 and step.overlap_d and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":     # (the profiled runs of tools/prof_r02.sh switch the extra legs off)
+        step.overlap_d = False
+        one_step(); torch.cuda.synchronize()
+        lib.afi_profile_enable(1)
+        for _ in range(2):
+            one_step()
+        torch.cuda.synchronize()
+        lib.afi_profile_enable(0)
+        for k in range(lib.afi_profile_num_kinds()):
+            if lib.afi_profile_kind_name(k).decode() == dom["kernel"]:
+                o3 = (C.c_double * 3)()
+                _lib.check(lib.afi_profile_get(k, o3), "afi_profile_get")
+                if o3[0] > 0:
+                    kernel_alone = {"launches": int(o3[0]), "avg_launch_us": o3[1] / o3[0] * 1e3, "achieved": o3[2] / (o3[1] * 1e-3) / 1e12}
+        step.overlap_d = True
     # the opt-in bf16 arithmetic on the same engine, same inputs (N = 1 only; never the headline value): 1 warm-up + the same K steps each
     other_dtypes = None
     if world == 1 and args.dtype is None and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":
@@ -513,6 +531,11 @@ def main():
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": dom_peak, "unit": "TFLOP/s",
                 "frac": dom["tflops"] / dom_peak, "traffic": traffic, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
                 "share_of_step_time": dom["ms_total"] / (elapsed * 1e3),
+                # `achieved` above is over the timed region, where the D phase runs on two streams: a launch's duration includes the time it
+                # shares the chip with the other stream's kernels (sum of durations > wall time).  The kernel with the chip to itself:
+                "kernel_alone": (dict(kernel_alone, frac=kernel_alone["achieved"] / dom_peak,
+                                      note="two extra steps with AFI_D_OVERLAP / AFI_G_OVERLAP off, same HIP-event brackets; profiles/r02 holds both traces")
+                                 if kernel_alone else None),
                 # fp32-equivalent rate of the dominant kernel against the fp32 MFMA roof it replaces (> 1 is the point of the emulated forms)
                 "achieved_over_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
                 "peak_note": "fp32-equivalent TFLOP/s: 2*M*N*K once per product; peak = dense bf16 MFMA 2500 (quoted at 2.4 GHz) / bf16 MFMAs per product (6, 3 or 1), or the fp32 MFMA 157.3.  Under the bf16x6 GEMM the chip holds 1.63 GHz (power-limited; profiles/r02/pmc_sq_steps1.csv: SQ_BUSY_CYCLES), where its matrix pipe is 67 % busy: DESIGN.md 4b",

@@ -6,6 +6,9 @@ D=profiles/r02
 mkdir -p $D
 cp $(find $P/trace -name "*kernel_stats.csv" | head -1) $D/kernel_stats_bench_steps3_warmup0.csv
 grep '^{' $P/bench_trace.log > $D/bench_line_under_rocprof_steps3_warmup0.json
+cp $(find $P/trace_serial -name "*kernel_stats.csv" | head -1) $D/kernel_stats_bench_steps3_warmup0_one_stream.csv
+grep '^{' $P/bench_trace_serial.log > $D/bench_line_under_rocprof_steps3_warmup0_one_stream.json
+python profiles/summarize_pmc.py $(find $P/pmc_sq_serial -name "*counter_collection.csv" | head -1) > $D/pmc_sq_steps1_one_stream.csv
 cp $(find $P/trace_fp32 -name "*kernel_stats.csv" | head -1) $D/kernel_stats_bench_steps3_warmup0_dtype_fp32.csv
 grep '^{' $P/bench_trace_fp32.log > $D/bench_line_under_rocprof_steps3_warmup0_dtype_fp32.json
 grep '^{' $P/bench_default.log > $D/bench_line_default_run.json
@@ -32,13 +35,13 @@ out = {"kernel": dom['kernel'], "dispatches_in_pass": int(dom['dispatches']), "m
                "launches of the dominant kernel in that step"}
 # clock the chip holds under the dominant kernel and its matrix-pipe duty there (SQ pass of the same command): SQ_BUSY_CYCLES is summed over
 # the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
-sq = {x['kernel']: x for x in csv.DictReader(open(f'{D}/pmc_sq_steps1.csv'))}.get(dom['kernel'])
-ks_all = {x['Name']: x for x in csv.DictReader(open(f'{D}/kernel_stats_bench_steps3_warmup0.csv'))}
+sq = {x['kernel']: x for x in csv.DictReader(open(f'{D}/pmc_sq_steps1_one_stream.csv'))}.get(dom['kernel'])
+ks_all = {x['Name']: x for x in csv.DictReader(open(f'{D}/kernel_stats_bench_steps3_warmup0_one_stream.csv'))}
 if sq and dom['kernel'] in ks_all:
     cyc = float(sq['SQ_BUSY_CYCLES_sum']) / 32 / int(sq['dispatches'])
     out["held_clock_ghz"] = round(cyc / float(ks_all[dom['kernel']]['AverageNs']), 3)
     out["mfma_busy_at_held_clock"] = round(float(sq['SQ_VALU_MFMA_BUSY_CYCLES_sum']) / (float(sq['SQ_BUSY_CYCLES_sum']) / 32 * 1024), 4)
-    out["clock_note"] = "SQ_BUSY_CYCLES / 32 shader engines / launches / rocprofv3 average duration; SQ_VALU_MFMA_BUSY_CYCLES / (those cycles x 1024 SIMDs)"
+    out["clock_note"] = "one-stream passes (AFI_D_OVERLAP=0: the kernel alone on the chip): SQ_BUSY_CYCLES / 32 shader engines / launches / rocprofv3 average duration; SQ_VALU_MFMA_BUSY_CYCLES / (those cycles x 1024 SIMDs)"
 json.dump(out, open(f'{D}/traffic_dominant_kernel.json', 'w'), indent=1)
 r = d['roofline']
 print('step  live HIP events :', r['kernel'], r['launches'], 'launches, avg', round(r['avg_launch_us'], 1), 'us,', round(r['achieved'], 1), 'TFLOP/s')

@@ -13,6 +13,10 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o step -- $B --steps 1 --warmup 0 --no-interp --no-cpu-baseline > $O/bench_write.log 2>&1
 timeout -k 10 300 rocprofv3 --pmc $SQ --output-format csv -d $O/pmc_sq -o step -- $B --steps 1 --warmup 0 --no-interp --no-cpu-baseline > $O/bench_sq.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fp32 -o step -- $B --steps 3 --warmup 0 --no-interp --no-cpu-baseline --dtype fp32 > $O/bench_trace_fp32.log 2>&1
+export AFI_D_OVERLAP=0      # the dominant kernel with the chip to itself (the default step runs the D phase on two streams)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_serial -o step -- $B --steps 3 --warmup 0 --no-interp --no-cpu-baseline > $O/bench_trace_serial.log 2>&1
+timeout -k 10 300 rocprofv3 --pmc $SQ --output-format csv -d $O/pmc_sq_serial -o step -- $B --steps 1 --warmup 0 --no-interp --no-cpu-baseline > $O/bench_sq_serial.log 2>&1
+unset AFI_D_OVERLAP
 echo step pmc done
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg1_trace -o cfg1 -- $L 100 > $O/cfg1_trace.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cfg1_fetch -o cfg1 -- $L 20 > $O/cfg1_fetch.log 2>&1
