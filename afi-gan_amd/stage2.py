@@ -95,6 +95,7 @@ class Stage2Adversarial:
         self.iter = 0
         self.losses = None
         self._names = []
+        self._bstream = None
 
     def d_step(self, guide_feats: Sequence[torch.Tensor], fpn_feats: Sequence[torch.Tensor]):
         """stage2_trainer.py:306-342: BCE(D(real),1) + BCE(D(fake.detach()),0) over the levels, backward, D optimizer step."""
@@ -107,17 +108,29 @@ class Stage2Adversarial:
             self.losses, self._names = torch.zeros(len(names), device=dev), names
         self.losses.zero_()
         self.opt.zero_grad()
+        overlap = os.environ.get("AFI_D_OVERLAP", "1") != "0"          # forwards in order on the caller's stream, backwards on a second one (stage1.py)
         with _wino_weight_cache(h, dev):                   # D's weights are fixed until the optimizer step below
             for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
                 real = ops.pixel_major(nearest_half(ops.pixel_major(g.detach())))
                 fake = ops.pixel_major(f.detach())
                 hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
                 for x, target in ((real[:, :, :hh, :ww], 1.0), (fake[:, :, :hh, :ww], 0.0)):
-                    logits, dws = h._d_forward(x, "d_ws")
-                    dz = h._scratch("dlogits", logits.numel(), dev)
+                    key = f"d_ws_{i}_{int(target)}" if overlap else "d_ws"          # (overlap: a workspace lives until its backward has run)
+                    logits, dws = h._d_forward(x, key)
+                    dz = h._scratch("dlogits" + (key if overlap else ""), logits.numel(), dev)
                     call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * hh * ww, target, 1.0,
                          C.c_void_p(self.losses.data_ptr() + 4 * i), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
-                    h._d_backward(x, dws, dz)
+                    if overlap:
+                        if self._bstream is None:
+                            self._bstream = torch.cuda.Stream(device=dev)
+                        self._bstream.wait_stream(torch.cuda.current_stream())
+                        with torch.cuda.stream(self._bstream):
+                            x.record_stream(self._bstream)
+                            h._d_backward(x, dws, dz)
+                    else:
+                        h._d_backward(x, dws, dz)
+            if overlap and self._bstream is not None:
+                torch.cuda.current_stream().wait_stream(self._bstream)
         if self.distributed:
             allreduce_sum_(self.opt.flat_grad, self.pg)
         lr = warmup_multistep_lr(self.base_lr, self.iter, *self.sched)
