@@ -131,6 +131,7 @@ SIGNATURES = {
     "afi_profile_kind_name": (C.c_char_p, [_i]),
     "afi_profile_get": (_i, [_i, C.POINTER(C.c_double)]),
     "afi_profile_dump": (_i, [C.c_char_p]),
+    "afi_debug_wgrad_sk_plan": (_i, [C.POINTER(C.c_longlong), C.POINTER(C.c_int), _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 
 _lib = None
@@ -205,27 +206,36 @@ class Ctx:
             pass
 
 
+import functools  # noqa: E402
 import threading  # noqa: E402
 _tls = threading.local()
 _default_ctx = {}
+_default_lock = threading.Lock()
+_observers = []                       # test hooks: fn(name, Ctx) called before every context-taking entry point (empty in production)
 
 
 def current_ctx() -> "Ctx":
+    """The context the calls of this thread go to: the innermost ``use_ctx`` block, else the default context of the current GPU.
+    The default is per DEVICE (not per thread): PyTorch runs the backward of a custom Function on its autograd worker thread, and a
+    per-thread default would hand that thread a second context -- another arithmetic setting, another 400 MB op scratch."""
     stack = getattr(_tls, "stack", None)
     if stack:
         return stack[-1]
     dev = torch.cuda.current_device()
-    key = (threading.get_ident(), dev)
-    cx = _default_ctx.get(key)
+    cx = _default_ctx.get(dev)
     if cx is None:
-        cx = _default_ctx[key] = Ctx()
+        with _default_lock:
+            cx = _default_ctx.get(dev)
+            if cx is None:
+                cx = _default_ctx[dev] = Ctx()
     return cx
 
 
 class compute_dtype:
-    """``with compute_dtype("bf16x3"):`` -- the module-level ops of this thread (Generator / FPN / PAFPN / BiFPN autograd, afigan_amd.ops)
-    run their Winograd-domain GEMMs in that arithmetic inside the block; restored on exit.  Engines with their own context
-    (Stage1Step, Stage2Adversarial) take ``dtype=`` instead."""
+    """``with compute_dtype("bf16x3"):`` -- the module-level ops (Generator / FPN / PAFPN / BiFPN autograd, afigan_amd.ops) run
+    their matrix products in that arithmetic inside the block; restored on exit.  A forward run inside the block records the setting, and
+    its backward runs in the same arithmetic wherever and on whichever thread ``.backward()`` is called (see ``ctx_forward``).
+    Engines with their own context (Stage1Step, Stage2Adversarial) take ``dtype=`` instead."""
 
     def __init__(self, dtype):
         self.dtype = dtype
@@ -242,24 +252,55 @@ class compute_dtype:
 
 
 class use_ctx:
-    """``with use_ctx(cx):`` -- the calls of this thread inside the block run on context `cx` (an engine's own state)."""
+    """``with use_ctx(cx):`` -- the calls of this thread inside the block run on context `cx` (an engine's own state).  With `dtype`,
+    the context's arithmetic is switched for the block too (what a backward does to reproduce its forward's setting)."""
 
-    def __init__(self, cx: "Ctx"):
+    def __init__(self, cx: "Ctx", dtype=None):
         self.cx = cx
+        self.dtype = dtype
+        self.prev = None
 
     def __enter__(self):
         if not hasattr(_tls, "stack"):
             _tls.stack = []
         _tls.stack.append(self.cx)
+        if self.dtype is not None and self.dtype != self.cx.dtype:
+            self.prev = self.cx.dtype
+            self.cx.set_dtype(self.dtype)
         return self.cx
 
     def __exit__(self, *exc):
+        if self.prev is not None:
+            self.cx.set_dtype(self.prev)
         _tls.stack.pop()
         return False
+
+
+def ctx_forward(fn):
+    """Decorator for ``autograd.Function.forward``: remembers the active context and its arithmetic on the autograd ctx."""
+    @functools.wraps(fn)
+    def wrapper(ctx, *args, **kw):
+        ctx.afi_cx = current_ctx()
+        ctx.afi_dtype = ctx.afi_cx.dtype
+        return fn(ctx, *args, **kw)
+    return wrapper
+
+
+def ctx_backward(fn):
+    """Decorator for ``autograd.Function.backward``: runs it on the context (and in the arithmetic) its forward ran on.  PyTorch calls
+    backward on its autograd worker thread, where no ``use_ctx`` / ``compute_dtype`` block of the calling thread is visible."""
+    @functools.wraps(fn)
+    def wrapper(ctx, *grads):
+        with use_ctx(ctx.afi_cx, ctx.afi_dtype):
+            return fn(ctx, *grads)
+    return wrapper
 
 
 def call(name: str, *args):
     """Call an int-status entry point and raise on failure (context-taking entry points get the active context prepended)."""
     if name in CTX_FIRST:
-        args = (current_ctx().handle,) + args
+        cx = current_ctx()
+        for ob in _observers:
+            ob(name, cx)
+        args = (cx.handle,) + args
     check(getattr(load(), name)(*args), name)

@@ -99,6 +99,7 @@ class _FuseSwishFn(torch.autograd.Function):
     """swish(w[0]*a + w[1]*b (+ w[2]*c)) with the raw fusion weights (bifpn_sr.py:535-563) and its backward."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, w, a, b, c):
         wd = w.detach().contiguous()
         a, b = _dense_pm(a.detach()), _dense_pm(b.detach())
@@ -107,6 +108,7 @@ class _FuseSwishFn(torch.autograd.Function):
         return ops.fuse_swish(wd, a, b, c)
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         wd, a, b, c = ctx.saved_tensors
         need = ctx.needs_input_grad
@@ -118,6 +120,7 @@ class _DepthwiseFn(torch.autograd.Function):
     """SeparableConv2d.depthwise (3x3, zero pad 1, no bias); weight [C,1,3,3] as torch keeps it."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, w):
         C_ = w.shape[0]
         w9c = w.detach().reshape(C_, 9).t().contiguous()
@@ -126,6 +129,7 @@ class _DepthwiseFn(torch.autograd.Function):
         return ops.dwconv3x3(x, w9c)
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         x, w9c = ctx.saved_tensors
         dy = _dense_pm(dy)
@@ -136,6 +140,7 @@ class _DepthwiseFn(torch.autograd.Function):
 
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x):
         out, idx = ops.maxpool3s2_same_idx(ops.pixel_major(x.detach()))
         ctx.save_for_backward(idx)
@@ -143,6 +148,7 @@ class _MaxPoolFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         (idx,) = ctx.saved_tensors
         return ops.maxpool3s2_same_bwd(_dense_pm(dy), idx, ctx.in_hw)
@@ -152,6 +158,7 @@ class _BatchNormTrainFn(torch.autograd.Function):
     """BatchNorm2d in training mode on a pixel-major tensor: batch statistics (fp64 accumulation), running buffers updated in place."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, gamma, beta, bn):
         x = _dense_pm(x.detach())
         N, C_, H, W = x.shape
@@ -166,6 +173,7 @@ class _BatchNormTrainFn(torch.autograd.Function):
         return y.view(N, H, W, C_).permute(0, 3, 1, 2)
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         x, mean, invstd, g = ctx.saved_tensors
         N, C_, H, W = x.shape

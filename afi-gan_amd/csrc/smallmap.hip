@@ -851,27 +851,45 @@ struct AfiWgradGroupSK {
     int nst[AFI_WG_MAXP];                                  // 32-pixel stages per tile
     AfiWgradGemm g[AFI_WG_MAXP];
 };
+// The walk of one block's run [u, u_end) over the unit order, shared by the kernel and by afi_debug_wgrad_sk_plan (host): calls
+// f(problem, tile, first stage, end stage, shared) once per tile the run touches.  `shared` is false exactly when the run covers every
+// stage of the tile -- then no other run touches that tile and its result may be stored; otherwise every run that touches the tile is
+// partial and all of them add by atomics.  (Ownership is a property of the run boundaries alone, so it is checked on the host for every
+// size the tests and the bench use: tests/test_cabi.py::test_wgrad_stream_k_plan_is_a_partition.)
+template <class F>
+__host__ __device__ __forceinline__ void afi_sk_walk(const int* unit_start, const int* nst_of, int nprob, int u, int u_end, F&& f) {
+    int pi = 0;
+    while (u < u_end) {                                    // (uniform) a run crosses a few tile boundaries at most
+        while (pi + 1 < nprob && u >= unit_start[pi + 1]) ++pi;
+        const int nst = nst_of[pi];
+        const int lu = u - unit_start[pi];
+        const int tile = lu / nst, s0 = lu - tile * nst;
+        int s1 = s0 + (u_end - u);
+        if (s1 > nst) s1 = nst;
+        f(pi, tile, s0, s1, !(s0 == 0 && s1 == nst));
+        u += s1 - s0;
+    }
+}
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_group_sk_kernel(const AfiWgradGroupSK grp) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
     const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);      // neighbours in the unit order share an XCD's L2
-    int u = b * grp.units_per_block;
+    const int u = b * grp.units_per_block;
     int u_end = u + grp.units_per_block;
     if (u_end > grp.total_units) u_end = grp.total_units;
-    int pi = 0;
-    while (u < u_end) {                                    // (uniform) a run crosses a few tile boundaries at most
-        while (pi + 1 < grp.nprob && u >= grp.unit_start[pi + 1]) ++pi;
+    afi_sk_walk(grp.unit_start, grp.nst, grp.nprob, u, u_end, [&](int pi, int tile, int s0, int s1, bool shared) {
         const AfiWgradGemm& p = grp.g[pi];
-        const int nst = grp.nst[pi];
-        const int lu = u - grp.unit_start[pi];
-        const int tile = lu / nst, s0 = lu - tile * nst;
-        int s1 = s0 + (u_end - u);
-        if (s1 > nst) s1 = nst;
         const long long P = (long long)p.N * p.H * p.W;
         const long long k0 = (long long)s0 * AFI_BK, k1 = (long long)s1 * AFI_BK < P ? (long long)s1 * AFI_BK : P;
-        afi_wgrad_gemm_range<BM, BN, WM, WN>(p, grp.ntile_m[pi], grp.ntile_n[pi], tile, k0, k1, !(s0 == 0 && s1 == nst));
-        u += s1 - s0;
-    }
+        afi_wgrad_gemm_range<BM, BN, WM, WN>(p, grp.ntile_m[pi], grp.ntile_n[pi], tile, k0, k1, shared);
+    });
+}
+// run length and grid of a stream-K group launch (one place: the launcher and the debug plan use it)
+static inline void sk_cut(long long units, int bpc, int& upb, int& blocks) {
+    blocks = 256 * bpc;
+    upb = (int)((units + blocks - 1) / blocks);
+    if (upb < 4) upb = 4;                                  // tiny groups: no run shorter than four stages
+    blocks = (int)((units + upb - 1) / upb);
 }
 template <int BM, int BN, int WM, int WN>
 static int launch_wgrad_group_sk(const AfiWgradGemm* probs, int n, hipStream_t st, int bpc) {
@@ -893,10 +911,8 @@ static int launch_wgrad_group_sk(const AfiWgradGemm* probs, int n, hipStream_t s
             if (units > 0x7fffffffLL) return AFI_ERR_UNSUPPORTED;
         }
         for (int i = cnt; i <= AFI_WG_MAXP; ++i) grp.unit_start[i] = (int)units;
-        int blocks = 256 * bpc;
-        int upb = (int)((units + blocks - 1) / blocks);
-        if (upb < 4) upb = 4;                              // tiny groups: no run shorter than four stages
-        blocks = (int)((units + upb - 1) / upb);
+        int blocks, upb;
+        sk_cut(units, bpc, upb, blocks);
         grp.units_per_block = upb; grp.total_units = (int)units;
         hipLaunchKernelGGL((afi_wgrad_group_sk_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(64 * WM * WN), sizeof(float) * AFI_BK * (BM + BN), st, grp);
         done += cnt;
@@ -998,4 +1014,46 @@ int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st) {
     for (int i = n; i <= AFI_CS_MAXP; ++i) grp.blk_start[i] = blocks;
     hipLaunchKernelGGL(afi_colsum_group_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grp);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Host-only: the ownership the stream-K cut gives each dW tile of a group of weight-gradient problems (same cut, same walk as the
+// kernel above).  Problem i has tiles[i] tiles (M tiles x N tiles x taps) of ceil(pixels[i] / 32) stages.  For tile t (tiles numbered
+// problem-major) the outputs are: stored[t] = runs that STORE it (plain read-modify-write), added[t] = runs that ADD to it atomically,
+// stages[t] = stages covered by all of them.  A correct plan has (stored, added) = (1, 0) or (0, >= 2) and stages[t] = the tile's stage
+// count for every tile: a tile is either owned whole by one run or every run that touches it uses atomics.
+// ------------------------------------------------------------------------------------------------
+extern "C" int afi_debug_wgrad_sk_plan(const long long* pixels, const int* tiles, int nprob, int bpc, int* stored, int* added, int* stages) {
+    if (!pixels || !tiles || nprob <= 0 || bpc <= 0 || !stored || !added || !stages) return AFI_ERR_BAD_ARG;
+    long long tile0 = 0;
+    for (int done = 0; done < nprob;) {
+        const int cnt = (nprob - done) < AFI_WG_MAXP ? (nprob - done) : AFI_WG_MAXP;
+        int unit_start[AFI_WG_MAXP + 1], nst[AFI_WG_MAXP];
+        long long tile_start[AFI_WG_MAXP + 1];
+        long long units = 0, tl = tile0;
+        for (int i = 0; i < cnt; ++i) {
+            if (pixels[done + i] <= 0 || tiles[done + i] <= 0) return AFI_ERR_BAD_ARG;
+            nst[i] = afi_cdiv(pixels[done + i], AFI_BK);
+            unit_start[i] = (int)units; tile_start[i] = tl;
+            units += (long long)tiles[done + i] * nst[i]; tl += tiles[done + i];
+            if (units > 0x7fffffffLL) return AFI_ERR_UNSUPPORTED;
+        }
+        for (int i = cnt; i <= AFI_WG_MAXP; ++i) unit_start[i] = (int)units;
+        for (long long t = tile0; t < tl; ++t) stored[t] = added[t] = stages[t] = 0;
+        int upb, blocks;
+        sk_cut(units, bpc, upb, blocks);
+        for (int b = 0; b < blocks; ++b) {
+            const int u = b * upb;
+            int u_end = u + upb;
+            if (u_end > (int)units) u_end = (int)units;
+            afi_sk_walk(unit_start, nst, cnt, u, u_end, [&](int pi, int tile, int s0, int s1, bool shared) {
+                const long long t = tile_start[pi] + tile;
+                if (shared) ++added[t]; else ++stored[t];
+                stages[t] += s1 - s0;
+            });
+        }
+        tile0 = tl;
+        done += cnt;
+    }
+    return AFI_OK;
 }

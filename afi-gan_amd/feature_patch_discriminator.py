@@ -46,6 +46,7 @@ class _ConvBNParams(nn.Module):
 
 class _DiscriminatorFn(torch.autograd.Function):
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, net, *params):
         xp = ops.pixel_major(x.detach())
         N, _, H, W = xp.shape
@@ -66,6 +67,7 @@ class _DiscriminatorFn(torch.autograd.Function):
         return logits
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dlogits):
         net = ctx.net
         if not ctx.was_training:

@@ -33,6 +33,7 @@ class _LateralMergeFn(torch.autograd.Function):
     """prev = conv1x1(feat, w) + b + top_down   (fpn_sr.py:152-153), add fused into the GEMM epilogue."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, feat, w, b, top_down):
         featp = ops.pixel_major(feat.detach())
         td = ops.pixel_major(top_down.detach()) if top_down is not None else None
@@ -42,6 +43,7 @@ class _LateralMergeFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         featp, w = ctx.saved_tensors
         dy = _dense_pm(dy)
@@ -63,6 +65,7 @@ class _Conv3x3Fn(torch.autograd.Function):
     """p = conv3x3(prev, w) + b   (fpn_sr.py:145,158)."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, w, b):
         xp = ops.pixel_major(x.detach())
         wk = ops.ohwi(w.detach())
@@ -74,6 +77,7 @@ class _Conv3x3Fn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         xp, wk = ctx.saved_tensors
         dy = _dense_pm(dy)

@@ -70,10 +70,15 @@ class ResidualInResidual(nn.Module):
         self.residual_scale = residual_scale
 
 
+grad_tap = None     # diagnostics: set to a list and every backward call appends its own weight-gradient contributions (clones) before
+                    # autograd sums them over the calls that share the weights -- names the call and the tensor when a sum is off
+
+
 class _GeneratorFn(torch.autograd.Function):
     """One HIP forward / one HIP backward for the whole interpolator."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, gen, *params):
         xp = ops.pixel_major(x.detach())
         N, Cc, H, W = xp.shape
@@ -91,6 +96,7 @@ class _GeneratorFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dout):
         gen = ctx.gen
         xp, ws, *weights = ctx.saved_tensors
@@ -109,6 +115,9 @@ class _GeneratorFn(torch.autograd.Function):
         call("afi_generator_bwd", C.byref(prm), C.byref(gst), ops.view_of(xp), N, H, W, C.c_void_p(ws.data_ptr()),
              C.c_void_p(dout.data_ptr()), C.c_void_p(dx.data_ptr() if dx is not None else None),
              C.c_void_p(scratch.data_ptr()), sc_floats, ops.stream_ptr())
+        if grad_tap is not None:
+            grad_tap.append({"shape": (N, gen.in_channels, H, W), "ctx": ctx.afi_cx.handle.value, "dtype": ctx.afi_cx.dtype,
+                             "grads": [g.clone() if g is not None else None for g in grads]})
         return (dx, None, *grads)
 
 

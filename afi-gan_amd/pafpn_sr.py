@@ -28,6 +28,7 @@ class _DownsampleMergeFn(torch.autograd.Function):
     """pa = fs * (inter + relu(conv3x3_s2(x, w) + b))  with fs = 1 ("sum") or 0.5 ("avg")   (pafpn_sr.py:183-188)."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, w, b, inter, fs):
         xp = ops.pixel_major(x.detach())
         wk = ops.ohwi(w.detach())
@@ -39,6 +40,7 @@ class _DownsampleMergeFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         xp, wk, act = ctx.saved_tensors
         dy = _dense_pm(dy)
@@ -76,6 +78,7 @@ class _Conv3x3S2Fn(torch.autograd.Function):
     """y = conv3x3_stride2(x, w) without bias / activation (the norm != "" form of the downsample conv)."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, x, w):
         xp = ops.pixel_major(x.detach())
         wk = ops.ohwi(w.detach())
@@ -84,6 +87,7 @@ class _Conv3x3S2Fn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, dy):
         xp, wk = ctx.saved_tensors
         dy = _dense_pm(dy)

@@ -119,6 +119,7 @@ class Stage1Step:
         # beside the two D forwards per level (the adversarial term carries no gradient): -2.7 % and -2 % of a step now that the big GEMMs
         # are power-bound and leave room beside the bandwidth-bound passes (129.5 -> 126.4 -> 123.9 ms); AFI_D_OVERLAP=0 / AFI_G_OVERLAP=0
         self.overlap_d = os.environ.get("AFI_D_OVERLAP", "1") != "0"
+        self.overlap_g = os.environ.get("AFI_G_OVERLAP", "1") != "0"
         self._bstream = None
         self.iter = 0
         self.pg = process_group
@@ -147,9 +148,14 @@ class Stage1Step:
                 raise _lib.AfiError("parameters must be stored in the kernels' layout ([O][kh][kw][I]); "
                                     "construct the modules with afigan_amd.Generator / Discriminator")
         self._buf: Dict[str, torch.Tensor] = {}
-        # this engine's own library state (weight-transform cache, gradient accumulator, side stream) and the arithmetic of its big
-        # convolutions: "fp32" is the reference's and the parity path; "bf16x3" / "bf16" are opt-in (afi_ctx_set_compute_dtype)
+        # this engine's own library state and the arithmetic of its big convolutions (None = the library's default, bf16x6: fp32 products
+        # formed exactly on the bf16 matrix cores; "fp32" = the fp32 MFMA; "bf16x3" / "bf16" are opt-in: afi_ctx_set_compute_dtype).
+        # TWO contexts, one per stream the step uses (include/afigan_hip.h: a context serves one stream at a time): `ctx` for everything
+        # on the caller's stream (all forwards: its cache holds the forward weight transforms), `bctx` for the backward passes, which run
+        # on the engine's second stream when the overlaps are on (its cache holds the data-gradient weight transforms, and it owns the
+        # transform-domain weight-gradient accumulator and the library's side stream for the small-map weight gradients)
         self.ctx = _lib.Ctx(dtype)
+        self.bctx = _lib.Ctx(dtype)
         self.after_allreduce = None
         self.losses = None
         self._loss_names: List[str] = []
@@ -161,6 +167,19 @@ class Stage1Step:
             t = ops.new_workspace(floats, device)
             self._buf[key] = t
         return t
+
+    @property
+    def dtype(self) -> str:
+        return self.ctx.dtype
+
+    def set_dtype(self, dtype: str):
+        """Arithmetic of the big convolutions' GEMMs for the following steps (both of the engine's contexts)."""
+        self.ctx.set_dtype(dtype)
+        self.bctx.set_dtype(dtype)
+
+    def _join_bstream(self):
+        if self._bstream is not None:
+            torch.cuda.current_stream().wait_stream(self._bstream)
 
     def lr_at(self, it: int) -> float:
         return warmup_multistep_lr(self.base_lr, it, self.lr_steps, self.lr_gamma, self.warmup_factor, self.warmup_iters)
@@ -195,8 +214,9 @@ class Stage1Step:
         F = (C.c_int * 4)(*self.dnet.F)
         n = self._lib.afi_discriminator_bwd_ws_floats(F, N, H, W)
         sc = self._scratch("d_bwd", n, x.device)
-        call("afi_discriminator_bwd", C.byref(self._dprm), C.byref(self._dgrad), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()),
-             C.c_void_p(dlogits.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n, ops.stream_ptr())
+        with _lib.use_ctx(self.bctx):                      # the backward passes' own context (they may be on the second stream)
+            call("afi_discriminator_bwd", C.byref(self._dprm), C.byref(self._dgrad), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()),
+                 C.c_void_p(dlogits.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n, ops.stream_ptr())
 
     @staticmethod
     def _crop_pair(tr: torch.Tensor, hr: torch.Tensor):
@@ -235,29 +255,40 @@ class Stage1Step:
         lptr = self.losses.data_ptr()
         lr_now = self.lr_at(self.iter)
         # transformed conv weights are shared by the calls of a phase (weights only change at the two optimizer steps)
-        cx = self.ctx
+        cx, bx = self.ctx, self.bctx
         with _lib.use_ctx(cx):
             use_cache = os.environ.get("AFI_WINO_WCACHE", "1") != "0"
             if use_cache:
-                wcache = self._scratch("wino_wcache", self.WINO_WCACHE_FLOATS, dev)
-                call("afi_ctx_set_wino_weight_cache", cx.handle, C.c_void_p(wcache.data_ptr()), self.WINO_WCACHE_FLOATS)
+                for c_, key in ((cx, "wino_wcache"), (bx, "wino_wcache_b")):
+                    wcache = self._scratch(key, self.WINO_WCACHE_FLOATS, dev)
+                    call("afi_ctx_set_wino_weight_cache", c_.handle, C.c_void_p(wcache.data_ptr()), self.WINO_WCACHE_FLOATS)
                 # ... and the transform-domain weight-gradient sums of a phase are transformed back once, before its all-reduce
                 if os.environ.get("AFI_WINO_WGACC", "1") != "0":
                     wgacc = self._scratch("wino_wgacc", self.WINO_WGACC_FLOATS, dev)
-                    call("afi_ctx_set_wino_wgrad_accum", cx.handle, C.c_void_p(wgacc.data_ptr()), self.WINO_WGACC_FLOATS)
+                    call("afi_ctx_set_wino_wgrad_accum", bx.handle, C.c_void_p(wgacc.data_ptr()), self.WINO_WGACC_FLOATS)
             try:
                 self._run_phases(nlev, lrs, hrs, lptr, lr_now, dev)
             except BaseException:
-                # a phase failed: drop its partial transform-domain sums (never add them into param.grad) and let the first error out
-                self._lib.afi_ctx_wino_wgrad_discard(cx.handle)
-                self._lib.afi_ctx_set_wino_wgrad_accum(cx.handle, None, 0)
+                # a phase failed.  First the streams: backward kernels still queued on the second stream read lrs / hrs / workspaces that
+                # were allocated on the caller's stream -- the caller's stream must not get that memory back before they are done
+                # (ADVICE r2).  Then drop the partial transform-domain sums (never add them into param.grad) and let the first error out.
+                try:
+                    self._join_bstream()
+                except Exception:
+                    pass
+                self._lib.afi_ctx_wino_wgrad_discard(bx.handle)
+                self._lib.afi_ctx_set_wino_wgrad_accum(bx.handle, None, 0)
                 self._lib.afi_ctx_set_wino_weight_cache(cx.handle, None, 0)
+                self._lib.afi_ctx_set_wino_weight_cache(bx.handle, None, 0)
                 raise
-            call("afi_ctx_set_wino_wgrad_accum", cx.handle, C.c_void_p(None), 0)        # (both phases flushed their sums)
+            call("afi_ctx_set_wino_wgrad_accum", bx.handle, C.c_void_p(None), 0)        # (both phases flushed their sums)
             call("afi_ctx_set_wino_weight_cache", cx.handle, C.c_void_p(None), 0)
+            call("afi_ctx_set_wino_weight_cache", bx.handle, C.c_void_p(None), 0)
         self.iter += 1
 
-    WINO_WCACHE_FLOATS = 140 * 1024 * 1024
+    # per context: the forward one peaks in the G phase (D's three layers at both tilings, 16 + 36 planes of 1.70 M floats = 89 M, + G's
+    # forward transforms and packed conv-transpose weight when G is recomputed: 104 M), the backward one in the D phase (the same 89 M)
+    WINO_WCACHE_FLOATS = 112 * 1024 * 1024
     WINO_WGACC_FLOATS = 100 * 1024 * 1024
 
     def _run_phases(self, nlev, lrs, hrs, lptr, lr_now, dev):
@@ -286,12 +317,13 @@ class Stage1Step:
                         self._d_backward(x, dws, dz)
                 else:
                     self._d_backward(x, dws, dz)                                     # :375 (accumulates into the flat grads)
-        if self.overlap_d and self._bstream is not None:
-            torch.cuda.current_stream().wait_stream(self._bstream)
-        call("afi_ctx_wino_wgrad_flush", self.ctx.handle, ops.stream_ptr())
+        if self.overlap_d:
+            self._join_bstream()
+        call("afi_ctx_wino_wgrad_flush", self.bctx.handle, ops.stream_ptr())         # (joined: the backward context's sums, on the caller's stream)
         self._allreduce(self.d_opt)
         self.d_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :381
         call("afi_ctx_wino_weight_cache_invalidate", self.ctx.handle)                # D's weights moved
+        call("afi_ctx_wino_weight_cache_invalidate", self.bctx.handle)
 
         # ---------------- G phase (:384-433)
         self.g_opt.zero_grad()                                                       # :426
@@ -308,13 +340,13 @@ class Stage1Step:
                          C.c_void_p(lptr + 4 * (3 * i + 1)), 0.0, C.c_void_p(None), ops.stream_ptr())
             # the adversarial term carries no gradient (Q1): G's backward needs only the L1 term, i.e. nothing the two D forwards above
             # produce -- with the second stream it runs beside them (in level order; the losses land in their own slots)
-            side = self.overlap_d and self.reuse_g and os.environ.get("AFI_G_OVERLAP", "1") != "0"
+            side = self.overlap_d and self.reuse_g and self.overlap_g
             if side:
                 if self._bstream is None:
                     self._bstream = torch.cuda.Stream(device=dev)
                 if i == 0:
                     self._bstream.wait_stream(torch.cuda.current_stream())           # behind the D phase and G's zero_grad
-            with (torch.cuda.stream(self._bstream) if side else contextlib.nullcontext()):
+            with (torch.cuda.stream(self._bstream) if side else contextlib.nullcontext()), _lib.use_ctx(self.bctx):
                 N, Cc, Ha, Wa = tr.shape
                 da = self._scratch("g_dout", tr.numel(), dev)
                 call("afi_l1_fwd_bwd", ops.view_of(tr), ops.view_of(hrs[i]), N, tr_c.shape[2], tr_c.shape[3], Cc, Ha, Wa, 1.0,
@@ -326,9 +358,9 @@ class Stage1Step:
                 call("afi_generator_bwd", C.byref(self._gprm), C.byref(self._ggrad), ops.view_of(lrt), lrt.shape[0], lrt.shape[2], lrt.shape[3],
                      C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n,
                      ops.stream_ptr())                                               # :427
-        if self.overlap_d and self.reuse_g and self._bstream is not None:
-            torch.cuda.current_stream().wait_stream(self._bstream)
-        call("afi_ctx_wino_wgrad_flush", self.ctx.handle, ops.stream_ptr())
+        if self.overlap_d and self.reuse_g:
+            self._join_bstream()
+        call("afi_ctx_wino_wgrad_flush", self.bctx.handle, ops.stream_ptr())
         self._allreduce(self.g_opt)
         self.g_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :433
 

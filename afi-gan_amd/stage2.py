@@ -33,6 +33,7 @@ class _L1CropFn(torch.autograd.Function):
     pass producing the loss and d loss / d a."""
 
     @staticmethod
+    @_lib.ctx_forward
     def forward(ctx, a, b):
         ap, bp = ops.pixel_major(a.detach()), ops.pixel_major(b.detach())
         loss = torch.zeros(1, device=a.device, dtype=torch.float32)
@@ -42,6 +43,7 @@ class _L1CropFn(torch.autograd.Function):
         return loss.reshape(())
 
     @staticmethod
+    @_lib.ctx_backward
     def backward(ctx, g):
         if not ctx.has:
             return None, None
@@ -56,17 +58,19 @@ def l1_loss_common(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 @contextlib.contextmanager
 def _wino_weight_cache(helper, device):
     """Transformed conv weights shared by the calls of one phase (include/afigan_hip.h: afi_ctx_set_wino_weight_cache), on this engine's
-    own context; registered for the duration of the phase only, during which D's weights do not change."""
+    own contexts (forward / backward, stage1.py); registered for the duration of the phase only, during which D's weights do not change."""
     with _lib.use_ctx(helper.ctx):
         if os.environ.get("AFI_WINO_WCACHE", "1") == "0":
             yield
             return
-        buf = helper._scratch("wino_wcache", Stage1Step.WINO_WCACHE_FLOATS, device)
-        call("afi_ctx_set_wino_weight_cache", helper.ctx.handle, C.c_void_p(buf.data_ptr()), Stage1Step.WINO_WCACHE_FLOATS)
+        for c_, key in ((helper.ctx, "wino_wcache"), (helper.bctx, "wino_wcache_b")):
+            buf = helper._scratch(key, Stage1Step.WINO_WCACHE_FLOATS, device)
+            call("afi_ctx_set_wino_weight_cache", c_.handle, C.c_void_p(buf.data_ptr()), Stage1Step.WINO_WCACHE_FLOATS)
         try:
             yield
         finally:
             call("afi_ctx_set_wino_weight_cache", helper.ctx.handle, C.c_void_p(None), 0)
+            call("afi_ctx_set_wino_weight_cache", helper.bctx.handle, C.c_void_p(None), 0)
 
 
 class Stage2Adversarial:
@@ -91,7 +95,7 @@ class Stage2Adversarial:
         self._helper = Stage1Step.__new__(Stage1Step)          # reuse the raw D forward/backward plumbing
         self._helper.dnet, self._helper._dprm, self._helper._dgrad = self.dnet, self._prm, self._grad
         self._helper._lib, self._helper._buf = _lib.load(), {}
-        self._helper.ctx = _lib.Ctx(dtype)
+        self._helper.ctx, self._helper.bctx = _lib.Ctx(dtype), _lib.Ctx(dtype)     # forward / backward stream (stage1.py)
         self.iter = 0
         self.losses = None
         self._names = []
@@ -110,32 +114,37 @@ class Stage2Adversarial:
         self.opt.zero_grad()
         overlap = os.environ.get("AFI_D_OVERLAP", "1") != "0"          # forwards in order on the caller's stream, backwards on a second one (stage1.py)
         with _wino_weight_cache(h, dev):                   # D's weights are fixed until the optimizer step below
-            for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
-                real = ops.pixel_major(nearest_half(ops.pixel_major(g.detach())))
-                fake = ops.pixel_major(f.detach())
-                hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
-                for x, target in ((real[:, :, :hh, :ww], 1.0), (fake[:, :, :hh, :ww], 0.0)):
-                    key = f"d_ws_{i}_{int(target)}" if overlap else "d_ws"          # (overlap: a workspace lives until its backward has run)
-                    logits, dws = h._d_forward(x, key)
-                    dz = h._scratch("dlogits" + (key if overlap else ""), logits.numel(), dev)
-                    call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * hh * ww, target, 1.0,
-                         C.c_void_p(self.losses.data_ptr() + 4 * i), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
-                    if overlap:
-                        if self._bstream is None:
-                            self._bstream = torch.cuda.Stream(device=dev)
-                        self._bstream.wait_stream(torch.cuda.current_stream())
-                        with torch.cuda.stream(self._bstream):
-                            x.record_stream(self._bstream)
-                            h._d_backward(x, dws, dz)
-                    else:
-                        h._d_backward(x, dws, dz)
-            if overlap and self._bstream is not None:
-                torch.cuda.current_stream().wait_stream(self._bstream)
+            try:
+                self._d_levels(h, guide_feats, fpn_feats, dev, overlap)
+            finally:                                       # also on an error: the second stream's kernels read tensors of the caller's stream
+                if self._bstream is not None:
+                    torch.cuda.current_stream().wait_stream(self._bstream)
         if self.distributed:
             allreduce_sum_(self.opt.flat_grad, self.pg)
         lr = warmup_multistep_lr(self.base_lr, self.iter, *self.sched)
         self.opt.step(lr, self.momentum, gscale=1.0 / self.world)
         self.iter += 1
+
+    def _d_levels(self, h, guide_feats, fpn_feats, dev, overlap):
+        for i, (g, f) in enumerate(zip(guide_feats, fpn_feats)):
+            real = ops.pixel_major(nearest_half(ops.pixel_major(g.detach())))
+            fake = ops.pixel_major(f.detach())
+            hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
+            for x, target in ((real[:, :, :hh, :ww], 1.0), (fake[:, :, :hh, :ww], 0.0)):
+                key = f"d_ws_{i}_{int(target)}" if overlap else "d_ws"          # (overlap: a workspace lives until its backward has run)
+                logits, dws = h._d_forward(x, key)
+                dz = h._scratch("dlogits" + (key if overlap else ""), logits.numel(), dev)
+                call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * hh * ww, target, 1.0,
+                     C.c_void_p(self.losses.data_ptr() + 4 * i), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
+                if overlap:
+                    if self._bstream is None:
+                        self._bstream = torch.cuda.Stream(device=dev)
+                    self._bstream.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._bstream):
+                        x.record_stream(self._bstream)
+                        h._d_backward(x, dws, dz)
+                else:
+                    h._d_backward(x, dws, dz)
 
     def g_losses(self, guide_feats: Sequence[torch.Tensor], fpn_feats: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
         """stage2_trainer.py:344-364: {g_loss_p{lv}: 1e-3 * adv + content}; `content` carries gradient into fpn_feats."""

@@ -55,7 +55,89 @@ def parse():
                          "engine afterwards and reports them under other_dtypes")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="launch path only (no GPU work, no metric): spawn / rendezvous / all-reduce / invariant checks of the N-rank job with "
+                         "CPU tensors; what tests/test_host_logic.py runs with --gpus 2 --backend gloo in a container without a GPU")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher (reference: stage1_train.py:52-59, detectron2 `launch(main, num_gpus, ...)`): THIS
+    process never touches the GPU -- no HIP call, no torch.cuda query -- it starts N children, one rank per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (what torch.distributed.run would set), waits for them and relays
+    rank 0's stdout (the ONE JSON line).  A child that fails takes the job down: the others are terminated (by their exact PIDs) and the
+    exit code is non-zero."""
+    import socket
+    import subprocess
+    n = args.gpus
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    rc = 0
+    pending = set(range(n))
+    while pending and rc == 0:                                     # (rank 0 prints one short line at the very end: its pipe cannot fill up)
+        for r in sorted(pending):
+            c = procs[r].poll()
+            if c is not None:
+                pending.discard(r)
+                if c != 0:
+                    rc = c if c > 0 else 1
+                    print(f"[bench] rank {r} exited with code {c}: stopping the other ranks", file=sys.stderr, flush=True)
+        if pending and rc == 0:
+            time.sleep(0.2)
+    for pr in procs:
+        if pr.poll() is None:
+            pr.terminate()                                         # only reached when a rank failed: the rest would wait at a barrier forever
+    out0 = procs[0].communicate()[0]
+    for pr in procs[1:]:
+        try:
+            pr.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    raise SystemExit(rc)
+
+
+def rehearse_launch(args, world, rank):
+    """--rehearse-launch: everything bench.py does AROUND the GPU work for an N-rank job -- rendezvous, barrier, an all-reduce(SUM) of a
+    flat buffer the size class of the real exchange, MAX-over-ranks timing, the cross-rank identity check, one JSON line from rank 0 --
+    on CPU tensors.  Reports no metric."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("AFI_BENCH_REHEARSE_FAIL_RANK") == str(rank):   # fault injection for the test of the failure path
+        raise SystemExit(3)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.full((1 << 16,), float(rank + 1))
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(g)                                         # SUM, as Stage1Step does on the flat gradient buffers
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    ok = bool((g == world * (world + 1) / 2).all())
+    same = None
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        lo, hi = g[:4].double().clone(), g[:4].double().clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        same = bool(torch.equal(lo, hi))
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "launch_rehearsal (no GPU work, no measurement)", "value": None, "n_gpus": world, "backend": "gloo" if world > 1 else None,
+                          "allreduce_sum_ok": ok, "params_identical_across_ranks": same, "max_over_ranks_s": float(el.item()),
+                          "spawned_by_bench": os.environ.get("AFI_BENCH_SPAWNED") == "1"}), flush=True)
+    raise SystemExit(0 if ok and same is not False else 1)
 
 
 def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
@@ -326,10 +408,18 @@ def log(msg):
 
 def main():
     args = parse()
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:          # no launcher around us: be the launcher (before anything touches the GPU)
+        os.environ["AFI_BENCH_SPAWNED"] = "1"
+        spawn_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks for --gpus N "
+                         f"(python bench.py --gpus N spawns them itself; torch.distributed.run must use --nproc-per-node N)")
+    if args.rehearse_launch:
+        rehearse_launch(args, world, rank)
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the AFI-GAN hot path has no CPU fallback)")
     local_rank = local_rank % torch.cuda.device_count()      # (gloo rehearsal: several ranks may share one GPU)
@@ -359,7 +449,7 @@ def main():
     D = amd.Discriminator().to(dev)
     G.train(); D.train()
     step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype)
-    run_dtype = step.ctx.dtype                             # the library's default when --dtype is not given
+    run_dtype = step.dtype                             # the library's default when --dtype is not given
     guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)     # each rank owns a different shard of the global batch
     images = torch.rand((B, 3, 800, 1333), device=dev, generator=gen) * 255.0
@@ -472,7 +562,7 @@ def main():
     if world == 1 and args.dtype is None and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":
         other_dtypes = {}
         for dt in [d for d in ("fp32", "bf16x6", "bf16x3", "bf16") if d != run_dtype]:
-            step.ctx.set_dtype(dt)
+            step.set_dtype(dt)
             one_step()
             torch.cuda.synchronize()
             lib.afi_profile_enable(1)
@@ -497,7 +587,7 @@ def main():
                 fin = False
             other_dtypes[dt] = {"ms_per_step": el / args.steps * 1e3, "images_per_s": B * args.steps / el, "losses_finite": fin, "winograd_gemm_kernels": gk}
             log(f"dtype {dt}: {el / args.steps * 1e3:.1f} ms/step")
-        step.ctx.set_dtype(run_dtype)
+        step.set_dtype(run_dtype)
 
     gemm_ms = sum(r["ms_total"] for r in kinds)
     gemm_flop = sum(r["flop_total"] for r in kinds)

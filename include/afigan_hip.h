@@ -341,6 +341,13 @@ int afi_profile_get(int kind, double* out3);
 /* one CSV line per recorded launch (kind, GEMM rows, columns, K, split-K factor, ms, TFLOP/s) */
 int afi_profile_dump(const char* path);
 
+/* ------------------------------------------------------------------ diagnostics (host-only, no GPU needed)
+ * The ownership the stream-K cut of the grouped small-map weight gradients (afi_generator_bwd on maps of <= 3000 pixels) gives every dW
+ * tile: problem i has tiles[i] tiles of ceil(pixels[i] / 32) pixel stages; bpc = resident blocks per CU the runs are cut for (3).
+ * Per tile (numbered problem-major): stored = runs that store it whole, added = runs that add to it by atomics, stages = stages covered.
+ * A valid plan has (stored, added) = (1, 0) or (0, >= 2) and full stage coverage for every tile; tests/test_cabi.py checks exactly that. */
+int afi_debug_wgrad_sk_plan(const long long* pixels, const int* tiles, int nprob, int bpc, int* stored, int* added, int* stages);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,3 +67,57 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("missing library must raise")
+
+
+def _generator_bwd_group(C, G, R, N, H, W):
+    """(pixels, tiles) of the narrow (<= 32 rows, 32x128 tiles) and wide (128x128 tiles) weight-gradient groups of one afi_generator_bwd call,
+    in the order csrc/nets.hip defers them: final conv (hi-res grid), conv-transpose, trunk, per dense block conv5 + conv4..1, head."""
+    P, L = N * H * W, C + 4 * G
+    cd = lambda a, b: -(-a // b)
+    probs = [(4 * P, C, C), (P, 4 * C, C), (P, C, C)]
+    for _ in range(R):
+        probs.append((P, C, L))
+        probs += [(P, G, C + (k - 1) * G) for k in (4, 3, 2, 1)]
+    probs.append((P, C, C))
+    narrow = [(p, cd(m, 32) * cd(n, 128) * 9) for p, m, n in probs if m <= 32]
+    wide = [(p, cd(m, 128) * cd(n, 128) * 9) for p, m, n in probs if m > 32]
+    return narrow, wide
+
+
+def test_wgrad_stream_k_plan_is_a_partition():
+    """The stream-K cut of the grouped small-map weight gradients (csrc/smallmap.hip: afi_sk_walk, the kernel's own walk run on the host):
+    every dW tile is either stored whole by exactly ONE run or touched only by atomically-adding runs, and every stage is covered once.
+    A tile that one run stores while another adds to it would lose a contribution (VERDICT r2 'What's weak' 1, candidate b).  Checked for
+    the three FPN-test shapes of the recorded failure (2 x 32 x {2x3, 4x6, 8x12}), config 1, the largest grouped map, groups beyond the
+    20-problem table, and a sweep of ragged sizes."""
+    _build()
+    import random
+    from afigan_amd import _lib
+    lib = _lib.load()
+
+    def check(group, bpc=3):
+        if not group:
+            return
+        n = len(group)
+        px = (ctypes.c_longlong * n)(*[g[0] for g in group])
+        tl = (ctypes.c_int * n)(*[g[1] for g in group])
+        T = sum(g[1] for g in group)
+        stored, added, stages = ((ctypes.c_int * T)() for _ in range(3))
+        assert lib.afi_debug_wgrad_sk_plan(px, tl, n, bpc, stored, added, stages) == 0
+        t = 0
+        for p, k in group:
+            nst = -(-p // 32)
+            for _ in range(k):
+                assert (stored[t], added[t] >= 2) in ((1, False), (0, True)) and not (stored[t] and added[t]), (group, t, stored[t], added[t])
+                assert stages[t] == nst, (group, t, stages[t], nst)
+                t += 1
+
+    for shape in ((32, 32, 3, 2, 2, 3), (32, 32, 3, 2, 4, 6), (32, 32, 3, 2, 8, 12), (256, 32, 3, 1, 25, 34), (256, 32, 3, 2, 25, 42),
+                  (256, 32, 3, 1, 50, 60), (16, 4, 3, 2, 5, 7), (256, 32, 8, 1, 13, 21)):
+        for grp in _generator_bwd_group(*shape):
+            for bpc in (1, 2, 3, 4):
+                check(grp, bpc)
+    rng = random.Random(0)
+    for _ in range(300):
+        n = rng.randint(1, 45)
+        check([(rng.randint(1, 5000), rng.randint(1, 40)) for _ in range(n)], rng.randint(1, 4))

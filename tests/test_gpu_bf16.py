@@ -159,7 +159,7 @@ def test_stage1_step_under_dtype(amd, dtype):
     for dt in ("fp32", dtype):
         G, D = copy.deepcopy(G0), copy.deepcopy(D0)
         step = amd.Stage1Step(G, D, base_lr=0.01, warmup_iters=0, dtype=dt)
-        assert step.ctx.dtype == dt
+        assert step.dtype == dt and step.bctx.dtype == dt
         step.run_step(lr, hr)
         res[dt] = (step.metrics(), [q.detach().clone() for q in list(G.parameters()) + list(D.parameters())], [q.detach().clone() for q in list(G0.parameters()) + list(D0.parameters())])
     m32, p32, p0 = res["fp32"]

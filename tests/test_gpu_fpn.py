@@ -60,7 +60,37 @@ def test_fpn_afigan_matches_oracle(amd, fuse_type):
     # up as percent-level relative noise although every term is accurate to 1e-7.)
     R = {k: torch.randn(o.shape, generator=torch.Generator().manual_seed(100 + i)) for i, (k, o) in enumerate(out.items())}
     loss = sum((o * R[k].cuda()).sum() for k, o in out.items())
-    loss.backward()
+    # The backward runs TWICE on the one saved forward: the data-gradient chain has no atomics, so the input gradients
+    # must agree bit for bit; weight gradients meet in fp32 atomics and may differ by their summation order only.  Each interpolator call's
+    # own weight-gradient contribution is tapped before autograd sums the three calls that share the weights, so a mismatch names the call.
+    from afigan_amd import generator_rdb as gen_mod
+    runs = []
+    for rep in range(2):
+        for t in list(fg.values()) + list(fpn.parameters()):
+            t.grad = None
+        gen_mod.grad_tap = taps = []
+        try:
+            loss.backward(retain_graph=(rep == 0))
+        finally:
+            gen_mod.grad_tap = None
+        runs.append(({k: v.grad.clone() for k, v in fg.items()}, {k: q.grad.contiguous().clone() for k, q in fpn.named_parameters()}, taps))
+    gnames = [k for k, _ in fpn.srf_module.named_parameters()]
+    order = fpn.srf_module._ordered_params()
+    tap_names = [next(n for n, q in fpn.srf_module.named_parameters() if q is o) for o in order]
+
+    def per_call_report():
+        lines = []
+        for ci, (a, b) in enumerate(zip(runs[0][2], runs[1][2])):
+            for n, ga, gb in zip(tap_names, a["grads"], b["grads"]):
+                d = (ga - gb).abs().max().item()
+                lines.append(f"call {ci} shape {a['shape']} ctx {a['ctx']:#x} {n}: |run1-run2|max {d:.3e} of {ga.abs().max().item():.3e}")
+        return "\n".join(l for l in lines if not l.endswith("0.000e+00 of 0.000e+00"))
+    assert len(runs[0][2]) == len(runs[1][2]) == 3
+    for k in fg:
+        assert torch.equal(runs[0][0][k], runs[1][0][k]), f"input gradient {k} differs between two backward passes of one forward\n" + per_call_report()
+    nondet = {k: _rel(runs[0][1][k], runs[1][1][k]) for k in runs[0][1]}
+    assert max(nondet.values()) <= 1e-6, f"weight gradients differ between two backward passes: { {k: v for k, v in nondet.items() if v > 1e-6} }\n" + per_call_report()
+    assert gnames and all(("srf_module." + n) in runs[0][1] for n in gnames)
 
     pr = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in fpn.state_dict().items()}
     fr = [feats[f"res{i + 2}"].clone().requires_grad_(True) for i in range(4)]
@@ -71,9 +101,13 @@ def test_fpn_afigan_matches_oracle(amd, fuse_type):
         assert _rel(out[k], ref[k]) < 1e-3, k
     for i in range(4):
         assert _rel(fg[f"res{i + 2}"].grad, fr[i].grad) < 1e-3, i
-    for k, p in fpn.named_parameters():
+    bad = {}
+    for k, p in fpn.named_parameters():                 # every tensor is checked (no stop at the first), so a failure shows its extent
         assert p.grad is not None, k
-        assert _rel(p.grad.contiguous(), pr[k].grad) < 1e-3, k
+        e = _rel(p.grad.contiguous(), pr[k].grad)
+        if not e < 1e-3:
+            bad[k] = e
+    assert not bad, f"parameter gradients off the oracle: {bad}\n" + per_call_report()
 
 
 def test_fpn_afigan_frozen_interpolator(amd):

@@ -262,3 +262,59 @@ def test_stage1_phase_caches_do_not_change_the_gradients(amd, monkeypatch):
         assert float((g1 - g0).norm() / g0.norm()) < 1e-5, mode
         for k, v in m0.items():
             assert abs(m1[k] - v) <= 2e-4 * abs(v) + 1e-6, (mode, k, m1[k], v)
+
+
+@pytest.mark.parametrize("overlap_d,overlap_g", [(False, False), (True, False), (True, True)])
+def test_stage1_one_stream_and_two_stream_steps_agree(amd, overlap_d, overlap_g):
+    """The D phase on two streams (forwards on the caller's, backwards on the engine's second one, each with its own afi_ctx_t) and G's
+    backward beside the G-phase D forwards are pure schedules: two steps from the same state give the same flat gradients, parameters and
+    losses as the one-stream engine (fp32 atomics reorder sums; nothing else may differ).  ADVICE r2: AFI_D_OVERLAP / AFI_G_OVERLAP."""
+    import copy
+    torch.manual_seed(0)
+    G0 = amd.Generator(n_residual_dense_blocks=3).cuda()
+    D0 = amd.Discriminator().cuda()
+    gen = torch.Generator(device="cuda").manual_seed(4)
+    hrs = [torch.randn((2, 256, 64, 96), device="cuda", generator=gen), torch.randn((2, 256, 32, 48), device="cuda", generator=gen)]
+    lrs = [torch.randn((2, 256, 33, 49), device="cuda", generator=gen), torch.randn((2, 256, 16, 24), device="cuda", generator=gen)]
+
+    def run(od, og):
+        G, D = copy.deepcopy(G0), copy.deepcopy(D0)
+        step = amd.Stage1Step(G, D, base_lr=0.05, warmup_iters=0)
+        step.overlap_d, step.overlap_g = od, og
+        assert step.ctx.handle.value != step.bctx.handle.value       # one context per stream (include/afigan_hip.h)
+        step.run_step(lrs, hrs)
+        grads = (step.d_opt.flat_grad.detach().clone(), step.g_opt.flat_grad.detach().clone())
+        step.run_step(lrs, hrs)
+        torch.cuda.synchronize()
+        return grads, step.metrics(), torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+    (d0, g0), m0, p0 = run(False, False)
+    (d1, g1), m1, p1 = run(overlap_d, overlap_g)
+    assert float((d1 - d0).norm() / d0.norm()) < 1e-5 and float((g1 - g0).norm() / g0.norm()) < 1e-5
+    assert float((p1 - p0).norm() / p0.norm()) < 1e-6
+    for k, v in m0.items():
+        assert abs(m1[k] - v) <= 2e-4 * abs(v) + 1e-6, (k, m1[k], v)
+
+
+def test_stage1_error_in_a_phase_joins_the_second_stream(amd):
+    """An exception inside the phases must not leave backward kernels of the second stream reading memory the caller's stream gets back
+    (ADVICE r2): the handler joins the stream, drops the partial weight-gradient sums, and the next step works."""
+    torch.manual_seed(0)
+    G = amd.Generator(n_residual_dense_blocks=3).cuda()
+    D = amd.Discriminator().cuda()
+    step = amd.Stage1Step(G, D, base_lr=0.01, warmup_iters=0)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    hrs = [torch.randn((1, 256, 32, 48), device="cuda", generator=gen)]
+    lrs = [torch.randn((1, 256, 16, 24), device="cuda", generator=gen)]
+    joined = []
+    orig_join, orig_all = step._join_bstream, step._allreduce
+    step._join_bstream = lambda: (joined.append(1), orig_join())[1]
+
+    def boom(opt):
+        raise RuntimeError("injected")
+    step._allreduce = boom
+    with pytest.raises(RuntimeError, match="injected"):
+        step.run_step(lrs, hrs)
+    assert len(joined) >= 2                                            # the phase's own join and the handler's
+    step._allreduce = orig_all
+    step.run_step(lrs, hrs)                                            # contexts are clean again (no pending sums, caches unregistered)
+    assert all(np.isfinite(v) for v in step.metrics().values())

@@ -350,3 +350,32 @@ def test_af_extractor_contract_on_cpu():
     assert amd.META_ARCH_REGISTRY.get("GeneralizedRCNN_AFExtractor") is amd.GeneralizedRCNN_AFExtractor
     from afigan.modeling.meta_arch import GeneralizedRCNN_AFExtractor as shim
     assert shim is amd.GeneralizedRCNN_AFExtractor
+
+
+def _run_bench(argv, env_extra=None, timeout=240):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (reference: stage1_train.py:52-59 `launch(main,
+    num_gpus, ...)`), the parent never touches a GPU (there is none here), and rank 0's JSON line is relayed with n_gpus == 2.
+    --rehearse-launch replaces the GPU work by CPU tensors: rendezvous, all-reduce(SUM), MAX-over-ranks time, cross-rank identity."""
+    import json
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--rehearse-launch"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["spawned_by_bench"] and line["allreduce_sum_ok"] and line["params_identical_across_ranks"] is True
+
+
+def test_bench_rejects_a_world_that_is_not_gpus_and_fails_with_its_ranks():
+    r = _run_bench(["--gpus", "4", "--rehearse-launch"], {"WORLD_SIZE": "2", "RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr
+    r = _run_bench(["--gpus", "2", "--backend", "gloo", "--rehearse-launch"], {"AFI_BENCH_REHEARSE_FAIL_RANK": "1"})
+    assert r.returncode == 3 and "rank 1 exited with code 3" in r.stderr and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
