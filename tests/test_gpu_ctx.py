@@ -71,23 +71,27 @@ def test_backward_runs_on_the_forward_context_and_arithmetic(amd, dtype, backwar
 
 
 def test_bf16_backward_differs_from_fp32(amd):
-    """The backward really changes arithmetic with the setting: input gradients under bf16 differ from fp32's by far more than fp32's own
-    rounding (1e-6), and bf16x6 (the exact split) does not."""
+    """The backward really changes arithmetic with the setting: after ONE fp32 forward, the weight gradients of a backward run under bf16
+    differ from an fp32 backward's by far more than fp32's own rounding, and those of bf16x6 (the exact split) do not.  (The INPUT
+    gradient is dominated by the bilinear skip, which no setting touches; the weight gradients come out of the GEMMs alone.)"""
     G = _gen(amd)
     x0 = torch.randn((1, 128, 32, 64), generator=torch.Generator().manual_seed(2))
     R = torch.randn((1, 128, 64, 128), generator=torch.Generator().manual_seed(3)).cuda()
     grads = {}
     for dt in ("fp32", "bf16x6", "bf16"):
+        for q in G.parameters():
+            q.grad = None
         x = x0.cuda().requires_grad_(True)
         with amd.compute_dtype("fp32"):                              # the same forward for all three: only the backward differs
             out = G(x)
-        fn = out.grad_fn
-        fn.afi_dtype = dt                                            # what ctx_forward recorded; the backward must obey it
+        out.grad_fn.afi_dtype = dt                                   # what ctx_forward recorded; the backward must obey it
         (out * R).sum().backward()
-        grads[dt] = x.grad.detach().double().cpu()
-    scale = grads["fp32"].abs().max()
-    assert ((grads["bf16x6"] - grads["fp32"]).abs().max() / scale).item() < 2e-5
-    assert ((grads["bf16"] - grads["fp32"]).abs().max() / scale).item() > 1e-4
+        grads[dt] = {k: q.grad.detach().double().cpu().contiguous() for k, q in G.named_parameters() if q.dim() == 4}
+
+    def worst(a, b):
+        return max(((a[k] - b[k]).norm() / b[k].norm()).item() for k in b)
+    assert worst(grads["bf16x6"], grads["fp32"]) < 2e-5
+    assert worst(grads["bf16"], grads["fp32"]) > 1e-4
 
 
 def test_use_ctx_covers_a_backward_inside_it(amd):

@@ -290,7 +290,7 @@ def test_stage1_one_stream_and_two_stream_steps_agree(amd, overlap_d, overlap_g)
     (d0, g0), m0, p0 = run(False, False)
     (d1, g1), m1, p1 = run(overlap_d, overlap_g)
     assert float((d1 - d0).norm() / d0.norm()) < 1e-5 and float((g1 - g0).norm() / g0.norm()) < 1e-5
-    assert float((p1 - p0).norm() / p0.norm()) < 1e-6
+    assert float((p1 - p0).norm() / p0.norm()) < 1e-5                  # (two runs of ONE schedule differ by 1.6e-6: atomics order after two lr = 0.05 steps)
     for k, v in m0.items():
         assert abs(m1[k] - v) <= 2e-4 * abs(v) + 1e-6, (k, m1[k], v)
 
