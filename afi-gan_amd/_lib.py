@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFI_LIB_PATH") or os.path.join(_HERE, "csrc", "libafigan_hip.so")   # override: A/B kernel builds
 
 AFI_MAX_RDB = 8
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class AfiError(RuntimeError):
@@ -61,7 +61,8 @@ SIGNATURES = {
     "afi_ctx_set_op_scratch": (_i, [_vp, _vp, _ll]),
     "afi_ctx_set_compute_dtype": (_i, [_vp, _i]),
     "afi_ctx_get_compute_dtype": (_i, [_vp]),
-    "afi_gemm_nt": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
+    "afi_gemm_nt_scratch_bytes": (_ll, [_i, _i, _i, _i]),
+    "afi_gemm_nt": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _ll, _vp]),
     "afi_gemm_tn": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
     "afi_ctx_set_wino_weight_cache": (_i, [_vp, _vp, _ll]),
     "afi_ctx_wino_weight_cache_invalidate": (_i, [_vp]),

@@ -1,18 +1,15 @@
 // bf16-MFMA variants of the two batched Winograd GEMMs (included by igemm.hip after AfiGemmNT / AfiGemmTN / ProfScope).
 //
-// The planes stay fp32 in HBM (the transforms, the epilogues and every caller are unchanged); a tile is converted to bf16 once, on
-// its way from the prefetch registers into LDS, and multiplied with v_mfma_f32_32x32x16_bf16 into fp32 accumulators.
+// The planes stay fp32 in HBM (the transforms, the epilogues and every caller are unchanged); an operand is converted to bf16 parts on
+// chip and multiplied on the bf16 matrix cores into fp32 accumulators.
 //   SPLIT = 1  "bf16":    x -> hi = bf16(x); one MFMA per k-step.  Operand error 2^-9: use on F(2x2) planes only.
 //   SPLIT = 3  "bf16x3":  x -> hi + lo, lo = bf16(x - hi); hi*hi + hi*lo + lo*hi (three MFMAs per k-step, the lo*lo term dropped):
 //                         operand error 2^-17, so the F(4x4) planes stay usable.  Three bf16 MFMAs cost 3/16 of the fp32 MFMA work.
 //   SPLIT = 6  "bf16x6":  x = hi + mid + lo exactly (three bf16 carry all 24 mantissa bits); the six products of order <= 2^-16
 //                         (hh, hm, mh, mm, hl, lh), smallest first: what is dropped (ml, lm, ll) is below fp32's own rounding of a
 //                         product, so the result is fp32-grade (measured 1e-6, like the fp32 MFMA) at 6/16 of its matrix-core work.
-// At bf16 rate a 128x128x32 stage is 256 (x3: 768) MFMA cycles per wave while its operands are 32 KB of fp32 from L2, so both forms
-// are bound by the L2 -> CU stream, not by the matrix cores: the roofline for this kernel is L2 bandwidth x 32 FLOP/B per tile pair.
-//
-// LDS image of a tile: [128 rows][32 bf16] = 64-byte rows, 16-byte chunk ch of row r stored at chunk ch ^ ((r >> 2) & 3): the
-// ds_read_b128 fragment reads (16 lanes = 16 consecutive rows, one chunk) and the ds_write_b64 staging writes are conflict-free.
+// NT (forward / data gradient): afi_gemm_nt_bf16_dma_kernel further down (LDS-DMA staging, v_mfma_f32_16x16x32_bf16).
+// TN (weight gradient): afi_gemm_tn_bf16_kernel (register staging, transposed LDS reads, v_mfma_f32_32x32x16_bf16).
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -26,145 +23,6 @@ __device__ __forceinline__ u32x2 afi_pack_bf16(f32x4 v) {
 __device__ __forceinline__ f32x4 afi_bf16_residual(f32x4 v) {          // v - float(bf16(v)), exact in fp32
     const bf16x4 h = __builtin_convertvector(v, bf16x4);
     return v - __builtin_convertvector(h, f32x4);
-}
-__device__ __forceinline__ int afi_bf16_tile_off(int row, int kq /* float4 column 0..7 */) {      // byte offset inside an 8 KB tile
-    return row * 64 + ((((kq >> 1) ^ (row >> 2)) & 3) << 4) + ((kq & 1) << 3);
-}
-
-// DB: two LDS buffers and one barrier per stage (two blocks per CU); !DB: one buffer, two barriers, three blocks per CU whose stages
-// interleave -- the form the six-product variant needs (its three images per operand are 48 KB per buffer).
-template <int SPLIT, bool DB>
-__global__ __launch_bounds__(256, DB ? 2 : 3) void afi_gemm_nt_bf16_kernel(const AfiGemmNT p, int ntile_n, int ntile_m, int chunk) {
-    constexpr int BM = 128, BN = 128, BK = 32, WN = 2, MI = 2, NI = 2;
-    constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);   // hi (, mid) (, lo) images per operand
-    constexpr int TILE = BM * BK * 2;                        // bytes of one bf16 tile image
-    constexpr int BUF = 2 * NPART * TILE;                    // A parts then B parts
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
-    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
-    const int tile_n = jb % ntile_n, tile_m = xcd * chunk + jb / ntile_n;
-    if (tile_m >= ntile_m) return;
-    const long long m0 = (long long)tile_m * BM;
-    const int n0 = tile_n * BN;
-    const int plane = (int)(m0 / p.rows_per_plane);
-    const int aq = tid & 7, ar = tid >> 3;                   // float4 column, first row (32 rows per pass, 4 passes)
-    const float* a_base = p.A + (m0 + ar) * p.K + 4 * aq;
-    const float* b_base = p.B + ((long long)plane * p.N + n0 + ar) * p.K + 4 * aq;
-    const long long pass = 32LL * p.K;
-    const int nK = p.K / BK;
-
-    f32x4 a_reg[4], b_reg[4];
-    auto issue = [&](int kc) {
-        const int k0 = kc * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a_reg[i] = *(const f32x4*)(a_base + i * pass + k0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) b_reg[i] = *(const f32x4*)(b_base + i * pass + k0);
-    };
-    auto stage_store = [&](int buf) {
-        unsigned char* base = smem_b + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int off = afi_bf16_tile_off(ar + 32 * i, aq);
-            *(u32x2*)(base + off) = afi_pack_bf16(a_reg[i]);
-            *(u32x2*)(base + NPART * TILE + off) = afi_pack_bf16(b_reg[i]);
-            if (SPLIT >= 3) {
-                const f32x4 ra = afi_bf16_residual(a_reg[i]), rb = afi_bf16_residual(b_reg[i]);
-                *(u32x2*)(base + TILE + off) = afi_pack_bf16(ra);
-                *(u32x2*)(base + NPART * TILE + TILE + off) = afi_pack_bf16(rb);
-                if (SPLIT == 6) {
-                    *(u32x2*)(base + 2 * TILE + off) = afi_pack_bf16(afi_bf16_residual(ra));
-                    *(u32x2*)(base + NPART * TILE + 2 * TILE + off) = afi_pack_bf16(afi_bf16_residual(rb));
-                }
-            }
-        }
-    };
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    // fragment addresses: lane (lr, lh) takes row (tile32 * 32 + lr), k = 16 s + 8 lh .. +7 = chunk 2 s + lh
-    int fa_off[MI][2], fb_off[NI][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) { const int row = (wm * MI + mi) * 32 + lr; fa_off[mi][s] = row * 64 + ((((2 * s + lh) ^ (row >> 2)) & 3) << 4); }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) { const int row = (wn * NI + ni) * 32 + lr; fb_off[ni][s] = NPART * TILE + row * 64 + ((((2 * s + lh) ^ (row >> 2)) & 3) << 4); }
-    }
-
-    issue(0);
-    if (DB) { stage_store(0); __syncthreads(); }
-    for (int kc = 0; kc < nK; ++kc) {
-        const bool more = kc + 1 < nK;
-        if (!DB) { stage_store(0); __syncthreads(); }
-        if (more) issue(kc + 1);                             // in flight behind this stage's MFMAs (and the other blocks of the CU)
-        const unsigned char* base = smem_b + (DB ? (kc & 1) * BUF : 0);
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 ah[MI], bh[NI], al[MI], bl[NI], am[MI], bm[NI];      // (SPLIT 3: "l" is the second part; SPLIT 6: h, m, l)
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                ah[mi] = *(const bf16x8*)(base + fa_off[mi][s]);
-                if (SPLIT == 3) al[mi] = *(const bf16x8*)(base + TILE + fa_off[mi][s]);
-                if (SPLIT == 6) { am[mi] = *(const bf16x8*)(base + TILE + fa_off[mi][s]); al[mi] = *(const bf16x8*)(base + 2 * TILE + fa_off[mi][s]); }
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                bh[ni] = *(const bf16x8*)(base + fb_off[ni][s]);
-                if (SPLIT == 3) bl[ni] = *(const bf16x8*)(base + TILE + fb_off[ni][s]);
-                if (SPLIT == 6) { bm[ni] = *(const bf16x8*)(base + TILE + fb_off[ni][s]); bl[ni] = *(const bf16x8*)(base + 2 * TILE + fb_off[ni][s]); }
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    if (SPLIT >= 3) {                        // small terms first
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-                    }
-                    if (SPLIT == 6) {
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bm[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bm[ni], acc[mi][ni], 0, 0, 0);
-                    }
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                }
-        }
-        if (DB && more) stage_store((kc + 1) & 1);           // the other buffer: its readers passed the barrier of the previous stage
-        __syncthreads();
-    }
-    // epilogue: accumulators -> LDS -> float4 rows of C   (same staging as afi_gemm_nt_kernel)
-    constexpr int LDC = BN + 4, C_F4 = BN / 4;
-    float* Cs = (float*)smem_b;
-    float* c_base = p.C + m0 * p.N + n0;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                Cs[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDC + (wn * NI + ni) * 32 + lr] = acc[mi][ni][r];
-        __syncthreads();
-        for (int item = tid; item < 2 * 32 * C_F4; item += 256) {
-            const int rloc = item / C_F4, c4 = item - rloc * C_F4;
-            const int rl = ((rloc >> 5) * MI + mi) * 32 + (rloc & 31);
-            *(f32x4*)(c_base + (long long)rl * p.N + 4 * c4) = *(const f32x4*)(Cs + rloc * LDC + 4 * c4);
-        }
-        if (mi + 1 < MI) __syncthreads();
-    }
-}
-
-static size_t afi_gemm_nt_bf16_lds(int split, bool db) {
-    const size_t ring = (db ? 2u : 1u) * 2u * (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 128u * 32u * 2u;      // buffers x (A, B) x parts x tile
-    const size_t cst = sizeof(float) * 64u * (128u + 4u);
-    return ring > cst ? ring : cst;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,3 +177,163 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
                 if (use_atomic) atomicAdd(dst, acc[mi][ni][r]); else *dst += acc[mi][ni][r];
             }
 }
+
+// ------------------------------------------------------------------------------------------------
+// Round 3: the NT GEMM with both operands staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no LDS store instructions) on
+// v_mfma_f32_16x16x32_bf16.  Measured against the register-staged kernel above in one process (tools/gemm_ab.py, random operands):
+// removing the conversion VALU alone changes nothing; removing the VGPR round trip and the ds_write stream is worth +17..20 %.
+//   A (the Winograd-domain activations V, fp32 in HBM as before -- the transforms and their traffic are unchanged) is copied VERBATIM into
+//   an fp32 LDS image [128 rows][32 floats] and split into bf16 parts when a wave reads its fragment (a wave owns its 32 rows, so each
+//   element is split once per block, as before).  128-byte rows, the 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 5): a lane's
+//   fragment is chunks 2q, 2q + 1 of row l15 (q = lane >> 4), and both ds_read_b128 are conflict-free (every b128 lane group hits 16
+//   distinct slots of the 256-byte bank row; found by exhaustive search over the linear swizzles).  The DMA writes LDS linearly
+//   (wave base + 16 * lane), so the swizzle is applied to each lane's SOURCE address.
+//   B (the transformed weights U, shared by every M tile of a plane) arrives PRE-SPLIT into bf16 parts in LDS-image order --
+//   [plane][N / 128][K / 32][part][128 x 64 bytes], chunk ch of row r at ch ^ ((-(r >> 2)) & 3) (conflict-free for the 16x16x32 fragment
+//   reads) -- written once per weight transform by afi_split_bf16_tiles_kernel, so a stage of it is a linear copy.
+//   One LDS buffer (16 KB + NPART x 8 KB = 40 KB for the six-product form), two barriers per stage, the next stage's DMA issued behind the
+//   second barrier: its latency is covered by the other resident blocks (four per CU at <= 128 registers).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int afi_bf16_tile16_off(int row, int kq /* float4 column 0..7 */) {
+    return row * 64 + ((((kq >> 1) ^ (-(row >> 2))) & 3) << 4) + ((kq & 1) << 3);
+}
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ bf16x8 afi_pack8_bf16(f32x4 lo, f32x4 hi) {
+    const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int SPLIT, int MINW>
+__global__ __launch_bounds__(256, MINW) void afi_gemm_nt_bf16_dma_kernel(const AfiGemmNT p, int ntile_n, int ntile_m, int chunk) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int MI = 2, NI = 8;                            // 4 x 1 waves of 32 x 128: a wave's A rows are its own
+    constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);
+    constexpr int TILE_A = BM * 128;                         // fp32 image, 16 KB
+    constexpr int TILE_B = BN * 64;                          // one bf16 image, 8 KB
+    constexpr int OFF_B = TILE_A;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile_n = jb % ntile_n, tile_m = xcd * chunk + jb / ntile_n;
+    if (tile_m >= ntile_m) return;
+    const long long m0 = (long long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int plane = (int)(m0 / p.rows_per_plane);
+    const int nK = p.K / BK;
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    // A: DMA instruction i of wave w fills rows 8 (4 i + w) .. + 7 (lane >> 3 = row, lane & 7 = physical chunk); source chunk = physical ^ swizzle
+    const int a_row0 = 8 * wave + (lane >> 3);
+    const int a_swz = ((lane >> 4) & 1) | ((wave & 1) << 2);                    // ((row >> 1) & 5) of every row this lane fills
+    const float* a_src = p.A + (m0 + a_row0) * p.K + 4 * ((lane & 7) ^ a_swz);
+    const long long a_step = 32LL * p.K;                     // 32 rows per DMA instruction
+    const unsigned char* b_src = (const unsigned char*)p.B + (((long long)plane * ntile_n + tile_n) * nK) * (long long)(NPART * TILE_B) + 16 * tid;
+    auto issue = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr)(a_src + i * a_step + kc * BK), (lptr)(smem_b + (4 * i + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NPART; ++i)
+            __builtin_amdgcn_global_load_lds((gptr)(b_src + (long long)kc * (NPART * TILE_B) + i * 4096), (lptr)(smem_b + OFF_B + (4 * i + wave) * 1024), 16, 0, 0);
+    };
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int fa_off[MI], fb_off[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { const int row = (wave * MI + mi) * 16 + l15; fa_off[mi] = row * 128 + (((2 * lq) ^ ((row >> 1) & 5)) << 4); }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { const int row = ni * 16 + l15; fb_off[ni] = OFF_B + row * 64 + (((lq ^ (-(row >> 2))) & 3) << 4); }
+    auto mfma = [](bf16x8 x, bf16x8 y, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0); };
+
+    issue(0);
+    for (int kc = 0; kc < nK; ++kc) {
+        __syncthreads();                                     // (vmcnt(0) in front of the barrier: the stage has landed)
+        bf16x8 ah[MI], am[MI], al[MI];                       // (SPLIT 3: "am" is the second part)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            // chunks 2q and 2q + 1 of the row: the swizzle never touches bit 0 ... of the PAIR index; bit 0 of the chunk may flip
+            const f32x4 c0 = *(const f32x4*)(smem_b + fa_off[mi]);
+            const f32x4 c1 = *(const f32x4*)(smem_b + (fa_off[mi] ^ 16));
+            ah[mi] = afi_pack8_bf16(c0, c1);
+            if (SPLIT >= 3) {
+                const f32x4 r0 = afi_bf16_residual(c0), r1 = afi_bf16_residual(c1);
+                am[mi] = afi_pack8_bf16(r0, r1);
+                if (SPLIT == 6) al[mi] = afi_pack8_bf16(afi_bf16_residual(r0), afi_bf16_residual(r1));
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            bf16x8 bh, bm, bl;
+            bh = *(const bf16x8*)(smem_b + fb_off[ni]);
+            if (SPLIT >= 3) bm = *(const bf16x8*)(smem_b + TILE_B + fb_off[ni]);
+            if (SPLIT == 6) bl = *(const bf16x8*)(smem_b + 2 * TILE_B + fb_off[ni]);
+            if (SPLIT == 6) {                                // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(am[mi], bm, acc[mi][ni]);
+            }
+            if (SPLIT >= 3) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(am[mi], bh, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bm, acc[mi][ni]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
+        }
+        __syncthreads();
+        if (kc + 1 < nK) issue(kc + 1);                      // the buffer is free again
+    }
+    // epilogue: accumulators -> LDS -> float4 rows of C, 16 rows of every wave per pass
+    constexpr int LDC = BN + 4, C_F4 = BN / 4;
+    // (the launcher sizes the dynamic LDS as max(stage buffer, 4 * 16 * LDC floats))
+    float* Cs = (float*)smem_b;
+    float* c_base = p.C + m0 * p.N + n0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(wave * 16 + lq * 4 + r) * LDC + ni * 16 + l15] = acc[mi][ni][r];
+        __syncthreads();
+        for (int item = tid; item < 4 * 16 * C_F4; item += 256) {
+            const int rloc = item / C_F4, c4 = item - rloc * C_F4;
+            const int rl = (rloc >> 4) * 32 + mi * 16 + (rloc & 15);
+            *(f32x4*)(c_base + (long long)rl * p.N + 4 * c4) = *(const f32x4*)(Cs + rloc * LDC + 4 * c4);
+        }
+        if (mi + 1 < MI) __syncthreads();
+    }
+}
+
+// B[plane][n][k] fp32 -> the pre-split LDS-image order of afi_gemm_nt_bf16_m16_kernel<.., BPRE = true>: one thread per float4.
+template <int SPLIT, int BN>
+__global__ __launch_bounds__(256) void afi_split_bf16_tiles_kernel(const float* __restrict__ B, unsigned char* __restrict__ out, int planes, int N, int K) {
+    constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);
+    constexpr int TILE_B = BN * 64;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int kq4 = K / 4;
+    const long long total = (long long)planes * N * kq4;
+    if (i >= total) return;
+    const int kq = (int)(i % kq4);
+    const long long rowg = i / kq4;                         // plane * N + n
+    const int n = (int)(rowg % N), plane = (int)(rowg / N);
+    const f32x4 v = *(const f32x4*)(B + rowg * K + 4 * kq);
+    const int tile_n = n / BN, row = n - tile_n * BN, kc = kq >> 3;
+    unsigned char* img = out + ((((long long)plane * (N / BN) + tile_n) * (K / 32)) + kc) * (long long)(NPART * TILE_B);
+    const int off = afi_bf16_tile16_off(row, kq & 7);
+    *(u32x2*)(img + off) = afi_pack_bf16(v);
+    if (SPLIT >= 3) {
+        const f32x4 r1 = afi_bf16_residual(v);
+        *(u32x2*)(img + TILE_B + off) = afi_pack_bf16(r1);
+        if (SPLIT == 6) *(u32x2*)(img + 2 * TILE_B + off) = afi_pack_bf16(afi_bf16_residual(r1));
+    }
+}
+

@@ -769,26 +769,34 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
 
 #include "afi_gemm_bf16.h"
 // the same GEMM on the bf16 matrix cores (split = 1: bf16 operands; 3: split-bf16, three MFMAs per k-step); fp32 planes in and out
-int afi_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st) {
+// B (transformed weights) [planes][N][K] fp32 -> the pre-split bf16 LDS-image order the DMA kernel stages verbatim (afi_gemm_bf16.h)
+int afi_launch_split_bf16_tiles(const float* B, void* out, int planes, int N, int K, int split, hipStream_t st) {
+    if (!B || !out || planes <= 0 || (N % 128) || (K % 32) || (split != 1 && split != 3 && split != 6)) return AFI_ERR_BAD_ARG;
+    const long long total = (long long)planes * N * (K / 4);
+    const dim3 grid((unsigned)((total + 255) / 256)), blk(256);
+    unsigned char* o = (unsigned char*)out;
+    if (split == 6) hipLaunchKernelGGL((afi_split_bf16_tiles_kernel<6, 128>), grid, blk, 0, st, B, o, planes, N, K);
+    else if (split == 3) hipLaunchKernelGGL((afi_split_bf16_tiles_kernel<3, 128>), grid, blk, 0, st, B, o, planes, N, K);
+    else hipLaunchKernelGGL((afi_split_bf16_tiles_kernel<1, 128>), grid, blk, 0, st, B, o, planes, N, K);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// the DMA form: A fp32 planes, B pre-split (afi_launch_split_bf16_tiles)
+int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st) {
     if (planes <= 0 || rows_per_plane <= 0 || N <= 0 || K <= 0 || (split != 1 && split != 3 && split != 6)) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
-    AfiGemmNT g{A, B, C, rows_per_plane, planes, N, K};
+    AfiGemmNT g{A, (const float*)Bsplit, C, rows_per_plane, planes, N, K};
     const long long M = rows_per_plane * planes;
     const int ntm = (int)(M / 128), ntn = N / 128, chunk = afi_cdiv(ntm, 8);
-    static const int db_env = afi_env_int("AFI_BF16_DB", 0);      // 1: two LDS buffers, one barrier per stage, two blocks per CU (A/B)
-    const bool db = db_env > 0 && split != 6;              // default: one buffer, three blocks per CU (measured +8 % over two buffers at two blocks)
-    const size_t lds = afi_gemm_nt_bf16_lds(split, db);
+    const size_t stage = 16384u + (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 8192u, epi = sizeof(float) * 64u * (128u + 4u);
+    const size_t lds = stage > epi ? stage : epi;
     ProfScope prof(st, 17, 2.0 * (double)M * N * K);
     prof.m = M; prof.n = N; prof.k = K; prof.split = split;
     const dim3 grid(chunk * ntn * 8), blk(256);
-    if (split == 6) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<6, false>), grid, blk, lds, st, g, ntn, ntm, chunk);
-    else if (split == 3 && db) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<3, true>), grid, blk, lds, st, g, ntn, ntm, chunk);
-    else if (split == 3) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<3, false>), grid, blk, lds, st, g, ntn, ntm, chunk);
-    else if (db) hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<1, true>), grid, blk, lds, st, g, ntn, ntm, chunk);
-    else hipLaunchKernelGGL((afi_gemm_nt_bf16_kernel<1, false>), grid, blk, lds, st, g, ntn, ntm, chunk);
+    if (split == 6) hipLaunchKernelGGL((afi_gemm_nt_bf16_dma_kernel<6, 4>), grid, blk, lds, st, g, ntn, ntm, chunk);
+    else if (split == 3) hipLaunchKernelGGL((afi_gemm_nt_bf16_dma_kernel<3, 4>), grid, blk, lds, st, g, ntn, ntm, chunk);
+    else hipLaunchKernelGGL((afi_gemm_nt_bf16_dma_kernel<1, 4>), grid, blk, lds, st, g, ntn, ntm, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
-
 int afi_launch_pix_gemm_sk(const AfiPixGemm& p, int b_rc, hipStream_t st);   // smallmap.hip
 int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
 int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);

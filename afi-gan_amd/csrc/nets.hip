@@ -14,7 +14,8 @@
 int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st);
 int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st);
 int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, hipStream_t st);
-int afi_launch_gemm_nt_bf16(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st);
+int afi_launch_split_bf16_tiles(const float* B, void* out, int planes, int N, int K, int split, hipStream_t st);
+int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st);
 int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
 int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // igemm.hip -> smallmap.hip
@@ -208,10 +209,12 @@ static long long wino4_tpad(int N, int H, int W) { return (((long long)N * ((H +
 static bool wino_d_f4() { static const int on = getenv("AFI_WINO_D_F4") ? atoi(getenv("AFI_WINO_D_F4")) : 0; return on != 0; }
 static bool wino_f4() { static const int on = getenv("AFI_WINO_F4") ? atoi(getenv("AFI_WINO_F4")) : 1; return on != 0; }
 // one size for both tilings: F(2x2,3x3) = 16 transform points over 2x2 tiles, F(4x4,3x3) = 36 points over 4x4 tiles
+// + the pre-split bf16 image of U the DMA GEMM stages (three 2-byte parts per element = 1.5 floats; afi_gemm_bf16.h)
+static long long wino_usplit_floats(int np, long long KN) { return align4((3 * np * KN + 1) / 2); }
 static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
     const long long T2 = wino_tpad(N, H, W), T4 = wino4_tpad(N, H, W);
-    const long long a = align4(16LL * K * Nc) + align4(16 * T2 * K) + align4(16 * T2 * Nc);
-    const long long b = align4(36LL * K * Nc) + align4(36 * T4 * K) + align4(36 * T4 * Nc);
+    const long long a = align4(16LL * K * Nc) + align4(16 * T2 * K) + align4(16 * T2 * Nc) + wino_usplit_floats(16, (long long)K * Nc);
+    const long long b = align4(36LL * K * Nc) + align4(36 * T4 * K) + align4(36 * T4 * Nc) + wino_usplit_floats(36, (long long)K * Nc);
     return a > b ? a : b;
 }
 // Any 3x3 / stride-1 conv DESCRIPTOR of the pixel GEMM (forward, b_rc = 0, or data gradient, b_rc = 1) run in Winograd form: the
@@ -220,6 +223,7 @@ static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
 // below this many pixels a conv of the interpolator stays on the direct small-map kernels.  Scanned with tools/interp_sweep.py
 // (fwd+bwd, 1024 -> 2048): 1x25x42 1.31 -> 1.04 ms, 2x25x34 1.49 -> 1.33 ms; 4096 and up lose from 3400 pixels on.
 static long long wino_g_minpix() { static const long long v = getenv("AFI_G_WINO_MINPIX") ? atoll(getenv("AFI_G_WINO_MINPIX")) : 2048; return v; }
+static bool wino_gemm_fast() { static const int fast = getenv("AFI_GEMM_NT") ? atoi(getenv("AFI_GEMM_NT")) : 1; return fast != 0; }
 static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
     static const int on = getenv("AFI_WINO_G") ? atoi(getenv("AFI_WINO_G")) : 1;
     if (!on || g.ntaps != 9 || g.gtap || g.r2_post) return false;
@@ -269,21 +273,31 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     float* U = ws;
     float* Vb = U + align4((long long)np * K * Nc);
     float* Mb = Vb + align4(np * Tpad * K);
+    float* Usp = Mb + align4(np * Tpad * Nc);              // pre-split bf16 image of U (DMA GEMM), when it is not served from the cache
+    // the bf16 settings run the LDS-DMA GEMM on tile-aligned shapes (every layer of the reference nets): its B operand is U split into
+    // bf16 parts in LDS-image order, made once per weight transform and cached in that form
+    const bool dma = dtype != AFI_DTYPE_F32 && wino_gemm_fast() && !(Tpad % 128) && !(Nc % 128) && !(K % 32);
     bool have_u = false;
-    if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc, b_rc ? K : Nc, b_rc ? Nc : K, align4((long long)np * K * Nc), have_u)) U = slot;
-    if (!have_u) AFI_TRY(f4 ? afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st)
-                            : afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
+    if (dma) {
+        if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc | (dtype << 4), b_rc ? K : Nc, b_rc ? Nc : K, wino_usplit_floats(np, (long long)K * Nc), have_u)) Usp = slot;
+    } else if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc, b_rc ? K : Nc, b_rc ? Nc : K, align4((long long)np * K * Nc), have_u)) U = slot;
+    if (!have_u) {
+        AFI_TRY(f4 ? afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st)
+                   : afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
+        if (dma) AFI_TRY(afi_launch_split_bf16_tiles(U, Usp, np, Nc, K, dtype, st));
+    }
     for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
         AfiView a = g.A;
         if (nph == 4) { a.p += (ph >> 1) * g.A.sH + (ph & 1) * g.A.sW; a.sH *= 2; a.sW *= 2; }
         AFI_TRY(f4 ? afi_launch_wino4_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K)
                    : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K));
     }
-    {   // tile-aligned shapes (every layer of the reference nets): the plain batched NT GEMM
-        static const int fast = getenv("AFI_GEMM_NT") ? atoi(getenv("AFI_GEMM_NT")) : 1;
-        const int rc = !fast ? AFI_ERR_UNSUPPORTED
-                     : dtype == AFI_DTYPE_F32 ? afi_launch_gemm_nt(Vb, U, Mb, np, Tpad, Nc, K, st)
-                                              : afi_launch_gemm_nt_bf16(Vb, U, Mb, np, Tpad, Nc, K, dtype, st);
+    if (dma) {
+        AFI_TRY(afi_launch_gemm_nt_bf16_dma(Vb, Usp, Mb, np, Tpad, Nc, K, dtype, st));
+        return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
+    }
+    if (dtype == AFI_DTYPE_F32 && wino_gemm_fast()) {      // tile-aligned shapes: the plain batched NT GEMM on the fp32 MFMA
+        const int rc = afi_launch_gemm_nt(Vb, U, Mb, np, Tpad, Nc, K, st);
         if (rc == AFI_OK) return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
         if (rc != AFI_ERR_UNSUPPORTED) return rc;
     }
@@ -397,7 +411,7 @@ static long long disc_wino_floats(const int F[4], int N, int H, int W) {
 
 extern "C" {
 
-int afi_abi_version(void) { return 2; }
+int afi_abi_version(void) { return 3; }
 
 const char* afi_status_string(int s) {
     switch (s) {
@@ -436,11 +450,22 @@ int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype) {
     return AFI_OK;
 }
 int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx) { return ctx ? ctx->dtype : afi_default_dtype(); }
-int afi_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int dtype, void* stream) {
+long long afi_gemm_nt_scratch_bytes(int planes, int N, int K, int dtype) {
+    if (planes <= 0 || N <= 0 || K <= 0) return -1;
+    if (dtype == AFI_DTYPE_F32) return 0;
+    if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6) return -1;
+    return (long long)planes * N * K * 2 * (dtype == AFI_DTYPE_BF16X6 ? 3 : (dtype == AFI_DTYPE_BF16X3 ? 2 : 1));
+}
+int afi_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int dtype, void* scratch, long long scratch_bytes,
+                void* stream) {
     if (!A || !B || !C) return AFI_ERR_BAD_ARG;
     if (dtype == AFI_DTYPE_F32) return afi_launch_gemm_nt(A, B, C, planes, rows_per_plane, N, K, (hipStream_t)stream);
     if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6) return AFI_ERR_BAD_ARG;
-    return afi_launch_gemm_nt_bf16(A, B, C, planes, rows_per_plane, N, K, dtype, (hipStream_t)stream);
+    if (planes <= 0 || rows_per_plane <= 0 || N <= 0 || K <= 0) return AFI_ERR_BAD_ARG;
+    if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
+    if (!scratch || scratch_bytes < afi_gemm_nt_scratch_bytes(planes, N, K, dtype)) return AFI_ERR_WORKSPACE;
+    AFI_TRY(afi_launch_split_bf16_tiles(B, scratch, planes, N, K, dtype, (hipStream_t)stream));
+    return afi_launch_gemm_nt_bf16_dma(A, scratch, C, planes, rows_per_plane, N, K, dtype, (hipStream_t)stream);
 }
 int afi_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int dtype, void* stream) {
     if (!Q || !V || !dU) return AFI_ERR_BAD_ARG;

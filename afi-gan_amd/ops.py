@@ -165,6 +165,22 @@ def zeros_like_many(tensors, need):
     return [flat.as_strided(t.size(), t.stride(), o) if o is not None else None for t, o in zip(tensors, offs)]
 
 
+def gemm_nt(A, B, dtype, out=None):
+    """afi_gemm_nt for tests and micro-benchmarks: C[g] = A[g] @ B[g]^T over the planes of dense [planes, rows, K] / [planes, N, K] tensors,
+    in the arithmetic `dtype` ("fp32", "bf16x6", "bf16x3", "bf16"); allocates the split-operand scratch the bf16 settings need."""
+    _check_cuda(A, B)
+    planes, rows, K = A.shape
+    N = B.shape[1]
+    lib = _lib.load()
+    dt = _lib.DTYPES[dtype]
+    nb = lib.afi_gemm_nt_scratch_bytes(planes, N, K, dt)
+    scratch = torch.empty(max(int(nb), 16), device=A.device, dtype=torch.uint8)
+    if out is None:
+        out = torch.empty((planes, rows, N), device=A.device, dtype=torch.float32)
+    _lib.check(lib.afi_gemm_nt(_p(A), _p(B), _p(out), planes, rows, N, K, dt, _p(scratch), nb, stream_ptr()), "afi_gemm_nt")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ convs
 OP_SCRATCH_FLOATS = 100 * 1024 * 1024          # 400 MB: 4 slabs of the largest map that is split (1536 tiles of 128x128)
 

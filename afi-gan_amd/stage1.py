@@ -286,9 +286,10 @@ class Stage1Step:
             call("afi_ctx_set_wino_weight_cache", bx.handle, C.c_void_p(None), 0)
         self.iter += 1
 
-    # per context: the forward one peaks in the G phase (D's three layers at both tilings, 16 + 36 planes of 1.70 M floats = 89 M, + G's
-    # forward transforms and packed conv-transpose weight when G is recomputed: 104 M), the backward one in the D phase (the same 89 M)
-    WINO_WCACHE_FLOATS = 112 * 1024 * 1024
+    # per context: the forward one peaks in the G phase (D's three layers at both tilings, 16 + 36 planes of 1.70 M elements = 89 M, + G's
+    # forward transforms and packed conv-transpose weight when G is recomputed: 104 M), the backward one in the D phase (the same 89 M);
+    # under the bf16 settings an element is cached as three bf16 parts (1.5 floats: the DMA GEMM's pre-split operand) -> 156 M floats
+    WINO_WCACHE_FLOATS = 168 * 1024 * 1024
     WINO_WGACC_FLOATS = 100 * 1024 * 1024
 
     def _run_phases(self, nlev, lrs, hrs, lptr, lr_now, dev):

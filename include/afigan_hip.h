@@ -93,8 +93,13 @@ int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
 int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype);
 int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over
- * `planes` groups; rows_per_plane % 128 == 0, N % 128 == 0, K % 32 == 0 (else AFI_ERR_UNSUPPORTED); fp32 in memory for every dtype. */
-int afi_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int dtype, void* stream);
+ * `planes` groups; rows_per_plane % 128 == 0, N % 128 == 0, K % 32 == 0 (else AFI_ERR_UNSUPPORTED); fp32 in memory for every dtype.
+ * Under the bf16 settings the B operand (inside the library: the transformed weights, shared by every row tile of a plane) is first split
+ * into bf16 parts in the order the kernel's LDS-DMA stages it; `scratch` (afi_gemm_nt_scratch_bytes; 0 for fp32) receives that image.
+ * The library never allocates: too little scratch is AFI_ERR_WORKSPACE. */
+long long afi_gemm_nt_scratch_bytes(int planes, int N, int K, int dtype);
+int afi_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int dtype, void* scratch,
+                long long scratch_bytes, void* stream);
 /* ... and the weight-gradient form  dU[g][m][n] += sum_k Q[g][k][m] * V[g][k][n]  (both operands k-slow; rows_per_plane = K per plane,
  * % 32 == 0; M % 128 == 0, N % 128 == 0).  Split-K with fp32 atomics: the summation order varies run to run. */
 int afi_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int dtype, void* stream);

@@ -50,7 +50,7 @@ def test_batched_gemms(amd, dtype):
         A = torch.randn((planes, rows, K), device="cuda", generator=g)
         B = torch.randn((planes, N, K), device="cuda", generator=g)
         Cm = torch.full((planes, rows, N), float("nan"), device="cuda")
-        _lib.check(lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), planes, rows, N, K, dt, st), "afi_gemm_nt")
+        amd.ops.gemm_nt(A, B, dtype, out=Cm)
         assert _rel(Cm, torch.bmm(A.double(), B.double().transpose(1, 2))) < TOL_GEMM[dtype], (planes, rows, N, K)
     for planes, rows, M, N in ((2, 64, 128, 128), (16, 1056, 256, 384), (36, 4096, 128, 256)):
         Q = torch.randn((planes, rows, M), device="cuda", generator=g)
@@ -59,8 +59,15 @@ def test_batched_gemms(amd, dtype):
         _lib.check(lib.afi_gemm_tn(C.c_void_p(Q.data_ptr()), C.c_void_p(V.data_ptr()), C.c_void_p(dU.data_ptr()), planes, rows, M, N, dt, st), "afi_gemm_tn")
         assert _rel(dU, 1.0 + torch.bmm(Q.double().transpose(1, 2), V.double())) < TOL_GEMM[dtype], (planes, rows, M, N)
     # shapes the tile-aligned kernels do not take are refused, not mangled
-    assert lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), 1, 100, 128, 32, dt, st) == 2
-    assert lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), 1, 128, 128, 32, 2, st) == 1
+    sc = torch.empty(1 << 20, device="cuda", dtype=torch.uint8)
+    ptrs = (C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()))
+    assert lib.afi_gemm_nt(*ptrs, 1, 100, 128, 32, dt, C.c_void_p(sc.data_ptr()), sc.numel(), st) == 2
+    assert lib.afi_gemm_nt(*ptrs, 1, 128, 128, 32, 2, C.c_void_p(sc.data_ptr()), sc.numel(), st) == 1
+    if dtype != "fp32":                                     # the bf16 settings need the split-operand scratch: refused without it, never allocated inside
+        assert lib.afi_gemm_nt_scratch_bytes(1, 128, 32, dt) == 128 * 32 * 2 * {"bf16x6": 3, "bf16x3": 2, "bf16": 1}[dtype]
+        assert lib.afi_gemm_nt(*ptrs, 1, 128, 128, 32, dt, None, 0, st) == 4
+    else:
+        assert lib.afi_gemm_nt_scratch_bytes(1, 128, 32, dt) == 0
 
 
 @pytest.mark.parametrize("kind", ["normal", "positive_large_mean", "wide_dynamic_range", "tiny_values", "sparse_post_relu"])
@@ -85,8 +92,7 @@ def test_bf16x6_is_fp32_grade_on_hard_operands(amd, kind):
     ref = torch.bmm(A.double(), B.double().transpose(1, 2))
     err = {}
     for dt in ("fp32", "bf16x6"):
-        Cm = torch.empty((planes, rows, N), device="cuda")
-        _lib.check(lib.afi_gemm_nt(C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), planes, rows, N, K, _lib.DTYPES[dt], st), "afi_gemm_nt")
+        Cm = amd.ops.gemm_nt(A, B, dt)
         err[dt] = ((Cm.double() - ref).abs().max() / ref.abs().max()).item()
     assert err["bf16x6"] <= 1.5 * err["fp32"] + 1e-7, (kind, err)
     assert err["fp32"] < 5e-6, (kind, err)

@@ -284,13 +284,14 @@ def test_stage1_one_stream_and_two_stream_steps_agree(amd, overlap_d, overlap_g)
         assert step.ctx.handle.value != step.bctx.handle.value       # one context per stream (include/afigan_hip.h)
         step.run_step(lrs, hrs)
         grads = (step.d_opt.flat_grad.detach().clone(), step.g_opt.flat_grad.detach().clone())
-        step.run_step(lrs, hrs)
+        params = torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])     # after ONE step
+        step.run_step(lrs, hrs)          # (a second step's gradients sit behind LeakyReLU masks of moved weights: compared through the losses only)
         torch.cuda.synchronize()
-        return grads, step.metrics(), torch.cat([p.detach().reshape(-1) for p in list(G.parameters()) + list(D.parameters())])
+        return grads, step.metrics(), params
     (d0, g0), m0, p0 = run(False, False)
     (d1, g1), m1, p1 = run(overlap_d, overlap_g)
     assert float((d1 - d0).norm() / d0.norm()) < 1e-5 and float((g1 - g0).norm() / g0.norm()) < 1e-5
-    assert float((p1 - p0).norm() / p0.norm()) < 1e-5                  # (two runs of ONE schedule differ by 1.6e-6: atomics order after two lr = 0.05 steps)
+    assert float((p1 - p0).norm() / p0.norm()) < 1e-6
     for k, v in m0.items():
         assert abs(m1[k] - v) <= 2e-4 * abs(v) + 1e-6, (k, m1[k], v)
 

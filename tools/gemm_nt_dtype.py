@@ -17,7 +17,9 @@ def run(planes, rows, N, K, iters=20):
     ref = torch.bmm(A[:2, :256].double(), B[:2].double().transpose(1, 2))
     st = amd.ops.stream_ptr()
     for name, dt in _lib.DTYPES.items():
-        args = (C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), planes, rows, N, K, dt, st)
+        nb = _lib.load().afi_gemm_nt_scratch_bytes(planes, N, K, dt)
+        sc = torch.empty(max(int(nb), 16), device="cuda", dtype=torch.uint8)
+        args = (C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), planes, rows, N, K, dt, C.c_void_p(sc.data_ptr()), nb, st)
         Cm.zero_()
         _lib.check(_lib.load().afi_gemm_nt(*args), "afi_gemm_nt")
         torch.cuda.synchronize()
