@@ -192,7 +192,10 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
 //   [plane][N / 128][K / 32][part][128 x 64 bytes], chunk ch of row r at ch ^ ((-(r >> 2)) & 3) (conflict-free for the 16x16x32 fragment
 //   reads) -- written once per weight transform by afi_split_bf16_tiles_kernel, so a stage of it is a linear copy.
 //   One LDS buffer (16 KB + NPART x 8 KB = 40 KB for the six-product form), two barriers per stage, the next stage's DMA issued behind the
-//   second barrier: its latency is covered by the other resident blocks (four per CU at <= 128 registers).
+//   second barrier: its latency is covered by the other resident blocks (four per CU at <= 128 registers).  Measured and rejected: two
+//   buffers with one barrier per stage and the next stage's DMA in flight under the MFMAs, at two blocks per CU: 8-10 % slower on every
+//   shape (profiles/r03/gemm_nt_dma_single_vs_double_buffer.log) -- the fourth and third resident block are worth more than the overlap
+//   inside one block, as with the register-staged kernels of rounds 1 and 2.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int afi_bf16_tile16_off(int row, int kq /* float4 column 0..7 */) {
     return row * 64 + ((((kq >> 1) ^ (-(row >> 2))) & 3) << 4) + ((kq & 1) << 3);
@@ -231,12 +234,13 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_bf16_dma_kernel(const A
     const long long a_step = 32LL * p.K;                     // 32 rows per DMA instruction
     const unsigned char* b_src = (const unsigned char*)p.B + (((long long)plane * ntile_n + tile_n) * nK) * (long long)(NPART * TILE_B) + 16 * tid;
     auto issue = [&](int kc) {
+        unsigned char* dst = smem_b;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr)(a_src + i * a_step + kc * BK), (lptr)(smem_b + (4 * i + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(a_src + i * a_step + kc * BK), (lptr)(dst + (4 * i + wave) * 1024), 16, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2 * NPART; ++i)
-            __builtin_amdgcn_global_load_lds((gptr)(b_src + (long long)kc * (NPART * TILE_B) + i * 4096), (lptr)(smem_b + OFF_B + (4 * i + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(b_src + (long long)kc * (NPART * TILE_B) + i * 4096), (lptr)(dst + OFF_B + (4 * i + wave) * 1024), 16, 0, 0);
     };
     f32x4 acc[MI][NI];
 #pragma unroll
@@ -253,12 +257,13 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_bf16_dma_kernel(const A
     issue(0);
     for (int kc = 0; kc < nK; ++kc) {
         __syncthreads();                                     // (vmcnt(0) in front of the barrier: the stage has landed)
+        const unsigned char* sm = smem_b;
         bf16x8 ah[MI], am[MI], al[MI];                       // (SPLIT 3: "am" is the second part)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             // chunks 2q and 2q + 1 of the row: the swizzle never touches bit 0 ... of the PAIR index; bit 0 of the chunk may flip
-            const f32x4 c0 = *(const f32x4*)(smem_b + fa_off[mi]);
-            const f32x4 c1 = *(const f32x4*)(smem_b + (fa_off[mi] ^ 16));
+            const f32x4 c0 = *(const f32x4*)(sm + fa_off[mi]);
+            const f32x4 c1 = *(const f32x4*)(sm + (fa_off[mi] ^ 16));
             ah[mi] = afi_pack8_bf16(c0, c1);
             if (SPLIT >= 3) {
                 const f32x4 r0 = afi_bf16_residual(c0), r1 = afi_bf16_residual(c1);
@@ -269,9 +274,9 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_bf16_dma_kernel(const A
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             bf16x8 bh, bm, bl;
-            bh = *(const bf16x8*)(smem_b + fb_off[ni]);
-            if (SPLIT >= 3) bm = *(const bf16x8*)(smem_b + TILE_B + fb_off[ni]);
-            if (SPLIT == 6) bl = *(const bf16x8*)(smem_b + 2 * TILE_B + fb_off[ni]);
+            bh = *(const bf16x8*)(sm + fb_off[ni]);
+            if (SPLIT >= 3) bm = *(const bf16x8*)(sm + TILE_B + fb_off[ni]);
+            if (SPLIT == 6) bl = *(const bf16x8*)(sm + 2 * TILE_B + fb_off[ni]);
             if (SPLIT == 6) {                                // smallest terms first; consecutive MFMAs go to different accumulators
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
