@@ -118,26 +118,42 @@ int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout,
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
+// The BatchNorm affine z = ((x - mean) * invstd) * gamma + beta with every operation rounded on its own (no FMA contraction): the forward's
+// activation and the backward's recomputed LeakyReLU' mask must take the SAME side of zero for every element, so both evaluate this one
+// function on the same fp32 operands (and a host restatement in plain fp32 tensor ops reproduces it bit for bit: tests/d_parity_util.py).
+__device__ __forceinline__ f32x4 afi_bn_affine(f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
+#pragma clang fp contract(off)
+    f32x4 t = v - mu;
+    t = t * is;
+    t = t * ga;
+    return t + be;
+}
+
 // ---------------------------------------------------------------- per-channel reductions over pixels
 // Generic two-value column reduction over a dense [P][C] matrix (ld = C, C % 4 == 0).
 //   MODE 0: s0 = sum (x - K),      s1 = sum (x - K)^2         K = x[0][c]      (BatchNorm statistics)
 //   MODE 1: s0 = sum g,            s1 = sum g * xhat          xhat = (x-mean)*invstd  (BatchNorm backward)
 //   MODE 2: s0 = sum g             (bias gradient)
+//   MODE 3: MODE 1 with g first multiplied by the LeakyReLU' mask of the normalised value (slope where z <= 0): the gradient arrives
+//           w.r.t. the ACTIVATION and the mask is recomputed from x here, instead of being streamed through the producing conv's epilogue
 // Block = 256 threads = 32 channel quads x 8 pixel lanes; grid = (C/128, chunks). Partials [chunks][2][C].
 #define AFI_RED_MAX_CHUNKS 256
 template <int MODE>
 __global__ __launch_bounds__(256) void afi_colred_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                 long long P, int C, long long ld, int rows_per_chunk, float* __restrict__ partial) {
+                                                                 long long P, int C, long long ld, int rows_per_chunk, float* __restrict__ partial,
+                                                                 const float* __restrict__ gamma = nullptr, const float* __restrict__ beta = nullptr,
+                                                                 float slope = 1.f) {
     __shared__ f32x4 red[2][8][32];
     const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c = blockIdx.x * 128 + cq * 4;
     const bool cok = c < C;
     f32x4 s0 = {0, 0, 0, 0}, s1 = {0, 0, 0, 0};
     if (cok) {
-        f32x4 k = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+        f32x4 k = {0, 0, 0, 0}, mu = {0, 0, 0, 0}, is = {0, 0, 0, 0}, ga = {0, 0, 0, 0}, be = {0, 0, 0, 0};
         if (MODE == 0) k = *(const f32x4*)(x + c);
-        if (MODE == 1) { mu = *(const f32x4*)(mean + c); is = *(const f32x4*)(invstd + c); }
+        if (MODE == 1 || MODE == 3) { mu = *(const f32x4*)(mean + c); is = *(const f32x4*)(invstd + c); }
+        if (MODE == 3) { ga = *(const f32x4*)(gamma + c); be = *(const f32x4*)(beta + c); }
         const long long r0 = (long long)blockIdx.y * rows_per_chunk;
         const long long r1 = (r0 + rows_per_chunk < P) ? r0 + rows_per_chunk : P;
         for (long long r = r0 + rl; r < r1; r += 8) {
@@ -147,6 +163,14 @@ __global__ __launch_bounds__(256) void afi_colred_partial_kernel(const float* __
             } else if (MODE == 1) {
                 f32x4 gv = *(const f32x4*)(g + r * ld + c);
                 f32x4 xh = (*(const f32x4*)(x + r * ld + c) - mu) * is;
+                s0 += gv; s1 += gv * xh;
+            } else if (MODE == 3) {
+                f32x4 gv = *(const f32x4*)(g + r * ld + c);
+                const f32x4 xv = *(const f32x4*)(x + r * ld + c);
+                const f32x4 z = afi_bn_affine(xv, mu, is, ga, be);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) gv[j] = z[j] > 0.f ? gv[j] : gv[j] * slope;
+                const f32x4 xh = (xv - mu) * is;
                 s0 += gv; s1 += gv * xh;
             } else {
                 s0 += *(const f32x4*)(g + r * ld + c);
@@ -284,7 +308,7 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     auto apply = [slope](f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
-        v = (v - mu) * is * ga + be;
+        v = afi_bn_affine(v, mu, is, ga, be);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
         return v;
@@ -322,36 +346,45 @@ __global__ void afi_bn_bwd_finalize_kernel(const float* __restrict__ partial, in
     if (dgamma) dgamma[c] += gscale * s1;
 }
 // dx = gamma * invstd * (g - sum_g/P - xhat * sum_gx/P)   (in place on g allowed)
+// MASK: g is the gradient w.r.t. the activation; it is first multiplied by the LeakyReLU' mask recomputed from x (see MODE 3 above)
+template <bool MASK>
 __global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dx,
                                         const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                        const float* __restrict__ sums, long long P, int C) {
+                                        const float* __restrict__ sums, long long P, int C, const float* __restrict__ beta, float slope) {
     const long long total4 = P * C / 4;
     const int C4 = C / 4;
     const float inv_n = 1.f / (float)P;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    auto apply = [inv_n](f32x4 gv, f32x4 xv, f32x4 mu, f32x4 is, f32x4 ga, f32x4 sg, f32x4 sgx) {
+    auto apply = [inv_n, slope](f32x4 gv, f32x4 xv, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be, f32x4 sg, f32x4 sgx) {
+        if (MASK) {
+            const f32x4 z = afi_bn_affine(xv, mu, is, ga, be);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = z[j] > 0.f ? gv[j] : gv[j] * slope;
+        }
         const f32x4 xh = (xv - mu) * is;
         return ga * is * (gv - sg * inv_n - xh * (sgx * inv_n));
     };
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if (stride % C4 == 0) {          // one channel group per thread: parameters hoisted, two element pairs in flight (see bn_apply)
         const int c = (int)(i % C4) * 4;
         const f32x4 mu = *(const f32x4*)(mean + c), is = *(const f32x4*)(invstd + c), ga = *(const f32x4*)(gamma + c);
+        const f32x4 be = MASK ? *(const f32x4*)(beta + c) : zero;
         const f32x4 sg = *(const f32x4*)(sums + c), sgx = *(const f32x4*)(sums + C + c);
         for (; i + stride < total4; i += 2 * stride) {
             const f32x4 g0 = __builtin_nontemporal_load((const f32x4*)(g + i * 4)), x0 = __builtin_nontemporal_load((const f32x4*)(x + i * 4));
             const f32x4 g1 = __builtin_nontemporal_load((const f32x4*)(g + (i + stride) * 4)), x1 = __builtin_nontemporal_load((const f32x4*)(x + (i + stride) * 4));
-            *(f32x4*)(dx + i * 4) = apply(g0, x0, mu, is, ga, sg, sgx);
-            *(f32x4*)(dx + (i + stride) * 4) = apply(g1, x1, mu, is, ga, sg, sgx);
+            *(f32x4*)(dx + i * 4) = apply(g0, x0, mu, is, ga, be, sg, sgx);
+            *(f32x4*)(dx + (i + stride) * 4) = apply(g1, x1, mu, is, ga, be, sg, sgx);
         }
         for (; i < total4; i += stride)
-            *(f32x4*)(dx + i * 4) = apply(*(const f32x4*)(g + i * 4), *(const f32x4*)(x + i * 4), mu, is, ga, sg, sgx);
+            *(f32x4*)(dx + i * 4) = apply(*(const f32x4*)(g + i * 4), *(const f32x4*)(x + i * 4), mu, is, ga, be, sg, sgx);
         return;
     }
     for (; i < total4; i += stride) {
         const int c = (int)(i % C4) * 4;
         *(f32x4*)(dx + i * 4) = apply(*(const f32x4*)(g + i * 4), *(const f32x4*)(x + i * 4), *(const f32x4*)(mean + c), *(const f32x4*)(invstd + c),
-                                      *(const f32x4*)(gamma + c), *(const f32x4*)(sums + c), *(const f32x4*)(sums + C + c));
+                                      *(const f32x4*)(gamma + c), MASK ? *(const f32x4*)(beta + c) : zero, *(const f32x4*)(sums + c), *(const f32x4*)(sums + C + c));
     }
 }
 // bias gradient finalize: db += alpha * sum
@@ -392,7 +425,7 @@ int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* 
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((afi_colred_partial_kernel<0>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, P, C, (long long)C, rpc, scratch);
+                       (const float*)nullptr, (const float*)nullptr, P, C, (long long)C, rpc, scratch, (const float*)nullptr, (const float*)nullptr, 1.f);
     hipLaunchKernelGGL(afi_bn_stats_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, x, P, C, mean, invstd,
                        var_out, running_mean, running_var, num_batches_tracked, eps, momentum);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
@@ -403,21 +436,26 @@ int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const
     hipLaunchKernelGGL(afi_bn_apply_lrelu_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, x, y, mean, invstd, gamma, beta, P, C, slope);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
+// mask_beta != nullptr: g is the gradient w.r.t. lrelu_slope(BN(x)) and the LeakyReLU' mask is recomputed from x (mask_beta = the norm's beta)
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma,
-                      float* dgamma, float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st) {
+                      float* dgamma, float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st, const float* mask_beta,
+                      float slope) {
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     float* sums = scratch + (long long)AFI_RED_MAX_CHUNKS * 4 * C;
-    hipLaunchKernelGGL((afi_colred_partial_kernel<1>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch);
+    const dim3 rgrid(afi_cdiv(C, 128), chunks), agrid(afi_ew_grid(P * C / 4));
+    if (mask_beta) hipLaunchKernelGGL((afi_colred_partial_kernel<3>), rgrid, dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch, gamma, mask_beta, slope);
+    else hipLaunchKernelGGL((afi_colred_partial_kernel<1>), rgrid, dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch, (const float*)nullptr, (const float*)nullptr, 1.f);
     hipLaunchKernelGGL(afi_bn_bwd_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, C, gscale, dgamma, dbeta, sums);
-    hipLaunchKernelGGL(afi_bn_bwd_apply_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C);
+    if (mask_beta) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, mask_beta, slope);
+    else hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st) {
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     hipLaunchKernelGGL((afi_colred_partial_kernel<2>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, (const float*)nullptr, g,
-                       (const float*)nullptr, (const float*)nullptr, P, C, ld, rpc, scratch);
+                       (const float*)nullptr, (const float*)nullptr, P, C, ld, rpc, scratch, (const float*)nullptr, (const float*)nullptr, 1.f);
     hipLaunchKernelGGL(afi_colsum_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, C, alpha, db);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }

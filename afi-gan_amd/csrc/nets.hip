@@ -31,7 +31,8 @@ int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* 
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                               long long P, int C, hipStream_t st, float slope = AFI_LRELU_SLOPE);
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
-                      float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st);
+                      float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st, const float* mask_beta = nullptr,
+                      float slope = AFI_LRELU_SLOPE);
 int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st);
 int afi_launch_stencil9_sum(const float* d9, int ld, const float* bias, float* out, int N, int H, int W, hipStream_t st);
 int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, int H, int W, hipStream_t st);
@@ -1277,6 +1278,8 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
     float* red = scratch + s.o_red;
     float* red2 = scratch + s.o_red2;
     float* dd9 = scratch + s.o_dd9;
+    // (round 3, re-measured with the DMA GEMM: forking the weight gradients of LARGE maps onto the side stream too: 113.2 vs 112.5 ms per step,
+    //  two A/B pairs on one box -- the chip has no room left beside the GEMMs)
     Fork fk(cx, st, P <= kSideStreamMaxPixels);
     hipStream_t sd = fk.side;                              // weight / bias gradients run beside the data-gradient chain
     const int F3 = prm->F[3];
@@ -1294,17 +1297,19 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
         AfiPixGemm g = pix_default(N, H, W);
         g.ntaps = 1; g.a_sgn = -1; g.Ck = 9; g.Ncols = F3; g.CoutPhase = F3;
         g.A = dense_view(dd9, H, W, 16); g.B = prm->w3; g.b_sRow = F3; g.b_sTap = 0;
-        g.O = dense_view(scratch + s.o_g[2], H, W, F3);
-        g.Z = y2; g.z_lo = 0; g.z_hi = F3;
+        g.O = dense_view(scratch + s.o_g[2], H, W, F3);      // gradient w.r.t. the ACTIVATION y2: its LeakyReLU' mask is applied by the BN backward
         AFI_TRY(PG(g, 1));
     }
     // ---- conv + BN + LReLU blocks, last first
     for (int n = 2; n >= 0; --n) {
         const int ci = prm->F[n], co = prm->F[n + 1];
-        float* g_ = scratch + s.o_g[n];               // d(BN output), already through the LReLU mask
+        float* g_ = scratch + s.o_g[n];               // d(activation of block n)
         const float* c = ws + l.o_c[n];
+        // LeakyReLU' and BatchNorm backward in one: the mask is recomputed from the saved conv output (the same pinned affine the forward
+        // evaluated: bit-identical decisions) inside the two passes that read it anyway, instead of streaming the activation through
+        // the producing data gradient's output transform as a third operand
         AFI_TRY(afi_launch_bn_bwd(g_, c, g_, ws + l.o_mean[n], ws + l.o_invstd[n], prm->gamma[n], gr->gamma[n], gr->beta[n], 1.f, P, co,
-                                  red, st));          // in place: g_ = d(conv output)
+                                  red, st, prm->beta[n], AFI_LRELU_SLOPE));          // in place: g_ = d(conv output)
         fk.after_main();                              // g_ = d(conv output) is complete
         // d(loss)/d(bias) of a conv that feeds a train-mode BatchNorm is EXACTLY zero: g_ = BN backward's dx, whose sum over the pixels
         // of a channel vanishes identically (the BN output does not change when a constant is added to its input).  The reference
@@ -1316,12 +1321,10 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
         if (gr->w[n] && s.n_wino > 0) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd));
         else if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0 && s.n_wino > 0) {
-            AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), xin, scratch + s.o_wino,
+            AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), null_view(), scratch + s.o_wino,
                               s.n_wino, part_, part_n_, st));
         } else if (n > 0) {
-            AfiPixGemm g = conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(scratch + s.o_g[n - 1], H, W, ci));
-            g.Z = xin; g.z_lo = 0; g.z_hi = ci;
-            AFI_TRY(PG(g, 1));
+            AFI_TRY(PG(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(scratch + s.o_g[n - 1], H, W, ci)), 1));
         } else if (dx && s.n_wino > 0) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(dx, H, W, ci), null_view(), scratch + s.o_wino, s.n_wino, part_,
                               part_n_, st));

@@ -103,13 +103,41 @@ class DProbe:
         return g, c
 
     def inject_fp64_forward(self):
-        """overwrite the saved conv outputs, activations and statistics with the fp64 forward's (rounded to fp32): identical masks"""
+        """overwrite the saved conv outputs, activations and statistics with the fp64 forward's (rounded to fp32): identical masks.
+        The backward recomputes a LeakyReLU' mask from the saved conv output as sign(((c - mean) * invstd) * gamma + beta), every operation
+        rounded to fp32 on its own (csrc/elementwise.hip: afi_bn_affine); for the handful of elements where that fp32 value lands on the
+        other side of zero than the fp64 pre-activation, the injected c is moved by single ulps until it does not (a < 1e-6 relative change
+        of one input element), so the masks are the reference's BY CONSTRUCTION.  Returns the number of elements nudged per layer."""
+        nudged = []
         for n in range(3):
+            pre = f"Discriminators.0.{n}.0.norm"
             c, y, mean, invstd = self.saved(n)
-            c.copy_(self.r64["c"][n].detach().float().cuda())
+            c32 = self.r64["c"][n].detach().float().cuda()
+            m32 = self.r64["mean"][n].float().cuda()
+            i32 = torch.rsqrt(self.r64["var"][n] + orc.BN_EPS).float().cuda()
+            ga, be = self.dp[pre + ".weight"].float().cuda(), self.dp[pre + ".bias"].float().cuda()
+            want = (self.r64["y"][n].detach() > 0).cuda()
+            bc = lambda v: v.view(1, -1, 1, 1)
+            up = (bc(ga) > 0)                                  # z grows with c where gamma > 0 (invstd > 0)
+            count = 0
+            for it in range(200):
+                z = ((c32 - bc(m32)) * bc(i32)) * bc(ga) + bc(be)
+                bad = (z > 0) != want
+                nb = int(bad.sum())
+                if it == 0:
+                    count = nb
+                if nb == 0:
+                    break
+                toward = torch.where(want == up, torch.full_like(c32, float("inf")), torch.full_like(c32, float("-inf")))
+                c32 = torch.where(bad, torch.nextafter(c32, toward), c32)
+            else:
+                raise AssertionError(f"layer {n}: could not make {nb} recomputed masks agree with the fp64 forward")
+            nudged.append(count)
+            c.copy_(c32)
             y.copy_(self.r64["y"][n].detach().float().cuda())
-            mean.copy_(self.r64["mean"][n].float().cuda())
-            invstd.copy_(torch.rsqrt(self.r64["var"][n] + orc.BN_EPS).float().cuda())
+            mean.copy_(m32)
+            invstd.copy_(i32)
+        return nudged
 
     def backward(self):
         """afi_discriminator_bwd on the workspace as it stands; returns (dx, {name: grad}) as logical tensors"""
