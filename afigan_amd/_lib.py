@@ -61,6 +61,8 @@ SIGNATURES = {
     "afi_ctx_set_op_scratch": (_i, [_vp, _vp, _ll]),
     "afi_ctx_set_compute_dtype": (_i, [_vp, _i]),
     "afi_ctx_get_compute_dtype": (_i, [_vp]),
+    "afi_ctx_set_option": (_i, [_vp, _i, _ll]),
+    "afi_ctx_get_option": (_ll, [_vp, _i]),
     "afi_gemm_nt_scratch_bytes": (_ll, [_i, _i, _i, _i]),
     "afi_gemm_nt": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _ll, _vp]),
     "afi_gemm_tn": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
@@ -173,6 +175,8 @@ CTX_FIRST = frozenset(n for n, (_, a) in SIGNATURES.items() if n.startswith(("af
 
 
 DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}             # AFI_DTYPE_* of include/afigan_hip.h
+OPTIONS = {"winograd": 0, "winograd_f4_backward": 1, "winograd_f4_forward": 2, "bn_stats_fp64": 3, "d_winograd_min_pixels": 4,
+           "g_winograd_min_pixels": 5, "g_smallmap_max_pixels": 6, "g_grouped_wgrad_max_pixels": 7}      # AFI_OPT_*
 
 
 class Ctx:
@@ -196,6 +200,13 @@ class Ctx:
             raise AfiError(f"compute dtype must be one of {sorted(DTYPES)}, got {dtype!r}")
         check(load().afi_ctx_set_compute_dtype(self.handle, DTYPES[dtype]), "afi_ctx_set_compute_dtype")
         self.dtype = dtype
+
+    def set_option(self, name, value):
+        """Algorithm option of this context (OPTIONS / AFI_OPT_* of include/afigan_hip.h); the library reads no environment variable."""
+        check(load().afi_ctx_set_option(self.handle, OPTIONS[name], int(value)), f"afi_ctx_set_option({name})")
+
+    def get_option(self, name):
+        return int(load().afi_ctx_get_option(self.handle, OPTIONS[name]))
 
     def __del__(self):
         try:

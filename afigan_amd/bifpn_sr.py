@@ -31,6 +31,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .fpn_sr import ShapeSpec, _dense_pm, _LateralMergeFn
+from .config import afi_freeze
 from .generator_rdb import Generator
 
 __all__ = ["BiFPN_AFIGAN", "LastLevelP6P7"]
@@ -207,6 +208,7 @@ class BiFPN_AFIGAN(nn.Module):
 
     def __init__(self, bottom_up, in_features, out_channels, fpn_repeat=7, norm="SyncBN", top_block=None, fuse_type="sum", cfg=None):
         super().__init__()
+        self._norm = norm
         assert fuse_type in {"avg", "sum"}
         if top_block is None or getattr(top_block, "num_levels", 0) != 2:
             raise _lib.AfiError("BiFPN_AFIGAN needs the two-level top block (LastLevelP6P7), as build_swint_bifpn_sr_backbone passes")
@@ -224,7 +226,7 @@ class BiFPN_AFIGAN(nn.Module):
             assert s == 2 * in_strides[i - 1], f"Strides {s} {in_strides[i - 1]} are not log2 contiguous"
         self.before_bifpn = _BeforeBiFPN(out_channels, in_channels, top_block)
         self.srf_module = Generator(in_channels=out_channels, n_residual_dense_blocks=3)       # bifpn_sr.py:270
-        if getattr(getattr(cfg, "MODEL", None), "AFI_FREEZE", False):
+        if afi_freeze(cfg):
             for p in self.srf_module.parameters():
                 p.requires_grad = False
         for l in range(self.N_LAYERS):
@@ -275,6 +277,16 @@ class BiFPN_AFIGAN(nn.Module):
         self._folded, self._folded_key = f, key
         return f
 
+    def _check_syncbn(self):
+        """norm="SyncBN" (the reference default, bifpn_sr.py:210) exchanges batch statistics between ranks; this path computes them per
+        process.  With one rank the two are the same function; with more they are not, so a TRAINING-mode forward under an initialised
+        process group of more than one rank is refused instead of silently differing (the reference ships no multi-GPU recipe for this
+        backbone; pass norm="BN" to train with per-rank statistics on purpose)."""
+        if self._norm == "SyncBN" and self.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_world_size() > 1:
+            raise _lib.AfiError('BiFPN_AFIGAN(norm="SyncBN") in training mode with world_size > 1: cross-rank batch statistics are not '
+                                'implemented on this path; construct it with norm="BN" for per-rank statistics')
+
     # ------------------------------------------------------------------------------------------------ forward (inference)
     def forward(self, x):
         # the interpolator runs several times on one set of weights: their transformed / packed forms are computed once
@@ -284,10 +296,12 @@ class BiFPN_AFIGAN(nn.Module):
         with ops.weight_transform_cache(first.device):
             return self._forward_impl(x)
 
-    def _forward_train(self, x):
+    def _forward_train(self, x, bottom_up_features=None):
         """The same seven layers with nothing folded, every piece differentiable (see the module docstring)."""
         bb = self.before_bifpn
-        bottom_up_features = self.bottom_up(x)
+        if bottom_up_features is None:
+            bottom_up_features = self.bottom_up(x)
+        self._check_syncbn()
         c3, c4, c5 = [bottom_up_features[k] for k in self.in_features]       # (the Functions below make their own pixel-major copies)
 
         def lat(t, seq):
@@ -319,12 +333,22 @@ class BiFPN_AFIGAN(nn.Module):
             feats = (p3_up, p4_out, p5_out, p6_out, p7_out)
         return dict(zip(self._out_features, feats))
 
+    def _wants_graph(self, feats):
+        """The differentiable path is needed whenever autograd could ask for a gradient: training mode, or grad mode on with a bottom-up
+        feature or ANY parameter of this module requiring grad (eval-mode fine-tuning on frozen statistics, a trainable bottom-up whose
+        input image does not require grad).  Decided on the bottom-up OUTPUTS, not on the raw input."""
+        if self.training:
+            return True
+        if not torch.is_grad_enabled():
+            return False
+        return any(t.requires_grad for t in feats) or any(p.requires_grad for p in self.parameters())
+
     def _forward_impl(self, x):
-        if self.training or torch.is_grad_enabled() and any(t.requires_grad for t in (x.values() if isinstance(x, dict) else [x])):
-            return self._forward_train(x)
+        bottom_up_features = self.bottom_up(x)
+        if self._wants_graph([bottom_up_features[k] for k in self.in_features]):
+            return self._forward_train(x, bottom_up_features)
         with torch.no_grad():
             f = self._prepare()
-            bottom_up_features = self.bottom_up(x)
             c3, c4, c5 = [ops.pixel_major(bottom_up_features[k]) for k in self.in_features]
 
             def lat(t, name):

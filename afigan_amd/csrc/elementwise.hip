@@ -412,13 +412,12 @@ static unsigned afi_ew_grid(long long work_items) {
 
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out,
                         float* running_mean, float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked, float eps,
-                        float momentum) {
+                        float momentum, bool fp64) {
     if (eps < 0.f) eps = AFI_BN_EPS;                        // negative = torch's BatchNorm2d defaults (the discriminator's norms)
     if (momentum < 0.f) momentum = AFI_BN_MOMENTUM;
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
-    static const int stats64 = getenv("AFI_BN_STATS_F64") ? atoi(getenv("AFI_BN_STATS_F64")) : 1;      // 0: the fp32 one-pass form (A/B only)
-    if (stats64 && (((uintptr_t)scratch) & 7) == 0) {
+    if (fp64 && (((uintptr_t)scratch) & 7) == 0) {         // (fp64 = false: the fp32 one-pass form, AFI_OPT_BN_STATS_FP64 = 0)
         hipLaunchKernelGGL(afi_bn_stats_partial_kernel, dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, P, C, (long long)C, rpc, (double*)scratch);
         hipLaunchKernelGGL(afi_bn_stats_finalize64_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, (const double*)scratch, chunks, x, P, C, mean,
                            invstd, var_out, running_mean, running_var, num_batches_tracked, eps, momentum);

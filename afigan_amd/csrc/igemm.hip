@@ -695,10 +695,6 @@ static bool afi_opt_in_big_lds(const void* fn) {
     done.insert({dev, fn});
     return true;
 }
-static int afi_env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 template <int BM, int BN, int WM, int WN, bool B_RC, int BK = AFI_BK, bool HALO = false, bool GTAP = false>
 static int launch_pix(const AfiPixGemm& p, hipStream_t st) {
     const long long M = (long long)p.N * p.H * p.W;
@@ -841,8 +837,7 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     const bool smallM = (long long)afi_cdiv(M, 128) * afi_cdiv(p.Ncols, 128) < 128;
     // small maps (csrc/smallmap.hip): long K -> the stream-K kernel (equal MFMA count per CU whatever the shape); short K (<= 16
     // stages, e.g. the 32-channel data gradients of the dense blocks) -> ONE launch of whole tiles, no split and no second pass
-    static const int sk_on = afi_env_int("AFI_SK", 1);
-    if (sk_on && smallM && p.b_sImg == 0) {
+    if (smallM && p.b_sImg == 0) {
         ProfScope prof(st, 15, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
         prof.m = M; prof.n = p.Ncols; prof.k = p.ntaps * p.nKphase * p.Ck;
         const int rc = afi_launch_pix_gemm_sk(p, b_rc, st);
@@ -850,9 +845,8 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
         prof.cancel();
     }
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work
-    static const int halo_on = afi_env_int("AFI_HALO", 1);
     const long long padded = (long long)p.N * afi_cdiv(p.H, AFI_HALO_TY) * AFI_HALO_TY * afi_cdiv(p.W, AFI_HALO_TX) * AFI_HALO_TX;
-    const bool halo = halo_on && p.ntaps == 9 && p.nKphase == 1 && p.a_up == 1 && !smallM && p.Ncols > 64 && padded * 100 <= M * 112;
+    const bool halo = p.ntaps == 9 && p.nKphase == 1 && p.a_up == 1 && !smallM && p.Ncols > 64 && padded * 100 <= M * 112;
     if (!b_rc) {
         if (p.Ncols <= 32) return launch_pix<128, 32, 4, 1, false>(p, st);
         if (p.Ncols <= 64) return smallM ? launch_pix<64, 64, 2, 2, false>(p, st) : launch_pix<128, 64, 2, 2, false>(p, st);
@@ -883,8 +877,7 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
         // Balance: the split is free here (partial sums meet in atomics), so pick the one whose block count fills whole
         // rounds of the chip's resident slots (256 CUs x 3 blocks): 2-6 rounds, best fill, fewest splits on ties.  "Cover the chip
         // ~4x" alone left 1.4-1.5 rounds for every big layer (D1: 288 tiles x 4 = 1152 blocks on 768 slots).
-        static const int bal = afi_env_int("AFI_WG_BAL", 1);
-        if (bal && BM == 128) {
+        if (BM == 128) {
             const long long slots = 768;
             double best = -1.0; int best_s = 0;
             for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {

@@ -27,7 +27,7 @@ int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStrea
 int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st);
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
                         float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked = nullptr, float eps = -1.f,
-                        float momentum = -1.f);
+                        float momentum = -1.f, bool fp64 = true);
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                               long long P, int C, hipStream_t st, float slope = AFI_LRELU_SLOPE);
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
@@ -102,23 +102,22 @@ struct WinoWgradAccum {
     int n = 0;
 };
 }  // namespace
-// arithmetic of the Winograd-domain GEMMs for new contexts and context-less calls (AFI_DEFAULT_DTYPE = 0 / 1 / 3 / 6 overrides: A/B runs)
-static int afi_default_dtype() {
-    static const int d = [] {
-        const char* v = getenv("AFI_DEFAULT_DTYPE");
-        const int x = v ? atoi(v) : AFI_DTYPE_DEFAULT;
-        return (x == AFI_DTYPE_F32 || x == AFI_DTYPE_BF16 || x == AFI_DTYPE_BF16X3 || x == AFI_DTYPE_BF16X6) ? x : AFI_DTYPE_DEFAULT;
-    }();
-    return d;
-}
+// Per-context options (afi_ctx_set_option; include/afigan_hip.h lists them).  Nothing in the library reads the environment: a choice that
+// changes numerics or scheduling is made by the caller, per context, and can be changed between calls.  Context-less calls use the defaults.
+struct AfiOptions { long long v[AFI_OPT_COUNT]; };
+static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ 0, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
+                                            /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
-    int dtype = afi_default_dtype();                       // arithmetic of the Winograd-domain GEMMs (afi_ctx_set_compute_dtype)
+    int dtype = AFI_DTYPE_DEFAULT;                         // arithmetic of the Winograd-domain GEMMs (afi_ctx_set_compute_dtype)
+    AfiOptions opt = kDefaultOptions;
     WinoWeightCache wcache;
     WinoWgradAccum wgacc;
     SideStream side;
 };
+static inline long long afi_opt(const afi_ctx* cx, int o) { return cx ? cx->opt.v[o] : kDefaultOptions.v[o]; }
+static inline int afi_default_dtype() { return AFI_DTYPE_DEFAULT; }
 namespace {
 // Fork/join onto the context's side stream (created on first use, on the context's device): the weight-gradient GEMMs and bias column
 // sums do not feed the data-gradient chain, so they run beside it.  Only event record / wait, so the sequence captures into a hipGraph.
@@ -205,10 +204,10 @@ static AfiWgradGemm conv_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W, 
 //      mode 1 = data gradient (K = Cout, columns = Cin, flipped taps).  ws: [U 16*K*Nc][V 16*Tpad*K][M 16*Tpad*Nc].
 static long long wino_tpad(int N, int H, int W) { return (((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + 127) / 128) * 128; }
 static long long wino4_tpad(int N, int H, int W) { return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4) + 127) / 128) * 128; }
-// AFI_WINO_D_F4=1: F(4x4) tiles also for the forwards a backward follows (faster; its ~3e-5 rounding moves ~30x more activations
+// AFI_OPT_WINOGRAD_F4_FORWARD: F(4x4) tiles also for the forwards a backward follows (faster; its ~3e-5 rounding moves ~30x more activations
 // across the LeakyReLU kink than an F(2x2)/direct forward does -- DESIGN.md "Winograd" has the measurement).  Off by default.
-static bool wino_d_f4() { static const int on = getenv("AFI_WINO_D_F4") ? atoi(getenv("AFI_WINO_D_F4")) : 0; return on != 0; }
-static bool wino_f4() { static const int on = getenv("AFI_WINO_F4") ? atoi(getenv("AFI_WINO_F4")) : 1; return on != 0; }
+static bool wino_d_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F4_FORWARD) != 0; }
+static bool wino_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F4_BACKWARD) != 0; }
 // one size for both tilings: F(2x2,3x3) = 16 transform points over 2x2 tiles, F(4x4,3x3) = 36 points over 4x4 tiles
 // + the pre-split bf16 image of U the DMA GEMM stages (three 2-byte parts per element = 1.5 floats; afi_gemm_bf16.h)
 static long long wino_usplit_floats(int np, long long KN) { return align4((3 * np * KN + 1) / 2); }
@@ -223,19 +222,16 @@ static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
 // gather, dense [rows][3][3][K-or-N] weights, >= 128 channels on both sides, >= 1024 pixels.
 // below this many pixels a conv of the interpolator stays on the direct small-map kernels.  Scanned with tools/interp_sweep.py
 // (fwd+bwd, 1024 -> 2048): 1x25x42 1.31 -> 1.04 ms, 2x25x34 1.49 -> 1.33 ms; 4096 and up lose from 3400 pixels on.
-static long long wino_g_minpix() { static const long long v = getenv("AFI_G_WINO_MINPIX") ? atoll(getenv("AFI_G_WINO_MINPIX")) : 2048; return v; }
-static bool wino_gemm_fast() { static const int fast = getenv("AFI_GEMM_NT") ? atoi(getenv("AFI_GEMM_NT")) : 1; return fast != 0; }
-static bool wino_eligible(const AfiPixGemm& g, int b_rc) {
-    static const int on = getenv("AFI_WINO_G") ? atoi(getenv("AFI_WINO_G")) : 1;
-    if (!on || g.ntaps != 9 || g.gtap || g.r2_post) return false;
+// (the workspace queries size the Winograd scratch for maps of >= 1024 pixels, so the run-time threshold cannot go below that)
+static long long wino_g_minpix(const afi_ctx* cx) { const long long v = afi_opt(cx, AFI_OPT_G_WINOGRAD_MIN_PIXELS); return v < 1024 ? 1024 : v; }
+static bool wino_eligible(const afi_ctx* cx, const AfiPixGemm& g, int b_rc) {
+    if (!afi_opt(cx, AFI_OPT_WINOGRAD) || g.ntaps != 9 || g.gtap || g.r2_post) return false;
     // plain 3x3 conv / its data gradient, or the data gradient of the 4-phase conv-transpose (its A operand is the hi-res
     // gradient read as four phase views: each phase is one channel block of a 3x3 data gradient with 4*Cout channels)
     const bool phases = g.nKphase == 4 && g.a_up == 2 && b_rc;
     if (!phases && (g.nKphase != 1 || g.a_up != 1)) return false;
-    static const int convt = getenv("AFI_WINO_CONVT") ? atoi(getenv("AFI_WINO_CONVT")) : 1;
-    if (phases && !convt) return false;
     if (g.Ck < 128 || g.Ncols < 128 || (g.Ck & 3) || (g.Ncols & 3)) return false;
-    if ((long long)g.N * g.H * g.W < wino_g_minpix()) return false;
+    if ((long long)g.N * g.H * g.W < wino_g_minpix(cx)) return false;
     const int I = b_rc ? g.Ncols : g.Ck;                   // innermost weight dimension of w[O][3][3][I]
     return g.b_sTap == I && g.b_sRow == 9LL * I && g.a_sgn == (b_rc ? -1 : 1);
 }
@@ -268,7 +264,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     // bf16 operands (2^-9) cannot carry the F(4x4) transforms (their 1/24 .. 8 coefficient range costs two more digits: 3 % error);
     // split-bf16 (2^-17) can
     const int dtype = cx ? cx->dtype : afi_default_dtype();
-    const bool f4 = (b_rc || fwd_f4) && wino_f4() && dtype != AFI_DTYPE_BF16 && (long long)g.N * g.H * g.W >= 8192;     // small maps: too few 4x4 tiles to fill the chip
+    const bool f4 = (b_rc || fwd_f4) && wino_f4(cx) && dtype != AFI_DTYPE_BF16 && (long long)g.N * g.H * g.W >= 8192;     // small maps: too few 4x4 tiles to fill the chip
     const int np = f4 ? 36 : 16;
     const long long Tpad = f4 ? wino4_tpad(g.N, g.H, g.W) : wino_tpad(g.N, g.H, g.W);
     float* U = ws;
@@ -277,7 +273,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     float* Usp = Mb + align4(np * Tpad * Nc);              // pre-split bf16 image of U (DMA GEMM), when it is not served from the cache
     // the bf16 settings run the LDS-DMA GEMM on tile-aligned shapes (every layer of the reference nets): its B operand is U split into
     // bf16 parts in LDS-image order, made once per weight transform and cached in that form
-    const bool dma = dtype != AFI_DTYPE_F32 && wino_gemm_fast() && !(Tpad % 128) && !(Nc % 128) && !(K % 32);
+    const bool dma = dtype != AFI_DTYPE_F32 && !(Tpad % 128) && !(Nc % 128) && !(K % 32);
     bool have_u = false;
     if (dma) {
         if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc | (dtype << 4), b_rc ? K : Nc, b_rc ? Nc : K, wino_usplit_floats(np, (long long)K * Nc), have_u)) Usp = slot;
@@ -297,7 +293,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
         AFI_TRY(afi_launch_gemm_nt_bf16_dma(Vb, Usp, Mb, np, Tpad, Nc, K, dtype, st));
         return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
     }
-    if (dtype == AFI_DTYPE_F32 && wino_gemm_fast()) {      // tile-aligned shapes: the plain batched NT GEMM on the fp32 MFMA
+    if (dtype == AFI_DTYPE_F32) {                          // tile-aligned shapes: the plain batched NT GEMM on the fp32 MFMA
         const int rc = afi_launch_gemm_nt(Vb, U, Mb, np, Tpad, Nc, K, st);
         if (rc == AFI_OK) return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
         if (rc != AFI_ERR_UNSUPPORTED) return rc;
@@ -355,7 +351,7 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
     const int dtype = cx ? cx->dtype : afi_default_dtype();
-    const bool f4 = wino_f4() && dtype != AFI_DTYPE_BF16 && (long long)N * H * W >= 8192;   // F(3x3,4x4): 36 transform points over 4x4 blocks of dY
+    const bool f4 = wino_f4(cx) && dtype != AFI_DTYPE_BF16 && (long long)N * H * W >= 8192;   // F(3x3,4x4): 36 transform points over 4x4 blocks of dY
     const int np = f4 ? 36 : 16;
     const long long Tpad = f4 ? wino4_tpad(N, H, W) : wino_tpad(N, H, W);
     float* dU = ws;
@@ -373,9 +369,7 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
         AFI_TRY(f4 ? afi_launch_wino4_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout) : afi_launch_wino_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout));
     }
     {   // tile-aligned shapes: the plain batched TN GEMM
-        static const int fast = getenv("AFI_GEMM_TN") ? atoi(getenv("AFI_GEMM_TN")) : 1;
-        const int rc = !fast ? AFI_ERR_UNSUPPORTED
-                     : dtype == AFI_DTYPE_F32 ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st)
+        const int rc = dtype == AFI_DTYPE_F32 ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st)
                                               : afi_launch_gemm_tn_bf16(Qb, Vb, dU, np, Tpad, Cout, Cin, dtype, st);
         if (rc == AFI_OK) {
             if (accum) return AFI_OK;                      // transformed at afi_wino_wgrad_flush()
@@ -397,14 +391,14 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
 }
 
 // Winograd or direct for a 3x3 conv of the discriminator: from ~1 K pixels on the 2.25x fewer matrix-core FLOPs win over the
-// transform traffic (measured: 2x336x200 1024->1024 18.8 -> 11.8 ms, 2x84x50 1.38 -> 0.72 ms).  AFI_WINO=0 switches it off.
-static bool use_wino(long long P) {
-    static const int on = getenv("AFI_WINO") ? atoi(getenv("AFI_WINO")) : 1;
-    static const long long minpix = getenv("AFI_WINO_MINPIX") ? atoll(getenv("AFI_WINO_MINPIX")) : 1024;
-    return on && P >= minpix;
+// transform traffic (measured: 2x336x200 1024->1024 18.8 -> 11.8 ms, 2x84x50 1.38 -> 0.72 ms).  AFI_OPT_WINOGRAD = 0 switches it off,
+// AFI_OPT_D_WINOGRAD_MIN_PIXELS moves the threshold (not below the 1024 pixels the workspace queries size the scratch from).
+static bool use_wino(const afi_ctx* cx, long long P) {
+    const long long minpix = afi_opt(cx, AFI_OPT_D_WINOGRAD_MIN_PIXELS);
+    return afi_opt(cx, AFI_OPT_WINOGRAD) && P >= (minpix < 1024 ? 1024 : minpix);
 }
 static long long disc_wino_floats(const int F[4], int N, int H, int W) {
-    if (!use_wino((long long)N * H * W)) return 0;
+    if ((long long)N * H * W < 1024) return 0;
     long long m = 0;
     for (int n = 0; n < 3; ++n) { const long long v = wino_ws_floats(N, H, W, F[n], F[n + 1]); if (v > m) m = v; }
     return m;
@@ -451,6 +445,16 @@ int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype) {
     return AFI_OK;
 }
 int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx) { return ctx ? ctx->dtype : afi_default_dtype(); }
+int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value) {
+    if (!ctx || option < 0 || option >= AFI_OPT_COUNT || value < 0) return AFI_ERR_BAD_ARG;
+    if (ctx->wgacc.n) return AFI_ERR_BAD_ARG;             // pending transform-domain sums belong to the tiling of the old setting
+    ctx->opt.v[option] = value;
+    return AFI_OK;
+}
+long long afi_ctx_get_option(const afi_ctx_t* ctx, int option) {
+    if (option < 0 || option >= AFI_OPT_COUNT) return -1;
+    return afi_opt(ctx, option);
+}
 long long afi_gemm_nt_scratch_bytes(int planes, int N, int K, int dtype) {
     if (planes <= 0 || N <= 0 || K <= 0) return -1;
     if (dtype == AFI_DTYPE_F32) return 0;
@@ -803,8 +807,7 @@ static long long part_floats(std::initializer_list<long long> layer_mn) {   // M
 // Winograd scratch of one interpolator call: the largest of its eligible convs (C->C and L->C on the low-res grid, the
 // conv-transpose as C->4C, C->C on the hi-res grid); 0 when nothing is eligible (small maps / few channels)
 static long long gen_wino_floats(int C, int L, int N, int H, int W) {
-    static const int on = getenv("AFI_WINO_G") ? atoi(getenv("AFI_WINO_G")) : 1;
-    if (!on || C < 128) return 0;
+    if (C < 128) return 0;
     long long m = 0;
     auto upd = [&](long long v) { if (v > m) m = v; };
     if ((long long)N * H * W >= 1024) { upd(wino_ws_floats(N, H, W, C, C)); upd(wino_ws_floats(N, H, W, L, C)); upd(wino_ws_floats(N, H, W, C, 4 * C)); }
@@ -877,7 +880,7 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     float* const part_ = ws + l.o_part;
     const long long part_n_ = l.n_part;
     auto PG = [&](AfiPixGemm g, int b_rc) {
-        if (l.n_wino > 0 && wino_eligible(g, b_rc)) return wino_run(cx, g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st);
+        if (l.n_wino > 0 && wino_eligible(cx, g, b_rc)) return wino_run(cx, g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st);
         g.partial = part_; g.partial_floats = part_n_;
         return afi_launch_pix_gemm(g, b_rc, st);
     };
@@ -908,10 +911,9 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     // (and whose four 32-column outputs are 27 tiles each, for 256 CUs), five steps whose source is ONE slice: step 0 multiplies x into
     // the columns of all five convs in one grouped launch (384 columns, K = 9*C), step j = 1..4 multiplies y_j (32 channels, K = 288)
     // into the convs that still need it; a conv's slice accumulates in place (beta = 1) and is activated by the step that completes
-    // it.  Same multiply-adds as generator_rdb.py:64-71, summed in another order (fp32 rounding only).  AFI_RDB_BATCH=0: conv by conv.
-    static const int rdb_batch = getenv("AFI_RDB_BATCH") ? atoi(getenv("AFI_RDB_BATCH")) : 1;
-    static const long long rdb_batch_maxp = getenv("AFI_RDB_BATCH_MAXP") ? atoll(getenv("AFI_RDB_BATCH_MAXP")) : 2048;
-    const bool batched = rdb_batch && l.P < rdb_batch_maxp;
+    // it.  Same multiply-adds as generator_rdb.py:64-71, summed in another order (fp32 rounding only).  AFI_OPT_G_SMALLMAP_MAX_PIXELS = 0:
+    // conv by conv at every size.
+    const bool batched = l.P < afi_opt(cx, AFI_OPT_G_SMALLMAP_MAX_PIXELS);
     for (int r = 0; r < R; ++r) {   // ResidualDenseBlock.forward (generator_rdb.py:64-71); the dense buffer replaces torch.cat
         AfiView b = buf(r);
         const bool last = (r == R - 1);
@@ -996,17 +998,15 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     float* const part_ = scratch + s.o_part;
     const long long part_n_ = s.n_part;
     auto PG = [&](AfiPixGemm g, int b_rc) {
-        if (s.n_wino > 0 && wino_eligible(g, b_rc)) return wino_run(cx, g, b_rc, scratch + s.o_wino, s.n_wino, part_, part_n_, st);
+        if (s.n_wino > 0 && wino_eligible(cx, g, b_rc)) return wino_run(cx, g, b_rc, scratch + s.o_wino, s.n_wino, part_, part_n_, st);
         g.partial = part_; g.partial_floats = part_n_;
         return afi_launch_pix_gemm(g, b_rc, st);
     };
     // Small maps (config-1 sizes): every weight / bias gradient is DEFERRED to the end of the pass and runs as ONE grouped launch
     // per tile shape (csrc/smallmap.hip: whole dW tiles per block, no split over pixels, no atomics, no zero-fill), instead of one
     // 7 .. 36-tile launch per layer on a side stream.  All their operands (dOut, dU, gA, gB, the per-block gradient buffers and the
-    // saved activations) stay alive until the call returns.  AFI_WG_GROUP=0 restores the per-layer launches.
-    static const int wg_group = getenv("AFI_WG_GROUP") ? atoi(getenv("AFI_WG_GROUP")) : 1;
-    static const long long wg_group_maxp = getenv("AFI_WG_GROUP_MAXP") ? atoll(getenv("AFI_WG_GROUP_MAXP")) : kSideStreamMaxPixels / 4;
-    const bool grouped = wg_group && l.P <= wg_group_maxp;
+    // saved activations) stay alive until the call returns.  AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS = 0 restores the per-layer launches.
+    const bool grouped = l.P <= afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS);
     AfiWgradGemm wg_wide[12], wg_narrow[4 * AFI_MAX_RDB];
     AfiColsumProb cs[8];
     int n_wide = 0, n_narrow = 0, n_cs = 0;
@@ -1019,7 +1019,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // weight gradient of a 3x3 conv: Winograd F(3x3,2x2) when both channel counts and the map are large enough, else direct
     auto WG = [&](AfiView dyv, AfiView xin, int n_, int h_, int w_, int co, int ci, float* dw, float alpha, hipStream_t s_) {
         if (grouped) return defer(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha));
-        if (s.n_wino > 0 && co >= 128 && ci >= 128 && (long long)n_ * h_ * w_ >= wino_g_minpix())
+        if (s.n_wino > 0 && co >= 128 && ci >= 128 && (long long)n_ * h_ * w_ >= wino_g_minpix(cx) && afi_opt(cx, AFI_OPT_WINOGRAD))
             return wino_wgrad(cx, dyv, xin, n_, h_, w_, co, ci, dw, alpha, scratch + s.o_wino2, s.n_wino, s_);
         return afi_launch_wgrad_gemm(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha), s_);
     };
@@ -1043,9 +1043,8 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // grouped form: ONE stream by default (flush at the end).  Flushing the deferred problems onto the side stream after the hi-res pair,
     // after each dense block and at the end was measured: the grouped launches then run beside the data-gradient chain, every kernel of
     // which gets slower by about what is gained (1.26 vs 1.19 ms eager, and 1.51 ms replayed from a hipGraph with its six fork/join
-    // edges): the chain's kernels already occupy every CU even where they wait on memory.  AFI_WG_OVERLAP=1 switches it back on.
-    static const int wg_overlap = getenv("AFI_WG_OVERLAP") ? atoi(getenv("AFI_WG_OVERLAP")) : 0;
-    Fork fk(cx, st, 4 * P <= kSideStreamMaxPixels && (!grouped || wg_overlap));
+    // edges): the chain's kernels already occupy every CU even where they wait on memory.  The fork is for the per-layer form only.
+    Fork fk(cx, st, 4 * P <= kSideStreamMaxPixels && !grouped);
     hipStream_t sd = fk.side;                              // weight / bias gradients
     bool unpack_pending = false;
     auto flush = [&](bool last) {                          // launch what has been deferred so far (its operands are complete on `st`)
@@ -1072,11 +1071,10 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     if (!grouped) fk.after_main();                                       // dU is complete
     if (gr->wT) {
         if (hipMemsetAsync(dwp, 0, sizeof(float) * 36LL * C * C, sd) != hipSuccess) return AFI_ERR_LAUNCH;
-        static const int convt = getenv("AFI_WINO_CONVT") ? atoi(getenv("AFI_WINO_CONVT")) : 1;
         if (grouped) {
             AFI_TRY(defer(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f)));
             n_wide_has_convT = true; unpack_pending = true;
-        } else if (convt && s.n_wino > 0 && C >= 128 && P >= wino_g_minpix()) {    // the four phases as channel blocks of one Winograd weight gradient
+        } else if (s.n_wino > 0 && C >= 128 && P >= wino_g_minpix(cx) && afi_opt(cx, AFI_OPT_WINOGRAD)) {    // the four phases as channel blocks of one Winograd weight gradient
             AFI_TRY(wino_wgrad(cx, dU, a7, N, H, W, 4 * C, C, dwp, 1.f, scratch + s.o_wino2, s.n_wino, sd, /*dy_phases=*/4, /*accumulate=*/false));
         } else {
             AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));
@@ -1232,15 +1230,15 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
         const int ci = prm->F[n], co = prm->F[n + 1];
         float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];
         float* mean = ws + l.o_mean[n]; float* invstd = ws + l.o_invstd[n];
-        if (l.n_wino > 0) {
+        if (l.n_wino > 0 && use_wino(cx, P)) {
             AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
-                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4()));
+                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx)));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
         if (training) {
             AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st,
-                                        prm->num_batches_tracked[n]));      // the counter ticks inside the statistics finalizer
+                                        prm->num_batches_tracked[n], -1.f, -1.f, afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0));      // the counter ticks inside the statistics finalizer
             AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
         } else {
             AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
@@ -1282,6 +1280,7 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
     //  two A/B pairs on one box -- the chip has no room left beside the GEMMs)
     Fork fk(cx, st, P <= kSideStreamMaxPixels);
     hipStream_t sd = fk.side;                              // weight / bias gradients run beside the data-gradient chain
+    const bool wino = s.n_wino > 0 && use_wino(cx, P);
     const int F3 = prm->F[3];
     // ---- last conv
     if (gr->b3) AFI_TRY(afi_launch_sum_accum(dlogits, P, 1.f, gr->b3, sd));
@@ -1318,14 +1317,14 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
         (void)red2;
         AfiView gy = dense_view(g_, H, W, co);
         AfiView xin = (n == 0) ? V(xv) : dense_view(ws + l.o_y[n - 1], H, W, ci);
-        if (gr->w[n] && s.n_wino > 0) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd));
+        if (gr->w[n] && wino) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd));
         else if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
-        if (n > 0 && s.n_wino > 0) {
+        if (n > 0 && wino) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), null_view(), scratch + s.o_wino,
                               s.n_wino, part_, part_n_, st));
         } else if (n > 0) {
             AFI_TRY(PG(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(scratch + s.o_g[n - 1], H, W, ci)), 1));
-        } else if (dx && s.n_wino > 0) {
+        } else if (dx && wino) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(dx, H, W, ci), null_view(), scratch + s.o_wino, s.n_wino, part_,
                               part_n_, st));
         } else if (dx) {

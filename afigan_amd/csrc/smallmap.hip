@@ -11,7 +11,7 @@
 //                            prologue / MFMA / store phases at different times (runs start at arbitrary stages), which removes the
 //                            lock-step of the one-tile-per-block split-K grid, where all blocks load, multiply and store together.
 //   afi_pix_sk_reduce_kernel sums a tile's slabs in a FIXED order (bit-reproducible, no atomics) and applies the fused epilogue.
-//   afi_wgrad_group_kernel   every weight gradient of one backward pass (19 convs, 23 parameter tensors) in ONE launch: the blocks
+//   afi_wgrad_group_sk_kernel   every weight gradient of one backward pass (19 convs, 23 parameter tensors) in ONE launch: the blocks
 //                            walk a table of AfiWgradGemm problems, each block owns a whole dW tile (all pixels), so there are no
 //                            atomics, no zero-fills, and the grid fills the chip (the per-layer launches were 7 .. 36 tiles each).
 //   afi_colsum_group_kernel  the bias gradients of the same pass in one launch.
@@ -325,16 +325,12 @@ __global__ __launch_bounds__(256) void afi_pix_sk_reduce_kernel(const AfiPixGemm
     }
 }
 
-static int sk_env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
 static unsigned sk_rcp(unsigned d) { return d <= 1 ? 0u : (unsigned)((1ULL << 32) / d) + 1u; }
 
 template <int BM, int BN, int WM, int WN, bool B_RC>
 static int launch_sk(const AfiPixGemm& p, hipStream_t st) {
-    static const int bpc = sk_env_int("AFI_SK_BPC", 2);          // persistent blocks per CU
-    static const int minq = sk_env_int("AFI_SK_MINQ", 4);        // at least this many K stages per block
+    constexpr int bpc = 2;                                 // persistent blocks per CU
+    constexpr int minq = 4;                                // at least this many K stages per block
     const long long M = (long long)p.N * p.H * p.W;
     AfiSkArgs sk;
     sk.ntile_m = afi_cdiv(M, BM); sk.ntile_n = afi_cdiv(p.Ncols, BN);
@@ -375,31 +371,6 @@ static int launch_sk(const AfiPixGemm& p, hipStream_t st) {
     if (second_pass && (!p.partial || p.partial_floats <= 0)) return AFI_ERR_UNSUPPORTED;
     const size_t lds = sizeof(float) * 2 * (BM * (AFI_BK + 4) + (B_RC ? AFI_BK * BN : BN * (AFI_BK + 4)));
     sk.dbg = nullptr;
-    static const char* diag = getenv("AFI_SK_DIAG");          // diagnostic: dump per-block cycle stamps of every launch (synchronises!)
-    if (diag) {
-        unsigned long long* d = nullptr;
-        if (hipMalloc(&d, sizeof(unsigned long long) * 10 * G) != hipSuccess) return AFI_ERR_LAUNCH;
-        (void)hipMemset(d, 0, sizeof(unsigned long long) * 10 * G);
-        sk.dbg = d;
-        hipLaunchKernelGGL((afi_pix_gemm_sk_kernel<BM, BN, WM, WN, B_RC, true>), dim3((unsigned)G), dim3(256), lds, st, p, sk);
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h(10 * G);
-        (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * 10 * G, hipMemcpyDeviceToHost);
-        (void)hipFree(d);
-        FILE* f = fopen(diag, "a");
-        if (f) {
-            unsigned long long r0 = ~0ULL, r1 = 0;
-            for (long long b = 0; b < G; ++b) { if (h[b * 10 + 6] < r0) r0 = h[b * 10 + 6]; if (h[b * 10 + 7] > r1) r1 = h[b * 10 + 7]; }
-            fprintf(f, "launch BM=%d BN=%d rc=%d M=%lld N=%d nK=%d G=%lld U=%lld span_us=%.2f\n", BM, BN, (int)B_RC, M, p.Ncols, sk.nK, G, U, (r1 - r0) * 0.01);
-            for (long long b = 0; b < G; b += (G > 64 ? G / 32 : 1)) {
-                const unsigned long long* e = &h[b * 10];
-                fprintf(f, "  blk %4lld start_us %.2f end_us %.2f | cyc: decode %lld issue %lld firstdata %lld loop %lld epi %lld | clk_MHz %.0f\n", b, (e[6] - r0) * 0.01, (e[7] - r0) * 0.01,
-                        (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]), (long long)(e[5] - e[4]),
-                        (e[7] > e[6]) ? (double)(e[8] - e[0]) / ((e[7] - e[6]) * 0.01) : 0.0);
-            }
-            fclose(f);
-        }
-    } else
     hipLaunchKernelGGL((afi_pix_gemm_sk_kernel<BM, BN, WM, WN, B_RC>), dim3((unsigned)G), dim3(256), lds, st, p, sk);
     if (second_pass) {
         const int cf4 = ((p.Ncols + 3) & ~3) >> 2;
@@ -414,11 +385,9 @@ template <bool B_RC> static int launch_wk(const AfiPixGemm& p, hipStream_t st);
 // Small-map form of a pixel GEMM: stream-K / even split-K with a slab reduction for long K, whole tiles with the fused epilogue for
 // short K.  AFI_ERR_UNSUPPORTED = "not this path" (the caller falls back to the tiled kernels).
 int afi_launch_pix_gemm_sk(const AfiPixGemm& p, int b_rc, hipStream_t st) {
-    static const int on = sk_env_int("AFI_SK", 1);
-    if (!on || p.gtap || p.b_sImg != 0) return AFI_ERR_UNSUPPORTED;
+    if (p.gtap || p.b_sImg != 0) return AFI_ERR_UNSUPPORTED;
     if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_UNSUPPORTED;
-    static const int wk_on = sk_env_int("AFI_WK", 1);      // K split inside the block (no second pass); AFI_WK=0: the stream-K form
-    if (wk_on) {
+    {   // K split inside the block (no second pass); the stream-K form below takes what its 32-bit index math refuses
         const int rc = b_rc ? launch_wk<true>(p, st) : launch_wk<false>(p, st);
         if (rc != AFI_ERR_UNSUPPORTED) return rc;
     }
@@ -755,8 +724,7 @@ static int wk_prepare(const AfiPixGemm& p, bool b_rc, AfiWkArgs& wk) {
 }
 // up to AFI_WK_MAXP simultaneous small-map GEMMs in one launch; validates everything before it launches anything
 int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st) {
-    static const int on = sk_env_int("AFI_SK", 1) && sk_env_int("AFI_WK", 1);
-    if (!on || n < 1 || n > AFI_WK_MAXP) return AFI_ERR_UNSUPPORTED;
+    if (n < 1 || n > AFI_WK_MAXP) return AFI_ERR_UNSUPPORTED;
     AfiWkGroup grp;
     grp.nprob = n;
     int tiles = 0;
@@ -782,35 +750,8 @@ static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
     const long long G = (long long)wk.ntile_m * wk.ntile_n;
     constexpr int LDK = AFI_BK + 4;
     const size_t lds = sizeof(float) * 8 * (2 * 32 * LDK);
-    static const int lean_min = sk_env_int("AFI_WK_LEAN_MIN", 1);     // the two-blocks-per-CU variant measured faster at every grid size (1.06 -> 1.01 ms at config 1)
-    const bool lean = G >= lean_min;
-    static const char* diag = getenv("AFI_SK_DIAG");
-    if (diag) {
-        unsigned long long* d = nullptr;
-        if (hipMalloc(&d, sizeof(unsigned long long) * 10 * G) != hipSuccess) return AFI_ERR_LAUNCH;
-        (void)hipMemset(d, 0, sizeof(unsigned long long) * 10 * G);
-        wk.dbg = d;
-        if (lean) hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, true, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
-        else hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, false, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
-        (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h(10 * G);
-        (void)hipMemcpy(h.data(), d, sizeof(unsigned long long) * 10 * G, hipMemcpyDeviceToHost);
-        (void)hipFree(d);
-        FILE* f = fopen(diag, "a");
-        if (f) {
-            unsigned long long r0 = ~0ULL, r1 = 0;
-            for (long long b = 0; b < G; ++b) { if (h[b * 10 + 6] < r0) r0 = h[b * 10 + 6]; if (h[b * 10 + 7] > r1) r1 = h[b * 10 + 7]; }
-            fprintf(f, "launch WK rc=%d lean=%d M=%lld N=%d nK=%d G=%lld span_us=%.2f\n", (int)B_RC, (int)lean, M, p.Ncols, wk.nK, G, (r1 - r0) * 0.01);
-            for (long long b = 0; b < G; b += (G > 64 ? G / 16 : 1)) {
-                const unsigned long long* e = &h[b * 10];
-                fprintf(f, "  blk %4lld start_us %.2f end_us %.2f | cyc: decode %lld issue %lld firstdata %lld loop %lld epi %lld | clk_MHz %.0f\n", b, (e[6] - r0) * 0.01, (e[7] - r0) * 0.01,
-                        (long long)(e[1] - e[0]), (long long)(e[2] - e[1]), (long long)(e[3] - e[2]), (long long)(e[4] - e[3]), (long long)(e[5] - e[4]),
-                        (e[7] > e[6]) ? (double)(e[8] - e[0]) / ((e[7] - e[6]) * 0.01) : 0.0);
-            }
-            fclose(f);
-        }
-    } else if (lean) hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
-    else hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, false>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
+    // one register set, two blocks per CU: measured faster than the two-set variant at every grid size (1.06 -> 1.01 ms at config 1)
+    hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -818,27 +759,6 @@ static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
 // grouped weight gradients: one launch, a table of problems, each block owns a whole dW tile (no split over pixels)
 // ------------------------------------------------------------------------------------------------
 #define AFI_WG_MAXP 20
-struct AfiWgradGroup {
-    int nprob;
-    int blk_start[AFI_WG_MAXP + 1];                        // prefix sums of blocks (ntile_m * ntile_n * ntaps * nsplit) per problem
-    short ntile_m[AFI_WG_MAXP], ntile_n[AFI_WG_MAXP];
-    short nsplit[AFI_WG_MAXP];                             // pixel-range slices per tile (> 1: the partial sums meet in fp32 atomics)
-    int kper[AFI_WG_MAXP];                                 // pixels per slice (multiple of 32)
-    AfiWgradGemm g[AFI_WG_MAXP];
-};
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) void afi_wgrad_group_kernel(const AfiWgradGroup grp) {
-    // bijective XCD remap: blocks b, b+8, .. share an XCD; give each XCD a contiguous run of logical blocks
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    int pi = 0;
-    while (pi + 1 < grp.nprob && t >= grp.blk_start[pi + 1]) ++pi;      // (uniform) <= 20 entries
-    const AfiWgradGemm& p = grp.g[pi];
-    const int ns = grp.nsplit[pi];
-    const int lt = t - grp.blk_start[pi];                  // slices of one tile are adjacent: they share both operand tiles' columns
-    afi_wgrad_gemm_body<BM, BN, WM, WN>(p, grp.ntile_m[pi], grp.ntile_n[pi], grp.kper[pi], lt / ns, lt % ns, ns > 1);
-}
-
 // Stream-K form: the (tile, 32-pixel stage) units of all problems are laid end to end and cut into EQUAL runs, one per block, with as
 // many blocks as the chip holds at once.  A block works through its run tile by tile -- at most a partial tile at each end -- and adds
 // a tile it shares with a neighbour by fp32 atomics; tiles it owns alone are stored.  Against "one tile slice per block" (above) this
@@ -920,45 +840,12 @@ static int launch_wgrad_group_sk(const AfiWgradGemm* probs, int n, hipStream_t s
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_wgrad_group(const AfiWgradGemm* probs, int n, hipStream_t st) {
-    static const int stages = sk_env_int("AFI_WG_STAGES", 14);    // K stages (of 32 pixels) per block: 850 pixels -> 2 slices, 3400 -> 8
-    AfiWgradGroup grp;
-    int done = 0;
-    while (done < n) {
-        const int cnt = (n - done) < AFI_WG_MAXP ? (n - done) : AFI_WG_MAXP;
-        grp.nprob = cnt;
-        int blocks = 0;
-        for (int i = 0; i < cnt; ++i) {
-            const AfiWgradGemm& g = probs[done + i];
-            if ((g.Ncols & 3) || (g.dy_up == 2 && (g.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;
-            grp.g[i] = g;
-            const long long P = (long long)g.N * g.H * g.W;
-            const int nst = afi_cdiv(P, AFI_BK);
-            int ns = stages > 0 ? afi_cdiv(nst, stages) : 1;
-            if (ns > 64) ns = 64;
-            const int kper = afi_cdiv(nst, ns) * AFI_BK;
-            ns = afi_cdiv(P, kper);                        // no empty slices
-            grp.ntile_m[i] = (short)afi_cdiv(g.Mrows, BM); grp.ntile_n[i] = (short)afi_cdiv(g.Ncols, BN);
-            grp.nsplit[i] = (short)ns; grp.kper[i] = kper;
-            grp.blk_start[i] = blocks;
-            blocks += grp.ntile_m[i] * grp.ntile_n[i] * g.ntaps * ns;
-        }
-        grp.blk_start[cnt] = blocks;
-        for (int i = cnt + 1; i <= AFI_WG_MAXP; ++i) grp.blk_start[i] = blocks;
-        hipLaunchKernelGGL((afi_wgrad_group_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(64 * WM * WN), sizeof(float) * AFI_BK * (BM + BN), st, grp);
-        done += cnt;
-    }
-    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
-}
 // wide = 0: problems with <= 32 rows (the RDB growth convs), 32 x 128 tiles; wide = 1: 128 x 128 tiles.  Problems are sorted by
 // the caller, longest pixel range first (the dispatcher hands blocks out in order: long tiles early, short ones fill the tail).
 int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st) {
     if (n <= 0) return AFI_OK;
-    static const int sk = sk_env_int("AFI_WG_SK", 1);      // 0: one tile slice per block (A/B)
-    static const int bpc = sk_env_int("AFI_WG_SK_BPC", 3); // resident blocks per CU the runs are cut for
-    if (sk) return wide ? launch_wgrad_group_sk<128, 128, 1, 4>(probs, n, st, bpc) : launch_wgrad_group_sk<32, 128, 1, 4>(probs, n, st, bpc);
-    return wide ? launch_wgrad_group<128, 128, 1, 4>(probs, n, st) : launch_wgrad_group<32, 128, 1, 4>(probs, n, st);
+    constexpr int bpc = 3;                                 // resident blocks per CU the stream-K runs are cut for
+    return wide ? launch_wgrad_group_sk<128, 128, 1, 4>(probs, n, st, bpc) : launch_wgrad_group_sk<32, 128, 1, 4>(probs, n, st, bpc);
 }
 
 // ------------------------------------------------------------------------------------------------

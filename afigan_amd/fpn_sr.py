@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib, ops
+from .config import afi_freeze
 from .generator_rdb import Generator
 
 ShapeSpec = namedtuple("ShapeSpec", ["channels", "stride"])
@@ -89,9 +90,37 @@ class _Conv3x3Fn(torch.autograd.Function):
         return dx, dw, db
 
 
+class FrozenBatchNorm2d(nn.Module):
+    """detectron2.layers.FrozenBatchNorm2d: BatchNorm2d with fixed statistics and affine, all four held as BUFFERS (weight, bias,
+    running_mean, running_var; eps 1e-5) -- no parameters, no num_batches_tracked, so reference / detectron2 checkpoints load strictly
+    and the module pickles.  A checkpoint written by a plain BatchNorm2d (with num_batches_tracked) loads too."""
+    _version = 3
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def forward(self, x):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        bias = self.bias - self.running_mean * scale
+        return x * scale.reshape(1, -1, 1, 1).to(x.dtype) + bias.reshape(1, -1, 1, 1).to(x.dtype)
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def __repr__(self):
+        return f"FrozenBatchNorm2d(num_features={self.num_features}, eps={self.eps})"
+
+
 def get_norm(norm, out_channels):
     """detectron2.layers.get_norm for the strings the reference's configs use (fpn_sr.py:74-81 passes cfg.MODEL.FPN.NORM through):
-    "" -> None, "BN", "SyncBN", "FrozenBN" (BatchNorm2d kept in eval mode with frozen affine), "GN" (32 groups)."""
+    "" -> None, "BN", "SyncBN" (torch's nn.SyncBatchNorm: statistics ARE exchanged between ranks on the FPN / PAFPN paths, unlike the BiFPN
+    path, which refuses multi-rank SyncBN training -- bifpn_sr.py), "FrozenBN" (fixed statistics and affine as buffers), "GN" (32 groups)."""
     if norm is None or norm == "":
         return None
     if norm == "BN":
@@ -101,12 +130,7 @@ def get_norm(norm, out_channels):
     if norm == "GN":
         return nn.GroupNorm(32, out_channels)
     if norm == "FrozenBN":
-        m = nn.BatchNorm2d(out_channels)
-        for p in m.parameters():
-            p.requires_grad = False
-        m.eval()
-        m.train = lambda mode=True: m                      # stays in eval mode
-        return m
+        return FrozenBatchNorm2d(out_channels)
     raise _lib.AfiError(f'norm "{norm}" is not available without detectron2 (supported: "", "BN", "SyncBN", "FrozenBN", "GN")')
 
 
@@ -162,7 +186,7 @@ class FPN_AFIGAN(nn.Module):
         for i, s in enumerate(in_strides[1:], 1):
             assert s == 2 * in_strides[i - 1], f"Strides {s} {in_strides[i - 1]} are not log2 contiguous"
         self.srf_module = Generator(in_channels=out_channels, n_residual_dense_blocks=3)        # fpn_sr.py:65
-        if getattr(getattr(cfg, "MODEL", None), "AFI_FREEZE", False):                          # :67-69
+        if afi_freeze(cfg):                          # :67-69
             for p in self.srf_module.parameters():
                 p.requires_grad = False
         lateral_convs, output_convs = [], []

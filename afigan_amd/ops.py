@@ -120,9 +120,6 @@ def weight_transform_cache(device, floats=32 * 1024 * 1024):
     on one set of weights.  The cache is keyed by weight ADDRESS, so every temporary weight copy made inside the block (``ohwi`` of a
     parameter that is not stored in the kernels' layout, ``.contiguous()`` of a bias) is kept alive until the block exits: a freed
     temporary's address could otherwise be handed to another same-shaped weight and hit the first one's transform.  Not re-entrant."""
-    if os.environ.get("AFI_WINO_WCACHE", "1") == "0":
-        yield
-        return
     cx = _lib.current_ctx()
     buf = cx.bufs.get("wcache")
     if buf is None or buf.numel() < floats:

@@ -19,6 +19,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from .fpn_sr import LastLevelMaxPool, ShapeSpec, _dense_pm, _FpnConv, get_norm
+from .config import afi_freeze
 from .generator_rdb import Generator
 
 __all__ = ["PAFPN_AFIGAN", "LastLevelMaxPool"]
@@ -107,7 +108,7 @@ class PAFPN_AFIGAN(nn.Module):
         for i, s in enumerate(in_strides[1:], 1):
             assert s == 2 * in_strides[i - 1], f"Strides {s} {in_strides[i - 1]} are not log2 contiguous"
         self.srf_module = Generator(in_channels=out_channels, n_residual_dense_blocks=3)        # pafpn_sr.py:67
-        if getattr(getattr(cfg, "MODEL", None), "AFI_FREEZE", False):                          # :69-71
+        if afi_freeze(cfg):                          # :69-71
             for p in self.srf_module.parameters():
                 p.requires_grad = False
         lateral_convs, output_convs, downsample_convs = [], [], []

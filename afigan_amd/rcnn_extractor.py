@@ -89,7 +89,8 @@ class GeneralizedRCNN_AFExtractor(nn.Module):
         return losses, processed_results                                               # :67-70
 
     def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
-        """rcnn_extractor.py:72-118 minus detectron2's post-processing: features -> proposals -> ROI-head predictions."""
+        """rcnn_extractor.py:72-118: features -> proposals -> ROI-head predictions, then (do_postprocess) each image's instances rescaled
+        to the input's "height" / "width" and wrapped as ``{"instances": r}`` -- the contract evaluators are written against."""
         assert not self.training
         images = self.preprocess_image(batched_inputs)
         features = self.backbone(images.tensor)
@@ -97,8 +98,67 @@ class GeneralizedRCNN_AFExtractor(nn.Module):
             if self.proposal_generator:
                 proposals, _ = self.proposal_generator(images, features, None)
             else:
-                proposals = [x["proposals"] for x in batched_inputs]
+                assert "proposals" in batched_inputs[0]
+                proposals = [x["proposals"].to(self.device) if hasattr(x["proposals"], "to") else x["proposals"] for x in batched_inputs]
             results, _ = self.roi_heads(images, features, proposals, None)
         else:
+            detected_instances = [x.to(self.device) if hasattr(x, "to") else x for x in detected_instances]        # :101
             results = self.roi_heads.forward_with_given_boxes(features, detected_instances)
+        if do_postprocess:
+            return self._postprocess(results, batched_inputs, images.image_sizes)                                   # :106-107
         return results
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes):
+        """rcnn_extractor.py:129-143: ``detector_postprocess(results, height, width)`` per image.  detectron2's own function when it is
+        importable; otherwise its box part (scale by output / network size, clip, drop empty boxes: detectron2 v0.1.1
+        modeling/postprocessing.py) on anything that carries ``image_size`` and ``pred_boxes`` -- and a loud error for instance fields this
+        package cannot rescale without detectron2 (masks, keypoints) rather than a silently wrong scale."""
+        try:
+            from detectron2.modeling.postprocessing import detector_postprocess
+        except Exception:
+            detector_postprocess = _detector_postprocess_boxes
+        out = []
+        for results_per_image, input_per_image, image_size in zip(instances, batched_inputs, image_sizes):
+            height = input_per_image.get("height", image_size[0])
+            width = input_per_image.get("width", image_size[1])
+            out.append({"instances": detector_postprocess(results_per_image, height, width)})
+        return out
+
+
+def _detector_postprocess_boxes(results, output_height, output_width):
+    import copy
+    from ._lib import AfiError
+    for f in ("pred_masks", "pred_keypoints"):
+        if getattr(results, f, None) is not None:
+            raise AfiError(f"rescaling `{f}` to the input size needs detectron2's detector_postprocess (not importable here); "
+                           "call inference(..., do_postprocess=False) for raw ROI-head results")
+    h, w = results.image_size
+    sx, sy = output_width / w, output_height / h
+    r = copy.copy(results)
+    boxes = getattr(results, "pred_boxes", None)
+    if boxes is None:
+        boxes = getattr(results, "proposal_boxes", None)
+        name = "proposal_boxes"
+    else:
+        name = "pred_boxes"
+    r.image_size = (output_height, output_width)
+    if boxes is None:
+        return r
+    t = (boxes.tensor if hasattr(boxes, "tensor") else boxes).clone()
+    t[:, 0::2] *= sx
+    t[:, 1::2] *= sy
+    t[:, 0::2].clamp_(min=0, max=output_width)
+    t[:, 1::2].clamp_(min=0, max=output_height)
+    keep = ((t[:, 2] - t[:, 0]) > 0) & ((t[:, 3] - t[:, 1]) > 0)
+    if hasattr(boxes, "tensor"):
+        nb = copy.copy(boxes)
+        nb.tensor = t[keep]
+        setattr(r, name, nb)
+    else:
+        setattr(r, name, t[keep])
+    for f in ("scores", "pred_classes", "objectness_logits"):
+        v = getattr(results, f, None)
+        if v is not None and hasattr(v, "__getitem__") and len(v) == len(keep):
+            setattr(r, f, v[keep])
+    return r

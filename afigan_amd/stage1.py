@@ -108,7 +108,8 @@ class Stage1Step:
     def __init__(self, G: Generator, D: Discriminator, base_lr: float = 1e-3, momentum: float = 0.9, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (270000,), lr_gamma: float = 0.1,
                  warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2,
-                 reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: Optional[str] = None):
+                 reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: Optional[str] = None,
+                 overlap_d: bool = True, overlap_g: bool = True, weight_cache: bool = True, wgrad_accum: bool = True):
         self.G, self.D = G, D
         self.gnet, self.dnet = G, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
@@ -117,9 +118,10 @@ class Stage1Step:
         self.reuse_g = reuse_generator_forward
         # D phase on two streams (forwards in order on the caller's, backwards in order on a second one), and in the G phase G's backward
         # beside the two D forwards per level (the adversarial term carries no gradient): -2.7 % and -2 % of a step now that the big GEMMs
-        # are power-bound and leave room beside the bandwidth-bound passes (129.5 -> 126.4 -> 123.9 ms); AFI_D_OVERLAP=0 / AFI_G_OVERLAP=0
-        self.overlap_d = os.environ.get("AFI_D_OVERLAP", "1") != "0"
-        self.overlap_g = os.environ.get("AFI_G_OVERLAP", "1") != "0"
+        # are power-bound and leave room beside the bandwidth-bound passes (129.5 -> 126.4 -> 123.9 ms); `overlap_d` / `overlap_g` (attributes too)
+        self.overlap_d, self.overlap_g = overlap_d, overlap_g
+        # per-phase cache of transformed weights / transform-domain sum of the weight gradients of a phase (pure re-orderings; off = per call)
+        self.weight_cache, self.wgrad_accum = weight_cache, wgrad_accum
         self._bstream = None
         self.iter = 0
         self.pg = process_group
@@ -257,13 +259,12 @@ class Stage1Step:
         # transformed conv weights are shared by the calls of a phase (weights only change at the two optimizer steps)
         cx, bx = self.ctx, self.bctx
         with _lib.use_ctx(cx):
-            use_cache = os.environ.get("AFI_WINO_WCACHE", "1") != "0"
-            if use_cache:
+            if self.weight_cache:
                 for c_, key in ((cx, "wino_wcache"), (bx, "wino_wcache_b")):
                     wcache = self._scratch(key, self.WINO_WCACHE_FLOATS, dev)
                     call("afi_ctx_set_wino_weight_cache", c_.handle, C.c_void_p(wcache.data_ptr()), self.WINO_WCACHE_FLOATS)
                 # ... and the transform-domain weight-gradient sums of a phase are transformed back once, before its all-reduce
-                if os.environ.get("AFI_WINO_WGACC", "1") != "0":
+                if self.wgrad_accum:
                     wgacc = self._scratch("wino_wgacc", self.WINO_WGACC_FLOATS, dev)
                     call("afi_ctx_set_wino_wgrad_accum", bx.handle, C.c_void_p(wgacc.data_ptr()), self.WINO_WGACC_FLOATS)
             try:

@@ -60,7 +60,7 @@ def _wino_weight_cache(helper, device):
     """Transformed conv weights shared by the calls of one phase (include/afigan_hip.h: afi_ctx_set_wino_weight_cache), on this engine's
     own contexts (forward / backward, stage1.py); registered for the duration of the phase only, during which D's weights do not change."""
     with _lib.use_ctx(helper.ctx):
-        if os.environ.get("AFI_WINO_WCACHE", "1") == "0":
+        if not getattr(helper, "weight_cache", True):
             yield
             return
         for c_, key in ((helper.ctx, "wino_wcache"), (helper.bctx, "wino_wcache_b")):
@@ -78,7 +78,8 @@ class Stage2Adversarial:
 
     def __init__(self, D: Discriminator, base_lr: float = 1e-2, momentum: float = 0.9, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (120000, 160000), lr_gamma: float = 0.1,
-                 warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2, process_group=None, dtype=None):
+                 warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2, process_group=None, dtype=None,
+                 overlap_d: bool = True, weight_cache: bool = True):
         self.D, self.dnet = D, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
         self.sched = (tuple(lr_steps), lr_gamma, warmup_factor, warmup_iters)
@@ -96,6 +97,8 @@ class Stage2Adversarial:
         self._helper.dnet, self._helper._dprm, self._helper._dgrad = self.dnet, self._prm, self._grad
         self._helper._lib, self._helper._buf = _lib.load(), {}
         self._helper.ctx, self._helper.bctx = _lib.Ctx(dtype), _lib.Ctx(dtype)     # forward / backward stream (stage1.py)
+        self._helper.weight_cache = weight_cache
+        self.overlap_d = overlap_d                               # forwards on the caller's stream, backwards on a second one (stage1.py)
         self.iter = 0
         self.losses = None
         self._names = []
@@ -112,7 +115,7 @@ class Stage2Adversarial:
             self.losses, self._names = torch.zeros(len(names), device=dev), names
         self.losses.zero_()
         self.opt.zero_grad()
-        overlap = os.environ.get("AFI_D_OVERLAP", "1") != "0"          # forwards in order on the caller's stream, backwards on a second one (stage1.py)
+        overlap = self.overlap_d
         with _wino_weight_cache(h, dev):                   # D's weights are fixed until the optimizer step below
             try:
                 self._d_levels(h, guide_feats, fpn_feats, dev, overlap)

@@ -55,6 +55,8 @@ def parse():
                          "engine afterwards and reports them under other_dtypes")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
+    ap.add_argument("--one-stream", action="store_true", help="Stage1Step(overlap_d=False, overlap_g=False): every kernel alone on the chip (the "
+                    "profiling passes of tools/prof_r03.sh: per-kernel durations comparable across rounds)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launch path only (no GPU work, no metric): spawn / rendezvous / all-reduce / invariant checks of the N-rank job with "
                          "CPU tensors; what tests/test_host_logic.py runs with --gpus 2 --backend gloo in a container without a GPU")
@@ -297,15 +299,16 @@ def bifpn_bench(amd, torch, iters=10, warmup=3):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters
 
-    dt_eager = timed(lambda: net(feats))
-    dt_graph = None
-    try:
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            net(feats)
-        dt_graph = timed(g.replay)
-    except Exception as e:
-        log(f"  hipGraph capture unavailable: {type(e).__name__}: {e}")
+    with torch.no_grad():                                   # inference (with grad mode on the module would build its autograd graph)
+        dt_eager = timed(lambda: net(feats))
+        dt_graph = None
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                net(feats)
+            dt_graph = timed(g.replay)
+        except Exception as e:
+            log(f"  hipGraph capture unavailable: {type(e).__name__}: {e}")
     g_px = sum(7 * (7 * 2 ** i) * (11 * 2 ** i) for i in range(4))               # 7 layers x (p7, p6, p5, p4 inputs)
     flop = g_px * G_FWD_FLOP_PER_INPX
     best = min(dt_eager, dt_graph) if dt_graph else dt_eager
@@ -448,7 +451,7 @@ def main():
     G = amd.Generator(n_residual_dense_blocks=3).to(dev)
     D = amd.Discriminator().to(dev)
     G.train(); D.train()
-    step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype)
+    step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype, overlap_d=not args.one_stream, overlap_g=not args.one_stream)
     run_dtype = step.dtype                             # the library's default when --dtype is not given
     guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)     # each rank owns a different shard of the global batch
@@ -624,7 +627,7 @@ def main():
                 # `achieved` above is over the timed region, where the D phase runs on two streams: a launch's duration includes the time it
                 # shares the chip with the other stream's kernels (sum of durations > wall time).  The kernel with the chip to itself:
                 "kernel_alone": (dict(kernel_alone, frac=kernel_alone["achieved"] / dom_peak,
-                                      note="two extra steps with AFI_D_OVERLAP / AFI_G_OVERLAP off, same HIP-event brackets; profiles/r02 holds both traces")
+                                      note="two extra steps with the engine's overlap_d / overlap_g off (one stream), same HIP-event brackets; profiles/r03 holds both traces")
                                  if kernel_alone else None),
                 # fp32-equivalent rate of the dominant kernel against the fp32 MFMA roof it replaces (> 1 is the point of the emulated forms)
                 "achieved_over_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,

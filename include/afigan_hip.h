@@ -8,7 +8,7 @@
  * so this header defines the boundary a binding for that path needs: plain pointers, sizes and a HIP stream;
  * no torch types; every function returns an int status (AFI_OK == 0) and never throws or allocates.
  * The Python binding a maintainer would add (ctypes) is shown in INTEGRATION.md and shipped in
- * afi-gan_amd/_lib.py.
+ * afigan_amd/_lib.py.
  *
  * Conventions
  *   - Activations are PIXEL-MAJOR ("NHWC"): element (n, y, x, c) of a view lives at
@@ -17,7 +17,8 @@
  *     (stage1_trainer.py:437-443) and channel slices of wider buffers are expressed through p / strides.
  *   - 3x3 weights are  [Cout][3][3][Cin]  (the physical layout of a [Cout,Cin,3,3] tensor in channels_last
  *     format, so the reference's state_dict shapes are unchanged); the ConvTranspose2d weight stays in torch's
- *     [Cin][Cout][6][6] layout.  All data is fp32; the matrix math runs on v_mfma_f32_32x32x2_f32 (exact f32).
+ *     [Cin][Cout][6][6] layout.  All data is fp32 in memory.  Matrix math: the Winograd-domain GEMMs of the big 3x3 convs in the context's arithmetic
+ *     (afi_ctx_set_compute_dtype: by default fp32 products formed exactly on the bf16 matrix cores), every other GEMM on v_mfma_f32_32x32x2_f32 (exact f32).
  *   - Channel counts must be multiples of 4 (float4 granularity); spatial sizes are arbitrary.
  *   - "accumulate" outputs (all gradients w.r.t. parameters) are += targets: zero them first, like
  *     optimizer.zero_grad() at stage1_trainer.py:374/426.
@@ -92,6 +93,22 @@ int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
 #define AFI_DTYPE_DEFAULT AFI_DTYPE_BF16X6
 int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype);
 int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
+/* Algorithm options of a context.  The library reads NO environment variable: every choice that changes numerics or scheduling is made
+ * here, per context, and may be changed between calls (refused while weight-gradient sums are pending).  ctx == NULL reads the default. */
+#define AFI_OPT_WINOGRAD 0                    /* 1 (default): 3x3 / stride-1 convs with >= 128 channels on both sides run in Winograd form from the pixel
+                                                 thresholds below; 0: direct implicit GEMM on the fp32 MFMA everywhere */
+#define AFI_OPT_WINOGRAD_F4_BACKWARD 1        /* 1 (default): F(4x4,3x3) / F(3x3,4x4) for data and weight gradients and for forwards no backward follows,
+                                                 from 8192 pixels; 0: F(2x2,3x3) everywhere */
+#define AFI_OPT_WINOGRAD_F4_FORWARD 2         /* 0 (default): forwards whose activations decide LeakyReLU masks stay on F(2x2) (its 1e-6 rounding against
+                                                 F(4x4)'s 3e-5: measured mask-flip study); 1: F(4x4) there too (8 % faster, 2.6x the flips) */
+#define AFI_OPT_BN_STATS_FP64 3               /* 1 (default): BatchNorm batch statistics accumulated in fp64 (torch's CPU accumulation type) */
+#define AFI_OPT_D_WINOGRAD_MIN_PIXELS 4       /* 1024: discriminator calls of fewer pixels stay direct (values below 1024 act as 1024) */
+#define AFI_OPT_G_WINOGRAD_MIN_PIXELS 5       /* 2048: the same for a convolution of the interpolator */
+#define AFI_OPT_G_SMALLMAP_MAX_PIXELS 6       /* 2048: below, the dense blocks run in column-batched form (5 grouped launches per block); 0: never */
+#define AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS 7  /* 3000: up to here all weight / bias gradients of a backward pass run as three grouped launches; 0: per layer */
+#define AFI_OPT_COUNT 8
+int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
+long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over
  * `planes` groups; rows_per_plane % 128 == 0, N % 128 == 0, K % 32 == 0 (else AFI_ERR_UNSUPPORTED); fp32 in memory for every dtype.
  * Under the bf16 settings the B operand (inside the library: the transformed weights, shared by every row tile of a plane) is first split

@@ -121,3 +121,23 @@ def test_wgrad_stream_k_plan_is_a_partition():
     for _ in range(300):
         n = rng.randint(1, 45)
         check([(rng.randint(1, 5000), rng.randint(1, 40)) for _ in range(n)], rng.randint(1, 4))
+
+
+def test_option_defaults_without_a_context():
+    """afi_ctx_get_option(NULL, .) reports the library defaults (host-only); unknown options are refused."""
+    _build()
+    from afigan_amd import _lib
+    lib = _lib.load()
+    want = {"winograd": 1, "winograd_f4_backward": 1, "winograd_f4_forward": 0, "bn_stats_fp64": 1, "d_winograd_min_pixels": 1024,
+            "g_winograd_min_pixels": 2048, "g_smallmap_max_pixels": 2048, "g_grouped_wgrad_max_pixels": 3000}
+    assert set(want) == set(_lib.OPTIONS)
+    for k, v in want.items():
+        assert lib.afi_ctx_get_option(None, _lib.OPTIONS[k]) == v, k
+    assert lib.afi_ctx_get_option(None, 8) == -1 and lib.afi_ctx_set_option(None, 0, 1) == 1
+    import shutil
+    import subprocess
+    nm = shutil.which("nm")
+    if nm:                                                  # the imported-symbol table of the shared object: no getenv among them
+        syms = subprocess.run([nm, "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+        assert "fopen" in syms or "hip" in syms             # (the listing worked)
+        assert "getenv" not in syms, "the library must not read the environment (options live in afi_ctx_t)"

@@ -185,8 +185,7 @@ def test_dtype_api_guards(amd):
     cx = _lib.Ctx()
     with pytest.raises(amd.AfiError):
         cx.set_dtype("fp16")
-    import os
-    dflt = int(os.environ.get("AFI_DEFAULT_DTYPE", _lib.DTYPES[DEFAULT_DTYPE]))
+    dflt = _lib.DTYPES[DEFAULT_DTYPE]
     assert cx.dtype == {v: k for k, v in _lib.DTYPES.items()}[dflt]
     assert _lib.load().afi_ctx_set_compute_dtype(cx.handle, 2) == 1 and _lib.load().afi_ctx_get_compute_dtype(cx.handle) == dflt
     cx.set_dtype("bf16x3")

@@ -1,4 +1,4 @@
-"""GPU parity of the BiFPN path (afi-gan_amd/bifpn_sr.py): the per-op pieces and their backward against torch-CPU
+"""GPU parity of the BiFPN path (afigan_amd/bifpn_sr.py): the per-op pieces and their backward against torch-CPU
 fp32 / fp64, the whole seven-layer forward (28 interpolator calls) against the fixtures captured from the imported reference
 BiFPN_AFIGAN in eval mode and in training mode (outputs, gradients, running statistics) and against the CPU oracle.
 Bar: 1e-3 relative fp32 (named exceptions below)."""
@@ -121,8 +121,17 @@ def test_bifpn_eval_vs_reference_fixture_and_oracle(amd, golden_dir):
     assert set(net.state_dict()) == set(p)                                    # the reference's state_dict contract
     net.load_state_dict(p, strict=True)
     net.eval()
-    out = net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})
+    with torch.no_grad():                                   # inference: the folded fast path (detectron2 runs evaluation under no_grad)
+        out = net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})
     assert list(out) == ["p3", "p4", "p5", "p6", "p7"] and net.size_divisibility == 128
+    # eval mode with grad mode ON and trainable parameters (frozen-statistics fine-tuning): the differentiable path, attached to the
+    # parameters (the fast path used to return detached outputs here), same values
+    out_g = net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})
+    assert all(o.requires_grad for o in out_g.values())
+    for k in out:
+        assert _rel(out_g[k], out[k]) < 1e-4, k
+    g = torch.autograd.grad(out_g["p3"].sum(), net.BiFPNLayer_6_conv3_up.pointwise.weight)[0]
+    assert float(g.abs().sum()) > 0
     with torch.no_grad():
         ref = orc.bifpn_afigan_forward(feats, p)
     for k, o in out.items():
@@ -132,7 +141,7 @@ def test_bifpn_eval_vs_reference_fixture_and_oracle(amd, golden_dir):
     # folded constants follow parameter updates (no stale cache)
     with torch.no_grad():
         net.BiFPNLayer_6_conv3_up.norm.bias.add_(0.5)
-    out2 = net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})
+        out2 = net({f"stage{i + 3}": f.cuda() for i, f in enumerate(feats)})
     assert _rel(out2["p3"], out["p3"] + 0.5) < 1e-5
 
 
@@ -256,16 +265,17 @@ def test_bifpn_hipgraph_capture(amd):
     net = amd.BiFPN_AFIGAN(_BottomUp3(), ["stage3", "stage4", "stage5"], 256, 7, norm="SyncBN", top_block=amd.LastLevelP6P7(16, 256, "SyncBN")).cuda().eval()
     g = torch.Generator(device="cuda").manual_seed(1)
     feats = {f"stage{i + 3}": torch.randn((1, c, 16 // 2 ** i, 32 // 2 ** i), device="cuda", generator=g) for i, c in enumerate([8, 12, 16])}
-    eager = net(feats)
-    torch.cuda.synchronize()
-    graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        captured = net(feats)
-    for v in feats.values():
-        v.mul_(0.5)                                        # new input values in the same buffers
-    graph.replay()
-    torch.cuda.synchronize()
-    eager2 = net(feats)
+    with torch.no_grad():                                   # (inference: the folded path; with grad mode on the module builds an autograd graph)
+        eager = net(feats)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            captured = net(feats)
+        for v in feats.values():
+            v.mul_(0.5)                                    # new input values in the same buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        eager2 = net(feats)
     for k in eager:
         assert torch.equal(captured[k], eager2[k]), k
         assert not torch.equal(captured[k], eager[k]), k

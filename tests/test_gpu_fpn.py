@@ -1,4 +1,4 @@
-"""GPU parity of the AFI feature-pyramid merge (afi-gan_amd/fpn_sr.py) against the CPU oracle's
+"""GPU parity of the AFI feature-pyramid merge (afigan_amd/fpn_sr.py) against the CPU oracle's
 restatement of fpn_sr.py:127-165: outputs p2..p6, gradients w.r.t. the bottom-up features, the lateral / output convs
 and the interpolator.  Bar: 1e-3 relative fp32."""
 import pytest

@@ -1,4 +1,4 @@
-"""GPU parity of the AFI path-aggregation pyramid (afi-gan_amd/pafpn_sr.py) against the CPU oracle's
+"""GPU parity of the AFI path-aggregation pyramid (afigan_amd/pafpn_sr.py) against the CPU oracle's
 restatement of pafpn_sr.py:147-193 and against the fixture captured from the imported reference: outputs p2..p6, gradients
 w.r.t. the bottom-up features, the lateral / downsample / output convs and the interpolator.  Bar: 1e-3 relative fp32."""
 import numpy as np

@@ -1,4 +1,4 @@
-"""GPU parity of one stage-1 G+D iteration (afi-gan_amd/stage1.py) against the golden replay of
+"""GPU parity of one stage-1 G+D iteration (afigan_amd/stage1.py) against the golden replay of
 stage1_trainer.py:336-433 over the reference modules, and against the CPU oracle on a ragged small pyramid."""
 import os
 
@@ -242,12 +242,10 @@ def test_stage1_phase_caches_do_not_change_the_gradients(amd, monkeypatch):
     Winograd tilings active: 2x64x96 -> F(4x4), 2x32x48 -> F(2x2)) yields the same flat gradient buffers with and without them,
     and two steps (weights moved in between: the caches must have been invalidated) the same losses."""
     def run(wcache, wgacc):
-        monkeypatch.setenv("AFI_WINO_WCACHE", wcache)
-        monkeypatch.setenv("AFI_WINO_WGACC", wgacc)
         torch.manual_seed(0)
         G = amd.Generator(n_residual_dense_blocks=3).cuda()
         D = amd.Discriminator().cuda()
-        step = amd.Stage1Step(G, D, base_lr=0.05, warmup_iters=0)
+        step = amd.Stage1Step(G, D, base_lr=0.05, warmup_iters=0, weight_cache=wcache == "1", wgrad_accum=wgacc == "1")
         gen = torch.Generator(device="cuda").manual_seed(3)
         hrs = [torch.randn((2, 256, 64, 96), device="cuda", generator=gen), torch.randn((2, 256, 32, 48), device="cuda", generator=gen)]
         lrs = [torch.randn((2, 256, 33, 49), device="cuda", generator=gen), torch.randn((2, 256, 16, 24), device="cuda", generator=gen)]
@@ -268,7 +266,7 @@ def test_stage1_phase_caches_do_not_change_the_gradients(amd, monkeypatch):
 def test_stage1_one_stream_and_two_stream_steps_agree(amd, overlap_d, overlap_g):
     """The D phase on two streams (forwards on the caller's, backwards on the engine's second one, each with its own afi_ctx_t) and G's
     backward beside the G-phase D forwards are pure schedules: two steps from the same state give the same flat gradients, parameters and
-    losses as the one-stream engine (fp32 atomics reorder sums; nothing else may differ).  ADVICE r2: AFI_D_OVERLAP / AFI_G_OVERLAP."""
+    losses as the one-stream engine (fp32 atomics reorder sums; nothing else may differ).  ADVICE r2: Stage1Step(overlap_d=, overlap_g=)."""
     import copy
     torch.manual_seed(0)
     G0 = amd.Generator(n_residual_dense_blocks=3).cuda()
@@ -279,8 +277,7 @@ def test_stage1_one_stream_and_two_stream_steps_agree(amd, overlap_d, overlap_g)
 
     def run(od, og):
         G, D = copy.deepcopy(G0), copy.deepcopy(D0)
-        step = amd.Stage1Step(G, D, base_lr=0.05, warmup_iters=0)
-        step.overlap_d, step.overlap_g = od, og
+        step = amd.Stage1Step(G, D, base_lr=0.05, warmup_iters=0, overlap_d=od, overlap_g=og)
         assert step.ctx.handle.value != step.bctx.handle.value       # one context per stream (include/afigan_hip.h)
         step.run_step(lrs, hrs)
         grads = (step.d_opt.flat_grad.detach().clone(), step.g_opt.flat_grad.detach().clone())

@@ -1,4 +1,4 @@
-"""GPU parity of the stage-2 adversarial terms (afi-gan_amd/stage2.py) against the CPU oracle's
+"""GPU parity of the stage-2 adversarial terms (afigan_amd/stage2.py) against the CPU oracle's
 restatement of stage2_trainer.py:299-364 (D step, then the generator-side losses whose L1 gradient reaches the FPN features)."""
 import numpy as np
 import pytest

@@ -1,6 +1,6 @@
-"""D forward+backward on one seeded input under the conv algorithm the environment selects (or torch's own fp32 / fp64 ops for
-tag torch32 / torch64); dumps the gradients so tools/dflip_cmp.py can compare the variants.  The switches are read once per
-process, hence one process per variant (tools/dflip_check.sh)."""
+"""D forward+backward on one seeded input under the conv algorithm the tag names -- context options of the library (afi_ctx_set_option):
+direct (winograd off), f2fwd (the default: F(2x2) forwards, F(4x4) gradients), f4fwd (F(4x4) forwards too), f2all (F(2x2) everywhere) --
+or torch's own fp32 / fp64 ops (torch32 / torch64); dumps the gradients so tools/dflip_cmp.py can compare the variants."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,6 +8,9 @@ import torch.nn.functional as F
 import afigan_amd as amd
 
 tag, H, W = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+_cx = amd._lib.current_ctx()
+for _k, _v in {"direct": {"winograd": 0}, "f4fwd": {"winograd_f4_forward": 1}, "f2all": {"winograd_f4_backward": 0}}.get(tag, {}).items():
+    _cx.set_option(_k, _v)
 torch.manual_seed(0)
 D = amd.Discriminator().cuda()
 x = torch.randn(2, 256, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)

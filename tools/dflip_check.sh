@@ -4,9 +4,9 @@ set -e
 H=${1:-100}; W=${2:-168}
 python tools/dflip_check.py torch64 $H $W
 python tools/dflip_check.py torch32 $H $W
-AFI_WINO=0 python tools/dflip_check.py direct $H $W
+python tools/dflip_check.py direct $H $W
 python tools/dflip_check.py f2fwd $H $W
-AFI_WINO_D_F4=1 python tools/dflip_check.py f4fwd $H $W
-AFI_WINO_F4=0 python tools/dflip_check.py f2all $H $W
+python tools/dflip_check.py f4fwd $H $W
+python tools/dflip_check.py f2all $H $W
 python tools/dflip_cmp.py torch32 direct f2all f2fwd f4fwd
 rm -f gpurun_out/dflip_*.pt
