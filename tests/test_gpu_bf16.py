@@ -139,9 +139,18 @@ def test_generator_fwd_bwd_under_dtype(amd, dtype):
     ref = orc.generator_forward(xr, pr, 3)
     (ref * R).sum().backward()
     xg = x.cuda().requires_grad_(True)
-    with amd.compute_dtype(dtype):
-        out = G(xg)
-        (out * R.cuda()).sum().backward()
+    from afigan_amd import _lib
+    seen = []
+    ob = lambda name, cx: seen.append((name, _lib.load().afi_ctx_get_compute_dtype(cx.handle)))      # noqa: E731
+    _lib._observers.append(ob)
+    try:
+        with amd.compute_dtype(dtype):
+            out = G(xg)
+            (out * R.cuda()).sum().backward()
+    finally:
+        _lib._observers.remove(ob)
+    # the backward (on PyTorch's autograd thread) really ran in the requested arithmetic: the library reports it at the call
+    assert seen == [("afi_generator_fwd", _lib.DTYPES[dtype]), ("afi_generator_bwd", _lib.DTYPES[dtype])], seen
     tol = TOL_NET[dtype]
     assert _rel(out, ref) < tol and _rel(xg.grad, xr.grad) < tol
     # parameter gradients, L2-relative per tensor: the forward's error (1e-5 of a pre-activation under bf16x3, 4e-3 under bf16) flips

@@ -1,7 +1,7 @@
 """Parity at BASELINE.json's full sizes (configs[1]: per-GPU batch 2, P2 = 200x336) where the whole-tensor oracle would
-take minutes: the three dominant kernels (forward, data gradient, weight gradient of D's 512 -> 1024 conv at P2 in both the
-direct and the Winograd form, and the
-generator's 256 -> 256 convs on the 208x336 up-sampled map) are checked
+take minutes: the dominant kernels (forward, data gradient, weight gradient of D's 512 -> 1024 and 1024 -> 1024 convs at P2 -- the latter
+is the heaviest layer of the step, K = 1024 -- in both the direct and the Winograd form, and the generator's 256 -> 256 convs on the
+208x336 up-sampled map) are checked
 
   * against an fp64 CPU evaluation of the defining sums at a few hundred sampled outputs (borders and tile seams included),
   * through size-independent properties: linearity  conv(a*x + b*y) == a*conv(x) + b*conv(y)  and the adjoint identity
@@ -31,7 +31,7 @@ def _sample_positions(rng, N, H, W, n):
 
 
 @pytest.mark.parametrize("algo", ["direct", "winograd"])
-@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 512, 1024, 200, 336), (2, 256, 256, 208, 336)])
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(2, 512, 1024, 200, 336), (2, 1024, 1024, 200, 336), (2, 256, 256, 208, 336)])
 def test_conv3x3_full_size_sampled_fp64_and_properties(amd, N, Cin, Cout, H, W, algo):
     ops = amd.ops
     rng = np.random.default_rng(0)
@@ -86,3 +86,103 @@ def test_conv3x3_full_size_sampled_fp64_and_properties(amd, N, Cin, Cout, H, W, 
     s_wgrad = (w.double() * dw.double()).sum().item()
     cs = (o0.double().norm() * dy.double().norm()).item()                       # Cauchy-Schwarz scale of the three inner products
     assert abs(s_fwd - s_dgrad) <= 1e-5 * cs and abs(s_fwd - s_wgrad) <= 1e-5 * cs
+
+
+def test_stage1_step_full_size_layer_by_layer_fp64(amd):
+    """ONE stage-1 iteration at configs[1]'s full size (batch 2, P2..P6 of 800x1333 images; stage1_trainer.py:336-433) -- what bench.py
+    times -- with its largest level checked against fp64 beyond "the losses are finite":
+
+      * the discriminator's D-phase forward on the real and on the fake P2 map (2 x 256 x 200 x 336), layer by layer: for a subset of
+        output channels of every conv, the conv output over ALL 134,400 pixels in fp64 (from the saved input activation of that layer),
+        its batch mean / 1/sqrt(var + eps) over all pixels, the normalised + LeakyReLU activation, and the logits of the last conv;
+      * d_loss_p2 recomputed in fp64 from the logits (both BCE terms);
+      * the interpolator's output on the 104 x 168 P2 input at sampled positions: the fp64 oracle on a 48 x 48 input patch around each
+        (wider than its receptive field), compared at the patch centre;
+      * content_loss_p2 (L1 over the cropped pair) recomputed in fp64 from the two full maps.
+
+    Everything is read back from the engine's own workspaces (afi_discriminator_ws_layout), with the weights as they were BEFORE the step."""
+    import ctypes as C
+    from afigan_amd import _lib
+    from oracle import afigan_oracle as orc
+    torch.manual_seed(0)
+    G = amd.Generator(n_residual_dense_blocks=3).cuda().train()
+    D = amd.Discriminator().cuda().train()
+    gw = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    dw = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    hr_shapes = [(200, 336), (100, 168), (50, 84), (25, 42), (13, 21)]
+    lr_shapes = [(104, 168), (52, 84), (26, 42), (13, 21), (7, 11)]
+    hrs = [torch.randn((2, 256, h, w), device="cuda", generator=gen).contiguous(memory_format=torch.channels_last) for h, w in hr_shapes]
+    lrs = [torch.randn((2, 256, h, w), device="cuda", generator=gen).contiguous(memory_format=torch.channels_last) for h, w in lr_shapes]
+    step = amd.Stage1Step(G, D, base_lr=1e-3)
+    step.run_step(lrs, hrs)
+    torch.cuda.synchronize()
+    m = step.metrics()
+    assert all(np.isfinite(v) for v in m.values())
+
+    N, H, W = 2, 200, 336
+    P = N * H * W
+    Fa = (C.c_int * 4)(256, 512, 1024, 1024)
+    off = (C.c_longlong * 12)()
+    _lib.check(_lib.load().afi_discriminator_ws_layout(Fa, N, H, W, off), "layout")
+    tr = step._buf["goutg_ws0"]                              # G(lr_p2): 2 x 256 x 208 x 336, cropped to the hr size below
+    rng = np.random.default_rng(5)
+    bce = 0.0
+    for target, x_in in ((1, hrs[0]), (0, tr[:, :, :H, :W])):
+        ws = step._buf[f"d_ws_0_{target}"]
+        logits = step._buf[f"d_ws_0_{target}_logits"][:P].view(N, H, W).double()
+        a = x_in.permute(0, 2, 3, 1).double()               # [N, H, W, Cin] fp64, the layer's input
+        for n in range(3):
+            ci, co = (256, 512, 1024)[n], (512, 1024, 1024)[n]
+            pre = f"Discriminators.0.{n}.0"
+            S = torch.from_numpy(np.sort(rng.choice(co, 6, replace=False))).cuda()
+            wS = dw[pre + ".weight"][S].double()             # [6, ci, 3, 3]
+            ap = torch.nn.functional.pad(a, (0, 0, 1, 1, 1, 1))
+            c64 = dw[pre + ".bias"][S].double().view(1, 1, 1, -1).expand(N, H, W, -1).clone()
+            for ky in range(3):
+                for kx in range(3):
+                    c64 += ap[:, ky:ky + H, kx:kx + W, :] @ wS[:, :, ky, kx].t()
+            c_hip = ws[off[n]:off[n] + P * co].view(N, H, W, co)
+            y_hip = ws[off[3 + n]:off[3 + n] + P * co].view(N, H, W, co)
+            mean_hip, invstd_hip = ws[off[6 + n]:off[6 + n] + co], ws[off[9 + n]:off[9 + n] + co]
+            sc = c64.abs().max().item()
+            assert (c_hip[..., S].double() - c64).abs().max().item() <= 1e-4 * sc, ("conv", target, n)
+            mean64 = c64.mean(dim=(0, 1, 2))
+            var64 = c64.var(dim=(0, 1, 2), unbiased=False)
+            is64 = torch.rsqrt(var64 + orc.BN_EPS)
+            assert (mean_hip[S].double() - mean64).abs().max().item() <= 1e-5 * (mean64.abs().max().item() + var64.sqrt().max().item()), ("mean", target, n)
+            assert ((invstd_hip[S].double() - is64).abs() / is64).max().item() <= 1e-5, ("invstd", target, n)
+            z64 = (c64 - mean64) * is64 * dw[pre + ".norm.weight"][S].double() + dw[pre + ".norm.bias"][S].double()
+            y64 = torch.where(z64 > 0, z64, 0.2 * z64)
+            assert (y_hip[..., S].double() - y64).abs().max().item() <= 1e-4 * y64.abs().max().item(), ("act", target, n)
+            a = y_hip.double()                               # next layer's input: the saved activation (all channels)
+            del ap, c64, z64, y64
+        w3 = dw["Discriminators.0.3.0.weight"][0].double()   # [1024, 3, 3]
+        ap = torch.nn.functional.pad(a, (0, 0, 1, 1, 1, 1))
+        z = dw["Discriminators.0.3.0.bias"].double().view(1, 1, 1).expand(N, H, W).clone()
+        for ky in range(3):
+            for kx in range(3):
+                z += ap[:, ky:ky + H, kx:kx + W, :] @ w3[:, ky, kx]
+        assert (logits - z).abs().max().item() <= 1e-4 * z.abs().max().item(), ("logits", target)
+        bce += torch.nn.functional.softplus(-logits if target == 1 else logits).mean().item()
+        del a, ap, z
+    assert abs(m["d_loss_p2"] - bce) <= 1e-5 * abs(bce), (m["d_loss_p2"], bce)
+
+    # ---- the interpolator at sampled positions of the P2 level, and the content loss over the whole cropped pair
+    gp64 = {k: v.double().cpu() for k, v in gw.items()}
+    lr0 = lrs[0].double().cpu()
+    Hl, Wl = 104, 168
+    # receptive field of an output pixel: 17 low-res 3x3 convs + the conv-transpose (2) + the hi-res conv (1) = 20 low-res pixels each way
+    for (n, cy, cx) in ((0, 0, 0), (1, Hl - 1, Wl - 1), (0, 50, 80)):
+        y0, x0 = min(max(cy - 24, 0), Hl - 48), min(max(cx - 24, 0), Wl - 48)
+        patch = lr0[n:n + 1, :, y0:y0 + 48, x0:x0 + 48]
+        ref = orc.generator_forward(patch, gp64, 3)          # [1, 256, 96, 96]; exact wherever the zero padding of the patch is out of reach
+        for dy_ in (0, 1):
+            for dx_ in (0, 1):
+                oy, ox = 2 * cy + dy_, 2 * cx + dx_
+                got = tr[n, :, oy, ox].double().cpu()
+                want = ref[0, :, oy - 2 * y0, ox - 2 * x0]
+                # (a sample at a map corner sits at the patch corner too: there the patch's zero padding IS the map's)
+                assert (got - want).abs().max().item() <= 1e-3 * want.abs().max().item(), ("G", n, oy, ox)
+    l1 = (tr[:, :, :H, :W].double() - hrs[0].double()).abs().mean().item()
+    assert abs(m["content_loss_p2"] - l1) <= 1e-5 * l1, (m["content_loss_p2"], l1)

@@ -87,3 +87,82 @@ def test_pafpn_odd_level_sizes_rejected(amd):
     feats = {"res2": torch.randn(1, 8, 8, 12, device="cuda"), "res3": torch.randn(1, 8, 4, 6, device="cuda")}
     out = net(feats)
     assert list(out) == ["p2", "p3"] and out["p3"].shape == (1, 32, 4, 6)
+
+
+# BASELINE.json configs[4] names this pyramid "bf16": the opt-in arithmetic settings of the big GEMMs, each with ITS OWN stated tolerance.
+#   vs the fp32 CPU oracle: outputs max-norm; input gradients max-norm and relative L2; parameter gradients relative L2 per tensor.
+#   Gradients sit behind ~60 LeakyReLU layers (three nested interpolator calls): a pre-activation that the CPU and the GPU round to
+#   different sides of zero flips one mask element, which moves the gradients behind it by a finite amount however exact the arithmetic
+#   is (tests/test_gpu_d_parity.py has the anatomy).  Measured on this case (tools/pafpn_flip_probe.py, profiles/r03/pafpn_flip_anatomy.txt):
+#   fp32, bf16x6 and bf16x3 ALL deviate from the oracle by the same 1.7e-2 max-norm / 2.2e-3 L2 -- ONE ReLU element of the 49,152 at the
+#   12x16 level, whose fp64 pre-activation is 9.4e-8 on a scale of 1.3 (below fp32's epsilon) and comes out -0.0 on the GPU, carries a
+#   gradient of 2.2 against ||dz|| = 150: 1.45e-2 relative L2 on every gradient behind it.  Not the arithmetic.  So the arithmetic itself is held by a
+#   SECOND comparison, against the HIP fp32 run of the same case (same rounding pattern, masks mostly shared): relative L2 per setting.
+PAFPN_TOL = {   # (outputs max, dfeat max, dfeat L2, dparam L2) vs the oracle;  (outputs max, dfeat L2) vs the HIP fp32 run
+    "fp32": ((1e-3, 3e-2, 5e-3, 3e-2), None),             # measured: 6.7e-7, 1.7e-2, 2.2e-3, 1.7e-2 (a 256-element bias behind the ReLU merges)
+    "bf16x6": ((1e-3, 3e-2, 5e-3, 3e-2), (1e-5, 1e-3)),
+    "bf16x3": ((1e-3, 3e-2, 5e-3, 3e-2), (1e-4, 5e-3)),
+    "bf16": ((5e-2, 5e-2, 1e-2, 1e-1), (5e-2, 2e-2)),
+}
+
+
+def test_pafpn_under_every_arithmetic_setting(amd):
+    """256-channel PAFPN_AFIGAN (pafpn_sr.py:147-193) on maps large enough that the Winograd-domain GEMMs carry the interpolator's and the
+    output convs' work (res2 96x128: 12288 pixels; the interpolator runs 12x16 -> 24x32 -> 48x64 -> 96x128), forward AND backward under
+    `compute_dtype(dtype)` for fp32 / bf16x6 / bf16x3 / bf16, against the fp32 CPU oracle and against the HIP fp32 run.  The library-side
+    arithmetic of the context is observed at every convolution entry point of the forward and of the backward (which PyTorch runs on its
+    autograd thread): all of them must report the setting."""
+    import threading
+    from afigan_amd import _lib
+    chans, strides, C = [8, 12, 16, 20], [4, 8, 16, 32], 256
+    bu = _BottomUp(chans, strides)
+    torch.manual_seed(11)
+    net = amd.PAFPN_AFIGAN(bu, ["res2", "res3", "res4", "res5"], C, norm="", top_block=amd.LastLevelMaxPool(), fuse_type="sum").cuda()
+    with torch.no_grad():
+        net.srf_module.load_state_dict(orc.closed_form_generator_params(C, 3, 32))
+    gen = torch.Generator().manual_seed(8)
+    feats = {f"res{i + 2}": torch.randn((1, c, 12 * 2 ** (3 - i), 16 * 2 ** (3 - i)), generator=gen) for i, c in enumerate(chans)}
+    R = None
+    pr = {k: v.detach().cpu().contiguous().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    fr = [feats[f"res{i + 2}"].clone().requires_grad_(True) for i in range(4)]
+    ref = orc.pafpn_afigan_forward(fr, [2, 3, 4, 5], pr, fuse_type="sum")
+    R = {k: torch.randn(o.shape, generator=torch.Generator().manual_seed(300 + i)) for i, (k, o) in enumerate(ref.items())}
+    sum((o * R[k]).sum() for k, o in ref.items()).backward()
+
+    def _l2(a, b):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        return ((a - b).norm() / (b.norm() + 1e-300)).item()
+    base = None
+    for dtype in ("fp32", "bf16x6", "bf16x3", "bf16"):
+        for q in net.parameters():
+            q.grad = None
+        fg = {k: v.cuda().requires_grad_(True) for k, v in feats.items()}
+        seen = []
+        ob = lambda name, cx: seen.append((name, threading.get_ident(), _lib.load().afi_ctx_get_compute_dtype(cx.handle)))      # noqa: E731
+        _lib._observers.append(ob)
+        try:
+            with amd.compute_dtype(dtype):
+                out = net(fg)
+                n_fwd = len(seen)
+                sum((o * R[k].cuda()).sum() for k, o in out.items()).backward()
+        finally:
+            _lib._observers.remove(ob)
+        assert n_fwd > 0 and len(seen) > n_fwd and {s[2] for s in seen} == {_lib.DTYPES[dtype]}, (dtype, {s[2] for s in seen})
+        assert any(s[0] == "afi_generator_bwd" for s in seen[n_fwd:]) and any("wino" in s[0] for s in seen)      # the Winograd path was taken
+        (t_out, t_dmax, t_dl2, t_pl2), vs32 = PAFPN_TOL[dtype]
+        dfeat = [fg[f"res{i + 2}"].grad.detach().clone() for i in range(4)]
+        e_out = max(_rel(out[k], ref[k]) for k in ref)
+        e_dmax = max(_rel(dfeat[i], fr[i].grad) for i in range(4))
+        e_dl2 = max(_l2(dfeat[i], fr[i].grad) for i in range(4))
+        e_pl2 = max((_l2(q.grad.contiguous(), pr[k].grad), k) for k, q in net.named_parameters())
+        print(f"{dtype}: vs oracle  out {e_out:.2e}  dfeat max {e_dmax:.2e}  L2 {e_dl2:.2e}  dparam L2 {e_pl2[0]:.2e} ({e_pl2[1]})")
+        assert e_out < t_out and e_dmax < t_dmax and e_dl2 < t_dl2 and e_pl2[0] < t_pl2, (dtype, e_out, e_dmax, e_dl2, e_pl2)
+        if base is None:
+            base = ({k: o.detach().clone() for k, o in out.items()}, dfeat)
+        else:
+            b_out = max(_rel(out[k], base[0][k]) for k in base[0])
+            b_dl2 = max(_l2(dfeat[i], base[1][i]) for i in range(4))
+            print(f"{dtype}: vs HIP fp32  out {b_out:.2e}  dfeat L2 {b_dl2:.2e}")
+            assert b_out < vs32[0] and b_dl2 < vs32[1], (dtype, b_out, b_dl2)
+            if dtype == "bf16":                             # and the setting is not a no-op: bf16 operands leave a visible trace
+                assert b_out > 1e-5
