@@ -161,8 +161,12 @@ def test_bifpn_train_vs_reference_fixture(amd, golden_dir):
         gold = fx["out/" + k]
         got = o.detach().cpu().numpy() if k != "p3" else o.detach()[:, ::4].cpu().numpy()
         assert np.abs(got - gold).max() <= 1e-3 * np.abs(gold).max(), k
-    # (the input gradients pass 28 interpolator calls and 61 training-mode norms: the LeakyReLU-mask flips between two fp32-grade
-    #  evaluations -- tests/test_gpu_d_parity.py -- put them at 1.5e-3 .. 2.5e-3 max-norm, whichever fp32-grade GEMM arithmetic runs)
+    # The input gradients pass 28 interpolator calls (~500 LeakyReLU layers), 14 zero-padded max-pools and 61 training-mode norms.  What
+    # bar can ANY fp32 implementation be held to?  tools/bifpn_grad_sensitivity.py (profiles/r03/bifpn_grad_sensitivity.txt) evaluates this
+    # very fixture on the fp64 CPU oracle with the inputs perturbed by one part in 10^6 -- exact arithmetic, rounding plays no role -- and
+    # the input gradients move by 2e-4 .. 2.8e-3 max-norm (8e-4 L2) depending on which kinks the perturbation crosses; the reference's own
+    # fp32 evaluation sits 2e-4 from fp64.  fp32 rounding perturbs every intermediate by 1e-7 .. 1e-6, so the measured 1.5e-3 .. 2.5e-3 of
+    # the HIP path (whichever fp32-grade GEMM arithmetic runs) is the function's own sensitivity, and the bar is 5e-3 max-norm.
     for k, f in fg.items():
         gold = fx["dfeat/" + k]
         assert np.abs(f.grad.cpu().numpy() - gold).max() <= 5e-3 * np.abs(gold).max(), k
