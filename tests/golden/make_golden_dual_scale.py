@@ -109,11 +109,31 @@ def install_shims():
     class _Unused(Transform):
         pass
 
+    # fvcore semantics the annotation path needs (afigan_utils.py:140-183; dataset_mapper.py:96-109): polygons go through apply_coords one
+    # by one, a CropTransform shifts coordinates by its origin and slices the image, `crop_tfm + TransformList` prepends
+    Transform.apply_polygons = lambda self, polygons: [self.apply_coords(p) for p in polygons]
+
+    class CropTransform(Transform):
+        def __init__(self, x0, y0, w, h): self.x0, self.y0, self.w, self.h = x0, y0, w, h
+        def apply_image(self, img): return img[self.y0:self.y0 + self.h, self.x0:self.x0 + self.w]
+        def apply_coords(self, coords):
+            coords[:, 0] -= self.x0
+            coords[:, 1] -= self.y0
+            return coords
+        def __add__(self, other): return TransformList([self] + list(other.transforms))
+
+    TransformList.apply_polygons = lambda self, polygons: _chain(self, polygons)
+
+    def _chain(tl, polygons):
+        for t in tl.transforms:
+            polygons = t.apply_polygons(polygons)
+        return polygons
+
     class D2RandomFlip:          # detectron2.data.transforms.RandomFlip: a class of its own, unrelated to the reference's copy
         pass
 
     fv = types.ModuleType("fvcore"); fvt = types.ModuleType("fvcore.transforms"); fvtt = types.ModuleType("fvcore.transforms.transform")
-    for n, c in dict(BlendTransform=_Unused, CropTransform=_Unused, HFlipTransform=HFlipTransform, NoOpTransform=NoOpTransform,
+    for n, c in dict(BlendTransform=_Unused, CropTransform=CropTransform, HFlipTransform=HFlipTransform, NoOpTransform=NoOpTransform,
                      Transform=Transform, TransformList=TransformList, VFlipTransform=VFlipTransform).items():
         setattr(fvtt, n, c)
     d2 = types.ModuleType("detectron2"); d2d = types.ModuleType("detectron2.data"); d2t = types.ModuleType("detectron2.data.transforms")
@@ -160,6 +180,86 @@ def make_mapper():
     print(f"dual_scale_mapper.npz: {n} cases; as written, the two lists agree on the flip in {shared} of {n // 2}")
 
 
+def make_annos():
+    """dual_scale_annos.npz -- the annotation side of the mapper with the reference's OWN code: RandomCrop.get_crop_size (transform_gen.py:245-264),
+    gen_crop_transform_with_instance (afigan_utils.py:379-406) and transform_instance_annotations (:140-183), loaded by path and driven exactly as
+    DatasetMapper.__call__ does (dataset_mapper.py:96-109,140-176) under a seeded numpy.random: the crop window, both images, and per instance the
+    transformed box and polygons of both lists.  afigan_utils.py imports pycocotools / detectron2.structures / fvcore.common at its top: stand-ins
+    for exactly those names (BoxMode.convert XYWH_ABS -> XYXY_ABS is the only one the recorded functions execute)."""
+    HFlip = install_shims()
+    spec = importlib.util.spec_from_file_location("ref_transform_gen", os.path.join(REF, "afigan/engine/transform_gen.py"))
+    tg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tg)
+    tg.T.RandomFlip = tg.RandomFlip                          # the "shared" flip variant (SURVEY 8f)
+
+    class BoxMode:
+        XYXY_ABS, XYWH_ABS = 0, 1
+        @staticmethod
+        def convert(box, from_mode, to_mode):
+            b = [float(v) for v in box]
+            assert to_mode == 0
+            return [b[0], b[1], b[0] + b[2], b[1] + b[3]] if from_mode == 1 else b
+    st = types.ModuleType("detectron2.structures")
+    for n in ("BitMasks", "Boxes", "Instances", "Keypoints", "PolygonMasks", "RotatedBoxes", "polygons_to_bitmask"):
+        setattr(st, n, type(n, (), {}))
+    st.BoxMode = BoxMode
+    cat = types.ModuleType("detectron2.data.catalog"); cat.MetadataCatalog = object()
+    pm = types.ModuleType("pycocotools.mask")
+    fio = types.ModuleType("fvcore.common.file_io"); fio.PathManager = object()
+    eng = types.ModuleType("afigan.engine"); eng.transform_gen = tg
+    sys.modules.update({"detectron2.structures": st, "detectron2.data.catalog": cat, "pycocotools": types.ModuleType("pycocotools"), "pycocotools.mask": pm,
+                        "fvcore.common": types.ModuleType("fvcore.common"), "fvcore.common.file_io": fio, "afigan": types.ModuleType("afigan"),
+                        "afigan.engine": eng, "afigan.engine.transform_gen": tg})
+    spec = importlib.util.spec_from_file_location("ref_afigan_utils", os.path.join(REF, "afigan/engine/afigan_utils.py"))
+    au = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(au)
+
+    annos0 = [
+        {"bbox": [10.0, 8.0, 30.0, 24.0], "bbox_mode": 1, "category_id": 3, "iscrowd": 0,
+         "segmentation": [[12.0, 9.5, 38.0, 10.0, 39.5, 30.0, 11.0, 31.5], [20.0, 15.0, 25.0, 15.0, 22.5, 20.0]]},
+        {"bbox": [40.0, 5.0, 62.0, 40.0], "bbox_mode": 0, "category_id": 7, "iscrowd": 0, "segmentation": [[41.0, 6.0, 61.0, 7.5, 55.0, 39.0, 43.5, 36.0]]},
+        {"bbox": [0.0, 30.0, 18.0, 16.0], "bbox_mode": 1, "category_id": 1, "iscrowd": 1, "segmentation": [[1.0, 31.0, 17.0, 31.0, 17.0, 45.0, 1.0, 45.0]]},
+        {"bbox": [50.0, 28.0, 13.5, 19.0], "bbox_mode": 1, "category_id": 5, "iscrowd": 0, "segmentation": [[50.5, 28.5, 63.0, 29.0, 62.0, 46.5, 51.0, 45.0]]},
+    ]
+    crops = [None, ("relative_range", (0.6, 0.7)), ("absolute", (30, 36)), ("relative", (0.5, 0.75))]
+    fx, n = {}, 0
+    for ci, crop in enumerate(crops):
+        for seed in range(5):
+            img = np.random.default_rng(400 + seed).integers(0, 256, size=(48, 64, 3), dtype=np.uint8)
+            annos = copy.deepcopy(annos0)
+            gens = [tg.ResizeShortestEdge((24, 28, 32), 50, "choice"), tg.RandomFlip()]
+            gens_r = copy.deepcopy(gens)
+            np.random.seed(7000 + 10 * ci + seed)
+            image = img
+            crop_tfm = None
+            if crop is not None:                                                                   # dataset_mapper.py:96-102
+                crop_gen = tg.RandomCrop(*crop)
+                crop_tfm = au.gen_crop_transform_with_instance(crop_gen.get_crop_size(image.shape[:2]), image.shape[:2], np.random.choice(annos))
+                image = crop_tfm.apply_image(image)
+            image, transforms = tg.apply_transform_gens(gens, image)                               # :103
+            image_r, transforms_r = tg.apply_transform_gens_overlap2(gens_r, copy.deepcopy(img), transforms)   # :105
+            if crop_tfm is not None:
+                transforms = crop_tfm + transforms                                                 # :108-109
+            k = f"{ci}/{seed}"
+            fx[k + "/in"], fx[k + "/image"], fx[k + "/image_r"] = img, np.ascontiguousarray(image), np.ascontiguousarray(image_r)
+            fx[k + "/crop"] = np.array([crop_tfm.x0, crop_tfm.y0, crop_tfm.w, crop_tfm.h] if crop_tfm is not None else [-1, -1, -1, -1])
+            fx[k + "/flip"] = np.array([any(isinstance(t, HFlip) for t in transforms.transforms), any(isinstance(t, HFlip) for t in transforms_r.transforms)])
+            for tag, tl, shape in (("", transforms, image.shape[:2]), ("_r", transforms_r, image_r.shape[:2])):
+                out = [au.transform_instance_annotations(copy.deepcopy(a), tl, shape) for a in annos if a.get("iscrowd", 0) == 0]      # :140-147,163-169
+                fx[k + "/boxes" + tag] = np.array([o["bbox"] for o in out], dtype=np.float64)
+                fx[k + "/poly_len" + tag] = np.array([len(q) for o in out for q in o["segmentation"]])
+                fx[k + "/poly_cnt" + tag] = np.array([len(o["segmentation"]) for o in out])
+                fx[k + "/poly" + tag] = np.concatenate([np.asarray(q, dtype=np.float64) for o in out for q in o["segmentation"]])
+            fx[k + "/rng_after"] = np.array(np.random.uniform())
+            n += 1
+    import json
+    fx["annotations_json"] = np.array(json.dumps(annos0))
+    fx["crops_json"] = np.array(json.dumps(crops))
+    np.savez_compressed(os.path.join(HERE, "dual_scale_annos.npz"), **fx)
+    print(f"dual_scale_annos.npz: {n} cases ({len(crops)} crop settings x 5 seeds)")
+
+
 if __name__ == "__main__":
     make_pil()
     make_mapper()
+    make_annos()

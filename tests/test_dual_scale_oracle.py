@@ -102,3 +102,67 @@ def test_normalize_pad_matches_torch_semantics():
         ref = (torch.from_numpy(i) - m) / s                                          # rcnn_only.py:31
         assert np.array_equal(out[n, :, :i.shape[1], :i.shape[2]], ref.numpy())
         assert not out[n, :, i.shape[1]:, :].any() and not out[n, :, :, i.shape[2]:].any()
+
+
+def _anno_cases(golden_dir):
+    import json
+    fx = dict(np.load(os.path.join(golden_dir, "dual_scale_annos.npz")))
+    annos = json.loads(str(fx["annotations_json"]))
+    crops = json.loads(str(fx["crops_json"]))
+    return fx, annos, crops
+
+
+def test_annotation_path_matches_reference_functions(golden_dir):
+    """The host side of the mapper's annotation path against outputs of the reference's OWN functions (tests/golden/dual_scale_annos.npz,
+    made by tests/golden/make_golden_dual_scale.py from transform_gen.py:220-264 RandomCrop, afigan_utils.py:379-406
+    gen_crop_transform_with_instance and :140-183 transform_instance_annotations, driven like dataset_mapper.py:96-109,140-176 under seeded
+    numpy.random): the crop window, the flip decisions, per instance the transformed box and polygons of BOTH transform lists, and the
+    position of numpy's random stream afterwards -- without a GPU (DualScaleMapper.plan is pure numpy)."""
+    import torch
+    from afigan_amd.dual_scale import DualScaleMapper, _apply_box_list, _apply_coords, _instances, _xyxy
+    fx, annos, crops = _anno_cases(golden_dir)
+    n_crop = 0
+    for ci, crop in enumerate(crops):
+        for seed in range(5):
+            k = f"{ci}/{seed}"
+            mapper = DualScaleMapper((24, 28, 32), 50, "choice", share_flip=True, device="cpu", mask_on=True, crop=tuple(crop) if crop else None)
+            np.random.seed(7000 + 10 * ci + seed)
+            pl = mapper.plan(48, 64, annos)
+            assert np.random.uniform() == float(fx[k + "/rng_after"]), k
+            want_crop = [int(v) for v in fx[k + "/crop"]]
+            assert (list(pl.crop) if pl.crop else [-1, -1, -1, -1]) == want_crop, k
+            n_crop += pl.crop is not None
+            assert [pl.flip, pl.flip_r] == [bool(v) for v in fx[k + "/flip"]], k
+            assert pl.size == fx[k + "/image"].shape[:2] and pl.size_r == fx[k + "/image_r"].shape[:2], k
+            keep = [a for a in annos if a.get("iscrowd", 0) == 0]
+            for tag, tf in (("", pl.tf), ("_r", pl.tf_r)):
+                np.testing.assert_allclose(_apply_box_list([_xyxy(a) for a in keep], tf), fx[k + "/boxes" + tag], rtol=0, atol=1e-9, err_msg=k + tag)
+                polys = np.concatenate([_apply_coords(np.asarray(q).reshape(-1, 2), tf).reshape(-1) for a in keep for q in a["segmentation"]])
+                np.testing.assert_allclose(polys, fx[k + "/poly" + tag], rtol=0, atol=1e-9, err_msg=k + tag)
+                assert [len(a["segmentation"]) for a in keep] == [int(v) for v in fx[k + "/poly_cnt" + tag]]
+            # Instances: clipped boxes (tight around the masks when the mapper crops), classes, polygon masks, empty instances dropped
+            inst = _instances(annos, pl.tf, pl.size, "cpu", mask_on=True, tight_boxes=crop is not None)
+            raw = torch.from_numpy(fx[k + "/boxes"]).float()
+            if crop is None:
+                b = raw.clone()
+                b[:, 0::2].clamp_(0, pl.size[1]); b[:, 1::2].clamp_(0, pl.size[0])
+                ne = ((b[:, 2] - b[:, 0]) > 0) & ((b[:, 3] - b[:, 1]) > 0)
+                assert torch.equal(inst.gt_boxes, b[ne]) and len(inst.gt_masks) == int(ne.sum())
+            else:                                            # dataset_mapper.py:156-157: gt_boxes = gt_masks.get_bounding_boxes()
+                assert len(inst.gt_masks) == len(inst.gt_boxes) == len(inst.gt_classes)
+                for bb, polys in zip(inst.gt_boxes, inst.gt_masks.polygons):
+                    allc = np.concatenate([q.reshape(-1, 2) for q in polys])
+                    # (detectron2's PolygonMasks.get_bounding_boxes starts its running maximum at ZERO: a polygon left of / above the crop keeps max = 0)
+                    np.testing.assert_allclose(bb.numpy(), np.concatenate([allc.min(0), np.maximum(allc.max(0), 0.0)]).astype(np.float32), rtol=0, atol=0)
+    assert n_crop == 15                                      # three crop settings x five seeds took the crop branch
+
+
+def test_polygon_masks_and_unsupported_mask_formats():
+    from afigan_amd import AfiError
+    from afigan_amd.dual_scale import DualScaleMapper, PolygonMasks
+    import torch
+    m = PolygonMasks([[[0, 0, 4, 0, 4, 3]], [], [[1, 1, 2, 5, 3, 1], [7, 7, 9, 7, 8, 9.5]]])
+    assert m.nonempty().tolist() == [True, False, True] and len(m[torch.tensor([True, False, True])]) == 2
+    assert m.get_bounding_boxes()[2].tolist() == [1.0, 1.0, 9.0, 9.5]
+    with pytest.raises(AfiError):
+        DualScaleMapper(mask_on=True, mask_format="bitmask", device="cpu")

@@ -137,3 +137,41 @@ def test_unsupported_inputs_fail_loudly():
         ops.resize_bilinear_u8(torch.zeros(4, 4, 4, dtype=torch.uint8, device="cuda"), 8, 8)        # RGBA resizes premultiplied in Pillow
     with pytest.raises(_lib.AfiError):
         ops.resize_bilinear_u8(torch.zeros(4, 4, 3, dtype=torch.float32, device="cuda"), 8, 8)
+
+
+def test_mapper_with_masks_and_random_crop_matches_reference_functions(golden_dir):
+    """DualScaleMapper(mask_on=True, crop=...) end to end on the device under the reference's own seeds (tests/golden/dual_scale_annos.npz):
+    the cropped + resized `image`, the UNCROPPED `image_x0.5` (dataset_mapper.py:98-105, as written), boxes, polygon masks, random stream."""
+    import json
+    from afigan_amd.dual_scale import DualScaleMapper
+    fx = _load(golden_dir, "dual_scale_annos.npz")
+    annos = json.loads(str(fx["annotations_json"]))
+    crops = json.loads(str(fx["crops_json"]))
+    for ci, crop in enumerate(crops):
+        for seed in range(5):
+            k = f"{ci}/{seed}"
+            mapper = DualScaleMapper((24, 28, 32), 50, "choice", share_flip=True, mask_on=True, crop=tuple(crop) if crop else None)
+            np.random.seed(7000 + 10 * ci + seed)
+            d = mapper({"image": fx[k + "/in"], "annotations": [dict(a) for a in annos]})
+            assert np.random.uniform() == float(fx[k + "/rng_after"]), k
+            assert np.array_equal(d["image"].cpu().numpy(), fx[k + "/image"].transpose(2, 0, 1)), k
+            assert np.array_equal(d["image_x0.5"].cpu().numpy(), fx[k + "/image_r"].transpose(2, 0, 1)), k
+            for key, tag in (("instances", ""), ("instances_x0.5", "_r")):
+                inst = d[key]
+                assert inst.image_size == fx[k + "/image" + tag].shape[:2]
+                lens = [int(v) for v in fx[k + "/poly_len" + tag]]
+                cnts = [int(v) for v in fx[k + "/poly_cnt" + tag]]
+                flat = fx[k + "/poly" + tag]
+                want, o, j = [], 0, 0
+                for c in cnts:                                # the fixture's polygons per (non-crowd) instance
+                    inst_p = []
+                    for _ in range(c):
+                        inst_p.append(flat[o:o + lens[j]]); o += lens[j]; j += 1
+                    want.append(inst_p)
+                got = inst.gt_masks.polygons
+                assert len(got) <= len(want)
+                gi = 0
+                for w in want:                                # every kept instance carries the reference's polygons, in order
+                    if gi < len(got) and len(got[gi]) == len(w) and all(np.allclose(a, b, rtol=0, atol=1e-9) for a, b in zip(got[gi], w)):
+                        gi += 1
+                assert gi == len(got), k
