@@ -64,6 +64,10 @@ struct AfiPixGemm {
     AfiView Z; int z_lo, z_hi;                 // multiply by (Z > 0 ? 1 : 0.2) for channels in [z_lo, z_hi)
     // split-K scratch (optional): [splitK][M][roundup4(Ncols)] partial slabs; the launcher picks splitK and fills it in
     float* partial; long long partial_floats; int splitK; int kper;   // kper: K stages per split (set by the launcher)
+    // BatchNorm batch statistics of the STORED output, accumulated by the Winograd output transform itself (a separate pass over the
+    // map otherwise): fp64 partial sums [stats_rows][2][Ncols] (sum, sum of squares per channel), one row per block of that launch; the
+    // launcher fills stats_rows.  Taken only by the plain-store epilogue on 256 / 512 / 1024-channel outputs; null = off.
+    double* stats; int stats_rows; int pad1_;
 };
 
 // Parameters of the weight-gradient GEMM:  dW[co'][tap][ci] += alpha * sum_pix dY[pix][co'] * X[pix+tap][ci]

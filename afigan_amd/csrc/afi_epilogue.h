@@ -69,7 +69,7 @@ __device__ __forceinline__ bool afi_epilogue_is_simple(const AfiPixGemm& p) {
     return p.o_up == 1 && p.beta == 0.f && !p.R1.p && !p.R2.p && !p.r2_post && p.oH >= p.H && p.oW >= p.W &&
            (!p.Z.p || (p.z_lo == 0 && p.z_hi >= p.Ncols));
 }
-__device__ __forceinline__ void afi_epilogue_store_simple(const AfiPixGemm& p, int img, int y, int x, int col, f32x4 accv) {
+__device__ __forceinline__ f32x4 afi_epilogue_store_simple(const AfiPixGemm& p, int img, int y, int x, int col, f32x4 accv) {
     const long long pix = (long long)img * p.O.sN + (long long)y * p.O.sH + (long long)x * p.O.sW + col;
     f32x4 v = p.alpha * accv;
     if (p.bias) v += *(const f32x4*)(p.bias + col);
@@ -84,5 +84,6 @@ __device__ __forceinline__ void afi_epilogue_store_simple(const AfiPixGemm& p, i
         for (int j = 0; j < 4; ++j) v[j] *= (z[j] > 0.f ? 1.f : AFI_LRELU_SLOPE);
     }
     *(f32x4*)(p.O.p + pix) = v;
+    return v;                                               // (the stored value: what fused statistics accumulate)
 }
 

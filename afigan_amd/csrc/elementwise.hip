@@ -244,26 +244,41 @@ __global__ __launch_bounds__(256) void afi_bn_stats_partial_kernel(const float* 
         *(f64x4*)(dst + C + c) = s1;
     }
 }
+// CH channels per 256-thread block, 256 / CH lanes per channel (each sums every (256 / CH)-th row, independent loads in flight; the lanes
+// meet through LDS in a fixed order: bit-reproducible).  CH = 32 for the <= 256 rows of the separate statistics pass, CH = 8 (32 lanes per
+// channel, 4x the blocks) for the up-to-1024 rows the Winograd output transforms leave.
+template <int CH>
 __global__ void afi_bn_stats_finalize64_kernel(const double* __restrict__ partial, int chunks, const float* __restrict__ x0, long long P, int C,
                                                float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ var_out,
                                                float* __restrict__ running_mean, float* __restrict__ running_var,
                                                long long* __restrict__ num_batches_tracked, float eps, float momentum) {
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;     // torch BatchNorm2d train mode
-    __shared__ double red[2][8][AFI_FIN_CH];
-    const int cl = threadIdx.x & (AFI_FIN_CH - 1), ln = threadIdx.x / AFI_FIN_CH;
-    const int c = blockIdx.x * AFI_FIN_CH + cl;
+    constexpr int LN = 256 / CH;
+    __shared__ double red[2][LN][CH];
+    const int cl = threadIdx.x & (CH - 1), ln = threadIdx.x / CH;
+    const int c = blockIdx.x * CH + cl;
     double a0 = 0.0, a1 = 0.0;
-    if (c < C)
-        for (int i = ln; i < chunks; i += 8) { a0 += partial[(long long)i * 2 * C + c]; a1 += partial[(long long)i * 2 * C + C + c]; }
+    if (c < C) {
+        int i = ln;
+        for (; i + 3 * LN < chunks; i += 4 * LN) {            // four rows in flight per lane
+            const double p0 = partial[(long long)i * 2 * C + c], q0 = partial[(long long)i * 2 * C + C + c];
+            const double p1 = partial[(long long)(i + LN) * 2 * C + c], q1 = partial[(long long)(i + LN) * 2 * C + C + c];
+            const double p2 = partial[(long long)(i + 2 * LN) * 2 * C + c], q2 = partial[(long long)(i + 2 * LN) * 2 * C + C + c];
+            const double p3 = partial[(long long)(i + 3 * LN) * 2 * C + c], q3 = partial[(long long)(i + 3 * LN) * 2 * C + C + c];
+            a0 += p0; a0 += p1; a0 += p2; a0 += p3;
+            a1 += q0; a1 += q1; a1 += q2; a1 += q3;
+        }
+        for (; i < chunks; i += LN) { a0 += partial[(long long)i * 2 * C + c]; a1 += partial[(long long)i * 2 * C + C + c]; }
+    }
     red[0][ln][cl] = a0; red[1][ln][cl] = a1;
     __syncthreads();
     if (ln != 0 || c >= C) return;
     double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { s0 += red[0][j][cl]; s1 += red[1][j][cl]; }        // fixed order: bit-reproducible
+    for (int j = 0; j < LN; ++j) { s0 += red[0][j][cl]; s1 += red[1][j][cl]; }        // fixed order: bit-reproducible
     const double inv_n = 1.0 / (double)P;
     const double d = s0 * inv_n;                    // mean - K
-    const double m = (double)x0[c] + d;
+    const double m = (x0 ? (double)x0[c] : 0.0) + d;     // (x0 == nullptr: unshifted sums, e.g. the partials of the Winograd output transforms)
     double var = s1 * inv_n - d * d;                // biased
     var = var > 0.0 ? var : 0.0;
     mean[c] = (float)m;
@@ -419,13 +434,24 @@ int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* 
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     if (fp64 && (((uintptr_t)scratch) & 7) == 0) {         // (fp64 = false: the fp32 one-pass form, AFI_OPT_BN_STATS_FP64 = 0)
         hipLaunchKernelGGL(afi_bn_stats_partial_kernel, dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, P, C, (long long)C, rpc, (double*)scratch);
-        hipLaunchKernelGGL(afi_bn_stats_finalize64_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, (const double*)scratch, chunks, x, P, C, mean,
+        hipLaunchKernelGGL(afi_bn_stats_finalize64_kernel<AFI_FIN_CH>, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, (const double*)scratch, chunks, x, P, C, mean,
                            invstd, var_out, running_mean, running_var, num_batches_tracked, eps, momentum);
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }
     hipLaunchKernelGGL((afi_colred_partial_kernel<0>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, P, C, (long long)C, rpc, scratch, (const float*)nullptr, (const float*)nullptr, 1.f);
     hipLaunchKernelGGL(afi_bn_stats_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, x, P, C, mean, invstd,
+                       var_out, running_mean, running_var, num_batches_tracked, eps, momentum);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// statistics from fp64 partial rows [rows][2][C] (sum, sum of squares; unshifted) that another kernel accumulated -- the Winograd output
+// transforms in their STATS form -- summed in row order; same outputs and running-buffer updates as afi_launch_bn_stats
+int afi_launch_bn_stats_from_partials(const double* partial, int rows, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
+                                      float* running_var, hipStream_t st, long long* num_batches_tracked, float eps, float momentum) {
+    if (eps < 0.f) eps = AFI_BN_EPS;
+    if (momentum < 0.f) momentum = AFI_BN_MOMENTUM;
+    if (!partial || rows <= 0 || P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_bn_stats_finalize64_kernel<8>, dim3(afi_cdiv(C, 8)), dim3(256), 0, st, partial, rows, (const float*)nullptr, P, C, mean, invstd,
                        var_out, running_mean, running_var, num_batches_tracked, eps, momentum);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }

@@ -28,6 +28,10 @@ int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout,
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
                         float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked = nullptr, float eps = -1.f,
                         float momentum = -1.f, bool fp64 = true);
+int afi_launch_bn_stats_from_partials(const double* partial, int rows, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
+                                      float* running_var, hipStream_t st, long long* num_batches_tracked = nullptr, float eps = -1.f, float momentum = -1.f);
+int afi_wino_stats_rows(long long T, int C);               // winograd.hip: rows of fp64 partials a STATS output transform writes (0: not fused)
+#define AFI_STATS_MAX_ROWS 1024
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                               long long P, int C, hipStream_t st, float slope = AFI_LRELU_SLOPE);
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
@@ -310,11 +314,22 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
 }
 
 // forward (mode 0: out = conv(in, w) + bias) or data gradient (mode 1: out = conv^T(in, w) * lrelu'(z)) by descriptor
+// stats (forward only): fp64 partial rows for the BatchNorm statistics of the output, accumulated by the output transform (afi_common.h);
+// *stats_rows receives the number of rows written, 0 when this call did not fuse them (the caller then runs the separate pass)
 static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
-                     float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false) {
+                     float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false,
+                     double* stats = nullptr, int* stats_rows = nullptr) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
     if (mode && z.p) { g.Z = z; g.z_lo = 0; g.z_hi = Nc; }
+    if (stats_rows) *stats_rows = 0;
+    if (stats && stats_rows && !mode) {
+        const int dtype = cx ? cx->dtype : afi_default_dtype();
+        const bool f4 = fwd_f4 && wino_f4(cx) && dtype != AFI_DTYPE_BF16 && (long long)N * H * W >= 8192;     // (the tiling wino_run will pick)
+        const long long T = f4 ? (long long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+        const int rows = afi_wino_stats_rows(T, Nc);
+        if (rows > 0) { g.stats = stats; *stats_rows = rows; }
+    }
     return wino_run(cx, g, mode, ws, ws_floats, part, part_floats, st, fwd_f4);
 }
 
@@ -1147,7 +1162,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
 // forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][y2 P*F3][d9 P*16][mean,invstd x3][red]
 struct DiscWs {
     long long P;
-    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_part, n_part, o_wino, n_wino, total;
+    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_part, n_part, o_wino, n_wino, total;
 };
 static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     DiscWs w;
@@ -1165,6 +1180,7 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
         w.o_invstd[n] = o; o += align4(F[n + 1]);
     }
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));
+    w.o_stats = o; o += 4LL * AFI_STATS_MAX_ROWS * fmax;  // fp64 partial rows [rows][2][C] of the statistics fused into the output transforms
     w.n_part = part_floats({w.P * F[1], w.P * F[2], w.P * F[3]});
     w.o_part = o; o += w.n_part;
     w.n_wino = disc_wino_floats(F, N, H, W);              // transient: Winograd U / V / M buffers, shared by the three convs
@@ -1230,13 +1246,20 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
         const int ci = prm->F[n], co = prm->F[n + 1];
         float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];
         float* mean = ws + l.o_mean[n]; float* invstd = ws + l.o_invstd[n];
+        int stats_rows = 0;
+        double* stats = (double*)(ws + l.o_stats);          // (8-byte aligned: every offset of the layout is a multiple of 4 floats and ws comes from an allocator)
+        const bool fuse_stats = training && afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0 && (((uintptr_t)stats) & 7) == 0;
         if (l.n_wino > 0 && use_wino(cx, P)) {
             AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
-                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx)));
+                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx), fuse_stats ? stats : nullptr, &stats_rows));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
-        if (training) {
+        if (training && stats_rows > 0) {                   // the output transform accumulated the sums while it stored c: only the finalizer is left
+            AFI_TRY(afi_launch_bn_stats_from_partials(stats, stats_rows, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], st,
+                                                      prm->num_batches_tracked[n]));
+            AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
+        } else if (training) {
             AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st,
                                         prm->num_batches_tracked[n], -1.f, -1.f, afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0));      // the counter ticks inside the statistics finalizer
             AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));

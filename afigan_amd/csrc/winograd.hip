@@ -181,12 +181,46 @@ int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, 
 // Same transform, but each output float4 goes through afi_epilogue_store with the conv's own descriptor: bias, alpha / beta,
 // LeakyReLU, the two residual adds with channel ranges, the bilinear x2 skip, the pixel-shuffle store of the conv-transpose
 // (columns = 4 phases x Cout) and the LeakyReLU' mask -- so any 3x3 / stride-1 conv of the interpolator can take this path.
-template <bool SIMPLE>
+// ---------------------------------------------------------------- BatchNorm statistics inside the output transforms
+// STATS variants of the two output-transform kernels below: every thread keeps the sum and the sum of squares of the values it STORES, per
+// channel of its float4, in fp64 (torch's CPU accumulation type for float; no shift needed at 53 bits), the block reduces them over the
+// threads that share a channel quad (blockDim % (C / 4) == 0: a thread's quad never changes along its grid-stride walk) and writes ONE
+// row of partials [2][C]; afi_launch_bn_stats_from_partials sums the rows in a fixed order.  Replaces a full pass over the map
+// (afi_bn_stats_partial_kernel: 1.85 ms of a stage-1 step).
+#define AFI_STATS_MAX_ROWS 1024
+typedef double f64x4w __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void afi_stats_acc(f64x4w& s0, f64x4w& s1, f32x4 v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; s0[j] += d; s1[j] += d * d; }
+}
+__device__ __forceinline__ void afi_stats_block_write(const AfiPixGemm& p, f64x4w s0, f64x4w s1) {
+    __shared__ f64x4w red[2][256];
+    const int C4 = p.Ncols >> 2;
+    red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    __syncthreads();
+    if ((int)threadIdx.x < C4) {
+        for (int k = threadIdx.x + C4; k < 256; k += C4) { s0 += red[0][k]; s1 += red[1][k]; }      // fixed order: bit-reproducible
+        double* row = p.stats + (long long)blockIdx.x * 2 * p.Ncols;
+        *(f64x4w*)(row + 4 * threadIdx.x) = s0;
+        *(f64x4w*)(row + p.Ncols + 4 * threadIdx.x) = s1;
+    }
+}
+// rows of partials (= blocks) the STATS launch of an output transform over T tiles x C channels uses; 0 = this shape is not fused
+int afi_wino_stats_rows(long long T, int C) {
+    if (C != 256 && C != 512 && C != 1024) return 0;
+    long long g = (T * (C >> 2) + 255) / 256;
+    if (g > AFI_STATS_MAX_ROWS) g = AFI_STATS_MAX_ROWS;
+    return (int)(g < 1 ? 1 : g);
+}
+static bool afi_stats_fusable(const AfiPixGemm& p) { return p.stats && (p.Ncols == 256 || p.Ncols == 512 || p.Ncols == 1024); }
+
+template <bool SIMPLE, bool STATS = false>
 __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* __restrict__ Min, long long Tpad, int Th, int Tw, long long T,
                                                                   const AfiPixGemm p) {
     const int C = p.Ncols, C4 = C >> 2;
     const long long total = T * C4;
     const long long plane = Tpad * C;
+    f64x4w st0 = {0, 0, 0, 0}, st1 = {0, 0, 0, 0};
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -210,17 +244,24 @@ __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* _
                 const int xx = 2 * tx + j;
                 if (xx >= p.W) continue;
                 const f32x4 v = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
-                if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx, c, v); else afi_epilogue_store(p, n, yy, xx, c, v);
+                if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xx, c, v); if (STATS) afi_stats_acc(st0, st1, o); }
+                else afi_epilogue_store(p, n, yy, xx, c, v);
             }
         }
     }
+    if (STATS) afi_stats_block_write(p, st0, st1);
 }
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st) {
     if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.Ncols <= 0 || (p.Ncols & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (p.H + 1) / 2, Tw = (p.W + 1) / 2;
     const long long T = (long long)p.N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    if (afi_epilogue_is_simple_host(p)) hipLaunchKernelGGL((afi_wino_output_epi_kernel<true>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
+    if (p.stats) {                                          // (the caller asked for fused statistics: afi_wino_stats_rows said this shape takes them)
+        if (!afi_epilogue_is_simple_host(p) || !afi_stats_fusable(p)) return AFI_ERR_BAD_ARG;
+        AfiPixGemm q = p;
+        q.stats_rows = afi_wino_stats_rows(T, p.Ncols);
+        hipLaunchKernelGGL((afi_wino_output_epi_kernel<true, true>), dim3(q.stats_rows), dim3(256), 0, st, M, Tpad, Th, Tw, T, q);
+    } else if (afi_epilogue_is_simple_host(p)) hipLaunchKernelGGL((afi_wino_output_epi_kernel<true>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     else hipLaunchKernelGGL((afi_wino_output_epi_kernel<false>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
@@ -440,12 +481,13 @@ int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hi
 }
 
 // output: M [36][Tpad][C] -> 4x4 pixels per tile through the descriptor's epilogue
-template <bool SIMPLE>
+template <bool SIMPLE, bool STATS = false>
 __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* __restrict__ Min, long long Tpad, int Th, int Tw, long long T,
                                                                    const AfiPixGemm p) {
     const int C = p.Ncols, C4 = C >> 2;
     const long long total = T * C4;
     const long long plane = Tpad * C;
+    f64x4w st0 = {0, 0, 0, 0}, st1 = {0, 0, 0, 0};
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -471,19 +513,29 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
             const f32x4 p12 = s[i][1] + s[i][2], d12 = s[i][1] - s[i][2], p34 = s[i][3] + s[i][4], d34 = s[i][3] - s[i][4];
             const f32x4 y0 = s[i][0] + p12 + p34, y1 = d12 + 2.f * d34, y2 = p12 + 4.f * p34, y3 = d12 + 8.f * d34 + s[i][5];
             const int xx = 4 * tx;
-            if (xx < p.W) { if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx, c, y0); else afi_epilogue_store(p, n, yy, xx, c, y0); }
-            if (xx + 1 < p.W) { if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx + 1, c, y1); else afi_epilogue_store(p, n, yy, xx + 1, c, y1); }
-            if (xx + 2 < p.W) { if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx + 2, c, y2); else afi_epilogue_store(p, n, yy, xx + 2, c, y2); }
-            if (xx + 3 < p.W) { if (SIMPLE) afi_epilogue_store_simple(p, n, yy, xx + 3, c, y3); else afi_epilogue_store(p, n, yy, xx + 3, c, y3); }
+            auto put = [&](int xo, f32x4 v) {
+                if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xo, c, v); if (STATS) afi_stats_acc(st0, st1, o); }
+                else afi_epilogue_store(p, n, yy, xo, c, v);
+            };
+            if (xx < p.W) put(xx, y0);
+            if (xx + 1 < p.W) put(xx + 1, y1);
+            if (xx + 2 < p.W) put(xx + 2, y2);
+            if (xx + 3 < p.W) put(xx + 3, y3);
         }
     }
+    if (STATS) afi_stats_block_write(p, st0, st1);
 }
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st) {
     if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.Ncols <= 0 || (p.Ncols & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (p.H + 3) / 4, Tw = (p.W + 3) / 4;
     const long long T = (long long)p.N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    if (afi_epilogue_is_simple_host(p)) hipLaunchKernelGGL((afi_wino4_output_epi_kernel<true>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
+    if (p.stats) {
+        if (!afi_epilogue_is_simple_host(p) || !afi_stats_fusable(p)) return AFI_ERR_BAD_ARG;
+        AfiPixGemm q = p;
+        q.stats_rows = afi_wino_stats_rows(T, p.Ncols);
+        hipLaunchKernelGGL((afi_wino4_output_epi_kernel<true, true>), dim3(q.stats_rows), dim3(256), 0, st, M, Tpad, Th, Tw, T, q);
+    } else if (afi_epilogue_is_simple_host(p)) hipLaunchKernelGGL((afi_wino4_output_epi_kernel<true>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     else hipLaunchKernelGGL((afi_wino4_output_epi_kernel<false>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
