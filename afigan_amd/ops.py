@@ -178,6 +178,18 @@ def gemm_nt(A, B, dtype, out=None):
     return out
 
 
+def gemm_tn(Q, V, dtype, out=None):
+    """afi_gemm_tn for tests and micro-benchmarks: dU[g] += Q[g]^T @ V[g] over the planes of dense [planes, rows, M] / [planes, rows, N]
+    tensors in the arithmetic `dtype`; `out` ([planes, M, N], zero-filled when omitted) is accumulated into, as the weight gradient is."""
+    _check_cuda(Q, V)
+    planes, rows, M = Q.shape
+    N = V.shape[2]
+    if out is None:
+        out = torch.zeros((planes, M, N), device=Q.device, dtype=torch.float32)
+    _lib.check(_lib.load().afi_gemm_tn(_p(Q), _p(V), _p(out), planes, rows, M, N, _lib.DTYPES[dtype], stream_ptr()), "afi_gemm_tn")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ convs
 OP_SCRATCH_FLOATS = 100 * 1024 * 1024          # 400 MB: 4 slabs of the largest map that is split (1536 tiles of 128x128)
 
