@@ -490,12 +490,12 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_dma_kernel(const AfiG
 // ------------------------------------------------------------------------------------------------
 struct AfiGemmTNPre { const unsigned char* Q; const unsigned char* V; float* dU; long long rows_per_plane; int planes, M, N; };
 
-template <int SPLIT>
-__global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_pre_kernel(const AfiGemmTNPre p, int ntile_m, int ntile_n, int kper) {
-    constexpr int BM = 128, BN = 256, MI = 2, NI = 4;
+template <int SPLIT, int BN, int NBUF, int MINB>
+__global__ __launch_bounds__(256, MINB) void afi_gemm_tn_bf16_pre_kernel(const AfiGemmTNPre p, int ntile_m, int ntile_n, int kper) {
+    constexpr int BM = 128, MI = 2, NI = BN / 64, NB = BN / 128;
     constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);
     constexpr int HALF = 4096, IMG = 8192;
-    constexpr int STAGE = 3 * NPART * HALF;                 // A, B0, B1 halves of every part
+    constexpr int STAGE = (1 + NB) * NPART * HALF;          // A, B0 (, B1) halves of every part
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_pre_kernel(const AfiG
     typedef __attribute__((address_space(3))) void* lptr;
     // the 3 * NPART halves of a stage are 4 KB each = four 1 KB DMA instructions; wave w issues instruction w of every half
     const unsigned char* a_src = p.Q + (((long long)plane * (p.M / 128) + tile_m) * nchunk + c0) * (long long)(NPART * IMG) + wave * 1024 + lane * 16;
-    const unsigned char* b_src = p.V + (((long long)plane * (p.N / 128) + 2 * tile_n) * nchunk + c0) * (long long)(NPART * IMG) + wave * 1024 + lane * 16;
+    const unsigned char* b_src = p.V + (((long long)plane * (p.N / 128) + NB * tile_n) * nchunk + c0) * (long long)(NPART * IMG) + wave * 1024 + lane * 16;
     const long long b_tile = nchunk * (long long)(NPART * IMG);
     auto issue = [&](int s, int buf) {
         unsigned char* dst = smem_b + buf * STAGE + wave * 1024;
@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_pre_kernel(const AfiG
         for (int pt = 0; pt < NPART; ++pt) {
             __builtin_amdgcn_global_load_lds((gptr)(a_src + off + pt * IMG), (lptr)(dst + pt * HALF), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr)(b_src + off + pt * IMG), (lptr)(dst + (NPART + pt) * HALF), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr)(b_src + b_tile + off + pt * IMG), (lptr)(dst + (2 * NPART + pt) * HALF), 16, 0, 0);
+            if (NB == 2) __builtin_amdgcn_global_load_lds((gptr)(b_src + b_tile + off + pt * IMG), (lptr)(dst + (2 * NPART + pt) * HALF), 16, 0, 0);
         }
     };
     int fa_off[MI][2], fb_off[NI][2];
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_pre_kernel(const AfiG
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fa_off[mi][rd] = 256 * r + 16 * ((4 * (wm * MI + mi) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = (1 + wn) * NPART * HALF + 256 * r + 16 * ((4 * ni + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = (NB == 2 ? (1 + wn) : 1) * NPART * HALF + 256 * r + 16 * ((4 * (NB == 2 ? ni : wn * NI + ni) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
         }
     }
     f32x16 acc[MI][NI];
@@ -554,8 +554,8 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_pre_kernel(const AfiG
     issue(0, 0);
     for (int s = 0; s < nS; ++s) {
         __syncthreads();                                     // stage s has landed; every wave is done with the other buffer
-        if (s + 1 < nS) issue(s + 1, (s + 1) & 1);
-        const unsigned char* sm = smem_b + (s & 1) * STAGE;
+        if (NBUF == 2 && s + 1 < nS) issue(s + 1, (s + 1) & 1);
+        const unsigned char* sm = smem_b + (NBUF == 2 ? (s & 1) * STAGE : 0);
         bf16x8 ah[MI], am[MI], al[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -585,6 +585,10 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_pre_kernel(const AfiG
             }
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
+        }
+        if (NBUF == 1) {
+            __syncthreads();
+            if (s + 1 < nS) issue(s + 1, 0);
         }
     }
     const bool use_atomic = gridDim.y > 1;

@@ -1002,19 +1002,22 @@ int afi_launch_split_bf16_kimg(const float* X, void* out, int planes, long long 
 // TN GEMM on pre-split image operands (afi_gemm_bf16.h); M % 128 == 0, N % 256 == 0, rows % 32 == 0
 int afi_launch_gemm_tn_bf16_pre(const void* Qimg, const void* Vimg, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st) {
     if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0 || (split != 1 && split != 3 && split != 6)) return AFI_ERR_BAD_ARG;
-    if ((rows_per_plane % 32) || (M % 128) || (N % 256)) return AFI_ERR_UNSUPPORTED;
-    const int ntm = M / 128, ntn = N / 256;
+    const int var = g_afi_tn_variant;                      // TEMP: 10 = 128x256 DB; 11 = 128x128 DB (3/CU); 12 = 128x128 single buffer (4/CU)
+    const int bn = var == 10 ? 256 : 128;
+    if ((rows_per_plane % 32) || (M % 128) || (N % bn)) return AFI_ERR_UNSUPPORTED;
+    const int ntm = M / 128, ntn = N / bn;
     const long long tiles = (long long)ntm * ntn * planes;
+    const int slots = var == 10 ? 512 : (var == 11 ? 768 : 1024);
     int splitK = 1;
     {
         const int maxsplit = (int)(rows_per_plane / (8 * 32)) > 0 ? (int)(rows_per_plane / (8 * 32)) : 1;
         double best = -1.0;
         for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {
             const long long blocks = tiles * s2;
-            if (blocks < 2 * 512 && s2 < maxsplit) continue;
-            if (blocks > 6 * 512 && best >= 0.0) break;
-            const long long rounds = (blocks + 511) / 512;
-            const double fill = (double)blocks / (double)(rounds * 512);
+            if (blocks < 2 * slots && s2 < maxsplit) continue;
+            if (blocks > 6 * slots && best >= 0.0) break;
+            const long long rounds = (blocks + slots - 1) / slots;
+            const double fill = (double)blocks / (double)(rounds * slots);
             if (fill > best + 1e-3) { best = fill; splitK = s2; }
         }
     }
@@ -1025,14 +1028,14 @@ int afi_launch_gemm_tn_bf16_pre(const void* Qimg, const void* Vimg, float* dU, i
     ProfScope prof(st, 18, 2.0 * (double)rows_per_plane * planes * M * N);
     prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
     const int npart = split == 6 ? 3 : (split == 3 ? 2 : 1);
-    const size_t lds = 2u * 3u * npart * 4096u;
+    const size_t lds = (var == 12 ? 1u : 2u) * (var == 10 ? 3u : 2u) * npart * 4096u;
     const dim3 grid((unsigned)tiles, splitK), blk(256);
-    if (lds >= 64 * 1024) {
-        if (!afi_opt_in_big_lds((const void*)afi_gemm_tn_bf16_pre_kernel<6>)) return AFI_ERR_LAUNCH;
-    }
-    if (split == 6) hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<6>), grid, blk, lds, st, g, ntm, ntn, kper);
-    else if (split == 3) hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<3>), grid, blk, lds, st, g, ntm, ntn, kper);
-    else hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<1>), grid, blk, lds, st, g, ntm, ntn, kper);
+    if (split != 6) return AFI_ERR_UNSUPPORTED;
+    if (var == 10) {
+        if (!afi_opt_in_big_lds((const void*)afi_gemm_tn_bf16_pre_kernel<6, 256, 2, 2>)) return AFI_ERR_LAUNCH;
+        hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<6, 256, 2, 2>), grid, blk, lds, st, g, ntm, ntn, kper);
+    } else if (var == 11) hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<6, 128, 2, 3>), grid, blk, lds, st, g, ntm, ntn, kper);
+    else hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<6, 128, 1, 4>), grid, blk, lds, st, g, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 extern "C" int afi_debug_tn_split(const float* X, void* out, int planes, long long rows, int C, int split, void* stream) {   // TEMP

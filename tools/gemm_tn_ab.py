@@ -37,7 +37,7 @@ def main():
     lib.afi_debug_gemm_tn_pre.argtypes, lib.afi_debug_gemm_tn_pre.restype = [vp, vp, vp, ci, ll, ci, ci, ci, vp], ci
     dev = torch.device("cuda:0")
     g = torch.Generator(device=dev).manual_seed(1)
-    for dtype in ("bf16x6", "bf16x3"):
+    for dtype in ("bf16x6",):
         Q = torch.randn(2, 512, 256, device=dev, generator=g)
         V = torch.randn(2, 512, 256, device=dev, generator=g)
         ref = torch.einsum("gkm,gkn->gmn", Q.double(), V.double())
@@ -46,6 +46,7 @@ def main():
             out = ops.gemm_tn(Q, V, dtype)
             print(f"{dtype} variant {v}: rel err vs fp64 {((out.double() - ref).norm() / ref.norm()).item():.3e}", flush=True)
         out = torch.zeros(2, 256, 256, device=dev)
+        setv(10)
         gemm_pre(lib, pre_images(lib, Q, dtype), pre_images(lib, V, dtype), out, 2, 512, 256, 256, dtype)
         print(f"{dtype} pre-split: rel err vs fp64 {((out.double() - ref).norm() / ref.norm()).item():.3e}", flush=True)
     import os
@@ -72,35 +73,27 @@ def main():
         V = torch.randn(planes, T, N, device=dev, generator=g)
         out = torch.zeros(planes, M, N, device=dev)
         line = f"planes {planes:2d} T {T:5d} M {M:4d} N {N:4d}:"
-        for dtype in ("bf16x6", "bf16x3"):
-            for v in (0, 3):
-                setv(v)
-                for _ in range(3):
-                    ops.gemm_tn(Q, V, dtype, out=out)
-                torch.cuda.synchronize()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                iters = 20
-                e0.record()
-                for _ in range(iters):
-                    ops.gemm_tn(Q, V, dtype, out=out)
-                e1.record()
-                torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / iters
-                tf = 2.0 * planes * T * M * N / us / 1e6
-                line += f"  {dtype} v{v} {us:7.1f} us {tf:6.1f} TF"
-            Qi, Vi = pre_images(lib, Q, dtype), pre_images(lib, V, dtype)
+        dtype = "bf16x6"
+        Qi, Vi = pre_images(lib, Q, dtype), pre_images(lib, V, dtype)
+        ref = None
+        for v in (3, 10, 11, 12):
+            setv(v)
+            run = (lambda: ops.gemm_tn(Q, V, dtype, out=out)) if v < 10 else (lambda: gemm_pre(lib, Qi, Vi, out, planes, T, M, N, dtype))
+            out.zero_(); run()
+            if ref is None:
+                ref = out.clone()
+            err = ((out - ref).norm() / ref.norm()).item()
             for _ in range(3):
-                gemm_pre(lib, Qi, Vi, out, planes, T, M, N, dtype)
+                run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(20):
-                gemm_pre(lib, Qi, Vi, out, planes, T, M, N, dtype)
+                run()
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / 20
-            line += f"  {dtype} PRE {us:7.1f} us {2.0 * planes * T * M * N / us / 1e6:6.1f} TF"
-            del Qi, Vi
+            line += f"  v{v} {us:7.1f} us {2.0 * planes * T * M * N / us / 1e6:6.1f} TF (d {err:.1e})"
         print(line, flush=True)
 
 
