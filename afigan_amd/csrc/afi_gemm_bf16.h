@@ -9,7 +9,8 @@
 //                         (hh, hm, mh, mm, hl, lh), smallest first: what is dropped (ml, lm, ll) is below fp32's own rounding of a
 //                         product, so the result is fp32-grade (measured 1e-6, like the fp32 MFMA) at 6/16 of its matrix-core work.
 // NT (forward / data gradient): afi_gemm_nt_bf16_dma_kernel further down (LDS-DMA staging, v_mfma_f32_16x16x32_bf16).
-// TN (weight gradient): afi_gemm_tn_bf16_kernel (register staging, transposed LDS reads, v_mfma_f32_32x32x16_bf16).
+// TN (weight gradient): afi_gemm_tn_bf16_kernel (register staging, transposed LDS reads, v_mfma_f32_32x32x16_bf16; three blocks per CU in the
+// six-product form).
 #pragma once
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -30,51 +31,6 @@ __device__ __forceinline__ f32x4 afi_bf16_residual(f32x4 v) {          // v - fl
     return v - __builtin_convertvector(h, f32x4);
 }
 
-// Eight fp32 -> their bf16 parts, pair-wise: one v_cvt_pk_bf16_f32 gives both elements' part, its two halves ARE the fp32 values of the part
-// (<< 16, & 0xffff0000), one packed subtract gives both residuals: 9 VALU instructions per pair for the three parts (the per-element
-// form above costs 15).  Bit-identical to afi_pack8_bf16 / afi_bf16_residual (same RNE conversions, exact subtractions).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-template <int NPART>
-__device__ __forceinline__ void afi_split8_bf16(const f32x2 (&x)[4], bf16x8& h, bf16x8& m, bf16x8& l) {
-    u32x4 ph, pm, pl;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const unsigned int a = __builtin_bit_cast(unsigned int, __builtin_convertvector(x[i], bf16x2));
-        ph[i] = a;
-        if (NPART >= 2) {
-            const f32x2 r1 = x[i] - f32x2{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u)};
-            const unsigned int b = __builtin_bit_cast(unsigned int, __builtin_convertvector(r1, bf16x2));
-            pm[i] = b;
-            if (NPART == 3) {
-                const f32x2 r2 = r1 - f32x2{__builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xffff0000u)};
-                pl[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
-            }
-        }
-    }
-    h = __builtin_bit_cast(bf16x8, ph);
-    if (NPART >= 2) m = __builtin_bit_cast(bf16x8, pm);
-    if (NPART == 3) l = __builtin_bit_cast(bf16x8, pl);
-}
-template <int NPART>
-__device__ __forceinline__ void afi_split4_bf16(f32x4 v, u32x2& h, u32x2& m, u32x2& l) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const f32x2 x{v[2 * i], v[2 * i + 1]};
-        const unsigned int a = __builtin_bit_cast(unsigned int, __builtin_convertvector(x, bf16x2));
-        h[i] = a;
-        if (NPART >= 2) {
-            const f32x2 r1 = x - f32x2{__builtin_bit_cast(float, a << 16), __builtin_bit_cast(float, a & 0xffff0000u)};
-            const unsigned int b = __builtin_bit_cast(unsigned int, __builtin_convertvector(r1, bf16x2));
-            m[i] = b;
-            if (NPART == 3) {
-                const f32x2 r2 = r1 - f32x2{__builtin_bit_cast(float, b << 16), __builtin_bit_cast(float, b & 0xffff0000u)};
-                l[i] = __builtin_bit_cast(unsigned int, __builtin_convertvector(r2, bf16x2));
-            }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM  dU[g][m][n] += sum_k Q[g][k][m] * V[g][k][n]: both operands are k-slow in memory, and the bf16 MFMA wants eight
 // consecutive k per lane.  The tiles go to LDS as they come -- [32 k][128 columns] bf16, 256-byte rows, the 16-byte chunk ch of row r at
@@ -82,6 +38,12 @@ __device__ __forceinline__ void afi_split4_bf16(f32x4 v, u32x2& h, u32x2& m, u32
 // 4-row x 16-column block, column i of the four rows delivered to lane i.  Two such reads (k 0..3, k 4..7 of the lane's k-group) make
 // one operand.  Stores (8 bytes per lane, 32 lanes = one 256-byte row) and the transposed reads are conflict-free on this image.
 // Split-K over blockIdx.y with fp32 atomics into dU, exactly like afi_gemm_tn_kernel.
+// Round 3, measured against this kernel in one process and rejected (profiles/r03/gemm_tn_variants_ab.log, counters beside it): (1) both
+// operands copied verbatim (fp32) by LDS-DMA, eight ds_read_b32 per fragment, split in registers, 128 x 256 tile: the split is then done
+// by both waves that share a fragment, 5.8 VALU instructions per MFMA, -6 %; (2) this kernel on v_mfma_f32_16x16x32_bf16: +-3 %;
+// (3) operands pre-split into these LDS images by their producers, pure LDS-DMA + transposed reads, no VALU at all, at 2 / 3 / 4 blocks
+// per CU: -1 % .. +6 % on the large shapes, -12 .. -27 % on the small ones, before the producers' 1.5x write bytes are counted.  Every
+// form holds 0.2 .. 0.27 of MFMA duty per resident wave; none reaches the NT kernel's four waves at 0.2 each.
 // ------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -137,17 +99,15 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
         unsigned char* base = smem_b + buf * BUF;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            u32x2 ah, am, al, bh, bm, bl;
-            afi_split4_bf16<NPART>(a_reg[i], ah, am, al);
-            afi_split4_bf16<NPART>(b_reg[i], bh, bm, bl);
-            *(u32x2*)(base + st_off[i]) = ah;
-            *(u32x2*)(base + NPART * TILE + st_off[i]) = bh;
+            *(u32x2*)(base + st_off[i]) = afi_pack_bf16(a_reg[i]);
+            *(u32x2*)(base + NPART * TILE + st_off[i]) = afi_pack_bf16(b_reg[i]);
             if (SPLIT >= 3) {
-                *(u32x2*)(base + TILE + st_off[i]) = am;
-                *(u32x2*)(base + NPART * TILE + TILE + st_off[i]) = bm;
+                const f32x4 ra = afi_bf16_residual(a_reg[i]), rb = afi_bf16_residual(b_reg[i]);
+                *(u32x2*)(base + TILE + st_off[i]) = afi_pack_bf16(ra);
+                *(u32x2*)(base + NPART * TILE + TILE + st_off[i]) = afi_pack_bf16(rb);
                 if (SPLIT == 6) {
-                    *(u32x2*)(base + 2 * TILE + st_off[i]) = al;
-                    *(u32x2*)(base + NPART * TILE + 2 * TILE + st_off[i]) = bl;
+                    *(u32x2*)(base + 2 * TILE + st_off[i]) = afi_pack_bf16(afi_bf16_residual(ra));
+                    *(u32x2*)(base + NPART * TILE + 2 * TILE + st_off[i]) = afi_pack_bf16(afi_bf16_residual(rb));
                 }
             }
         }
@@ -230,404 +190,6 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
             }
 }
 
-template <int SPLIT>
-__global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_m16_kernel(const AfiGemmTN p, int ntile_m, int ntile_n, int kper) {
-    constexpr int BM = 128, BN = 128, BK = 32, WN = 2;
-    constexpr bool DB = false;
-    constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);
-    constexpr int TILE = BK * BM * 2;                        // 8 KB: [32 k][128 columns] bf16
-    constexpr int BUF = 2 * NPART * TILE;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 31, lh = lane >> 5;
-    int t;
-    {   // contiguous run of logical ids per XCD; planes slowest, N tiles fastest (as afi_gemm_tn_kernel)
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    const int tile_n = t % ntile_n; t /= ntile_n;
-    const int tile_m = t % ntile_m; const int plane = t / ntile_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const long long k_begin = (long long)blockIdx.y * kper;
-    const long long k_end = (k_begin + kper < p.rows_per_plane) ? k_begin + kper : p.rows_per_plane;
-    if (k_begin >= k_end) return;                            // (whole block: EXEC stays full for the transposed reads below)
-    const int nK = (int)((k_end - k_begin) / BK);
-    const int cq = tid & 31, kr = tid >> 5;                  // float4 column, first k row (8 rows per pass, 4 passes)
-    const float* a_base = p.Q + ((long long)plane * p.rows_per_plane + k_begin + kr) * p.M + m0 + 4 * cq;
-    const float* b_base = p.V + ((long long)plane * p.rows_per_plane + k_begin + kr) * p.N + n0 + 4 * cq;
-    const long long a_pass = 8LL * p.M, b_pass = 8LL * p.N, a_stage = (long long)BK * p.M, b_stage = (long long)BK * p.N;
-
-    f32x4 a_reg[4], b_reg[4];
-    auto issue = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a_reg[i] = *(const f32x4*)(a_base + kc * a_stage + i * a_pass);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) b_reg[i] = *(const f32x4*)(b_base + kc * b_stage + i * b_pass);
-    };
-    int st_off[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = kr + 8 * i;
-        st_off[i] = 256 * r + 16 * ((cq >> 1) ^ (((r & 3) << 2) | ((r >> 2) & 3))) + 8 * (cq & 1);
-    }
-    auto stage_store = [&](int buf) {
-        unsigned char* base = smem_b + buf * BUF;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x2 ah, am, al, bh, bm, bl;
-            afi_split4_bf16<NPART>(a_reg[i], ah, am, al);
-            afi_split4_bf16<NPART>(b_reg[i], bh, bm, bl);
-            *(u32x2*)(base + st_off[i]) = ah;
-            *(u32x2*)(base + NPART * TILE + st_off[i]) = bh;
-            if (SPLIT >= 3) {
-                *(u32x2*)(base + TILE + st_off[i]) = am;
-                *(u32x2*)(base + NPART * TILE + TILE + st_off[i]) = bm;
-                if (SPLIT == 6) {
-                    *(u32x2*)(base + 2 * TILE + st_off[i]) = al;
-                    *(u32x2*)(base + NPART * TILE + 2 * TILE + st_off[i]) = bl;
-                }
-            }
-        }
-    };
-    // transposed-read addresses: 16-column tile ct, read rd: rows 8 g + 4 rd + q of the 32-deep stage (g = lane >> 4: the lane group's k octet)
-    constexpr int TI = 4;                                    // 4 x 4 tiles of 16 x 16 per wave
-    int fa_off[TI][2], fb_off[TI][2];
-    {
-        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const int r = 8 * g + 4 * rd + q;
-            const int swz = ((r & 3) << 2) | ((r >> 2) & 3);
-#pragma unroll
-            for (int mi = 0; mi < TI; ++mi) fa_off[mi][rd] = 256 * r + 16 * ((2 * (wm * TI + mi) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
-#pragma unroll
-            for (int ni = 0; ni < TI; ++ni) fb_off[ni][rd] = NPART * TILE + 256 * r + 16 * ((2 * (wn * TI + ni) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
-        }
-    }
-    f32x4 acc[TI][TI];
-#pragma unroll
-    for (int mi = 0; mi < TI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto mfma = [](bf16x8 x, bf16x8 y, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0); };
-
-    issue(0);
-    for (int kc = 0; kc < nK; ++kc) {
-        const bool more = kc + 1 < nK;
-        stage_store(0); __syncthreads();
-        if (more) issue(kc + 1);
-        const unsigned char* base = smem_b;
-        bf16x8 ah[TI], am[TI], al[TI];
-#pragma unroll
-        for (int mi = 0; mi < TI; ++mi) {
-            ah[mi] = afi_tr_frag(base, fa_off[mi][0], fa_off[mi][1]);
-            if (NPART >= 2) am[mi] = afi_tr_frag(base + TILE, fa_off[mi][0], fa_off[mi][1]);
-            if (NPART == 3) al[mi] = afi_tr_frag(base + 2 * TILE, fa_off[mi][0], fa_off[mi][1]);
-        }
-#pragma unroll
-        for (int ni = 0; ni < TI; ++ni) {
-            bf16x8 bh, bm, bl;
-            bh = afi_tr_frag(base, fb_off[ni][0], fb_off[ni][1]);
-            if (NPART >= 2) bm = afi_tr_frag(base + TILE, fb_off[ni][0], fb_off[ni][1]);
-            if (NPART == 3) bl = afi_tr_frag(base + 2 * TILE, fb_off[ni][0], fb_off[ni][1]);
-            if (SPLIT == 6) {
-#pragma unroll
-                for (int mi = 0; mi < TI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < TI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < TI; ++mi) acc[mi][ni] = mfma(am[mi], bm, acc[mi][ni]);
-            }
-            if (SPLIT >= 3) {
-#pragma unroll
-                for (int mi = 0; mi < TI; ++mi) acc[mi][ni] = mfma(am[mi], bh, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < TI; ++mi) acc[mi][ni] = mfma(ah[mi], bm, acc[mi][ni]);
-            }
-#pragma unroll
-            for (int mi = 0; mi < TI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
-        }
-        __syncthreads();
-    }
-    const bool use_atomic = gridDim.y > 1;
-    float* out = p.dU + (long long)plane * p.M * p.N;
-#pragma unroll
-    for (int mi = 0; mi < TI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < TI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + (wm * TI + mi) * 16 + (lane >> 4) * 4 + r;
-                float* dst = out + (long long)row * p.N + n0 + (wn * TI + ni) * 16 + (lane & 15);
-                if (use_atomic) atomicAdd(dst, acc[mi][ni][r]); else *dst += acc[mi][ni][r];
-            }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Round 3: the TN GEMM with both operands staged by LDS-DMA.  Both operands are activations (dY and X in the transform domain), so
-// neither can be pre-split for free; the tiles are copied VERBATIM -- fp32, [16 k][128 | 256 columns], row-major, no swizzle -- and a
-// lane gathers its eight k of one column with eight ds_read_b32 (32 consecutive floats per half wave: conflict-free as they lie) and
-// splits them in registers.  Against the kernel above: 128 x 256 block, 64 x 128 wave tiles (six fragments per 48 MFMAs instead of
-// four per 24), 4 bytes per element through LDS instead of 6 written + 6 read transposed, no VGPR staging, no ds_write stream; the price
-// is that a fragment is split by both waves that share it.  Two stage buffers (24 KB each), one barrier per stage, the next stage's DMA
-// in flight under the MFMAs; two blocks per CU (128 accumulator registers).
-// ------------------------------------------------------------------------------------------------
-template <int SPLIT>
-__global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_dma_kernel(const AfiGemmTN p, int ntile_m, int ntile_n, int kper) {
-    constexpr int BM = 128, BN = 256, BK = 16, MI = 2, NI = 4;
-    constexpr int NPART = SPLIT == 6 ? 3 : 2;
-    constexpr int TILE_A = BK * BM * 4, TILE_B = BK * BN * 4, STAGE = TILE_A + TILE_B;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, lh = lane >> 5;
-    int t;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    const int tile_n = t % ntile_n; t /= ntile_n;
-    const int tile_m = t % ntile_m; const int plane = t / ntile_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const long long k_begin = (long long)blockIdx.y * kper;
-    const long long k_end = (k_begin + kper < p.rows_per_plane) ? k_begin + kper : p.rows_per_plane;
-    if (k_begin >= k_end) return;
-    const int nK = (int)((k_end - k_begin) / BK);
-    typedef const __attribute__((address_space(1))) void* gptr;
-    typedef __attribute__((address_space(3))) void* lptr;
-    // A: DMA instruction i of wave w fills rows 2 (2 w + i), + 1 (lane >> 5 = row, lane & 31 = float4 column); B: instruction i fills row 4 w + i
-    const float* a_src = p.Q + ((long long)plane * p.rows_per_plane + k_begin + 4 * wave + lh) * p.M + m0 + 4 * lr;
-    const float* b_src = p.V + ((long long)plane * p.rows_per_plane + k_begin + 4 * wave) * p.N + n0 + 4 * lane;
-    const long long a_stage = (long long)BK * p.M, b_stage = (long long)BK * p.N;
-    auto issue = [&](int kc, int buf) {
-        unsigned char* dst = smem_b + buf * STAGE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gptr)(a_src + kc * a_stage + 2LL * i * p.M), (lptr)(dst + (2 * wave + i) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr)(b_src + kc * b_stage + (long long)i * p.N), (lptr)(dst + TILE_A + (4 * wave + i) * 1024), 16, 0, 0);
-    };
-    int fa_off[MI], fb_off[NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) fa_off[mi] = 8 * lh * (BM * 4) + ((wm * MI + mi) * 32 + lr) * 4;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) fb_off[ni] = TILE_A + 8 * lh * (BN * 4) + ((wn * NI + ni) * 32 + lr) * 4;
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    auto mfma = [](bf16x8 x, bf16x8 y, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); };
-
-    issue(0, 0);
-    for (int kc = 0; kc < nK; ++kc) {
-        __syncthreads();                                     // stage kc has landed (vmcnt(0)); every wave is done with the other buffer
-        if (kc + 1 < nK) issue(kc + 1, (kc + 1) & 1);
-        const unsigned char* sm = smem_b + (kc & 1) * STAGE;
-        bf16x8 ah[MI], am[MI], al[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            f32x2 c[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { c[j][0] = *(const float*)(sm + fa_off[mi] + 2 * j * (BM * 4)); c[j][1] = *(const float*)(sm + fa_off[mi] + (2 * j + 1) * (BM * 4)); }
-            afi_split8_bf16<NPART>(c, ah[mi], am[mi], al[mi]);
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            f32x2 c[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { c[j][0] = *(const float*)(sm + fb_off[ni] + 2 * j * (BN * 4)); c[j][1] = *(const float*)(sm + fb_off[ni] + (2 * j + 1) * (BN * 4)); }
-            bf16x8 bh, bm, bl;
-            afi_split8_bf16<NPART>(c, bh, bm, bl);
-            if (SPLIT == 6) {                                // smallest terms first, as in the kernel above
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(am[mi], bm, acc[mi][ni]);
-            }
-            if (SPLIT == 3) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(am[mi], bh, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bm, acc[mi][ni]);
-            }
-            if (SPLIT == 6) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(am[mi], bh, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bm, acc[mi][ni]);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
-        }
-    }
-    const bool use_atomic = gridDim.y > 1;
-    float* out = p.dU + (long long)plane * p.M * p.N;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float* dst = out + (long long)row * p.N + n0 + (wn * NI + ni) * 32 + lr;
-                if (use_atomic) atomicAdd(dst, acc[mi][ni][r]); else *dst += acc[mi][ni][r];
-            }
-}
-
-// ------------------------------------------------------------------------------------------------
-// TN GEMM on operands that arrive PRE-SPLIT in LDS-image order (the weight-gradient transforms write them that way: both operands of this
-// GEMM are produced for it alone).  Image = [32 k][128 columns] bf16 of one part, 256-byte rows, chunk swizzle of the kernel above;
-// global order [plane][columns / 128][k / 32][part][8 KB].  A stage is 16 k = one half (4 KB) of each of the 3 + 6 images of a 128 x 256
-// block tile, copied linearly by LDS-DMA; fragments by ds_read_b64_tr_b16 exactly as above.  No conversion, no VGPR staging, no LDS
-// store instructions; two stage buffers (2 x 36 KB), one barrier per stage.
-// ------------------------------------------------------------------------------------------------
-struct AfiGemmTNPre { const unsigned char* Q; const unsigned char* V; float* dU; long long rows_per_plane; int planes, M, N; };
-
-template <int SPLIT, int BN, int NBUF, int MINB>
-__global__ __launch_bounds__(256, MINB) void afi_gemm_tn_bf16_pre_kernel(const AfiGemmTNPre p, int ntile_m, int ntile_n, int kper) {
-    constexpr int BM = 128, MI = 2, NI = BN / 64, NB = BN / 128;
-    constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);
-    constexpr int HALF = 4096, IMG = 8192;
-    constexpr int STAGE = (1 + NB) * NPART * HALF;          // A, B0 (, B1) halves of every part
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int lr = lane & 31, lh = lane >> 5;
-    int t;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
-    }
-    const int tile_n = t % ntile_n; t /= ntile_n;
-    const int tile_m = t % ntile_m; const int plane = t / ntile_m;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const long long k_begin = (long long)blockIdx.y * kper;
-    const long long k_end = (k_begin + kper < p.rows_per_plane) ? k_begin + kper : p.rows_per_plane;
-    if (k_begin >= k_end) return;
-    const int nS = (int)((k_end - k_begin) / 16);            // 16-k stages (kper is a multiple of 32)
-    const long long nchunk = p.rows_per_plane / 32, c0 = k_begin / 32;
-    typedef const __attribute__((address_space(1))) void* gptr;
-    typedef __attribute__((address_space(3))) void* lptr;
-    // the 3 * NPART halves of a stage are 4 KB each = four 1 KB DMA instructions; wave w issues instruction w of every half
-    const unsigned char* a_src = p.Q + (((long long)plane * (p.M / 128) + tile_m) * nchunk + c0) * (long long)(NPART * IMG) + wave * 1024 + lane * 16;
-    const unsigned char* b_src = p.V + (((long long)plane * (p.N / 128) + NB * tile_n) * nchunk + c0) * (long long)(NPART * IMG) + wave * 1024 + lane * 16;
-    const long long b_tile = nchunk * (long long)(NPART * IMG);
-    auto issue = [&](int s, int buf) {
-        unsigned char* dst = smem_b + buf * STAGE + wave * 1024;
-        const long long off = (long long)(s >> 1) * (NPART * IMG) + (s & 1) * HALF;
-#pragma unroll
-        for (int pt = 0; pt < NPART; ++pt) {
-            __builtin_amdgcn_global_load_lds((gptr)(a_src + off + pt * IMG), (lptr)(dst + pt * HALF), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr)(b_src + off + pt * IMG), (lptr)(dst + (NPART + pt) * HALF), 16, 0, 0);
-            if (NB == 2) __builtin_amdgcn_global_load_lds((gptr)(b_src + b_tile + off + pt * IMG), (lptr)(dst + (2 * NPART + pt) * HALF), 16, 0, 0);
-        }
-    };
-    int fa_off[MI][2], fb_off[NI][2];
-    {
-        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
-#pragma unroll
-        for (int rd = 0; rd < 2; ++rd) {
-            const int r = 8 * (g >> 1) + 4 * rd + q;
-            const int swz = ((r & 3) << 2) | ((r >> 2) & 3);
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) fa_off[mi][rd] = 256 * r + 16 * ((4 * (wm * MI + mi) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = (NB == 2 ? (1 + wn) : 1) * NPART * HALF + 256 * r + 16 * ((4 * (NB == 2 ? ni : wn * NI + ni) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
-        }
-    }
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    auto mfma = [](bf16x8 x, bf16x8 y, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); };
-
-    issue(0, 0);
-    for (int s = 0; s < nS; ++s) {
-        __syncthreads();                                     // stage s has landed; every wave is done with the other buffer
-        if (NBUF == 2 && s + 1 < nS) issue(s + 1, (s + 1) & 1);
-        const unsigned char* sm = smem_b + (NBUF == 2 ? (s & 1) * STAGE : 0);
-        bf16x8 ah[MI], am[MI], al[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            ah[mi] = afi_tr_frag(sm, fa_off[mi][0], fa_off[mi][1]);
-            if (NPART >= 2) am[mi] = afi_tr_frag(sm + HALF, fa_off[mi][0], fa_off[mi][1]);
-            if (NPART == 3) al[mi] = afi_tr_frag(sm + 2 * HALF, fa_off[mi][0], fa_off[mi][1]);
-        }
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            bf16x8 bh, bm, bl;
-            bh = afi_tr_frag(sm, fb_off[ni][0], fb_off[ni][1]);
-            if (NPART >= 2) bm = afi_tr_frag(sm + HALF, fb_off[ni][0], fb_off[ni][1]);
-            if (NPART == 3) bl = afi_tr_frag(sm + 2 * HALF, fb_off[ni][0], fb_off[ni][1]);
-            if (SPLIT == 6) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(am[mi], bm, acc[mi][ni]);
-            }
-            if (SPLIT >= 3) {
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(am[mi], bh, acc[mi][ni]);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bm, acc[mi][ni]);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
-        }
-        if (NBUF == 1) {
-            __syncthreads();
-            if (s + 1 < nS) issue(s + 1, 0);
-        }
-    }
-    const bool use_atomic = gridDim.y > 1;
-    float* out = p.dU + (long long)plane * p.M * p.N;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float* dst = out + (long long)row * p.N + n0 + (wn * NI + ni) * 32 + lr;
-                if (use_atomic) atomicAdd(dst, acc[mi][ni][r]); else *dst += acc[mi][ni][r];
-            }
-}
-
-// byte offset of the float4 (k row r, columns 4 cq ..) inside one [32][128] bf16 image (8 bytes per part)
-__device__ __forceinline__ int afi_bf16_kimg_off(int r, int cq) {
-    return 256 * r + 16 * ((cq >> 1) ^ (((r & 3) << 2) | ((r >> 2) & 3))) + 8 * (cq & 1);
-}
-// X[plane][k][C] fp32 -> images [plane][C / 128][k / 32][part][8 KB] (stand-alone form of what the weight-gradient transforms write)
-template <int SPLIT>
-__global__ __launch_bounds__(256) void afi_split_bf16_kimg_kernel(const float* __restrict__ X, unsigned char* __restrict__ out, int planes, long long rows, int C) {
-    constexpr int NPART = SPLIT == 6 ? 3 : (SPLIT == 3 ? 2 : 1);
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int c4 = C / 4;
-    if (i >= (long long)planes * rows * c4) return;
-    const int cq = (int)(i % c4);
-    const long long rowg = i / c4;
-    const long long k = rowg % rows; const int plane = (int)(rowg / rows);
-    const f32x4 v = *(const f32x4*)(X + rowg * C + 4 * cq);
-    unsigned char* img = out + ((((long long)plane * (C / 128) + (cq >> 5)) * (rows / 32)) + (k >> 5)) * (long long)(NPART * 8192) + afi_bf16_kimg_off((int)(k & 31), cq & 31);
-    u32x2 h, m, l;
-    afi_split4_bf16<NPART>(v, h, m, l);
-    *(u32x2*)img = h;
-    if (NPART >= 2) *(u32x2*)(img + 8192) = m;
-    if (NPART == 3) *(u32x2*)(img + 16384) = l;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Round 3: the NT GEMM with both operands staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no LDS store instructions) on
 // v_mfma_f32_16x16x32_bf16.  Measured against the register-staged kernel above in one process (tools/gemm_ab.py, random operands):
@@ -645,7 +207,8 @@ __global__ __launch_bounds__(256) void afi_split_bf16_kimg_kernel(const float* _
 //   second barrier: its latency is covered by the other resident blocks (four per CU at <= 128 registers).  Measured and rejected: two
 //   buffers with one barrier per stage and the next stage's DMA in flight under the MFMAs, at two blocks per CU: 8-10 % slower on every
 //   shape (profiles/r03/gemm_nt_dma_single_vs_double_buffer.log) -- the fourth and third resident block are worth more than the overlap
-//   inside one block, as with the register-staged kernels of rounds 1 and 2.
+//   inside one block, as with the register-staged kernels of rounds 1 and 2.  Also measured: the A split pair-wise (v_cvt_pk + two masks + one
+//   packed subtract per pair and part: 9 instead of 15 VALU instructions per pair), bit-identical, +-1 % -- the kernel is not VALU-bound.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int afi_bf16_tile16_off(int row, int kq /* float4 column 0..7 */) {
     return row * 64 + ((((kq >> 1) ^ (-(row >> 2))) & 3) << 4) + ((kq & 1) << 3);

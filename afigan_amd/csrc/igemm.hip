@@ -936,23 +936,20 @@ int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, lo
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
-int g_afi_tn_variant = 1;                                   // TEMP (A/B): 0 = register-staged kernel everywhere
-extern "C" void afi_debug_set_tn_variant(int v) { g_afi_tn_variant = v; }
-
 int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st) {
     if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0 || (split != 1 && split != 3 && split != 6)) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
-    const bool dma = g_afi_tn_variant == 1 && split >= 3 && (N % 256) == 0;         // LDS-DMA kernel: 128 x 256 tiles
-    const int ntm = M / 128, ntn = dma ? N / 256 : N / 128;
+    const int ntm = M / 128, ntn = N / 128;
     const long long tiles = (long long)ntm * ntn * planes;
-    // two resident blocks per CU (512 slots); a stage is ~16x shorter than the fp32 kernel's, so blocks keep >= 16 stages each
+    // resident blocks: three per CU for the six-product form (one 48 KB buffer, 166 registers), two for the double-buffered others;
+    // a stage is ~16x shorter than the fp32 kernel's, so blocks keep >= 16 stages each
+    const int slots = split == 6 ? 768 : 512;
     int splitK = 1;
     {
         const int maxsplit = (int)(rows_per_plane / (16 * 32)) > 0 ? (int)(rows_per_plane / (16 * 32)) : 1;
         double best = -1.0;
         for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {
             const long long blocks = tiles * s2;
-            const int slots = g_afi_tn_variant == 3 ? 768 : 512;
             if (blocks < 2 * slots && s2 < maxsplit) continue;
             if (blocks > 6 * slots && best >= 0.0) break;
             const long long rounds = (blocks + slots - 1) / slots;
@@ -966,83 +963,13 @@ int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int plane
     AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
     ProfScope prof(st, 18, 2.0 * (double)rows_per_plane * planes * M * N);
     prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
-    if (dma) {
-        const dim3 grid((unsigned)tiles, splitK), blk(256);
-        const size_t lds = 2u * 16u * (128u + 256u) * 4u;      // two stages of [16 k][128 + 256 columns] fp32
-        if (split == 6) hipLaunchKernelGGL((afi_gemm_tn_bf16_dma_kernel<6>), grid, blk, lds, st, g, ntm, ntn, kper);
-        else hipLaunchKernelGGL((afi_gemm_tn_bf16_dma_kernel<3>), grid, blk, lds, st, g, ntm, ntn, kper);
-        return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
-    }
-    if (g_afi_tn_variant == 2 && split >= 3) {             // TEMP: 16x16x32 MFMA form of the register-staged kernel
-        const size_t lds2 = 2u * (split == 6 ? 3u : 2u) * 8192u;
-        const dim3 grid((unsigned)tiles, splitK), blk(256);
-        if (split == 6) hipLaunchKernelGGL((afi_gemm_tn_bf16_m16_kernel<6>), grid, blk, lds2, st, g, ntm, ntn, kper);
-        else hipLaunchKernelGGL((afi_gemm_tn_bf16_m16_kernel<3>), grid, blk, lds2, st, g, ntm, ntn, kper);
-        return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
-    }
-    const bool db = split != 6;                            // six-product form: one 48 KB buffer, two blocks per CU
+    const bool db = split != 6;                            // six-product form: one 48 KB buffer
     const size_t lds = (db ? 2u : 1u) * 2u * (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 8192u;
     const dim3 grid((unsigned)tiles, splitK), blk(256);
     if (split == 6) hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<6, false>), grid, blk, lds, st, g, ntm, ntn, kper);
     else if (split == 3) hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<3, true>), grid, blk, lds, st, g, ntm, ntn, kper);
     else hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<1, true>), grid, blk, lds, st, g, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
-}
-
-int afi_launch_split_bf16_kimg(const float* X, void* out, int planes, long long rows, int C, int split, hipStream_t st) {
-    if (planes <= 0 || rows <= 0 || (rows % 32) || (C % 128)) return AFI_ERR_BAD_ARG;
-    const long long n = (long long)planes * rows * (C / 4);
-    const dim3 grid((unsigned)((n + 255) / 256)), blk(256);
-    if (split == 6) hipLaunchKernelGGL((afi_split_bf16_kimg_kernel<6>), grid, blk, 0, st, X, (unsigned char*)out, planes, rows, C);
-    else if (split == 3) hipLaunchKernelGGL((afi_split_bf16_kimg_kernel<3>), grid, blk, 0, st, X, (unsigned char*)out, planes, rows, C);
-    else hipLaunchKernelGGL((afi_split_bf16_kimg_kernel<1>), grid, blk, 0, st, X, (unsigned char*)out, planes, rows, C);
-    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
-}
-
-// TN GEMM on pre-split image operands (afi_gemm_bf16.h); M % 128 == 0, N % 256 == 0, rows % 32 == 0
-int afi_launch_gemm_tn_bf16_pre(const void* Qimg, const void* Vimg, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st) {
-    if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0 || (split != 1 && split != 3 && split != 6)) return AFI_ERR_BAD_ARG;
-    const int var = g_afi_tn_variant;                      // TEMP: 10 = 128x256 DB; 11 = 128x128 DB (3/CU); 12 = 128x128 single buffer (4/CU)
-    const int bn = var == 10 ? 256 : 128;
-    if ((rows_per_plane % 32) || (M % 128) || (N % bn)) return AFI_ERR_UNSUPPORTED;
-    const int ntm = M / 128, ntn = N / bn;
-    const long long tiles = (long long)ntm * ntn * planes;
-    const int slots = var == 10 ? 512 : (var == 11 ? 768 : 1024);
-    int splitK = 1;
-    {
-        const int maxsplit = (int)(rows_per_plane / (8 * 32)) > 0 ? (int)(rows_per_plane / (8 * 32)) : 1;
-        double best = -1.0;
-        for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {
-            const long long blocks = tiles * s2;
-            if (blocks < 2 * slots && s2 < maxsplit) continue;
-            if (blocks > 6 * slots && best >= 0.0) break;
-            const long long rounds = (blocks + slots - 1) / slots;
-            const double fill = (double)blocks / (double)(rounds * slots);
-            if (fill > best + 1e-3) { best = fill; splitK = s2; }
-        }
-    }
-    int kper = (int)((rows_per_plane + splitK - 1) / splitK);
-    kper = ((kper + 31) / 32) * 32;
-    splitK = (int)((rows_per_plane + kper - 1) / kper);
-    AfiGemmTNPre g{(const unsigned char*)Qimg, (const unsigned char*)Vimg, dU, rows_per_plane, planes, M, N};
-    ProfScope prof(st, 18, 2.0 * (double)rows_per_plane * planes * M * N);
-    prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
-    const int npart = split == 6 ? 3 : (split == 3 ? 2 : 1);
-    const size_t lds = (var == 12 ? 1u : 2u) * (var == 10 ? 3u : 2u) * npart * 4096u;
-    const dim3 grid((unsigned)tiles, splitK), blk(256);
-    if (split != 6) return AFI_ERR_UNSUPPORTED;
-    if (var == 10) {
-        if (!afi_opt_in_big_lds((const void*)afi_gemm_tn_bf16_pre_kernel<6, 256, 2, 2>)) return AFI_ERR_LAUNCH;
-        hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<6, 256, 2, 2>), grid, blk, lds, st, g, ntm, ntn, kper);
-    } else if (var == 11) hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<6, 128, 2, 3>), grid, blk, lds, st, g, ntm, ntn, kper);
-    else hipLaunchKernelGGL((afi_gemm_tn_bf16_pre_kernel<6, 128, 1, 4>), grid, blk, lds, st, g, ntm, ntn, kper);
-    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
-}
-extern "C" int afi_debug_tn_split(const float* X, void* out, int planes, long long rows, int C, int split, void* stream) {   // TEMP
-    return afi_launch_split_bf16_kimg(X, out, planes, rows, C, split, (hipStream_t)stream);
-}
-extern "C" int afi_debug_gemm_tn_pre(const void* Q, const void* V, float* dU, int planes, long long rows, int M, int N, int split, void* stream) {   // TEMP
-    return afi_launch_gemm_tn_bf16_pre(Q, V, dU, planes, rows, M, N, split, (hipStream_t)stream);
 }
 
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st) {
