@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void afi_gemm_tn_kernel(const AfiGemmTN p, int
 // ------------------------------------------------------------------------------------------------
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; int kind; double flops; long long m; int n, k, split; };
+struct ProfRec { hipEvent_t a, b; int kind; double flops; long long m; int n, k, split, planes; };
 struct ProfState {
     bool on = false;
     std::vector<ProfRec> recs;
@@ -629,14 +629,14 @@ hipEvent_t prof_event() {
 }
 struct ProfScope {
     hipStream_t st; int kind; double flops; hipEvent_t a{};
-    long long m = 0; int n = 0, k = 0, split = 1;         // GEMM shape of the launch (rows, columns, K; split-K factor), for afi_profile_dump
+    long long m = 0; int n = 0, k = 0, split = 1, planes = 1;   // GEMM shape of the launch (rows over all planes, columns, K; split-K factor; planes), for afi_profile_dump
     ProfScope(hipStream_t s, int kd, double f) : st(s), kind(kd), flops(f) {
         if (g_prof.on) { a = prof_event(); (void)hipEventRecord(a, st); }
     }
     bool live = true;
     void cancel() { live = false; }                        // nothing was launched under this scope (the caller falls back to another kernel)
     ~ProfScope() {
-        if (g_prof.on && live) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops, m, n, k, split}); }
+        if (g_prof.on && live) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops, m, n, k, split, planes}); }
     }
 };
 }  // namespace
@@ -661,16 +661,17 @@ extern "C" int afi_profile_get(int kind, double* out) {
     return AFI_OK;
 }
 
-// one CSV line per recorded launch: kind,rows,cols,k,split,ms,tflops  (analysis aid: which shapes fill a kind's bucket)
+// one CSV line per recorded launch: kind,rows,cols,k,split,planes,ms,tflops  (analysis aid: which shapes fill a kind's bucket;
+// split is the split-K factor, or the bf16 parts setting (6 / 3 / 1) for the batched NT GEMM)
 #include <stdio.h>
 extern "C" int afi_profile_dump(const char* path) {
     FILE* f = fopen(path, "w");
     if (!f) return AFI_ERR_BAD_ARG;
-    fprintf(f, "kind,rows,cols,k,split,ms,tflops\n");
+    fprintf(f, "kind,rows,cols,k,split,planes,ms,tflops\n");
     for (const ProfRec& r : g_prof.recs) {
         float ms = 0.f;
         if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { fclose(f); return AFI_ERR_LAUNCH; }
-        fprintf(f, "\"%s\",%lld,%d,%d,%d,%.4f,%.2f\n", kKindNames[r.kind], r.m, r.n, r.k, r.split, ms, ms > 0.f ? r.flops / (ms * 1e-3) / 1e12 : 0.0);
+        fprintf(f, "\"%s\",%lld,%d,%d,%d,%d,%.4f,%.2f\n", kKindNames[r.kind], r.m, r.n, r.k, r.split, r.planes, ms, ms > 0.f ? r.flops / (ms * 1e-3) / 1e12 : 0.0);
     }
     fclose(f);
     return AFI_OK;
@@ -757,7 +758,7 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
     const int ntm = (int)(M / 128), ntn = N / 128, chunk = afi_cdiv(ntm, 8);
     const size_t lds = sizeof(float) * 2 * 128 * (AFI_BK + 4);
     ProfScope prof(st, 13, 2.0 * (double)M * N * K);
-    prof.m = M; prof.n = N; prof.k = K;
+    prof.m = M; prof.n = N; prof.k = K; prof.planes = planes;
     // (two register sets for the A stream, PF = 2, spill under the 168-register cap of 3 blocks per CU: 95 instead of 262 TFLOP/s)
     hipLaunchKernelGGL((afi_gemm_nt_kernel<1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ntn, ntm, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
@@ -786,7 +787,7 @@ int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, in
     const size_t stage = 16384u + (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 8192u, epi = sizeof(float) * 64u * (128u + 4u);
     const size_t lds = stage > epi ? stage : epi;
     ProfScope prof(st, 17, 2.0 * (double)M * N * K);
-    prof.m = M; prof.n = N; prof.k = K; prof.split = split;
+    prof.m = M; prof.n = N; prof.k = K; prof.split = split; prof.planes = planes;
     const dim3 grid(chunk * ntn * 8), blk(256);
     if (split == 6) hipLaunchKernelGGL((afi_gemm_nt_bf16_dma_kernel<6, 4>), grid, blk, lds, st, g, ntn, ntm, chunk);
     else if (split == 3) hipLaunchKernelGGL((afi_gemm_nt_bf16_dma_kernel<3, 4>), grid, blk, lds, st, g, ntn, ntm, chunk);
@@ -931,7 +932,7 @@ int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, lo
     splitK = (int)((rows_per_plane + kper - 1) / kper);
     AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
     ProfScope prof(st, 14, 2.0 * (double)rows_per_plane * planes * M * N);
-    prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
+    prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK; prof.planes = planes;
     hipLaunchKernelGGL(afi_gemm_tn_kernel, dim3((unsigned)tiles, splitK), dim3(256), sizeof(float) * AFI_BK * 256, st, g, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
@@ -962,7 +963,7 @@ int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int plane
     splitK = (int)((rows_per_plane + kper - 1) / kper);
     AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
     ProfScope prof(st, 18, 2.0 * (double)rows_per_plane * planes * M * N);
-    prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK;
+    prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK; prof.planes = planes;
     const bool db = split != 6;                            // six-product form: one 48 KB buffer
     const size_t lds = (db ? 2u : 1u) * 2u * (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 8192u;
     const dim3 grid((unsigned)tiles, splitK), blk(256);

@@ -142,6 +142,34 @@ def rehearse_launch(args, world, rank):
     raise SystemExit(0 if ok and same is not False else 1)
 
 
+KERNEL_TOKENS = ("gemm_nt", "gemm_tn", "pix_gemm_wk", "pix_gemm", "wgrad")
+
+
+def committed_traffic(fname, dom_kernel):
+    """HBM traffic of a dominant kernel cannot be read live (PMC counters need their own rocprofv3 passes): report the committed
+    measurement of the same command when there is one (the newest profiles/rNN/<fname>), else None.  The record names the kernel it was
+    taken on -- another dominant kernel nulls it -- and is tied to the kernel SOURCE it was measured on by a sha256: a later edit of that
+    file nulls it too."""
+    for rnd in ("r03", "r02", "r01"):
+        tpath = os.path.join(ROOT, "profiles", rnd, fname)
+        if not os.path.exists(tpath):
+            continue
+        try:
+            tj = json.load(open(tpath))
+            same = [t for t in KERNEL_TOKENS if t in dom_kernel][:1] == [t for t in KERNEL_TOKENS if t in str(tj.get("kernel", ""))][:1]
+            src = tj.get("kernel_source")
+            fresh = bool(src) and file_sha256(os.path.join(ROOT, src)) == tj.get("kernel_source_sha256")
+            if not same or not fresh:
+                return None                                # measured on another kernel, or on another version of this one: stale
+            return {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch"),
+                    "measured_at": tj.get("measured_at"), "kernel_source": src, "kernel_source_sha256": tj.get("kernel_source_sha256"),
+                    "held_clock_ghz": tj.get("held_clock_ghz"), "mfma_busy_at_held_clock": tj.get("mfma_busy_at_held_clock"),
+                    "source": f"profiles/{rnd}/{fname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; FETCH x2 per the gfx950 correction)"}
+        except (OSError, ValueError, KeyError):
+            return None
+    return None
+
+
 def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
     """Generator(n_rdb=3) forward + full backward (input grad + all weight grads, loss = out.sum()) through the C-ABI.
     Timed twice: eager launches, and the same call sequence captured once into a hipGraph and replayed (no host launch cost;
@@ -221,7 +249,8 @@ def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
         roof = {"bound": "mfma", "kernel": d0["kernel"], "achieved": d0["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": d0["tflops"] / PEAK_FP32_MFMA_TFLOPS, "launches": d0["launches_per_iter"], "avg_launch_us": d0["avg_launch_us"],
                 "gemm_launches_per_iter": sum(r["launches_per_iter"] for r in kinds), "gemm_us_per_iter": sum(r["us_per_iter"] for r in kinds),
-                "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in kinds], "traffic": None}
+                "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in kinds],
+                "traffic": committed_traffic("traffic_cfg1_dominant_kernel.json", d0["kernel"]) if (N, H, W) == (1, 25, 34) else None}
     return {"roofline": roof, "shape": f"{N}x256x{H}x{W}->{N}x256x{2 * H}x{2 * W}", "launch": mode, "ms": dt * 1e3, "ms_eager": dt_eager * 1e3,
             "ms_graph": None if dt_graph is None else dt_graph * 1e3, "ms_host_enqueue": t_enq * 1e3,
             "out_mpix_per_s": out_px / dt / 1e6, "in_mpix_per_s": out_px / 4 / dt / 1e6, "tflops": flop / dt / 1e12,
@@ -603,31 +632,7 @@ def main():
 
     gemm_ms = sum(r["ms_total"] for r in kinds)
     gemm_flop = sum(r["flop_total"] for r in kinds)
-    # HBM traffic of the dominant kernel cannot be read live (PMC counters need their own rocprofv3 passes): report the
-    # committed measurement of the same command when there is one (profiles/r01/traffic_dominant_kernel.json), else null
-    # (the newest profiles/rNN that holds one; the record names the kernel it was taken on -- a different dominant kernel nulls it)
-    traffic = None
-    for rnd in ("r03", "r02", "r01"):
-        tpath = os.path.join(ROOT, "profiles", rnd, "traffic_dominant_kernel.json")
-        if not os.path.exists(tpath):
-            continue
-        try:
-            tj = json.load(open(tpath))
-            same = [t for t in ("gemm_nt", "gemm_tn", "pix_gemm_wk", "pix_gemm", "wgrad") if t in dom["kernel"]][:1] == \
-                   [t for t in ("gemm_nt", "gemm_tn", "pix_gemm_wk", "pix_gemm", "wgrad") if t in str(tj.get("kernel", ""))][:1]
-            # ... and the record is tied to the kernel SOURCE it was measured on: a later edit of the kernel file nulls it
-            src = tj.get("kernel_source")
-            fresh = bool(src) and file_sha256(os.path.join(ROOT, src)) == tj.get("kernel_source_sha256")
-            if not same or not fresh:
-                break                                      # measured on another kernel, or on another version of this one: stale
-            traffic = {"hbm_bytes_per_launch": tj["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch"),
-                       "measured_at": tj.get("measured_at"), "kernel_source": src, "kernel_source_sha256": tj.get("kernel_source_sha256"),
-                       "held_clock_ghz": tj.get("held_clock_ghz"), "mfma_busy_at_held_clock": tj.get("mfma_busy_at_held_clock"),
-                       "source": f"profiles/{rnd}/traffic_dominant_kernel.json "
-                       "(rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command; FETCH x2 per the gfx950 correction)"}
-        except (OSError, ValueError, KeyError):
-            traffic = None
-        break
+    traffic = committed_traffic("traffic_dominant_kernel.json", dom["kernel"])
     # the Winograd GEMMs' own roof: the dense bf16 MFMA peak over the bf16 MFMAs issued per fp32-equivalent product (6 / 3 / 1), or the
     # fp32 MFMA peak; every other kernel multiplies on the fp32 MFMA
     def kind_peak(name):
@@ -644,7 +649,7 @@ def main():
                                  if kernel_alone else None),
                 # fp32-equivalent rate of the dominant kernel against the fp32 MFMA roof it replaces (> 1 is the point of the emulated forms)
                 "achieved_over_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                "peak_note": "fp32-equivalent TFLOP/s: 2*M*N*K once per product; peak = dense bf16 MFMA 2500 (quoted at 2.4 GHz) / bf16 MFMAs per product (6, 3 or 1), or the fp32 MFMA 157.3.  Under the bf16x6 GEMM the chip holds 1.63 GHz (power-limited; profiles/r02/pmc_sq_steps1.csv: SQ_BUSY_CYCLES), where its matrix pipe is 67 % busy: DESIGN.md 4b",
+                "peak_note": "fp32-equivalent TFLOP/s: 2*M*N*K once per product; peak = dense bf16 MFMA 2500 (quoted at 2.4 GHz) / bf16 MFMAs per product (6, 3 or 1), or the fp32 MFMA 157.3.  Dense bf16 MFMA work is power-limited on this chip: traffic.held_clock_ghz / traffic.mfma_busy_at_held_clock are the clock it holds under this kernel and the matrix-pipe duty there (SQ_BUSY_CYCLES, SQ_VALU_MFMA_BUSY_CYCLES of the one-stream counter pass): DESIGN.md 4b",
                 # the whole step in EXECUTED matrix-core products (what the GEMM launches multiplied, Winograd-domain for the big convs): the time
                 # they need at each kernel's own peak over the wall time -- the one <= 1 "achieved roofline" figure of the step
                 "frac_step_executed": peak_s / elapsed,
