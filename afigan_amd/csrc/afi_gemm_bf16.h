@@ -319,7 +319,9 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_bf16_dma_kernel(const A
         for (int item = tid; item < 4 * 16 * C_F4; item += 256) {
             const int rloc = item / C_F4, c4 = item - rloc * C_F4;
             const int rl = (rloc >> 4) * 32 + mi * 16 + (rloc & 15);
-            *(f32x4*)(c_base + (long long)rl * p.N + 4 * c4) = *(const f32x4*)(Cs + rloc * LDC + 4 * c4);
+            // C is written once and read next by another kernel, far beyond L2's reach: nontemporal, so it does not push the A / B tiles that
+            // the neighbouring blocks are about to re-read out of the XCD's L2 (FETCH_SIZE -12 %, +1..3 % on the large shapes)
+            __builtin_nontemporal_store(*(const f32x4*)(Cs + rloc * LDC + 4 * c4), (f32x4*)(c_base + (long long)rl * p.N + 4 * c4));
         }
         if (mi + 1 < MI) __syncthreads();
     }

@@ -75,7 +75,7 @@ int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
  * error of the batched GEMM against fp64 on the same operands (tools/gemm_nt_dtype.py; tolerances asserted in tests/test_gpu_bf16.py):
  *   AFI_DTYPE_BF16X6  (default) each operand is split EXACTLY into three bf16, x = hi + mid + lo (3 x 8 = all 24 mantissa bits; the
  *                     residuals x - hi and x - hi - mid are exact in fp32), and the six partial products of order >= 2^-16
- *                     (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are accumulated smallest first in fp32 by v_mfma_f32_32x32x16_bf16;
+ *                     (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) are accumulated smallest first in fp32 by the bf16 MFMA (16x16x32 / 32x32x16);
  *                     a bf16 x bf16 product is exact in fp32, and what is dropped (mid*lo, lo*mid, lo*lo <= 2^-23 of a product) is the
  *                     size of fp32's own rounding of that product.  Error 0.5e-6 .. 1.1e-6 -- at or below the fp32 MFMA's on every shape
  *                     measured -- at 1.5x its speed.  fp32-grade: every parity test of this repo runs on it at the fp32 tolerances.
@@ -85,7 +85,11 @@ int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
  *   AFI_DTYPE_BF16    operands rounded to bf16 (8 bits), one MFMA; every convolution on F(2x2,3x3) tiles (the F(4x4) transforms do not
  *                     survive 8-bit operands: 3 % error).  Error 2.5e-3; conv outputs within 2e-2, networks 5e-2 / 1e-1.  Opt-in:
  *                     the reference has no reduced-precision mode (SOLVER.AMP is never read, defaults.py:82).
- * Refused while weight-gradient sums are pending.  AFI_DEFAULT_DTYPE=<n> in the environment overrides the default (A/B runs). */
+ * What follows the setting: the three batched GEMMs of a Winograd convolution -- forward (NT), data gradient (NT on the flipped weights)
+ * and weight gradient (TN) -- so a backward pass runs in the arithmetic its forward ran in (the autograd wrappers carry the forward's context
+ * into backward).  What never does: the direct implicit-GEMM kernels (1x1 and lateral convs, stride-2 and transposed convs, ragged / small
+ * maps, the small-map grouped kernels) and their weight-gradient GEMMs multiply on v_mfma_f32_32x32x2_f32 under every setting.
+ * Refused while weight-gradient sums are pending.  No environment variable changes the default. */
 #define AFI_DTYPE_F32 0
 #define AFI_DTYPE_BF16 1
 #define AFI_DTYPE_BF16X3 3
