@@ -785,6 +785,8 @@ int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, in
     const long long M = rows_per_plane * planes;
     const int ntm = (int)(M / 128), ntn = N / 128, chunk = afi_cdiv(ntm, 8);
     const size_t stage = 16384u + (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 8192u, epi = sizeof(float) * 64u * (128u + 4u);
+    // (four blocks per CU fill every register and all of LDS: kernels of the other stream only get on a CU when a block of this one retires.  Padding
+    //  the LDS request to hold it at three blocks, to leave them room: the kernel alone 357 -> 426 us, the two-stream step 112.8 -> 118.4 ms.)
     const size_t lds = stage > epi ? stage : epi;
     ProfScope prof(st, 17, 2.0 * (double)M * N * K);
     prof.m = M; prof.n = N; prof.k = K; prof.split = split; prof.planes = planes;
