@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
 //   buffers with one barrier per stage and the next stage's DMA in flight under the MFMAs, at two blocks per CU: 8-10 % slower on every
 //   shape (profiles/r03/gemm_nt_dma_single_vs_double_buffer.log) -- the fourth and third resident block are worth more than the overlap
 //   inside one block, as with the register-staged kernels of rounds 1 and 2.  Also measured: the A split pair-wise (v_cvt_pk + two masks + one
-//   packed subtract per pair and part: 9 instead of 15 VALU instructions per pair), bit-identical, +-1 % -- the kernel is not VALU-bound.
+//   packed subtract per pair and part: 9 instead of 15 VALU instructions per pair), bit-identical, +-1 % -- the kernel is not VALU-bound;
+//   eight waves of 32 x 64 per block at six waves per SIMD (80 registers): -18 % (half the MFMAs per B fragment read and per barrier).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int afi_bf16_tile16_off(int row, int kq /* float4 column 0..7 */) {
     return row * 64 + ((((kq >> 1) ^ (-(row >> 2))) & 3) << 4) + ((kq & 1) << 3);
