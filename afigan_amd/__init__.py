@@ -16,7 +16,7 @@ _lib.load()     # fail loudly at import time when the HIP library is missing
 from . import ops  # noqa: E402
 from .generator_rdb import Generator  # noqa: E402
 from .feature_patch_discriminator import Discriminator  # noqa: E402
-from .stage1 import Stage1Step, warmup_multistep_lr  # noqa: E402
+from .stage1 import GuidePrefetcher, Stage1Step, warmup_multistep_lr  # noqa: E402
 from .fpn_sr import FPN_AFIGAN, LastLevelMaxPool  # noqa: E402
 from .pafpn_sr import PAFPN_AFIGAN  # noqa: E402
 from .bifpn_sr import BiFPN_AFIGAN, LastLevelP6P7  # noqa: E402
@@ -28,4 +28,4 @@ from .rcnn_only import RCNN_FPN_only  # noqa: E402
 from .rcnn_extractor import GeneralizedRCNN_AFExtractor, META_ARCH_REGISTRY  # noqa: E402
 from .config import add_afigan_config, get_cfg  # noqa: E402
 
-__all__ = ["Generator", "Discriminator", "Stage1Step", "warmup_multistep_lr", "FPN_AFIGAN", "PAFPN_AFIGAN", "BiFPN_AFIGAN", "LastLevelP6P7", "LastLevelMaxPool", "Stage2Adversarial", "l1_loss_common", "nearest_half", "DualScaleMapper", "preprocess_images", "ops", "AfiError", "compute_dtype", "BACKBONE_REGISTRY", "GUIDE_ARCH_REGISTRY", "build_guide_model", "RCNN_FPN_only", "GeneralizedRCNN_AFExtractor", "META_ARCH_REGISTRY", "Stage2Step", "add_afigan_config", "get_cfg"]
+__all__ = ["Generator", "Discriminator", "Stage1Step", "GuidePrefetcher", "warmup_multistep_lr", "FPN_AFIGAN", "PAFPN_AFIGAN", "BiFPN_AFIGAN", "LastLevelP6P7", "LastLevelMaxPool", "Stage2Adversarial", "l1_loss_common", "nearest_half", "DualScaleMapper", "preprocess_images", "ops", "AfiError", "compute_dtype", "BACKBONE_REGISTRY", "GUIDE_ARCH_REGISTRY", "build_guide_model", "RCNN_FPN_only", "GeneralizedRCNN_AFExtractor", "META_ARCH_REGISTRY", "Stage2Step", "add_afigan_config", "get_cfg"]

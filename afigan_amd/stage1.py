@@ -60,6 +60,52 @@ def broadcast_module_state_(modules, src: int = 0, group=None) -> None:
             torch.distributed.broadcast(t, src=src, group=group)
 
 
+class GuidePrefetcher:
+    """The two forwards of the FROZEN guide network (stage1_trainer.py:316-327: ``feature_model(data, "image")`` and ``(data, "image_x0.5")``
+    under no_grad, eval mode) for batch i + 1, issued on a second stream while batch i trains.  The guide has no trainable state and no
+    BatchNorm updates, so its features do not depend on the G / D updates of the iteration they overlap: the result is the same tensors one
+    iteration earlier, nothing else.  ``submit(fn)`` runs ``fn()`` -- any callable returning the feature tensors (lists / dicts of them) --
+    on the prefetch stream behind whatever the caller's stream has queued (its inputs are ready); ``take()`` makes the caller's stream wait
+    for them and hands them over (``record_stream`` keeps the allocator from recycling them while the caller's stream still reads them)."""
+
+    def __init__(self, device=None):
+        self.stream = torch.cuda.Stream(device=device)
+        self._pending = None
+
+    @staticmethod
+    def _tensors(o):
+        if torch.is_tensor(o):
+            yield o
+        elif isinstance(o, dict):
+            for v in o.values():
+                yield from GuidePrefetcher._tensors(v)
+        elif isinstance(o, (list, tuple)):
+            for v in o:
+                yield from GuidePrefetcher._tensors(v)
+
+    def submit(self, fn):
+        if self._pending is not None:
+            raise RuntimeError("GuidePrefetcher.submit: the previous batch's features were not taken")
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream), torch.no_grad():
+            out = fn()
+        self._pending = out
+
+    def take(self):
+        if self._pending is None:
+            raise RuntimeError("GuidePrefetcher.take: nothing was submitted")
+        out, self._pending = self._pending, None
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(self.stream)
+        for t in self._tensors(out):
+            t.record_stream(cur)
+        return out
+
+    @property
+    def pending(self):
+        return self._pending is not None
+
+
 class _FlatOptim:
     """Flat gradient + momentum buffers for one network and the device-side descriptor table of the fused SGD kernel
     (torch.optim.SGD semantics as configured by detectron2 build_optimizer: momentum 0.9, weight decay 1e-4, 0 for norm

@@ -57,6 +57,9 @@ def parse():
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
     ap.add_argument("--one-stream", action="store_true", help="Stage1Step(overlap_d=False, overlap_g=False): every kernel alone on the chip (the "
                     "profiling passes of tools/prof_r03.sh: per-kernel durations comparable across rounds)")
+    ap.add_argument("--no-guide-prefetch", action="store_true", help="run the frozen guide network's two forwards at the head of every step on the step's own "
+                    "stream (default: the NEXT batch's guide forwards are issued on a second stream while the current batch trains -- "
+                    "afigan_amd.GuidePrefetcher; one guide pair and one training step per timed step either way)")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launch path only (no GPU work, no metric): spawn / rendezvous / all-reduce / invariant checks of the N-rank job with "
                          "CPU tensors; what tests/test_host_logic.py runs with --gpus 2 --backend gloo in a container without a GPU")
@@ -501,14 +504,26 @@ def main():
         syn_hr = [torch.randn((B, 256, h, w), device=dev, generator=gen).contiguous(memory_format=torch.channels_last) for h, w in hr_shapes]
         syn_lr = [torch.randn((B, 256, h, w), device=dev, generator=gen).contiguous(memory_format=torch.channels_last) for h, w in lr_shapes]
 
+    def guide_pair():
+        hr_ = guide(images)                                        # stage1_trainer.py:320
+        lr_ = guide(images_half)                                   # :321
+        return [hr_[f"p{d}"] for d in range(2, 7)], [lr_[f"p{d}"] for d in range(2, 7)]      # :325-327
+
+    # The guide is frozen (eval, no_grad, no BatchNorm updates): the features of batch i + 1 do not depend on the G / D updates of
+    # iteration i, so its two forwards are issued on a second stream while iteration i trains.  Every timed step still contains ONE guide
+    # pair and ONE training step (the pair it launches is consumed by the next step; the first one is launched by the warm-up).
+    prefetch = amd.GuidePrefetcher(dev) if (guide is not None and not args.no_guide_prefetch and not args.one_stream) else None
+
     def one_step():
-        if guide is not None:
-            hr_ = guide(images)                                    # stage1_trainer.py:320
-            lr_ = guide(images_half)                               # :321
-            hr = [hr_[f"p{d}"] for d in range(2, 7)]               # :325-327
-            lr = [lr_[f"p{d}"] for d in range(2, 7)]
-        else:
+        if guide is None:
             hr, lr = syn_hr, syn_lr
+        elif prefetch is None:
+            hr, lr = guide_pair()
+        else:
+            if not prefetch.pending:
+                prefetch.submit(guide_pair)                        # (first call only)
+            hr, lr = prefetch.take()
+            prefetch.submit(guide_pair)                            # the next batch's features, beside this step
         step.run_step(lr, hr)
         return hr, lr
 
@@ -676,6 +691,7 @@ def main():
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
                                f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",
                    "global_batch": world * B, "parallelism": f"dp{world}", "guide": "r50fpn (GEMM 1x1 via hipBLASLt + own 3x3 MFMA conv)" if guide is not None else "synthetic-pyramid",
+                   "guide_prefetch": prefetch is not None,
                    "reuse_generator_forward": True},
         "algorithmic_tflop_per_image": flop_img / 1e12,
         "step_tflops_per_gpu": flop_img * B * args.steps / elapsed / 1e12,

@@ -316,3 +316,36 @@ def test_stage1_error_in_a_phase_joins_the_second_stream(amd):
     step._allreduce = orig_all
     step.run_step(lrs, hrs)                                            # contexts are clean again (no pending sums, caches unregistered)
     assert all(np.isfinite(v) for v in step.metrics().values())
+
+
+def test_guide_prefetcher_hands_over_the_same_features_one_step_early(amd):
+    """afigan_amd.GuidePrefetcher (the frozen guide's two forwards of stage1_trainer.py:316-327 issued for batch i + 1 while batch i trains):
+    the features it hands over equal a direct call's bit for bit, over several overlapped iterations; misuse raises."""
+    from afigan_amd.guide import GuideR50FPN
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    guide = GuideR50FPN().to(dev)
+    gen = torch.Generator(device=dev).manual_seed(7)
+    images = [torch.rand((1, 3, 128, 160), device=dev, generator=gen) * 255.0 for _ in range(3)]
+
+    def pair(img):
+        return lambda: [guide(img)[f"p{d}"] for d in range(2, 7)]
+    with torch.no_grad():
+        direct = [[t.clone() for t in pair(img)()] for img in images]
+    pf = amd.GuidePrefetcher(dev)
+    with pytest.raises(RuntimeError):
+        pf.take()
+    pf.submit(pair(images[0]))
+    with pytest.raises(RuntimeError):
+        pf.submit(pair(images[1]))
+    burn = torch.randn((2048, 2048), device=dev)
+    for i in range(3):
+        feats = pf.take()
+        if i + 1 < 3:
+            pf.submit(pair(images[i + 1]))                 # runs beside the "training step" below
+        for _ in range(4):                                 # something for the caller's stream to do meanwhile
+            burn = torch.tanh(burn @ burn * 1e-3)
+        assert not pf.pending or i + 1 < 3
+        for a, b in zip(feats, direct[i]):
+            assert torch.equal(a, b), i
+    torch.cuda.synchronize()
