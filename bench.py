@@ -547,6 +547,8 @@ def main():
     if args.warmup:
         assert [tuple(t.shape[2:]) for t in hr] == hr_shapes and [tuple(t.shape[2:]) for t in lr] == lr_shapes, \
             ([t.shape for t in hr], [t.shape for t in lr])
+    if prefetch is not None and not prefetch.pending:      # (--warmup 0: the first batch's features, like a warm-up step leaves them; K pairs in K timed steps)
+        prefetch.submit(guide_pair)
     sync()
     if rank == 0:
         lib.afi_profile_enable(1)
