@@ -514,16 +514,18 @@ def main():
     # pair and ONE training step (the pair it launches is consumed by the next step; the first one is launched by the warm-up).
     prefetch = amd.GuidePrefetcher(dev) if (guide is not None and not args.no_guide_prefetch and not args.one_stream) else None
 
-    def one_step():
+    def one_step(last=False, solo=False):
+        """solo: nothing runs beside the step (the `kernel_alone` leg): a pending prefetched pair is used up, none is launched."""
         if guide is None:
             hr, lr = syn_hr, syn_lr
-        elif prefetch is None:
+        elif prefetch is None or (solo and not prefetch.pending):
             hr, lr = guide_pair()
         else:
             if not prefetch.pending:
                 prefetch.submit(guide_pair)                        # (first call only)
             hr, lr = prefetch.take()
-            prefetch.submit(guide_pair)                            # the next batch's features, beside this step
+            if not (last or solo):
+                prefetch.submit(guide_pair)                        # the next batch's features, beside this step
         step.run_step(lr, hr)
         return hr, lr
 
@@ -547,14 +549,15 @@ def main():
     if args.warmup:
         assert [tuple(t.shape[2:]) for t in hr] == hr_shapes and [tuple(t.shape[2:]) for t in lr] == lr_shapes, \
             ([t.shape for t in hr], [t.shape for t in lr])
-    if prefetch is not None and not prefetch.pending:      # (--warmup 0: the first batch's features, like a warm-up step leaves them; K pairs in K timed steps)
-        prefetch.submit(guide_pair)
     sync()
     if rank == 0:
         lib.afi_profile_enable(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
+    # K guide pairs inside the K timed steps either way: after a warm-up the first step consumes the pair the warm-up launched and every
+    # step, the last included, launches one; with --warmup 0 (the profiled runs: rocprofv3 then sees exactly the timed launches) the first
+    # step launches its own pair first and the last one launches none
+    for i in range(args.steps):
+        one_step(last=(args.warmup == 0 and i == args.steps - 1))
     sync()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
@@ -601,11 +604,12 @@ def main():
     # shares the chip with the other stream's kernels.  The same kernel with the chip to itself: two extra steps with the overlaps off.
     kernel_alone = None
     if world == 1 and step.overlap_d and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":     # (the profiled runs of tools/prof_r02.sh switch the extra legs off)
-        step.overlap_d = False
-        one_step(); torch.cuda.synchronize()
+        og = step.overlap_g
+        step.overlap_d = step.overlap_g = False
+        one_step(solo=True); torch.cuda.synchronize()
         lib.afi_profile_enable(1)
         for _ in range(2):
-            one_step()
+            one_step(solo=True)
         torch.cuda.synchronize()
         lib.afi_profile_enable(0)
         for k in range(lib.afi_profile_num_kinds()):
@@ -614,7 +618,7 @@ def main():
                 _lib.check(lib.afi_profile_get(k, o3), "afi_profile_get")
                 if o3[0] > 0:
                     kernel_alone = {"launches": int(o3[0]), "avg_launch_us": o3[1] / o3[0] * 1e3, "achieved": o3[2] / (o3[1] * 1e-3) / 1e12}
-        step.overlap_d = True
+        step.overlap_d, step.overlap_g = True, og
     # the opt-in bf16 arithmetic on the same engine, same inputs (N = 1 only; never the headline value): 1 warm-up + the same K steps each
     other_dtypes = None
     if world == 1 and args.dtype is None and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":
@@ -662,7 +666,7 @@ def main():
                 # `achieved` above is over the timed region, where the D phase runs on two streams: a launch's duration includes the time it
                 # shares the chip with the other stream's kernels (sum of durations > wall time).  The kernel with the chip to itself:
                 "kernel_alone": (dict(kernel_alone, frac=kernel_alone["achieved"] / dom_peak,
-                                      note="two extra steps with the engine's overlap_d / overlap_g off (one stream), same HIP-event brackets; profiles/r03 holds both traces")
+                                      note="two extra steps with the engine's overlap_d / overlap_g and the guide prefetch off (one stream), same HIP-event brackets; profiles/r03 holds both traces")
                                  if kernel_alone else None),
                 # fp32-equivalent rate of the dominant kernel against the fp32 MFMA roof it replaces (> 1 is the point of the emulated forms)
                 "achieved_over_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
