@@ -155,7 +155,8 @@ class Stage1Step:
                  weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (270000,), lr_gamma: float = 0.1,
                  warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2,
                  reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: Optional[str] = None,
-                 overlap_d: bool = True, overlap_g: bool = True, weight_cache: bool = True, wgrad_accum: bool = True):
+                 overlap_d: bool = True, overlap_g: bool = True, weight_cache: bool = True, wgrad_accum: bool = True,
+                 g_bwd_small_first: bool = True):
         self.G, self.D = G, D
         self.gnet, self.dnet = G, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
@@ -166,6 +167,7 @@ class Stage1Step:
         # beside the two D forwards per level (the adversarial term carries no gradient): -2.7 % and -2 % of a step now that the big GEMMs
         # are power-bound and leave room beside the bandwidth-bound passes (129.5 -> 126.4 -> 123.9 ms); `overlap_d` / `overlap_g` (attributes too)
         self.overlap_d, self.overlap_g = overlap_d, overlap_g
+        self.g_bwd_small_first = g_bwd_small_first          # G-phase backward passes on the second stream: smallest level first (see _run_phases)
         # per-phase cache of transformed weights / transform-domain sum of the weight gradients of a phase (pure re-orderings; off = per call)
         self.weight_cache, self.wgrad_accum = weight_cache, wgrad_accum
         self._bstream = None
@@ -375,6 +377,34 @@ class Stage1Step:
 
         # ---------------- G phase (:384-433)
         self.g_opt.zero_grad()                                                       # :426
+
+        def g_backward(i, tr, ws):                                                   # :410 (L1 term) and :427; under the backward context
+            N, Cc, Ha, Wa = tr.shape
+            tr_c, _ = self._crop_pair(tr, hrs[i])
+            da = self._scratch("g_dout", tr.numel(), dev)
+            call("afi_l1_fwd_bwd", ops.view_of(tr), ops.view_of(hrs[i]), N, tr_c.shape[2], tr_c.shape[3], Cc, Ha, Wa, 1.0,
+                 C.c_void_p(lptr + 4 * (3 * i + 2)), 1.0, C.c_void_p(da.data_ptr()), ops.stream_ptr())
+            lrt = lrs[i]
+            n = self._lib.afi_generator_bwd_ws_floats(self.G.in_channels, self.G.growth_rate, self.G.n_residual_dense_blocks,
+                                                      lrt.shape[0], lrt.shape[2], lrt.shape[3])
+            sc = self._scratch("g_bwd", n, dev)
+            call("afi_generator_bwd", C.byref(self._gprm), C.byref(self._ggrad), ops.view_of(lrt), lrt.shape[0], lrt.shape[2], lrt.shape[3],
+                 C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n, ops.stream_ptr())
+
+        # The adversarial term carries no gradient (Q1): G's backward needs only the L1 term, i.e. nothing the D forwards of this phase
+        # produce -- only the forwards kept from the top of the step.  With the second stream all five backward passes are queued on it
+        # first, SMALLEST LEVEL FIRST, and run beside the D forwards, which go largest level first (their order is fixed by the BatchNorm
+        # running statistics): latency-bound small-map chains beside chip-filling GEMMs at both ends of the phase, instead of big beside
+        # big at its head and small beside small (an idle chip) at its tail.  (The losses land in their own slots; the weight gradients
+        # are summed in another order: fp32 rounding only.)
+        side = self.overlap_d and self.reuse_g and self.overlap_g
+        if side:
+            if self._bstream is None:
+                self._bstream = torch.cuda.Stream(device=dev)
+            self._bstream.wait_stream(torch.cuda.current_stream())                   # behind the D phase and G's zero_grad
+            with torch.cuda.stream(self._bstream), _lib.use_ctx(self.bctx):
+                for i in (reversed(range(nlev)) if self.g_bwd_small_first else range(nlev)):
+                    g_backward(i, *trs[i])
         for i in range(nlev):
             if self.reuse_g:
                 tr, ws = trs[i]                                                      # Q5: identical to recomputing G(lr)
@@ -386,26 +416,9 @@ class Stage1Step:
                 if key == "adv":                                                     # :408, no gradient (Q1)
                     call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], 1.0, 1.0,
                          C.c_void_p(lptr + 4 * (3 * i + 1)), 0.0, C.c_void_p(None), ops.stream_ptr())
-            # the adversarial term carries no gradient (Q1): G's backward needs only the L1 term, i.e. nothing the two D forwards above
-            # produce -- with the second stream it runs beside them (in level order; the losses land in their own slots)
-            side = self.overlap_d and self.reuse_g and self.overlap_g
-            if side:
-                if self._bstream is None:
-                    self._bstream = torch.cuda.Stream(device=dev)
-                if i == 0:
-                    self._bstream.wait_stream(torch.cuda.current_stream())           # behind the D phase and G's zero_grad
-            with (torch.cuda.stream(self._bstream) if side else contextlib.nullcontext()), _lib.use_ctx(self.bctx):
-                N, Cc, Ha, Wa = tr.shape
-                da = self._scratch("g_dout", tr.numel(), dev)
-                call("afi_l1_fwd_bwd", ops.view_of(tr), ops.view_of(hrs[i]), N, tr_c.shape[2], tr_c.shape[3], Cc, Ha, Wa, 1.0,
-                     C.c_void_p(lptr + 4 * (3 * i + 2)), 1.0, C.c_void_p(da.data_ptr()), ops.stream_ptr())      # :410
-                lrt = lrs[i]
-                n = self._lib.afi_generator_bwd_ws_floats(self.G.in_channels, self.G.growth_rate, self.G.n_residual_dense_blocks,
-                                                          lrt.shape[0], lrt.shape[2], lrt.shape[3])
-                sc = self._scratch("g_bwd", n, dev)
-                call("afi_generator_bwd", C.byref(self._gprm), C.byref(self._ggrad), ops.view_of(lrt), lrt.shape[0], lrt.shape[2], lrt.shape[3],
-                     C.c_void_p(ws.data_ptr()), C.c_void_p(da.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n,
-                     ops.stream_ptr())                                               # :427
+            if not side:
+                with _lib.use_ctx(self.bctx):
+                    g_backward(i, tr, ws)
         if self.overlap_d and self.reuse_g:
             self._join_bstream()
         call("afi_ctx_wino_wgrad_flush", self.bctx.handle, ops.stream_ptr())

@@ -492,7 +492,8 @@ def main():
     G = amd.Generator(n_residual_dense_blocks=3).to(dev)
     D = amd.Discriminator().to(dev)
     G.train(); D.train()
-    step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype, overlap_d=not args.one_stream, overlap_g=not args.one_stream)
+    step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype, overlap_d=not args.one_stream, overlap_g=not args.one_stream,
+                          g_bwd_small_first=os.environ.get("AFI_BENCH_G_BWD_ORDER", "small-first") != "level-order")   # (A/B of the G-phase schedule)
     run_dtype = step.dtype                             # the library's default when --dtype is not given
     guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)     # each rank owns a different shard of the global batch
