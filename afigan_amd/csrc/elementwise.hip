@@ -118,6 +118,38 @@ int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout,
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
+// Dense-block growth convs, weight gradients of a block in ONE GEMM (nets.hip: afi_generator_bwd): the four gradients dy_1..dy_4 are the
+// adjacent G-channel slices [C, C + 4G) of the block's gradient buffer and every conv reads a prefix of the block's activation buffer, so
+// dWp[4G][3][3][L] = dy[C : C + 4G] (x) cat[0 : L] holds all four -- rows (k-1)G .. kG, columns c < C + (k-1)G are conv k's gradient; the rest
+// (a conv paired with channels that come after it) is never read.  This kernel adds the valid part into the four parameter gradients.
+__global__ __launch_bounds__(256) void afi_rdb_wgrad_unpack_kernel(const float* __restrict__ dWp, float* dw1, float* dw2, float* dw3, float* dw4, int C, int G, float alpha) {
+    const int L = C + 4 * G;
+    const long long total = 4LL * G * 9 * (L >> 2);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % (L >> 2)) * 4;
+        const long long rt = e / (L >> 2);                   // row * 9 + tap
+        const int row = (int)(rt / 9), tap = (int)(rt - 9LL * row);
+        const int k = row / G, o = row - k * G;              // conv k + 1
+        const int cin = C + k * G;
+        if (c4 >= cin) continue;
+        float* dw = k == 0 ? dw1 : (k == 1 ? dw2 : (k == 2 ? dw3 : dw4));
+        if (!dw) continue;
+        const f32x4 v = *(const f32x4*)(dWp + rt * L + c4);
+        f32x4* dst = (f32x4*)(dw + ((long long)o * 9 + tap) * cin + c4);
+        f32x4 d = *dst;
+        d += alpha * v;
+        *dst = d;
+    }
+}
+int afi_launch_rdb_wgrad_unpack(const float* dWp, float* const dw[4], int C, int G, float alpha, hipStream_t st) {
+    if (!dWp || C <= 0 || G <= 0 || (C & 3) || (G & 3)) return AFI_ERR_BAD_ARG;
+    const long long total = 4LL * G * 9 * ((C + 4 * G) >> 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(afi_rdb_wgrad_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dWp, dw[0], dw[1], dw[2], dw[3], C, G, alpha);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // The BatchNorm affine z = ((x - mean) * invstd) * gamma + beta with every operation rounded on its own (no FMA contraction): the forward's
 // activation and the backward's recomputed LeakyReLU' mask must take the SAME side of zero for every element, so both evaluate this one
 // function on the same fp32 operands (and a host restatement in plain fp32 tensor ops reproduces it bit for bit: tests/d_parity_util.py).
