@@ -67,7 +67,8 @@ struct AfiPixGemm {
     // BatchNorm batch statistics of the STORED output, accumulated by the Winograd output transform itself (a separate pass over the
     // map otherwise): fp64 partial sums [stats_rows][2][Ncols] (sum, sum of squares per channel), one row per block of that launch; the
     // launcher fills stats_rows.  Taken only by the plain-store epilogue on 256 / 512 / 1024-channel outputs; null = off.
-    double* stats; int stats_rows; int pad1_;
+    double* stats; int stats_rows;
+    int no_wcache;                             // Winograd form: B is a per-call scratch (its pointer says nothing about its contents): never cache its transform
 };
 
 // Parameters of the weight-gradient GEMM:  dW[co'][tap][ci] += alpha * sum_pix dY[pix][co'] * X[pix+tap][ci]

@@ -150,6 +150,29 @@ int afi_launch_rdb_wgrad_unpack(const float* dWp, float* const dw[4], int C, int
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
+// ... and the data-gradient side of the same idea: the growth convs' weights on the block input x, Wx[(k-1)G + o][tap][c] = w_k[o][tap][c], c < C
+__global__ __launch_bounds__(256) void afi_rdb_xpart_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, const float* __restrict__ w3,
+                                                                 const float* __restrict__ w4, float* __restrict__ out, int C, int G) {
+    const long long total = 4LL * G * 9 * (C >> 2);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % (C >> 2)) * 4;
+        const long long rt = e / (C >> 2);
+        const int row = (int)(rt / 9), tap = (int)(rt - 9LL * row);
+        const int k = row / G, o = row - k * G;
+        const int cin = C + k * G;
+        const float* w = k == 0 ? w1 : (k == 1 ? w2 : (k == 2 ? w3 : w4));
+        *(f32x4*)(out + rt * C + c4) = *(const f32x4*)(w + ((long long)o * 9 + tap) * cin + c4);
+    }
+}
+int afi_launch_rdb_xpart_pack(const float* const w[4], float* out, int C, int G, hipStream_t st) {
+    if (!out || !w[0] || !w[1] || !w[2] || !w[3] || C <= 0 || G <= 0 || (C & 3) || (G & 3)) return AFI_ERR_BAD_ARG;
+    const long long total = 4LL * G * 9 * (C >> 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(afi_rdb_xpart_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, w[0], w[1], w[2], w[3], out, C, G);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // The BatchNorm affine z = ((x - mean) * invstd) * gamma + beta with every operation rounded on its own (no FMA contraction): the forward's
 // activation and the backward's recomputed LeakyReLU' mask must take the SAME side of zero for every element, so both evaluate this one
 // function on the same fp32 operands (and a host restatement in plain fp32 tensor ops reproduces it bit for bit: tests/d_parity_util.py).

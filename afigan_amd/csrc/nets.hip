@@ -26,6 +26,7 @@ int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hi
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
 int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st);
 int afi_launch_rdb_wgrad_unpack(const float* dWp, float* const dw[4], int C, int G, float alpha, hipStream_t st);
+int afi_launch_rdb_xpart_pack(const float* const w[4], float* out, int C, int G, hipStream_t st);
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
                         float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked = nullptr, float eps = -1.f,
                         float momentum = -1.f, bool fp64 = true);
@@ -111,7 +112,8 @@ struct WinoWgradAccum {
 // changes numerics or scheduling is made by the caller, per context, and can be changed between calls.  Context-less calls use the defaults.
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ 0, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
-                                            /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000}};
+                                            /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
+                                            /*G_BATCH_GROWTH_GRADS*/ 1}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -280,7 +282,8 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     // bf16 parts in LDS-image order, made once per weight transform and cached in that form
     const bool dma = dtype != AFI_DTYPE_F32 && !(Tpad % 128) && !(Nc % 128) && !(K % 32);
     bool have_u = false;
-    if (dma) {
+    if (g.no_wcache) {
+    } else if (dma) {
         if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc | (dtype << 4), b_rc ? K : Nc, b_rc ? Nc : K, wino_usplit_floats(np, (long long)K * Nc), have_u)) Usp = slot;
     } else if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc, b_rc ? K : Nc, b_rc ? Nc : K, align4((long long)np * K * Nc), have_u)) U = slot;
     if (!have_u) {
@@ -854,7 +857,7 @@ long long afi_generator_fwd_ws_floats(int C, int G, int n_rdb, int N, int H, int
 
 // backward scratch layout: [dU 4P*C][gA P*C][gB P*C][dBuf0 P*L][dBuf1 P*L][dWp 36*C*C][red]
 struct GenBwdWs {
-    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_rdbw, n_rdbw, o_red, o_part, n_part, o_wino, n_wino, o_wino2, total;
+    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_rdbw, n_rdbw, o_rdbx, n_rdbx, o_red, o_part, n_part, o_wino, n_wino, o_wino2, total;
 };
 static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenBwdWs w;
@@ -868,6 +871,8 @@ static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_dwp = o; o += align4(36LL * C * C);
     w.n_rdbw = align4(4LL * G * 9 * L);                   // packed weight gradient of a dense block's four growth convs (one per block:
     w.o_rdbw = o; o += (long long)n_rdb * w.n_rdbw;       //  the side stream may still be unpacking block r while block r - 1 is filled)
+    w.n_rdbx = align4(4LL * G * 9 * C);                   // the growth convs' weights on the block input, packed [4G][3][3][C] (when no cache holds them)
+    w.o_rdbx = o; o += (long long)n_rdb * w.n_rdbx;
     w.o_red = o; o += align4(afi_reduce_scratch_floats(C));
     w.n_part = part_floats({P * C, P * L, 4 * P * C});
     w.o_part = o; o += w.n_part;
@@ -1025,7 +1030,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // 7 .. 36-tile launch per layer on a side stream.  All their operands (dOut, dU, gA, gB, the per-block gradient buffers and the
     // saved activations) stay alive until the call returns.  AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS = 0 restores the per-layer launches.
     const bool grouped = l.P <= afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS);
-    const bool batch_growth = !grouped;                    // larger maps: a block's four growth-conv weight gradients as one packed GEMM (below)
+    const bool batch_growth = !grouped && afi_opt(cx, AFI_OPT_G_BATCH_GROWTH_GRADS) != 0;   // larger maps: a block's four growth-conv weight gradients as one packed GEMM (below)
     AfiWgradGemm wg_wide[12], wg_narrow[4 * AFI_MAX_RDB];
     AfiColsumProb cs[8];
     int n_wide = 0, n_narrow = 0, n_cs = 0;
@@ -1135,10 +1140,39 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
                 const AfiWgradGemm wd = conv_wgrad_desc(dyk, b, N, H, W, G, cin, gr->rdb_w[r][k - 1], 1.f);
                 AFI_TRY(grouped ? defer(wd) : afi_launch_wgrad_gemm(wd, sd));
             }
+            if (batch_growth) {
+                // larger maps: only the part of conv_k's data gradient that lands on y_1 .. y_{k-1} (channels [C, cin): (k-1) G columns) runs
+                // here, in chain order -- each finalises the slice the next one reads; the parts that land on the block input x (channels
+                // [0, C)) of all four convs are ONE data gradient from the 4G adjacent channels dy_1 .. dy_4 after the chain (below)
+                if (k == 1) continue;
+                AfiPixGemm g = conv_dgrad_desc(dyk, N, H, W, G, prm->rdb_w[r][k - 1] + C, cin - C, ch_off(d, C));
+                g.b_sRow = 9LL * cin; g.b_sTap = cin;                   // (a column range of the [G][3][3][cin] weight)
+                g.beta = 1.f;
+                g.Z = ch_off(b, C); g.z_lo = cin - C - G; g.z_hi = cin - C;      // conv_{k-1}'s slice becomes final
+                AFI_TRY(PG(g, 1));
+                continue;
+            }
             AfiPixGemm g = conv_dgrad_desc(dyk, N, H, W, G, prm->rdb_w[r][k - 1], cin, d);
             g.beta = 1.f;                                               // dense connections: accumulate
             if (k >= 2) { g.Z = b; g.z_lo = cin - G; g.z_hi = cin; }    // conv_{k-1}'s slice becomes final
             if (k == 1 && r == 0) {                                     // RRDB skip (+dT) and the head conv's LReLU
+                g.R2 = gB; g.r2s = 1.f; g.r2_lo = 0; g.r2_hi = C;
+                g.Z = b; g.z_lo = 0; g.z_hi = C;
+            }
+            AFI_TRY(PG(g, 1));
+        }
+        if (batch_growth) {
+            // d[0:C) += sum_k W_k[:, :, :, 0:C]^T (*) dy_k: a 4G -> C data gradient on the packed weights [4G][3][3][C] -- Winograd-eligible at the
+            // reference's widths (128 -> 256 channels) where the four per-conv ones (32 -> 256 .. 352) were direct GEMMs 288 deep
+            const float* const wk[4] = {prm->rdb_w[r][0], prm->rdb_w[r][1], prm->rdb_w[r][2], prm->rdb_w[r][3]};
+            float* Wx = scratch + s.o_rdbx + (long long)r * s.n_rdbx;
+            bool hit = false, scratch_b = true;
+            if (float* slot = wino_wcache_slot(cx, prm->rdb_w[r][0], /*tag: growth x-part pack*/ 3, 0, 4 * G, C, s.n_rdbx, hit)) { Wx = slot; scratch_b = false; }
+            if (!hit) AFI_TRY(afi_launch_rdb_xpart_pack(wk, Wx, C, G, st));
+            AfiPixGemm g = conv_dgrad_desc(ch_off(d, C), N, H, W, 4 * G, Wx, C, d);
+            g.beta = 1.f;
+            g.no_wcache = scratch_b ? 1 : 0;
+            if (r == 0) {                                               // RRDB skip (+dT) and the head conv's LReLU
                 g.R2 = gB; g.r2s = 1.f; g.r2_lo = 0; g.r2_hi = C;
                 g.Z = b; g.z_lo = 0; g.z_hi = C;
             }

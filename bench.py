@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--no-guide-prefetch", action="store_true", help="run the frozen guide network's two forwards at the head of every step on the step's own "
                     "stream (default: the NEXT batch's guide forwards are issued on a second stream while the current batch trains -- "
                     "afigan_amd.GuidePrefetcher; one guide pair and one training step per timed step either way)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="afi_ctx_set_option on the engine's contexts (A/B runs), "
+                    "e.g. --option g_batch_growth_grads=0; names: afigan_amd._lib.OPTIONS")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launch path only (no GPU work, no metric): spawn / rendezvous / all-reduce / invariant checks of the N-rank job with "
                          "CPU tensors; what tests/test_host_logic.py runs with --gpus 2 --backend gloo in a container without a GPU")
@@ -494,6 +496,9 @@ def main():
     G.train(); D.train()
     step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype, overlap_d=not args.one_stream, overlap_g=not args.one_stream,
                           g_bwd_small_first=os.environ.get("AFI_BENCH_G_BWD_ORDER", "small-first") != "level-order")   # (A/B of the G-phase schedule)
+    for kv in args.option:
+        name, _, val = kv.partition("=")
+        step.ctx.set_option(name, int(val)); step.bctx.set_option(name, int(val))
     run_dtype = step.dtype                             # the library's default when --dtype is not given
     guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)     # each rank owns a different shard of the global batch
@@ -698,7 +703,7 @@ def main():
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
                                f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",
                    "global_batch": world * B, "parallelism": f"dp{world}", "guide": "r50fpn (GEMM 1x1 via hipBLASLt + own 3x3 MFMA conv)" if guide is not None else "synthetic-pyramid",
-                   "guide_prefetch": prefetch is not None,
+                   "guide_prefetch": prefetch is not None, "options": args.option or None,
                    "reuse_generator_forward": True},
         "algorithmic_tflop_per_image": flop_img / 1e12,
         "step_tflops_per_gpu": flop_img * B * args.steps / elapsed / 1e12,

@@ -129,11 +129,12 @@ def test_option_defaults_without_a_context():
     from afigan_amd import _lib
     lib = _lib.load()
     want = {"winograd": 1, "winograd_f4_backward": 1, "winograd_f4_forward": 0, "bn_stats_fp64": 1, "d_winograd_min_pixels": 1024,
-            "g_winograd_min_pixels": 2048, "g_smallmap_max_pixels": 2048, "g_grouped_wgrad_max_pixels": 3000}
+            "g_winograd_min_pixels": 2048, "g_smallmap_max_pixels": 2048, "g_grouped_wgrad_max_pixels": 3000,
+            "g_batch_growth_grads": 1}
     assert set(want) == set(_lib.OPTIONS)
     for k, v in want.items():
         assert lib.afi_ctx_get_option(None, _lib.OPTIONS[k]) == v, k
-    assert lib.afi_ctx_get_option(None, 8) == -1 and lib.afi_ctx_set_option(None, 0, 1) == 1
+    assert lib.afi_ctx_get_option(None, len(want)) == -1 and lib.afi_ctx_set_option(None, 0, 1) == 1
     import shutil
     import subprocess
     nm = shutil.which("nm")
