@@ -173,6 +173,31 @@ int afi_launch_rdb_xpart_pack(const float* const w[4], float* out, int C, int G,
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
+// in-place LeakyReLU on nch channels of a pixel-major view (the slice of growth conv 1 after the batched forward step: nets.hip)
+__global__ __launch_bounds__(256) void afi_lrelu_slice_kernel(AfiView v, int N, int H, int W, int nch) {
+    const int c4n = nch >> 2;
+    const long long total = (long long)N * H * W * c4n;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % c4n) * 4;
+        long long pix = e / c4n;
+        const int x = (int)(pix % W); pix /= W;
+        const int y = (int)(pix % H); const int n = (int)(pix / H);
+        f32x4* p = (f32x4*)(v.p + (long long)n * v.sN + (long long)y * v.sH + (long long)x * v.sW + c4);
+        f32x4 t = *p;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = t[j] > 0.f ? t[j] : t[j] * AFI_LRELU_SLOPE;
+        *p = t;
+    }
+}
+int afi_launch_lrelu_slice(AfiView v, int N, int H, int W, int nch, hipStream_t st) {
+    if (!v.p || N <= 0 || H <= 0 || W <= 0 || nch <= 0 || (nch & 3)) return AFI_ERR_BAD_ARG;
+    const long long total = (long long)N * H * W * (nch >> 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(afi_lrelu_slice_kernel, dim3((unsigned)blocks), dim3(256), 0, st, v, N, H, W, nch);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // The BatchNorm affine z = ((x - mean) * invstd) * gamma + beta with every operation rounded on its own (no FMA contraction): the forward's
 // activation and the backward's recomputed LeakyReLU' mask must take the SAME side of zero for every element, so both evaluate this one
 // function on the same fp32 operands (and a host restatement in plain fp32 tensor ops reproduces it bit for bit: tests/d_parity_util.py).

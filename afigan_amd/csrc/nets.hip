@@ -27,6 +27,7 @@ int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStrea
 int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st);
 int afi_launch_rdb_wgrad_unpack(const float* dWp, float* const dw[4], int C, int G, float alpha, hipStream_t st);
 int afi_launch_rdb_xpart_pack(const float* const w[4], float* out, int C, int G, hipStream_t st);
+int afi_launch_lrelu_slice(AfiView v, int N, int H, int W, int nch, hipStream_t st);
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
                         float* running_var, float* scratch, hipStream_t st, long long* num_batches_tracked = nullptr, float eps = -1.f,
                         float momentum = -1.f, bool fp64 = true);
@@ -835,7 +836,7 @@ static long long gen_wino_floats(int C, int L, int N, int H, int W) {
 }
 struct GenWs {
     long long P, L;
-    long long o_wp, o_buf, o_t, o_a7, o_u, o_part, n_part, o_wino, n_wino, total;
+    long long o_wp, o_buf, o_t, o_a7, o_u, o_part, n_part, o_wino, n_wino, o_rdbx, n_rdbx, total;
 };
 static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenWs w;
@@ -850,6 +851,8 @@ static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_part = o; o += w.n_part;
     w.n_wino = gen_wino_floats(C, (int)w.L, N, H, W);
     w.o_wino = o; o += w.n_wino;
+    w.n_rdbx = align4(4LL * G * 9 * C);                   // the growth convs' weights on the block input, packed [4G][3][3][C] (when no cache holds them)
+    w.o_rdbx = o; o += (long long)n_rdb * w.n_rdbx;
     w.total = o;
     return w;
 }
@@ -937,6 +940,9 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     // it.  Same multiply-adds as generator_rdb.py:64-71, summed in another order (fp32 rounding only).  AFI_OPT_G_SMALLMAP_MAX_PIXELS = 0:
     // conv by conv at every size.
     const bool batched = l.P < afi_opt(cx, AFI_OPT_G_SMALLMAP_MAX_PIXELS);
+    // (4G <= C: the Winograd scratch is sized for C -> C; every shape of the reference has G = 32, C = 256)
+    const bool xbatch = !batched && l.P > afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS) && afi_opt(cx, AFI_OPT_G_BATCH_GROWTH_GRADS) != 0 &&
+                        (4 * G <= C || l.n_wino == 0);
     for (int r = 0; r < R; ++r) {   // ResidualDenseBlock.forward (generator_rdb.py:64-71); the dense buffer replaces torch.cat
         AfiView b = buf(r);
         const bool last = (r == R - 1);
@@ -973,6 +979,28 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
             }
             continue;
         }
+        if (xbatch) {
+            // larger maps: what the four growth convs take from the block input x is ONE conv C -> 4G on the packed weights [4G][3][3][C]
+            // (Winograd-eligible at the reference's widths; the per-conv form runs four 32-column direct GEMMs 2304+ deep), stored as raw
+            // partial sums in their four slices; conv_k then adds what it takes from y_1 .. y_{k-1} ((k-1) G channels) and activates.
+            // Same multiply-adds as generator_rdb.py:64-71, summed in another order.
+            const float* const wk[4] = {prm->rdb_w[r][0], prm->rdb_w[r][1], prm->rdb_w[r][2], prm->rdb_w[r][3]};
+            float* Wx = ws + l.o_rdbx + (long long)r * l.n_rdbx;
+            bool hit = false, scratch_b = true;
+            if (float* slot = wino_wcache_slot(cx, prm->rdb_w[r][0], /*tag: growth x-part pack*/ 3, 0, 4 * G, C, l.n_rdbx, hit)) { Wx = slot; scratch_b = false; }
+            if (!hit) AFI_TRY(afi_launch_rdb_xpart_pack(wk, Wx, C, G, st));
+            AfiPixGemm ga = conv_fwd_desc(b, N, H, W, C, Wx, nullptr, 4 * G, ch_off(b, C));
+            ga.no_wcache = scratch_b ? 1 : 0;
+            AFI_TRY(PG(ga, 0));
+            AFI_TRY(afi_launch_lrelu_slice(ch_off(b, C), N, H, W, G, st));          // conv_1 takes nothing else: its slice is complete
+            for (int k = 2; k <= 4; ++k) {
+                const int cin = C + (k - 1) * G;
+                AfiPixGemm g = conv_fwd_desc(ch_off(b, C), N, H, W, cin - C, prm->rdb_w[r][k - 1] + C, nullptr, G, ch_off(b, cin));
+                g.b_sRow = 9LL * cin; g.b_sTap = cin;                   // (a column range of the [G][3][3][cin] weight)
+                g.beta = 1.f; g.lrelu = 1;
+                AFI_TRY(PG(g, 0));
+            }
+        } else
         for (int k = 1; k <= 4; ++k) {
             const int cin = C + (k - 1) * G;
             AfiPixGemm g = conv_fwd_desc(b, N, H, W, cin, prm->rdb_w[r][k - 1], nullptr, G, ch_off(b, cin));
@@ -1030,7 +1058,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // 7 .. 36-tile launch per layer on a side stream.  All their operands (dOut, dU, gA, gB, the per-block gradient buffers and the
     // saved activations) stay alive until the call returns.  AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS = 0 restores the per-layer launches.
     const bool grouped = l.P <= afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS);
-    const bool batch_growth = !grouped && afi_opt(cx, AFI_OPT_G_BATCH_GROWTH_GRADS) != 0;   // larger maps: a block's four growth-conv weight gradients as one packed GEMM (below)
+    const bool batch_growth = !grouped && afi_opt(cx, AFI_OPT_G_BATCH_GROWTH_GRADS) != 0 && (4 * G <= C || s.n_wino == 0);   // larger maps: a block's four growth-conv weight gradients as one packed GEMM (below)
     AfiWgradGemm wg_wide[12], wg_narrow[4 * AFI_MAX_RDB];
     AfiColsumProb cs[8];
     int n_wide = 0, n_narrow = 0, n_cs = 0;

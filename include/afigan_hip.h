@@ -110,9 +110,10 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
 #define AFI_OPT_G_WINOGRAD_MIN_PIXELS 5       /* 2048: the same for a convolution of the interpolator */
 #define AFI_OPT_G_SMALLMAP_MAX_PIXELS 6       /* 2048: below, the dense blocks run in column-batched form (5 grouped launches per block); 0: never */
 #define AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS 7  /* 3000: up to here all weight / bias gradients of a backward pass run as three grouped launches; 0: per layer */
-#define AFI_OPT_G_BATCH_GROWTH_GRADS 8         /* 1 (default): above G_GROUPED_WGRAD_MAX_PIXELS the four growth convs of a dense block share ONE weight-gradient GEMM
-                                               * (4G rows, packed, then unpacked) and ONE data gradient onto the block input (packed [4G][3][3][C] weights) --
-                                               * Winograd-eligible at the reference's widths; 0: four G-row / G-deep GEMMs per block, as generator_rdb.py:64-71 reads */
+#define AFI_OPT_G_BATCH_GROWTH_GRADS 8         /* 1 (default): above G_GROUPED_WGRAD_MAX_PIXELS the four growth convs of a dense block are batched where they share
+                                               * an operand: what they take from the block input is ONE conv C -> 4G on packed weights [4G][3][3][C] (forward) and ONE
+                                               * data gradient 4G -> C (backward), their weight gradients ONE 4G-row GEMM (packed, then unpacked) -- all Winograd-
+                                               * eligible at the reference's widths; 0: four G-column / G-row GEMMs per block, as generator_rdb.py:64-71 reads */
 #define AFI_OPT_COUNT 9
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);

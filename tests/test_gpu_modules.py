@@ -415,9 +415,9 @@ def test_results_do_not_depend_on_uninitialised_memory(amd, monkeypatch):
 
 @pytest.mark.parametrize("C,g,hw", [(128, 32, (72, 64)), (32, 8, (80, 64)), (64, 32, (60, 56))])
 def test_generator_batched_growth_gradients_match_the_per_conv_form(amd, C, g, hw):
-    """AFI_OPT_G_BATCH_GROWTH_GRADS (larger maps: a dense block's four growth-conv weight gradients as one packed GEMM, their data gradients
-    onto the block input as one packed data gradient; Winograd form at 128 channels) against the per-conv form of generator_rdb.py:64-71,
-    and both against the oracle."""
+    """AFI_OPT_G_BATCH_GROWTH_GRADS (larger maps: what a dense block's four growth convs take from the block input as one packed conv, their data
+    gradients onto it as one packed data gradient, their weight gradients as one packed GEMM; Winograd form at 128 channels) against the
+    per-conv form of generator_rdb.py:64-71, and both against the oracle: outputs, input gradient, every parameter gradient."""
     from afigan_amd import _lib
     gp = orc.closed_form_generator_params(C, 2, g)
     x = torch.randn((1, C, *hw), generator=torch.Generator().manual_seed(21))
@@ -431,15 +431,16 @@ def test_generator_batched_growth_gradients_match_the_per_conv_form(amd, C, g, h
         with _lib.use_ctx(cx):
             out = G(xg)
             (out * torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)).sum().backward()
-        res[flag] = (xg.grad.clone(), {k: _logical(p.grad).clone() for k, p in G.named_parameters()})
+        res[flag] = (xg.grad.clone(), {k: _logical(p.grad).clone() for k, p in G.named_parameters()}, out.detach().clone())
     pr = {k: v.clone().requires_grad_(True) for k, v in gp.items()}
     xr = x.clone().requires_grad_(True)
     ref = orc.generator_forward(xr, pr, n_rdb=2)
     (ref * torch.linspace(-1, 1, ref.numel()).view_as(ref)).sum().backward()
     for flag in (1, 0):
+        assert _rel(res[flag][2], ref) < 1e-3, flag
         assert _rel(res[flag][0], xr.grad) < 1e-3, flag
         for k in pr:
             assert _rel(res[flag][1][k], pr[k].grad) < 1e-3, (flag, k)
-    assert _rel(res[1][0], res[0][0]) < 2e-5
+    assert _rel(res[1][2], res[0][2]) < 2e-5 and _rel(res[1][0], res[0][0]) < 2e-5
     for k in pr:
         assert _rel(res[1][1][k], res[0][1][k]) < 2e-5, k
