@@ -1,3 +1,4 @@
+# A/B of the G-phase backward order on one box: smallest level first (default) against level order
 cd $GRAFT_REPO_ROOT
 export AFI_BENCH_OTHER_DTYPES=0
 P='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith("{")][-1]); print(sys.argv[1], round(d["ms_per_step"],2), round(d["roofline"]["avg_launch_us"],1))'
