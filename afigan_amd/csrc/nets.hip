@@ -1313,7 +1313,8 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
     afi_ctx* cx = ctx; (void)cx;
     AFI_CTX_CHECK(ctx);
     AFI_TRY(disc_check(prm));
-    if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || !logits) return AFI_ERR_BAD_ARG;
+    const bool stats_only = training == 3;                 // BatchNorm side effects only: no last activation, last conv or logits
+    if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || (!logits && !stats_only)) return AFI_ERR_BAD_ARG;
     const DiscWs l = disc_ws(prm->F, N, H, W);
     if (ws_floats < l.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1336,21 +1337,22 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
+        const bool skip_apply = stats_only && n == 2;       // nothing reads the last block's activation
         if (training && stats_rows > 0) {                   // the output transform accumulated the sums while it stored c: only the finalizer is left
             AFI_TRY(afi_launch_bn_stats_from_partials(stats, stats_rows, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], st,
                                                       prm->num_batches_tracked[n]));
-            AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
+            if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
         } else if (training) {
             AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st,
                                         prm->num_batches_tracked[n], -1.f, -1.f, afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0));      // the counter ticks inside the statistics finalizer
-            AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
+            if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
         } else {
             AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
             AFI_TRY(afi_launch_bn_apply_lrelu(c, y, prm->running_mean[n], invstd, prm->gamma[n], prm->beta[n], P, co, st));
         }
         in = dense_view(y, H, W, co);
     }
-    {   // last conv 3x3 F3 -> 1 (:40-41): D9[q][t] = <y2[q], w3[t]> on the MFMA kernel (1x1, 9 columns), then the 9-tap stencil
+    if (!stats_only) {   // last conv 3x3 F3 -> 1 (:40-41): D9[q][t] = <y2[q], w3[t]> on the MFMA kernel (1x1, 9 columns), then the 9-tap stencil
         const int F3 = prm->F[3];
         float* d9 = ws + l.o_d9;
         AfiPixGemm g = pix_default(N, H, W);

@@ -247,16 +247,18 @@ class Stage1Step:
              ops.stream_ptr())
         return out, ws
 
-    def _d_forward(self, x: torch.Tensor, ws_key: str, backward_follows: bool = True):
+    def _d_forward(self, x: torch.Tensor, ws_key: str, backward_follows: bool = True, stats_only: bool = False):
         """training = 1: train-mode forward whose saved activations feed afi_discriminator_bwd; 2: train-mode statistics and
-        logits only (the G phase, stage1_trainer.py:399-403: no gradient ever flows through these two calls, Q1)."""
+        logits only (the G phase, stage1_trainer.py:399-403: no gradient ever flows through these two calls, Q1); 3: the BatchNorm
+        side effects only (the G phase's D(real) call, :401-403: nothing reads its logits -- the running statistics advance exactly as
+        in the reference, the last activation / last conv / logits are not computed)."""
         N, _, H, W = x.shape
         F = (C.c_int * 4)(*self.dnet.F)
         n = self._lib.afi_discriminator_fwd_ws_floats(F, N, H, W)
         ws = self._scratch(ws_key, n, x.device)
         logits = self._scratch(ws_key + "_logits", N * H * W, x.device)
-        call("afi_discriminator_fwd", C.byref(self._dprm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), 1 if backward_follows else 2,
-             C.c_void_p(ws.data_ptr()), n, ops.stream_ptr())
+        call("afi_discriminator_fwd", C.byref(self._dprm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()),
+             1 if backward_follows else (3 if stats_only else 2), C.c_void_p(ws.data_ptr()), n, ops.stream_ptr())
         return logits, ws
 
     def _d_backward(self, x: torch.Tensor, ws: torch.Tensor, dlogits: torch.Tensor):
@@ -412,7 +414,7 @@ class Stage1Step:
                 tr, ws = self._g_forward(i, lrs[i], "g_ws")                          # :389-391
             tr_c, hr_c = self._crop_pair(tr, hrs[i])
             for x, key in ((tr_c, "adv"), (hr_c, None)):                             # :399-403 (fake first, then real)
-                logits, _ = self._d_forward(x, "d_ws", backward_follows=False)
+                logits, _ = self._d_forward(x, "d_ws", backward_follows=False, stats_only=(key != "adv"))
                 if key == "adv":                                                     # :408, no gradient (Q1)
                     call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], 1.0, 1.0,
                          C.c_void_p(lptr + 4 * (3 * i + 1)), 0.0, C.c_void_p(None), ops.stream_ptr())

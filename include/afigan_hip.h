@@ -195,7 +195,10 @@ int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* 
  * num_batches_tracked += 1 (torch BatchNorm2d train mode);  training == 0: running statistics.
  * training == 1: afi_discriminator_bwd may follow on this workspace (the forward convs then keep the Winograd tiling whose
  * rounding does not disturb LeakyReLU mask decisions);  training == 2: train-mode statistics and logits only, no backward
- * will follow (stage-1 G phase, stage-2 generator-side terms): the convs may take the cheaper F(4x4,3x3) tiling, as in eval. */
+ * will follow (stage-1 G phase, stage-2 generator-side terms): the convs may take the cheaper F(4x4,3x3) tiling, as in eval.
+ * training == 3: as 2, but only the BatchNorm side effects are wanted (stage1_trainer.py:401-403: the G phase's D(real) call, whose
+ * logits nothing reads): the running statistics and num_batches_tracked advance exactly as in mode 2; the last block's activation, the
+ * last conv and the logits are not computed and `logits` may be NULL. */
 int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t x, int N, int H, int W, float* logits, int training,
                           float* ws, long long ws_floats, void* stream);
 /* Backward (training-mode forward only).  grads: += targets (w, b, gamma, beta, w3, b3; other fields ignored).

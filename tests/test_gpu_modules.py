@@ -444,3 +444,33 @@ def test_generator_batched_growth_gradients_match_the_per_conv_form(amd, C, g, h
     assert _rel(res[1][2], res[0][2]) < 2e-5 and _rel(res[1][0], res[0][0]) < 2e-5
     for k in pr:
         assert _rel(res[1][1][k], res[0][1][k]) < 2e-5, k
+
+
+@pytest.mark.parametrize("shape", [(2, 26, 42), (1, 13, 21)])
+def test_discriminator_stats_only_forward_has_the_same_side_effects(amd, shape):
+    """afi_discriminator_fwd(training = 3) -- the G phase's D(real) call of stage1_trainer.py:401-403, whose logits nothing reads -- leaves the
+    BatchNorm running statistics and counters bit-identical to the full forward-only call (training = 2) and writes no logits."""
+    import ctypes as C
+    from afigan_amd import _lib, ops
+    N, H, W = shape
+    dp = orc.closed_form_discriminator_params()
+    x = ops.pixel_major(torch.randn((N, 256, H, W), generator=torch.Generator().manual_seed(31)).cuda())
+    states = {}
+    for mode in (2, 3):
+        D = amd.Discriminator().cuda()
+        D.load_state_dict(dp)
+        D.train()
+        net = D.Discriminators[0]
+        prm, keep = net._param_struct(net._ordered_params())
+        F = (C.c_int * 4)(*net.F)
+        n = _lib.load().afi_discriminator_fwd_ws_floats(F, N, H, W)
+        ws = torch.empty(n, device="cuda")
+        logits = torch.full((N, 1, H, W), 7.0, device="cuda")
+        _lib.call("afi_discriminator_fwd", C.byref(prm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), mode, C.c_void_p(ws.data_ptr()), n,
+                  ops.stream_ptr())
+        torch.cuda.synchronize()
+        states[mode] = ({k: v.clone() for k, v in D.state_dict().items() if "running" in k or "num_batches" in k}, logits.clone())
+    assert states[2][0].keys() == states[3][0].keys() and len(states[2][0]) == 9
+    for k in states[2][0]:
+        assert torch.equal(states[2][0][k], states[3][0][k]), k
+    assert not torch.equal(states[2][1], torch.full_like(states[2][1], 7.0)) and torch.equal(states[3][1], torch.full_like(states[3][1], 7.0))
