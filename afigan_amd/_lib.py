@@ -198,8 +198,9 @@ class Ctx:
     def set_dtype(self, dtype):
         if dtype not in DTYPES:
             raise AfiError(f"compute dtype must be one of {sorted(DTYPES)}, got {dtype!r}")
-        check(load().afi_ctx_set_compute_dtype(self.handle, DTYPES[dtype]), "afi_ctx_set_compute_dtype")
-        self.dtype = dtype
+        with _dtype_lock:                                  # the default context is shared by the threads of a device (autograd worker included)
+            check(load().afi_ctx_set_compute_dtype(self.handle, DTYPES[dtype]), "afi_ctx_set_compute_dtype")
+            self.dtype = dtype
 
     def set_option(self, name, value):
         """Algorithm option of this context (OPTIONS / AFI_OPT_* of include/afigan_hip.h); the library reads no environment variable."""
@@ -223,6 +224,7 @@ import threading  # noqa: E402
 _tls = threading.local()
 _default_ctx = {}
 _default_lock = threading.Lock()
+_dtype_lock = threading.RLock()       # serialises arithmetic switches of a (possibly shared) context: library call + the mirror attribute together
 _observers = []                       # test hooks: fn(name, Ctx) called before every context-taking entry point (empty in production)
 
 
@@ -282,9 +284,11 @@ class use_ctx:
         return self.cx
 
     def __exit__(self, *exc):
+        # the stack first: afi_ctx_set_compute_dtype is refused while weight-gradient sums are pending, and if restoring the arithmetic
+        # raises, every later call of this thread must still go to the context it had before the block, not to a stale one
+        _tls.stack.pop()
         if self.prev is not None:
             self.cx.set_dtype(self.prev)
-        _tls.stack.pop()
         return False
 
 

@@ -72,8 +72,32 @@ class Node:
         return self
 
     def merge_from_file(self, path):
+        """yacs semantics: ``yaml.safe_load`` (a config file cannot run code), then the literal parse yacs applies to string values --
+        the reference yamls write tuples as "(a, b)" strings -- and ``!!python/tuple`` nodes accepted as plain tuples."""
+        import ast
         import yaml
-        d = yaml.unsafe_load(open(path)) or {}             # (the reference yamls write tuples as "(a, b)" strings or python tuples)
+
+        class _Loader(yaml.SafeLoader):
+            pass
+        _Loader.add_constructor("tag:yaml.org,2002:python/tuple", lambda ld, node: tuple(ld.construct_sequence(node, deep=True)))
+
+        def literal(v):
+            if isinstance(v, dict):
+                return {k: literal(x) for k, x in v.items()}
+            if isinstance(v, list):
+                return [literal(x) for x in v]
+            if isinstance(v, str):
+                try:                                       # yacs _decode_cfg_value: "(800, 1333)" -> (800, 1333), "1e-3" -> 0.001; other strings stay
+                    return ast.literal_eval(v)
+                except (ValueError, SyntaxError):
+                    return v
+            return v
+        with open(path) as f:
+            d = yaml.load(f, Loader=_Loader) or {}
+        base = d.pop("_BASE_", None) if isinstance(d, dict) else None
+        d = literal(d)
+        if base is not None:
+            d["_BASE_"] = base
         base = d.get("_BASE_")
         if base:
             self.merge_from_file(os.path.join(os.path.dirname(path), base))

@@ -218,7 +218,15 @@ class DualScaleMapper:
         instance (training with INPUT.CROP and annotations), the short-edge size and flips of both lists, both output sizes and the two
         transform lists the annotations follow.  Pure numpy: no device work."""
         crop = None
-        if self.crop_gen is not None and annotations is not None and len(annotations):
+        if self.crop_gen is not None and annotations is None:
+            # dataset_mapper.py:84-91: without an "annotations" key the reference prepends the RandomCrop to BOTH transform lists (image and
+            # image_x0.5 each randomly cropped, two more draws).  That branch is not mirrored here: refuse it instead of handing back
+            # uncropped data with another random-stream position (ADVICE r3)
+            raise _lib.AfiError("INPUT.CROP is enabled and the sample has no \"annotations\" key: the reference's crop of both images "
+                                "(dataset_mapper.py:84-91) is not supported on the dual-scale path; pass annotations or disable the crop")
+        if self.crop_gen is not None and len(annotations) == 0:
+            raise ValueError("a must be non-empty")            # np.random.choice([]) in the reference (dataset_mapper.py:101)
+        if self.crop_gen is not None:
             crop_size = self.crop_gen.get_crop_size((h0, w0))                    # (argument order of dataset_mapper.py:98-102: the size draws first,
             inst = annotations[np.random.randint(len(annotations))]              #  then np.random.choice(annotations) = one randint draw, then the origin)
             crop = gen_crop_transform_with_instance(crop_size, (h0, w0), inst)

@@ -64,9 +64,16 @@ class GuidePrefetcher:
     """The two forwards of the FROZEN guide network (stage1_trainer.py:316-327: ``feature_model(data, "image")`` and ``(data, "image_x0.5")``
     under no_grad, eval mode) for batch i + 1, issued on a second stream while batch i trains.  The guide has no trainable state and no
     BatchNorm updates, so its features do not depend on the G / D updates of the iteration they overlap: the result is the same tensors one
-    iteration earlier, nothing else.  ``submit(fn)`` runs ``fn()`` -- any callable returning the feature tensors (lists / dicts of them) --
-    on the prefetch stream behind whatever the caller's stream has queued (its inputs are ready); ``take()`` makes the caller's stream wait
-    for them and hands them over (``record_stream`` keeps the allocator from recycling them while the caller's stream still reads them)."""
+    iteration earlier, nothing else.  ``submit(fn, *inputs)`` runs ``fn()`` -- any callable returning the feature tensors (lists / dicts of
+    them) -- on the prefetch stream behind whatever the caller's stream has queued (its inputs are ready); ``take()`` makes the caller's
+    stream wait for them and hands them over (``record_stream`` keeps the allocator from recycling them while the caller's stream still
+    reads them).
+
+    Lifetime contract of what ``fn`` READS: those tensors were allocated on the caller's stream and are read by kernels of the
+    prefetch stream, so the caching allocator must not hand their blocks to a new caller-stream allocation before the guide forward is done.
+    ``submit`` therefore (1) marks every tensor passed as ``inputs`` and every tensor found in ``fn``'s closure cells / ``functools.partial``
+    arguments with ``record_stream(prefetch stream)`` and (2) keeps references to them until ``take()``; a caller whose ``fn`` reaches its
+    inputs some other way (a global, an attribute) passes them explicitly.  The caller may drop its own references right after ``submit``."""
 
     def __init__(self, device=None):
         self.stream = torch.cuda.Stream(device=device)
@@ -83,18 +90,37 @@ class GuidePrefetcher:
             for v in o:
                 yield from GuidePrefetcher._tensors(v)
 
-    def submit(self, fn):
+    @staticmethod
+    def _closure_tensors(fn):
+        """CUDA tensors a callable holds on to: closure cells, default arguments, functools.partial arguments (lists / tuples / dicts
+        are walked; a bound method's instance, module attributes and globals are not: pass such inputs to ``submit`` explicitly)."""
+        seen = []
+        for cell in getattr(fn, "__closure__", None) or ():
+            try:
+                seen.extend(GuidePrefetcher._tensors(cell.cell_contents))
+            except ValueError:                              # empty cell
+                pass
+        seen.extend(GuidePrefetcher._tensors(list(getattr(fn, "__defaults__", None) or ())))
+        seen.extend(GuidePrefetcher._tensors(dict(getattr(fn, "__kwdefaults__", None) or {})))
+        seen.extend(GuidePrefetcher._tensors(list(getattr(fn, "args", ()) or ())))
+        seen.extend(GuidePrefetcher._tensors(dict(getattr(fn, "keywords", None) or {})))
+        return [t for t in seen if t.is_cuda]
+
+    def submit(self, fn, *inputs):
         if self._pending is not None:
             raise RuntimeError("GuidePrefetcher.submit: the previous batch's features were not taken")
+        held = [t for t in self._tensors(list(inputs)) if t.is_cuda] + self._closure_tensors(fn)
         self.stream.wait_stream(torch.cuda.current_stream())
+        for t in held:
+            t.record_stream(self.stream)                    # read by the prefetch stream: not recyclable before its work is done
         with torch.cuda.stream(self.stream), torch.no_grad():
             out = fn()
-        self._pending = out
+        self._pending = (out, held)                         # the references live until take()
 
     def take(self):
         if self._pending is None:
             raise RuntimeError("GuidePrefetcher.take: nothing was submitted")
-        out, self._pending = self._pending, None
+        (out, _held), self._pending = self._pending, None
         cur = torch.cuda.current_stream()
         cur.wait_stream(self.stream)
         for t in self._tensors(out):
@@ -113,6 +139,7 @@ class _FlatOptim:
 
     def __init__(self, named_params, weight_decay, weight_decay_norm):
         self.params = [p for _, p in named_params]
+        self.names = [n for n, _ in named_params]
         dev = self.params[0].device
         sizes = [p.numel() for p in self.params]
         offs = np.concatenate([[0], np.cumsum([(n + 3) // 4 * 4 for n in sizes])])
@@ -120,6 +147,7 @@ class _FlatOptim:
         self.flat_grad = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.flat_mom = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.grad_ptrs = []
+        self._offs = [int(o) for o in offs[:-1]]
         descs = (SgdDesc * len(self.params))()
         for i, ((name, p), n) in enumerate(zip(named_params, sizes)):
             o = int(offs[i])
@@ -143,6 +171,32 @@ class _FlatOptim:
     def zero_grad(self):
         self.flat_grad.zero_()
 
+    def _logical(self, flat: torch.Tensor, i: int) -> torch.Tensor:
+        """View of parameter i's segment of a flat buffer in the parameter's LOGICAL shape ([O,I,kh,kw] for conv weights, whatever
+        their memory order here)."""
+        p, o = self.params[i], self._offs[i]
+        seg = flat[o:o + p.numel()]
+        if p.dim() == 4 and not p.is_contiguous():
+            O, I, kh, kw = p.shape
+            return seg.view(O, kh, kw, I).permute(0, 3, 1, 2)
+        return seg.view(p.shape)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        """torch.optim.SGD's per-parameter state, keyed by parameter NAME: {name: momentum_buffer} in the parameter's logical shape
+        (what DetectionCheckpointer stores as optimizer.state[p]["momentum_buffer"], stage1_trainer.py:129-148)."""
+        return {n: self._logical(self.flat_mom, i).detach().clone(memory_format=torch.contiguous_format) for i, n in enumerate(self.names)}
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        missing = [n for n in self.names if n not in sd]
+        extra = [n for n in sd if n not in set(self.names)]
+        if missing or extra:
+            raise KeyError(f"optimizer state: missing {missing}, unexpected {extra}")
+        for i, n in enumerate(self.names):
+            v = sd[n]
+            if tuple(v.shape) != tuple(self.params[i].shape):
+                raise ValueError(f"optimizer state {n}: shape {tuple(v.shape)} != {tuple(self.params[i].shape)}")
+            self._logical(self.flat_mom, i).copy_(v.to(self.flat_mom.device, torch.float32))
+
     def step(self, lr, momentum, gscale=1.0):
         call("afi_sgd_momentum_step", C.c_void_p(self.descs.data_ptr()), self.n, self.max_n, float(lr), float(momentum), float(gscale),
              ops.stream_ptr())
@@ -156,7 +210,7 @@ class Stage1Step:
                  warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2,
                  reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: Optional[str] = None,
                  overlap_d: bool = True, overlap_g: bool = True, weight_cache: bool = True, wgrad_accum: bool = True,
-                 g_bwd_small_first: bool = True):
+                 g_bwd_small_first: bool = True, overlap_comm: bool = True):
         self.G, self.D = G, D
         self.gnet, self.dnet = G, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
@@ -168,6 +222,9 @@ class Stage1Step:
         # are power-bound and leave room beside the bandwidth-bound passes (129.5 -> 126.4 -> 123.9 ms); `overlap_d` / `overlap_g` (attributes too)
         self.overlap_d, self.overlap_g = overlap_d, overlap_g
         self.g_bwd_small_first = g_bwd_small_first          # G-phase backward passes on the second stream: smallest level first (see _run_phases)
+        # data-parallel runs: the two gradient all-reduces are issued asynchronously and run beside work that does not need them -- D's
+        # beside G's five backward passes (second stream), G's beside the G phase's D forwards (see _run_phases); False = blocking, in place
+        self.overlap_comm = overlap_comm
         # per-phase cache of transformed weights / transform-domain sum of the weight gradients of a phase (pure re-orderings; off = per call)
         self.weight_cache, self.wgrad_accum = weight_cache, wgrad_accum
         self._bstream = None
@@ -231,6 +288,26 @@ class Stage1Step:
         if self._bstream is not None:
             torch.cuda.current_stream().wait_stream(self._bstream)
 
+    # ------------------------------------------------------------------------------------------------ engine state (resume)
+    def state_dict(self) -> Dict[str, object]:
+        """What a resumed run needs beyond the two networks' own ``state_dict()``: the reference checkpoints, per network, the optimizer
+        (momentum buffers), the scheduler (``last_epoch``) and the iteration (stage1_trainer.py:129-174, DetectionCheckpointer with
+        ``optimizer=`` / ``scheduler=``).  Momentum buffers are keyed by parameter name and stored in the parameter's logical
+        [O,I,kh,kw] shape, so the file does not depend on this engine's memory layout."""
+        return {"iteration": int(self.iter),
+                "G_optimizer": {"momentum_buffer": self.g_opt.state_dict()},
+                "D_optimizer": {"momentum_buffer": self.d_opt.state_dict()},
+                "scheduler": {"last_epoch": int(self.iter), "base_lr": self.base_lr, "steps": list(self.lr_steps), "gamma": self.lr_gamma,
+                              "warmup_factor": self.warmup_factor, "warmup_iters": self.warmup_iters}}
+
+    def load_state_dict(self, sd: Dict[str, object]):
+        """Inverse of ``state_dict``; the networks' parameters / BN buffers are loaded by the caller into G and D (in place: the engine
+        holds their storage).  The learning-rate schedule itself is a constructor argument and stays this engine's."""
+        self._join_bstream()
+        self.g_opt.load_state_dict(sd["G_optimizer"]["momentum_buffer"])
+        self.d_opt.load_state_dict(sd["D_optimizer"]["momentum_buffer"])
+        self.iter = int(sd["iteration"])
+
     def lr_at(self, it: int) -> float:
         return warmup_multistep_lr(self.base_lr, it, self.lr_steps, self.lr_gamma, self.warmup_factor, self.warmup_iters)
 
@@ -276,12 +353,21 @@ class Stage1Step:
         h, w = min(tr.shape[2], hr.shape[2]), min(tr.shape[3], hr.shape[3])
         return tr[:, :, :h, :w], hr[:, :, :h, :w]
 
-    def _allreduce(self, opt: _FlatOptim):
-        """ONE collective per network per iteration: sum the flat gradient buffer over the ranks (RCCL over xGMI; gloo in
-        the CPU rehearsal).  The 1/world averaging is folded into the fused SGD kernel's gradient scale, so between this
-        call and the optimizer step ``param.grad`` holds the SUM over ranks."""
+    # ONE collective per network per iteration: sum the flat gradient buffer over the ranks (RCCL over xGMI; gloo in the CPU rehearsal).
+    # The 1/world averaging is folded into the fused SGD kernel's gradient scale, so between the collective and the optimizer step
+    # ``param.grad`` holds the SUM over ranks.
+    def _allreduce_start(self, opt: _FlatOptim):
+        """Issue the collective behind what the CURRENT stream has queued and return at once (``async_op``: RCCL runs it on its own
+        stream); nothing may touch ``opt.flat_grad`` until ``_allreduce_finish``."""
+        if self.distributed and self.overlap_comm:
+            return torch.distributed.all_reduce(opt.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
         if self.distributed:
             allreduce_sum_(opt.flat_grad, self.pg)
+        return None
+
+    def _allreduce_finish(self, opt: _FlatOptim, work):
+        if work is not None:
+            work.wait()                            # (nccl: the current stream waits for the collective; gloo: the host does)
         if self.after_allreduce is not None:       # observation point for tests: `opt.flat_grad` holds the SUM over ranks here
             self.after_allreduce("D" if opt is self.d_opt else "G", opt)
 
@@ -372,10 +458,15 @@ class Stage1Step:
         if self.overlap_d:
             self._join_bstream()
         call("afi_ctx_wino_wgrad_flush", self.bctx.handle, ops.stream_ptr())         # (joined: the backward context's sums, on the caller's stream)
-        self._allreduce(self.d_opt)
-        self.d_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :381
-        call("afi_ctx_wino_weight_cache_invalidate", self.ctx.handle)                # D's weights moved
-        call("afi_ctx_wino_weight_cache_invalidate", self.bctx.handle)
+        # D's gradient exchange (61.4 MB at the reference's widths) is issued here and waited for only where D's weights are needed: G's
+        # five backward passes need nothing of D (below), so with the second stream they run beside the collective
+        d_work = self._allreduce_start(self.d_opt)
+
+        def d_finish():
+            self._allreduce_finish(self.d_opt, d_work)
+            self.d_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)          # :381
+            call("afi_ctx_wino_weight_cache_invalidate", self.ctx.handle)            # D's weights moved
+            call("afi_ctx_wino_weight_cache_invalidate", self.bctx.handle)
 
         # ---------------- G phase (:384-433)
         self.g_opt.zero_grad()                                                       # :426
@@ -400,13 +491,19 @@ class Stage1Step:
         # big at its head and small beside small (an idle chip) at its tail.  (The losses land in their own slots; the weight gradients
         # are summed in another order: fp32 rounding only.)
         side = self.overlap_d and self.reuse_g and self.overlap_g
+        g_work = None
         if side:
             if self._bstream is None:
                 self._bstream = torch.cuda.Stream(device=dev)
-            self._bstream.wait_stream(torch.cuda.current_stream())                   # behind the D phase and G's zero_grad
+            self._bstream.wait_stream(torch.cuda.current_stream())                   # behind the D phase's flush and G's zero_grad (not behind D's all-reduce)
             with torch.cuda.stream(self._bstream), _lib.use_ctx(self.bctx):
                 for i in (reversed(range(nlev)) if self.g_bwd_small_first else range(nlev)):
                     g_backward(i, *trs[i])
+                # G's gradients are final once its last backward pass has run: its sums are transformed back and its exchange (31.3 MB) is
+                # issued from the second stream, beside the D forwards the caller's stream still has to run
+                call("afi_ctx_wino_wgrad_flush", self.bctx.handle, ops.stream_ptr())
+                g_work = self._allreduce_start(self.g_opt)
+        d_finish()                                                                   # D's weights move before the G phase's D forwards read them
         for i in range(nlev):
             if self.reuse_g:
                 tr, ws = trs[i]                                                      # Q5: identical to recomputing G(lr)
@@ -423,13 +520,24 @@ class Stage1Step:
                     g_backward(i, tr, ws)
         if self.overlap_d and self.reuse_g:
             self._join_bstream()
-        call("afi_ctx_wino_wgrad_flush", self.bctx.handle, ops.stream_ptr())
-        self._allreduce(self.g_opt)
+        if not side:
+            call("afi_ctx_wino_wgrad_flush", self.bctx.handle, ops.stream_ptr())
+            g_work = self._allreduce_start(self.g_opt)
+        self._allreduce_finish(self.g_opt, g_work)
         self.g_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :433
 
-    def metrics(self, check_finite: bool = True) -> Dict[str, float]:
-        """Loss values of the last step (one device sync).  g_loss_p = 1e-3*adv + content (stage1_trainer.py:411)."""
-        vals = self.losses.detach().cpu().tolist()
+    def metrics(self, check_finite: bool = True, reduce: bool = False) -> Dict[str, float]:
+        """Loss values of the last step (one device sync).  g_loss_p = 1e-3*adv + content (stage1_trainer.py:411).
+        ``reduce=True`` in a data-parallel run: the MEAN over the ranks -- the reference's ``_write_metrics`` gathers every rank's dict by
+        pickle on every iteration and averages on rank 0 (stage1_trainer.py:453-492); here it is ONE all-reduce of the 3-per-level loss
+        vector, whenever the caller asks (every logging period, not every iteration), and every rank gets the averages.  Collective:
+        all ranks must call it together."""
+        vec = self.losses.detach()
+        if reduce and self.distributed:
+            vec = vec.clone()
+            torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            vec = vec / self.world
+        vals = vec.cpu().tolist()
         out = dict(zip(self._loss_names, vals))
         for k in list(out):
             if k.startswith("adv_loss_p"):

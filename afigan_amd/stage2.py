@@ -168,8 +168,28 @@ class Stage2Adversarial:
                 out[f"g_loss_p{lv}"] = adv.reshape(()) * 1e-3 + content
         return out
 
-    def d_metrics(self) -> Dict[str, float]:
-        return dict(zip(self._names, self.losses.detach().cpu().tolist()))
+    def d_metrics(self, reduce: bool = False) -> Dict[str, float]:
+        """D losses of the last d_step; ``reduce=True``: mean over the data-parallel ranks by ONE all-reduce (collective; stage1.py)."""
+        vec = self.losses.detach()
+        if reduce and self.distributed:
+            vec = vec.clone()
+            torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            vec = vec / self.world
+        return dict(zip(self._names, vec.cpu().tolist()))
+
+    def state_dict(self) -> Dict[str, object]:
+        """D's optimizer / scheduler / iteration as the reference checkpoints them beside the network (stage2_trainer.py: D_checkpointer
+        with optimizer= and scheduler=); same format as Stage1Step.state_dict's D half."""
+        steps, gamma, wf, wi = self.sched
+        return {"iteration": int(self.iter), "D_optimizer": {"momentum_buffer": self.opt.state_dict()},
+                "scheduler": {"last_epoch": int(self.iter), "base_lr": self.base_lr, "steps": list(steps), "gamma": gamma,
+                              "warmup_factor": wf, "warmup_iters": wi}}
+
+    def load_state_dict(self, sd: Dict[str, object]):
+        if self._bstream is not None:
+            torch.cuda.current_stream().wait_stream(self._bstream)
+        self.opt.load_state_dict(sd["D_optimizer"]["momentum_buffer"])
+        self.iter = int(sd["iteration"])
 
 
 class Stage2Step:

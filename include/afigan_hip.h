@@ -202,7 +202,14 @@ int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* 
 int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t x, int N, int H, int W, float* logits, int training,
                           float* ws, long long ws_floats, void* stream);
 /* Backward (training-mode forward only).  grads: += targets (w, b, gamma, beta, w3, b3; other fields ignored).
- * dx: DENSE [N,H,W,F0] or NULL (both reference loops feed detached inputs). */
+ * dx: DENSE [N,H,W,F0] or NULL (both reference loops feed detached inputs).
+ * PRECONDITION: `prm` holds the values the forward saw -- in particular gamma[n] / beta[n] must be BIT-IDENTICAL to the forward's.
+ * The LeakyReLU' masks are recomputed here from the saved conv outputs c[n] (workspace) through the same affine
+ * ((c - mean) * invstd) * gamma + beta, evaluated in the same order, instead of being read from the saved activations; a caller that
+ * steps the BatchNorm affine between the two calls gets masks of ANOTHER affine and no error (the weights w[n] may not move either:
+ * the data gradients read them).  Both reference loops run backward before any optimizer step (stage1_trainer.py:374-381,
+ * stage2_trainer.py:335-342).  tests/test_gpu_d_parity.py::test_masks_recomputed_in_backward_match_the_forward counts the
+ * disagreeing masks on un-nudged inputs. */
 int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* grads, afi_view_t x, int N, int H, int W,
                           const float* ws, const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream);
 

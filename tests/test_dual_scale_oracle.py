@@ -166,3 +166,16 @@ def test_polygon_masks_and_unsupported_mask_formats():
     assert m.get_bounding_boxes()[2].tolist() == [1.0, 1.0, 9.0, 9.5]
     with pytest.raises(AfiError):
         DualScaleMapper(mask_on=True, mask_format="bitmask", device="cpu")
+
+
+def test_crop_without_annotations_is_refused_not_skipped():
+    """dataset_mapper.py:84-91,96-102: with INPUT.CROP on, a sample without an "annotations" key gets BOTH images cropped by the reference
+    (not mirrored here: AfiError instead of silently uncropped data), and an empty annotation list raises from np.random.choice([])."""
+    from afigan_amd import _lib
+    from afigan_amd.dual_scale import DualScaleMapper
+    m = DualScaleMapper((24, 28, 32), 50, "choice", device="cpu", crop=("relative", (0.8, 0.8)))
+    with pytest.raises(_lib.AfiError, match="annotations"):
+        m.plan(40, 60, None)
+    with pytest.raises(ValueError, match="non-empty"):
+        m.plan(40, 60, [])
+    assert DualScaleMapper((24, 28, 32), 50, "choice", device="cpu").plan(40, 60, None).crop is None      # no crop configured: unchanged

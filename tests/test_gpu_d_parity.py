@@ -65,3 +65,25 @@ def test_backward_on_own_forward_within_flip_noise(amd, N, H, W, seed):
     pr = DProbe(amd, N, H, W, seed)
     e = pr.errors(*pr.backward())
     assert e["dx_l2"] < TOL_OWN_FORWARD_L2 and e["worst_l2"][0] < TOL_OWN_FORWARD_L2, e
+
+
+@pytest.mark.parametrize("N,H,W,seed", CASES + [(2, 50, 84, 5)])
+def test_masks_recomputed_in_backward_match_the_forward(amd, N, H, W, seed):
+    """afi_discriminator_bwd does not read the saved activations: it recomputes each LeakyReLU' decision from the saved conv output as
+    sign(((c - mean) * invstd) * gamma + beta), every operation rounded to fp32 (include/afigan_hip.h: the precondition on gamma / beta).
+    On the library's OWN, un-nudged forward the recomputed decisions must agree with the activations the forward stored -- the count of
+    disagreeing masks is reported and must be zero -- and with the fp64 forward injected WITHOUT the ulp nudges of
+    DProbe.inject_fp64_forward the number of elements that would land on the other side is what that helper repairs."""
+    pr = DProbe(amd, N, H, W, seed)
+    bc = lambda v: v.view(1, -1, 1, 1)
+    disagree = []
+    for n in range(3):
+        pre = f"Discriminators.0.{n}.0.norm"
+        c, y, mean, invstd = pr.saved(n)
+        ga, be = pr.dp[pre + ".weight"].float().cuda(), pr.dp[pre + ".bias"].float().cuda()
+        z = ((c - bc(mean)) * bc(invstd)) * bc(ga) + bc(be)
+        disagree.append(int(((z > 0) != (y > 0)).sum()))
+    assert disagree == [0, 0, 0], disagree
+    nudged = pr.inject_fp64_forward()                      # (count of elements whose recomputed fp32 decision differed from fp64's before nudging)
+    total = sum(pr.net.F[n + 1] for n in range(3)) * pr.P
+    assert sum(nudged) <= max(8, total // 10**5), (nudged, total)

@@ -160,14 +160,16 @@ def test_stage1_trajectory_four_iterations_vs_oracle(amd):
             assert ((sd[k].cpu() - v).abs().max() / (v.abs().max() + 1e-30)).item() < 2e-3, k
 
 
-def _dp_gpu_worker(rank, world, port, tmp):
-    """Two ranks share the one GPU of the test box and talk over gloo (RCCL needs one GPU per rank): exercises the real
-    distributed code path of Stage1Step (broadcast, flat-buffer all-reduce, fused SGD with 1/world) on the HIP kernels."""
+def _dp_gpu_worker(rank, world, port, tmp, backend="gloo", overlap_comm=True):
+    """backend "gloo": two ranks share the one GPU of the test box (RCCL needs one GPU per rank); backend "nccl" (= RCCL): one GPU per
+    rank.  Either way the real distributed code path of Stage1Step runs on the HIP kernels: broadcast, flat-buffer all-reduces (issued
+    asynchronously beside G's backward passes / the G phase's D forwards with overlap_comm), fused SGD with 1/world, reduced metrics."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch.distributed as dist
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(rank if backend == "nccl" else 0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     import afigan_amd as amd
     C, g = 16, 4
     torch.manual_seed(50 + rank)                               # different init per rank; the broadcast must fix it
@@ -176,8 +178,8 @@ def _dp_gpu_worker(rank, world, port, tmp):
     gen = torch.Generator().manual_seed(1000 + rank)           # this rank's shard of the global batch
     lr_f = [torch.randn((1, C, 7, 11), generator=gen).cuda(), torch.randn((1, C, 4, 6), generator=gen).cuda()]
     hr_f = [torch.randn((1, C, 13, 21), generator=gen).cuda(), torch.randn((1, C, 8, 12), generator=gen).cuda()]
-    step = amd.Stage1Step(G, D, base_lr=0.01, warmup_iters=0)  # picks up the initialised process group
-    assert step.distributed and step.world == world
+    step = amd.Stage1Step(G, D, base_lr=0.01, warmup_iters=0, overlap_comm=overlap_comm)  # picks up the initialised process group
+    assert step.distributed and step.world == world and step.overlap_comm == overlap_comm
     w0 = {k: v.detach().clone() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())}
     # single-rank gradients of this shard from the same starting weights (independent engine, no process group)
     import copy
@@ -197,17 +199,13 @@ def _dp_gpu_worker(rank, world, port, tmp):
            "d_sum_flat": snap["D"].cpu(), "g_sum_flat": snap["G"].cpu(),
            "d_solo_flat": solo.d_opt.flat_grad.detach().cpu().clone(),
            "d_sizes": [({id(q): n for n, q in D.named_parameters()}[id(p)], p.numel()) for p in step.d_order],
-           "metrics": step.metrics()}
+           "metrics": step.metrics(), "metrics_mean": step.metrics(reduce=True)}
     torch.save(out, os.path.join(tmp, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_stage1_data_parallel_two_ranks_one_gpu(amd, tmp_path):
-    import torch.multiprocessing as mp
-    port = 29700 + (os.getpid() % 1000)
-    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+def _check_dp_results(r0, r1):
     for k in r0["w0"]:
         assert torch.equal(r0["w0"][k], r1["w0"][k]), k           # broadcast from rank 0
         if "running" in k or "num_batches" in k:
@@ -234,6 +232,104 @@ def test_stage1_data_parallel_two_ranks_one_gpu(amd, tmp_path):
             assert scale == 0.0 and g.abs().max().item() == 0.0, k      # bias in front of a train-mode BN: exactly zero
             continue
         assert scale > 0 and ((g - w).abs().max() / scale).item() < 1e-4, k
+    # metrics(reduce=True): every rank holds the mean of the ranks' own values (stage1_trainer.py:453-492 averages on rank 0)
+    for k, v in r0["metrics_mean"].items():
+        assert r1["metrics_mean"][k] == v, k
+        assert abs(v - 0.5 * (r0["metrics"][k] + r1["metrics"][k])) <= 1e-6 * max(1.0, abs(v)), k
+
+
+def test_stage1_data_parallel_two_ranks_one_gpu(amd, tmp_path):
+    """gloo, two ranks on the one test GPU, with the gradient exchange overlapped (default) and blocking: same invariants, and the two
+    schedules leave the same parameters (the collectives are only moved in time; fp32 atomics reorder sums, nothing else may differ)."""
+    import torch.multiprocessing as mp
+    res = {}
+    for overlap in (True, False):
+        d = tmp_path / f"ov{int(overlap)}"
+        d.mkdir()
+        port = 29700 + (os.getpid() % 1000) + (7 if overlap else 0)
+        mp.spawn(_dp_gpu_worker, args=(2, port, str(d), "gloo", overlap), nprocs=2, join=True)
+        r0, r1 = torch.load(d / "r0.pt"), torch.load(d / "r1.pt")
+        _check_dp_results(r0, r1)
+        res[overlap] = r0
+    for k, v in res[True]["w1"].items():
+        if "num_batches" in k:
+            assert torch.equal(v, res[False]["w1"][k]), k
+        else:
+            assert ((v - res[False]["w1"][k]).abs().max() / (v.abs().max() + 1e-30)).item() < 1e-5, k
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs where the box has >= 2 devices")
+def test_stage1_data_parallel_rccl(amd, tmp_path):
+    """The same invariants over the `nccl` backend (RCCL over xGMI), one process per device -- picked up by any box that shows two or
+    more GPUs (the builder's boxes show one; SURVEY 8e, stage1_trainer.py:80-89)."""
+    import torch.multiprocessing as mp
+    port = 29900 + (os.getpid() % 1000)
+    mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path), "nccl", True), nprocs=2, join=True)
+    _check_dp_results(torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt"))
+
+
+def test_stage1_engine_state_round_trip(amd):
+    """Stage1Step.state_dict / load_state_dict (momentum buffers by parameter name in logical [O,I,kh,kw] shape, iteration;
+    stage1_trainer.py:129-174): 2 steps -> save -> new engine on freshly constructed networks -> load -> 2 steps lands where 4
+    uninterrupted steps land (the weight-gradient kernels add partial tiles by fp32 atomics, so "where" is 1e-5, not bit for bit; the
+    buffers themselves travel bit for bit), and dropping the momentum on the way does not (the test can see the state)."""
+    import copy
+    C, g = 16, 4
+    torch.manual_seed(21)
+    G0 = amd.Generator(in_channels=C, n_residual_dense_blocks=2, growth_rate=g).cuda()
+    D0 = amd.Discriminator(in_filters=C).cuda()
+    gen = torch.Generator().manual_seed(22)
+    batches = [([torch.randn((2, C, 7, 11), generator=gen).cuda(), torch.randn((2, C, 4, 6), generator=gen).cuda()],
+                [torch.randn((2, C, 13, 21), generator=gen).cuda(), torch.randn((2, C, 8, 12), generator=gen).cuda()]) for _ in range(4)]
+    sched = dict(base_lr=0.05, lr_steps=(3,), lr_gamma=0.5, warmup_factor=0.1, warmup_iters=2)
+
+    def flat(G, D):
+        return torch.cat([v.detach().double().reshape(-1).cpu() for v in list(G.state_dict().values()) + list(D.state_dict().values())])
+
+    Ga, Da = copy.deepcopy(G0), copy.deepcopy(D0)
+    ref = amd.Stage1Step(Ga, Da, **sched)
+    for lr_f, hr_f in batches:
+        ref.run_step(lr_f, hr_f)
+    want = flat(Ga, Da)
+
+    Gb, Db = copy.deepcopy(G0), copy.deepcopy(D0)
+    first = amd.Stage1Step(Gb, Db, **sched)
+    for lr_f, hr_f in batches[:2]:
+        first.run_step(lr_f, hr_f)
+    torch.cuda.synchronize()
+    ckpt = {"G": {k: v.cpu() for k, v in Gb.state_dict().items()}, "D": {k: v.cpu() for k, v in Db.state_dict().items()},
+            "engine": {k: v for k, v in first.state_dict().items()}}
+    assert ckpt["engine"]["iteration"] == 2 and ckpt["engine"]["scheduler"]["last_epoch"] == 2
+    for net, opt in (("G_optimizer", first.g_opt), ("D_optimizer", first.d_opt)):
+        mb = ckpt["engine"][net]["momentum_buffer"]
+        assert list(mb) == opt.names
+        for n, p in zip(opt.names, opt.params):
+            assert tuple(mb[n].shape) == tuple(p.shape) and mb[n].is_contiguous(), n       # logical shape, layout-independent
+        assert any(float(v.abs().max()) > 0 for v in mb.values())
+
+    def resume(with_momentum):
+        Gc = amd.Generator(in_channels=C, n_residual_dense_blocks=2, growth_rate=g).cuda()
+        Dc = amd.Discriminator(in_filters=C).cuda()
+        Gc.load_state_dict(ckpt["G"]); Dc.load_state_dict(ckpt["D"])
+        eng = amd.Stage1Step(Gc, Dc, **sched)
+        sd = copy.deepcopy(ckpt["engine"])
+        if not with_momentum:
+            for net in ("G_optimizer", "D_optimizer"):
+                sd[net]["momentum_buffer"] = {k: torch.zeros_like(v) for k, v in sd[net]["momentum_buffer"].items()}
+        eng.load_state_dict(sd)
+        assert eng.iter == 2
+        if with_momentum:
+            assert torch.equal(eng.g_opt.flat_mom, first.g_opt.flat_mom) and torch.equal(eng.d_opt.flat_mom, first.d_opt.flat_mom)
+        for lr_f, hr_f in batches[2:]:
+            eng.run_step(lr_f, hr_f)
+        return flat(Gc, Dc)
+
+    got = resume(True)
+    assert float((got - want).norm() / want.norm()) < 1e-5
+    assert float((resume(False) - want).norm() / want.norm()) > 1e-4
+    with pytest.raises(KeyError):
+        bad = copy.deepcopy(ckpt["engine"]); bad["G_optimizer"]["momentum_buffer"].pop(first.g_opt.names[0])
+        first.load_state_dict(bad)
 
 
 def test_stage1_phase_caches_do_not_change_the_gradients(amd, monkeypatch):
@@ -304,16 +400,16 @@ def test_stage1_error_in_a_phase_joins_the_second_stream(amd):
     hrs = [torch.randn((1, 256, 32, 48), device="cuda", generator=gen)]
     lrs = [torch.randn((1, 256, 16, 24), device="cuda", generator=gen)]
     joined = []
-    orig_join, orig_all = step._join_bstream, step._allreduce
+    orig_join, orig_all = step._join_bstream, step._allreduce_start
     step._join_bstream = lambda: (joined.append(1), orig_join())[1]
 
     def boom(opt):
         raise RuntimeError("injected")
-    step._allreduce = boom
+    step._allreduce_start = boom
     with pytest.raises(RuntimeError, match="injected"):
         step.run_step(lrs, hrs)
     assert len(joined) >= 2                                            # the phase's own join and the handler's
-    step._allreduce = orig_all
+    step._allreduce_start = orig_all
     step.run_step(lrs, hrs)                                            # contexts are clean again (no pending sums, caches unregistered)
     assert all(np.isfinite(v) for v in step.metrics().values())
 
@@ -348,4 +444,50 @@ def test_guide_prefetcher_hands_over_the_same_features_one_step_early(amd):
         assert not pf.pending or i + 1 < 3
         for a, b in zip(feats, direct[i]):
             assert torch.equal(a, b), i
+    torch.cuda.synchronize()
+
+
+def test_guide_prefetcher_keeps_its_inputs_alive(amd):
+    """the images of batch i + 1 are allocated on the caller's stream, read by the prefetch stream, and dropped by the caller
+    right after ``submit``.  The prefetcher must keep them from the caching allocator until the guide forward has run: the block is not
+    handed to the caller's next same-size allocation, and the features equal a direct call's."""
+    from afigan_amd.guide import GuideR50FPN
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    guide = GuideR50FPN().to(dev)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    img = torch.rand((1, 3, 128, 160), device=dev, generator=gen) * 255.0
+    with torch.no_grad():
+        direct = [guide(img)[f"p{d}"].clone() for d in range(2, 7)]
+    torch.cuda.synchronize()
+    burn = torch.randn((4096, 4096), device=dev)
+    pf = amd.GuidePrefetcher(dev)
+    def make(batch):
+        def fn(b=None):
+            x = burn
+            for _ in range(6):                              # keeps the prefetch stream busy before it reads the image
+                x = torch.tanh(x @ x * 1e-3)
+            return [guide((batch if b is None else b)["image"])[f"p{d}"] for d in range(2, 7)]
+        return fn
+
+    import functools
+    for how in ("closure", "partial", "explicit"):
+        batch = {"image": img.clone()}
+        old_ptr = batch["image"].data_ptr()
+        if how == "closure":
+            pf.submit(make(batch))                          # the callable's closure holds the batch dict
+        elif how == "partial":
+            pf.submit(functools.partial(make({}), batch))   # reached through functools.partial arguments
+        else:
+            holder = [batch]
+            pf.submit(lambda: make(holder[0])(), batch["image"])     # (closure -> list -> dict is walked too; passed explicitly as well)
+            holder.clear()
+        assert any(t.data_ptr() == old_ptr for t in pf._pending[1]), how
+        batch.clear()                                       # the caller drops its references right after submit
+        fresh = [torch.full((1, 3, 128, 160), 1e9, device=dev) for _ in range(4)]     # the caller's next allocations of that size
+        assert all(t.data_ptr() != old_ptr for t in fresh), how
+        feats = pf.take()
+        for a, b in zip(feats, direct):
+            assert torch.equal(a, b), how
+        del fresh, feats
     torch.cuda.synchronize()

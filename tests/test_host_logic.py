@@ -129,6 +129,39 @@ def test_flat_gradient_buffers_are_views():
     assert all(torch.all(p.grad == 0) for p in g.parameters())
 
 
+def test_optimizer_state_is_keyed_by_name_in_logical_shape():
+    """_FlatOptim.state_dict / load_state_dict (the momentum buffers DetectionCheckpointer saves with optimizer=, stage1_trainer.py:
+    129-148): one tensor per parameter name, in the parameter's logical [O,I,kh,kw] shape whatever the kernels' memory order, and the
+    round trip through another instance is exact; unknown / missing names and wrong shapes are refused."""
+    amd = _amd()
+    from afigan_amd.stage1 import _FlatOptim
+    def make():
+        g = amd.Generator(in_channels=16, n_residual_dense_blocks=2, growth_rate=4)
+        names = {id(p): n for n, p in g.named_parameters()}
+        return g, _FlatOptim([(names[id(p)], p) for p in g._ordered_params()], 1e-4, 0.0)
+    g, opt = make()
+    opt.flat_mom.copy_(torch.arange(opt.total, dtype=torch.float32))
+    sd = opt.state_dict()
+    assert set(sd) == {n for n, _ in g.named_parameters()} and list(sd) == opt.names
+    for n, p in g.named_parameters():
+        assert tuple(sd[n].shape) == tuple(p.shape) and sd[n].is_contiguous(), n
+    w = dict(g.named_parameters())["Generators.0.0.0.weight"]          # [O,I,3,3] stored as [O][3][3][I]
+    i = opt.names.index("Generators.0.0.0.weight")
+    O, I, kh, kw = w.shape
+    o, i_, y, x = 3, 5, 1, 2
+    assert sd["Generators.0.0.0.weight"][o, i_, y, x].item() == opt._offs[i] + ((o * kh + y) * kw + x) * I + i_
+    _, opt2 = make()
+    opt2.load_state_dict({k: v.clone() for k, v in sd.items()})
+    assert torch.equal(opt2.flat_mom, opt.flat_mom)
+    bad = dict(sd); bad.pop(opt.names[0])
+    with pytest.raises(KeyError):
+        opt2.load_state_dict(bad)
+    with pytest.raises(KeyError):
+        opt2.load_state_dict({**sd, "nope": torch.zeros(1)})
+    with pytest.raises(ValueError):
+        opt2.load_state_dict({**sd, opt.names[0]: torch.zeros(2, 2)})
+
+
 def _dp_worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
