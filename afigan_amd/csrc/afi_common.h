@@ -69,7 +69,16 @@ struct AfiPixGemm {
     // launcher fills stats_rows.  Taken only by the plain-store epilogue on 256 / 512 / 1024-channel outputs; null = off.
     double* stats; int stats_rows;
     int no_wcache;                             // Winograd form: B is a per-call scratch (its pointer says nothing about its contents): never cache its transform
+    // Small-map bf16x6 form (csrc/smallmap.hip, afi_pix_gemm_wk6): the weights pre-split into bf16 MFMA-fragment images,
+    // [N tile of 32][K stage of 32][n half][hi | mid | lo][lane] x 16 B, K stages in the kernel's own order (channel chunk, K phase, tap);
+    // null = the fp32-MFMA kernel reads B itself.  A problem on input channels [c_lo, c_lo + Ck) of a wider weight starts at stage
+    // bimg_stage0 = c_lo / 32 * ntaps of that weight's image; bimg_nstages = stages per N tile of the whole image.
+    const unsigned char* Bimg; int bimg_stage0, bimg_nstages;
 };
+#define AFI_WK6_STAGE_BYTES 6144
+// one weight (or weight view) to turn into such an image: the B addressing of AfiPixGemm (b_rc = 0: row n at B + n*b_sRow + tap*b_sTap + c;
+// b_rc = 1: row (kphase*Ck + c) at B + ...*b_sRow + tap*b_sTap + n), image bytes = ceil(Ncols/32) * ceil(Ck/32)*nKphase*ntaps * 6144
+struct AfiWk6ImgJob { const float* B; long long b_sRow, b_sTap; int Ncols, Ck, ntaps, nKphase, b_rc, pad0; unsigned char* dst; };
 
 // Parameters of the weight-gradient GEMM:  dW[co'][tap][ci] += alpha * sum_pix dY[pix][co'] * X[pix+tap][ci]
 struct AfiWgradGemm {

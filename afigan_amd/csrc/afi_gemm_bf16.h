@@ -13,23 +13,7 @@
 // six-product form).
 #pragma once
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ u32x2 afi_pack_bf16(f32x4 v) {
-    const bf16x4 h = __builtin_convertvector(v, bf16x4);
-    return __builtin_bit_cast(u32x2, h);
-}
-__device__ __forceinline__ bf16x8 afi_pack8_bf16(f32x4 lo, f32x4 hi) {
-    const bf16x4 a = __builtin_convertvector(lo, bf16x4), b = __builtin_convertvector(hi, bf16x4);
-    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-__device__ __forceinline__ f32x4 afi_bf16_residual(f32x4 v) {          // v - float(bf16(v)), exact in fp32
-    const bf16x4 h = __builtin_convertvector(v, bf16x4);
-    return v - __builtin_convertvector(h, f32x4);
-}
+#include "afi_bf16_split.h"
 
 // ------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM  dU[g][m][n] += sum_k Q[g][k][m] * V[g][k][n]: both operands are k-slow in memory, and the bf16 MFMA wants eight
@@ -45,16 +29,6 @@ __device__ __forceinline__ f32x4 afi_bf16_residual(f32x4 v) {          // v - fl
 // per CU: -1 % .. +6 % on the large shapes, -12 .. -27 % on the small ones, before the producers' 1.5x write bytes are counted.  Every
 // form holds 0.2 .. 0.27 of MFMA duty per resident wave; none reaches the NT kernel's four waves at 0.2 each.
 // ------------------------------------------------------------------------------------------------
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ bf16x8 afi_tr_frag(const unsigned char* base, int off_lo, int off_hi) {
-    typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + off_lo));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(base + off_hi));
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-
 template <int SPLIT, bool DB>
 __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmTN p, int ntile_m, int ntile_n, int kper) {
     constexpr int BM = 128, BN = 128, BK = 32, WN = 2, MI = 2, NI = 2;

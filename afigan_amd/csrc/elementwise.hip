@@ -141,6 +141,41 @@ __global__ __launch_bounds__(256) void afi_rdb_wgrad_unpack_kernel(const float* 
         *dst = d;
     }
 }
+// the same for several dense blocks in one launch (small maps: a launch per block costs more than the work): blockIdx.y = block
+struct AfiRdbUnpackMulti { const float* dWp; long long stride; float* dw[8][4]; };
+__global__ __launch_bounds__(256) void afi_rdb_wgrad_unpack_multi_kernel(const AfiRdbUnpackMulti t, int C, int G, float alpha) {
+    const int r = blockIdx.y;
+    const float* __restrict__ dWp = t.dWp + (long long)r * t.stride;
+    const int L = C + 4 * G;
+    const long long total = 4LL * G * 9 * (L >> 2);
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % (L >> 2)) * 4;
+        const long long rt = e / (L >> 2);
+        const int row = (int)(rt / 9), tap = (int)(rt - 9LL * row);
+        const int k = row / G, o = row - k * G;
+        const int cin = C + k * G;
+        if (c4 >= cin) continue;
+        float* dw = t.dw[r][k];
+        if (!dw) continue;
+        const f32x4 v = *(const f32x4*)(dWp + rt * L + c4);
+        f32x4* dst = (f32x4*)(dw + ((long long)o * 9 + tap) * cin + c4);
+        f32x4 d = *dst;
+        d += alpha * v;
+        *dst = d;
+    }
+}
+int afi_launch_rdb_wgrad_unpack_multi(const float* dWp, long long stride, float* const (*dw)[4], int nblocks, int C, int G, float alpha, hipStream_t st) {
+    if (!dWp || nblocks <= 0 || nblocks > 8 || C <= 0 || G <= 0 || (C & 3) || (G & 3)) return AFI_ERR_BAD_ARG;
+    AfiRdbUnpackMulti t;
+    t.dWp = dWp; t.stride = stride;
+    for (int r = 0; r < 8; ++r)
+        for (int k = 0; k < 4; ++k) t.dw[r][k] = r < nblocks ? dw[r][k] : nullptr;
+    const long long total = 4LL * G * 9 * ((C + 4 * G) >> 2);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(afi_rdb_wgrad_unpack_multi_kernel, dim3((unsigned)blocks, (unsigned)nblocks), dim3(256), 0, st, t, C, G, alpha);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
 int afi_launch_rdb_wgrad_unpack(const float* dWp, float* const dw[4], int C, int G, float alpha, hipStream_t st) {
     if (!dWp || C <= 0 || G <= 0 || (C & 3) || (G & 3)) return AFI_ERR_BAD_ARG;
     const long long total = 4LL * G * 9 * ((C + 4 * G) >> 2);

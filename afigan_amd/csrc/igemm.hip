@@ -617,8 +617,10 @@ const char* kKindNames[] = {
     "pix_gemm_wk (small-map pixel GEMM, K split inside the block; grouped launches included)",
     "wgrad_group (grouped weight gradients of a small-map backward pass)",
     "gemm_nt_bf16<128x128> (batched Winograd GEMM on the bf16 MFMA: bf16x6 / bf16x3 / bf16 operands, fp32 accumulate)",
-    "gemm_tn_bf16<128x128> (Winograd weight-gradient GEMM on the bf16 MFMA: bf16x6 / bf16x3 / bf16 operands, fp32 accumulate)"};   // one kind per kernel, as rocprofv3 lists them
-constexpr int kNumKinds = 19;
+    "gemm_tn_bf16<128x128> (Winograd weight-gradient GEMM on the bf16 MFMA: bf16x6 / bf16x3 / bf16 operands, fp32 accumulate)",
+    "wgrad_group6 (grouped weight gradients of a small-map backward pass on the bf16 MFMA, bf16x6 operands, fp32 accumulate)",
+    "pix_gemm_wk6 (small-map pixel GEMM on the bf16 MFMA, bf16x6 operands on pre-split weight images, fp32 accumulate; grouped launches included)"};   // one kind per kernel, as rocprofv3 lists them
+constexpr int kNumKinds = 21;
 hipEvent_t prof_event() {
     if (g_prof.used == g_prof.pool.size()) {
         hipEvent_t e;
@@ -799,6 +801,7 @@ int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, in
 int afi_launch_pix_gemm_sk(const AfiPixGemm& p, int b_rc, hipStream_t st);   // smallmap.hip
 int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
 int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);
+int afi_launch_wgrad6_group(const AfiWgradGemm* probs, int n, hipStream_t st);
 // grouped small-map launches, bracketed for the live roofline like every other GEMM launch
 int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st) {
     double fl = 0.0; long long m = 0; int nn = 0;
@@ -807,7 +810,9 @@ int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStrea
         fl += 2.0 * (double)M * probs[i].Ncols * probs[i].ntaps * probs[i].nKphase * probs[i].Ck;
         m = M; nn += probs[i].Ncols;
     }
-    ProfScope prof(st, 15, fl);
+    bool all6 = n > 0;
+    for (int i = 0; i < n; ++i) all6 = all6 && probs[i].Bimg != nullptr;
+    ProfScope prof(st, all6 ? 20 : 15, fl);
     prof.m = m; prof.n = nn; prof.k = n > 0 ? probs[0].ntaps * probs[0].nKphase * probs[0].Ck : 0;
     const int rc = afi_launch_pix_gemm_wk_group(probs, n, b_rc, st);
     if (rc == AFI_ERR_UNSUPPORTED) prof.cancel();          // nothing was launched: the caller falls back to one launch per problem
@@ -819,6 +824,16 @@ int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipS
     ProfScope prof(st, 16, fl);
     prof.m = n;
     return afi_launch_wgrad_group(probs, n, wide, st);
+}
+// the same group on the bf16 matrix cores (bf16x6); AFI_ERR_UNSUPPORTED = nothing launched (the caller falls back to the fp32 groups)
+int afi_launch_wgrad_gemm_group6(const AfiWgradGemm* probs, int n, hipStream_t st) {
+    double fl = 0.0;
+    for (int i = 0; i < n; ++i) fl += 2.0 * (double)probs[i].N * probs[i].H * probs[i].W * probs[i].Mrows * probs[i].Ncols * probs[i].ntaps;
+    ProfScope prof(st, 19, fl);
+    prof.m = n; prof.split = 6;
+    const int rc = afi_launch_wgrad6_group(probs, n, st);
+    if (rc == AFI_ERR_UNSUPPORTED) prof.cancel();
+    return rc;
 }
 int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     AfiPixGemm p = p_in;
@@ -841,7 +856,7 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     // small maps (csrc/smallmap.hip): long K -> the stream-K kernel (equal MFMA count per CU whatever the shape); short K (<= 16
     // stages, e.g. the 32-channel data gradients of the dense blocks) -> ONE launch of whole tiles, no split and no second pass
     if (smallM && p.b_sImg == 0) {
-        ProfScope prof(st, 15, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
+        ProfScope prof(st, p.Bimg ? 20 : 15, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
         prof.m = M; prof.n = p.Ncols; prof.k = p.ntaps * p.nKphase * p.Ck;
         const int rc = afi_launch_pix_gemm_sk(p, b_rc, st);
         if (rc != AFI_ERR_UNSUPPORTED) return rc;

@@ -19,13 +19,17 @@ int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, in
 int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
 int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // igemm.hip -> smallmap.hip
+int afi_launch_wgrad_gemm_group6(const AfiWgradGemm* probs, int n, hipStream_t st);            // the wide group on the bf16 matrix cores (bf16x6)
 int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st);
 int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
+long long afi_wk6_image_bytes(int Ncols, int Ck, int ntaps, int nKphase);                       // smallmap.hip: bf16x6 weight images of the small-map kernels
+int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st);
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
 int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st);
 int afi_launch_rdb_wgrad_unpack(const float* dWp, float* const dw[4], int C, int G, float alpha, hipStream_t st);
+int afi_launch_rdb_wgrad_unpack_multi(const float* dWp, long long stride, float* const (*dw)[4], int nblocks, int C, int G, float alpha, hipStream_t st);
 int afi_launch_rdb_xpart_pack(const float* const w[4], float* out, int C, int G, hipStream_t st);
 int afi_launch_lrelu_slice(AfiView v, int N, int H, int W, int nch, hipStream_t st);
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
@@ -99,7 +103,7 @@ struct SideStream {                                        // fork/join target o
 struct WinoWeightCache {
     float* buf = nullptr;
     long long floats = 0, used = 0;
-    struct Entry { const float* w; int f4, mode, O, I; long long off; } e[64];
+    struct Entry { const float* w; int f4, mode, O, I; long long off; } e[128];
     int n = 0;
 };
 struct WinoWgradAccum {
@@ -114,7 +118,7 @@ struct WinoWgradAccum {
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ 0, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
-                                            /*G_BATCH_GROWTH_GRADS*/ 1}};
+                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -255,11 +259,73 @@ static float* wino_wcache_slot(afi_ctx* cx, const float* w, int f4, int mode, in
         const WinoWeightCache::Entry& e = c.e[i];
         if (e.w == w && e.f4 == f4 && e.mode == mode && e.O == O && e.I == I) { hit = true; return c.buf + e.off; }
     }
-    if (c.n == 64 || c.used + need > c.floats) return nullptr;
+    if (c.n == 128 || c.used + need > c.floats) return nullptr;
     c.e[c.n++] = WinoWeightCache::Entry{w, f4, mode, O, I, c.used};
     float* slot = c.buf + c.used;
     c.used += need;
     return slot;
+}
+
+// ---- bf16x6 weight images of the small-map kernels (csrc/smallmap.hip: afi_pix_gemm_wk6).  A whole-net call on a small map lists the
+// weights its pixel GEMMs read (forward: K-contiguous; data gradients: row-contiguous), gets every image from the context's weight cache
+// when one is registered (built on first use, found again until the cache is invalidated) or builds it into the call's own workspace, all
+// missing ones in ONE launch, and attaches the image to each GEMM descriptor; a descriptor without an image runs on the fp32-MFMA kernel.
+#define AFI_WG6_WIDE 16                                    // wide weight-gradient problems of one small-map backward pass (7 + one per dense block)
+constexpr long long kWk6MaxPixels = 4096;                  // workspaces reserve the image arena for calls up to this many low-res pixels
+constexpr int kWk6MaxReq = 24;
+struct Wk6Req { const float* key; const float* src; int Ncols, Ck, nKphase, b_rc; long long b_sRow, b_sTap; };
+static inline long long wk6_req_floats(int Ncols, int Ck, int nKphase) { return align4((afi_wk6_image_bytes(Ncols, Ck, 9, nKphase) + 3) / 4); }
+struct Wk6Images {
+    bool on = false;
+    int n = 0;
+    struct Ent { const float* key; const unsigned char* img; int nstages; } e[kWk6MaxReq];
+    // the image of the weight `key`, for a problem that reads its input channels [c_lo, c_lo + g.Ck) (c_lo a multiple of 32)
+    void attach(AfiPixGemm& g, const float* key, int c_lo = 0) const {
+        if (!on || (c_lo & 31)) return;
+        for (int i = 0; i < n; ++i)
+            if (e[i].key == key) { g.Bimg = e[i].img; g.bimg_nstages = e[i].nstages; g.bimg_stage0 = (c_lo / 32) * g.ntaps; return; }
+    }
+};
+static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, float* arena, long long arena_floats, hipStream_t st) {
+    im.on = false; im.n = 0;
+    if (n > kWk6MaxReq) return AFI_OK;
+    AfiWk6ImgJob jobs[kWk6MaxReq];
+    int nj = 0;
+    long long used = 0;
+    for (int i = 0; i < n; ++i) {
+        const Wk6Req& r = reqs[i];
+        const long long need = wk6_req_floats(r.Ncols, r.Ck, r.nKphase);
+        bool hit = false;
+        float* slot = wino_wcache_slot(cx, r.key, /*tag: wk6 image, forward / data gradient*/ 4 + r.b_rc, r.nKphase, r.Ncols, r.Ck, need, hit);
+        if (!slot) {
+            if (!arena || used + need > arena_floats) { im.n = 0; return AFI_OK; }      // no room: the call stays on the fp32-MFMA kernels
+            slot = arena + used; used += need; hit = false;
+        }
+        if (!hit) jobs[nj++] = AfiWk6ImgJob{r.src, r.b_sRow, r.b_sTap, r.Ncols, r.Ck, 9, r.nKphase, r.b_rc, 0, (unsigned char*)slot};
+        im.e[im.n++] = Wk6Images::Ent{r.key, (const unsigned char*)slot, afi_cdiv(r.Ck, 32) * 9 * r.nKphase};
+    }
+    if (nj) AFI_TRY(afi_launch_wk6_images(jobs, nj, st));
+    im.on = true;
+    return AFI_OK;
+}
+static inline bool wk6_shapes_ok(int C, int G, int R) { return (C % 32) == 0 && (G % 32) == 0 && 5 * R + 4 <= kWk6MaxReq; }
+// the final conv on the up-sampled map (4x the pixels) stays on the small-map kernel while the map has at most this many pixels: at config 1
+// (50 x 68) the Winograd form is five launches of 9 .. 19 us (weight transform, bf16 split, input transform, GEMM, output transform)
+constexpr long long kWk6HiResMaxPixels = 4096;
+// arena floats of one call: every forward image / every data-gradient image of the interpolator
+static long long gen_wk6_fwd_floats(int C, int G, int R, long long P) {
+    if (P > kWk6MaxPixels || !wk6_shapes_ok(C, G, R)) return 0;
+    const int L = C + 4 * G;
+    long long f = 3 * wk6_req_floats(C, C, 1) + wk6_req_floats(4 * C, C, 1);         // head, trunk, final conv; conv-transpose
+    for (int k = 1; k <= 4; ++k) f += (long long)R * wk6_req_floats(G, C + (k - 1) * G, 1);
+    return f + (long long)R * wk6_req_floats(C, L, 1);
+}
+static long long gen_wk6_bwd_floats(int C, int G, int R, long long P) {
+    if (P > kWk6MaxPixels || !wk6_shapes_ok(C, G, R)) return 0;
+    const int L = C + 4 * G;
+    long long f = 3 * wk6_req_floats(C, C, 1) + wk6_req_floats(C, C, 4);             // head, trunk, final conv; conv-transpose
+    for (int k = 1; k <= 4; ++k) f += (long long)R * wk6_req_floats(C + (k - 1) * G, G, 1);
+    return f + (long long)R * wk6_req_floats(L, C, 1);
 }
 
 static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st,
@@ -426,7 +492,7 @@ static long long disc_wino_floats(const int F[4], int N, int H, int W) {
 
 extern "C" {
 
-int afi_abi_version(void) { return 3; }
+int afi_abi_version(void) { return 4; }
 
 const char* afi_status_string(int s) {
     switch (s) {
@@ -836,7 +902,7 @@ static long long gen_wino_floats(int C, int L, int N, int H, int W) {
 }
 struct GenWs {
     long long P, L;
-    long long o_wp, o_buf, o_t, o_a7, o_u, o_part, n_part, o_wino, n_wino, o_rdbx, n_rdbx, total;
+    long long o_wp, o_buf, o_t, o_a7, o_u, o_part, n_part, o_wino, n_wino, o_rdbx, n_rdbx, o_img, n_img, total;
 };
 static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenWs w;
@@ -853,6 +919,8 @@ static GenWs gen_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_wino = o; o += w.n_wino;
     w.n_rdbx = align4(4LL * G * 9 * C);                   // the growth convs' weights on the block input, packed [4G][3][3][C] (when no cache holds them)
     w.o_rdbx = o; o += (long long)n_rdb * w.n_rdbx;
+    w.n_img = gen_wk6_fwd_floats(C, G, n_rdb, w.P);         // small maps: bf16x6 weight images of the forward GEMMs (when no weight cache holds them)
+    w.o_img = o; o += w.n_img;
     w.total = o;
     return w;
 }
@@ -860,7 +928,7 @@ long long afi_generator_fwd_ws_floats(int C, int G, int n_rdb, int N, int H, int
 
 // backward scratch layout: [dU 4P*C][gA P*C][gB P*C][dBuf0 P*L][dBuf1 P*L][dWp 36*C*C][red]
 struct GenBwdWs {
-    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_rdbw, n_rdbw, o_rdbx, n_rdbx, o_red, o_part, n_part, o_wino, n_wino, o_wino2, total;
+    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_rdbw, n_rdbw, o_rdbx, n_rdbx, o_red, o_part, n_part, o_wino, n_wino, o_wino2, o_img, n_img, total;
 };
 static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenBwdWs w;
@@ -882,6 +950,8 @@ static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.n_wino = gen_wino_floats(C, (int)L, N, H, W);
     w.o_wino = o; o += w.n_wino;                          // data-gradient chain (main stream)
     w.o_wino2 = o; o += w.n_wino;                         // weight gradients (side stream on small maps)
+    w.n_img = gen_wk6_bwd_floats(C, G, n_rdb, P);           // small maps: bf16x6 weight images of the data-gradient GEMMs
+    w.o_img = o; o += w.n_img;
     w.total = o;
     return w;
 }
@@ -906,7 +976,7 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     float* const part_ = ws + l.o_part;
     const long long part_n_ = l.n_part;
     auto PG = [&](AfiPixGemm g, int b_rc) {
-        if (l.n_wino > 0 && wino_eligible(cx, g, b_rc)) return wino_run(cx, g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st);
+        if (!g.Bimg && l.n_wino > 0 && wino_eligible(cx, g, b_rc)) return wino_run(cx, g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st);
         g.partial = part_; g.partial_floats = part_n_;
         return afi_launch_pix_gemm(g, b_rc, st);
     };
@@ -928,9 +998,28 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
             AFI_TRY(afi_launch_convT_pack(prm->wT, wp, C, C, st));
         }
     }
+    // Small maps: the dense block in COLUMN-BATCHED form (below); under the default arithmetic its GEMMs, the head / trunk convs and the
+    // conv-transpose run on the bf16 matrix cores in the six-product form, on pre-split weight images (csrc/smallmap.hip)
+    const bool six = l.n_img > 0 && (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_BF16X6;
+    const bool batched = l.P < afi_opt(cx, AFI_OPT_G_SMALLMAP_MAX_PIXELS) || (six && l.P <= afi_opt(cx, AFI_OPT_G_SMALLMAP6_MAX_PIXELS));
+    Wk6Images im;
+    if (batched && six) {
+        Wk6Req rq[kWk6MaxReq];
+        int nr = 0;
+        rq[nr++] = Wk6Req{prm->w0, prm->w0, C, C, 1, 0, 9LL * C, C};
+        for (int r = 0; r < R; ++r) {
+            for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; rq[nr++] = Wk6Req{prm->rdb_w[r][k - 1], prm->rdb_w[r][k - 1], G, cin, 1, 0, 9LL * cin, cin}; }
+            rq[nr++] = Wk6Req{prm->rdb_w[r][4], prm->rdb_w[r][4], C, (int)l.L, 1, 0, 9LL * l.L, l.L};
+        }
+        rq[nr++] = Wk6Req{prm->w7, prm->w7, C, C, 1, 0, 9LL * C, C};
+        rq[nr++] = Wk6Req{prm->wT, wp, 4 * C, C, 1, 0, 9LL * C, C};           // (keyed by the parameter, built from its packed form above)
+        if (4 * l.P <= kWk6HiResMaxPixels) rq[nr++] = Wk6Req{prm->w9, prm->w9, C, C, 1, 0, 9LL * C, C};
+        AFI_TRY(wk6_build(cx, im, rq, nr, ws + l.o_img, l.n_img, st));
+    }
     {   // head conv + LReLU (generator_rdb.py:91-93) -> channels [0,C) of RDB 0's dense buffer
         AfiPixGemm g = conv_fwd_desc(x, N, H, W, C, prm->w0, prm->b0, C, buf(0));
         g.lrelu = 1;
+        im.attach(g, prm->w0);
         AFI_TRY(PG(g, 0));
     }
     // Small maps: the dense block in COLUMN-BATCHED form.  conv_k reads cat(x, y1 .. y_{k-1}); instead of five convs whose K grows
@@ -939,7 +1028,6 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     // into the convs that still need it; a conv's slice accumulates in place (beta = 1) and is activated by the step that completes
     // it.  Same multiply-adds as generator_rdb.py:64-71, summed in another order (fp32 rounding only).  AFI_OPT_G_SMALLMAP_MAX_PIXELS = 0:
     // conv by conv at every size.
-    const bool batched = l.P < afi_opt(cx, AFI_OPT_G_SMALLMAP_MAX_PIXELS);
     // (4G <= C: the Winograd scratch is sized for C -> C; every shape of the reference has G = 32, C = 256)
     const bool xbatch = !batched && l.P > afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS) && afi_opt(cx, AFI_OPT_G_BATCH_GROWTH_GRADS) != 0 &&
                         (4 * G <= C || l.n_wino == 0);
@@ -950,6 +1038,7 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
             AfiPixGemm g = conv_fwd_desc(ch_off(b, c_lo), N, H, W, nch, prm->rdb_w[r][4] + c_lo, nullptr, C, last ? t : buf(r + 1));
             g.b_sRow = 9LL * L; g.b_sTap = L;
             g.alpha = last ? rs * rs : rs;
+            im.attach(g, prm->rdb_w[r][4], c_lo);
             return g;
         };
         if (batched) {
@@ -963,6 +1052,7 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
                     g.b_sRow = 9LL * cin; g.b_sTap = cin;
                     g.beta = j == 0 ? 0.f : 1.f;
                     g.lrelu = (k == j + 1) ? 1 : 0;     // this step completes conv_k
+                    im.attach(g, prm->rdb_w[r][k - 1], c_lo);
                     probs[n++] = g;
                 }
                 AfiPixGemm g5 = conv5_desc(c_lo, nch);
@@ -1020,16 +1110,19 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     {   // trunk conv + LReLU (:97-99)
         AfiPixGemm g = conv_fwd_desc(t, N, H, W, C, prm->w7, prm->b7, C, a7);
         g.lrelu = 1;
+        im.attach(g, prm->w7);
         AFI_TRY(PG(g, 0));
     }
     {   // ConvTranspose2d k6 s2 p2 + LReLU (:101-105) as a 4-phase 3x3 conv with a pixel-shuffle store
         AfiPixGemm g = convT_fwd_desc(a7, N, H, W, C, wp, prm->bT, C, u);
         g.lrelu = 1;
+        im.attach(g, prm->wT);
         AFI_TRY(PG(g, 0));
     }
     {   // final conv (:107-108) + bilinear x2 skip of the input (:125,130) fused in the epilogue
         AfiPixGemm g = conv_fwd_desc(u, N, 2 * H, 2 * W, C, prm->w9, prm->b9, C, V(outv));
         g.R1 = x; g.r1s = 1.f; g.r1_lo = 0; g.r1_hi = C; g.r1_bilinear = 1;
+        im.attach(g, prm->w9);                              // (small maps only: no image was requested otherwise)
         AFI_TRY(PG(g, 0));
     }
     return AFI_OK;
@@ -1049,7 +1142,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     float* const part_ = scratch + s.o_part;
     const long long part_n_ = s.n_part;
     auto PG = [&](AfiPixGemm g, int b_rc) {
-        if (s.n_wino > 0 && wino_eligible(cx, g, b_rc)) return wino_run(cx, g, b_rc, scratch + s.o_wino, s.n_wino, part_, part_n_, st);
+        if (!g.Bimg && s.n_wino > 0 && wino_eligible(cx, g, b_rc)) return wino_run(cx, g, b_rc, scratch + s.o_wino, s.n_wino, part_, part_n_, st);
         g.partial = part_; g.partial_floats = part_n_;
         return afi_launch_pix_gemm(g, b_rc, st);
     };
@@ -1057,15 +1150,24 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // per tile shape (csrc/smallmap.hip: whole dW tiles per block, no split over pixels, no atomics, no zero-fill), instead of one
     // 7 .. 36-tile launch per layer on a side stream.  All their operands (dOut, dU, gA, gB, the per-block gradient buffers and the
     // saved activations) stay alive until the call returns.  AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS = 0 restores the per-layer launches.
-    const bool grouped = l.P <= afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS);
+    const bool bf6 = (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_BF16X6;
+    const bool grouped = l.P <= afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS) || (bf6 && s.n_img > 0 && l.P <= afi_opt(cx, AFI_OPT_G_SMALLMAP6_MAX_PIXELS));
     const bool batch_growth = !grouped && afi_opt(cx, AFI_OPT_G_BATCH_GROWTH_GRADS) != 0 && (4 * G <= C || s.n_wino == 0);   // larger maps: a block's four growth-conv weight gradients as one packed GEMM (below)
-    AfiWgradGemm wg_wide[12], wg_narrow[4 * AFI_MAX_RDB];
+    // Small maps under the default arithmetic: the data-gradient GEMMs on pre-split weight images and the grouped weight gradients on the
+    // bf16 matrix cores in the six-product form (csrc/smallmap.hip).  The four growth convs' weight gradients of a block then run as ONE
+    // 4G-row problem dy[C : C + 4G] (x) cat[0 : L] into a packed [4G][3][3][L] buffer (1.26x their products, on the 128 x 128 tile of that
+    // kernel instead of four 32-row problems on the fp32 one), unpacked after the group launch -- the large-map form of the same gradients.
+    const bool six = grouped && bf6;
+    const bool pack_growth6 = six && (4 * G) % 4 == 0 && R + 7 <= AFI_WG6_WIDE;
+    constexpr int kWide = 20;
+    static_assert(kWide >= AFI_WG6_WIDE, "table of deferred wide problems");
+    AfiWgradGemm wg_wide[kWide], wg_narrow[4 * AFI_MAX_RDB];
     AfiColsumProb cs[8];
     int n_wide = 0, n_narrow = 0, n_cs = 0;
     bool n_wide_has_convT = false;
     auto defer = [&](const AfiWgradGemm& g) {
         if (g.Mrows <= 32 && n_narrow < 4 * AFI_MAX_RDB) { wg_narrow[n_narrow++] = g; return AFI_OK; }
-        if (g.Mrows > 32 && n_wide < 12) { wg_wide[n_wide++] = g; return AFI_OK; }
+        if (g.Mrows > 32 && n_wide < kWide) { wg_wide[n_wide++] = g; return AFI_OK; }
         return afi_launch_wgrad_gemm(g, (hipStream_t)stream);       // table full (unusual shapes): launch it on its own
     };
     // weight gradient of a 3x3 conv: Winograd F(3x3,2x2) when both channel counts and the map are large enough, else direct
@@ -1099,17 +1201,47 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     Fork fk(cx, st, 4 * P <= kSideStreamMaxPixels && !grouped);
     hipStream_t sd = fk.side;                              // weight / bias gradients
     bool unpack_pending = false;
+    int packed_blocks = 0;                                 // dense blocks whose packed growth-conv gradient is in wg_wide (unpacked behind the group)
+    unsigned packed_mask = 0;
     auto flush = [&](bool last) {                          // launch what has been deferred so far (its operands are complete on `st`)
         if (!grouped || (!last && !fk.on)) return AFI_OK;
         if (n_wide + n_narrow + n_cs == 0 && !(last && unpack_pending)) return AFI_OK;
         fk.after_main();
-        AFI_TRY(afi_launch_wgrad_gemm_group(wg_wide, n_wide, 1, sd));
+        int rc6 = AFI_ERR_UNSUPPORTED;
+        if (six && n_wide > 0) rc6 = afi_launch_wgrad_gemm_group6(wg_wide, n_wide, sd);
+        if (rc6 == AFI_ERR_UNSUPPORTED) AFI_TRY(afi_launch_wgrad_gemm_group(wg_wide, n_wide, 1, sd));
+        else AFI_TRY(rc6);
         AFI_TRY(afi_launch_wgrad_gemm_group(wg_narrow, n_narrow, 0, sd));
         AFI_TRY(afi_launch_colsum_group(cs, n_cs, sd));
         if (unpack_pending && gr->wT && n_wide_has_convT) { AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd)); unpack_pending = false; }
+        if (packed_blocks > 0) {                           // every packed growth-conv gradient of the pass in ONE launch (a block that was not packed: null targets)
+            float* dws[AFI_MAX_RDB][4];
+            for (int r = 0; r < R; ++r)
+                for (int k = 0; k < 4; ++k) dws[r][k] = (packed_mask & (1u << r)) ? gr->rdb_w[r][k] : nullptr;
+            AFI_TRY(afi_launch_rdb_wgrad_unpack_multi(scratch + s.o_rdbw, s.n_rdbw, dws, R, C, G, 1.f, sd));
+            packed_mask = 0; packed_blocks = 0;
+        }
         n_wide = n_narrow = n_cs = 0; n_wide_has_convT = false;
         return AFI_OK;
     };
+    Wk6Images im;                                          // weight images of the data-gradient GEMMs (row-contiguous weights)
+    if (six && s.n_img > 0) {
+        Wk6Req rq[kWk6MaxReq];
+        int nr = 0;
+        rq[nr++] = Wk6Req{prm->wT, wp, C, C, 4, 1, 9LL * C, C};               // conv-transpose data gradient: K = (phase, Cout, tap) of the packed weight
+        rq[nr++] = Wk6Req{prm->w7, prm->w7, C, C, 1, 1, 9LL * C, C};
+        for (int r = 0; r < R; ++r) {
+            rq[nr++] = Wk6Req{prm->rdb_w[r][4], prm->rdb_w[r][4], L, C, 1, 1, 9LL * L, L};
+            for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; rq[nr++] = Wk6Req{prm->rdb_w[r][k - 1], prm->rdb_w[r][k - 1], cin, G, 1, 1, 9LL * cin, cin}; }
+        }
+        if (dx) rq[nr++] = Wk6Req{prm->w0, prm->w0, C, C, 1, 1, 9LL * C, C};
+        if (4 * P <= kWk6HiResMaxPixels) rq[nr++] = Wk6Req{prm->w9, prm->w9, C, C, 1, 1, 9LL * C, C};
+        AFI_TRY(wk6_build(cx, im, rq, nr, scratch + s.o_img, s.n_img, st));
+    }
+    // (the packed conv-transpose gradient and the packed growth-conv gradients are neighbours in the scratch: ONE fill for both)
+    const bool one_fill = pack_growth6 && gr->wT && s.o_rdbw == s.o_dwp + align4(36LL * C * C);
+    if (one_fill) { if (hipMemsetAsync(scratch + s.o_dwp, 0, sizeof(float) * (size_t)(align4(36LL * C * C) + (long long)R * s.n_rdbw), st) != hipSuccess) return AFI_ERR_LAUNCH; }
+    else if (pack_growth6 && hipMemsetAsync(scratch + s.o_rdbw, 0, sizeof(float) * (size_t)R * s.n_rdbw, st) != hipSuccess) return AFI_ERR_LAUNCH;
 
     // ---- final conv (generator_rdb.py:107-108)
     if (gr->w9) AFI_TRY(WG(dOut, u, N, 2 * H, 2 * W, C, C, gr->w9, 1.f, sd));
@@ -1117,12 +1249,13 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     {
         AfiPixGemm g = conv_dgrad_desc(dOut, N, 2 * H, 2 * W, C, prm->w9, C, dU);
         g.Z = u; g.z_lo = 0; g.z_hi = C;                       // through the LReLU after the conv-transpose
+        im.attach(g, prm->w9);                                 // (small maps: the small-map kernel instead of the five Winograd launches)
         AFI_TRY(PG(g, 1));
     }
     // ---- conv-transpose (:101-105)
     if (!grouped) fk.after_main();                                       // dU is complete
     if (gr->wT) {
-        if (hipMemsetAsync(dwp, 0, sizeof(float) * 36LL * C * C, sd) != hipSuccess) return AFI_ERR_LAUNCH;
+        if (!one_fill && hipMemsetAsync(dwp, 0, sizeof(float) * 36LL * C * C, sd) != hipSuccess) return AFI_ERR_LAUNCH;
         if (grouped) {
             AFI_TRY(defer(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f)));
             n_wide_has_convT = true; unpack_pending = true;
@@ -1137,6 +1270,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     {
         AfiPixGemm g = convT_dgrad_desc(dU, N, H, W, C, wp, C, gA);
         g.Z = a7; g.z_lo = 0; g.z_hi = C;
+        im.attach(g, prm->wT);
         AFI_TRY(PG(g, 1));
     }
     // ---- trunk conv (:97-99): gA = d(pre-activation of a7)
@@ -1144,7 +1278,11 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     if (gr->w7) AFI_TRY(WG(gA, t, N, H, W, C, C, gr->w7, 1.f, sd));
     if (gr->b7) AFI_TRY(CS(gA.p, P, C, C, gr->b7, sd));
     AFI_TRY(flush(false));                                 // final conv, conv-transpose and trunk gradients: all their operands exist now
-    AFI_TRY(PG(conv_dgrad_desc(gA, N, H, W, C, prm->w7, C, gB), 1));    // gB = dT
+    {
+        AfiPixGemm g = conv_dgrad_desc(gA, N, H, W, C, prm->w7, C, gB);  // gB = dT
+        im.attach(g, prm->w7);
+        AFI_TRY(PG(g, 1));
+    }
     // ---- ResidualInResidual (:27-30) and the RDB chain (:64-71), last block first
     AfiView Gt = gB;        // incoming gradient tensor, true gradient = gs * Gt
     float gs = rs;
@@ -1158,13 +1296,14 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
             g.alpha = rs * gs;
             g.R1 = Gt; g.r1s = gs; g.r1_lo = 0; g.r1_hi = C;           // identity path of the block
             g.Z = b; g.z_lo = C + 3 * G; g.z_hi = L;                   // conv4's LReLU: its slice is final after this kernel
+            im.attach(g, prm->rdb_w[r][4]);
             AFI_TRY(PG(g, 1));
         }
         for (int k = 4; k >= 1; --k) {
             const int cin = C + (k - 1) * G;
             AfiView dyk = ch_off(d, cin);                               // d(pre-activation of conv_k), G channels
             if (!grouped) fk.after_main();                               // dyk's slice was finalised by the previous dgrad
-            if (gr->rdb_w[r][k - 1] && !batch_growth) {
+            if (gr->rdb_w[r][k - 1] && !batch_growth && !pack_growth6) {
                 const AfiWgradGemm wd = conv_wgrad_desc(dyk, b, N, H, W, G, cin, gr->rdb_w[r][k - 1], 1.f);
                 AFI_TRY(grouped ? defer(wd) : afi_launch_wgrad_gemm(wd, sd));
             }
@@ -1187,7 +1326,14 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
                 g.R2 = gB; g.r2s = 1.f; g.r2_lo = 0; g.r2_hi = C;
                 g.Z = b; g.z_lo = 0; g.z_hi = C;
             }
+            im.attach(g, prm->rdb_w[r][k - 1]);
             AFI_TRY(PG(g, 1));
+        }
+        if (pack_growth6 && (gr->rdb_w[r][0] || gr->rdb_w[r][1] || gr->rdb_w[r][2] || gr->rdb_w[r][3])) {
+            // (every slice of d[C : C + 4G] is final now; each conv reads a prefix of b: rows paired with channels behind their conv's
+            //  input are computed and never read by the unpack)
+            AFI_TRY(defer(conv_wgrad_desc(ch_off(d, C), b, N, H, W, 4 * G, L, scratch + s.o_rdbw + (long long)r * s.n_rdbw, 1.f)));
+            packed_mask |= 1u << r; ++packed_blocks;
         }
         if (batch_growth) {
             // d[0:C) += sum_k W_k[:, :, :, 0:C]^T (*) dy_k: a 4G -> C data gradient on the packed weights [4G][3][3][C] -- Winograd-eligible at the
@@ -1232,6 +1378,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
         AFI_TRY(afi_launch_bilinear2x_bwd(dout, N, H, W, C, 0.f, dx, st));           // skip path (:125)
         AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->w0, C, dense_view(dx, H, W, C));
         g.beta = 1.f;
+        im.attach(g, prm->w0);
         AFI_TRY(PG(g, 1));
     }
     AFI_TRY(flush(true));                                  // head conv (and, without the side stream, everything deferred so far)

@@ -26,9 +26,11 @@ __device__ __attribute__((aligned(16))) float afi_zeros_smallmap[4] = {0.f, 0.f,
 
 #include "afi_epilogue.h"
 #include "afi_wgrad_body.h"
+#include "afi_bf16_split.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
+#include <type_traits>
 
 // stream-K partition: unit = one BK-deep K stage of one tile; tile t owns units [t*nK, (t+1)*nK); logical block b owns
 // [b*U/G, (b+1)*U/G).  G <= U, so no block is empty and the blocks that touch a tile are consecutive.  The launcher prefers a G
@@ -700,6 +702,313 @@ __global__ __launch_bounds__(512, 4) void afi_pix_gemm_wk_group_kernel(const Afi
     afi_wk_body<B_RC, true, false>(grp.p[pi], grp.wk[pi], t - grp.tile_start[pi]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// afi_pix_gemm_wk6: the same block structure (one 32 x 32 output tile, eight waves each multiplying an eighth of K, partial tiles meeting
+// in LDS, fused epilogue) on the bf16 matrix cores in the six-product form of csrc/afi_gemm_bf16.h: every fp32 operand is x = hi + mid + lo
+// exactly (three bf16), the six products of relative size >= 2^-16 are summed smallest first into fp32 accumulators.  fp32 results at
+// 6/16 of the fp32-MFMA pipe time: 24 v_mfma_f32_16x16x32_bf16 (384 cycles) per 32-deep stage of a wave instead of 16
+// v_mfma_f32_32x32x2_f32 (1024 cycles).
+//   * B (weights) arrives PRE-SPLIT in fragment order (AfiPixGemm::Bimg, built by afi_wk6_image_kernel once per weight and pass, or once
+//     per optimizer step when the caller registers a weight cache): a lane's operand of one (n half, part) is ONE 16-byte load straight
+//     into the register the MFMA reads -- no LDS, no conversion, and the same image serves the forward (K-contiguous weights) and the
+//     data gradient (row-contiguous weights: the builder does the transposition), so the kernel has no B_RC variant.
+//   * A (activations / gradients, fp32 in memory as before) is gathered in FRAGMENT layout too: lane (l15, lq) loads the eight consecutive
+//     channels 8 lq .. 8 lq + 7 of pixel row l15 (two 16-byte buffer loads per 16-row half) and splits them in registers
+//     (afi_pack8_bf16 / afi_bf16_residual).  A wave's split work is amortised over its 32 columns only -- 16 elements per lane and stage
+//     against 24 MFMAs -- which is why B must not be split here as well (vector issue, not the matrix pipe, would then set the pace).
+//   * No LDS in the K loop at all; the 36 KB of the block hold only the eight partial tiles of the reduction.
+// One register set: the next stage's A gather is issued as soon as the split has consumed the current one, the next B fragments behind the
+// MFMAs that read the current ones; four waves per SIMD (two blocks per CU) cover what remains of the latency.
+// ------------------------------------------------------------------------------------------------
+#ifndef AFI_WK6_ABLATE
+#define AFI_WK6_ABLATE 0                                   // tools/micro/wk6_bench.cpp only: 1 no MFMAs, 2 no A gather, 4 no B loads, 8 no split (wrong results)
+#endif
+template <bool DIAG, int NW = 8>
+__device__ __forceinline__ void afi_wk6_body(const AfiPixGemm& p, const AfiWkArgs& sk, const int lb) {
+    constexpr int BK = AFI_BK, LDK = BK + 4, PATCH = 32 * LDK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (DIAG) { if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + 6] = __builtin_amdgcn_s_memrealtime(); }
+    AFI_STAMP(0);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int M = sk.M, HW = sk.HW;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A.p, 0, 0x7FFFFFF0, 0x00020000);
+    const int tile_n = (int)afi_udiv((unsigned)lb, (unsigned)sk.ntile_m, sk.rcp_ntm), tile_m = lb - tile_n * sk.ntile_m;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int kc0 = wave_u * sk.nK / NW, kc1 = (wave_u + 1) * sk.nK / NW;   // this wave's K stages
+    const int nK = kc1 - kc0;
+    // this tile's part of the weight image: stage s of the problem at + s * 6144 bytes; a lane's fragment (n half ni, part) at
+    // + (3 ni + part) * 1024 + 16 lane.  Addressed as a buffer (32-bit offsets; the launcher checks the image stays below 2 GB)
+    const unsigned char* img = p.Bimg + ((long long)tile_n * p.bimg_nstages + p.bimg_stage0) * AFI_WK6_STAGE_BYTES;
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, 0x7FFFFFF0, 0x00020000);
+    const int last_stage = sk.nK - 1;
+
+    // ---- A gather, COALESCED: lane (r8 = lane >> 3, q8 = lane & 7) loads the 16 bytes q8 of the 128-byte channel chunk of pixel rows
+    //      m0 + r8 + 8 i (i = 0..3): eight adjacent lanes read one whole cache line.  (Gathering straight into the MFMA's fragment layout
+    //      -- lane (l15, lq) = row l15, channels 8 lq .. + 7 -- makes every group of adjacent lanes touch 16 different lines: measured with
+    //      tools/micro/wk6_bench.cpp, that gather alone cost 12.7 of the kernel's 27.9 us at 850 x 384 x 2304, against 5 us for the split
+    //      and the MFMAs.)  The fragments are formed through the wave's own LDS patch, as in the fp32 kernel above: no block barrier.
+    const int q8 = lane & 7, r8 = lane >> 3;
+    unsigned a_off[4], a_mask[4];
+#pragma unroll
+    for (int i2 = 0; i2 < 4; ++i2) {
+        const int m = m0 + r8 + 8 * i2;
+        const unsigned im = afi_udiv((unsigned)m, (unsigned)HW, sk.rcp_HW);
+        const int rem = m - (int)im * HW;
+        const int y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W), x = rem - y * p.W;
+        unsigned mk = 1u;
+        if (p.ntaps == 9) {
+            const unsigned cm = ((unsigned)(x - p.a_sgn) < (unsigned)p.W ? 1u : 0u) | 2u | ((unsigned)(x + p.a_sgn) < (unsigned)p.W ? 4u : 0u);
+            mk = ((unsigned)(y - p.a_sgn) < (unsigned)p.H ? cm : 0u) | (cm << 3) | ((unsigned)(y + p.a_sgn) < (unsigned)p.H ? (cm << 6) : 0u);
+        }
+        a_mask[i2] = m < M ? mk : 0u;
+        a_off[i2] = 4u * (unsigned)((m < M ? (int)im : 0) * (int)p.A.sN + (y * p.a_up) * (int)p.A.sH + (x * p.a_up) * (int)p.A.sW + 4 * q8);
+    }
+    // STAGE ROTATION: wave w of M tile m walks its K stages starting at stage (m mod nK) and wraps, so the blocks of one N tile (27 M
+    // tiles at config 1, most of them on one XCD) do not ask for the same weight-image stage at the same time.  Same products, another
+    // (fixed) order of the fp32 sums per M tile.  (Measured neutral at config 1 -- the kernel is not bound by first touches of the image --
+    //  and kept: it spreads the requests of an XCD over the L2's channels.)
+    const int rot = nK > 1 ? (int)((unsigned)tile_m % (unsigned)nK) : 0;
+    const int kq0 = (int)afi_udiv((unsigned)kc0, (unsigned)p.ntaps, sk.rcp_taps);
+    const int w_tap = kc0 - kq0 * p.ntaps, w_kph = kq0 & (p.nKphase - 1), w_c0 = (kq0 >> sk.kph_shift) * BK;   // the wave's first stage (wrap target)
+    const int kq = (int)afi_udiv((unsigned)(kc0 + rot), (unsigned)p.ntaps, sk.rcp_taps);
+    int k_tap = kc0 + rot - kq * p.ntaps, k_kph = kq & (p.nKphase - 1), k_c0 = (kq >> sk.kph_shift) * BK;   // NEXT stage to gather
+    int k_abs = kc0 + rot;                                 // ... and its index in the problem's stage order
+    auto stage_advance = [&]() {
+        if (++k_tap == p.ntaps) {
+            k_tap = 0;
+            if (++k_kph == p.nKphase) { k_kph = 0; k_c0 += BK; }
+        }
+        if (++k_abs == kc1) { k_abs = kc0; k_tap = w_tap; k_kph = w_kph; k_c0 = w_c0; }
+    };
+    float* As = smem + wave_u * PATCH;                     // this wave's patch: [32 rows][LDK] fp32 (later its partial output tile)
+    u32x4 a_raw[4], b_raw[2][3];
+    // ONE register set per operand.  A: stage s + 2 is in flight in a_raw while stage s + 1 sits in the LDS patch and stage s is multiplied;
+    // B: the weight fragments of an n half are re-requested (next stage) right behind the twelve MFMAs that read them.
+    // (Loads are issued unconditionally -- counted vmcnt waits need a path-independent count: a masked A lane reads out of range = zeros,
+    //  a B load past the problem's last stage re-reads that stage and is never used.)
+    auto load_a = [&](bool more) {
+        int dy = 0, dx = 0;
+        if (p.ntaps == 9) { dy = k_tap / 3 - 1; dx = k_tap - (k_tap / 3) * 3 - 1; }
+        const int a_delta = 4 * ((dy * p.a_sgn * p.a_up + (k_kph >> 1)) * (int)p.A.sH + (dx * p.a_sgn * p.a_up + (k_kph & 1)) * (int)p.A.sW + k_c0);
+        unsigned mm = more ? 1u : 0u;
+        asm volatile("" : "+v"(mm));
+        const unsigned okc = (k_c0 + 4 * q8) < p.Ck ? mm : 0u;                        // (only the last channel chunk can be partial)
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+            const unsigned ok = (a_mask[i2] >> k_tap) & okc;
+            if constexpr ((AFI_WK6_ABLATE & 2) == 0)
+                a_raw[i2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, ok ? a_off[i2] + (unsigned)a_delta : 0xFFFFFFFFu, 0, 0);
+            else { const unsigned o = ok ? a_off[i2] + (unsigned)a_delta : 0xFFFFFFFFu; a_raw[i2] = u32x4{o, o, o, o}; }
+        }
+        stage_advance();
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) *(u32x4*)(As + (r8 + 8 * i2) * LDK + 4 * q8) = a_raw[i2];
+    };
+    u32x4 fa[2][2];                                        // fragment layout: row 16 mi + l15, channels 8 lq + 4 h .. + 3
+    auto read_frags = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) fa[mi][h] = *(const u32x4*)(As + (16 * mi + l15) * LDK + 8 * lq + 4 * h);
+    };
+    auto lds_order = [&]() {                               // (lgkmcnt only) a wave's LDS instructions execute in order; this pins the compiler's order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    };
+    auto load_b = [&](int ni, int stage_abs) {             // (ni: compile-time at every call site)
+        const int st = stage_abs < last_stage ? stage_abs : last_stage;
+        const int soff = __builtin_amdgcn_readfirstlane(st) * AFI_WK6_STAGE_BYTES;
+#pragma unroll
+        for (int pt = 0; pt < 3; ++pt) {
+            if constexpr ((AFI_WK6_ABLATE & 4) == 0)
+                b_raw[ni][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (unsigned)(16 * lane + (3 * ni + pt) * 1024), soff, 0);
+            else { const unsigned o = (unsigned)soff + lane; b_raw[ni][pt] = u32x4{o, o, o, o}; }
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto mfma = [](u32x4 x, u32x4 y, f32x4 c) -> f32x4 {
+        if constexpr ((AFI_WK6_ABLATE & 1) != 0) { asm volatile("" :: "v"(x), "v"(y)); return c; }
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
+    };
+
+    AFI_STAMP(1);
+    const int kb_first = k_abs;
+    load_a(0 < nK);                                        // stage 0 (k_abs moves on to the second stage)
+    AFI_STAMP(2);
+    store_a();
+    lds_order();
+    read_frags();
+    int kb_next = k_abs;                                   // the stage a_raw is about to receive: its weight fragments follow the current MFMAs
+    load_a(1 < nK);                                        // stage 1
+    // (the first weight fragments are requested BEHIND the second gather, the order every later stage has: the loop's counted waits are the
+    //  merge of the entry and the back-edge states, and with the fragments requested first every stage waited for them before its stores)
+    load_b(0, kb_first);
+    load_b(1, kb_first);
+    AFI_STAMP(3);
+    for (int kc = 0; kc < nK; ++kc) {
+        u32x4 ah[2], am[2], al[2];                          // packed bf16 pairs: element 2 j in the low half of word j
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 c = __builtin_bit_cast(f32x4, fa[mi][h]);
+                unsigned h0, m0_, l0, h1, m1_, l1;
+                if constexpr ((AFI_WK6_ABLATE & 8) == 0) {
+                    afi_split3_pair(c[0], c[1], h0, m0_, l0);
+                    afi_split3_pair(c[2], c[3], h1, m1_, l1);
+                } else { h0 = fa[mi][h][0]; h1 = fa[mi][h][1]; m0_ = fa[mi][h][2]; m1_ = fa[mi][h][3]; l0 = h0 ^ m0_; l1 = h1 ^ m1_; }
+                ah[mi][2 * h] = h0; ah[mi][2 * h + 1] = h1; am[mi][2 * h] = m0_; am[mi][2 * h + 1] = m1_; al[mi][2 * h] = l0; al[mi][2 * h + 1] = l1;
+            }
+        // the fragments of stage kc are split: the patch is free for stage kc + 1 (gathered one stage ago), a_raw for stage kc + 2
+        store_a();
+        const int kb_this = kb_next;
+        kb_next = k_abs;
+        load_a(kc + 2 < nK);
+        lds_order();
+        read_frags();                                      // stage kc + 1, in flight under the MFMAs below
+        // per accumulator: smallest terms first; consecutive MFMAs alternate between the two accumulators of the n half
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma(al[mi], b_raw[ni][0], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma(ah[mi], b_raw[ni][2], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma(am[mi], b_raw[ni][1], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma(am[mi], b_raw[ni][0], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma(ah[mi], b_raw[ni][1], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma(ah[mi], b_raw[ni][0], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(ni, kb_this);                           // this half's fragments of the next stage
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    lds_order();                                           // (the patch becomes this wave's partial output tile below)
+    AFI_STAMP(4);
+    // ---- the eight partial tiles meet in LDS (each wave writes its own patch), then 256 threads sum them and run the fused epilogue;
+    //      the epilogue's own operands are requested first (their global round trip runs under the LDS write, the barrier and the reads)
+    const int e_rl = tid >> 3, e_c4 = tid & 7;
+    const int e_m = m0 + e_rl, e_col = n0 + 4 * e_c4;
+    const bool e_on = tid < 256 && e_m < M && e_col < p.Ncols;
+    AfiEpiPre epre; int e_img = 0, e_y = 0, e_x = 0;
+    if (e_on) {
+        afi_gfloat* zpage = (afi_gfloat*)afi_zeros;
+        asm volatile("" : "+v"(zpage));
+        const unsigned im = afi_udiv((unsigned)e_m, (unsigned)HW, sk.rcp_HW);
+        const int rem = e_m - (int)im * HW;
+        e_y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W); e_x = rem - e_y * p.W; e_img = (int)im;
+        epre = afi_epilogue_prefetch(p, e_img, e_y, e_x, e_col, zpage);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) As[(16 * mi + 4 * lq + r) * LDK + 16 * ni + l15] = acc[mi][ni][r];
+    __syncthreads();
+    if (e_on) {
+        f32x4 v = *(const f32x4*)(smem + e_rl * LDK + 4 * e_c4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += *(const f32x4*)(smem + w * PATCH + e_rl * LDK + 4 * e_c4);     // fixed order: bit-reproducible
+        afi_epilogue_finish(p, epre, e_img, e_y, e_x, v);
+    }
+    AFI_STAMP(5);
+    AFI_STAMP(8);
+    if constexpr (DIAG) { if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + 7] = __builtin_amdgcn_s_memrealtime(); }
+}
+template <bool DIAG = false>
+__global__ __launch_bounds__(512, 4) void afi_pix_gemm_wk6_kernel(const AfiPixGemm p, const AfiWkArgs sk) {
+    afi_wk6_body<DIAG>(p, sk, afi_xcd_logical_id());
+}
+__global__ __launch_bounds__(512, 4) void afi_pix_gemm_wk6_group_kernel(const AfiWkGroup grp) {
+    const int t = afi_xcd_logical_id();
+    int pi = 0;
+    while (pi + 1 < grp.nprob && t >= grp.tile_start[pi + 1]) ++pi;     // (uniform)
+    afi_wk6_body<false>(grp.p[pi], grp.wk[pi], t - grp.tile_start[pi]);
+}
+
+// Weight images of afi_pix_gemm_wk6.  One thread per (job, N tile, K stage, n half, lane): the lane's eight consecutive k of column
+// n = 32 tile + 16 half + (lane & 15) -- k = 8 (lane >> 4) .. + 7 of the stage's 32-channel chunk at its (K phase, tap) -- read through the
+// job's B addressing (zeros beyond Ncols / Ck), split, and stored as the three 16-byte fragments the kernel loads.
+#define AFI_WK6_MAXJOBS 24
+struct AfiWk6ImgJobs {
+    int njobs, pad_;
+    int unit_start[AFI_WK6_MAXJOBS + 1];                   // prefix sums of (N tiles x stages) per job
+    int nstages[AFI_WK6_MAXJOBS];
+    AfiWk6ImgJob j[AFI_WK6_MAXJOBS];
+};
+__global__ __launch_bounds__(256) void afi_wk6_image_kernel(const AfiWk6ImgJobs jobs) {
+    const int u = (int)blockIdx.x * 2 + (int)(threadIdx.x >> 7);
+    if (u >= jobs.unit_start[jobs.njobs]) return;
+    int ji = 0;
+    while (ji + 1 < jobs.njobs && u >= jobs.unit_start[ji + 1]) ++ji;
+    const AfiWk6ImgJob& jb = jobs.j[ji];
+    const int nst = jobs.nstages[ji];
+    const int local = u - jobs.unit_start[ji];
+    const int tile_n = local / nst, stage = local - tile_n * nst;
+    const int tap = stage % jb.ntaps, kq = stage / jb.ntaps;
+    const int kph = kq % jb.nKphase, chunk = kq / jb.nKphase;
+    const int t = threadIdx.x & 127, ni = t >> 6, lane = t & 63, l15 = lane & 15, lq = lane >> 4;
+    const int n = tile_n * 32 + 16 * ni + l15, c = chunk * 32 + 8 * lq;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    if (n < jb.Ncols) {
+        if (!jb.b_rc) {
+            const float* src = jb.B + (long long)n * jb.b_sRow + (long long)tap * jb.b_sTap + c;
+            if (c + 4 <= jb.Ck) v0 = *(const f32x4*)src;
+            if (c + 8 <= jb.Ck) v1 = *(const f32x4*)(src + 4);
+        } else {
+            const float* src = jb.B + ((long long)kph * jb.Ck + c) * jb.b_sRow + (long long)tap * jb.b_sTap + n;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (c + j < jb.Ck) v0[j] = src[(long long)j * jb.b_sRow];
+                if (c + 4 + j < jb.Ck) v1[j] = src[(long long)(4 + j) * jb.b_sRow];
+            }
+        }
+    }
+    unsigned char* dst = jb.dst + ((long long)tile_n * nst + stage) * AFI_WK6_STAGE_BYTES + (3 * ni) * 1024 + 16 * lane;
+    const f32x4 r0 = afi_bf16_residual(v0), r1 = afi_bf16_residual(v1);
+    *(bf16x8*)dst = afi_pack8_bf16(v0, v1);
+    *(bf16x8*)(dst + 1024) = afi_pack8_bf16(r0, r1);
+    *(bf16x8*)(dst + 2048) = afi_pack8_bf16(afi_bf16_residual(r0), afi_bf16_residual(r1));
+}
+long long afi_wk6_image_bytes(int Ncols, int Ck, int ntaps, int nKphase) {
+    return (long long)afi_cdiv(Ncols, 32) * afi_cdiv(Ck, AFI_BK) * ntaps * nKphase * AFI_WK6_STAGE_BYTES;
+}
+int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st) {
+    for (int done = 0; done < n;) {
+        const int cnt = (n - done) < AFI_WK6_MAXJOBS ? (n - done) : AFI_WK6_MAXJOBS;
+        AfiWk6ImgJobs tb;
+        tb.njobs = cnt; tb.pad_ = 0;
+        long long units = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const AfiWk6ImgJob& j = jobs[done + i];
+            if (!j.B || !j.dst || j.Ncols <= 0 || j.Ck <= 0 || (j.ntaps != 1 && j.ntaps != 9) || (j.nKphase != 1 && j.nKphase != 4)) return AFI_ERR_BAD_ARG;
+            if ((j.Ck & 3) || (!j.b_rc && ((j.b_sRow | j.b_sTap) & 3)) || (((uintptr_t)j.B | (uintptr_t)j.dst) & 15)) return AFI_ERR_UNSUPPORTED;   // float4 reads, 16-byte stores
+            tb.j[i] = j;
+            tb.nstages[i] = afi_cdiv(j.Ck, AFI_BK) * j.ntaps * j.nKphase;
+            tb.unit_start[i] = (int)units;
+            units += (long long)afi_cdiv(j.Ncols, 32) * tb.nstages[i];
+            if (units > 0x3fffffffLL) return AFI_ERR_UNSUPPORTED;
+        }
+        for (int i = cnt; i <= AFI_WK6_MAXJOBS; ++i) tb.unit_start[i] = (int)units;
+        hipLaunchKernelGGL(afi_wk6_image_kernel, dim3((unsigned)((units + 1) / 2)), dim3(256), 0, st, tb);
+        done += cnt;
+    }
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // fills the kernel's argument block; AFI_ERR_UNSUPPORTED when the problem does not fit the kernel's 32-bit index math
 static int wk_prepare(const AfiPixGemm& p, bool b_rc, AfiWkArgs& wk) {
     const long long M = (long long)p.N * p.H * p.W;
@@ -722,6 +1031,13 @@ static int wk_prepare(const AfiPixGemm& p, bool b_rc, AfiWkArgs& wk) {
     if ((long long)wk.ntile_m * wk.ntile_n * wk.ntile_m >= (1LL << 32)) return AFI_ERR_UNSUPPORTED;
     return AFI_OK;
 }
+// the bf16x6 kernel takes a problem when it carries a weight image whose tile range stays inside the kernel's 32-bit buffer offsets
+static bool wk6_ok(const AfiPixGemm& p, const AfiWkArgs& wk) {
+    if (!p.Bimg || p.bimg_nstages <= 0 || p.bimg_stage0 < 0 || (((uintptr_t)p.Bimg) & 15)) return false;
+    if (p.bimg_stage0 + wk.nK > p.bimg_nstages) return false;
+    if (p.Ck & 3) return false;
+    return (long long)p.bimg_nstages * AFI_WK6_STAGE_BYTES < 0x7FFFFFF0LL;
+}
 // up to AFI_WK_MAXP simultaneous small-map GEMMs in one launch; validates everything before it launches anything
 int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st) {
     if (n < 1 || n > AFI_WK_MAXP) return AFI_ERR_UNSUPPORTED;
@@ -736,6 +1052,12 @@ int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipSt
         tiles += grp.wk[i].ntile_m * grp.wk[i].ntile_n;
     }
     for (int i = n; i <= AFI_WK_MAXP; ++i) grp.tile_start[i] = tiles;
+    bool all6 = true;
+    for (int i = 0; i < n; ++i) all6 = all6 && wk6_ok(probs[i], grp.wk[i]);
+    if (all6) {
+        hipLaunchKernelGGL(afi_pix_gemm_wk6_group_kernel, dim3((unsigned)tiles), dim3(512), sizeof(float) * 8 * 32 * (AFI_BK + 4), st, grp);
+        return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+    }
     const size_t lds = sizeof(float) * 8 * (2 * 32 * (AFI_BK + 4));
     if (b_rc) hipLaunchKernelGGL((afi_pix_gemm_wk_group_kernel<true>), dim3((unsigned)tiles), dim3(512), lds, st, grp);
     else hipLaunchKernelGGL((afi_pix_gemm_wk_group_kernel<false>), dim3((unsigned)tiles), dim3(512), lds, st, grp);
@@ -749,6 +1071,12 @@ static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
     { const int rc = wk_prepare(p, B_RC, wk); if (rc != AFI_OK) return rc; }
     const long long G = (long long)wk.ntile_m * wk.ntile_n;
     constexpr int LDK = AFI_BK + 4;
+    if (wk6_ok(p, wk)) {                                   // bf16x6 on the pre-split weight image (no B_RC distinction: the image holds the k-contiguous fragments)
+        // (measured and dropped: sixteen waves per tile -- 1024-thread blocks, four waves per SIMD -- for the grids of at most one block per CU
+        //  (216 tiles, K = 2304 / 9216): 13.4 against 12.3 us and 37.5 against 37.5; the loop is bound by vector issue, not by latency)
+        hipLaunchKernelGGL((afi_pix_gemm_wk6_kernel<false>), dim3((unsigned)G), dim3(512), sizeof(float) * 8 * 32 * LDK, st, p, wk);
+        return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+    }
     const size_t lds = sizeof(float) * 8 * (2 * 32 * LDK);
     // one register set, two blocks per CU: measured faster than the two-set variant at every grid size (1.06 -> 1.01 ms at config 1)
     hipLaunchKernelGGL((afi_pix_gemm_wk_kernel<B_RC, true>), dim3((unsigned)G), dim3(512), lds, st, p, wk);
@@ -835,6 +1163,301 @@ static int launch_wgrad_group_sk(const AfiWgradGemm* probs, int n, hipStream_t s
         sk_cut(units, bpc, upb, blocks);
         grp.units_per_block = upb; grp.total_units = (int)units;
         hipLaunchKernelGGL((afi_wgrad_group_sk_kernel<BM, BN, WM, WN>), dim3((unsigned)blocks), dim3(64 * WM * WN), sizeof(float) * AFI_BK * (BM + BN), st, grp);
+        done += cnt;
+    }
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16x6 form of the grouped weight gradients (128 x 128 tiles): the gather of afi_wgrad_gemm_range (both operands pixel-major, the X
+// rows shifted by the tap and masked at the map border) around the LDS images and transposed fragment reads of afi_gemm_tn_bf16_kernel
+// (csrc/afi_gemm_bf16.h): a stage's 32 pixels x 128 channels of dY and of X are split into three bf16 parts on their way from the
+// prefetch registers into LDS ([32 k][128 columns] per part, 16-byte chunks swizzled), fragments come out k-fast through
+// ds_read_b64_tr_b16, and the six products of relative size >= 2^-16 run on v_mfma_f32_32x32x16_bf16, smallest first, into fp32
+// accumulators -- fp32-grade sums at 6/16 of the fp32-MFMA pipe time.  Same stream-K walk, same store / atomic rule as the fp32 kernel.
+// ------------------------------------------------------------------------------------------------
+#ifndef AFI_WG6_ABLATE
+#define AFI_WG6_ABLATE 0                                   // tools/micro/wg6_bench.cpp only: 1 no MFMAs, 2 no gather, 4 no split, 8 no fragment reads, 16 no result stores
+#endif
+__device__ __forceinline__ void afi_wgrad6_gemm_range(const AfiWgradGemm& p, int ntile_m, int ntile_n, int t, long long k_begin, long long k_end, bool use_atomic) {
+    constexpr int BM = 128, BN = 128, BK = AFI_BK, NT = 256, WN = 2, MI = 2, NI = 2;
+    constexpr int TILE = BK * BM * 2;                      // one bf16 image: [32 k][128 columns], 8 KB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [dY: hi | mid | lo][X: hi | mid | lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    typedef const __attribute__((address_space(1))) float gfloat;
+    typedef const __attribute__((address_space(1))) f32x4 gf32x4;
+    gfloat* zpage = (gfloat*)afi_zeros;
+    asm volatile("" : "+v"(zpage));
+    int tap, tile_n, tile_m;
+    tap = t % p.ntaps; t /= p.ntaps;                       // taps fastest: the 9 blocks of one (m, n) tile share dY and most of X in L2
+    tile_n = t % ntile_n; tile_m = t / ntile_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    int dy = 0, dx = 0;
+    if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+    const int HW = p.H * p.W;
+    if (k_begin >= k_end) return;                          // (whole block: EXEC stays full for the transposed reads below)
+    const int nK = (int)((k_end - k_begin + BK - 1) / BK);
+
+    // ---- loader: thread = the eight channels 8 c8 .. + 7 of the pixels (k rows) kr and kr + 16 of a stage, for both operands: two 16-byte
+    //      buffer loads per operand and row (16 adjacent lanes read 512 contiguous bytes of one pixel), and per part ONE 16-byte LDS store
+    //      of a whole chunk.  Everything is branch-free -- validity is an out-of-range offset (the buffer returns zeros), the walk over the
+    //      pixels advances (y, x) and the two offsets by selects -- and the descriptor fields the loop needs are copied out of the kernel
+    //      argument block first: with the per-pass branches, `while` wraps and argument re-loads of the first version the empty stage
+    //      skeleton cost 57 of the kernel's 162 us (tools/micro/wg6_bench.cpp).
+    const int c8 = tid & 15, kr = tid >> 4;
+    const int pW = p.W, pH = p.H, xs = p.x_stride, pxH = p.xH, pxW = p.xW;
+    const int a_col = m0 + 8 * c8;
+    int a_ph = 0, a_ch = a_col;
+    if (p.dy_up == 2) { a_ph = a_col / p.CoutPhase; a_ch = a_col - a_ph * p.CoutPhase; }
+    // (Mrows, Ncols and CoutPhase are multiples of 4; the two float4 halves of the 8-channel group are validated separately)
+    const unsigned a_ok0 = a_col < p.Mrows ? 1u : 0u, a_ok1 = a_col + 4 < p.Mrows ? 1u : 0u;
+    const int b_col = n0 + 8 * c8;
+    const unsigned b_ok0 = b_col < p.Ncols ? 1u : 0u, b_ok1 = b_col + 4 < p.Ncols ? 1u : 0u;
+    // second half of the dY group: the next four channels, or (pixel-shuffled dY whose phase ends inside the group) the next phase's first
+    int a_half = 4;
+    if (p.dy_up == 2 && a_ch + 4 >= p.CoutPhase) {
+        const int ph1 = a_ph + 1;
+        a_half = ((ph1 >> 1) - (a_ph >> 1)) * (int)p.DY.sH + ((ph1 & 1) - (a_ph & 1)) * (int)p.DY.sW - a_ch;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.DY.p, 0, 0x7FFFFFF0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.X.p, 0, 0x7FFFFFF0, 0x00020000);
+    // (32-bit element offsets: the launcher admits small-map problems only, whose operands span less than 2^28 elements)
+    const int a_eH = p.dy_up * (int)p.DY.sH, a_eW = p.dy_up * (int)p.DY.sW;
+    const int adv_y = BK / pW, adv_x = BK - adv_y * pW;
+    const int a_adv = adv_y * a_eH + adv_x * a_eW, a_wrapx = a_eH - pW * a_eW, a_wrapy = (int)p.DY.sN - pH * a_eH;
+    const int b_eH = xs * (int)p.X.sH, b_eW = xs * (int)p.X.sW;
+    const int b_adv = adv_y * b_eH + adv_x * b_eW, b_wrapx = b_eH - pW * b_eW, b_wrapy = (int)p.X.sN - pH * b_eH;
+    const bool single_wrap = adv_y + 1 <= pH;              // (uniform) a stage of 32 pixels crosses at most one image boundary
+    int a_off[2], b_off[2], py[2], px[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long pix = k_begin + kr + 16 * i;
+        const int n = (int)(pix / HW); const int rem = (int)(pix - (long long)n * HW);
+        py[i] = rem / pW; px[i] = rem - py[i] * pW;
+        a_off[i] = n * (int)p.DY.sN + py[i] * a_eH + px[i] * a_eW + (a_ph >> 1) * (int)p.DY.sH + (a_ph & 1) * (int)p.DY.sW + a_ch;
+        b_off[i] = n * (int)p.X.sN + py[i] * b_eH + dy * (int)p.X.sH + px[i] * b_eW + dx * (int)p.X.sW + b_col;
+    }
+    int k_left = (int)(k_end - k_begin) - kr;              // pixels of this thread's first row still inside the range (row i: - 16 i)
+    u32x4 a_reg[2][2], b_reg[2][2];
+    auto prefetch = [&](bool more) {
+        unsigned mmv = more ? 1u : 0u;
+        asm volatile("" : "+v"(mmv));                      // (loads stay unconditional: counted vmcnt waits)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned in = (k_left - 16 * i > 0) ? mmv : 0u;
+            const int yy = py[i] * xs + dy, xx = px[i] * xs + dx;
+            const unsigned inb = ((unsigned)yy < (unsigned)pxH && (unsigned)xx < (unsigned)pxW) ? in : 0u;
+            const unsigned ao = 4u * (unsigned)a_off[i], bo = 4u * (unsigned)b_off[i];
+            if constexpr ((AFI_WG6_ABLATE & 2) == 0) {
+                a_reg[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (in & a_ok0) ? ao : 0xFFFFFFFFu, 0, 0);
+                a_reg[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (in & a_ok1) ? ao + 4u * (unsigned)a_half : 0xFFFFFFFFu, 0, 0);
+                b_reg[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (inb & b_ok0) ? bo : 0xFFFFFFFFu, 0, 0);
+                b_reg[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (inb & b_ok1) ? bo + 16u : 0xFFFFFFFFu, 0, 0);
+            } else {
+                a_reg[i][0] = u32x4{ao, ao, ao, ao}; a_reg[i][1] = u32x4{in, ao, ao, ao}; b_reg[i][0] = u32x4{bo, bo, bo, bo}; b_reg[i][1] = u32x4{inb, bo, bo, bo};
+            }
+            if (single_wrap) {                             // (uniform) the common case, by selects
+                px[i] += adv_x; py[i] += adv_y; a_off[i] += a_adv; b_off[i] += b_adv;
+                const bool wx = px[i] >= pW;
+                px[i] -= wx ? pW : 0; py[i] += wx ? 1 : 0; a_off[i] += wx ? a_wrapx : 0; b_off[i] += wx ? b_wrapx : 0;
+                const bool wy = py[i] >= pH;
+                py[i] -= wy ? pH : 0; a_off[i] += wy ? a_wrapy : 0; b_off[i] += wy ? b_wrapy : 0;
+            } else {                                       // maps of fewer than 32 + W pixels
+                px[i] += adv_x; py[i] += adv_y; a_off[i] += a_adv; b_off[i] += b_adv;
+                if (px[i] >= pW) { px[i] -= pW; ++py[i]; a_off[i] += a_wrapx; b_off[i] += b_wrapx; }
+                while (py[i] >= pH) { py[i] -= pH; a_off[i] += a_wrapy; b_off[i] += b_wrapy; }
+            }
+        }
+        k_left -= BK;
+    };
+    int st_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = kr + 16 * i;
+        st_off[i] = 256 * r + 16 * (c8 ^ (((r & 3) << 2) | ((r >> 2) & 3)));
+    }
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int op = 0; op < 2; ++op) {               // dY, then X
+                const f32x4 v0 = __builtin_bit_cast(f32x4, op ? b_reg[i][0] : a_reg[i][0]), v1 = __builtin_bit_cast(f32x4, op ? b_reg[i][1] : a_reg[i][1]);
+                unsigned char* base = smem_b + op * 3 * TILE + st_off[i];
+                if constexpr ((AFI_WG6_ABLATE & 4) != 0) {
+                    const u32x4 u0 = __builtin_bit_cast(u32x4, v0), u1 = __builtin_bit_cast(u32x4, v1);
+                    *(u32x4*)base = u0; *(u32x4*)(base + TILE) = u1; *(u32x4*)(base + 2 * TILE) = u32x4{u0[0], u1[0], u0[2], u1[2]};
+                    continue;
+                }
+                u32x4 h, m, l;                              // (pair-wise split: one v_cvt_pk_bf16_f32 per part and pair, afi_bf16_split.h)
+                unsigned hh, mm_, ll;
+                afi_split3_pair(v0[0], v0[1], hh, mm_, ll); h[0] = hh; m[0] = mm_; l[0] = ll;
+                afi_split3_pair(v0[2], v0[3], hh, mm_, ll); h[1] = hh; m[1] = mm_; l[1] = ll;
+                afi_split3_pair(v1[0], v1[1], hh, mm_, ll); h[2] = hh; m[2] = mm_; l[2] = ll;
+                afi_split3_pair(v1[2], v1[3], hh, mm_, ll); h[3] = hh; m[3] = mm_; l[3] = ll;
+                *(u32x4*)base = h; *(u32x4*)(base + TILE) = m; *(u32x4*)(base + 2 * TILE) = l;
+            }
+    };
+    // transposed-read addresses of k-step 0 (k-step 1: + 16 rows = + 4096 bytes), as in afi_gemm_tn_bf16_kernel
+    int fa_off[MI][2], fb_off[NI][2];
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int r = 8 * (g >> 1) + 4 * rd + q;
+            const int swz = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa_off[mi][rd] = 256 * r + 16 * ((4 * (wm * MI + mi) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = 3 * TILE + 256 * r + 16 * ((4 * (wn * NI + ni) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+        }
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto frag = [&](const unsigned char* base, int o0, int o1) -> bf16x8 {
+        if constexpr ((AFI_WG6_ABLATE & 8) != 0) { const unsigned v = (unsigned)(o0 + o1) + (unsigned)(size_t)base; return __builtin_bit_cast(bf16x8, u32x4{v, v, v, v}); }
+        return afi_tr_frag(base, o0, o1);
+    };
+    auto mm = [](bf16x8 x, bf16x8 y, f32x16 c) -> f32x16 {
+        if constexpr ((AFI_WG6_ABLATE & 1) != 0) { asm volatile("" :: "v"(x), "v"(y)); return c; }
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
+    };
+    prefetch(true);
+    for (int kc = 0; kc < nK; ++kc) {
+        stage_store();
+        __syncthreads();
+        prefetch(kc + 1 < nK);                             // the next stage's gather runs under this stage's 48 MFMAs
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 ah[MI], am[MI], al[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                ah[mi] = frag(smem_b + 4096 * s2, fa_off[mi][0], fa_off[mi][1]);
+                am[mi] = frag(smem_b + 4096 * s2 + TILE, fa_off[mi][0], fa_off[mi][1]);
+                al[mi] = frag(smem_b + 4096 * s2 + 2 * TILE, fa_off[mi][0], fa_off[mi][1]);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {              // one column block's fragments at a time (register budget: three blocks per CU)
+                const bf16x8 bh = frag(smem_b + 4096 * s2, fb_off[ni][0], fb_off[ni][1]);
+                const bf16x8 bm = frag(smem_b + 4096 * s2 + TILE, fb_off[ni][0], fb_off[ni][1]);
+                const bf16x8 bl = frag(smem_b + 4096 * s2 + 2 * TILE, fb_off[ni][0], fb_off[ni][1]);
+                // per accumulator smallest terms first; consecutive MFMAs alternate between the two accumulators
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(al[mi], bh, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bl, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(am[mi], bm, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(am[mi], bh, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bm, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bh, acc[mi][ni]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < p.Mrows) {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int col = n0 + (wn * NI + ni) * 32 + lr;
+                    if (col < p.Ncols) {
+                        float* dst = p.DW + (long long)row * p.dw_sRow + (long long)tap * p.dw_sTap + col;
+                        const float v = p.alpha * acc[mi][ni][r];
+                        if constexpr ((AFI_WG6_ABLATE & 16) != 0) { if (v == 123.456f) *dst = v; }
+                        else if (use_atomic) atomicAdd(dst, v); else *dst += v;
+                    }
+                }
+            }
+        }
+}
+__global__ __launch_bounds__(256, 3) void afi_wgrad6_group_sk_kernel(const AfiWgradGroupSK grp) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+    const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);      // neighbours in the unit order share an XCD's L2
+    const int u = b * grp.units_per_block;
+    int u_end = u + grp.units_per_block;
+    if (u_end > grp.total_units) u_end = grp.total_units;
+    afi_sk_walk(grp.unit_start, grp.nst, grp.nprob, u, u_end, [&](int pi, int tile, int s0, int s1, bool shared) {
+        const AfiWgradGemm& p = grp.g[pi];
+        const long long P = (long long)p.N * p.H * p.W;
+        const long long k0 = (long long)s0 * AFI_BK, k1 = (long long)s1 * AFI_BK < P ? (long long)s1 * AFI_BK : P;
+        afi_wgrad6_gemm_range(p, grp.ntile_m[pi], grp.ntile_n[pi], tile, k0, k1, shared);
+    });
+}
+// the grouped weight gradients of one small-map backward pass on the bf16 matrix cores (six-product form); 3x3 / 1x1 problems only
+int afi_launch_wgrad6_group(const AfiWgradGemm* probs, int n, hipStream_t st) {
+    if (n <= 0) return AFI_OK;
+    for (int i = 0; i < n; ++i) {                          // 3x3 / 1x1 problems whose operands the kernel's 32-bit element offsets reach
+        const AfiWgradGemm& g = probs[i];
+        auto span = [&](const AfiView& v, int up, int hh, int ww) { return v.sN * g.N + v.sH * ((long long)hh * up + 2) + v.sW * ((long long)ww * up + 2) + 4096; };
+        if (g.ntaps > 9 || g.dy_sTap != 0 || g.x_sTap != 0) return AFI_ERR_UNSUPPORTED;
+        if (g.DY.sN < 0 || g.DY.sH < 0 || g.DY.sW < 0 || g.X.sN < 0 || g.X.sH < 0 || g.X.sW < 0) return AFI_ERR_UNSUPPORTED;
+        if (span(g.DY, g.dy_up, g.H, g.W) >= (1LL << 28) || span(g.X, g.x_stride, g.xH, g.xW) >= (1LL << 28)) return AFI_ERR_UNSUPPORTED;   // buffer offsets in bytes
+        if ((((uintptr_t)g.DY.p | (uintptr_t)g.X.p) & 15) || ((g.DY.sN | g.DY.sH | g.DY.sW | g.X.sN | g.X.sH | g.X.sW) & 3)) return AFI_ERR_UNSUPPORTED;       // 16-byte loads
+    }
+    constexpr int bpc = 3;
+    AfiWgradGroupSK grp;
+    int done = 0;
+    while (done < n) {
+        const int cnt = (n - done) < AFI_WG_MAXP ? (n - done) : AFI_WG_MAXP;
+        grp.nprob = cnt;
+        // TILE-ALIGNED RUNS.  Equal runs cut anywhere make nearly every dW tile shared by two runs, and a shared tile is added by fp32
+        // atomics: ~100 MB of them per config-1 pass, all issued when the runs end together, against a chip-wide atomic rate of ~1.3 TB/s
+        // -- half of the kernel's time.  Most tiles of a pass have the SAME stage count (every low-res conv: ceil(850 / 32) = 27), so the
+        // run length is a multiple of that count and those problems go first: each of their tiles is then owned whole by one run and
+        // STORED; only the problems with another stage count (the conv on the up-sampled map) are cut across tiles and add atomically.
+        int nst_of[AFI_WG_MAXP]; long long tiles_of[AFI_WG_MAXP];
+        for (int i = 0; i < cnt; ++i) {
+            const AfiWgradGemm& g = probs[done + i];
+            if ((g.Ncols & 3) || (g.Mrows & 3) || (g.dy_up == 2 && (g.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;
+            nst_of[i] = afi_cdiv((long long)g.N * g.H * g.W, AFI_BK);
+            tiles_of[i] = (long long)afi_cdiv(g.Mrows, 128) * afi_cdiv(g.Ncols, 128) * g.ntaps;
+        }
+        int nst_c = nst_of[0]; long long best = -1;
+        for (int i = 0; i < cnt; ++i) {
+            long long t = 0;
+            for (int j = 0; j < cnt; ++j) if (nst_of[j] == nst_of[i]) t += tiles_of[j];
+            if (t > best) { best = t; nst_c = nst_of[i]; }
+        }
+        int order[AFI_WG_MAXP], no = 0;
+        for (int i = 0; i < cnt; ++i) if (nst_of[i] == nst_c) order[no++] = i;
+        for (int i = 0; i < cnt; ++i) if (nst_of[i] != nst_c) order[no++] = i;
+        long long units = 0;
+        for (int k = 0; k < cnt; ++k) {
+            const int i = order[k];
+            const AfiWgradGemm& g = probs[done + i];
+            grp.g[k] = g;
+            grp.nst[k] = nst_of[i];
+            grp.ntile_m[k] = (short)afi_cdiv(g.Mrows, 128); grp.ntile_n[k] = (short)afi_cdiv(g.Ncols, 128);
+            grp.unit_start[k] = (int)units;
+            units += tiles_of[i] * nst_of[i];
+            if (units > 0x7fffffffLL) return AFI_ERR_UNSUPPORTED;
+        }
+        for (int i = cnt; i <= AFI_WG_MAXP; ++i) grp.unit_start[i] = (int)units;
+        int blocks, upb;
+        {
+            const long long slots = 256LL * bpc;
+            long long mult = nst_c >= 4 ? 1 : (4 + nst_c - 1) / nst_c;               // no run shorter than four stages
+            while ((units + mult * nst_c - 1) / (mult * nst_c) > slots) ++mult;      // all runs resident at once (a second, partly filled round costs a whole run)
+            upb = (int)(mult * nst_c);
+            blocks = (int)((units + upb - 1) / upb);
+            if (blocks * 4 < slots) sk_cut(units, bpc, upb, blocks);                 // tiny groups: fill the chip instead (every tile shared)
+        }
+        grp.units_per_block = upb; grp.total_units = (int)units;
+        hipLaunchKernelGGL(afi_wgrad6_group_sk_kernel, dim3((unsigned)blocks), dim3(256), 6 * 8192, st, grp);
         done += cnt;
     }
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;

@@ -114,7 +114,10 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                * an operand: what they take from the block input is ONE conv C -> 4G on packed weights [4G][3][3][C] (forward) and ONE
                                                * data gradient 4G -> C (backward), their weight gradients ONE 4G-row GEMM (packed, then unpacked) -- all Winograd-
                                                * eligible at the reference's widths; 0: four G-column / G-row GEMMs per block, as generator_rdb.py:64-71 reads */
-#define AFI_OPT_COUNT 9
+#define AFI_OPT_G_SMALLMAP6_MAX_PIXELS 9      /* 4096: under AFI_DTYPE_BF16X6 (and channel counts that are multiples of 32) interpolator calls of up to this many
+                                               * low-res pixels run the small-map schedule -- column-batched dense blocks, grouped weight gradients, every conv on the
+                                               * bf16x6 small-map kernels with pre-split weight images (csrc/smallmap.hip) -- whatever options 5..7 say; 0: options 5..7 alone */
+#define AFI_OPT_COUNT 10
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over

@@ -186,3 +186,75 @@ def test_stage1_step_full_size_layer_by_layer_fp64(amd):
                 assert (got - want).abs().max().item() <= 1e-3 * want.abs().max().item(), ("G", n, oy, ox)
     l1 = (tr[:, :, :H, :W].double() - hrs[0].double()).abs().mean().item()
     assert abs(m["content_loss_p2"] - l1) <= 1e-5 * l1, (m["content_loss_p2"], l1)
+
+
+def test_discriminator_backward_full_size_sampled_fp64(amd):
+    """The P2-level discriminator backward of configs[1] (2 x 256 x 200 x 336, default arithmetic: F(4x4) Winograd data and weight
+    gradients on the bf16x6 GEMMs) against fp64 evaluations of the defining sums from the tensors the call itself saved -- the one
+    reduction length no whole-tensor oracle comparison reaches (feature_patch_discriminator.py:32-41):
+
+      * dW[o, i, ky, kx] = sum over all 134,400 pixels of  g_n[pix, o] * a_{n-1}[pix + tap, i]  for 64 random (o, i, ky, kx) of each of the
+        three 3x3 convs (g_n = d loss / d conv output n, left in the backward scratch; a_{n-1} = the saved input activation), i.e. the
+        F(3x3,4x4) weight-gradient GEMM with K = 538,624 tile rows per transform point;
+      * dx[n, i, y, x] = sum over (o, ky, kx) of  g_0[n, o, y + 1 - ky, x + 1 - kx] * w_0[o, i, ky, kx]  at 64 positions (corners, tile seams,
+        random), all 256 channels each: the F(4x4) data gradient.
+
+    Bar: 1e-4 of the tensor's max-norm."""
+    import ctypes as C
+    from afigan_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(0)
+    N, H, W = 2, 200, 336
+    P = N * H * W
+    F = (256, 512, 1024, 1024)
+    D = amd.Discriminator().cuda().train()
+    net = D.Discriminators[0]
+    gen = torch.Generator(device="cuda").manual_seed(31)
+    x = ops.new_pixel_major(N, 256, H, W, "cuda"); x.normal_(generator=gen)
+    dl = torch.randn((N, 1, H, W), device="cuda", generator=gen) / P
+    params = net._ordered_params()
+    prm, _keep = net._param_struct(params)
+    grads = [torch.zeros_like(q) for q in params]
+    gst, _ = net._param_struct(grads, already_packed=True, grads=True)
+    Fa = (C.c_int * 4)(*F)
+    nf, nb = lib.afi_discriminator_fwd_ws_floats(Fa, N, H, W), lib.afi_discriminator_bwd_ws_floats(Fa, N, H, W)
+    ws, sc = torch.empty(nf, device="cuda"), torch.empty(nb, device="cuda")
+    logits = torch.empty((N, 1, H, W), device="cuda")
+    dx = ops.new_pixel_major(N, 256, H, W, "cuda")
+    st = ops.stream_ptr()
+    _lib.call("afi_discriminator_fwd", C.byref(prm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), 1, C.c_void_p(ws.data_ptr()), nf, st)
+    _lib.call("afi_discriminator_bwd", C.byref(prm), C.byref(gst), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()), C.c_void_p(dl.data_ptr()),
+              C.c_void_p(dx.data_ptr()), C.c_void_p(sc.data_ptr()), nb, st)
+    torch.cuda.synchronize()
+    off = (C.c_longlong * 12)()
+    _lib.check(lib.afi_discriminator_ws_layout(Fa, N, H, W, off), "layout")
+    rng = np.random.default_rng(7)
+    g_off = [0, P * F[1], P * F[1] + P * F[2]]                # DiscBwdWs: one d(conv output) buffer per block, left in place by the call
+    wnames = {id(p): k for k, p in D.named_parameters()}
+    for n in range(3):
+        ci, co = F[n], F[n + 1]
+        g_n = sc[g_off[n]:g_off[n] + P * co].view(N, H, W, co)
+        a_in = x.permute(0, 2, 3, 1) if n == 0 else ws[off[3 + n - 1]:off[3 + n - 1] + P * ci].view(N, H, W, ci)
+        wparam = [p for p in params if wnames[id(p)] == f"Discriminators.0.{n}.0.weight"][0]
+        dW = grads[[id(p) for p in params].index(id(wparam))]                 # logical [co, ci, 3, 3]
+        scale = dW.double().abs().max().item()
+        assert scale > 0
+        worst = 0.0
+        for _ in range(64):
+            o, i, ky, kx = int(rng.integers(co)), int(rng.integers(ci)), int(rng.integers(3)), int(rng.integers(3))
+            gcol = g_n[..., o].double()                                        # [N, H, W]
+            acol = torch.nn.functional.pad(a_in[..., i].double(), (1, 1, 1, 1))[:, ky:ky + H, kx:kx + W]
+            ref = (gcol * acol).sum().item()
+            worst = max(worst, abs(dW[o, i, ky, kx].item() - ref) / scale)
+        assert worst <= 1e-4, ("wgrad", n, worst)
+    # the F(4x4) data gradient of block 0: every input channel at sampled pixels
+    g0 = torch.nn.functional.pad(sc[0:P * F[1]].view(N, H, W, F[1]).double(), (0, 0, 1, 1, 1, 1))
+    w0 = [p for p in params if wnames[id(p)] == "Discriminators.0.0.0.weight"][0].detach().double()     # [512, 256, 3, 3]
+    scale = dx.double().abs().max().item()
+    worst = 0.0
+    pos = _sample_positions(rng, N, H, W, 60) + [(0, 3, 3), (0, 4, 4), (1, 199, 335), (1, 196, 332)]
+    for (n_, yy, xx) in pos:
+        dpatch = g0[n_, yy:yy + 3, xx:xx + 3, :].flip(0, 1)                    # index (ky, kx) -> g0[y + 1 - ky, x + 1 - kx], [3, 3, 512]
+        ref = torch.einsum("yxo,oiyx->i", dpatch, w0)
+        worst = max(worst, (dx[n_, :, yy, xx].double() - ref).abs().max().item() / scale)
+    assert worst <= 1e-4, ("dgrad", worst)
