@@ -147,7 +147,7 @@ def rehearse_launch(args, world, rank):
     raise SystemExit(0 if ok and same is not False else 1)
 
 
-KERNEL_TOKENS = ("gemm_nt", "gemm_tn", "pix_gemm_wk", "pix_gemm", "wgrad")
+KERNEL_TOKENS = ("gemm_nt", "gemm_tn", "pix_gemm_wk6", "pix_gemm_wk", "pix_gemm", "wgrad6", "wgrad")
 
 
 def committed_traffic(fname, dom_kernel):
@@ -155,7 +155,7 @@ def committed_traffic(fname, dom_kernel):
     measurement of the same command when there is one (the newest profiles/rNN/<fname>), else None.  The record names the kernel it was
     taken on -- another dominant kernel nulls it -- and is tied to the kernel SOURCE it was measured on by a sha256: a later edit of that
     file nulls it too."""
-    for rnd in ("r03", "r02", "r01"):
+    for rnd in ("r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", rnd, fname)
         if not os.path.exists(tpath):
             continue
@@ -248,11 +248,16 @@ def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
             kinds.append({"kernel": lib.afi_profile_kind_name(k).decode(), "launches_per_iter": out3[0] / prof_iters, "us_per_iter": out3[1] * 1e3 / prof_iters,
                           "avg_launch_us": out3[1] * 1e3 / out3[0], "tflops": out3[2] / (out3[1] * 1e-3) / 1e12 if out3[1] > 0 else 0.0})
     kinds.sort(key=lambda r: -r["us_per_iter"])
+    # a kernel's own roof: the bf16x6 kernels (names say "bf16") multiply six bf16 MFMAs per fp32-equivalent product, the others use the fp32 MFMA
+    for r in kinds:
+        r["peak"] = gemm_peak("bf16x6") if "bf16" in r["kernel"] else PEAK_FP32_MFMA_TFLOPS
+        r["frac"] = r["tflops"] / r["peak"]
     roof = None
     if kinds:
         d0 = kinds[0]
-        roof = {"bound": "mfma", "kernel": d0["kernel"], "achieved": d0["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": d0["tflops"] / PEAK_FP32_MFMA_TFLOPS, "launches": d0["launches_per_iter"], "avg_launch_us": d0["avg_launch_us"],
+        roof = {"bound": "mfma", "kernel": d0["kernel"], "achieved": d0["tflops"], "peak": d0["peak"], "unit": "TFLOP/s",
+                "frac": d0["frac"], "launches": d0["launches_per_iter"], "avg_launch_us": d0["avg_launch_us"],
+                "achieved_over_fp32_mfma_peak": d0["tflops"] / PEAK_FP32_MFMA_TFLOPS,
                 "gemm_launches_per_iter": sum(r["launches_per_iter"] for r in kinds), "gemm_us_per_iter": sum(r["us_per_iter"] for r in kinds),
                 "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in kinds],
                 "traffic": committed_traffic("traffic_cfg1_dominant_kernel.json", d0["kernel"]) if (N, H, W) == (1, 25, 34) else None}
