@@ -78,7 +78,25 @@ struct AfiPixGemm {
 #define AFI_WK6_STAGE_BYTES 6144
 // one weight (or weight view) to turn into such an image: the B addressing of AfiPixGemm (b_rc = 0: row n at B + n*b_sRow + tap*b_sTap + c;
 // b_rc = 1: row (kphase*Ck + c) at B + ...*b_sRow + tap*b_sTap + n), image bytes = ceil(Ncols/32) * ceil(Ck/32)*nKphase*ntaps * 6144
-struct AfiWk6ImgJob { const float* B; long long b_sRow, b_sTap; int Ncols, Ck, ntaps, nKphase, b_rc, pad0; unsigned char* dst; };
+// stage_off / nstages_img (0 = this job's own stage count): the job fills stages [stage_off, stage_off + its stages) of an image whose N tiles
+// are nstages_img stages apart -- several weights side by side along K in ONE image (the dense block's four growth convs as one data gradient)
+struct AfiWk6ImgJob { const float* B; long long b_sRow, b_sTap; int Ncols, Ck, ntaps, nKphase, b_rc, stage_off; unsigned char* dst; int nstages_img, pad1; };
+
+// Fused growth-conv chain of one dense block on a small map (csrc/smallmap.hip: afi_rdb_chain6_kernel): three dependent 3x3 convs with
+// 32-channel outputs -- y2, y3, y4 of ResidualDenseBlock.forward, or the data gradients g3, g2, g1 of its backward -- in ONE launch.  A block
+// owns an 8 x 8 pixel tile, keeps region 0 (the chain's 32-channel input: y1 / g4) with a 3-pixel halo in LDS and recomputes each link on
+// a halo that shrinks by one (12 x 12, 10 x 10, 8 x 8): phase p multiplies regions 0..p (K chunks of 32 channels, 9 taps each, weights
+// from bf16x6 images) into the next region, adds `partial`, applies LeakyReLU (mode 0) or the LeakyReLU' factor of Z (mode 1), zeroes what
+// lies outside the map (the convs' zero padding), and the owner stores its own 8 x 8 pixels to `out`.
+struct AfiChain6Phase {
+    const unsigned char* img[3]; int stage0[3]; int pad_;    // K chunk ci (region ci): weight-image stages [stage0, stage0 + 9) of an N tile of 32
+    AfiView partial, Z, out;                                 // 32-channel views on the map (p points at the slice's first channel)
+};
+struct AfiChain6 {
+    int N, H, W, a_sgn, mode, tiles_y, tiles_x, pad_;
+    AfiView src0, copy0;                                     // region 0's source; optional copy of its own pixels (null p: off)
+    AfiChain6Phase ph[3];
+};
 
 // Parameters of the weight-gradient GEMM:  dW[co'][tap][ci] += alpha * sum_pix dY[pix][co'] * X[pix+tap][ci]
 struct AfiWgradGemm {

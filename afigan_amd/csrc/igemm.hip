@@ -859,7 +859,7 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
         ProfScope prof(st, p.Bimg ? 20 : 15, 2.0 * (double)M * p.Ncols * p.ntaps * p.nKphase * p.Ck);
         prof.m = M; prof.n = p.Ncols; prof.k = p.ntaps * p.nKphase * p.Ck;
         const int rc = afi_launch_pix_gemm_sk(p, b_rc, st);
-        if (rc != AFI_ERR_UNSUPPORTED) return rc;
+        if (rc != AFI_ERR_UNSUPPORTED || p.Bimg) return rc;  // (a problem that carries a weight image is defined by it: never fall back to reading B)
         prof.cancel();
     }
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work

@@ -24,6 +24,7 @@ int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st);
 int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
 long long afi_wk6_image_bytes(int Ncols, int Ck, int ntaps, int nKphase);                       // smallmap.hip: bf16x6 weight images of the small-map kernels
 int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st);
+int afi_launch_rdb_chain6(const AfiChain6& c, hipStream_t st);                                   // smallmap.hip: a dense block's chain of 32-channel convs in one launch
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st);
@@ -118,7 +119,7 @@ struct WinoWgradAccum {
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ 0, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
-                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096}};
+                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -272,43 +273,67 @@ static float* wino_wcache_slot(afi_ctx* cx, const float* w, int f4, int mode, in
 // missing ones in ONE launch, and attaches the image to each GEMM descriptor; a descriptor without an image runs on the fp32-MFMA kernel.
 #define AFI_WG6_WIDE 16                                    // wide weight-gradient problems of one small-map backward pass (7 + one per dense block)
 constexpr long long kWk6MaxPixels = 4096;                  // workspaces reserve the image arena for calls up to this many low-res pixels
-constexpr int kWk6MaxReq = 24;
-struct Wk6Req { const float* key; const float* src; int Ncols, Ck, nKphase, b_rc; long long b_sRow, b_sTap; };
+constexpr int kWk6MaxReq = 24, kWk6MaxJobs = 40;
+// One image request: `key` names it in the cache (with `tag`: 0 forward / K-contiguous weights, 1 data gradient / row-contiguous weights,
+// 2 a dense block's four growth convs side by side along K: the data gradient 4G -> C of their block-input columns); njob source weights,
+// job j filling the K chunks [chunk0_j, chunk0_j + Ck_j / 32) of every N tile.
+struct Wk6Src { const float* src; int Ck; long long b_sRow, b_sTap; };
+struct Wk6Req { const float* key; int tag, Ncols, Ck, nKphase, b_rc, njob; Wk6Src j[4]; };
+static inline Wk6Req wk6_req(const float* key, const float* src, int Ncols, int Ck, int nKphase, int b_rc, long long b_sRow, long long b_sTap) {
+    Wk6Req r;
+    r.key = key; r.tag = b_rc; r.Ncols = Ncols; r.Ck = Ck; r.nKphase = nKphase; r.b_rc = b_rc; r.njob = 1;
+    r.j[0] = Wk6Src{src, Ck, b_sRow, b_sTap};
+    return r;
+}
 static inline long long wk6_req_floats(int Ncols, int Ck, int nKphase) { return align4((afi_wk6_image_bytes(Ncols, Ck, 9, nKphase) + 3) / 4); }
 struct Wk6Images {
     bool on = false;
     int n = 0;
-    struct Ent { const float* key; const unsigned char* img; int nstages; } e[kWk6MaxReq];
+    struct Ent { const float* key; int tag; const unsigned char* img; int nstages; } e[kWk6MaxReq];
+    const Ent* find(const float* key, int tag) const {
+        if (!on) return nullptr;
+        for (int i = 0; i < n; ++i) if (e[i].key == key && e[i].tag == tag) return &e[i];
+        return nullptr;
+    }
     // the image of the weight `key`, for a problem that reads its input channels [c_lo, c_lo + g.Ck) (c_lo a multiple of 32)
-    void attach(AfiPixGemm& g, const float* key, int c_lo = 0) const {
+    void attach(AfiPixGemm& g, const float* key, int c_lo = 0, int tag = -1) const {
         if (!on || (c_lo & 31)) return;
         for (int i = 0; i < n; ++i)
-            if (e[i].key == key) { g.Bimg = e[i].img; g.bimg_nstages = e[i].nstages; g.bimg_stage0 = (c_lo / 32) * g.ntaps; return; }
+            if (e[i].key == key && (tag < 0 ? e[i].tag < 2 : e[i].tag == tag)) { g.Bimg = e[i].img; g.bimg_nstages = e[i].nstages; g.bimg_stage0 = (c_lo / 32) * g.ntaps; return; }
     }
 };
 static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, float* arena, long long arena_floats, hipStream_t st) {
     im.on = false; im.n = 0;
     if (n > kWk6MaxReq) return AFI_OK;
-    AfiWk6ImgJob jobs[kWk6MaxReq];
+    AfiWk6ImgJob jobs[kWk6MaxJobs];
     int nj = 0;
     long long used = 0;
     for (int i = 0; i < n; ++i) {
         const Wk6Req& r = reqs[i];
         const long long need = wk6_req_floats(r.Ncols, r.Ck, r.nKphase);
         bool hit = false;
-        float* slot = wino_wcache_slot(cx, r.key, /*tag: wk6 image, forward / data gradient*/ 4 + r.b_rc, r.nKphase, r.Ncols, r.Ck, need, hit);
+        float* slot = wino_wcache_slot(cx, r.key, /*tags 4..6: wk6 images*/ 4 + r.tag, r.nKphase, r.Ncols, r.Ck, need, hit);
         if (!slot) {
             if (!arena || used + need > arena_floats) { im.n = 0; return AFI_OK; }      // no room: the call stays on the fp32-MFMA kernels
             slot = arena + used; used += need; hit = false;
         }
-        if (!hit) jobs[nj++] = AfiWk6ImgJob{r.src, r.b_sRow, r.b_sTap, r.Ncols, r.Ck, 9, r.nKphase, r.b_rc, 0, (unsigned char*)slot};
-        im.e[im.n++] = Wk6Images::Ent{r.key, (const unsigned char*)slot, afi_cdiv(r.Ck, 32) * 9 * r.nKphase};
+        const int nst = afi_cdiv(r.Ck, 32) * 9 * r.nKphase;
+        if (!hit) {
+            int chunk0 = 0;
+            for (int k = 0; k < r.njob; ++k) {
+                if (nj == kWk6MaxJobs) { im.n = 0; return AFI_OK; }
+                jobs[nj++] = AfiWk6ImgJob{r.j[k].src, r.j[k].b_sRow, r.j[k].b_sTap, r.Ncols, r.j[k].Ck, 9, r.nKphase, r.b_rc, chunk0 * 9 * r.nKphase,
+                                          (unsigned char*)slot, r.njob > 1 ? nst : 0, 0};
+                chunk0 += afi_cdiv(r.j[k].Ck, 32);
+            }
+        }
+        im.e[im.n++] = Wk6Images::Ent{r.key, r.tag, (const unsigned char*)slot, nst};
     }
     if (nj) AFI_TRY(afi_launch_wk6_images(jobs, nj, st));
     im.on = true;
     return AFI_OK;
 }
-static inline bool wk6_shapes_ok(int C, int G, int R) { return (C % 32) == 0 && (G % 32) == 0 && 5 * R + 4 <= kWk6MaxReq; }
+static inline bool wk6_shapes_ok(int C, int G, int R) { return (C % 32) == 0 && (G % 32) == 0 && 6 * R + 4 <= kWk6MaxReq && 9 * R + 4 <= kWk6MaxJobs; }
 // the final conv on the up-sampled map (4x the pixels) stays on the small-map kernel while the map has at most this many pixels: at config 1
 // (50 x 68) the Winograd form is five launches of 9 .. 19 us (weight transform, bf16 split, input transform, GEMM, output transform)
 constexpr long long kWk6HiResMaxPixels = 4096;
@@ -325,7 +350,7 @@ static long long gen_wk6_bwd_floats(int C, int G, int R, long long P) {
     const int L = C + 4 * G;
     long long f = 3 * wk6_req_floats(C, C, 1) + wk6_req_floats(C, C, 4);             // head, trunk, final conv; conv-transpose
     for (int k = 1; k <= 4; ++k) f += (long long)R * wk6_req_floats(C + (k - 1) * G, G, 1);
-    return f + (long long)R * wk6_req_floats(L, C, 1);
+    return f + (long long)R * (wk6_req_floats(L, C, 1) + wk6_req_floats(C, 4 * G, 1));           // (+ the growth convs' block-input columns side by side)
 }
 
 static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st,
@@ -928,7 +953,7 @@ long long afi_generator_fwd_ws_floats(int C, int G, int n_rdb, int N, int H, int
 
 // backward scratch layout: [dU 4P*C][gA P*C][gB P*C][dBuf0 P*L][dBuf1 P*L][dWp 36*C*C][red]
 struct GenBwdWs {
-    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_rdbw, n_rdbw, o_rdbx, n_rdbx, o_red, o_part, n_part, o_wino, n_wino, o_wino2, o_img, n_img, total;
+    long long o_du, o_ga, o_gb, o_db0, o_db1, o_dwp, o_rdbw, n_rdbw, o_rdbx, n_rdbx, o_red, o_part, n_part, o_wino, n_wino, o_wino2, o_img, n_img, o_gch, n_gch, total;
 };
 static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     GenBwdWs w;
@@ -952,6 +977,8 @@ static GenBwdWs gen_bwd_ws(int C, int G, int n_rdb, int N, int H, int W) {
     w.o_wino2 = o; o += w.n_wino;                         // weight gradients (side stream on small maps)
     w.n_img = gen_wk6_bwd_floats(C, G, n_rdb, P);           // small maps: bf16x6 weight images of the data-gradient GEMMs
     w.o_img = o; o += w.n_img;
+    w.n_gch = w.n_img > 0 ? align4(P * 4LL * G) : 0;        // small maps: the final growth-conv gradients g1..g4 of a block, [P][4G] (the chain kernel's output)
+    w.o_gch = o; o += (long long)n_rdb * w.n_gch;
     w.total = o;
     return w;
 }
@@ -1006,14 +1033,14 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     if (batched && six) {
         Wk6Req rq[kWk6MaxReq];
         int nr = 0;
-        rq[nr++] = Wk6Req{prm->w0, prm->w0, C, C, 1, 0, 9LL * C, C};
+        rq[nr++] = wk6_req(prm->w0, prm->w0, C, C, 1, 0, 9LL * C, C);
         for (int r = 0; r < R; ++r) {
-            for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; rq[nr++] = Wk6Req{prm->rdb_w[r][k - 1], prm->rdb_w[r][k - 1], G, cin, 1, 0, 9LL * cin, cin}; }
-            rq[nr++] = Wk6Req{prm->rdb_w[r][4], prm->rdb_w[r][4], C, (int)l.L, 1, 0, 9LL * l.L, l.L};
+            for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; rq[nr++] = wk6_req(prm->rdb_w[r][k - 1], prm->rdb_w[r][k - 1], G, cin, 1, 0, 9LL * cin, cin); }
+            rq[nr++] = wk6_req(prm->rdb_w[r][4], prm->rdb_w[r][4], C, (int)l.L, 1, 0, 9LL * l.L, l.L);
         }
-        rq[nr++] = Wk6Req{prm->w7, prm->w7, C, C, 1, 0, 9LL * C, C};
-        rq[nr++] = Wk6Req{prm->wT, wp, 4 * C, C, 1, 0, 9LL * C, C};           // (keyed by the parameter, built from its packed form above)
-        if (4 * l.P <= kWk6HiResMaxPixels) rq[nr++] = Wk6Req{prm->w9, prm->w9, C, C, 1, 0, 9LL * C, C};
+        rq[nr++] = wk6_req(prm->w7, prm->w7, C, C, 1, 0, 9LL * C, C);
+        rq[nr++] = wk6_req(prm->wT, wp, 4 * C, C, 1, 0, 9LL * C, C);           // (keyed by the parameter, built from its packed form above)
+        if (4 * l.P <= kWk6HiResMaxPixels) rq[nr++] = wk6_req(prm->w9, prm->w9, C, C, 1, 0, 9LL * C, C);
         AFI_TRY(wk6_build(cx, im, rq, nr, ws + l.o_img, l.n_img, st));
     }
     {   // head conv + LReLU (generator_rdb.py:91-93) -> channels [0,C) of RDB 0's dense buffer
@@ -1041,6 +1068,45 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
             im.attach(g, prm->rdb_w[r][4], c_lo);
             return g;
         };
+        // The chain y1 -> y2 -> y3 -> y4 in ONE launch (csrc/smallmap.hip: afi_rdb_chain6_kernel) under the bf16x6 small-map schedule: step 0
+        // leaves conv_2..4's sums over the block input as raw partials in a scratch (the trunk conv's output buffer, free until then), the
+        // chain kernel adds what they take from y1..y3 (recomputing tile halos), activates and writes y2..y4 into the dense buffer, and
+        // conv5's 4G growth channels are ONE GEMM behind it: three launches per block instead of five.
+        const bool chain = batched && im.on && (afi_opt(cx, AFI_OPT_G_RDB_CHAIN) & 1) != 0 && G == 32 && 3 * G <= C && im.find(prm->rdb_w[r][1], 0) && im.find(prm->rdb_w[r][2], 0) &&
+                           im.find(prm->rdb_w[r][3], 0) && im.find(prm->rdb_w[r][4], 0);
+        if (chain) {
+            AfiPixGemm probs[5];
+            int n = 0;
+            for (int k = 1; k <= 4; ++k) {              // what conv_k takes from the block input x: y1 complete, conv_2..4 raw partials -> scratch
+                const int cin = C + (k - 1) * G;
+                AfiPixGemm g = conv_fwd_desc(b, N, H, W, C, prm->rdb_w[r][k - 1], nullptr, G, k == 1 ? ch_off(b, C) : ch_off(a7, (k - 2) * G));
+                g.b_sRow = 9LL * cin; g.b_sTap = cin;
+                g.lrelu = k == 1 ? 1 : 0;
+                im.attach(g, prm->rdb_w[r][k - 1], 0);
+                probs[n++] = g;
+            }
+            AfiPixGemm g5 = conv5_desc(0, C);
+            g5.R1 = b; g5.r1_lo = 0; g5.r1_hi = C; g5.r1s = last ? rs : 1.f;
+            if (last) { g5.R2 = buf(0); g5.r2s = 1.f; g5.r2_lo = 0; g5.r2_hi = C; }
+            probs[n++] = g5;
+            AFI_TRY(afi_launch_pix_gemm_group(probs, n, 0, st));
+            AfiChain6 cd;
+            memset(&cd, 0, sizeof(cd));
+            cd.N = N; cd.H = H; cd.W = W; cd.a_sgn = 1; cd.mode = 0;
+            cd.src0 = ch_off(b, C);
+            for (int ph = 0; ph < 3; ++ph) {            // phase ph: conv_{ph + 2} over y1 .. y_{ph + 1}
+                const Wk6Images::Ent* e = im.find(prm->rdb_w[r][ph + 1], 0);
+                for (int ci = 0; ci <= ph; ++ci) { cd.ph[ph].img[ci] = e->img; cd.ph[ph].stage0[ci] = (C / 32 + ci) * 9; }
+                cd.ph[ph].partial = ch_off(a7, ph * G);
+                cd.ph[ph].Z = null_view();
+                cd.ph[ph].out = ch_off(b, C + (ph + 1) * G);
+            }
+            AFI_TRY(afi_launch_rdb_chain6(cd, st));
+            AfiPixGemm gy = conv5_desc(C, 4 * G);       // conv5 over y1..y4, added to what step 0 stored
+            gy.beta = 1.f;
+            AFI_TRY(PG(gy, 0));
+            continue;
+        }
         if (batched) {
             for (int j = 0; j <= 4; ++j) {              // source slice j: x (j = 0) or y_j
                 const int c_lo = j == 0 ? 0 : C + (j - 1) * G, nch = j == 0 ? C : G;
@@ -1224,18 +1290,26 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
         n_wide = n_narrow = n_cs = 0; n_wide_has_convT = false;
         return AFI_OK;
     };
+    // (the dense blocks' gradient chains g4 -> g3 -> g2 -> g1 as one launch each, below: needs the packed weight gradients and 32-channel slices)
+    const bool chain_shapes = six && pack_growth6 && s.n_gch > 0 && G == 32 && (C % 32) == 0 && (afi_opt(cx, AFI_OPT_G_RDB_CHAIN) == 1 || afi_opt(cx, AFI_OPT_G_RDB_CHAIN) == 2);
     Wk6Images im;                                          // weight images of the data-gradient GEMMs (row-contiguous weights)
     if (six && s.n_img > 0) {
         Wk6Req rq[kWk6MaxReq];
         int nr = 0;
-        rq[nr++] = Wk6Req{prm->wT, wp, C, C, 4, 1, 9LL * C, C};               // conv-transpose data gradient: K = (phase, Cout, tap) of the packed weight
-        rq[nr++] = Wk6Req{prm->w7, prm->w7, C, C, 1, 1, 9LL * C, C};
+        rq[nr++] = wk6_req(prm->wT, wp, C, C, 4, 1, 9LL * C, C);               // conv-transpose data gradient: K = (phase, Cout, tap) of the packed weight
+        rq[nr++] = wk6_req(prm->w7, prm->w7, C, C, 1, 1, 9LL * C, C);
         for (int r = 0; r < R; ++r) {
-            rq[nr++] = Wk6Req{prm->rdb_w[r][4], prm->rdb_w[r][4], L, C, 1, 1, 9LL * L, L};
-            for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; rq[nr++] = Wk6Req{prm->rdb_w[r][k - 1], prm->rdb_w[r][k - 1], cin, G, 1, 1, 9LL * cin, cin}; }
+            rq[nr++] = wk6_req(prm->rdb_w[r][4], prm->rdb_w[r][4], L, C, 1, 1, 9LL * L, L);
+            for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; rq[nr++] = wk6_req(prm->rdb_w[r][k - 1], prm->rdb_w[r][k - 1], cin, G, 1, 1, 9LL * cin, cin); }
+            if (chain_shapes) {                             // the four growth convs' block-input columns side by side along K: ONE data gradient 4G -> C
+                Wk6Req q;
+                q.key = prm->rdb_w[r][0]; q.tag = 2; q.Ncols = C; q.Ck = 4 * G; q.nKphase = 1; q.b_rc = 1; q.njob = 4;
+                for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; q.j[k - 1] = Wk6Src{prm->rdb_w[r][k - 1], G, 9LL * cin, cin}; }
+                rq[nr++] = q;
+            }
         }
-        if (dx) rq[nr++] = Wk6Req{prm->w0, prm->w0, C, C, 1, 1, 9LL * C, C};
-        if (4 * P <= kWk6HiResMaxPixels) rq[nr++] = Wk6Req{prm->w9, prm->w9, C, C, 1, 1, 9LL * C, C};
+        if (dx) rq[nr++] = wk6_req(prm->w0, prm->w0, C, C, 1, 1, 9LL * C, C);
+        if (4 * P <= kWk6HiResMaxPixels) rq[nr++] = wk6_req(prm->w9, prm->w9, C, C, 1, 1, 9LL * C, C);
         AFI_TRY(wk6_build(cx, im, rq, nr, scratch + s.o_img, s.n_img, st));
     }
     // (the packed conv-transpose gradient and the packed growth-conv gradients are neighbours in the scratch: ONE fill for both)
@@ -1298,6 +1372,49 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
             g.Z = b; g.z_lo = C + 3 * G; g.z_hi = L;                   // conv4's LReLU: its slice is final after this kernel
             im.attach(g, prm->rdb_w[r][4]);
             AFI_TRY(PG(g, 1));
+        }
+        const bool chain = chain_shapes && im.find(prm->rdb_w[r][0], 2) && im.find(prm->rdb_w[r][1], 1) && im.find(prm->rdb_w[r][2], 1) && im.find(prm->rdb_w[r][3], 1);
+        if (chain) {
+            // g4 (final above) -> g3 -> g2 -> g1 in ONE launch (csrc/smallmap.hip: afi_rdb_chain6_kernel): link k adds what conv_{k+1} .. conv_4
+            // send back to y_k to conv5's share (the raw slice of d), applies y_k's LeakyReLU' and stores g_k -- into a [P][4G] buffer of
+            // its own, next to a copy of g4: the raw slices of d stay intact for the neighbour tiles that recompute them on their halo.
+            // What the four convs send to the block input is then ONE data gradient 4G -> C on their block-input columns side by side.
+            AfiView Gc = dense_view(scratch + s.o_gch + (long long)r * s.n_gch, H, W, 4LL * G);
+            AfiChain6 cd;
+            memset(&cd, 0, sizeof(cd));
+            cd.N = N; cd.H = H; cd.W = W; cd.a_sgn = -1; cd.mode = 1;
+            cd.src0 = ch_off(d, C + 3 * G);
+            cd.copy0 = ch_off(Gc, 3 * G);
+            for (int ph = 0; ph < 3; ++ph) {                            // phase ph: g_{3 - ph} from g4 .. g_{4 - ph}
+                const int kout = 3 - ph, slice = C + (kout - 1) * G;    // conv index whose output gradient this link produces; its channel slice
+                for (int ci = 0; ci <= ph; ++ci) {                      // region ci holds g_{4 - ci}: it returns through conv_{4 - ci}'s columns of slice kout
+                    const Wk6Images::Ent* e = im.find(prm->rdb_w[r][3 - ci], 1);
+                    cd.ph[ph].img[ci] = e->img + (long long)(slice / 32) * e->nstages * AFI_WK6_STAGE_BYTES;
+                    cd.ph[ph].stage0[ci] = 0;
+                }
+                cd.ph[ph].partial = ch_off(d, slice);
+                cd.ph[ph].Z = ch_off(b, slice);
+                cd.ph[ph].out = ch_off(Gc, (kout - 1) * G);
+            }
+            AFI_TRY(afi_launch_rdb_chain6(cd, st));
+            {
+                AfiPixGemm g = conv_dgrad_desc(Gc, N, H, W, 4 * G, prm->rdb_w[r][0], C, d);
+                g.beta = 1.f;
+                if (r == 0) {                                           // RRDB skip (+dT) and the head conv's LReLU
+                    g.R2 = gB; g.r2s = 1.f; g.r2_lo = 0; g.r2_hi = C;
+                    g.Z = b; g.z_lo = 0; g.z_hi = C;
+                }
+                im.attach(g, prm->rdb_w[r][0], 0, /*tag: the four growth convs side by side*/ 2);
+                if (!g.Bimg) return AFI_ERR_LAUNCH;
+                AFI_TRY(PG(g, 1));
+            }
+            if (gr->rdb_w[r][0] || gr->rdb_w[r][1] || gr->rdb_w[r][2] || gr->rdb_w[r][3]) {
+                AFI_TRY(defer(conv_wgrad_desc(Gc, b, N, H, W, 4 * G, L, scratch + s.o_rdbw + (long long)r * s.n_rdbw, 1.f)));
+                packed_mask |= 1u << r; ++packed_blocks;
+            }
+            AFI_TRY(flush(false));
+            Gt = d; gs = 1.f;
+            continue;
         }
         for (int k = 4; k >= 1; --k) {
             const int cin = C + (k - 1) * G;

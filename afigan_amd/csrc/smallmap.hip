@@ -30,6 +30,8 @@ __device__ __attribute__((aligned(16))) float afi_zeros_smallmap[4] = {0.f, 0.f,
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
+#include <mutex>
+#include <set>
 #include <type_traits>
 
 // stream-K partition: unit = one BK-deep K stage of one tile; tile t owns units [t*nK, (t+1)*nK); logical block b owns
@@ -391,7 +393,7 @@ int afi_launch_pix_gemm_sk(const AfiPixGemm& p, int b_rc, hipStream_t st) {
     if (p.ntaps != 1 && p.ntaps != 9) return AFI_ERR_UNSUPPORTED;
     {   // K split inside the block (no second pass); the stream-K form below takes what its 32-bit index math refuses
         const int rc = b_rc ? launch_wk<true>(p, st) : launch_wk<false>(p, st);
-        if (rc != AFI_ERR_UNSUPPORTED) return rc;
+        if (rc != AFI_ERR_UNSUPPORTED || p.Bimg) return rc; // (a problem that carries a weight image is defined by it: the kernels below would read B)
     }
     if (p.Ncols <= 32) return b_rc ? launch_sk<128, 32, 4, 1, true>(p, st) : launch_sk<128, 32, 4, 1, false>(p, st);
     return b_rc ? launch_sk<64, 64, 2, 2, true>(p, st) : launch_sk<64, 64, 2, 2, false>(p, st);
@@ -942,7 +944,7 @@ __global__ __launch_bounds__(512, 4) void afi_pix_gemm_wk6_group_kernel(const Af
 // Weight images of afi_pix_gemm_wk6.  One thread per (job, N tile, K stage, n half, lane): the lane's eight consecutive k of column
 // n = 32 tile + 16 half + (lane & 15) -- k = 8 (lane >> 4) .. + 7 of the stage's 32-channel chunk at its (K phase, tap) -- read through the
 // job's B addressing (zeros beyond Ncols / Ck), split, and stored as the three 16-byte fragments the kernel loads.
-#define AFI_WK6_MAXJOBS 24
+#define AFI_WK6_MAXJOBS 40
 struct AfiWk6ImgJobs {
     int njobs, pad_;
     int unit_start[AFI_WK6_MAXJOBS + 1];                   // prefix sums of (N tiles x stages) per job
@@ -977,7 +979,8 @@ __global__ __launch_bounds__(256) void afi_wk6_image_kernel(const AfiWk6ImgJobs 
             }
         }
     }
-    unsigned char* dst = jb.dst + ((long long)tile_n * nst + stage) * AFI_WK6_STAGE_BYTES + (3 * ni) * 1024 + 16 * lane;
+    const int nst_img = jb.nstages_img > 0 ? jb.nstages_img : nst;
+    unsigned char* dst = jb.dst + ((long long)tile_n * nst_img + jb.stage_off + stage) * AFI_WK6_STAGE_BYTES + (3 * ni) * 1024 + 16 * lane;
     const f32x4 r0 = afi_bf16_residual(v0), r1 = afi_bf16_residual(v1);
     *(bf16x8*)dst = afi_pack8_bf16(v0, v1);
     *(bf16x8*)(dst + 1024) = afi_pack8_bf16(r0, r1);
@@ -995,6 +998,7 @@ int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st) {
         for (int i = 0; i < cnt; ++i) {
             const AfiWk6ImgJob& j = jobs[done + i];
             if (!j.B || !j.dst || j.Ncols <= 0 || j.Ck <= 0 || (j.ntaps != 1 && j.ntaps != 9) || (j.nKphase != 1 && j.nKphase != 4)) return AFI_ERR_BAD_ARG;
+            if (j.stage_off < 0 || (j.nstages_img > 0 && j.stage_off + afi_cdiv(j.Ck, AFI_BK) * j.ntaps * j.nKphase > j.nstages_img)) return AFI_ERR_BAD_ARG;
             if ((j.Ck & 3) || (!j.b_rc && ((j.b_sRow | j.b_sTap) & 3)) || (((uintptr_t)j.B | (uintptr_t)j.dst) & 15)) return AFI_ERR_UNSUPPORTED;   // float4 reads, 16-byte stores
             tb.j[i] = j;
             tb.nstages[i] = afi_cdiv(j.Ck, AFI_BK) * j.ntaps * j.nKphase;
@@ -1031,6 +1035,237 @@ static int wk_prepare(const AfiPixGemm& p, bool b_rc, AfiWkArgs& wk) {
     if ((long long)wk.ntile_m * wk.ntile_n * wk.ntile_m >= (1LL << 32)) return AFI_ERR_UNSUPPORTED;
     return AFI_OK;
 }
+// ------------------------------------------------------------------------------------------------
+// afi_rdb_chain6_kernel: the dense block's chain of 32-channel convs (AfiChain6, afi_common.h) in one launch.  At config 1 each link was
+// a launch of its own whose 1 us of matrix work sat in 9 us of fixed cost (launch, first touches, reduction, epilogue), four per block
+// and direction; here a link is a phase of a resident block: its inputs are in LDS, its weights come from the same bf16x6 images the
+// small-map GEMMs read, and what a neighbour tile would have provided is recomputed on the halo (144 + 100 + 64 pixels per 64 owned, on
+// 32-column GEMMs: noise next to the launches saved).
+//   Sixteen waves.  A phase's work items are (PAIR of 16-pixel row groups of its region, K slice): 5 x 2, 4 x 3 and 2 x 5 items for the
+//   three phases, i.e. 5 / 6 / 6 stages in a row per wave instead of 9 / 18 / 27 -- the kernel is a latency chain, so its length counts --
+//   and a stage's six 1-KB weight fragments (from L2, prefetched one stage ahead) feed 24 MFMAs on two row groups.
+//   An item leaves its raw partial tiles in an LDS slot of its K slice; behind a barrier all threads sum the slots in FIXED order
+//   (bit-reproducible), add `partial`, apply the LeakyReLU / LeakyReLU' factor, zero what lies outside the map, and store float4 rows to
+//   the next region and -- the owner's 8 x 8 pixels -- to `out`.
+// ------------------------------------------------------------------------------------------------
+// LDS: the three regions hold their 32 channels PRE-SPLIT -- per pixel 240 bytes: hi | mid | lo, each 32 bf16 (64 bytes) + 16 bytes of pad,
+// so that a fragment (lane = pixel l15, channels 8 lq .. + 7) is ONE 16-byte read per part and the 16 lanes of a read group fall on
+// distinct banks (pixel stride 60 banks) -- because a region element is read by nine taps of up to three links: split at every read
+// (v3 of this kernel), the 36 vector instructions per fragment against 12 MFMAs on a 32-column GEMM made the block's 171 wave-stages
+// a vector-issue queue on ONE CU: 16 of the launch's 23 us (tools/micro/ch6_bench.cpp: the same time with the weight loads or the MFMAs
+// removed).  Split once where the element is produced, a stage is six weight loads, six LDS reads and 24 MFMAs.
+#define AFI_CH6_PIX 240                                    // bytes per region pixel
+#define AFI_CH6_R1 (196 * AFI_CH6_PIX)
+#define AFI_CH6_R2 ((196 + 144) * AFI_CH6_PIX)
+#define AFI_CH6_SLOTS ((196 + 144 + 100) * AFI_CH6_PIX)    // K-slice partial tiles (fp32, 36 floats per row): 2 slots of 144 rows / 3 of 112 / 5 of 64
+#define AFI_CH6_LDP 36
+#define AFI_CH6_SLOT_ROWS 336
+#define AFI_CH6_LDS_BYTES (AFI_CH6_SLOTS + AFI_CH6_SLOT_ROWS * AFI_CH6_LDP * 4)
+#ifndef AFI_CH6_ABLATE
+#define AFI_CH6_ABLATE 0                                   // tools/micro/ch6_bench.cpp only: 1 no stages (loads + MFMAs), 2 no weight-fragment loads, 4 no MFMAs
+#endif
+__device__ __forceinline__ void afi_ch6_store_split(unsigned char* pix_base, int c4, f32x4 v) {      // channels c4 .. c4 + 3 of one pixel -> its three parts
+    unsigned h0, m0_, l0, h1, m1_, l1;
+    afi_split3_pair(v[0], v[1], h0, m0_, l0);
+    afi_split3_pair(v[2], v[3], h1, m1_, l1);
+    *(u32x2*)(pix_base + 2 * c4) = u32x2{h0, h1};
+    *(u32x2*)(pix_base + 80 + 2 * c4) = u32x2{m0_, m1_};
+    *(u32x2*)(pix_base + 160 + 2 * c4) = u32x2{l0, l1};
+}
+template <int P, int MODE>
+__device__ __forceinline__ void afi_chain6_phase(const AfiChain6& c, unsigned char* lds, int n, int y0, int x0) {
+    constexpr int LDP = AFI_CH6_LDP;
+    constexpr int S = 12 - 2 * P, NPIX = S * S, NSUB = (NPIX + 15) / 16, HP = 2 - P, NST = 9 * (P + 1);
+    constexpr int KS = P == 0 ? 2 : (P == 1 ? 3 : 5), NPAIR = (NSUB + 1) / 2, NITEM = NPAIR * KS, ROWS = NSUB * 16;
+    static_assert(KS * ROWS <= AFI_CH6_SLOT_ROWS, "slot area");
+    auto R = [&](int ci) -> unsigned char* { return lds + (ci == 0 ? 0 : (ci == 1 ? AFI_CH6_R1 : AFI_CH6_R2)); };   // regions 0 (14 x 14), 1 (12 x 12), 2 (10 x 10)
+    float* slots = (float*)(lds + AFI_CH6_SLOTS);           // [KS][ROWS][LDP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, lq = lane >> 4;
+    const AfiChain6Phase& ph = c.ph[P];
+    typedef const __attribute__((address_space(1))) u32x4 gu32x4;
+    auto mfma = [](u32x4 x, u32x4 y, f32x4 a) -> f32x4 {
+        if constexpr ((AFI_CH6_ABLATE & 4) != 0) { asm volatile("" :: "v"(x), "v"(y)); return a; }
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), a, 0, 0, 0);
+    };
+    // the epilogue's own operands (`partial`, Z: first touches of lines the previous kernel wrote) are requested BEFORE the K loop
+    constexpr int NEPI = (NPIX * 8 + 1023) / 1024;
+    f32x4 e_part[NEPI], e_z[MODE == 1 ? NEPI : 1];
+#pragma unroll
+    for (int it = 0; it < NEPI; ++it) {
+        const int e = tid + 1024 * it, q2 = e >> 3, c4 = (e & 7) * 4;
+        const int py_ = q2 / S, px_ = q2 - py_ * S;
+        const int gy = y0 - HP + py_, gx = x0 - HP + px_;
+        const bool inside = e < NPIX * 8 && (unsigned)gy < (unsigned)c.H && (unsigned)gx < (unsigned)c.W;
+        e_part[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (MODE == 1) e_z[it] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (inside) {
+            e_part[it] = *(const f32x4*)(ph.partial.p + (long long)n * ph.partial.sN + (long long)gy * ph.partial.sH + (long long)gx * ph.partial.sW + c4);
+            if constexpr (MODE == 1) e_z[it] = *(const f32x4*)(ph.Z.p + (long long)n * ph.Z.sN + (long long)gy * ph.Z.sH + (long long)gx * ph.Z.sW + c4);
+        }
+    }
+    for (int item = wave; item < NITEM; item += 16) {       // (uniform per wave)
+        const int pr = item / KS, ks = item - pr * KS;
+        const int s_lo = ks * NST / KS, s_hi = (ks + 1) * NST / KS;
+        const bool two = 2 * pr + 1 < NSUB;                 // (uniform) an odd group count: the last pair's second group repeats the first, unused
+        int qy[2], qx[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int u = two ? 2 * pr + g : 2 * pr;
+            const int q = 16 * u + l15, qq = q < NPIX ? q : NPIX - 1;
+            qy[g] = qq / S; qx[g] = qq - qy[g] * S;
+        }
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 bw[2][6];                                     // weight fragments of two stages in flight: [n half][hi | mid | lo]
+        auto load_b = [&](int set, int st) {                // stage st = 9 chunk + tap (clamped: a prefetch past the slice re-reads its last stage)
+            st = st < s_hi ? st : s_hi - 1;
+            const int ci = st / 9, tap = st - 9 * ci;
+            const unsigned char* base = ph.img[ci] + (long long)(ph.stage0[ci] + tap) * AFI_WK6_STAGE_BYTES + 16 * lane;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if constexpr ((AFI_CH6_ABLATE & 3) == 0) bw[set][k] = *(gu32x4*)(base + k * 1024);
+                else { const unsigned o = (unsigned)(size_t)base + k; bw[set][k] = u32x4{o, o, o, o}; }
+            }
+        };
+        auto stage = [&](int set, int st) {
+            if constexpr ((AFI_CH6_ABLATE & 1) != 0) { acc[0][0][0] += __uint_as_float(bw[set][0][0]) * (float)st; return; }
+            const int ci = st / 9, tap = st - 9 * ci;
+            const int Sc = 14 - 2 * ci, off = 1 + P - ci;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            u32x4 ah[2], am[2], al[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const unsigned char* a = R(ci) + ((qy[g] + off + c.a_sgn * dy) * Sc + (qx[g] + off + c.a_sgn * dx)) * AFI_CH6_PIX + 16 * lq;
+                ah[g] = *(const u32x4*)a; am[g] = *(const u32x4*)(a + 80); al[g] = *(const u32x4*)(a + 160);
+            }
+            // per accumulator smallest terms first; consecutive MFMAs go to the four different accumulators (a dependent MFMA waits for its
+            // predecessor's result: six in a row on one accumulator were most of a stage's time)
+#define AFI_CH6_TERM(A, B)                                                                                  \
+            _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) acc[g][ni] = mfma(A[g], bw[set][3 * ni + B], acc[g][ni]);
+            AFI_CH6_TERM(al, 0)
+            AFI_CH6_TERM(ah, 2)
+            AFI_CH6_TERM(am, 1)
+            AFI_CH6_TERM(am, 0)
+            AFI_CH6_TERM(ah, 1)
+            AFI_CH6_TERM(ah, 0)
+#undef AFI_CH6_TERM
+        };
+        load_b(0, s_lo);
+        int st = s_lo;
+        for (; st + 2 <= s_hi; st += 2) {                   // pairs of stages, then (odd count) the last one
+            load_b(1, st + 1);
+            stage(0, st);
+            load_b(0, st + 2);
+            stage(1, st + 1);
+        }
+        if (st < s_hi) stage(0, st);
+        // the item's raw partial tiles -> its K slice's slot: lane (l15, lq) holds channels l15, 16 + l15 of rows 4 lq .. 4 lq + 3 of a group
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            if (g == 1 && !two) break;
+            float* sl = slots + ((long long)ks * ROWS + 16 * (2 * pr + g)) * LDP;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sl[(4 * lq + r) * LDP + 16 * ni + l15] = acc[g][ni][r];
+        }
+    }
+    __syncthreads();
+    // ---- the link's epilogue, by all threads: one float4 (four channels of one pixel) per item
+#pragma unroll
+    for (int it = 0; it < NEPI; ++it) {
+        const int e = tid + 1024 * it;
+        if (e >= NPIX * 8) break;
+        const int q2 = e >> 3, c4 = (e & 7) * 4;
+        f32x4 v = *(const f32x4*)(slots + q2 * LDP + c4);
+#pragma unroll
+        for (int k = 1; k < KS; ++k) v += *(const f32x4*)(slots + ((long long)k * ROWS + q2) * LDP + c4);          // fixed order
+        const int py_ = q2 / S, px_ = q2 - py_ * S;
+        const int gy = y0 - HP + py_, gx = x0 - HP + px_;
+        const bool inside = (unsigned)gy < (unsigned)c.H && (unsigned)gx < (unsigned)c.W;
+        if (inside) {
+            v += e_part[it];
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = v[k] > 0.f ? v[k] : v[k] * AFI_LRELU_SLOPE;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] *= e_z[it][k] > 0.f ? 1.f : AFI_LRELU_SLOPE;
+            }
+        } else {
+            v = f32x4{0.f, 0.f, 0.f, 0.f};                  // the convs' zero padding
+        }
+        if constexpr (P < 2) afi_ch6_store_split(R(P + 1) + q2 * AFI_CH6_PIX, c4, v);
+        if (inside && (unsigned)(py_ - HP) < 8u && (unsigned)(px_ - HP) < 8u)
+            *(f32x4*)(ph.out.p + (long long)n * ph.out.sN + (long long)gy * ph.out.sH + (long long)gx * ph.out.sW + c4) = v;
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(1024, 4) void afi_rdb_chain6_kernel(const AfiChain6 c) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_c[];
+    const int tid = threadIdx.x;
+    int b = blockIdx.x;
+    const int tx = b % c.tiles_x; b /= c.tiles_x;
+    const int ty = b % c.tiles_y; const int n = b / c.tiles_y;
+    const int y0 = ty * 8, x0 = tx * 8;
+    // (measured and dropped: touching the 2592 lines of weight fragments the block will read, up front, to pay one HBM round trip instead
+    //  of one per stage: 26 against 24 us per launch -- the stages are not waiting for first touches)
+    // region 0 (14 x 14 pixels x 32 channels): eight lanes read one pixel's 128 bytes; zeros outside the map; split on the way into LDS
+    for (int idx = tid; idx < 196 * 8; idx += 1024) {
+        const int pix = idx >> 3, seg = idx & 7;
+        const int ry = pix / 14, rx = pix - ry * 14;
+        const int gy = y0 - 3 + ry, gx = x0 - 3 + rx;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const bool inside = (unsigned)gy < (unsigned)c.H && (unsigned)gx < (unsigned)c.W;
+        if (inside) v = *(const f32x4*)(c.src0.p + (long long)n * c.src0.sN + (long long)gy * c.src0.sH + (long long)gx * c.src0.sW + 4 * seg);
+        afi_ch6_store_split(smem_c + pix * AFI_CH6_PIX, 4 * seg, v);
+        if (c.copy0.p && inside && (unsigned)(ry - 3) < 8u && (unsigned)(rx - 3) < 8u)
+            *(f32x4*)(c.copy0.p + (long long)n * c.copy0.sN + (long long)gy * c.copy0.sH + (long long)gx * c.copy0.sW + 4 * seg) = v;
+    }
+    __syncthreads();
+    afi_chain6_phase<0, MODE>(c, smem_c, n, y0, x0);
+    __syncthreads();
+    afi_chain6_phase<1, MODE>(c, smem_c, n, y0, x0);
+    __syncthreads();
+    afi_chain6_phase<2, MODE>(c, smem_c, n, y0, x0);
+}
+static bool chain6_opt_in() {                               // 100 KB of dynamic LDS: an opt-in per kernel and per device
+    static std::mutex mu;
+    static std::set<int> done;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count(dev)) return true;
+    if (hipFuncSetAttribute((const void*)afi_rdb_chain6_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)afi_rdb_chain6_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    done.insert(dev);
+    return true;
+}
+int afi_launch_rdb_chain6(const AfiChain6& c_in, hipStream_t st) {
+    AfiChain6 c = c_in;
+    if (c.N <= 0 || c.H <= 0 || c.W <= 0 || (c.a_sgn != 1 && c.a_sgn != -1) || (c.mode != 0 && c.mode != 1) || !c.src0.p) return AFI_ERR_BAD_ARG;
+    auto al16 = [](const AfiView& v) { return !(((uintptr_t)v.p) & 15) && !((v.sN | v.sH | v.sW) & 3); };
+    if (!al16(c.src0) || (c.copy0.p && !al16(c.copy0))) return AFI_ERR_UNSUPPORTED;
+    for (int p = 0; p < 3; ++p) {
+        if (!c.ph[p].partial.p || !c.ph[p].out.p || (c.mode == 1 && !c.ph[p].Z.p)) return AFI_ERR_BAD_ARG;
+        for (int ci = 0; ci <= p; ++ci) if (!c.ph[p].img[ci] || (((uintptr_t)c.ph[p].img[ci]) & 15) || c.ph[p].stage0[ci] < 0) return AFI_ERR_BAD_ARG;
+    }
+    c.tiles_y = afi_cdiv(c.H, 8); c.tiles_x = afi_cdiv(c.W, 8);
+    const long long blocks = (long long)c.N * c.tiles_y * c.tiles_x;
+    if (blocks > 0x7fffffffLL) return AFI_ERR_UNSUPPORTED;
+    for (int p = 0; p < 3; ++p) {                          // float4 epilogue accesses
+        if (!al16(c.ph[p].partial) || !al16(c.ph[p].out) || (c.mode == 1 && !al16(c.ph[p].Z))) return AFI_ERR_UNSUPPORTED;
+    }
+    if (!chain6_opt_in()) return AFI_ERR_LAUNCH;
+    if (c.mode == 0) hipLaunchKernelGGL(afi_rdb_chain6_kernel<0>, dim3((unsigned)blocks), dim3(1024), (size_t)AFI_CH6_LDS_BYTES, st, c);
+    else hipLaunchKernelGGL(afi_rdb_chain6_kernel<1>, dim3((unsigned)blocks), dim3(1024), (size_t)AFI_CH6_LDS_BYTES, st, c);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // the bf16x6 kernel takes a problem when it carries a weight image whose tile range stays inside the kernel's 32-bit buffer offsets
 static bool wk6_ok(const AfiPixGemm& p, const AfiWkArgs& wk) {
     if (!p.Bimg || p.bimg_nstages <= 0 || p.bimg_stage0 < 0 || (((uintptr_t)p.Bimg) & 15)) return false;

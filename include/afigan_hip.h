@@ -117,7 +117,12 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
 #define AFI_OPT_G_SMALLMAP6_MAX_PIXELS 9      /* 4096: under AFI_DTYPE_BF16X6 (and channel counts that are multiples of 32) interpolator calls of up to this many
                                                * low-res pixels run the small-map schedule -- column-batched dense blocks, grouped weight gradients, every conv on the
                                                * bf16x6 small-map kernels with pre-split weight images (csrc/smallmap.hip) -- whatever options 5..7 say; 0: options 5..7 alone */
-#define AFI_OPT_COUNT 10
+#define AFI_OPT_G_RDB_CHAIN 10                /* 0 (default): one launch per link of a dense block's chain of 32-channel convs.  1: under the small-map bf16x6
+                                               * schedule the chain (y1 -> y2 -> y3 -> y4 forward, g4 -> g3 -> g2 -> g1 backward; growth rate 32) is ONE launch that
+                                               * recomputes tile halos (afi_rdb_chain6_kernel): three launches per block and direction instead of five, 35 instead of 47
+                                               * per config-1 forward + backward -- measured at break-even (19 us per chain launch against four links of 9 us minus the
+                                               * 11 us GEMM it adds), so off by default; 2 / 3: backward / forward only (A/B) */
+#define AFI_OPT_COUNT 11
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over

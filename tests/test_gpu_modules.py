@@ -474,3 +474,40 @@ def test_discriminator_stats_only_forward_has_the_same_side_effects(amd, shape):
     for k in states[2][0]:
         assert torch.equal(states[2][0][k], states[3][0][k]), k
     assert not torch.equal(states[2][1], torch.full_like(states[2][1], 7.0)) and torch.equal(states[3][1], torch.full_like(states[3][1], 7.0))
+
+
+def test_generator_chain_kernel_schedule_matches_the_per_link_schedule(amd):
+    """Option g_rdb_chain (off by default): a dense block's chain of 32-channel convs as ONE launch that recomputes tile halos
+    (csrc/smallmap.hip: afi_rdb_chain6_kernel; generator_rdb.py:64-71 and its backward).  Same products as the per-link launches in another
+    order, so at config-1 size every output, the input gradient and all 23 parameter gradients of the two schedules agree to fp32 rounding
+    (measured 6e-7; a LeakyReLU decision that rounding flips would show as ~1e-3: none on this input), forward-only / backward-only included."""
+    import ctypes as C
+    from afigan_amd import _lib, ops
+    lib = _lib.load()
+    N, H, W = 1, 25, 34
+    torch.manual_seed(0)
+    G = amd.Generator(n_residual_dense_blocks=3).cuda()
+    x = ops.pixel_major(torch.randn(N, 256, H, W).cuda())
+    params = G._ordered_params()
+    prm, _keep = G._param_struct(params)
+    nf = lib.afi_generator_fwd_ws_floats(256, 32, 3, N, H, W)
+    nb = lib.afi_generator_bwd_ws_floats(256, 32, 3, N, H, W)
+    dout = ops.new_pixel_major(N, 256, 2 * H, 2 * W, "cuda"); dout.normal_()
+    cx = _lib.Ctx()
+    res = {}
+    with _lib.use_ctx(cx):
+        for mode in (0, 1, 2, 3):
+            cx.set_option("g_rdb_chain", mode)
+            ws, sc = torch.zeros(nf, device="cuda"), torch.zeros(nb, device="cuda")
+            grads = [torch.zeros_like(p) for p in params]
+            gst, _ = G._param_struct(grads, already_packed=True)
+            out = ops.new_pixel_major(N, 256, 2 * H, 2 * W, "cuda"); dx = ops.new_pixel_major(N, 256, H, W, "cuda")
+            st = ops.stream_ptr()
+            _lib.call("afi_generator_fwd", C.byref(prm), ops.view_of(x), N, H, W, ops.view_of(out), C.c_void_p(ws.data_ptr()), nf, st)
+            _lib.call("afi_generator_bwd", C.byref(prm), C.byref(gst), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()), C.c_void_p(dout.data_ptr()),
+                      C.c_void_p(dx.data_ptr()), C.c_void_p(sc.data_ptr()), nb, st)
+            torch.cuda.synchronize()
+            res[mode] = [out.clone(), dx.clone()] + [g.clone() for g in grads]
+    for mode in (1, 2, 3):
+        for i, (a, b) in enumerate(zip(res[mode], res[0])):
+            assert _rel(a, b) < 2e-5, (mode, i)

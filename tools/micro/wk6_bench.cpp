@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     if (!rc) { g.b_sRow = 9LL * Ck; g.b_sTap = Ck; } else { g.b_sRow = 9LL * Ncols; g.b_sTap = Ncols; }
     g.O = AfiView{o32, (long long)H * W * Ncols, (long long)W * Ncols, Ncols};
     hipStream_t st; CK(hipStreamCreate(&st));
-    AfiWk6ImgJob job{dw, g.b_sRow, g.b_sTap, Ncols, Ck, 9, 1, rc, 0, img};
+    AfiWk6ImgJob job{dw, g.b_sRow, g.b_sTap, Ncols, Ck, 9, 1, rc, 0, img, 0, 0};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto timeit = [&](auto&& fn, int iters) { for (int i = 0; i < 5; ++i) fn(); hipEventRecord(e0, st); for (int i = 0; i < iters; ++i) fn(); hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); return ms * 1e3f / iters; };
     const float t_img = timeit([&] { afi_launch_wk6_images(&job, 1, st); }, 20);
