@@ -1649,48 +1649,27 @@ int afi_launch_wgrad6_group(const AfiWgradGemm* probs, int n, hipStream_t st) {
     while (done < n) {
         const int cnt = (n - done) < AFI_WG_MAXP ? (n - done) : AFI_WG_MAXP;
         grp.nprob = cnt;
-        // TILE-ALIGNED RUNS.  Equal runs cut anywhere make nearly every dW tile shared by two runs, and a shared tile is added by fp32
-        // atomics: ~100 MB of them per config-1 pass, all issued when the runs end together, against a chip-wide atomic rate of ~1.3 TB/s
-        // -- half of the kernel's time.  Most tiles of a pass have the SAME stage count (every low-res conv: ceil(850 / 32) = 27), so the
-        // run length is a multiple of that count and those problems go first: each of their tiles is then owned whole by one run and
-        // STORED; only the problems with another stage count (the conv on the up-sampled map) are cut across tiles and add atomically.
-        int nst_of[AFI_WG_MAXP]; long long tiles_of[AFI_WG_MAXP];
+        // Equal runs over the resident slots, as the fp32 group kernel cuts them.  Measured with tools/micro/wg6_bench.cpp (config 1, run
+        // length in stages: time per launch): 16: 163 us, 22 (three blocks per CU, this rule): 143, 27 (= one low-res tile: every tile of a
+        // low-res conv owned whole by one run and STORED instead of added by fp32 atomics; 602 blocks): 158, 32 (two per CU): 163, 54: 202
+        // -- the atomics of shared tiles are not what the kernel waits for; three resident blocks per CU are what it needs.
+        long long units = 0;
         for (int i = 0; i < cnt; ++i) {
             const AfiWgradGemm& g = probs[done + i];
             if ((g.Ncols & 3) || (g.Mrows & 3) || (g.dy_up == 2 && (g.CoutPhase & 3))) return AFI_ERR_UNSUPPORTED;
-            nst_of[i] = afi_cdiv((long long)g.N * g.H * g.W, AFI_BK);
-            tiles_of[i] = (long long)afi_cdiv(g.Mrows, 128) * afi_cdiv(g.Ncols, 128) * g.ntaps;
-        }
-        int nst_c = nst_of[0]; long long best = -1;
-        for (int i = 0; i < cnt; ++i) {
-            long long t = 0;
-            for (int j = 0; j < cnt; ++j) if (nst_of[j] == nst_of[i]) t += tiles_of[j];
-            if (t > best) { best = t; nst_c = nst_of[i]; }
-        }
-        int order[AFI_WG_MAXP], no = 0;
-        for (int i = 0; i < cnt; ++i) if (nst_of[i] == nst_c) order[no++] = i;
-        for (int i = 0; i < cnt; ++i) if (nst_of[i] != nst_c) order[no++] = i;
-        long long units = 0;
-        for (int k = 0; k < cnt; ++k) {
-            const int i = order[k];
-            const AfiWgradGemm& g = probs[done + i];
-            grp.g[k] = g;
-            grp.nst[k] = nst_of[i];
-            grp.ntile_m[k] = (short)afi_cdiv(g.Mrows, 128); grp.ntile_n[k] = (short)afi_cdiv(g.Ncols, 128);
-            grp.unit_start[k] = (int)units;
-            units += tiles_of[i] * nst_of[i];
+            grp.g[i] = g;
+            grp.nst[i] = afi_cdiv((long long)g.N * g.H * g.W, AFI_BK);
+            grp.ntile_m[i] = (short)afi_cdiv(g.Mrows, 128); grp.ntile_n[i] = (short)afi_cdiv(g.Ncols, 128);
+            grp.unit_start[i] = (int)units;
+            units += (long long)grp.ntile_m[i] * grp.ntile_n[i] * g.ntaps * grp.nst[i];
             if (units > 0x7fffffffLL) return AFI_ERR_UNSUPPORTED;
         }
         for (int i = cnt; i <= AFI_WG_MAXP; ++i) grp.unit_start[i] = (int)units;
         int blocks, upb;
-        {
-            const long long slots = 256LL * bpc;
-            long long mult = nst_c >= 4 ? 1 : (4 + nst_c - 1) / nst_c;               // no run shorter than four stages
-            while ((units + mult * nst_c - 1) / (mult * nst_c) > slots) ++mult;      // all runs resident at once (a second, partly filled round costs a whole run)
-            upb = (int)(mult * nst_c);
-            blocks = (int)((units + upb - 1) / upb);
-            if (blocks * 4 < slots) sk_cut(units, bpc, upb, blocks);                 // tiny groups: fill the chip instead (every tile shared)
-        }
+#ifdef AFI_WG6_UPB_OVERRIDE
+        if (AFI_WG6_UPB_OVERRIDE > 0) { upb = AFI_WG6_UPB_OVERRIDE; blocks = (int)((units + upb - 1) / upb); } else
+#endif
+        sk_cut(units, bpc, upb, blocks);
         grp.units_per_block = upb; grp.total_units = (int)units;
         hipLaunchKernelGGL(afi_wgrad6_group_sk_kernel, dim3((unsigned)blocks), dim3(256), 6 * 8192, st, grp);
         done += cnt;

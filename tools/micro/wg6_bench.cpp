@@ -2,6 +2,8 @@
 // on the config-1 problem set (seven 3x3 weight gradients of the interpolator at 25 x 34 / 50 x 68 + three packed growth-conv problems):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DAFI_WG6_ABLATE=n] tools/micro/wg6_bench.cpp -o tools/micro/wg6_bench[_n]
 // AFI_WG6_ABLATE removes parts of a stage (1 MFMAs, 2 gather, 4 split, 8 fragment reads, 16 result stores; results are wrong then).
+static int g_upb = 0;
+#define AFI_WG6_UPB_OVERRIDE g_upb                          // (argv[3]: run length of the stream-K cut, 0 = the launcher's own rule)
 #include "../../afigan_amd/csrc/smallmap.hip"
 #include <cstdio>
 #include <cstdlib>
@@ -19,6 +21,7 @@ static AfiWgradGemm prob(float* dy, float* x, float* dw, int H, int W, int Cout,
 int main(int argc, char** argv) {
     const int H = argc > 1 ? atoi(argv[1]) : 25, W = argc > 2 ? atoi(argv[2]) : 34;
     const int C = 256, G = 32, L = 384, P = H * W;
+    g_upb = argc > 3 ? atoi(argv[3]) : 0;
     float *act, *grad, *dw;
     CK(hipMalloc(&act, (size_t)4 * P * 1024 * 4)); CK(hipMalloc(&grad, (size_t)4 * P * 1024 * 4)); CK(hipMalloc(&dw, (size_t)1024 * 9 * 384 * 4 * 2));
     std::vector<float> h((size_t)4 * P * 1024);
@@ -42,6 +45,6 @@ int main(int argc, char** argv) {
     (void)hipEventRecord(e1, st); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     double fl = 0; for (auto& g : pr) fl += 2.0 * g.N * g.H * g.W * g.Mrows * g.Ncols * 9;
-    printf("wg6 ablate %d  %dx%d  %zu problems | %.1f us per launch (%.1f TF/s)\n", AFI_WG6_ABLATE, H, W, pr.size(), ms * 1e3 / iters, fl / (ms * 1e-3 / iters) * 1e-12);
+    printf("wg6 ablate %d  %dx%d  upb %d  %zu problems | %.1f us per launch (%.1f TF/s)\n", AFI_WG6_ABLATE, H, W, g_upb, pr.size(), ms * 1e3 / iters, fl / (ms * 1e-3 / iters) * 1e-12);
     return 0;
 }
