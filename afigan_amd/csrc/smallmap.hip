@@ -414,6 +414,7 @@ struct AfiWkArgs {
     int M, HW;
     unsigned rcp_HW, rcp_W, rcp_taps, rcp_ntm;
     int kph_shift;
+    int nj;                    // bf16x6 kernel: 32-column halves... 1 = 32 x 32 tiles, 2 = 32 x 64 (ntile_n counts tiles of 32 nj columns)
     unsigned long long* dbg;   // diagnostic build only
 };
 // Fused epilogue with every optional operand loaded UP FRONT (address select to the zero page when a term is off, its scale then 0):
@@ -725,9 +726,11 @@ __global__ __launch_bounds__(512, 4) void afi_pix_gemm_wk_group_kernel(const Afi
 #ifndef AFI_WK6_ABLATE
 #define AFI_WK6_ABLATE 0                                   // tools/micro/wk6_bench.cpp only: 1 no MFMAs, 2 no A gather, 4 no B loads, 8 no split (wrong results)
 #endif
-template <bool DIAG, int NW = 8>
+// NJ = 2: a wave's tile is 32 x 64 -- the same A fragments (gather, LDS staging, split: 110 of the ~160 vector-issue slots of a 32 x 32
+// stage) feed 48 MFMAs instead of 24; 150 registers, so one block per CU: for the grids that still cover the chip with 64-column tiles.
+template <bool DIAG, int NW = 8, int NJ = 1>
 __device__ __forceinline__ void afi_wk6_body(const AfiPixGemm& p, const AfiWkArgs& sk, const int lb) {
-    constexpr int BK = AFI_BK, LDK = BK + 4, PATCH = 32 * LDK;
+    constexpr int BK = AFI_BK, LDK = BK + 4, TN = 32 * NJ, LDC = TN + 4, PATCH = 32 * LDC, NH = 2 * NJ;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (DIAG) { if (threadIdx.x == 0) sk.dbg[(long long)blockIdx.x * 10 + 6] = __builtin_amdgcn_s_memrealtime(); }
     AFI_STAMP(0);
@@ -736,13 +739,16 @@ __device__ __forceinline__ void afi_wk6_body(const AfiPixGemm& p, const AfiWkArg
     const int M = sk.M, HW = sk.HW;
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.A.p, 0, 0x7FFFFFF0, 0x00020000);
     const int tile_n = (int)afi_udiv((unsigned)lb, (unsigned)sk.ntile_m, sk.rcp_ntm), tile_m = lb - tile_n * sk.ntile_m;
-    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int m0 = tile_m * 32, n0 = tile_n * TN;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int kc0 = wave_u * sk.nK / NW, kc1 = (wave_u + 1) * sk.nK / NW;   // this wave's K stages
     const int nK = kc1 - kc0;
     // this tile's part of the weight image: stage s of the problem at + s * 6144 bytes; a lane's fragment (n half ni, part) at
     // + (3 ni + part) * 1024 + 16 lane.  Addressed as a buffer (32-bit offsets; the launcher checks the image stays below 2 GB)
-    const unsigned char* img = p.Bimg + ((long long)tile_n * p.bimg_nstages + p.bimg_stage0) * AFI_WK6_STAGE_BYTES;
+    const unsigned char* img = p.Bimg + ((long long)tile_n * NJ * p.bimg_nstages + p.bimg_stage0) * AFI_WK6_STAGE_BYTES;
+    // (NJ = 2: the tile's second 32 columns are the image's next N tile, bimg_nstages stages further; an odd tile count: the last block's
+    //  second half re-reads the first -- its columns lie beyond Ncols and are never stored)
+    const int sub1 = (NJ == 2 && (tile_n * 2 + 1) * 32 < p.Ncols) ? p.bimg_nstages * AFI_WK6_STAGE_BYTES : 0;
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)img, 0, 0x7FFFFFF0, 0x00020000);
     const int last_stage = sk.nK - 1;
 
@@ -785,7 +791,7 @@ __device__ __forceinline__ void afi_wk6_body(const AfiPixGemm& p, const AfiWkArg
         if (++k_abs == kc1) { k_abs = kc0; k_tap = w_tap; k_kph = w_kph; k_c0 = w_c0; }
     };
     float* As = smem + wave_u * PATCH;                     // this wave's patch: [32 rows][LDK] fp32 (later its partial output tile)
-    u32x4 a_raw[4], b_raw[2][3];
+    u32x4 a_raw[4], b_raw[NH][3];
     // ONE register set per operand.  A: stage s + 2 is in flight in a_raw while stage s + 1 sits in the LDS patch and stage s is multiplied;
     // B: the weight fragments of an n half are re-requested (next stage) right behind the twelve MFMAs that read them.
     // (Loads are issued unconditionally -- counted vmcnt waits need a path-independent count: a masked A lane reads out of range = zeros,
@@ -824,19 +830,19 @@ __device__ __forceinline__ void afi_wk6_body(const AfiPixGemm& p, const AfiWkArg
     };
     auto load_b = [&](int ni, int stage_abs) {             // (ni: compile-time at every call site)
         const int st = stage_abs < last_stage ? stage_abs : last_stage;
-        const int soff = __builtin_amdgcn_readfirstlane(st) * AFI_WK6_STAGE_BYTES;
+        const int soff = __builtin_amdgcn_readfirstlane(st) * AFI_WK6_STAGE_BYTES + ((ni >> 1) ? sub1 : 0);
 #pragma unroll
         for (int pt = 0; pt < 3; ++pt) {
             if constexpr ((AFI_WK6_ABLATE & 4) == 0)
-                b_raw[ni][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (unsigned)(16 * lane + (3 * ni + pt) * 1024), soff, 0);
+                b_raw[ni][pt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (unsigned)(16 * lane + (3 * (ni & 1) + pt) * 1024), soff, 0);
             else { const unsigned o = (unsigned)soff + lane; b_raw[ni][pt] = u32x4{o, o, o, o}; }
         }
     };
-    f32x4 acc[2][2];
+    f32x4 acc[2][NH];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NH; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     auto mfma = [](u32x4 x, u32x4 y, f32x4 c) -> f32x4 {
         if constexpr ((AFI_WK6_ABLATE & 1) != 0) { asm volatile("" :: "v"(x), "v"(y)); return c; }
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), c, 0, 0, 0);
@@ -853,8 +859,8 @@ __device__ __forceinline__ void afi_wk6_body(const AfiPixGemm& p, const AfiWkArg
     load_a(1 < nK);                                        // stage 1
     // (the first weight fragments are requested BEHIND the second gather, the order every later stage has: the loop's counted waits are the
     //  merge of the entry and the back-edge states, and with the fragments requested first every stage waited for them before its stores)
-    load_b(0, kb_first);
-    load_b(1, kb_first);
+#pragma unroll
+    for (int ni = 0; ni < NH; ++ni) load_b(ni, kb_first);
     AFI_STAMP(3);
     for (int kc = 0; kc < nK; ++kc) {
         u32x4 ah[2], am[2], al[2];                          // packed bf16 pairs: element 2 j in the low half of word j
@@ -879,7 +885,7 @@ __device__ __forceinline__ void afi_wk6_body(const AfiPixGemm& p, const AfiWkArg
         read_frags();                                      // stage kc + 1, in flight under the MFMAs below
         // per accumulator: smallest terms first; consecutive MFMAs alternate between the two accumulators of the n half
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NH; ++ni) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) acc[mi][ni] = mfma(al[mi], b_raw[ni][0], acc[mi][ni]);
 #pragma unroll
@@ -901,30 +907,38 @@ __device__ __forceinline__ void afi_wk6_body(const AfiPixGemm& p, const AfiWkArg
     AFI_STAMP(4);
     // ---- the eight partial tiles meet in LDS (each wave writes its own patch), then 256 threads sum them and run the fused epilogue;
     //      the epilogue's own operands are requested first (their global round trip runs under the LDS write, the barrier and the reads)
-    const int e_rl = tid >> 3, e_c4 = tid & 7;
-    const int e_m = m0 + e_rl, e_col = n0 + 4 * e_c4;
-    const bool e_on = tid < 256 && e_m < M && e_col < p.Ncols;
-    AfiEpiPre epre; int e_img = 0, e_y = 0, e_x = 0;
-    if (e_on) {
-        afi_gfloat* zpage = (afi_gfloat*)afi_zeros;
-        asm volatile("" : "+v"(zpage));
-        const unsigned im = afi_udiv((unsigned)e_m, (unsigned)HW, sk.rcp_HW);
-        const int rem = e_m - (int)im * HW;
-        e_y = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W); e_x = rem - e_y * p.W; e_img = (int)im;
-        epre = afi_epilogue_prefetch(p, e_img, e_y, e_x, e_col, zpage);
+    constexpr int C4 = TN / 4;                              // float4 columns of the tile
+    AfiEpiPre epre[NJ]; int e_img[NJ], e_y[NJ], e_x[NJ]; bool e_on[NJ];
+#pragma unroll
+    for (int it = 0; it < NJ; ++it) {
+        const int item = tid + 256 * it, e_rl = item / C4, e_c4 = item - e_rl * C4;
+        const int e_m = m0 + e_rl, e_col = n0 + 4 * e_c4;
+        e_on[it] = tid < 256 && e_m < M && e_col < p.Ncols;
+        e_img[it] = e_y[it] = e_x[it] = 0;
+        if (e_on[it]) {
+            afi_gfloat* zpage = (afi_gfloat*)afi_zeros;
+            asm volatile("" : "+v"(zpage));
+            const unsigned im = afi_udiv((unsigned)e_m, (unsigned)HW, sk.rcp_HW);
+            const int rem = e_m - (int)im * HW;
+            e_y[it] = (int)afi_udiv((unsigned)rem, (unsigned)p.W, sk.rcp_W); e_x[it] = rem - e_y[it] * p.W; e_img[it] = (int)im;
+            epre[it] = afi_epilogue_prefetch(p, e_img[it], e_y[it], e_x[it], e_col, zpage);
+        }
     }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NH; ++ni)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) As[(16 * mi + 4 * lq + r) * LDK + 16 * ni + l15] = acc[mi][ni][r];
+            for (int r = 0; r < 4; ++r) As[(16 * mi + 4 * lq + r) * LDC + 16 * ni + l15] = acc[mi][ni][r];
     __syncthreads();
-    if (e_on) {
-        f32x4 v = *(const f32x4*)(smem + e_rl * LDK + 4 * e_c4);
 #pragma unroll
-        for (int w = 1; w < NW; ++w) v += *(const f32x4*)(smem + w * PATCH + e_rl * LDK + 4 * e_c4);     // fixed order: bit-reproducible
-        afi_epilogue_finish(p, epre, e_img, e_y, e_x, v);
+    for (int it = 0; it < NJ; ++it) {
+        if (!e_on[it]) continue;
+        const int item = tid + 256 * it, e_rl = item / C4, e_c4 = item - e_rl * C4;
+        f32x4 v = *(const f32x4*)(smem + e_rl * LDC + 4 * e_c4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += *(const f32x4*)(smem + w * PATCH + e_rl * LDC + 4 * e_c4);     // fixed order: bit-reproducible
+        afi_epilogue_finish(p, epre[it], e_img[it], e_y[it], e_x[it], v);
     }
     AFI_STAMP(5);
     AFI_STAMP(8);
@@ -939,6 +953,17 @@ __global__ __launch_bounds__(512, 4) void afi_pix_gemm_wk6_group_kernel(const Af
     int pi = 0;
     while (pi + 1 < grp.nprob && t >= grp.tile_start[pi + 1]) ++pi;     // (uniform)
     afi_wk6_body<false>(grp.p[pi], grp.wk[pi], t - grp.tile_start[pi]);
+}
+// the 32 x 64 form (one block per CU): single problems, and groups whose wide problems take it (wk.nj == 2) beside 32-column ones
+__global__ __launch_bounds__(512, 2) void afi_pix_gemm_wk6w_kernel(const AfiPixGemm p, const AfiWkArgs sk) {
+    afi_wk6_body<false, 8, 2>(p, sk, afi_xcd_logical_id());
+}
+__global__ __launch_bounds__(512, 2) void afi_pix_gemm_wk6w_group_kernel(const AfiWkGroup grp) {
+    const int t = afi_xcd_logical_id();
+    int pi = 0;
+    while (pi + 1 < grp.nprob && t >= grp.tile_start[pi + 1]) ++pi;     // (uniform)
+    if (grp.wk[pi].nj == 2) afi_wk6_body<false, 8, 2>(grp.p[pi], grp.wk[pi], t - grp.tile_start[pi]);
+    else afi_wk6_body<false, 8, 1>(grp.p[pi], grp.wk[pi], t - grp.tile_start[pi]);
 }
 
 // Weight images of afi_pix_gemm_wk6.  One thread per (job, N tile, K stage, n half, lane): the lane's eight consecutive k of column
@@ -1031,10 +1056,14 @@ static int wk_prepare(const AfiPixGemm& p, bool b_rc, AfiWkArgs& wk) {
     wk.M = (int)M; wk.HW = p.H * p.W;
     wk.rcp_HW = sk_rcp((unsigned)wk.HW); wk.rcp_W = sk_rcp((unsigned)p.W); wk.rcp_taps = sk_rcp((unsigned)p.ntaps); wk.rcp_ntm = sk_rcp((unsigned)wk.ntile_m);
     wk.kph_shift = p.nKphase == 4 ? 2 : 0;
+    wk.nj = 1;
     wk.dbg = nullptr;
     if ((long long)wk.ntile_m * wk.ntile_n * wk.ntile_m >= (1LL << 32)) return AFI_ERR_UNSUPPORTED;
     return AFI_OK;
 }
+// the bf16x6 kernel's 32 x 64 form for this problem: half as many (twice as wide) tiles
+static inline void wk6_widen(const AfiPixGemm& p, AfiWkArgs& wk) { wk.nj = 2; wk.ntile_n = afi_cdiv(p.Ncols, 64); }
+static inline bool wk6_wide_candidate(const AfiPixGemm& p, const AfiWkArgs& wk) { return p.Ncols >= 64 && wk.nK >= 16; }
 // ------------------------------------------------------------------------------------------------
 // afi_rdb_chain6_kernel: the dense block's chain of 32-channel convs (AfiChain6, afi_common.h) in one launch.  At config 1 each link was
 // a launch of its own whose 1 us of matrix work sat in 9 us of fixed cost (launch, first touches, reduction, epilogue), four per block
@@ -1271,7 +1300,19 @@ static bool wk6_ok(const AfiPixGemm& p, const AfiWkArgs& wk) {
     if (!p.Bimg || p.bimg_nstages <= 0 || p.bimg_stage0 < 0 || (((uintptr_t)p.Bimg) & 15)) return false;
     if (p.bimg_stage0 + wk.nK > p.bimg_nstages) return false;
     if (p.Ck & 3) return false;
-    return (long long)p.bimg_nstages * AFI_WK6_STAGE_BYTES < 0x7FFFFFF0LL;
+    return 2LL * p.bimg_nstages * AFI_WK6_STAGE_BYTES < 0x7FFFFFF0LL;      // (the 32 x 64 form reaches into the next N tile of the image)
+}
+static bool wk6_opt_in_wide() {                             // the 32 x 64 form keeps eight 32 x 68 partial tiles: 69.6 KB of dynamic LDS, an opt-in per kernel and device
+    static std::mutex mu;
+    static std::set<int> done;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count(dev)) return true;
+    if (hipFuncSetAttribute((const void*)afi_pix_gemm_wk6w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    if (hipFuncSetAttribute((const void*)afi_pix_gemm_wk6w_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    done.insert(dev);
+    return true;
 }
 // up to AFI_WK_MAXP simultaneous small-map GEMMs in one launch; validates everything before it launches anything
 int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st) {
@@ -1290,6 +1331,24 @@ int afi_launch_pix_gemm_wk_group(const AfiPixGemm* probs, int n, int b_rc, hipSt
     bool all6 = true;
     for (int i = 0; i < n; ++i) all6 = all6 && wk6_ok(probs[i], grp.wk[i]);
     if (all6) {
+        // 32 x 64 tiles for the group's wide, long-K problems when the launch still has a block for at least half the CUs that way
+        // (the dense block's first step: four 32-column problems + conv5's 256 columns = 108 + 108 blocks instead of 108 + 216)
+        int wide_tiles = 0;
+        for (int i = 0; i < n; ++i)
+            wide_tiles += wk6_wide_candidate(probs[i], grp.wk[i]) ? grp.wk[i].ntile_m * afi_cdiv(probs[i].Ncols, 64) : grp.wk[i].ntile_m * grp.wk[i].ntile_n;
+        bool any_wide = false;
+        for (int i = 0; i < n; ++i) any_wide = any_wide || wk6_wide_candidate(probs[i], grp.wk[i]);
+        if (any_wide && wide_tiles >= 128 && wk6_opt_in_wide()) {
+            tiles = 0;
+            for (int i = 0; i < n; ++i) {
+                if (wk6_wide_candidate(probs[i], grp.wk[i])) wk6_widen(probs[i], grp.wk[i]);
+                grp.tile_start[i] = tiles;
+                tiles += grp.wk[i].ntile_m * grp.wk[i].ntile_n;
+            }
+            for (int i = n; i <= AFI_WK_MAXP; ++i) grp.tile_start[i] = tiles;
+            hipLaunchKernelGGL(afi_pix_gemm_wk6w_group_kernel, dim3((unsigned)tiles), dim3(512), sizeof(float) * 8 * 32 * (64 + 4), st, grp);
+            return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+        }
         hipLaunchKernelGGL(afi_pix_gemm_wk6_group_kernel, dim3((unsigned)tiles), dim3(512), sizeof(float) * 8 * 32 * (AFI_BK + 4), st, grp);
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }
@@ -1309,6 +1368,11 @@ static int launch_wk(const AfiPixGemm& p, hipStream_t st) {
     if (wk6_ok(p, wk)) {                                   // bf16x6 on the pre-split weight image (no B_RC distinction: the image holds the k-contiguous fragments)
         // (measured and dropped: sixteen waves per tile -- 1024-thread blocks, four waves per SIMD -- for the grids of at most one block per CU
         //  (216 tiles, K = 2304 / 9216): 13.4 against 12.3 us and 37.5 against 37.5; the loop is bound by vector issue, not by latency)
+        if (wk6_wide_candidate(p, wk) && (long long)wk.ntile_m * afi_cdiv(p.Ncols, 64) >= 128 && wk6_opt_in_wide()) {   // 32 x 64 tiles while they cover half the chip
+            wk6_widen(p, wk);
+            hipLaunchKernelGGL(afi_pix_gemm_wk6w_kernel, dim3((unsigned)(wk.ntile_m * wk.ntile_n)), dim3(512), sizeof(float) * 8 * 32 * (64 + 4), st, p, wk);
+            return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+        }
         hipLaunchKernelGGL((afi_pix_gemm_wk6_kernel<false>), dim3((unsigned)G), dim3(512), sizeof(float) * 8 * 32 * LDK, st, p, wk);
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }
