@@ -81,6 +81,10 @@ struct AfiPixGemm {
 // stage_off / nstages_img (0 = this job's own stage count): the job fills stages [stage_off, stage_off + its stages) of an image whose N tiles
 // are nstages_img stages apart -- several weights side by side along K in ONE image (the dense block's four growth convs as one data gradient)
 struct AfiWk6ImgJob { const float* B; long long b_sRow, b_sTap; int Ncols, Ck, ntaps, nKphase, b_rc, stage_off; unsigned char* dst; int nstages_img, pad1; };
+// Work of a small-map backward pass that depends on nothing the pass computes and rides in its image launch as extra blocks (a launch of its
+// own costs each of them more than the work): zero_p[0 .. 4 zero_n4) = 0 (the packed gradient buffers the stream-K weight gradients add into),
+// and bl_dx[N,H,W,C] = bilinear2x^T(bl_dout[N,2H,2W,C]) (the skip path's gradient, generator_rdb.py:125).  Null pointers: off.
+struct AfiWk6Side { float* zero_p; long long zero_n4; const float* bl_dout; float* bl_dx; int bl_N, bl_H, bl_W, bl_C; };
 
 // Fused growth-conv chain of one dense block on a small map (csrc/smallmap.hip: afi_rdb_chain6_kernel): three dependent 3x3 convs with
 // 32-channel outputs -- y2, y3, y4 of ResidualDenseBlock.forward, or the data gradients g3, g2, g1 of its backward -- in ONE launch.  A block

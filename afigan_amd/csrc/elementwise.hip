@@ -4,7 +4,9 @@
 // All of them are float4-vectorised along the contiguous channel dimension of the pixel-major layout;
 // reductions use wavefront shuffles (64 lanes) + one LDS hop per block.
 #include "afi_common.h"
+#include "afi_bilinear.h"
 #include <stdlib.h>
+#include <string.h>
 
 #define AFI_BN_EPS 1e-5f
 #define AFI_BN_MOMENTUM 0.1f
@@ -75,9 +77,9 @@ int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hi
 #define AFI_CT_CO 2                                          // 8 -> 2: 1024 blocks for the 256x256 layer (the pass is latency-bound: 21 / 28 us with 256 blocks)
 #define AFI_CT_LD (AFI_CT_CO * 36 + 1)
 template <bool UNPACK>
-__global__ __launch_bounds__(256) void afi_convT_repack_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cin, int Cout) {
+__device__ __forceinline__ void afi_convT_repack_body(const float* __restrict__ src, float* __restrict__ dst, int Cin, int Cout, int bx, int by) {
     __shared__ float T[AFI_CT_CI][AFI_CT_LD];                 // [ci][co_l*36 + ky*6 + kx]
-    const int ci0 = blockIdx.x * AFI_CT_CI, co0 = blockIdx.y * AFI_CT_CO, tid = threadIdx.x;
+    const int ci0 = bx * AFI_CT_CI, co0 = by * AFI_CT_CO, tid = threadIdx.x;
     // pack: src = W [Cin][Cout][6][6], dst = Wp [(phase*Cout + co)][tap][ci];  unpack: src = dWp, dst = dW (accumulated)
     // packed side: thread -> (ci lane, row), row = (phase, co_l, tap)
     auto packed_pass = [&](auto&& f) {
@@ -108,6 +110,10 @@ __global__ __launch_bounds__(256) void afi_convT_repack_kernel(const float* __re
         __syncthreads();
         torch_pass([&](float& t, long long off) { dst[off] += t; });      // dW += (accumulating gradient buffer)
     }
+}
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void afi_convT_repack_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cin, int Cout) {
+    afi_convT_repack_body<UNPACK>(src, dst, Cin, Cout, blockIdx.x, blockIdx.y);
 }
 int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStream_t st) {
     hipLaunchKernelGGL(afi_convT_repack_kernel<false>, dim3((Cin + AFI_CT_CI - 1) / AFI_CT_CI, (Cout + AFI_CT_CO - 1) / AFI_CT_CO), dim3(256), 0, st, W, Wp, Cin, Cout);
@@ -143,12 +149,11 @@ __global__ __launch_bounds__(256) void afi_rdb_wgrad_unpack_kernel(const float* 
 }
 // the same for several dense blocks in one launch (small maps: a launch per block costs more than the work): blockIdx.y = block
 struct AfiRdbUnpackMulti { const float* dWp; long long stride; float* dw[8][4]; };
-__global__ __launch_bounds__(256) void afi_rdb_wgrad_unpack_multi_kernel(const AfiRdbUnpackMulti t, int C, int G, float alpha) {
-    const int r = blockIdx.y;
+__device__ __forceinline__ void afi_rdb_wgrad_unpack_multi_body(const AfiRdbUnpackMulti& t, int C, int G, float alpha, int bx, int nbx, int r) {
     const float* __restrict__ dWp = t.dWp + (long long)r * t.stride;
     const int L = C + 4 * G;
     const long long total = 4LL * G * 9 * (L >> 2);
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    for (long long e = (long long)bx * blockDim.x + threadIdx.x; e < total; e += (long long)nbx * blockDim.x) {
         const int c4 = (int)(e % (L >> 2)) * 4;
         const long long rt = e / (L >> 2);
         const int row = (int)(rt / 9), tap = (int)(rt - 9LL * row);
@@ -163,6 +168,9 @@ __global__ __launch_bounds__(256) void afi_rdb_wgrad_unpack_multi_kernel(const A
         d += alpha * v;
         *dst = d;
     }
+}
+__global__ __launch_bounds__(256) void afi_rdb_wgrad_unpack_multi_kernel(const AfiRdbUnpackMulti t, int C, int G, float alpha) {
+    afi_rdb_wgrad_unpack_multi_body(t, C, G, alpha, blockIdx.x, gridDim.x, blockIdx.y);
 }
 int afi_launch_rdb_wgrad_unpack_multi(const float* dWp, long long stride, float* const (*dw)[4], int nblocks, int C, int G, float alpha, hipStream_t st) {
     if (!dWp || nblocks <= 0 || nblocks > 8 || C <= 0 || G <= 0 || (C & 3) || (G & 3)) return AFI_ERR_BAD_ARG;
@@ -182,6 +190,112 @@ int afi_launch_rdb_wgrad_unpack(const float* dWp, float* const dw[4], int C, int
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(afi_rdb_wgrad_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dWp, dw[0], dw[1], dw[2], dw[3], C, G, alpha);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped bias gradients: db[c] += alpha * sum_rows g[row][c] for up to 8 matrices in one launch (fp32 atomics: a few thousand adds)
+// ------------------------------------------------------------------------------------------------
+#define AFI_CS_MAXP 8
+struct AfiColsumGroup {
+    int nprob;
+    int blk_start[AFI_CS_MAXP + 1];
+    struct { const float* g; float* db; long long P, ld; int C; int rows_per_blk; float alpha; int pad; } d[AFI_CS_MAXP];
+};
+__device__ __forceinline__ void afi_colsum_group_body(const AfiColsumGroup& grp, const int b) {
+    __shared__ f32x4 red[16][16];
+    int pi = 0;
+    while (pi + 1 < grp.nprob && b >= grp.blk_start[pi + 1]) ++pi;
+    const auto& d = grp.d[pi];
+    const int lbk = b - grp.blk_start[pi];
+    const int ccs = (d.C + 63) / 64;                       // 64-channel column groups
+    const int cg = lbk % ccs, rc = lbk / ccs;
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = cg * 64 + cq * 4;
+    const long long r0 = (long long)rc * d.rows_per_blk;
+    const long long r1 = (r0 + d.rows_per_blk < d.P) ? r0 + d.rows_per_blk : d.P;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (c < d.C)
+        for (long long r = r0 + rl; r < r1; r += 16) s += *(const f32x4*)(d.g + r * d.ld + c);
+    red[rl][cq] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cc = threadIdx.x >> 2, j = threadIdx.x & 3;
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v += red[i][cc][j];
+        const int ch = cg * 64 + cc * 4 + j;
+        if (ch < d.C) atomicAdd(d.db + ch, d.alpha * v);
+    }
+}
+__global__ __launch_bounds__(256) void afi_colsum_group_kernel(const AfiColsumGroup grp) { afi_colsum_group_body(grp, blockIdx.x); }
+static int afi_colsum_group_fill(const AfiColsumProb* probs, int n, AfiColsumGroup& grp, int& blocks) {
+    if (n > AFI_CS_MAXP) return AFI_ERR_BAD_ARG;
+    grp.nprob = n;
+    blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (probs[i].C & 3) return AFI_ERR_UNSUPPORTED;
+        const int rpb = 128;                               // rows per block: 850 rows -> 7 blocks per column group
+        grp.d[i].g = probs[i].g; grp.d[i].db = probs[i].db; grp.d[i].P = probs[i].P; grp.d[i].ld = probs[i].ld;
+        grp.d[i].C = probs[i].C; grp.d[i].rows_per_blk = rpb; grp.d[i].alpha = probs[i].alpha; grp.d[i].pad = 0;
+        grp.blk_start[i] = blocks;
+        blocks += ((probs[i].C + 63) / 64) * afi_cdiv(probs[i].P, rpb);
+    }
+    for (int i = n; i <= AFI_CS_MAXP; ++i) grp.blk_start[i] = blocks;
+    return AFI_OK;
+}
+int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st) {
+    if (n <= 0) return AFI_OK;
+    AfiColsumGroup grp;
+    int blocks = 0;
+    { const int rc = afi_colsum_group_fill(probs, n, grp, blocks); if (rc != AFI_OK) return rc; }
+    hipLaunchKernelGGL(afi_colsum_group_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grp);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// The tail of a small-map generator backward in ONE launch: the grouped bias gradients, the conv-transpose gradient's unpack and the dense
+// blocks' packed growth-conv gradients' unpack -- three launches of 5 .. 9 us each whose work is a fraction of that (the first depends on
+// nothing of the other two; the unpacks read what the grouped weight-gradient launch in front of this one wrote).  Blocks [0, nb_cs) run the
+// column sums, [nb_cs, nb_cs + nb_ct) the conv-transpose tiles (ctx x cty), the rest the dense blocks (nb_rdb per block).  Same bodies as the
+// three kernels above: same bits.
+struct AfiGenBwdTail {
+    AfiColsumGroup cs; int nb_cs;
+    const float* ct_src; float* ct_dst; int ct_Cin, ct_Cout, ct_bx, nb_ct;
+    AfiRdbUnpackMulti rdb; int rdb_C, rdb_G, nb_rdb, n_rdb; float rdb_alpha; int pad_;
+};
+__global__ __launch_bounds__(256) void afi_g_bwd_tail_kernel(const AfiGenBwdTail t) {
+    int b = blockIdx.x;                                     // (every branch below is uniform per block)
+    if (b < t.nb_cs) { afi_colsum_group_body(t.cs, b); return; }
+    b -= t.nb_cs;
+    if (b < t.nb_ct) { afi_convT_repack_body<true>(t.ct_src, t.ct_dst, t.ct_Cin, t.ct_Cout, b % t.ct_bx, b / t.ct_bx); return; }
+    b -= t.nb_ct;
+    afi_rdb_wgrad_unpack_multi_body(t.rdb, t.rdb_C, t.rdb_G, t.rdb_alpha, b % t.nb_rdb, t.nb_rdb, b / t.nb_rdb);
+}
+// any of the three parts may be absent (n_cs = 0, dWpT = null, nblocks = 0)
+int afi_launch_g_bwd_tail(const AfiColsumProb* cs, int n_cs, const float* dWpT, float* dWT, int Cin, int Cout,
+                          const float* dWp, long long stride, float* const (*dw)[4], int nblocks, int C, int G, float alpha, hipStream_t st) {
+    AfiGenBwdTail t;
+    memset(&t, 0, sizeof(t));
+    if (n_cs > 0) { const int rc = afi_colsum_group_fill(cs, n_cs, t.cs, t.nb_cs); if (rc != AFI_OK) return rc; }
+    if (dWpT) {
+        if (!dWT || Cin <= 0 || Cout <= 0) return AFI_ERR_BAD_ARG;
+        t.ct_src = dWpT; t.ct_dst = dWT; t.ct_Cin = Cin; t.ct_Cout = Cout;
+        t.ct_bx = (Cin + AFI_CT_CI - 1) / AFI_CT_CI;
+        t.nb_ct = t.ct_bx * ((Cout + AFI_CT_CO - 1) / AFI_CT_CO);
+    }
+    if (nblocks > 0) {
+        if (!dWp || nblocks > 8 || C <= 0 || G <= 0 || (C & 3) || (G & 3)) return AFI_ERR_BAD_ARG;
+        t.rdb.dWp = dWp; t.rdb.stride = stride;
+        for (int r = 0; r < 8; ++r)
+            for (int k = 0; k < 4; ++k) t.rdb.dw[r][k] = r < nblocks ? dw[r][k] : nullptr;
+        const long long total = 4LL * G * 9 * ((C + 4 * G) >> 2);
+        long long blocks = (total + 255) / 256;
+        if (blocks > 1024) blocks = 1024;
+        t.rdb_C = C; t.rdb_G = G; t.nb_rdb = (int)blocks; t.n_rdb = nblocks; t.rdb_alpha = alpha;
+    }
+    const long long grid = (long long)t.nb_cs + t.nb_ct + (long long)t.nb_rdb * t.n_rdb;
+    if (grid <= 0) return AFI_OK;
+    hipLaunchKernelGGL(afi_g_bwd_tail_kernel, dim3((unsigned)grid), dim3(256), 0, st, t);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -711,10 +825,7 @@ int afi_launch_l1(AfiView a, AfiView b, int N, int h, int w, int C, int Ha, int 
 }
 
 // ---------------------------------------------------------------- bilinear x2 (standalone forward / backward)
-__device__ __forceinline__ void afi_bil_idx2(int o, int L, int& i0, int& i1, float& lam) {
-    float s = fmaxf(0.5f * (float)o - 0.25f, 0.f);
-    i0 = (int)s; lam = s - (float)i0; i1 = min(i0 + 1, L - 1);
-}
+// (index map and the transpose's element: afi_bilinear.h)
 // out[N,2H,2W,C] (dense) = beta*out + bilinear2x(x[N,H,W,C] view)
 __global__ void afi_bilinear2x_fwd_kernel(AfiView x, int N, int H, int W, int C, float beta, float* __restrict__ out) {
     const int C4 = C / 4;
@@ -734,23 +845,9 @@ __global__ void afi_bilinear2x_fwd_kernel(AfiView x, int N, int H, int W, int C,
 }
 // dx[N,H,W,C] (dense) = beta*dx + bilinear2x^T(dout[N,2H,2W,C] dense)
 __global__ void afi_bilinear2x_bwd_kernel(const float* __restrict__ dout, int N, int H, int W, int C, float beta, float* __restrict__ dx) {
-    const int C4 = C / 4;
-    const long long total = (long long)N * H * W * C4;
+    const long long total = (long long)N * H * W * (C / 4);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4; long long r = i / C4;
-        const int xi = (int)(r % W); r /= W; const int yi = (int)(r % H); const int n = (int)(r / H);
-        f32x4 acc = {0, 0, 0, 0};
-        for (int yo = max(2 * yi - 2, 0); yo <= min(2 * yi + 2, 2 * H - 1); ++yo) {
-            int y0, y1; float ly; afi_bil_idx2(yo, H, y0, y1, ly);
-            const float wy = (y0 == yi ? 1.f - ly : 0.f) + (y1 == yi ? ly : 0.f);
-            if (wy == 0.f) continue;
-            for (int xo = max(2 * xi - 2, 0); xo <= min(2 * xi + 2, 2 * W - 1); ++xo) {
-                int x0, x1; float lx; afi_bil_idx2(xo, W, x0, x1, lx);
-                const float wx = (x0 == xi ? 1.f - lx : 0.f) + (x1 == xi ? lx : 0.f);
-                if (wx == 0.f) continue;
-                acc += (wy * wx) * *(const f32x4*)(dout + (((long long)n * 2 * H + yo) * 2 * W + xo) * C + c);
-            }
-        }
+        f32x4 acc = afi_bilinear2x_bwd_elem(dout, H, W, C, i);
         if (beta != 0.f) acc += beta * *(const f32x4*)(dx + i * 4);
         *(f32x4*)(dx + i * 4) = acc;
     }

@@ -23,7 +23,7 @@ int afi_launch_wgrad_gemm_group6(const AfiWgradGemm* probs, int n, hipStream_t s
 int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st);
 int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
 long long afi_wk6_image_bytes(int Ncols, int Ck, int ntaps, int nKphase);                       // smallmap.hip: bf16x6 weight images of the small-map kernels
-int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st);
+int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st, const AfiWk6Side* side);
 int afi_launch_rdb_chain6(const AfiChain6& c, hipStream_t st);                                   // smallmap.hip: a dense block's chain of 32-channel convs in one launch
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
@@ -31,6 +31,8 @@ int afi_launch_convT_pack(const float* W, float* Wp, int Cin, int Cout, hipStrea
 int afi_launch_convT_unpack_grad(const float* dWp, float* dW, int Cin, int Cout, hipStream_t st);
 int afi_launch_rdb_wgrad_unpack(const float* dWp, float* const dw[4], int C, int G, float alpha, hipStream_t st);
 int afi_launch_rdb_wgrad_unpack_multi(const float* dWp, long long stride, float* const (*dw)[4], int nblocks, int C, int G, float alpha, hipStream_t st);
+int afi_launch_g_bwd_tail(const AfiColsumProb* cs, int n_cs, const float* dWpT, float* dWT, int Cin, int Cout,
+                          const float* dWp, long long stride, float* const (*dw)[4], int nblocks, int C, int G, float alpha, hipStream_t st);
 int afi_launch_rdb_xpart_pack(const float* const w[4], float* out, int C, int G, hipStream_t st);
 int afi_launch_lrelu_slice(AfiView v, int N, int H, int W, int nch, hipStream_t st);
 int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
@@ -302,8 +304,12 @@ struct Wk6Images {
             if (e[i].key == key && (tag < 0 ? e[i].tag < 2 : e[i].tag == tag)) { g.Bimg = e[i].img; g.bimg_nstages = e[i].nstages; g.bimg_stage0 = (c_lo / 32) * g.ntaps; return; }
     }
 };
-static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, float* arena, long long arena_floats, hipStream_t st) {
+// side (optional): work that rides in the image launch (AfiWk6Side); *side_done says whether it did -- no launch happens when every image
+// came from the caller's weight cache, or when the images do not fit
+static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, float* arena, long long arena_floats, hipStream_t st,
+                     const AfiWk6Side* side = nullptr, bool* side_done = nullptr) {
     im.on = false; im.n = 0;
+    if (side_done) *side_done = false;
     if (n > kWk6MaxReq) return AFI_OK;
     AfiWk6ImgJob jobs[kWk6MaxJobs];
     int nj = 0;
@@ -329,7 +335,10 @@ static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, floa
         }
         im.e[im.n++] = Wk6Images::Ent{r.key, r.tag, (const unsigned char*)slot, nst};
     }
-    if (nj) AFI_TRY(afi_launch_wk6_images(jobs, nj, st));
+    if (nj) {
+        AFI_TRY(afi_launch_wk6_images(jobs, nj, st, side));
+        if (side && side_done) *side_done = true;
+    }
     im.on = true;
     return AFI_OK;
 }
@@ -1278,13 +1287,14 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
         if (rc6 == AFI_ERR_UNSUPPORTED) AFI_TRY(afi_launch_wgrad_gemm_group(wg_wide, n_wide, 1, sd));
         else AFI_TRY(rc6);
         AFI_TRY(afi_launch_wgrad_gemm_group(wg_narrow, n_narrow, 0, sd));
-        AFI_TRY(afi_launch_colsum_group(cs, n_cs, sd));
-        if (unpack_pending && gr->wT && n_wide_has_convT) { AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd)); unpack_pending = false; }
-        if (packed_blocks > 0) {                           // every packed growth-conv gradient of the pass in ONE launch (a block that was not packed: null targets)
+        {   // bias gradients, the conv-transpose gradient's unpack and every packed growth-conv gradient of the pass (a block that was not packed:
+            // null targets) in ONE launch
+            const bool ct = unpack_pending && gr->wT && n_wide_has_convT;
             float* dws[AFI_MAX_RDB][4];
             for (int r = 0; r < R; ++r)
                 for (int k = 0; k < 4; ++k) dws[r][k] = (packed_mask & (1u << r)) ? gr->rdb_w[r][k] : nullptr;
-            AFI_TRY(afi_launch_rdb_wgrad_unpack_multi(scratch + s.o_rdbw, s.n_rdbw, dws, R, C, G, 1.f, sd));
+            AFI_TRY(afi_launch_g_bwd_tail(cs, n_cs, ct ? dwp : nullptr, gr->wT, C, C, scratch + s.o_rdbw, s.n_rdbw, dws, packed_blocks > 0 ? R : 0, C, G, 1.f, sd));
+            if (ct) unpack_pending = false;
             packed_mask = 0; packed_blocks = 0;
         }
         n_wide = n_narrow = n_cs = 0; n_wide_has_convT = false;
@@ -1293,6 +1303,9 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // (the dense blocks' gradient chains g4 -> g3 -> g2 -> g1 as one launch each, below: needs the packed weight gradients and 32-channel slices)
     const bool chain_shapes = six && pack_growth6 && s.n_gch > 0 && G == 32 && (C % 32) == 0 && (afi_opt(cx, AFI_OPT_G_RDB_CHAIN) == 1 || afi_opt(cx, AFI_OPT_G_RDB_CHAIN) == 2);
     Wk6Images im;                                          // weight images of the data-gradient GEMMs (row-contiguous weights)
+    // (the packed conv-transpose gradient and the packed growth-conv gradients are neighbours in the scratch: ONE fill for both)
+    const bool one_fill = pack_growth6 && gr->wT && s.o_rdbw == s.o_dwp + align4(36LL * C * C) && (s.n_rdbw & 3) == 0;
+    bool filled = false, skip_grad_done = false;
     if (six && s.n_img > 0) {
         Wk6Req rq[kWk6MaxReq];
         int nr = 0;
@@ -1310,11 +1323,18 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
         }
         if (dx) rq[nr++] = wk6_req(prm->w0, prm->w0, C, C, 1, 1, 9LL * C, C);
         if (4 * P <= kWk6HiResMaxPixels) rq[nr++] = wk6_req(prm->w9, prm->w9, C, C, 1, 1, 9LL * C, C);
-        AFI_TRY(wk6_build(cx, im, rq, nr, scratch + s.o_img, s.n_img, st));
+        // riders of that launch (they depend on nothing this pass computes): the zero fill below and the skip path's gradient into dx
+        AfiWk6Side side;
+        memset(&side, 0, sizeof(side));
+        if (one_fill && (((uintptr_t)(scratch + s.o_dwp)) & 15) == 0) { side.zero_p = scratch + s.o_dwp; side.zero_n4 = (align4(36LL * C * C) + (long long)R * s.n_rdbw) / 4; }
+        if (dx && (C & 3) == 0) { side.bl_dout = dout; side.bl_dx = dx; side.bl_N = N; side.bl_H = H; side.bl_W = W; side.bl_C = C; }
+        bool rode = false;
+        AFI_TRY(wk6_build(cx, im, rq, nr, scratch + s.o_img, s.n_img, st, &side, &rode));
+        filled = rode && side.zero_p;
+        skip_grad_done = rode && side.bl_dx;
     }
-    // (the packed conv-transpose gradient and the packed growth-conv gradients are neighbours in the scratch: ONE fill for both)
-    const bool one_fill = pack_growth6 && gr->wT && s.o_rdbw == s.o_dwp + align4(36LL * C * C);
-    if (one_fill) { if (hipMemsetAsync(scratch + s.o_dwp, 0, sizeof(float) * (size_t)(align4(36LL * C * C) + (long long)R * s.n_rdbw), st) != hipSuccess) return AFI_ERR_LAUNCH; }
+    if (filled) {}
+    else if (one_fill) { if (hipMemsetAsync(scratch + s.o_dwp, 0, sizeof(float) * (size_t)(align4(36LL * C * C) + (long long)R * s.n_rdbw), st) != hipSuccess) return AFI_ERR_LAUNCH; }
     else if (pack_growth6 && hipMemsetAsync(scratch + s.o_rdbw, 0, sizeof(float) * (size_t)R * s.n_rdbw, st) != hipSuccess) return AFI_ERR_LAUNCH;
 
     // ---- final conv (generator_rdb.py:107-108)
@@ -1492,7 +1512,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     if (gr->w0) AFI_TRY(WG(Gt, x, N, H, W, C, C, gr->w0, 1.f, sd));
     if (gr->b0) AFI_TRY(CS(Gt.p, P, C, L, gr->b0, sd));
     if (dx) {
-        AFI_TRY(afi_launch_bilinear2x_bwd(dout, N, H, W, C, 0.f, dx, st));           // skip path (:125)
+        if (!skip_grad_done) AFI_TRY(afi_launch_bilinear2x_bwd(dout, N, H, W, C, 0.f, dx, st));           // skip path (:125)
         AfiPixGemm g = conv_dgrad_desc(Gt, N, H, W, C, prm->w0, C, dense_view(dx, H, W, C));
         g.beta = 1.f;
         im.attach(g, prm->w0);

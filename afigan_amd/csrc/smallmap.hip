@@ -27,6 +27,7 @@ __device__ __attribute__((aligned(16))) float afi_zeros_smallmap[4] = {0.f, 0.f,
 #include "afi_epilogue.h"
 #include "afi_wgrad_body.h"
 #include "afi_bf16_split.h"
+#include "afi_bilinear.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
@@ -975,8 +976,26 @@ struct AfiWk6ImgJobs {
     int unit_start[AFI_WK6_MAXJOBS + 1];                   // prefix sums of (N tiles x stages) per job
     int nstages[AFI_WK6_MAXJOBS];
     AfiWk6ImgJob j[AFI_WK6_MAXJOBS];
+    int nb_img, nb_zero;                                   // blocks of image units, then of the zero fill (8 float4 per thread), then of the skip gradient (one float4 per thread)
+    AfiWk6Side side;
 };
 __global__ __launch_bounds__(256) void afi_wk6_image_kernel(const AfiWk6ImgJobs jobs) {
+    if ((int)blockIdx.x >= jobs.nb_img) {                   // (uniform) the riders of a backward pass: AfiWk6Side
+        const int zb = (int)blockIdx.x - jobs.nb_img;
+        if (zb < jobs.nb_zero) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const long long i = (long long)zb * 2048 + j * 256 + threadIdx.x;
+                if (i < jobs.side.zero_n4) ((f32x4*)jobs.side.zero_p)[i] = z;
+            }
+        } else {
+            const long long i = (long long)(zb - jobs.nb_zero) * 256 + threadIdx.x;
+            if (i < (long long)jobs.side.bl_N * jobs.side.bl_H * jobs.side.bl_W * (jobs.side.bl_C / 4))
+                *(f32x4*)(jobs.side.bl_dx + i * 4) = afi_bilinear2x_bwd_elem(jobs.side.bl_dout, jobs.side.bl_H, jobs.side.bl_W, jobs.side.bl_C, i);
+        }
+        return;
+    }
     const int u = (int)blockIdx.x * 2 + (int)(threadIdx.x >> 7);
     if (u >= jobs.unit_start[jobs.njobs]) return;
     int ji = 0;
@@ -1014,8 +1033,12 @@ __global__ __launch_bounds__(256) void afi_wk6_image_kernel(const AfiWk6ImgJobs 
 long long afi_wk6_image_bytes(int Ncols, int Ck, int ntaps, int nKphase) {
     return (long long)afi_cdiv(Ncols, 32) * afi_cdiv(Ck, AFI_BK) * ntaps * nKphase * AFI_WK6_STAGE_BYTES;
 }
-int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st) {
-    for (int done = 0; done < n;) {
+int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st, const AfiWk6Side* side = nullptr) {
+    if (side) {
+        if ((side->zero_p && ((((uintptr_t)side->zero_p) & 15) || side->zero_n4 < 0)) ||
+            (side->bl_dx && (!side->bl_dout || side->bl_N <= 0 || side->bl_H <= 0 || side->bl_W <= 0 || side->bl_C <= 0 || (side->bl_C & 3)))) return AFI_ERR_BAD_ARG;
+    }
+    for (int done = 0; done < n || side;) {
         const int cnt = (n - done) < AFI_WK6_MAXJOBS ? (n - done) : AFI_WK6_MAXJOBS;
         AfiWk6ImgJobs tb;
         tb.njobs = cnt; tb.pad_ = 0;
@@ -1032,7 +1055,17 @@ int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st) {
             if (units > 0x3fffffffLL) return AFI_ERR_UNSUPPORTED;
         }
         for (int i = cnt; i <= AFI_WK6_MAXJOBS; ++i) tb.unit_start[i] = (int)units;
-        hipLaunchKernelGGL(afi_wk6_image_kernel, dim3((unsigned)((units + 1) / 2)), dim3(256), 0, st, tb);
+        tb.nb_img = (int)((units + 1) / 2); tb.nb_zero = 0;
+        tb.side = AfiWk6Side{nullptr, 0, nullptr, nullptr, 0, 0, 0, 0};
+        long long blocks = tb.nb_img;
+        if (side) {                                         // (with the first batch of jobs, or alone)
+            tb.side = *side;
+            if (side->zero_p) { tb.nb_zero = afi_cdiv(side->zero_n4, 2048); blocks += tb.nb_zero; }
+            if (side->bl_dx) blocks += afi_cdiv((long long)side->bl_N * side->bl_H * side->bl_W * (side->bl_C / 4), 256);
+            side = nullptr;
+        }
+        if (blocks > 0x3fffffffLL) return AFI_ERR_UNSUPPORTED;
+        if (blocks > 0) hipLaunchKernelGGL(afi_wk6_image_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tb);
         done += cnt;
     }
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
@@ -1749,60 +1782,7 @@ int afi_launch_wgrad_group(const AfiWgradGemm* probs, int n, int wide, hipStream
     return wide ? launch_wgrad_group_sk<128, 128, 1, 4>(probs, n, st, bpc) : launch_wgrad_group_sk<32, 128, 1, 4>(probs, n, st, bpc);
 }
 
-// ------------------------------------------------------------------------------------------------
-// grouped bias gradients: db[c] += alpha * sum_rows g[row][c] for up to 8 matrices in one launch (fp32 atomics: a few thousand adds)
-// ------------------------------------------------------------------------------------------------
-#define AFI_CS_MAXP 8
-struct AfiColsumGroup {
-    int nprob;
-    int blk_start[AFI_CS_MAXP + 1];
-    struct { const float* g; float* db; long long P, ld; int C; int rows_per_blk; float alpha; int pad; } d[AFI_CS_MAXP];
-};
-__global__ __launch_bounds__(256) void afi_colsum_group_kernel(const AfiColsumGroup grp) {
-    __shared__ f32x4 red[16][16];
-    int pi = 0;
-    const int b = blockIdx.x;
-    while (pi + 1 < grp.nprob && b >= grp.blk_start[pi + 1]) ++pi;
-    const auto& d = grp.d[pi];
-    const int lbk = b - grp.blk_start[pi];
-    const int ccs = (d.C + 63) / 64;                       // 64-channel column groups
-    const int cg = lbk % ccs, rc = lbk / ccs;
-    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = cg * 64 + cq * 4;
-    const long long r0 = (long long)rc * d.rows_per_blk;
-    const long long r1 = (r0 + d.rows_per_blk < d.P) ? r0 + d.rows_per_blk : d.P;
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (c < d.C)
-        for (long long r = r0 + rl; r < r1; r += 16) s += *(const f32x4*)(d.g + r * d.ld + c);
-    red[rl][cq] = s;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int cc = threadIdx.x >> 2, j = threadIdx.x & 3;
-        float v = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) v += red[i][cc][j];
-        const int ch = cg * 64 + cc * 4 + j;
-        if (ch < d.C) atomicAdd(d.db + ch, d.alpha * v);
-    }
-}
-int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st) {
-    if (n <= 0) return AFI_OK;
-    if (n > AFI_CS_MAXP) return AFI_ERR_BAD_ARG;
-    AfiColsumGroup grp;
-    grp.nprob = n;
-    int blocks = 0;
-    for (int i = 0; i < n; ++i) {
-        if (probs[i].C & 3) return AFI_ERR_UNSUPPORTED;
-        const int rpb = 128;                               // rows per block: 850 rows -> 7 blocks per column group
-        grp.d[i].g = probs[i].g; grp.d[i].db = probs[i].db; grp.d[i].P = probs[i].P; grp.d[i].ld = probs[i].ld;
-        grp.d[i].C = probs[i].C; grp.d[i].rows_per_blk = rpb; grp.d[i].alpha = probs[i].alpha; grp.d[i].pad = 0;
-        grp.blk_start[i] = blocks;
-        blocks += ((probs[i].C + 63) / 64) * afi_cdiv(probs[i].P, rpb);
-    }
-    for (int i = n; i <= AFI_CS_MAXP; ++i) grp.blk_start[i] = blocks;
-    hipLaunchKernelGGL(afi_colsum_group_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grp);
-    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
-}
+// (grouped bias gradients: elementwise.hip, afi_launch_colsum_group / afi_launch_g_bwd_tail)
 
 // ------------------------------------------------------------------------------------------------
 // Host-only: the ownership the stream-K cut gives each dW tile of a group of weight-gradient problems (same cut, same walk as the
