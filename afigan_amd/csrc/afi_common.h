@@ -85,6 +85,12 @@ struct AfiWk6ImgJob { const float* B; long long b_sRow, b_sTap; int Ncols, Ck, n
 // own costs each of them more than the work): zero_p[0 .. 4 zero_n4) = 0 (the packed gradient buffers the stream-K weight gradients add into),
 // and bl_dx[N,H,W,C] = bilinear2x^T(bl_dout[N,2H,2W,C]) (the skip path's gradient, generator_rdb.py:125).  Null pointers: off.
 struct AfiWk6Side { float* zero_p; long long zero_n4; const float* bl_dout; float* bl_dx; int bl_N, bl_H, bl_W, bl_C; };
+// The conv-transpose weight W [Cin][Cout][6][6] (generator_rdb.py:101-105) STRAIGHT into a bf16x6 image, with no packed fp32 copy in between
+// (that copy was a launch of its own in front of the image launch): mode 0 the forward's image -- columns (phase, co), K = ci: the image of
+// Wp [(phase*Cout + co)][tap][ci] --, mode 1 the data gradient's -- columns ci, K = (32-channel chunk of co, phase, tap).  Through an LDS
+// tile (32 ci x 4 co, or 16 ci x 8 co, x 36 taps) so that reads and stores stay contiguous.  pack_dst (optional): the packed fp32 form Wp is
+// written as well, by further blocks of the same launch (for the callers that still read it).  Cin, Cout multiples of 32.
+struct AfiWk6ConvT { const float* W; unsigned char* dst; float* pack_dst; int Cin, Cout, mode, pad_; };
 
 // Fused growth-conv chain of one dense block on a small map (csrc/smallmap.hip: afi_rdb_chain6_kernel): three dependent 3x3 convs with
 // 32-channel outputs -- y2, y3, y4 of ResidualDenseBlock.forward, or the data gradients g3, g2, g1 of its backward -- in ONE launch.  A block

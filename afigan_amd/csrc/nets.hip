@@ -23,7 +23,7 @@ int afi_launch_wgrad_gemm_group6(const AfiWgradGemm* probs, int n, hipStream_t s
 int afi_launch_colsum_group(const AfiColsumProb* probs, int n, hipStream_t st);
 int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStream_t st);
 long long afi_wk6_image_bytes(int Ncols, int Ck, int ntaps, int nKphase);                       // smallmap.hip: bf16x6 weight images of the small-map kernels
-int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st, const AfiWk6Side* side);
+int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st, const AfiWk6Side* side, const AfiWk6ConvT* ct);
 int afi_launch_rdb_chain6(const AfiChain6& c, hipStream_t st);                                   // smallmap.hip: a dense block's chain of 32-channel convs in one launch
 int afi_launch_nchw_to_nhwc(const float* in, float* out, int N, int C, int P, hipStream_t st);
 int afi_launch_nhwc_to_nchw(const float* in, float* out, int N, int C, int P, hipStream_t st);
@@ -280,11 +280,14 @@ constexpr int kWk6MaxReq = 24, kWk6MaxJobs = 40;
 // 2 a dense block's four growth convs side by side along K: the data gradient 4G -> C of their block-input columns); njob source weights,
 // job j filling the K chunks [chunk0_j, chunk0_j + Ck_j / 32) of every N tile.
 struct Wk6Src { const float* src; int Ck; long long b_sRow, b_sTap; };
-struct Wk6Req { const float* key; int tag, Ncols, Ck, nKphase, b_rc, njob; Wk6Src j[4]; };
+// convT: the source is the conv-transpose weight in its torch layout [Cin][Cout][6][6] (AfiWk6ConvT; 1 the forward's image, 2 the data gradient's;
+// pack_dst: the packed fp32 form written by the same launch) instead of a K- / row-contiguous matrix
+struct Wk6Req { const float* key; int tag, Ncols, Ck, nKphase, b_rc, njob; Wk6Src j[4]; int convT; float* pack_dst; };
 static inline Wk6Req wk6_req(const float* key, const float* src, int Ncols, int Ck, int nKphase, int b_rc, long long b_sRow, long long b_sTap) {
     Wk6Req r;
     r.key = key; r.tag = b_rc; r.Ncols = Ncols; r.Ck = Ck; r.nKphase = nKphase; r.b_rc = b_rc; r.njob = 1;
     r.j[0] = Wk6Src{src, Ck, b_sRow, b_sTap};
+    r.convT = 0; r.pack_dst = nullptr;
     return r;
 }
 static inline long long wk6_req_floats(int Ncols, int Ck, int nKphase) { return align4((afi_wk6_image_bytes(Ncols, Ck, 9, nKphase) + 3) / 4); }
@@ -305,13 +308,17 @@ struct Wk6Images {
     }
 };
 // side (optional): work that rides in the image launch (AfiWk6Side); *side_done says whether it did -- no launch happens when every image
-// came from the caller's weight cache, or when the images do not fit
+// came from the caller's weight cache, or when the images do not fit.  *ct_built: the conv-transpose request (Wk6Req::convT) was built here
+// (and with it its packed fp32 form, when asked for), not found in the cache.
 static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, float* arena, long long arena_floats, hipStream_t st,
-                     const AfiWk6Side* side = nullptr, bool* side_done = nullptr) {
+                     const AfiWk6Side* side = nullptr, bool* side_done = nullptr, bool* ct_built = nullptr) {
     im.on = false; im.n = 0;
     if (side_done) *side_done = false;
+    if (ct_built) *ct_built = false;
     if (n > kWk6MaxReq) return AFI_OK;
     AfiWk6ImgJob jobs[kWk6MaxJobs];
+    AfiWk6ConvT ct;
+    bool have_ct = false;
     int nj = 0;
     long long used = 0;
     for (int i = 0; i < n; ++i) {
@@ -324,7 +331,12 @@ static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, floa
             slot = arena + used; used += need; hit = false;
         }
         const int nst = afi_cdiv(r.Ck, 32) * 9 * r.nKphase;
-        if (!hit) {
+        if (!hit && r.convT) {
+            if (have_ct) { im.n = 0; return AFI_OK; }                                    // (one per launch)
+            // forward: Ncols = 4 Cout, Ck = Cin; data gradient: Ncols = Cin, Ck = Cout
+            ct = AfiWk6ConvT{r.j[0].src, (unsigned char*)slot, r.pack_dst, r.convT == 1 ? r.Ck : r.Ncols, r.convT == 1 ? r.Ncols / 4 : r.Ck, r.convT == 1 ? 0 : 1, 0};
+            have_ct = true;
+        } else if (!hit) {
             int chunk0 = 0;
             for (int k = 0; k < r.njob; ++k) {
                 if (nj == kWk6MaxJobs) { im.n = 0; return AFI_OK; }
@@ -335,9 +347,10 @@ static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, floa
         }
         im.e[im.n++] = Wk6Images::Ent{r.key, r.tag, (const unsigned char*)slot, nst};
     }
-    if (nj) {
-        AFI_TRY(afi_launch_wk6_images(jobs, nj, st, side));
+    if (nj || have_ct) {
+        AFI_TRY(afi_launch_wk6_images(jobs, nj, st, side, have_ct ? &ct : nullptr));
         if (side && side_done) *side_done = true;
+        if (have_ct && ct_built) *ct_built = true;
     }
     im.on = true;
     return AFI_OK;
@@ -1024,21 +1037,12 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     AfiView t = dense_view(ws + l.o_t, H, W, C), a7 = dense_view(ws + l.o_a7, H, W, C);
     AfiView u = dense_view(ws + l.o_u, 2 * H, 2 * W, C);
 
-    {   // packed conv-transpose weight: from the caller's weight cache when one is registered (BiFPN: 28 calls on one set of weights)
-        bool hit = false;
-        const long long wp_floats = 36LL * C * C;
-        if (float* slot = wino_wcache_slot(cx, prm->wT, /*tag: convT pack*/ 2, 0, C, C, align4(wp_floats), hit)) {
-            if (!hit) AFI_TRY(afi_launch_convT_pack(prm->wT, slot, C, C, st));
-            if (hipMemcpyAsync(wp, slot, sizeof(float) * wp_floats, hipMemcpyDeviceToDevice, st) != hipSuccess) return AFI_ERR_LAUNCH;
-        } else {
-            AFI_TRY(afi_launch_convT_pack(prm->wT, wp, C, C, st));
-        }
-    }
     // Small maps: the dense block in COLUMN-BATCHED form (below); under the default arithmetic its GEMMs, the head / trunk convs and the
     // conv-transpose run on the bf16 matrix cores in the six-product form, on pre-split weight images (csrc/smallmap.hip)
     const bool six = l.n_img > 0 && (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_BF16X6;
     const bool batched = l.P < afi_opt(cx, AFI_OPT_G_SMALLMAP_MAX_PIXELS) || (six && l.P <= afi_opt(cx, AFI_OPT_G_SMALLMAP6_MAX_PIXELS));
     Wk6Images im;
+    bool packed = false;                                   // the packed conv-transpose weight `wp` (the backward reads it from this workspace) exists
     if (batched && six) {
         Wk6Req rq[kWk6MaxReq];
         int nr = 0;
@@ -1048,9 +1052,22 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
             rq[nr++] = wk6_req(prm->rdb_w[r][4], prm->rdb_w[r][4], C, (int)l.L, 1, 0, 9LL * l.L, l.L);
         }
         rq[nr++] = wk6_req(prm->w7, prm->w7, C, C, 1, 0, 9LL * C, C);
-        rq[nr++] = wk6_req(prm->wT, wp, 4 * C, C, 1, 0, 9LL * C, C);           // (keyed by the parameter, built from its packed form above)
+        // the conv-transpose image straight from the parameter's own layout, its packed form written by further blocks of the same launch
+        // (the pack used to be a launch of its own in front of this one)
+        rq[nr] = wk6_req(prm->wT, prm->wT, 4 * C, C, 1, 0, 9LL * C, C);
+        rq[nr].convT = 1; rq[nr].pack_dst = wp; ++nr;
         if (4 * l.P <= kWk6HiResMaxPixels) rq[nr++] = wk6_req(prm->w9, prm->w9, C, C, 1, 0, 9LL * C, C);
-        AFI_TRY(wk6_build(cx, im, rq, nr, ws + l.o_img, l.n_img, st));
+        AFI_TRY(wk6_build(cx, im, rq, nr, ws + l.o_img, l.n_img, st, nullptr, nullptr, &packed));
+    }
+    if (!packed) {   // packed conv-transpose weight: from the caller's weight cache when one is registered (BiFPN: 28 calls on one set of weights)
+        bool hit = false;
+        const long long wp_floats = 36LL * C * C;
+        if (float* slot = wino_wcache_slot(cx, prm->wT, /*tag: convT pack*/ 2, 0, C, C, align4(wp_floats), hit)) {
+            if (!hit) AFI_TRY(afi_launch_convT_pack(prm->wT, slot, C, C, st));
+            if (hipMemcpyAsync(wp, slot, sizeof(float) * wp_floats, hipMemcpyDeviceToDevice, st) != hipSuccess) return AFI_ERR_LAUNCH;
+        } else {
+            AFI_TRY(afi_launch_convT_pack(prm->wT, wp, C, C, st));
+        }
     }
     {   // head conv + LReLU (generator_rdb.py:91-93) -> channels [0,C) of RDB 0's dense buffer
         AfiPixGemm g = conv_fwd_desc(x, N, H, W, C, prm->w0, prm->b0, C, buf(0));
@@ -1309,14 +1326,15 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     if (six && s.n_img > 0) {
         Wk6Req rq[kWk6MaxReq];
         int nr = 0;
-        rq[nr++] = wk6_req(prm->wT, wp, C, C, 4, 1, 9LL * C, C);               // conv-transpose data gradient: K = (phase, Cout, tap) of the packed weight
+        rq[nr] = wk6_req(prm->wT, prm->wT, C, C, 4, 1, 9LL * C, C);            // conv-transpose data gradient: K = (Cout chunk, phase, tap), straight from the parameter's layout
+        rq[nr].convT = 2; ++nr;
         rq[nr++] = wk6_req(prm->w7, prm->w7, C, C, 1, 1, 9LL * C, C);
         for (int r = 0; r < R; ++r) {
             rq[nr++] = wk6_req(prm->rdb_w[r][4], prm->rdb_w[r][4], L, C, 1, 1, 9LL * L, L);
             for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; rq[nr++] = wk6_req(prm->rdb_w[r][k - 1], prm->rdb_w[r][k - 1], cin, G, 1, 1, 9LL * cin, cin); }
             if (chain_shapes) {                             // the four growth convs' block-input columns side by side along K: ONE data gradient 4G -> C
                 Wk6Req q;
-                q.key = prm->rdb_w[r][0]; q.tag = 2; q.Ncols = C; q.Ck = 4 * G; q.nKphase = 1; q.b_rc = 1; q.njob = 4;
+                q.key = prm->rdb_w[r][0]; q.tag = 2; q.Ncols = C; q.Ck = 4 * G; q.nKphase = 1; q.b_rc = 1; q.njob = 4; q.convT = 0; q.pack_dst = nullptr;
                 for (int k = 1; k <= 4; ++k) { const int cin = C + (k - 1) * G; q.j[k - 1] = Wk6Src{prm->rdb_w[r][k - 1], G, 9LL * cin, cin}; }
                 rq[nr++] = q;
             }

@@ -28,6 +28,7 @@ __device__ __attribute__((aligned(16))) float afi_zeros_smallmap[4] = {0.f, 0.f,
 #include "afi_wgrad_body.h"
 #include "afi_bf16_split.h"
 #include "afi_bilinear.h"
+#include "afi_convt_pack.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <vector>
@@ -976,12 +977,66 @@ struct AfiWk6ImgJobs {
     int unit_start[AFI_WK6_MAXJOBS + 1];                   // prefix sums of (N tiles x stages) per job
     int nstages[AFI_WK6_MAXJOBS];
     AfiWk6ImgJob j[AFI_WK6_MAXJOBS];
-    int nb_img, nb_zero;                                   // blocks of image units, then of the zero fill (8 float4 per thread), then of the skip gradient (one float4 per thread)
+    // blocks of image units, then of the conv-transpose image, of its packed fp32 form, of the zero fill (8 float4 per thread), of the skip gradient (one float4 per thread)
+    int nb_img, nb_ct, nb_ctpack, nb_zero;
+    AfiWk6ConvT ct;
     AfiWk6Side side;
 };
+#define AFI_WK6_CT_LDS (32 * (4 * 36 + 1))                  /* floats: 32 x 145 (mode 0) >= 16 x 289 (mode 1) >= the pack's 32 x 73 */
+template <int MODE>
+__device__ __forceinline__ void afi_wk6_convT_image_body(const AfiWk6ConvT& ct, const int b, float* T) {
+    constexpr int CI = MODE ? 16 : 32, CO = MODE ? 8 : 4, LD = CO * 36 + 1, RQ = CO * 9;   // tile, LDS row, float4 per ci row
+    const int nbx = ct.Cin / CI, bx = b % nbx, by = b / nbx;
+    const int ci0 = CI * bx, co0 = CO * by, tid = threadIdx.x;
+    for (int i = tid; i < CI * RQ; i += 256) {              // row r: the CO * 36 contiguous floats of (ci0 + r, co0 .. co0 + CO)
+        const int r = i / RQ, q = i - r * RQ;
+        const f32x4 v = *(const f32x4*)(ct.W + ((long long)(ci0 + r) * ct.Cout + co0) * 36 + 4 * q);
+        float* d = T + r * LD + 4 * q;
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    __syncthreads();
+    const int grp = tid >> 4, l = tid & 15;                 // sixteen lanes per (phase, tap)
+    for (int q = grp; q < 36; q += 16) {
+        const int phase = q / 9, tap = q - 9 * phase;
+        const int kk = ((phase >> 1) + 2 - 2 * (tap / 3 - 1)) * 6 + ((phase & 1) + 2 - 2 * (tap % 3 - 1));   // ky * 6 + kx
+        f32x4 v0, v1;
+        unsigned char* dst;
+        if constexpr (MODE == 0) {                          // column (phase, co0 + co_l), k = ci: the lane's eight consecutive ci
+            const int co_l = l & 3, lq = l >> 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v0[j] = T[(8 * lq + j) * LD + co_l * 36 + kk]; v1[j] = T[(8 * lq + 4 + j) * LD + co_l * 36 + kk]; }
+            const int n = phase * ct.Cout + co0 + co_l;
+            const int nst = (ct.Cin >> 5) * 9, stage = bx * 9 + tap;
+            dst = ct.dst + ((long long)(n >> 5) * nst + stage) * AFI_WK6_STAGE_BYTES + (3 * ((n >> 4) & 1)) * 1024 + 16 * (16 * lq + (n & 15));
+        } else {                                            // column ci0 + l, k = co: this block's eight co are one lane group of their chunk
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v0[j] = T[l * LD + j * 36 + kk]; v1[j] = T[l * LD + (4 + j) * 36 + kk]; }
+            const int n = ci0 + l;
+            const int nst = (ct.Cout >> 5) * 36, stage = ((co0 >> 5) * 4 + phase) * 9 + tap;
+            dst = ct.dst + ((long long)(n >> 5) * nst + stage) * AFI_WK6_STAGE_BYTES + (3 * ((n >> 4) & 1)) * 1024 + 16 * (16 * ((co0 >> 3) & 3) + (n & 15));
+        }
+        const f32x4 r0 = afi_bf16_residual(v0), r1 = afi_bf16_residual(v1);
+        *(bf16x8*)dst = afi_pack8_bf16(v0, v1);
+        *(bf16x8*)(dst + 1024) = afi_pack8_bf16(r0, r1);
+        *(bf16x8*)(dst + 2048) = afi_pack8_bf16(afi_bf16_residual(r0), afi_bf16_residual(r1));
+    }
+}
 __global__ __launch_bounds__(256) void afi_wk6_image_kernel(const AfiWk6ImgJobs jobs) {
-    if ((int)blockIdx.x >= jobs.nb_img) {                   // (uniform) the riders of a backward pass: AfiWk6Side
-        const int zb = (int)blockIdx.x - jobs.nb_img;
+    if ((int)blockIdx.x >= jobs.nb_img) {                   // (uniform) what rides with the images: AfiWk6ConvT, AfiWk6Side
+        __shared__ __attribute__((aligned(16))) float T[AFI_WK6_CT_LDS];
+        int zb = (int)blockIdx.x - jobs.nb_img;
+        if (zb < jobs.nb_ct) {
+            if (jobs.ct.mode == 0) afi_wk6_convT_image_body<0>(jobs.ct, zb, T);
+            else afi_wk6_convT_image_body<1>(jobs.ct, zb, T);
+            return;
+        }
+        zb -= jobs.nb_ct;
+        if (zb < jobs.nb_ctpack) {
+            const int nbx = (jobs.ct.Cin + AFI_CT_CI - 1) / AFI_CT_CI;
+            afi_convT_repack_body<false>(jobs.ct.W, jobs.ct.pack_dst, jobs.ct.Cin, jobs.ct.Cout, zb % nbx, zb / nbx, (float (*)[AFI_CT_LD])T);
+            return;
+        }
+        zb -= jobs.nb_ctpack;
         if (zb < jobs.nb_zero) {
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1033,12 +1088,17 @@ __global__ __launch_bounds__(256) void afi_wk6_image_kernel(const AfiWk6ImgJobs 
 long long afi_wk6_image_bytes(int Ncols, int Ck, int ntaps, int nKphase) {
     return (long long)afi_cdiv(Ncols, 32) * afi_cdiv(Ck, AFI_BK) * ntaps * nKphase * AFI_WK6_STAGE_BYTES;
 }
-int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st, const AfiWk6Side* side = nullptr) {
+int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st, const AfiWk6Side* side = nullptr, const AfiWk6ConvT* ct = nullptr) {
+    static_assert(AFI_WK6_CT_LDS >= 16 * (8 * 36 + 1) && AFI_WK6_CT_LDS >= AFI_CT_CI * AFI_CT_LD, "one LDS tile for the three conv-transpose bodies");
+    if (ct) {
+        if (!ct->W || !ct->dst || ct->Cin <= 0 || ct->Cout <= 0 || (ct->mode != 0 && ct->mode != 1)) return AFI_ERR_BAD_ARG;
+        if ((ct->Cin & 31) || (ct->Cout & 31) || (((uintptr_t)ct->W | (uintptr_t)ct->dst) & 15)) return AFI_ERR_UNSUPPORTED;
+    }
     if (side) {
         if ((side->zero_p && ((((uintptr_t)side->zero_p) & 15) || side->zero_n4 < 0)) ||
             (side->bl_dx && (!side->bl_dout || side->bl_N <= 0 || side->bl_H <= 0 || side->bl_W <= 0 || side->bl_C <= 0 || (side->bl_C & 3)))) return AFI_ERR_BAD_ARG;
     }
-    for (int done = 0; done < n || side;) {
+    for (int done = 0; done < n || side || ct;) {
         const int cnt = (n - done) < AFI_WK6_MAXJOBS ? (n - done) : AFI_WK6_MAXJOBS;
         AfiWk6ImgJobs tb;
         tb.njobs = cnt; tb.pad_ = 0;
@@ -1055,10 +1115,18 @@ int afi_launch_wk6_images(const AfiWk6ImgJob* jobs, int n, hipStream_t st, const
             if (units > 0x3fffffffLL) return AFI_ERR_UNSUPPORTED;
         }
         for (int i = cnt; i <= AFI_WK6_MAXJOBS; ++i) tb.unit_start[i] = (int)units;
-        tb.nb_img = (int)((units + 1) / 2); tb.nb_zero = 0;
+        tb.nb_img = (int)((units + 1) / 2); tb.nb_zero = tb.nb_ct = tb.nb_ctpack = 0;
         tb.side = AfiWk6Side{nullptr, 0, nullptr, nullptr, 0, 0, 0, 0};
+        tb.ct = AfiWk6ConvT{nullptr, nullptr, nullptr, 0, 0, 0, 0};
         long long blocks = tb.nb_img;
-        if (side) {                                         // (with the first batch of jobs, or alone)
+        if (ct) {                                           // (with the first batch of jobs, or alone)
+            tb.ct = *ct;
+            tb.nb_ct = ct->mode ? (ct->Cin / 16) * (ct->Cout / 8) : (ct->Cin / 32) * (ct->Cout / 4);
+            if (ct->pack_dst) tb.nb_ctpack = ((ct->Cin + AFI_CT_CI - 1) / AFI_CT_CI) * ((ct->Cout + AFI_CT_CO - 1) / AFI_CT_CO);
+            blocks += tb.nb_ct + tb.nb_ctpack;
+            ct = nullptr;
+        }
+        if (side) {
             tb.side = *side;
             if (side->zero_p) { tb.nb_zero = afi_cdiv(side->zero_n4, 2048); blocks += tb.nb_zero; }
             if (side->bl_dx) blocks += afi_cdiv((long long)side->bl_N * side->bl_H * side->bl_W * (side->bl_C / 4), 256);
