@@ -134,6 +134,7 @@ SIGNATURES = {
     "afi_profile_kind_name": (C.c_char_p, [_i]),
     "afi_profile_get": (_i, [_i, C.POINTER(C.c_double)]),
     "afi_profile_dump": (_i, [C.c_char_p]),
+    "afi_debug_wk6_convT_images": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_longlong), _vp]),
     "afi_debug_wgrad_sk_plan": (_i, [C.POINTER(C.c_longlong), C.POINTER(C.c_int), _i, _i, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 

@@ -539,6 +539,20 @@ static long long disc_wino_floats(const int F[4], int N, int H, int W) {
 
 extern "C" {
 
+int afi_debug_wk6_convT_images(const float* W, int Cin, int Cout, int mode, void* direct, float* pack_ride, void* via_pack, float* pack_ref,
+                               long long* bytes, void* stream) {
+    if (Cin <= 0 || Cout <= 0 || (Cin & 31) || (Cout & 31) || (mode != 0 && mode != 1) || !bytes) return AFI_ERR_BAD_ARG;
+    *bytes = mode == 0 ? afi_wk6_image_bytes(4 * Cout, Cin, 9, 1) : afi_wk6_image_bytes(Cin, Cout, 9, 4);
+    if (!W && !direct && !via_pack) return AFI_OK;
+    if (!W || !direct || !pack_ride || !via_pack || !pack_ref) return AFI_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const AfiWk6ConvT ct{W, (unsigned char*)direct, pack_ride, Cin, Cout, mode, 0};
+    AFI_TRY(afi_launch_wk6_images(nullptr, 0, st, nullptr, &ct));
+    AFI_TRY(afi_launch_convT_pack(W, pack_ref, Cin, Cout, st));
+    const AfiWk6ImgJob job = mode == 0 ? AfiWk6ImgJob{pack_ref, 9LL * Cin, Cin, 4 * Cout, Cin, 9, 1, 0, 0, (unsigned char*)via_pack, 0, 0}
+                                       : AfiWk6ImgJob{pack_ref, 9LL * Cin, Cin, Cin, Cout, 9, 4, 1, 0, (unsigned char*)via_pack, 0, 0};
+    return afi_launch_wk6_images(&job, 1, st, nullptr, nullptr);
+}
 int afi_abi_version(void) { return 4; }
 
 const char* afi_status_string(int s) {

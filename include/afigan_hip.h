@@ -395,6 +395,14 @@ int afi_profile_dump(const char* path);
  * Per tile (numbered problem-major): stored = runs that store it whole, added = runs that add to it by atomics, stages = stages covered.
  * A valid plan has (stored, added) = (1, 0) or (0, >= 2) and full stage coverage for every tile; tests/test_cabi.py checks exactly that. */
 int afi_debug_wgrad_sk_plan(const long long* pixels, const int* tiles, int nprob, int bpc, int* stored, int* added, int* stages);
+/* (GPU) The bf16x6 weight image of a conv-transpose weight W [Cin][Cout][6][6] built the two ways the library knows, for a byte comparison
+ * (tests/test_gpu_ops.py): `direct` straight from W's own layout by the LDS-tiled blocks that ride in the small-map image launch, together
+ * with the packed fp32 form `pack_ride` [4 Cout][9][Cin] written by further blocks of that launch; `via_pack` from the packed form
+ * `pack_ref` made by the stand-alone pack kernel, through the generic image job.  mode 0: the forward's image (4 Cout columns, K = Cin),
+ * mode 1: the data gradient's (Cin columns, K = (Cout chunk, phase, tap)).  Returns the image size in bytes through *bytes (buffers may be
+ * null to query it).  Cin, Cout multiples of 32. */
+int afi_debug_wk6_convT_images(const float* W, int Cin, int Cout, int mode, void* direct, float* pack_ride, void* via_pack, float* pack_ref,
+                               long long* bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -365,3 +365,27 @@ def test_conv3x3_winograd_inference_form(amd, N, Cin, Cout, H, W, act):
     ref = F.relu(ref) if act == 2 else (F.leaky_relu(ref, 0.2) if act == 1 else ref)
     out = ops.conv3x3_wino_infer(_pm(x), w.cuda(), b.cuda(), act=act)
     _close(out, ref, tol=3e-4 if N * H * W >= 8192 else 1e-4, what="wino inference conv")
+
+
+@pytest.mark.parametrize("Cin,Cout,mode", [(256, 256, 0), (256, 256, 1), (64, 32, 0), (32, 96, 1)])
+def test_conv_transpose_weight_image_built_from_the_parameter_layout(amd, Cin, Cout, mode):
+    """The small-map schedule builds the conv-transpose weight's bf16x6 image straight from W [Cin][Cout][6][6] (LDS-tiled blocks inside
+    the image launch) and lets further blocks of that launch write the packed fp32 form: both must equal, byte for byte, what the
+    stand-alone pack kernel followed by the generic image job produces (generator_rdb.py:101-105 as a 4-phase 3x3 conv)."""
+    import ctypes as C
+    from afigan_amd import _lib, ops
+    lib = _lib.load()
+    W = torch.randn(Cin, Cout, 6, 6, device="cuda", generator=torch.Generator(device="cuda").manual_seed(Cin + Cout + mode))
+    nbytes = C.c_longlong(0)
+    _lib.check(lib.afi_debug_wk6_convT_images(None, Cin, Cout, mode, None, None, None, None, C.byref(nbytes), None), "size query")
+    direct = torch.full((nbytes.value,), 0xA5, dtype=torch.uint8, device="cuda")
+    via = torch.full((nbytes.value,), 0x5A, dtype=torch.uint8, device="cuda")
+    pack_ride = torch.full((36 * Cin * Cout,), float("nan"), device="cuda")
+    pack_ref = torch.full((36 * Cin * Cout,), float("nan"), device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _lib.check(lib.afi_debug_wk6_convT_images(p(W), Cin, Cout, mode, p(direct), p(pack_ride), p(via), p(pack_ref), C.byref(nbytes), ops.stream_ptr()),
+               "afi_debug_wk6_convT_images")
+    torch.cuda.synchronize()
+    assert torch.equal(pack_ride, pack_ref)
+    assert not torch.isnan(pack_ref).any()
+    assert torch.equal(direct, via)
