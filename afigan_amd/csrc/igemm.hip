@@ -819,6 +819,7 @@ int afi_launch_pix_gemm_group(const AfiPixGemm* probs, int n, int b_rc, hipStrea
     return rc;
 }
 int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st) {
+    if (n <= 0) return AFI_OK;                             // (nothing to launch: no profile bracket either)
     double fl = 0.0;
     for (int i = 0; i < n; ++i) fl += 2.0 * (double)probs[i].N * probs[i].H * probs[i].W * probs[i].Mrows * probs[i].Ncols * probs[i].ntaps;
     ProfScope prof(st, 16, fl);
@@ -827,6 +828,7 @@ int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipS
 }
 // the same group on the bf16 matrix cores (bf16x6); AFI_ERR_UNSUPPORTED = nothing launched (the caller falls back to the fp32 groups)
 int afi_launch_wgrad_gemm_group6(const AfiWgradGemm* probs, int n, hipStream_t st) {
+    if (n <= 0) return AFI_OK;
     double fl = 0.0;
     for (int i = 0; i < n; ++i) fl += 2.0 * (double)probs[i].N * probs[i].H * probs[i].W * probs[i].Mrows * probs[i].Ncols * probs[i].ntaps;
     ProfScope prof(st, 19, fl);
