@@ -37,6 +37,21 @@ __device__ __forceinline__ void afi_split3_pair(float x0, float x1, unsigned& hi
     lo = afi_cvt_pk_bf16(r0, r1);
 }
 
+// ... with the four subtractions kept as v_sub_f32: beside MFMAs a v_pk_add_f32 (which -O3 forms out of the two adjacent subtractions) costs
+// about three plain ones (MI355X_MICROARCH.md, 'price of one filler beside MFMAs'); for loops whose vector issue runs in the shadow of MFMAs
+__device__ __forceinline__ void afi_split3_pair_np(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = afi_cvt_pk_bf16(x0, x1);
+    float r0 = x0 - __uint_as_float(hi << 16);
+    asm volatile("" : "+v"(r0));
+    float r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    asm volatile("" : "+v"(r1));
+    mid = afi_cvt_pk_bf16(r0, r1);
+    r0 -= __uint_as_float(mid << 16);
+    asm volatile("" : "+v"(r0));
+    r1 -= __uint_as_float(mid & 0xffff0000u);
+    lo = afi_cvt_pk_bf16(r0, r1);
+}
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ bf16x8 afi_tr_frag(const unsigned char* base, int off_lo, int off_hi) {

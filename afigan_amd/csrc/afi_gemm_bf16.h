@@ -152,16 +152,40 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
     }
     const bool use_atomic = gridDim.y > 1;
     float* out = p.dU + (long long)plane * p.M * p.N;
+    const long long ldn = p.N;
+    if (use_atomic) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                float* dst = out + (long long)row * p.N + n0 + (wn * NI + ni) * 32 + lr;
-                if (use_atomic) atomicAdd(dst, acc[mi][ni][r]); else *dst += acc[mi][ni][r];
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    atomicAdd(out + (long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr, acc[mi][ni][r]);
+                }
+    } else {
+        // dU += acc on a tile this block owns: ALL old values first, then add and store.  Written as `*dst += acc` per element the compiler
+        // emitted load / s_waitcnt vmcnt(0) / store 64 times in a row (a later load may alias an earlier store): 64 serial round trips
+        // per thread at the end of every tile (found with in-kernel stamps on the small-map weight-gradient kernel, smallmap.hip)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float old[NI][16];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    old[ni][r] = out[(long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr];
+                }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    out[(long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr] = old[ni][r] + acc[mi][ni][r];
+                }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

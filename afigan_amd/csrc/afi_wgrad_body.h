@@ -162,23 +162,41 @@ __device__ __forceinline__ void afi_wgrad_gemm_range(const AfiWgradGemm& p, int 
         __syncthreads();
     }
 
+    // dW += alpha * acc.  The descriptor fields are copied out first and, on a tile this block owns alone, ALL old values are loaded before
+    // the first store: written as `*dst += v` per element the compiler emitted load / s_waitcnt vmcnt(0) / store (and re-read the
+    // descriptor from the argument block) for each of a thread's elements in turn -- serial round trips at the end of every tile.
+    const int pM = p.Mrows, pN = p.Ncols;
+    const float alpha = p.alpha;
+    float* const base = p.DW + (long long)tap * p.dw_sTap;
+    const long long sRow = p.dw_sRow;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    for (int mi = 0; mi < MI; ++mi) {
+        float old[16][NI];
+        if (!use_atomic) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * MI * 32 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
-            if (row < p.Mrows) {
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * MI * 32 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int col = n0 + wn * NI * 32 + NI * lr + ni;
-                    if (col < p.Ncols) {
-                        float* dst = p.DW + (long long)row * p.dw_sRow + (long long)tap * p.dw_sTap + col;
-                        const float v = p.alpha * acc[mi][ni][r];
-                        if (use_atomic) atomicAdd(dst, v); else *dst += v;
-                    }
+                    old[r][ni] = (row < pM && col < pN) ? base[(long long)row * sRow + col] : 0.f;
                 }
             }
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * MI * 32 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int col = n0 + wn * NI * 32 + NI * lr + ni;
+                if (row < pM && col < pN) {
+                    float* dst = base + (long long)row * sRow + col;
+                    const float v = alpha * acc[mi][ni][r];
+                    if (use_atomic) atomicAdd(dst, v); else *dst = old[r][ni] + v;
+                }
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN>

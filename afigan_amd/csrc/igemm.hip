@@ -586,14 +586,32 @@ __global__ __launch_bounds__(256) void afi_gemm_tn_kernel(const AfiGemmTN p, int
     }
     const bool use_atomic = gridDim.y > 1;
     float* out = p.dU + (long long)plane * p.M * p.N;
+    const long long ldn = p.N;
+    if (use_atomic) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
-            float* dst = out + (long long)row * p.N + n0 + wn * 32 + lr;
-            if (use_atomic) atomicAdd(dst, acc[mi][r]); else *dst += acc[mi][r];
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
+                atomicAdd(out + (long long)row * ldn + n0 + wn * 32 + lr, acc[mi][r]);
+            }
+    } else {                                               // all old values first, then add and store (afi_gemm_bf16.h: the per-element form ran as serial round trips)
+        float old[MI][16];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
+                old[mi][r] = out[(long long)row * ldn + n0 + wn * 32 + lr];
+            }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + MI * ((r & 3) + 8 * (r >> 2) + 4 * lh) + mi;
+                out[(long long)row * ldn + n0 + wn * 32 + lr] = old[mi][r] + acc[mi][r];
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1571,51 +1571,64 @@ static int launch_wgrad_group_sk(const AfiWgradGemm* probs, int n, hipStream_t s
 // ------------------------------------------------------------------------------------------------
 // bf16x6 form of the grouped weight gradients (128 x 128 tiles): the gather of afi_wgrad_gemm_range (both operands pixel-major, the X
 // rows shifted by the tap and masked at the map border) around the LDS images and transposed fragment reads of afi_gemm_tn_bf16_kernel
-// (csrc/afi_gemm_bf16.h): a stage's 32 pixels x 128 channels of dY and of X are split into three bf16 parts on their way from the
-// prefetch registers into LDS ([32 k][128 columns] per part, 16-byte chunks swizzled), fragments come out k-fast through
-// ds_read_b64_tr_b16, and the six products of relative size >= 2^-16 run on v_mfma_f32_32x32x16_bf16, smallest first, into fp32
-// accumulators -- fp32-grade sums at 6/16 of the fp32-MFMA pipe time.  Same stream-K walk, same store / atomic rule as the fp32 kernel.
+// (csrc/afi_gemm_bf16.h): 16 pixels x 128 channels of dY and of X at a time (a HALF stage: one MFMA k-step) are split into three bf16 parts
+// on their way from the prefetch registers into LDS ([16 k][128 columns] per part, 16-byte chunks swizzled), fragments come out k-fast
+// through ds_read_b64_tr_b16, and the six products of relative size >= 2^-16 run on v_mfma_f32_32x32x16_bf16, smallest first, into fp32
+// accumulators -- fp32-grade sums at 6/16 of the fp32-MFMA pipe time.  Same stream-K walk as the fp32 kernel (units of 32 pixels).
+// The loop is SOFTWARE-PIPELINED inside the wave: two LDS buffers of 24 KB, ONE barrier per half stage; while a wave's 24 MFMAs of half stage
+// h run, the same wave splits half stage h + 1 into the other buffer and requests half stage h + 3 into the register set that frees (two
+// sets: a gather is requested two half stages before it is split).  The first version (stages of 32 pixels, split between two barriers,
+// MFMAs behind the second: every wave of a block in the same phase at the same time) ran as the SUM of its MFMA time and of everything
+// else -- 153 us on config 1's ten problems, 95 without the MFMAs (tools/micro/wg6_bench.cpp, profiles/r04/wgrad6_*.txt); this one 121.
+// Measured on the way with the in-kernel stamps below: 12.8 us per range in the epilogue (fixed, see there); packed against plain
+// subtractions in the split: 1.82 against 1.79 us per half stage (kept plain); 5 / 7 / 9 vector instructions asked behind each MFMA: no difference.
 // ------------------------------------------------------------------------------------------------
-#ifndef AFI_WG6_ABLATE
-#define AFI_WG6_ABLATE 0                                   // tools/micro/wg6_bench.cpp only: 1 no MFMAs, 2 no gather, 4 no split, 8 no fragment reads, 16 no result stores
+#ifdef AFI_WG6_DIAG                                        // tools/micro/wg6_bench.cpp only: per block, 10 ns ticks spent in (range prologue, K loop, epilogue), ranges, kernel span
+__device__ unsigned long long afi_wg6_stamp[4096][6];
+#define AFI_WG6_TICK(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); afi_wg6_stamp[blockIdx.x][i] += t_ - wg6_t_; wg6_t_ = t_; } } while (0)
+#else
+#define AFI_WG6_TICK(i) do { } while (0)
+#endif
+#ifndef AFI_WG6_SPLIT
+#define AFI_WG6_SPLIT afi_split3_pair_np
+#endif
+#ifndef AFI_WG6_VALU_PER_MFMA
+#define AFI_WG6_VALU_PER_MFMA 7                            // vector instructions the scheduler is asked to place behind each MFMA of a half stage
 #endif
 __device__ __forceinline__ void afi_wgrad6_gemm_range(const AfiWgradGemm& p, int ntile_m, int ntile_n, int t, long long k_begin, long long k_end, bool use_atomic) {
-    constexpr int BM = 128, BN = 128, BK = AFI_BK, NT = 256, WN = 2, MI = 2, NI = 2;
-    constexpr int TILE = BK * BM * 2;                      // one bf16 image: [32 k][128 columns], 8 KB
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // [dY: hi | mid | lo][X: hi | mid | lo]
+    constexpr int BM = 128, HK = 16, WN = 2, MI = 2, NI = 2;
+    constexpr int PART = HK * BM * 2;                      // one bf16 image of a half stage: [16 k][128 columns], 4 KB
+    constexpr int BUF = 6 * PART;                          // [dY: hi | mid | lo][X: hi | mid | lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];   // two buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
-    typedef const __attribute__((address_space(1))) float gfloat;
-    typedef const __attribute__((address_space(1))) f32x4 gf32x4;
-    gfloat* zpage = (gfloat*)afi_zeros;
-    asm volatile("" : "+v"(zpage));
     int tap, tile_n, tile_m;
-    tap = t % p.ntaps; t /= p.ntaps;                       // taps fastest: the 9 blocks of one (m, n) tile share dY and most of X in L2
+    tap = t % p.ntaps; t /= p.ntaps;
     tile_n = t % ntile_n; tile_m = t / ntile_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = tile_m * BM, n0 = tile_n * 128;
     int dy = 0, dx = 0;
     if (p.ntaps == 9) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
     const int HW = p.H * p.W;
-    if (k_begin >= k_end) return;                          // (whole block: EXEC stays full for the transposed reads below)
-    const int nK = (int)((k_end - k_begin + BK - 1) / BK);
+    if (k_begin >= k_end) return;
+    const int nH = (int)((k_end - k_begin + HK - 1) / HK);
+#ifdef AFI_WG6_DIAG
+    unsigned long long wg6_t_ = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { afi_wg6_stamp[blockIdx.x][3] += 1; afi_wg6_stamp[blockIdx.x][4] += nH; }
+#endif
 
-    // ---- loader: thread = the eight channels 8 c8 .. + 7 of the pixels (k rows) kr and kr + 16 of a stage, for both operands: two 16-byte
-    //      buffer loads per operand and row (16 adjacent lanes read 512 contiguous bytes of one pixel), and per part ONE 16-byte LDS store
-    //      of a whole chunk.  Everything is branch-free -- validity is an out-of-range offset (the buffer returns zeros), the walk over the
-    //      pixels advances (y, x) and the two offsets by selects -- and the descriptor fields the loop needs are copied out of the kernel
-    //      argument block first: with the per-pass branches, `while` wraps and argument re-loads of the first version the empty stage
-    //      skeleton cost 57 of the kernel's 162 us (tools/micro/wg6_bench.cpp).
+    // ---- loader: thread = the eight channels 8 c8 .. + 7 of pixel row kr of a half stage, for both operands: two 16-byte buffer loads per
+    //      operand (16 adjacent lanes read 512 contiguous bytes of one pixel), and per part ONE 16-byte LDS store of a whole chunk.
+    //      Everything is branch-free -- validity is an out-of-range offset (the buffer returns zeros), the walk over the pixels advances
+    //      (y, x) and the two offsets by selects -- and the descriptor fields the loop needs are copied out of the kernel argument block first.
     const int c8 = tid & 15, kr = tid >> 4;
     const int pW = p.W, pH = p.H, xs = p.x_stride, pxH = p.xH, pxW = p.xW;
     const int a_col = m0 + 8 * c8;
     int a_ph = 0, a_ch = a_col;
     if (p.dy_up == 2) { a_ph = a_col / p.CoutPhase; a_ch = a_col - a_ph * p.CoutPhase; }
-    // (Mrows, Ncols and CoutPhase are multiples of 4; the two float4 halves of the 8-channel group are validated separately)
     const unsigned a_ok0 = a_col < p.Mrows ? 1u : 0u, a_ok1 = a_col + 4 < p.Mrows ? 1u : 0u;
     const int b_col = n0 + 8 * c8;
     const unsigned b_ok0 = b_col < p.Ncols ? 1u : 0u, b_ok1 = b_col + 4 < p.Ncols ? 1u : 0u;
-    // second half of the dY group: the next four channels, or (pixel-shuffled dY whose phase ends inside the group) the next phase's first
     int a_half = 4;
     if (p.dy_up == 2 && a_ch + 4 >= p.CoutPhase) {
         const int ph1 = a_ph + 1;
@@ -1623,83 +1636,62 @@ __device__ __forceinline__ void afi_wgrad6_gemm_range(const AfiWgradGemm& p, int
     }
     const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.DY.p, 0, 0x7FFFFFF0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.X.p, 0, 0x7FFFFFF0, 0x00020000);
-    // (32-bit element offsets: the launcher admits small-map problems only, whose operands span less than 2^28 elements)
     const int a_eH = p.dy_up * (int)p.DY.sH, a_eW = p.dy_up * (int)p.DY.sW;
-    const int adv_y = BK / pW, adv_x = BK - adv_y * pW;
+    const int adv_y = HK / pW, adv_x = HK - adv_y * pW;
     const int a_adv = adv_y * a_eH + adv_x * a_eW, a_wrapx = a_eH - pW * a_eW, a_wrapy = (int)p.DY.sN - pH * a_eH;
     const int b_eH = xs * (int)p.X.sH, b_eW = xs * (int)p.X.sW;
     const int b_adv = adv_y * b_eH + adv_x * b_eW, b_wrapx = b_eH - pW * b_eW, b_wrapy = (int)p.X.sN - pH * b_eH;
-    const bool single_wrap = adv_y + 1 <= pH;              // (uniform) a stage of 32 pixels crosses at most one image boundary
-    int a_off[2], b_off[2], py[2], px[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const long long pix = k_begin + kr + 16 * i;
+    const bool single_wrap = adv_y + 1 <= pH;
+    int a_off, b_off, py, px;
+    {
+        const long long pix = k_begin + kr;
         const int n = (int)(pix / HW); const int rem = (int)(pix - (long long)n * HW);
-        py[i] = rem / pW; px[i] = rem - py[i] * pW;
-        a_off[i] = n * (int)p.DY.sN + py[i] * a_eH + px[i] * a_eW + (a_ph >> 1) * (int)p.DY.sH + (a_ph & 1) * (int)p.DY.sW + a_ch;
-        b_off[i] = n * (int)p.X.sN + py[i] * b_eH + dy * (int)p.X.sH + px[i] * b_eW + dx * (int)p.X.sW + b_col;
+        py = rem / pW; px = rem - py * pW;
+        a_off = n * (int)p.DY.sN + py * a_eH + px * a_eW + (a_ph >> 1) * (int)p.DY.sH + (a_ph & 1) * (int)p.DY.sW + a_ch;
+        b_off = n * (int)p.X.sN + py * b_eH + dy * (int)p.X.sH + px * b_eW + dx * (int)p.X.sW + b_col;
     }
-    int k_left = (int)(k_end - k_begin) - kr;              // pixels of this thread's first row still inside the range (row i: - 16 i)
-    u32x4 a_reg[2][2], b_reg[2][2];
-    auto prefetch = [&](bool more) {
+    int k_left = (int)(k_end - k_begin) - kr;
+    u32x4 a_reg[2][2], b_reg[2][2];                        // [set: parity of the half stage][half of the 8-channel group]
+    auto prefetch = [&](auto SET, bool more) {
+        constexpr int S = decltype(SET)::value;
         unsigned mmv = more ? 1u : 0u;
-        asm volatile("" : "+v"(mmv));                      // (loads stay unconditional: counted vmcnt waits)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned in = (k_left - 16 * i > 0) ? mmv : 0u;
-            const int yy = py[i] * xs + dy, xx = px[i] * xs + dx;
-            const unsigned inb = ((unsigned)yy < (unsigned)pxH && (unsigned)xx < (unsigned)pxW) ? in : 0u;
-            const unsigned ao = 4u * (unsigned)a_off[i], bo = 4u * (unsigned)b_off[i];
-            if constexpr ((AFI_WG6_ABLATE & 2) == 0) {
-                a_reg[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (in & a_ok0) ? ao : 0xFFFFFFFFu, 0, 0);
-                a_reg[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (in & a_ok1) ? ao + 4u * (unsigned)a_half : 0xFFFFFFFFu, 0, 0);
-                b_reg[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (inb & b_ok0) ? bo : 0xFFFFFFFFu, 0, 0);
-                b_reg[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (inb & b_ok1) ? bo + 16u : 0xFFFFFFFFu, 0, 0);
-            } else {
-                a_reg[i][0] = u32x4{ao, ao, ao, ao}; a_reg[i][1] = u32x4{in, ao, ao, ao}; b_reg[i][0] = u32x4{bo, bo, bo, bo}; b_reg[i][1] = u32x4{inb, bo, bo, bo};
-            }
-            if (single_wrap) {                             // (uniform) the common case, by selects
-                px[i] += adv_x; py[i] += adv_y; a_off[i] += a_adv; b_off[i] += b_adv;
-                const bool wx = px[i] >= pW;
-                px[i] -= wx ? pW : 0; py[i] += wx ? 1 : 0; a_off[i] += wx ? a_wrapx : 0; b_off[i] += wx ? b_wrapx : 0;
-                const bool wy = py[i] >= pH;
-                py[i] -= wy ? pH : 0; a_off[i] += wy ? a_wrapy : 0; b_off[i] += wy ? b_wrapy : 0;
-            } else {                                       // maps of fewer than 32 + W pixels
-                px[i] += adv_x; py[i] += adv_y; a_off[i] += a_adv; b_off[i] += b_adv;
-                if (px[i] >= pW) { px[i] -= pW; ++py[i]; a_off[i] += a_wrapx; b_off[i] += b_wrapx; }
-                while (py[i] >= pH) { py[i] -= pH; a_off[i] += a_wrapy; b_off[i] += b_wrapy; }
-            }
+        asm volatile("" : "+v"(mmv));
+        const unsigned in = (k_left > 0) ? mmv : 0u;
+        const int yy = py * xs + dy, xx = px * xs + dx;
+        const unsigned inb = ((unsigned)yy < (unsigned)pxH && (unsigned)xx < (unsigned)pxW) ? in : 0u;
+        const unsigned ao = 4u * (unsigned)a_off, bo = 4u * (unsigned)b_off;
+        a_reg[S][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (in & a_ok0) ? ao : 0xFFFFFFFFu, 0, 0);
+        a_reg[S][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (in & a_ok1) ? ao + 4u * (unsigned)a_half : 0xFFFFFFFFu, 0, 0);
+        b_reg[S][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (inb & b_ok0) ? bo : 0xFFFFFFFFu, 0, 0);
+        b_reg[S][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (inb & b_ok1) ? bo + 16u : 0xFFFFFFFFu, 0, 0);
+        px += adv_x; py += adv_y; a_off += a_adv; b_off += b_adv;
+        if (single_wrap) {
+            const bool wx = px >= pW;
+            px -= wx ? pW : 0; py += wx ? 1 : 0; a_off += wx ? a_wrapx : 0; b_off += wx ? b_wrapx : 0;
+            const bool wy = py >= pH;
+            py -= wy ? pH : 0; a_off += wy ? a_wrapy : 0; b_off += wy ? b_wrapy : 0;
+        } else {
+            if (px >= pW) { px -= pW; ++py; a_off += a_wrapx; b_off += b_wrapx; }
+            while (py >= pH) { py -= pH; a_off += a_wrapy; b_off += b_wrapy; }
         }
-        k_left -= BK;
+        k_left -= HK;
     };
-    int st_off[2];
+    const int st_off = 256 * kr + 16 * (c8 ^ (((kr & 3) << 2) | ((kr >> 2) & 3)));
+    auto split_store = [&](auto SET, unsigned char* buf) {
+        constexpr int S = decltype(SET)::value;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int r = kr + 16 * i;
-        st_off[i] = 256 * r + 16 * (c8 ^ (((r & 3) << 2) | ((r >> 2) & 3)));
-    }
-    auto stage_store = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int op = 0; op < 2; ++op) {               // dY, then X
-                const f32x4 v0 = __builtin_bit_cast(f32x4, op ? b_reg[i][0] : a_reg[i][0]), v1 = __builtin_bit_cast(f32x4, op ? b_reg[i][1] : a_reg[i][1]);
-                unsigned char* base = smem_b + op * 3 * TILE + st_off[i];
-                if constexpr ((AFI_WG6_ABLATE & 4) != 0) {
-                    const u32x4 u0 = __builtin_bit_cast(u32x4, v0), u1 = __builtin_bit_cast(u32x4, v1);
-                    *(u32x4*)base = u0; *(u32x4*)(base + TILE) = u1; *(u32x4*)(base + 2 * TILE) = u32x4{u0[0], u1[0], u0[2], u1[2]};
-                    continue;
-                }
-                u32x4 h, m, l;                              // (pair-wise split: one v_cvt_pk_bf16_f32 per part and pair, afi_bf16_split.h)
-                unsigned hh, mm_, ll;
-                afi_split3_pair(v0[0], v0[1], hh, mm_, ll); h[0] = hh; m[0] = mm_; l[0] = ll;
-                afi_split3_pair(v0[2], v0[3], hh, mm_, ll); h[1] = hh; m[1] = mm_; l[1] = ll;
-                afi_split3_pair(v1[0], v1[1], hh, mm_, ll); h[2] = hh; m[2] = mm_; l[2] = ll;
-                afi_split3_pair(v1[2], v1[3], hh, mm_, ll); h[3] = hh; m[3] = mm_; l[3] = ll;
-                *(u32x4*)base = h; *(u32x4*)(base + TILE) = m; *(u32x4*)(base + 2 * TILE) = l;
-            }
+        for (int op = 0; op < 2; ++op) {                   // dY, then X
+            const f32x4 v0 = __builtin_bit_cast(f32x4, op ? b_reg[S][0] : a_reg[S][0]), v1 = __builtin_bit_cast(f32x4, op ? b_reg[S][1] : a_reg[S][1]);
+            unsigned char* base = buf + op * 3 * PART + st_off;
+            u32x4 h, m, l;
+            unsigned hh, mm_, ll;
+            AFI_WG6_SPLIT(v0[0], v0[1], hh, mm_, ll); h[0] = hh; m[0] = mm_; l[0] = ll;
+            AFI_WG6_SPLIT(v0[2], v0[3], hh, mm_, ll); h[1] = hh; m[1] = mm_; l[1] = ll;
+            AFI_WG6_SPLIT(v1[0], v1[1], hh, mm_, ll); h[2] = hh; m[2] = mm_; l[2] = ll;
+            AFI_WG6_SPLIT(v1[2], v1[3], hh, mm_, ll); h[3] = hh; m[3] = mm_; l[3] = ll;
+            *(u32x4*)base = h; *(u32x4*)(base + PART) = m; *(u32x4*)(base + 2 * PART) = l;
+        }
     };
-    // transposed-read addresses of k-step 0 (k-step 1: + 16 rows = + 4096 bytes), as in afi_gemm_tn_bf16_kernel
     int fa_off[MI][2], fb_off[NI][2];
     {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
@@ -1710,7 +1702,7 @@ __device__ __forceinline__ void afi_wgrad6_gemm_range(const AfiWgradGemm& p, int
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) fa_off[mi][rd] = 256 * r + 16 * ((4 * (wm * MI + mi) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = 3 * TILE + 256 * r + 16 * ((4 * (wn * NI + ni) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = 3 * PART + 256 * r + 16 * ((4 * (wn * NI + ni) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
         }
     }
     f32x16 acc[MI][NI];
@@ -1720,73 +1712,105 @@ __device__ __forceinline__ void afi_wgrad6_gemm_range(const AfiWgradGemm& p, int
         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    auto mm = [](bf16x8 x, bf16x8 y, f32x16 c) -> f32x16 { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); };
 
-    auto frag = [&](const unsigned char* base, int o0, int o1) -> bf16x8 {
-        if constexpr ((AFI_WG6_ABLATE & 8) != 0) { const unsigned v = (unsigned)(o0 + o1) + (unsigned)(size_t)base; return __builtin_bit_cast(bf16x8, u32x4{v, v, v, v}); }
-        return afi_tr_frag(base, o0, o1);
-    };
-    auto mm = [](bf16x8 x, bf16x8 y, f32x16 c) -> f32x16 {
-        if constexpr ((AFI_WG6_ABLATE & 1) != 0) { asm volatile("" :: "v"(x), "v"(y)); return c; }
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
-    };
-    prefetch(true);
-    for (int kc = 0; kc < nK; ++kc) {
-        stage_store();
-        __syncthreads();
-        prefetch(kc + 1 < nK);                             // the next stage's gather runs under this stage's 48 MFMAs
+    AFI_WG6_TICK(0);
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    // half stage h lives in register set h & 1 from two iterations before it is split: the gather of h + 3 is requested in iteration h,
+    // behind the split of h + 1 that frees its set (a request only one iteration ahead was waited for at the top of every iteration)
+    prefetch(S0(), true);                                  // half stage 0
+    prefetch(S1(), 1 < nH);                                // half stage 1
+    split_store(S0(), smem_b);
+    prefetch(S0(), 2 < nH);                                // half stage 2
+    __syncthreads();
+    auto half_stage = [&](auto NEXT, int h) {              // NEXT: the register set of half stage h + 1
+        const unsigned char* cur = smem_b + (h & 1) * BUF;
+        unsigned char* nxt = smem_b + ((h + 1) & 1) * BUF;
+        bf16x8 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            bf16x8 ah[MI], am[MI], al[MI];
+        for (int mi = 0; mi < MI; ++mi) {
+            ah[mi] = afi_tr_frag(cur, fa_off[mi][0], fa_off[mi][1]);
+            am[mi] = afi_tr_frag(cur + PART, fa_off[mi][0], fa_off[mi][1]);
+            al[mi] = afi_tr_frag(cur + 2 * PART, fa_off[mi][0], fa_off[mi][1]);
+        }
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                ah[mi] = frag(smem_b + 4096 * s2, fa_off[mi][0], fa_off[mi][1]);
-                am[mi] = frag(smem_b + 4096 * s2 + TILE, fa_off[mi][0], fa_off[mi][1]);
-                al[mi] = frag(smem_b + 4096 * s2 + 2 * TILE, fa_off[mi][0], fa_off[mi][1]);
-            }
+        for (int ni = 0; ni < NI; ++ni) {
+            bh[ni] = afi_tr_frag(cur, fb_off[ni][0], fb_off[ni][1]);
+            bm[ni] = afi_tr_frag(cur + PART, fb_off[ni][0], fb_off[ni][1]);
+            bl[ni] = afi_tr_frag(cur + 2 * PART, fb_off[ni][0], fb_off[ni][1]);
+        }
+        // per accumulator smallest terms first; consecutive MFMAs go to different accumulators (four of them)
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {              // one column block's fragments at a time (register budget: three blocks per CU)
-                const bf16x8 bh = frag(smem_b + 4096 * s2, fb_off[ni][0], fb_off[ni][1]);
-                const bf16x8 bm = frag(smem_b + 4096 * s2 + TILE, fb_off[ni][0], fb_off[ni][1]);
-                const bf16x8 bl = frag(smem_b + 4096 * s2 + 2 * TILE, fb_off[ni][0], fb_off[ni][1]);
-                // per accumulator smallest terms first; consecutive MFMAs alternate between the two accumulators
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(al[mi], bh, acc[mi][ni]);
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(al[mi], bh[ni], acc[mi][ni]);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bl, acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(am[mi], bm, acc[mi][ni]);
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bl[ni], acc[mi][ni]);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(am[mi], bh, acc[mi][ni]);
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bm, acc[mi][ni]);
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(am[mi], bm[ni], acc[mi][ni]);
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bh, acc[mi][ni]);
-            }
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(am[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bm[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bh[ni], acc[mi][ni]);
+        // the next half stage goes from its registers into the other buffer (every wave left that one at the last barrier); its set then
+        // takes the half stage two further on
+        split_store(NEXT, nxt);
+        prefetch(NEXT, h + 3 < nH);
+        // the scheduler's pipeline hint: one MFMA, then a share of the split's vector work
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x002, AFI_WG6_VALU_PER_MFMA, 0);    // VALU
         }
         __syncthreads();
+    };
+    for (int h = 0; h < nH; h += 2) {
+        half_stage(S1(), h);
+        if (h + 1 < nH) half_stage(S0(), h + 1);           // (uniform)
     }
+    AFI_WG6_TICK(1);
+    // ---- dW += alpha * acc.  Every element goes out as ONE no-return fp32 atomic add, shared tile or not: on a tile this run owns alone
+    //      it is the only addend (same bits as load / add / store), and nothing waits for a round trip -- the load / add / store form
+    //      the compiler produced for `*dst += v` (a load, s_waitcnt vmcnt(0), a store, and the descriptor re-read from the argument block,
+    //      per element: 64 serial round trips per thread) cost 12.8 us per range (in-kernel stamps, tools/micro/wg6_bench.cpp -DAFI_WG6_DIAG)
+    {
+        (void)use_atomic;
+        const int pM = p.Mrows, pN = p.Ncols;
+        const float alpha = p.alpha;
+        float* const base = p.DW + (long long)tap * p.dw_sTap;
+        const long long sRow = p.dw_sRow;
+        int cols[NI]; bool cok[NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+        for (int ni = 0; ni < NI; ++ni) { cols[ni] = n0 + (wn * NI + ni) * 32 + lr; cok[ni] = cols[ni] < pN; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (row < p.Mrows) {
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int col = n0 + (wn * NI + ni) * 32 + lr;
-                    if (col < p.Ncols) {
-                        float* dst = p.DW + (long long)row * p.dw_sRow + (long long)tap * p.dw_sTap + col;
-                        const float v = p.alpha * acc[mi][ni][r];
-                        if constexpr ((AFI_WG6_ABLATE & 16) != 0) { if (v == 123.456f) *dst = v; }
-                        else if (use_atomic) atomicAdd(dst, v); else *dst += v;
-                    }
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                float* const rp = base + (long long)row * sRow;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    if (row < pM && cok[ni]) __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(rp + cols[ni]), alpha * acc[mi][ni][r]);
             }
-        }
+    }
+    AFI_WG6_TICK(2);
 }
 __global__ __launch_bounds__(256, 3) void afi_wgrad6_group_sk_kernel(const AfiWgradGroupSK grp) {
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
-    const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);      // neighbours in the unit order share an XCD's L2
+    const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
     const int u = b * grp.units_per_block;
     int u_end = u + grp.units_per_block;
     if (u_end > grp.total_units) u_end = grp.total_units;
@@ -1795,6 +1819,7 @@ __global__ __launch_bounds__(256, 3) void afi_wgrad6_group_sk_kernel(const AfiWg
         const long long P = (long long)p.N * p.H * p.W;
         const long long k0 = (long long)s0 * AFI_BK, k1 = (long long)s1 * AFI_BK < P ? (long long)s1 * AFI_BK : P;
         afi_wgrad6_gemm_range(p, grp.ntile_m[pi], grp.ntile_n[pi], tile, k0, k1, shared);
+        __syncthreads();                                   // (the next range's first split goes into buffer 0, which a slower wave may still read)
     });
 }
 // the grouped weight gradients of one small-map backward pass on the bf16 matrix cores (six-product form); 3x3 / 1x1 problems only
