@@ -189,6 +189,185 @@ __global__ __launch_bounds__(256, 2) void afi_gemm_tn_bf16_kernel(const AfiGemmT
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 4: the six-product weight-gradient GEMM, SOFTWARE-PIPELINED inside the wave (the scheme of the small-map weight-gradient kernel,
+// smallmap.hip: afi_wgrad6_gemm_range, where in-kernel stamps showed the block-phased loop above running as the SUM of its MFMA time and
+// of its split / staging time -- every wave of a block splits between the barriers and multiplies behind them, and three resident blocks
+// overlap those phases poorly).  Half stages of 16 k rows (one MFMA k-step): two LDS buffers of 24 KB ([dY hi | mid | lo][X hi | mid | lo],
+// [16 k][128 columns] bf16 each, the same swizzle and transposed fragment reads as above), ONE barrier per half stage; while a wave's 24
+// MFMAs of half stage h run, the same wave splits half stage h + 1 from its registers into the other buffer (pair-wise split, one
+// v_cvt_pk_bf16_f32 per part and pair, one 16-byte LDS store per part) and requests half stage h + 3 into the register set that frees.
+// Thread = the eight columns 8 c8 .. + 7 of k row kr of a half stage, for both operands (16 adjacent lanes read 512 contiguous bytes).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void afi_gemm_tn_bf16x6_pipe_kernel(const AfiGemmTN p, int ntile_m, int ntile_n, int kper) {
+    constexpr int BM = 128, BN = 128, HK = 16, WN = 2, MI = 2, NI = 2;
+    constexpr int PART = HK * BM * 2;                        // 4 KB: [16 k][128 columns] bf16
+    constexpr int BUF = 6 * PART;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    int t;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tile_n = t % ntile_n; t /= ntile_n;
+    const int tile_m = t % ntile_m; const int plane = t / ntile_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long long k_begin = (long long)blockIdx.y * kper;
+    const long long k_end = (k_begin + kper < p.rows_per_plane) ? k_begin + kper : p.rows_per_plane;
+    if (k_begin >= k_end) return;                            // (whole block: EXEC stays full for the transposed reads below)
+    const int nH = (int)((k_end - k_begin) / HK);           // (the launcher keeps every K range a multiple of 32 rows)
+    const int c8 = tid & 15, kr = tid >> 4;
+    const float* a_ptr = p.Q + ((long long)plane * p.rows_per_plane + k_begin + kr) * p.M + m0 + 8 * c8;
+    const float* b_ptr = p.V + ((long long)plane * p.rows_per_plane + k_begin + kr) * p.N + n0 + 8 * c8;
+    const long long a_step = (long long)HK * p.M, b_step = (long long)HK * p.N;
+
+    f32x4 a_reg[2][2], b_reg[2][2];                          // [set: parity of the half stage][half of the 8-column group]
+    auto prefetch = [&](auto SET, bool more) {
+        constexpr int S = decltype(SET)::value;
+        if (more) {                                          // (uniform; the last two requests of a range are not made)
+            a_reg[S][0] = *(const f32x4*)a_ptr; a_reg[S][1] = *(const f32x4*)(a_ptr + 4);
+            b_reg[S][0] = *(const f32x4*)b_ptr; b_reg[S][1] = *(const f32x4*)(b_ptr + 4);
+        }
+        a_ptr += a_step; b_ptr += b_step;
+    };
+    const int st_off = 256 * kr + 16 * (c8 ^ (((kr & 3) << 2) | ((kr >> 2) & 3)));
+    auto split_store = [&](auto SET, unsigned char* buf) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {                     // Q, then V
+            const f32x4 v0 = op ? b_reg[S][0] : a_reg[S][0], v1 = op ? b_reg[S][1] : a_reg[S][1];
+            unsigned char* base = buf + op * 3 * PART + st_off;
+            u32x4 h, m, l;
+            unsigned hh, mm_, ll;
+            afi_split3_pair_np(v0[0], v0[1], hh, mm_, ll); h[0] = hh; m[0] = mm_; l[0] = ll;
+            afi_split3_pair_np(v0[2], v0[3], hh, mm_, ll); h[1] = hh; m[1] = mm_; l[1] = ll;
+            afi_split3_pair_np(v1[0], v1[1], hh, mm_, ll); h[2] = hh; m[2] = mm_; l[2] = ll;
+            afi_split3_pair_np(v1[2], v1[3], hh, mm_, ll); h[3] = hh; m[3] = mm_; l[3] = ll;
+            *(u32x4*)base = h; *(u32x4*)(base + PART) = m; *(u32x4*)(base + 2 * PART) = l;
+        }
+    };
+    int fa_off[MI][2], fb_off[NI][2];
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int r = 8 * (g >> 1) + 4 * rd + q;
+            const int swz = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa_off[mi][rd] = 256 * r + 16 * ((4 * (wm * MI + mi) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = 3 * PART + 256 * r + 16 * ((4 * (wn * NI + ni) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+        }
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    auto mm = [](bf16x8 x, bf16x8 y, f32x16 c) -> f32x16 { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0); };
+
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    prefetch(S0(), true);                                    // half stage 0
+    prefetch(S1(), 1 < nH);                                  // half stage 1
+    split_store(S0(), smem_b);
+    prefetch(S0(), 2 < nH);                                  // half stage 2
+    __syncthreads();
+    auto half_stage = [&](auto NEXT, int h) {                // NEXT: the register set of half stage h + 1
+        const unsigned char* cur = smem_b + (h & 1) * BUF;
+        unsigned char* nxt = smem_b + ((h + 1) & 1) * BUF;
+        bf16x8 ah[MI], am[MI], al[MI], bh[NI], bm[NI], bl[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            ah[mi] = afi_tr_frag(cur, fa_off[mi][0], fa_off[mi][1]);
+            am[mi] = afi_tr_frag(cur + PART, fa_off[mi][0], fa_off[mi][1]);
+            al[mi] = afi_tr_frag(cur + 2 * PART, fa_off[mi][0], fa_off[mi][1]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            bh[ni] = afi_tr_frag(cur, fb_off[ni][0], fb_off[ni][1]);
+            bm[ni] = afi_tr_frag(cur + PART, fb_off[ni][0], fb_off[ni][1]);
+            bl[ni] = afi_tr_frag(cur + 2 * PART, fb_off[ni][0], fb_off[ni][1]);
+        }
+        // per accumulator smallest terms first (the order of the kernel above); consecutive MFMAs go to different accumulators
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(al[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bl[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(am[mi], bm[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(am[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bm[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bh[ni], acc[mi][ni]);
+        if (h + 1 < nH) split_store(NEXT, nxt);              // (uniform) every wave left that buffer at the last barrier
+        prefetch(NEXT, h + 3 < nH);
+        // the scheduler's pipeline hint: one MFMA, then a share of the split's vector work
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __syncthreads();
+    };
+    for (int h = 0; h < nH; h += 2) {
+        half_stage(S1(), h);
+        if (h + 1 < nH) half_stage(S0(), h + 1);             // (uniform)
+    }
+    const bool use_atomic = gridDim.y > 1;
+    float* out = p.dU + (long long)plane * p.M * p.N;
+    const long long ldn = p.N;
+    if (use_atomic) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(out + (long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr), acc[mi][ni][r]);
+                }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float old[NI][16];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    old[ni][r] = out[(long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr];
+                }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    out[(long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr] = old[ni][r] + acc[mi][ni][r];
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Round 3: the NT GEMM with both operands staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no LDS store instructions) on
 // v_mfma_f32_16x16x32_bf16.  Measured against the register-staged kernel above in one process (tools/gemm_ab.py, random operands):
 // removing the conversion VALU alone changes nothing; removing the VGPR round trip and the ds_write stream is worth +17..20 %.

@@ -1004,7 +1004,7 @@ int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int plane
     const bool db = split != 6;                            // six-product form: one 48 KB buffer
     const size_t lds = (db ? 2u : 1u) * 2u * (split == 6 ? 3u : (split == 3 ? 2u : 1u)) * 8192u;
     const dim3 grid((unsigned)tiles, splitK), blk(256);
-    if (split == 6) hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<6, false>), grid, blk, lds, st, g, ntm, ntn, kper);
+    if (split == 6) hipLaunchKernelGGL(afi_gemm_tn_bf16x6_pipe_kernel, grid, blk, lds, st, g, ntm, ntn, kper);   // (the same 48 KB: two buffers of 24)
     else if (split == 3) hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<3, true>), grid, blk, lds, st, g, ntm, ntn, kper);
     else hipLaunchKernelGGL((afi_gemm_tn_bf16_kernel<1, true>), grid, blk, lds, st, g, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
