@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFI_LIB_PATH") or os.path.join(_HERE, "csrc", "libafigan_hip.so")   # override: A/B kernel builds
 
 AFI_MAX_RDB = 8
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class AfiError(RuntimeError):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "afi_discriminator_fwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
     "afi_discriminator_bwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
     "afi_discriminator_ws_layout": (_i, [C.POINTER(C.c_int), _i, _i, _i, C.POINTER(C.c_longlong)]),
+    "afi_discriminator_saved_activations": (_i, [_vp, C.POINTER(C.c_int), _i, _i, _i]),
     "afi_discriminator_fwd": (_i, [_vp, _DP, View, _i, _i, _i, _vp, _i, _vp, _ll, _vp]),
     "afi_discriminator_bwd": (_i, [_vp, _DP, _DP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_conv3x3_fwd": (_i, [_vp, View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, _i, _vp]),
@@ -178,7 +179,7 @@ CTX_FIRST = frozenset(n for n, (_, a) in SIGNATURES.items() if n.startswith(("af
 DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}             # AFI_DTYPE_* of include/afigan_hip.h
 OPTIONS = {"winograd": 0, "winograd_f4_backward": 1, "winograd_f4_forward": 2, "bn_stats_fp64": 3, "d_winograd_min_pixels": 4,
            "g_winograd_min_pixels": 5, "g_smallmap_max_pixels": 6, "g_grouped_wgrad_max_pixels": 7, "g_batch_growth_grads": 8,
-           "g_smallmap6_max_pixels": 9, "g_rdb_chain": 10}      # AFI_OPT_*
+           "g_smallmap6_max_pixels": 9, "g_rdb_chain": 10, "d_fold_bn_apply": 11}      # AFI_OPT_*
 
 
 class Ctx:

@@ -22,6 +22,11 @@ struct AfiView {
     long long sN, sH, sW;
 };
 
+// A tensor that is read THROUGH a BatchNorm affine and LeakyReLU(0.2): the reader sees lrelu(((x - mean) * invstd) * gamma + beta) per channel
+// (csrc/afi_bn.h: the exact arithmetic of the stand-alone apply pass), zero padding stays zero.  mean = null: off.  Taken by the Winograd
+// input transforms: a discriminator block's activation is then never written -- its consumers read the saved conv output.
+struct AfiBnLoad { const float* mean; const float* invstd; const float* gamma; const float* beta; };
+
 // Parameters of the pixel-M implicit GEMM (forward conv, conv-transpose forward, and both dgrads).
 //   C[m][n] = sum_k A[m][k] * B[k][n],  m <-> (img, y, x) on the GEMM pixel grid N x H x W,
 //   k <-> (tap, kphase, c),  n <-> output column.
@@ -74,6 +79,7 @@ struct AfiPixGemm {
     // null = the fp32-MFMA kernel reads B itself.  A problem on input channels [c_lo, c_lo + Ck) of a wider weight starts at stage
     // bimg_stage0 = c_lo / 32 * ntaps of that weight's image; bimg_nstages = stages per N tile of the whole image.
     const unsigned char* Bimg; int bimg_stage0, bimg_nstages;
+    AfiBnLoad a_bn;                                        // Winograd form only: A is read through this affine + LeakyReLU (every other form refuses it)
 };
 #define AFI_WK6_STAGE_BYTES 6144
 // one weight (or weight view) to turn into such an image: the B addressing of AfiPixGemm (b_rc = 0: row n at B + n*b_sRow + tap*b_sTap + c;

@@ -6,6 +6,7 @@
 #include "afi_common.h"
 #include "afi_bilinear.h"
 #include "afi_convt_pack.h"
+#include "afi_bn.h"
 #include <stdlib.h>
 #include <string.h>
 
@@ -310,16 +311,7 @@ int afi_launch_lrelu_slice(AfiView v, int N, int H, int W, int nch, hipStream_t 
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
-// The BatchNorm affine z = ((x - mean) * invstd) * gamma + beta with every operation rounded on its own (no FMA contraction): the forward's
-// activation and the backward's recomputed LeakyReLU' mask must take the SAME side of zero for every element, so both evaluate this one
-// function on the same fp32 operands (and a host restatement in plain fp32 tensor ops reproduces it bit for bit: tests/d_parity_util.py).
-__device__ __forceinline__ f32x4 afi_bn_affine(f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
-#pragma clang fp contract(off)
-    f32x4 t = v - mu;
-    t = t * is;
-    t = t * ga;
-    return t + be;
-}
+// (the BatchNorm affine afi_bn_affine and its LeakyReLU: afi_bn.h)
 
 // ---------------------------------------------------------------- per-channel reductions over pixels
 // Generic two-value column reduction over a dense [P][C] matrix (ld = C, C % 4 == 0).
@@ -514,12 +506,7 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
     const int C4 = C / 4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    auto apply = [slope](f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
-        v = afi_bn_affine(v, mu, is, ga, be);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] > 0.f ? v[j] : v[j] * slope;
-        return v;
-    };
+    auto apply = [slope](f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) { return afi_bn_lrelu(v, mu, is, ga, be, slope); };
     if (stride % C4 == 0) {
         // a thread stays on one channel group: its four parameter vectors are loaded once, and four independent 16-B loads are
         // kept in flight per thread (a streaming kernel needs ~37 KB outstanding per CU to cover the HBM latency)

@@ -859,6 +859,7 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
     AfiPixGemm p = p_in;
     const long long M = (long long)p.N * p.H * p.W;
     if (M <= 0 || p.Ncols <= 0 || p.Ck <= 0) return AFI_ERR_BAD_ARG;
+    if (p.a_bn.mean) return AFI_ERR_UNSUPPORTED;            // an operand read through a BatchNorm affine: the Winograd input transforms only
     if (p.b_sImg != 0 && ((long long)p.H * p.W) % 128 != 0) return AFI_ERR_BAD_ARG;   // per-image weights: tiles must not straddle images
     if (b_rc && (p.Ncols & 3)) return AFI_ERR_UNSUPPORTED;       // RC weight rows are read as float4 along n
     if (!b_rc && (p.Ck & 3)) return AFI_ERR_UNSUPPORTED;         // KC weight rows are read as float4 along c

@@ -59,9 +59,9 @@ int afi_launch_dwconv3x3(AfiView x, int N, int H, int W, int C, const float* w, 
 int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out, hipStream_t st);
 int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st);
 int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
-int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0);
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr);
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
-int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0);
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr);
 int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
 int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0);
@@ -121,7 +121,7 @@ struct WinoWgradAccum {
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ 0, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
-                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0}};
+                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -408,8 +408,8 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
         AfiView a = g.A;
         if (nph == 4) { a.p += (ph >> 1) * g.A.sH + (ph & 1) * g.A.sW; a.sH *= 2; a.sW *= 2; }
-        AFI_TRY(f4 ? afi_launch_wino4_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K)
-                   : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K));
+        AFI_TRY(f4 ? afi_launch_wino4_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn)
+                   : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn));
     }
     if (dma) {
         AFI_TRY(afi_launch_gemm_nt_bf16_dma(Vb, Usp, Mb, np, Tpad, Nc, K, dtype, st));
@@ -434,11 +434,13 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
 // forward (mode 0: out = conv(in, w) + bias) or data gradient (mode 1: out = conv^T(in, w) * lrelu'(z)) by descriptor
 // stats (forward only): fp64 partial rows for the BatchNorm statistics of the output, accumulated by the output transform (afi_common.h);
 // *stats_rows receives the number of rows written, 0 when this call did not fuse them (the caller then runs the separate pass)
+// in_bn: `in` is read through a BatchNorm affine + LeakyReLU (AfiBnLoad): the activation of the block that produced it is never written
 static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
                      float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false,
-                     double* stats = nullptr, int* stats_rows = nullptr) {
+                     double* stats = nullptr, int* stats_rows = nullptr, const AfiBnLoad* in_bn = nullptr) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
+    if (in_bn) g.a_bn = *in_bn;
     if (mode && z.p) { g.Z = z; g.z_lo = 0; g.z_hi = Nc; }
     if (stats_rows) *stats_rows = 0;
     if (stats && stats_rows && !mode) {
@@ -479,8 +481,9 @@ static float* wino_wgacc_slot(afi_ctx* cx, float* dw, int f4, int O, int I, floa
 // dy_phases = 4: dy is the hi-res gradient of a 4-phase conv-transpose; its phase views fill the four channel blocks of Q and
 // dw is the packed weight gradient [4*CoutPhase][3][3][Cin] (Cout = 4*CoutPhase).  accumulate = false keeps the call out of the
 // phase accumulator (its dw is a per-call scratch that is unpacked right away).
+// x_bn: x is read through a BatchNorm affine + LeakyReLU (AfiBnLoad)
 static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws, long long ws_floats,
-                      hipStream_t st, int dy_phases = 1, bool accumulate = true) {
+                      hipStream_t st, int dy_phases = 1, bool accumulate = true, const AfiBnLoad* x_bn = nullptr) {
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
     const int dtype = cx ? cx->dtype : afi_default_dtype();
@@ -494,7 +497,7 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     if (accumulate)
         if (float* slot = wino_wgacc_slot(cx, dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
     if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
-    AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st) : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st));
+    AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn) : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn));
     const int cph = Cout / dy_phases;
     for (int ph = 0; ph < dy_phases; ++ph) {
         AfiView d = dy;
@@ -553,7 +556,7 @@ int afi_debug_wk6_convT_images(const float* W, int Cin, int Cout, int mode, void
                                        : AfiWk6ImgJob{pack_ref, 9LL * Cin, Cin, Cin, Cout, 9, 4, 1, 0, (unsigned char*)via_pack, 0, 0};
     return afi_launch_wk6_images(&job, 1, st, nullptr, nullptr);
 }
-int afi_abi_version(void) { return 4; }
+int afi_abi_version(void) { return 5; }
 
 const char* afi_status_string(int s) {
     switch (s) {
@@ -1594,6 +1597,11 @@ int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* 
     for (int n = 0; n < 3; ++n) { off12[n] = l.o_c[n]; off12[3 + n] = l.o_y[n]; off12[6 + n] = l.o_mean[n]; off12[9 + n] = l.o_invstd[n]; }
     return AFI_OK;
 }
+int afi_discriminator_saved_activations(const afi_ctx_t* ctx, const int F[4], int N, int H, int W) {
+    if (!F || N <= 0 || H <= 0 || W <= 0) return -1;
+    const DiscWs l = disc_ws(F, N, H, W);
+    return (l.n_wino > 0 && use_wino(ctx, l.P) && afi_opt(ctx, AFI_OPT_D_FOLD_BN_APPLY) != 0) ? 4 : 7;
+}
 struct DiscBwdWs { long long o_g[3], o_dd9, o_red, o_red2, o_part, n_part, o_wino, n_wino, o_wino2, total; };
 static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     DiscBwdWs w;
@@ -1640,6 +1648,13 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
     const long long P = l.P;
     float* red = ws + l.o_red;
     AfiView in = V(xv);
+    // AFI_OPT_D_FOLD_BN_APPLY (off by default: measured slower, include/afigan_hip.h): under the Winograd path the activation of blocks 0 and 1
+    // is never written -- the next block's input transform reads the saved conv output through the block's BatchNorm affine + LeakyReLU
+    // (AfiBnLoad: the arithmetic of the apply pass, bit for bit), and so do the backward's weight-gradient input transforms.  Block 2's
+    // activation feeds the last conv (a direct GEMM) and is always written.
+    const bool wino = l.n_wino > 0 && use_wino(cx, P);
+    const bool fold = wino && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0;
+    AfiBnLoad in_bn{nullptr, nullptr, nullptr, nullptr};
     for (int n = 0; n < 3; ++n) {       // Conv2d 3x3 + bias -> BN -> LeakyReLU (feature_patch_discriminator.py:35-38)
         const int ci = prm->F[n], co = prm->F[n + 1];
         float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];
@@ -1647,26 +1662,32 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
         int stats_rows = 0;
         double* stats = (double*)(ws + l.o_stats);          // (8-byte aligned: every offset of the layout is a multiple of 4 floats and ws comes from an allocator)
         const bool fuse_stats = training && afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0 && (((uintptr_t)stats) & 7) == 0;
-        if (l.n_wino > 0 && use_wino(cx, P)) {
+        if (wino) {
             AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
-                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx), fuse_stats ? stats : nullptr, &stats_rows));
+                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx), fuse_stats ? stats : nullptr, &stats_rows, in_bn.mean ? &in_bn : nullptr));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
-        const bool skip_apply = stats_only && n == 2;       // nothing reads the last block's activation
+        const bool skip_apply = (stats_only && n == 2) || (fold && n < 2);       // nothing reads the last block's activation / the next block reads c through the affine
+        const float* mean_used = mean;
         if (training && stats_rows > 0) {                   // the output transform accumulated the sums while it stored c: only the finalizer is left
             AFI_TRY(afi_launch_bn_stats_from_partials(stats, stats_rows, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], st,
                                                       prm->num_batches_tracked[n]));
-            if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
         } else if (training) {
             AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st,
                                         prm->num_batches_tracked[n], -1.f, -1.f, afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0));      // the counter ticks inside the statistics finalizer
-            if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean, invstd, prm->gamma[n], prm->beta[n], P, co, st));
         } else {
             AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
-            AFI_TRY(afi_launch_bn_apply_lrelu(c, y, prm->running_mean[n], invstd, prm->gamma[n], prm->beta[n], P, co, st));
+            mean_used = prm->running_mean[n];
         }
-        in = dense_view(y, H, W, co);
+        if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean_used, invstd, prm->gamma[n], prm->beta[n], P, co, st));
+        if (fold && n < 2) {
+            in = dense_view(c, H, W, co);
+            in_bn = AfiBnLoad{mean_used, invstd, prm->gamma[n], prm->beta[n]};
+        } else {
+            in = dense_view(y, H, W, co);
+            in_bn = AfiBnLoad{nullptr, nullptr, nullptr, nullptr};
+        }
     }
     if (!stats_only) {   // last conv 3x3 F3 -> 1 (:40-41): D9[q][t] = <y2[q], w3[t]> on the MFMA kernel (1x1, 9 columns), then the 9-tap stencil
         const int F3 = prm->F[3];
@@ -1738,8 +1759,13 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
         // full HBM pass over g_ per layer.  (Eval-mode BN has no backward here; the bias of the last conv is handled above.)
         (void)red2;
         AfiView gy = dense_view(g_, H, W, co);
-        AfiView xin = (n == 0) ? V(xv) : dense_view(ws + l.o_y[n - 1], H, W, ci);
-        if (gr->w[n] && wino) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd));
+        // (Winograd path: the forward never wrote the activations of blocks 0 and 1 -- the input transform reads block n - 1's saved conv
+        //  output through its affine + LeakyReLU, as the forward's did)
+        const bool xin_folded = wino && n > 0 && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0;
+        AfiView xin = (n == 0) ? V(xv) : dense_view(ws + (xin_folded ? l.o_c[n - 1] : l.o_y[n - 1]), H, W, ci);
+        AfiBnLoad x_bn{nullptr, nullptr, nullptr, nullptr};
+        if (xin_folded) x_bn = AfiBnLoad{ws + l.o_mean[n - 1], ws + l.o_invstd[n - 1], prm->gamma[n - 1], prm->beta[n - 1]};
+        if (gr->w[n] && wino) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd, 1, true, xin_folded ? &x_bn : nullptr));
         else if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0 && wino) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), null_view(), scratch + s.o_wino,

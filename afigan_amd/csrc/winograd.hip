@@ -16,6 +16,7 @@
 // so the result differs from the direct kernel by a few ulp of the accumulated sum (tests hold it to the same 1e-3 bar).
 #include "afi_common.h"
 #include "afi_epilogue.h"
+#include "afi_bn.h"
 
 static bool afi_epilogue_is_simple_host(const AfiPixGemm& p) {
     return p.o_up == 1 && p.beta == 0.f && !p.R1.p && !p.R2.p && !p.r2_post && p.oH >= p.H && p.oW >= p.W &&
@@ -69,8 +70,10 @@ int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hip
 
 // ---------------------------------------------------------------- input: X (view, [N][H][W][C]) -> V [16][Tpad][C]
 // thread = (tile, channel quad); the 4x4 patch starts at (2*ty - 1, 2*tx - 1), zeros outside the image
+// BN: x is read through a BatchNorm affine + LeakyReLU (AfiBnLoad, afi_bn.h) -- the input is a discriminator block's saved conv output
+template <bool BN>
 __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T,
-                                                             long long Tpad, float* __restrict__ Vout, long long ldo) {
+                                                             long long Tpad, float* __restrict__ Vout, long long ldo, const AfiBnLoad bn) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
@@ -86,6 +89,8 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
         }
         const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
         const float* base = x.p + (long long)n * x.sN + c;
+        f32x4 mu, is, ga, be;
+        if constexpr (BN) { mu = *(const f32x4*)(bn.mean + c); is = *(const f32x4*)(bn.invstd + c); ga = *(const f32x4*)(bn.gamma + c); be = *(const f32x4*)(bn.beta + c); }
         f32x4 d[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -94,7 +99,10 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
             for (int j = 0; j < 4; ++j) {
                 const int xx = 2 * tx - 1 + j;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) v = *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW);
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                    v = *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW);
+                    if constexpr (BN) v = afi_bn_lrelu(v, mu, is, ga, be, AFI_LRELU_SLOPE);
+                }
                 d[i][j] = v;
             }
         }
@@ -115,12 +123,17 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
         }
     }
 }
-int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo) {
-    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+static inline bool wino_bn_ok(const AfiBnLoad* bn) {
+    return !bn || !bn->mean || (bn->invstd && bn->gamma && bn->beta && !((((uintptr_t)bn->mean) | ((uintptr_t)bn->invstd) | ((uintptr_t)bn->gamma) | ((uintptr_t)bn->beta)) & 15));
+}
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !wino_bn_ok(bn)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino_input_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C);
+    const AfiBnLoad off{nullptr, nullptr, nullptr, nullptr};
+    if (bn && bn->mean) hipLaunchKernelGGL(afi_wino_input_kernel<true>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C, *bn);
+    else hipLaunchKernelGGL(afi_wino_input_kernel<false>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C, off);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -378,8 +391,9 @@ __device__ __forceinline__ void wino4_bt(T& d0, T& d1, T& d2, T& d3, T& d4, T& d
 }
 
 // input: X (view) -> V [36][Tpad][C]; the 6x6 patch of tile (ty, tx) starts at (4*ty - 1, 4*tx - 1)
+template <bool BN>
 __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                              float* __restrict__ Vout, long long ldo) {
+                                                              float* __restrict__ Vout, long long ldo, const AfiBnLoad bn) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
@@ -395,6 +409,8 @@ __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, i
         }
         const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
         const float* base = x.p + (long long)n * x.sN + c;
+        f32x4 mu, is, ga, be;
+        if constexpr (BN) { mu = *(const f32x4*)(bn.mean + c); is = *(const f32x4*)(bn.invstd + c); ga = *(const f32x4*)(bn.gamma + c); be = *(const f32x4*)(bn.beta + c); }
         f32x4 d[6][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -402,7 +418,12 @@ __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, i
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int xx = 4 * tx - 1 + j;
-                d[i][j] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW) : zero;
+                f32x4 v = zero;
+                if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                    v = *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW);
+                    if constexpr (BN) v = afi_bn_lrelu(v, mu, is, ga, be, AFI_LRELU_SLOPE);
+                }
+                d[i][j] = v;
             }
         }
 #pragma unroll
@@ -415,12 +436,14 @@ __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, i
         }
     }
 }
-int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo) {
-    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !wino_bn_ok(bn)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino4_input_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C);
+    const AfiBnLoad off{nullptr, nullptr, nullptr, nullptr};
+    if (bn && bn->mean) hipLaunchKernelGGL(afi_wino4_input_kernel<true>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C, *bn);
+    else hipLaunchKernelGGL(afi_wino4_input_kernel<false>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C, off);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

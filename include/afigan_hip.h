@@ -122,7 +122,13 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                * recomputes tile halos (afi_rdb_chain6_kernel): three launches per block and direction instead of five, 35 instead of 47
                                                * per config-1 forward + backward -- measured at break-even (19 us per chain launch against four links of 9 us minus the
                                                * 11 us GEMM it adds), so off by default; 2 / 3: backward / forward only (A/B) */
-#define AFI_OPT_COUNT 11
+#define AFI_OPT_D_FOLD_BN_APPLY 11            /* 0 (default): every block's BatchNorm apply + LeakyReLU pass writes its activation.  1: where the discriminator's 3x3 convs
+                                               * run in Winograd form the pass of blocks 0 and 1 is folded into the readers of the activation (the next block's input
+                                               * transform, the backward's weight-gradient input transform read the saved conv output through the affine) and the
+                                               * activation is never written (afi_discriminator_saved_activations) -- bit-identical results, one full read + write of
+                                               * the activation less per block, and measured SLOWER: the transforms re-apply the affine on every overlapping tile read
+                                               * (stage-1 step 103.7 against 103.5 ms, 113.6 against 113.2 with every kernel alone on the chip) */
+#define AFI_OPT_COUNT 12
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over
@@ -198,6 +204,16 @@ long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W);
  * workspace: off12 = { c[0..2] conv outputs [P][F(n+1)], y[0..2] activations, mean[0..2], invstd[0..2] }.  For parity tooling
  * (tests feed the reference's saved activations to the backward; feature_patch_discriminator.py:35-38) and activation checkpoints. */
 int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* off12);
+/* Which activations the forward really writes, as a bit mask (bit n: y[n]).  Under AFI_OPT_D_FOLD_BN_APPLY = 1, where the 3x3 convs run in
+ * Winograd form (maps of at least AFI_OPT_D_WINOGRAD_MIN_PIXELS pixels, AFI_OPT_WINOGRAD on), the activations of blocks 0 and 1 are NEVER
+ * written: the next block's input
+ * transform -- and the backward's weight-gradient input transforms -- read the saved conv output c[n] through the block's BatchNorm affine
+ * and LeakyReLU, y = lrelu_0.2(((c - mean) * invstd) * gamma + beta) with every operation rounded to fp32 on its own (the arithmetic the
+ * apply pass has; a reader of the workspace reproduces y[n] bit for bit from c[n], mean[n], invstd[n] and the block's gamma / beta that
+ * way: tests/d_parity_util.py).  The mask is 4 (y[2] only) there and 7 everywhere else (the default).
+ * ctx may be NULL (defaults).
+ * afi_discriminator_bwd must run under the same options as its forward. */
+int afi_discriminator_saved_activations(const afi_ctx_t* ctx, const int F[4], int N, int H, int W);
 
 /* logits[N,H,W] (dense) = Discriminators[0](x).  training != 0: batch statistics, running stats advance once,
  * num_batches_tracked += 1 (torch BatchNorm2d train mode);  training == 0: running statistics.

@@ -36,6 +36,16 @@ def fwd_ref(x, p, dt):
     return out
 
 
+def activation_from_saved(c, mean, invstd, gamma, beta, slope=0.2):
+    """A block's activation from what the forward keeps: lrelu(((c - mean) * invstd) * gamma + beta), every operation rounded to fp32 on its own
+    (csrc/afi_bn.h) -- plain fp32 tensor ops reproduce the library's value bit for bit.  c: [N, C, H, W] (any strides); the vectors [C].
+    Where the 3x3 convs run in Winograd form the library never writes the activations of blocks 0 and 1
+    (include/afigan_hip.h: afi_discriminator_saved_activations) and every reader goes through this."""
+    bc = lambda v: v.view(1, -1, 1, 1)
+    z = ((c - bc(mean)) * bc(invstd)) * bc(gamma) + bc(beta)
+    return torch.where(z > 0, z, z * slope)
+
+
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return ((a - b).abs().max() / (b.abs().max() + 1e-300)).item()
@@ -82,6 +92,7 @@ class DProbe:
                   C.c_void_p(self.ws.data_ptr()), self.nf, ops.stream_ptr())
         self.off = (C.c_longlong * 12)()
         _lib.call("afi_discriminator_ws_layout", self.Fa, N, H, W, self.off)
+        self.written = lib.afi_discriminator_saved_activations(None, self.Fa, N, H, W)      # bit n: the forward wrote y[n]
         self.P = N * H * W
 
     def ws_mat(self, o, ch):
@@ -89,9 +100,14 @@ class DProbe:
         return self.ws[o:o + self.P * ch].view(self.N, self.H, self.W, ch).permute(0, 3, 1, 2)
 
     def saved(self, n):
+        """(c, y, mean, invstd) of block n as the forward left them; y is reconstructed from the other three where the library does not write it"""
         ch = self.net.F[n + 1]
         off = self.off
-        return (self.ws_mat(off[n], ch), self.ws_mat(off[3 + n], ch), self.ws[off[6 + n]:off[6 + n] + ch], self.ws[off[9 + n]:off[9 + n] + ch])
+        c, mean, invstd = self.ws_mat(off[n], ch), self.ws[off[6 + n]:off[6 + n] + ch], self.ws[off[9 + n]:off[9 + n] + ch]
+        if self.written & (1 << n):
+            return (c, self.ws_mat(off[3 + n], ch), mean, invstd)
+        pre = f"Discriminators.0.{n}.0.norm"
+        return (c, activation_from_saved(c, mean, invstd, self.dp[pre + ".weight"].float().cuda(), self.dp[pre + ".bias"].float().cuda()), mean, invstd)
 
     def mask_flips(self):
         """(HIP vs fp64, torch-CPU fp32 vs fp64) LeakyReLU mask disagreements per layer"""
@@ -134,7 +150,8 @@ class DProbe:
                 raise AssertionError(f"layer {n}: could not make {nb} recomputed masks agree with the fp64 forward")
             nudged.append(count)
             c.copy_(c32)
-            y.copy_(self.r64["y"][n].detach().float().cuda())
+            if self.written & (1 << n):
+                y.copy_(self.r64["y"][n].detach().float().cuda())      # (elsewhere the backward reads c through the affine: the nudged c carries the reference's masks)
             mean.copy_(m32)
             invstd.copy_(i32)
         return nudged

@@ -8,9 +8,15 @@ is the heaviest layer of the step, K = 1024 -- in both the direct and the Winogr
     <conv(x), dy> == <x, dgrad(dy)> == <w, wgrad(dy, x)>  (one scalar each, accumulated in fp64).
 
 Bar: 1e-3 relative fp32 (north-star)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from d_parity_util import activation_from_saved  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -125,6 +131,7 @@ def test_stage1_step_full_size_layer_by_layer_fp64(amd):
     Fa = (C.c_int * 4)(256, 512, 1024, 1024)
     off = (C.c_longlong * 12)()
     _lib.check(_lib.load().afi_discriminator_ws_layout(Fa, N, H, W, off), "layout")
+    written = _lib.load().afi_discriminator_saved_activations(None, Fa, N, H, W)
     tr = step._buf["goutg_ws0"]                              # G(lr_p2): 2 x 256 x 208 x 336, cropped to the hr size below
     rng = np.random.default_rng(5)
     bce = 0.0
@@ -143,8 +150,11 @@ def test_stage1_step_full_size_layer_by_layer_fp64(amd):
                 for kx in range(3):
                     c64 += ap[:, ky:ky + H, kx:kx + W, :] @ wS[:, :, ky, kx].t()
             c_hip = ws[off[n]:off[n] + P * co].view(N, H, W, co)
-            y_hip = ws[off[3 + n]:off[3 + n] + P * co].view(N, H, W, co)
             mean_hip, invstd_hip = ws[off[6 + n]:off[6 + n] + co], ws[off[9 + n]:off[9 + n] + co]
+            if written & (1 << n):
+                y_hip = ws[off[3 + n]:off[3 + n] + P * co].view(N, H, W, co)
+            else:       # Winograd path: the activation is never written; its readers see the saved conv output through the affine (same fp32 arithmetic)
+                y_hip = activation_from_saved(c_hip.permute(0, 3, 1, 2), mean_hip, invstd_hip, dw[pre + ".norm.weight"].float(), dw[pre + ".norm.bias"].float()).permute(0, 2, 3, 1)
             sc = c64.abs().max().item()
             assert (c_hip[..., S].double() - c64).abs().max().item() <= 1e-4 * sc, ("conv", target, n)
             mean64 = c64.mean(dim=(0, 1, 2))
@@ -228,13 +238,22 @@ def test_discriminator_backward_full_size_sampled_fp64(amd):
     torch.cuda.synchronize()
     off = (C.c_longlong * 12)()
     _lib.check(lib.afi_discriminator_ws_layout(Fa, N, H, W, off), "layout")
+    written = lib.afi_discriminator_saved_activations(None, Fa, N, H, W)
     rng = np.random.default_rng(7)
     g_off = [0, P * F[1], P * F[1] + P * F[2]]                # DiscBwdWs: one d(conv output) buffer per block, left in place by the call
     wnames = {id(p): k for k, p in D.named_parameters()}
     for n in range(3):
         ci, co = F[n], F[n + 1]
         g_n = sc[g_off[n]:g_off[n] + P * co].view(N, H, W, co)
-        a_in = x.permute(0, 2, 3, 1) if n == 0 else ws[off[3 + n - 1]:off[3 + n - 1] + P * ci].view(N, H, W, ci)
+        if n == 0:
+            a_in = x.permute(0, 2, 3, 1)
+        elif written & (1 << (n - 1)):
+            a_in = ws[off[3 + n - 1]:off[3 + n - 1] + P * ci].view(N, H, W, ci)
+        else:       # (the backward's input transform read block n - 1's conv output through its affine: so does this check)
+            pre_ = f"Discriminators.0.{n - 1}.0.norm"
+            byname = {wnames[id(p)]: p for p in params}
+            a_in = activation_from_saved(ws[off[n - 1]:off[n - 1] + P * ci].view(N, H, W, ci).permute(0, 3, 1, 2), ws[off[6 + n - 1]:off[6 + n - 1] + ci],
+                                         ws[off[9 + n - 1]:off[9 + n - 1] + ci], byname[pre_ + ".weight"].detach().float(), byname[pre_ + ".bias"].detach().float()).permute(0, 2, 3, 1)
         wparam = [p for p in params if wnames[id(p)] == f"Discriminators.0.{n}.0.weight"][0]
         dW = grads[[id(p) for p in params].index(id(wparam))]                 # logical [co, ci, 3, 3]
         scale = dW.double().abs().max().item()

@@ -511,3 +511,47 @@ def test_generator_chain_kernel_schedule_matches_the_per_link_schedule(amd):
     for mode in (1, 2, 3):
         for i, (a, b) in enumerate(zip(res[mode], res[0])):
             assert _rel(a, b) < 2e-5, (mode, i)
+
+
+def test_discriminator_bn_apply_folded_into_its_readers_is_the_same_network(amd):
+    """Option d_fold_bn_apply (off by default: measured slower, include/afigan_hip.h): under the Winograd path the BatchNorm apply + LeakyReLU of
+    blocks 0 and 1 is evaluated by the READERS of the activation (the next block's input transform, the backward's weight-gradient input
+    transform) on the saved conv output, with the arithmetic of the apply pass -- the activation is never written
+    (feature_patch_discriminator.py:35-38).  Logits and the input gradient must come out bit for bit, parameter gradients to the run-to-run
+    spread of the split-K atomics; the workspace query reports which activations exist."""
+    import ctypes as C
+    from afigan_amd import _lib, ops
+    lib = _lib.load()
+    N, H, W = 1, 32, 40                                     # 1280 pixels: Winograd form
+    torch.manual_seed(3)
+    D = amd.Discriminator(in_filters=256).cuda()
+    D.train()
+    net = D.Discriminators[0]
+    x = ops.pixel_major(torch.randn(N, 256, H, W).cuda())
+    dl = torch.randn(N * H * W, device="cuda")
+    params = net._ordered_params()
+    Fa = (C.c_int * 4)(*net.F)
+    nf, nb = lib.afi_discriminator_fwd_ws_floats(Fa, N, H, W), lib.afi_discriminator_bwd_ws_floats(Fa, N, H, W)
+    res = {}
+    for flag in (0, 1):
+        cx = _lib.Ctx()
+        cx.set_option("d_fold_bn_apply", flag)
+        assert lib.afi_discriminator_saved_activations(cx.handle, Fa, N, H, W) == (4 if flag else 7)
+        with _lib.use_ctx(cx):
+            prm, keep = net._param_struct(params)
+            grads = [torch.zeros_like(t) for t in keep]
+            gst, _k2 = net._param_struct(grads, already_packed=True, grads=True)
+            ws, sc = torch.full((nf,), float("nan"), device="cuda"), torch.zeros(nb, device="cuda")
+            logits = torch.empty(N * H * W, device="cuda")
+            dx = ops.new_pixel_major(N, 256, H, W, "cuda")
+            st = ops.stream_ptr()
+            _lib.call("afi_discriminator_fwd", C.byref(prm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), 1, C.c_void_p(ws.data_ptr()), nf, st)
+            _lib.call("afi_discriminator_bwd", C.byref(prm), C.byref(gst), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()), C.c_void_p(dl.data_ptr()),
+                      C.c_void_p(dx.data_ptr()), C.c_void_p(sc.data_ptr()), nb, st)
+            torch.cuda.synchronize()
+        res[flag] = (logits.clone(), dx.clone(), [g.clone() for g in grads])
+    assert lib.afi_discriminator_saved_activations(None, Fa, N, H, W) == 7
+    assert torch.equal(res[0][0], res[1][0]), "logits"
+    assert torch.equal(res[0][1], res[1][1]), "input gradient"
+    for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
+        assert _rel(a, b) < 2e-5, i
