@@ -58,6 +58,31 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(h32.data(), o32, h32.size() * 4, hipMemcpyDeviceToHost));
     double md = 0, mx = 0;
     for (size_t i = 0; i < h6.size(); ++i) { md = fmax(md, fabs((double)h6[i] - h32[i])); mx = fmax(mx, fabs((double)h32[i])); }
+    // in-kernel stamps of the 32 x 32 form (DIAG build of the kernel: s_memtime at the phase boundaries, s_memrealtime at both ends)
+    {
+        AfiWkArgs wk;
+        if (wk_prepare(g6, false, wk) == AFI_OK && wk6_ok(g6, wk)) {
+            const int G = wk.ntile_m * wk.ntile_n;
+            unsigned long long* dbg;
+            CK(hipMalloc(&dbg, (size_t)G * 10 * 8)); CK(hipMemset(dbg, 0, (size_t)G * 10 * 8));
+            wk.dbg = dbg;
+            for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((afi_pix_gemm_wk6_kernel<true>), dim3((unsigned)G), dim3(512), sizeof(float) * 8 * 32 * (AFI_BK + 4), st, g6, wk);
+            CK(hipStreamSynchronize(st));
+            std::vector<unsigned long long> hd((size_t)G * 10);
+            CK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
+            double ph[6] = {0, 0, 0, 0, 0, 0}, span = 0; unsigned long long t0min = ~0ull, t1max = 0;
+            for (int b = 0; b < G; ++b) {
+                const unsigned long long* d = &hd[(size_t)b * 10];
+                const int idx[7] = {0, 1, 2, 3, 4, 5, 8};
+                for (int i = 0; i < 6; ++i) ph[i] += (double)(d[idx[i + 1]] - d[idx[i]]);
+                span += (double)(d[7] - d[6]);
+                if (d[6] < t0min) t0min = d[6];
+                if (d[7] > t1max) t1max = d[7];
+            }
+            printf("stamps (32 x 32 form, %d blocks, mean per block, shader cycles): setup %.0f | first gather issued %.0f | prologue (first stage staged, second requested, first weights requested) %.0f | K loop %.0f | reduce + epilogue %.0f | tail %.0f || block span %.2f us, first start to last end %.2f us\n",
+                   G, ph[0] / G, ph[1] / G, ph[2] / G, ph[3] / G, ph[4] / G, ph[5] / G, span / G * 0.01, (double)(t1max - t0min) * 0.01);
+        }
+    }
     const double fl = 2.0 * P * Ncols * 9.0 * Ck;
     printf("ablate %d  M %d N %d K %d rc %d | image build %.1f us | fp32 wk %.1f us (%.1f TF/s) | wk6 %.1f us (%.1f TF/s) | max diff %.3g of %.3g\n", AFI_WK6_ABLATE, P, Ncols,
            9 * Ck, rc, t_img, t32, fl / t32 * 1e-6, t6, fl / t6 * 1e-6, md, mx);
