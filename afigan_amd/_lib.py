@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFI_LIB_PATH") or os.path.join(_HERE, "csrc", "libafigan_hip.so")   # override: A/B kernel builds
 
 AFI_MAX_RDB = 8
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class AfiError(RuntimeError):
@@ -65,7 +65,8 @@ SIGNATURES = {
     "afi_ctx_get_option": (_ll, [_vp, _i]),
     "afi_gemm_nt_scratch_bytes": (_ll, [_i, _i, _i, _i]),
     "afi_gemm_nt": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _ll, _vp]),
-    "afi_gemm_tn": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp]),
+    "afi_gemm_tn_scratch_bytes": (_ll, [_i, _i]),
+    "afi_gemm_tn": (_i, [_vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _ll, _vp]),
     "afi_ctx_set_wino_weight_cache": (_i, [_vp, _vp, _ll]),
     "afi_ctx_wino_weight_cache_invalidate": (_i, [_vp]),
     "afi_ctx_set_wino_wgrad_accum": (_i, [_vp, _vp, _ll]),
@@ -176,7 +177,7 @@ CTX_FIRST = frozenset(n for n, (_, a) in SIGNATURES.items() if n.startswith(("af
                       and not n.endswith(("_ws_floats", "_ws_layout", "pack_weight", "unpack_wgrad")))
 
 
-DTYPES = {"fp32": 0, "bf16": 1, "bf16x3": 3, "bf16x6": 6}             # AFI_DTYPE_* of include/afigan_hip.h
+DTYPES = {"fp32": 0, "bf16": 1, "f16x3": 2, "bf16x3": 3, "bf16x6": 6}             # AFI_DTYPE_* of include/afigan_hip.h
 OPTIONS = {"winograd": 0, "winograd_f4_backward": 1, "winograd_f4_forward": 2, "bn_stats_fp64": 3, "d_winograd_min_pixels": 4,
            "g_winograd_min_pixels": 5, "g_smallmap_max_pixels": 6, "g_grouped_wgrad_max_pixels": 7, "g_batch_growth_grads": 8,
            "g_smallmap6_max_pixels": 9, "g_rdb_chain": 10, "d_fold_bn_apply": 11}      # AFI_OPT_*

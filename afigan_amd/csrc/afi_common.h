@@ -13,6 +13,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define AFI_ERR_BAD_ARG 1
 #define AFI_ERR_UNSUPPORTED 2
 #define AFI_ERR_LAUNCH 3
+#ifndef AFI_TRY
+#define AFI_TRY(expr) do { int _s = (expr); if (_s != AFI_OK) return _s; } while (0)
+#endif
 
 // A pixel-major ("NHWC") tensor view: element (n, y, x, c) lives at p[n*sN + y*sH + x*sW + c].
 // Strides are in elements; the channel stride is always 1.  Cropped views (stage-1 _reshape_stage1)
@@ -128,6 +131,11 @@ struct AfiWgradGemm {
     float alpha;
     int splitK;
 };
+
+// f16x3 arithmetic of the batched Winograd GEMMs (afi_gemm_f16.h): where an operand's power-of-two scale comes from.  amax[plane * stride]
+// (device memory, written by the kernel that produced the operand) times cmul[plane] bounds the plane's largest magnitude.  stride = 0: one
+// value for all planes (the largest magnitude of the tensor the planes are a transform of).
+struct AfiF16Bound { const float* amax; int stride; int pad_; float cmul[36]; };
 
 // one bias-gradient problem of afi_launch_colsum_group: db[c] += alpha * sum_rows g[row*ld + c], c < C
 struct AfiColsumProb { const float* g; float* db; long long P, ld; int C; float alpha; };

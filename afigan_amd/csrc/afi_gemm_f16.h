@@ -1,0 +1,401 @@
+// "f16x3": the two batched Winograd GEMMs with each fp32 operand split into TWO fp16 pieces and three products (included by igemm.hip
+// after afi_gemm_bf16.h).
+//
+//   x' = x * s                    s a power of two chosen per operand and Winograd plane so that |x'| < 2^15 (fp16's largest finite value
+//                                 is 65504); the multiplication is exact
+//   hi = f16(x'), lo = f16(x' - hi)     round to nearest; the residual is exact in fp32 and has at most 13 significant bits, of which lo
+//                                 keeps 11: |x' - hi - lo| <= 2^-23 |x'| wherever lo is a normal fp16 number, <= 2^-25 absolute below
+//   a.b ~ (lo_a.hi_b + hi_a.lo_b + hi_a.hi_b) / (s_a s_b)      three v_mfma_f32_*_f16 into one fp32 accumulator, smallest terms first;
+//                                 fp16 x fp16 products are exact in the accumulator's fp32; the dropped lo.lo term is <= 2^-22 of the
+//                                 product (random sign, rms 2^-23.6: below the accumulator's own rounding of a sum of such products)
+//
+// against bf16x6 (afi_gemm_bf16.h: three bf16 pieces, six products): half the matrix-core work, two thirds of the split's vector work,
+// two thirds of the pre-split weight bytes.  What bf16 had for free and fp16 does not is RANGE: an fp16 piece is normal only between
+// 2^-14 and 2^16, so the operand is scaled first.  The scale needs the operand's largest magnitude, which is not known when its tiles
+// stream by, so it comes from an upper BOUND that is known before the GEMM starts:
+//   * activations (A of the NT GEMM; both operands of the TN GEMM) are Winograd transforms of a tensor whose largest magnitude `amax` the
+//     transform kernel computes as a by-product of the loads it does anyway (one atomic max per block, winograd.hip); every plane a of
+//     the transform satisfies |V[a]| <= c_a amax with c_a the product of the absolute row sums of the transform matrix (F(2x2): 4;
+//     F(4x4): 36 .. 100; the dY transforms: <= 1), and s_a = 2^(14 - floor(log2(c_a amax))).  A bound that is loose by a factor L costs
+//     log2(L) binades of the range below the largest element, never precision of the elements that matter: lo stays a normal number for
+//     every element within 2^-18 / L of the bound, and below that the ABSOLUTE error of an element is 2^-25 / s = 2^-40 L of the bound --
+//     fp32's own rounding of the plane's large elements is 2^-24 of them.
+//   * weights (B of the NT GEMM) are split once per weight transform by afi_split_f16_tiles_kernel with the exact per-plane maximum.
+// The accumulators hold s_a s_b C; the epilogue multiplies by 1 / s_a and 1 / s_b (exact; two steps so that neither factor leaves
+// fp32's range).
+#pragma once
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// (AfiF16Bound: afi_common.h)
+
+// the power of two s with bound * s in [2^14, 2^15) (bound > 0, finite); bounds below 2^-100 (and zero) take s = 2^114
+__device__ __forceinline__ float afi_f16_scale(float bound) {
+    unsigned e = (__float_as_uint(bound) >> 23) & 0xffu;
+    e = e < 27u ? 27u : e;
+    return __uint_as_float((268u - e) << 23);
+}
+__device__ __forceinline__ float afi_pow2_inverse(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }   // s a normal power of two
+
+// a pair of values and their (power-of-two) scale -> packed fp16 pieces of x * s (x0 in the low half).  The residual is formed by one
+// fused multiply-add per element straight from the packed hi (v_fma_mix_f32 reads either half of it as an fp16 source): x * s is exact,
+// so fma(x, s, -hi) is the same number as (x * s) - hi
+__device__ __forceinline__ void afi_split2_f16_pair(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
+    // four instructions per pair (left to itself hipcc forms hi twice, packed and per element: seven): v_fma_mixlo/hi_f16 round
+    // fma(f32, f32, f16-or-f32) to fp16 into the low / high half of the destination and keep the other half
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+    hi = h; lo = l;
+}
+// eight values (two float4) -> the hi and lo MFMA operands / 16-byte LDS rows
+__device__ __forceinline__ void afi_split2_f16_x8(f32x4 v0, f32x4 v1, float s, u32x4& h, u32x4& l) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    afi_split2_f16_pair(v0[0], v0[1], s, h0, l0);
+    afi_split2_f16_pair(v0[2], v0[3], s, h1, l1);
+    afi_split2_f16_pair(v1[0], v1[1], s, h2, l2);
+    afi_split2_f16_pair(v1[2], v1[3], s, h3, l3);
+    h = u32x4{h0, h1, h2, h3};
+    l = u32x4{l0, l1, l2, l3};
+}
+__device__ __forceinline__ f16x8 afi_tr_frag_f16(const unsigned char* base, int off_lo, int off_hi) {
+    return __builtin_bit_cast(f16x8, afi_tr_frag(base, off_lo, off_hi));
+}
+
+// ------------------------------------------------------------------------------------------------
+// largest magnitude per plane of X [planes][per_plane] (per_plane a multiple of 4), as the bit pattern of a non-negative float under an
+// unsigned atomic max (monotonic): out[plane] must be zero-filled before the launch.  grid = (blocks per plane, planes).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float afi_wave_max(float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
+}
+// every thread brings its own maximum; thread 0 publishes the block's, and only if it can still raise the slot (a relaxed device-scope
+// read first: after the first blocks most of a launch's blocks add nothing, and thousands of atomics on ONE word would serialise at the
+// memory side, ~12 ns each)
+__device__ __forceinline__ void afi_block_amax_publish(float m, float* slot) {
+    __shared__ float red[16];
+    m = afi_wave_max(m);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
+        const unsigned bits = __float_as_uint(m);
+        const unsigned cur = __hip_atomic_load((const unsigned*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (bits > cur) (void)atomicMax((unsigned*)slot, bits);
+    }
+}
+__global__ __launch_bounds__(256) void afi_absmax_planes_kernel(const float* __restrict__ X, long long per_plane, float* __restrict__ out) {
+    const float* x = X + (long long)blockIdx.y * per_plane;
+    const long long n4 = per_plane >> 2;
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(x + 4 * i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    afi_block_amax_publish(m, out + blockIdx.y);
+}
+
+// ------------------------------------------------------------------------------------------------
+// B[plane][n][k] fp32 -> [header: the plane scales s_b][fp16 pieces in the LDS-image order of the NT kernel below]:
+// [plane][N / 128][K / 32][hi | lo][128 rows x 64 bytes], 16-byte chunk ch of row r at ch ^ ((-(r >> 2)) & 3) (afi_bf16_tile16_off).
+// bmax[plane]: the plane's largest magnitude (afi_absmax_planes_kernel).  One thread per float4.
+// ------------------------------------------------------------------------------------------------
+#define AFI_F16_HDR_BYTES 512                               // floats [0, 64): the plane scales; [64, 128): the plane maxima they were made from
+template <int BN>
+__global__ __launch_bounds__(256) void afi_split_f16_tiles_kernel(const float* __restrict__ B, unsigned char* __restrict__ out, const float* __restrict__ bmax,
+                                                                  int planes, int N, int K) {
+    constexpr int TILE_B = BN * 64;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int kq4 = K / 4;
+    const long long total = (long long)planes * N * kq4;
+    if (i >= total) return;
+    const int kq = (int)(i % kq4);
+    const long long rowg = i / kq4;                         // plane * N + n
+    const int n = (int)(rowg % N), plane = (int)(rowg / N);
+    const float s = afi_f16_scale(bmax[plane]);
+    if (n == 0 && kq == 0) ((float*)out)[plane] = s;
+    const f32x4 v = *(const f32x4*)(B + rowg * K + 4 * kq);
+    const int tile_n = n / BN, row = n - tile_n * BN, kc = kq >> 3;
+    unsigned char* img = out + AFI_F16_HDR_BYTES + ((((long long)plane * (N / BN) + tile_n) * (K / 32)) + kc) * (long long)(2 * TILE_B);
+    const int off = afi_bf16_tile16_off(row, kq & 7);
+    unsigned h0, h1, l0, l1;
+    afi_split2_f16_pair(v[0], v[1], s, h0, l0);
+    afi_split2_f16_pair(v[2], v[3], s, h1, l1);
+    *(u32x2*)(img + off) = u32x2{h0, h1};
+    *(u32x2*)(img + TILE_B + off) = u32x2{l0, l1};
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT GEMM  C[g][m][n] = sum_k A[g][m][k] B[g][n][k]: the structure of afi_gemm_nt_bf16_dma_kernel (afi_gemm_bf16.h: both operands staged by
+// LDS-DMA, A verbatim as fp32 with the swizzle on the source address and split when a wave reads its fragment, B pre-split in LDS-image
+// order; v_mfma_f32_16x16x32, four blocks per CU, one stage buffer and two barriers per stage) with two fp16 pieces: a 32 KB stage
+// (16 A + 2 x 8 B), 48 MFMAs per wave and stage instead of 96, the scale in the split and its inverse in the epilogue.
+// ------------------------------------------------------------------------------------------------
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void afi_gemm_nt_f16x3_kernel(const AfiGemmNT p, const AfiF16Bound ab, int ntile_n, int ntile_m, int chunk) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int MI = 2, NI = 8;                            // 4 x 1 waves of 32 x 128: a wave's A rows are its own
+    constexpr int TILE_A = BM * 128;                         // fp32 image, 16 KB
+    constexpr int TILE_B = BN * 64;                          // one fp16 image, 8 KB
+    constexpr int OFF_B = TILE_A;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile_n = jb % ntile_n, tile_m = xcd * chunk + jb / ntile_n;
+    if (tile_m >= ntile_m) return;
+    const long long m0 = (long long)tile_m * BM;
+    const int n0 = tile_n * BN;
+    const int plane = (int)(m0 / p.rows_per_plane);
+    const int nK = p.K / BK;
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    const int a_row0 = 8 * wave + (lane >> 3);
+    const int a_swz = ((lane >> 4) & 1) | ((wave & 1) << 2);                    // ((row >> 1) & 5) of every row this lane fills
+    const float* a_src = p.A + (m0 + a_row0) * p.K + 4 * ((lane & 7) ^ a_swz);
+    const long long a_step = 32LL * p.K;                     // 32 rows per DMA instruction
+    const unsigned char* b_hdr = (const unsigned char*)p.B;
+    const unsigned char* b_src = b_hdr + AFI_F16_HDR_BYTES + (((long long)plane * ntile_n + tile_n) * nK) * (long long)(2 * TILE_B) + 16 * tid;
+    auto issue = [&](int kc) {
+        unsigned char* dst = smem_b;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr)(a_src + i * a_step + kc * BK), (lptr)(dst + (4 * i + wave) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr)(b_src + (long long)kc * (2 * TILE_B) + i * 4096), (lptr)(dst + OFF_B + (4 * i + wave) * 1024), 16, 0, 0);
+    };
+    issue(0);
+    // the plane's scales (block-uniform: scalar loads, under the first stage's flight)
+    const float s_a = afi_f16_scale(ab.amax[(long long)plane * ab.stride] * ab.cmul[plane]);
+    const float inv_a = afi_pow2_inverse(s_a), inv_b = afi_pow2_inverse(((const float*)b_hdr)[plane]);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int fa_off[MI], fb_off[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { const int row = (wave * MI + mi) * 16 + l15; fa_off[mi] = row * 128 + (((2 * lq) ^ ((row >> 1) & 5)) << 4); }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { const int row = ni * 16 + l15; fb_off[ni] = OFF_B + row * 64 + (((lq ^ (-(row >> 2))) & 3) << 4); }
+    auto mfma = [](f16x8 x, f16x8 y, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0); };
+
+    for (int kc = 0; kc < nK; ++kc) {
+        // the stage has landed: this wave's DMA by the explicit wait, the other waves' by the barrier behind it.  (Nothing else orders a
+        // ds_read behind a pending LDS-DMA; hipcc puts this wait in front of the barrier of afi_gemm_nt_bf16_dma_kernel by itself and did
+        // NOT in this kernel -- every stage after the first was read while it was still arriving.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned char* sm = smem_b;
+        f16x8 ah[MI], al[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const f32x4 c0 = *(const f32x4*)(sm + fa_off[mi]);
+            const f32x4 c1 = *(const f32x4*)(sm + (fa_off[mi] ^ 16));
+            u32x4 h, l;
+            afi_split2_f16_x8(c0, c1, s_a, h, l);
+            ah[mi] = __builtin_bit_cast(f16x8, h);
+            al[mi] = __builtin_bit_cast(f16x8, l);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const f16x8 bh = *(const f16x8*)(sm + fb_off[ni]);
+            const f16x8 bl = *(const f16x8*)(sm + TILE_B + fb_off[ni]);
+            // smallest terms first; consecutive MFMAs go to different accumulators
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
+        }
+        __syncthreads();
+        if (kc + 1 < nK) issue(kc + 1);                      // the buffer is free again
+    }
+    // epilogue: accumulators / (s_a s_b) -> LDS -> float4 rows of C, 16 rows of every wave per pass
+    constexpr int LDC = BN + 4, C_F4 = BN / 4;
+    float* Cs = (float*)smem_b;
+    float* c_base = p.C + m0 * p.N + n0;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(wave * 16 + lq * 4 + r) * LDC + ni * 16 + l15] = (acc[mi][ni][r] * inv_a) * inv_b;
+        __syncthreads();
+        for (int item = tid; item < 4 * 16 * C_F4; item += 256) {
+            const int rloc = item / C_F4, c4 = item - rloc * C_F4;
+            const int rl = (rloc >> 4) * 32 + mi * 16 + (rloc & 15);
+            __builtin_nontemporal_store(*(const f32x4*)(Cs + rloc * LDC + 4 * c4), (f32x4*)(c_base + (long long)rl * p.N + 4 * c4));
+        }
+        if (mi + 1 < MI) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN (weight-gradient) GEMM  dU[g][m][n] += sum_k Q[g][k][m] V[g][k][n]: the in-wave pipeline of afi_gemm_tn_bf16x6_pipe_kernel (half stages
+// of 16 k rows, two LDS buffers, one barrier per half stage, a wave splits half stage h + 1 and requests h + 3 beside its own MFMAs of
+// h; [16 k][128 columns] 16-bit images read transposed with ds_read_b64_tr_b16) with two fp16 pieces per operand: 16 KB per buffer
+// ([Q hi | Q lo | V hi | V lo]), 12 MFMAs (32x32x16) per wave and half stage instead of 24.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_kernel(const AfiGemmTN p, const AfiF16Bound qb, const AfiF16Bound vb, int ntile_m, int ntile_n, int kper) {
+    constexpr int BM = 128, BN = 128, HK = 16, WN = 2, MI = 2, NI = 2;
+    constexpr int PART = HK * BM * 2;                        // 4 KB: [16 k][128 columns] fp16
+    constexpr int BUF = 4 * PART;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    int t;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tile_n = t % ntile_n; t /= ntile_n;
+    const int tile_m = t % ntile_m; const int plane = t / ntile_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long long k_begin = (long long)blockIdx.y * kper;
+    const long long k_end = (k_begin + kper < p.rows_per_plane) ? k_begin + kper : p.rows_per_plane;
+    if (k_begin >= k_end) return;                            // (whole block: EXEC stays full for the transposed reads below)
+    const int nH = (int)((k_end - k_begin) / HK);           // (the launcher keeps every K range a multiple of 32 rows)
+    const int c8 = tid & 15, kr = tid >> 4;
+    const float* a_ptr = p.Q + ((long long)plane * p.rows_per_plane + k_begin + kr) * p.M + m0 + 8 * c8;
+    const float* b_ptr = p.V + ((long long)plane * p.rows_per_plane + k_begin + kr) * p.N + n0 + 8 * c8;
+    const long long a_step = (long long)HK * p.M, b_step = (long long)HK * p.N;
+
+    f32x4 a_reg[2][2], b_reg[2][2];                          // [set: parity of the half stage][half of the 8-column group]
+    auto prefetch = [&](auto SET, bool more) {
+        constexpr int S = decltype(SET)::value;
+        if (more) {                                          // (uniform; the last two requests of a range are not made)
+            a_reg[S][0] = *(const f32x4*)a_ptr; a_reg[S][1] = *(const f32x4*)(a_ptr + 4);
+            b_reg[S][0] = *(const f32x4*)b_ptr; b_reg[S][1] = *(const f32x4*)(b_ptr + 4);
+        }
+        a_ptr += a_step; b_ptr += b_step;
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, 1> S1;
+    prefetch(S0(), true);                                    // half stage 0
+    prefetch(S1(), 1 < nH);                                  // half stage 1
+    const float s_q = afi_f16_scale(qb.amax[(long long)plane * qb.stride] * qb.cmul[plane]);
+    const float s_v = afi_f16_scale(vb.amax[(long long)plane * vb.stride] * vb.cmul[plane]);
+    const float inv_q = afi_pow2_inverse(s_q), inv_v = afi_pow2_inverse(s_v);
+    const int st_off = 256 * kr + 16 * (c8 ^ (((kr & 3) << 2) | ((kr >> 2) & 3)));
+    auto split_store = [&](auto SET, unsigned char* buf) {
+        constexpr int S = decltype(SET)::value;
+#pragma unroll
+        for (int op = 0; op < 2; ++op) {                     // Q, then V
+            const float s = op ? s_v : s_q;
+            const f32x4 v0 = op ? b_reg[S][0] : a_reg[S][0], v1 = op ? b_reg[S][1] : a_reg[S][1];
+            unsigned char* base = buf + op * 2 * PART + st_off;
+            u32x4 h, l;
+            afi_split2_f16_x8(v0, v1, s, h, l);
+            *(u32x4*)base = h; *(u32x4*)(base + PART) = l;
+        }
+    };
+    int fa_off[MI][2], fb_off[NI][2];
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int r = 8 * (g >> 1) + 4 * rd + q;
+            const int swz = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa_off[mi][rd] = 256 * r + 16 * ((4 * (wm * MI + mi) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = 2 * PART + 256 * r + 16 * ((4 * (wn * NI + ni) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+        }
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    auto mm = [](f16x8 x, f16x8 y, f32x16 c) -> f32x16 { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); };
+
+    split_store(S0(), smem_b);
+    prefetch(S0(), 2 < nH);                                  // half stage 2
+    __syncthreads();
+    auto half_stage = [&](auto NEXT, int h) {                // NEXT: the register set of half stage h + 1
+        const unsigned char* cur = smem_b + (h & 1) * BUF;
+        unsigned char* nxt = smem_b + ((h + 1) & 1) * BUF;
+        f16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            ah[mi] = afi_tr_frag_f16(cur, fa_off[mi][0], fa_off[mi][1]);
+            al[mi] = afi_tr_frag_f16(cur + PART, fa_off[mi][0], fa_off[mi][1]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            bh[ni] = afi_tr_frag_f16(cur, fb_off[ni][0], fb_off[ni][1]);
+            bl[ni] = afi_tr_frag_f16(cur + PART, fb_off[ni][0], fb_off[ni][1]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(al[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bl[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bh[ni], acc[mi][ni]);
+        if (h + 1 < nH) split_store(NEXT, nxt);              // (uniform) every wave left that buffer at the last barrier
+        prefetch(NEXT, h + 3 < nH);
+        // the scheduler's pipeline hint: one MFMA, then a share of the split's vector work
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+        }
+        __syncthreads();
+    };
+    for (int h = 0; h < nH; h += 2) {
+        half_stage(S1(), h);
+        if (h + 1 < nH) half_stage(S0(), h + 1);             // (uniform)
+    }
+    const bool use_atomic = gridDim.y > 1;
+    float* out = p.dU + (long long)plane * p.M * p.N;
+    const long long ldn = p.N;
+    if (use_atomic) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(out + (long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr),
+                                                            (acc[mi][ni][r] * inv_q) * inv_v);
+                }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float old[NI][16];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    old[ni][r] = out[(long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr];
+                }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    out[(long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr] = old[ni][r] + (acc[mi][ni][r] * inv_q) * inv_v;
+                }
+        }
+    }
+}

@@ -637,8 +637,10 @@ const char* kKindNames[] = {
     "gemm_nt_bf16<128x128> (batched Winograd GEMM on the bf16 MFMA: bf16x6 / bf16x3 / bf16 operands, fp32 accumulate)",
     "gemm_tn_bf16<128x128> (Winograd weight-gradient GEMM on the bf16 MFMA: bf16x6 / bf16x3 / bf16 operands, fp32 accumulate)",
     "wgrad_group6 (grouped weight gradients of a small-map backward pass on the bf16 MFMA, bf16x6 operands, fp32 accumulate)",
-    "pix_gemm_wk6 (small-map pixel GEMM on the bf16 MFMA, bf16x6 operands on pre-split weight images, fp32 accumulate; grouped launches included)"};   // one kind per kernel, as rocprofv3 lists them
-constexpr int kNumKinds = 21;
+    "pix_gemm_wk6 (small-map pixel GEMM on the bf16 MFMA, bf16x6 operands on pre-split weight images, fp32 accumulate; grouped launches included)",
+    "gemm_nt_f16x3<128x128> (batched Winograd GEMM on the f16 MFMA: two scaled fp16 pieces per operand, three products, fp32 accumulate)",
+    "gemm_tn_f16x3<128x128> (Winograd weight-gradient GEMM on the f16 MFMA: two scaled fp16 pieces per operand, three products, fp32 accumulate)"};   // one kind per kernel, as rocprofv3 lists them
+constexpr int kNumKinds = 23;
 hipEvent_t prof_event() {
     if (g_prof.used == g_prof.pool.size()) {
         hipEvent_t e;
@@ -814,6 +816,88 @@ int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, in
     if (split == 6) hipLaunchKernelGGL((afi_gemm_nt_bf16_dma_kernel<6, 4>), grid, blk, lds, st, g, ntn, ntm, chunk);
     else if (split == 3) hipLaunchKernelGGL((afi_gemm_nt_bf16_dma_kernel<3, 4>), grid, blk, lds, st, g, ntn, ntm, chunk);
     else hipLaunchKernelGGL((afi_gemm_nt_bf16_dma_kernel<1, 4>), grid, blk, lds, st, g, ntn, ntm, chunk);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
+// ---- f16x3 (afi_gemm_f16.h): two fp16 pieces per operand, three MFMAs per k-step, power-of-two scales per operand and plane
+#include "afi_gemm_f16.h"
+// per-plane maxima of X [planes][per_plane] into out[planes]; `out` must already be zero (the launch only raises it)
+int afi_launch_absmax_planes(const float* X, long long per_plane, int planes, float* out, hipStream_t st) {
+    if (!X || !out || planes <= 0 || per_plane <= 0 || (per_plane & 3)) return AFI_ERR_BAD_ARG;
+    long long g = (per_plane / 4 + 255) / 256;
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(afi_absmax_planes_kernel, dim3((unsigned)g, planes), dim3(256), 0, st, X, per_plane, out);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// B (transformed weights) [planes][N][K] fp32 -> header (scales, maxima) + fp16 pieces in the NT kernel's LDS-image order: three launches
+// (zero the header, per-plane maxima, split), once per weight transform
+long long afi_f16_image_bytes(int planes, int N, int K) { return AFI_F16_HDR_BYTES + (long long)planes * N * K * 4; }
+int afi_launch_split_f16_tiles(const float* B, void* out, int planes, int N, int K, hipStream_t st) {
+    if (!B || !out || planes <= 0 || planes > 36 || (N % 128) || (K % 32)) return AFI_ERR_BAD_ARG;
+    if (hipMemsetAsync(out, 0, AFI_F16_HDR_BYTES, st) != hipSuccess) return AFI_ERR_LAUNCH;
+    float* bmax = (float*)out + 64;
+    AFI_TRY(afi_launch_absmax_planes(B, (long long)N * K, planes, bmax, st));
+    const long long total = (long long)planes * N * (K / 4);
+    hipLaunchKernelGGL((afi_split_f16_tiles_kernel<128>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, (unsigned char*)out, (const float*)bmax, planes, N, K);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// the bounds of the Winograd transforms' planes relative to the largest magnitude of the tensor they transform (afi_gemm_f16.h): the
+// product of the absolute row sums of the transform matrix.  kind: 0 exact per-plane maxima (stride 1, factor 1), 1 F(2x2) input
+// (B^T d B), 2 F(4x4) input, 3 F(2x2) dY (G' e G'^T), 4 F(4x4) dY
+AfiF16Bound afi_f16_bound(const float* amax, int kind) {
+    AfiF16Bound b;
+    b.amax = amax; b.stride = kind == 0 ? 1 : 0; b.pad_ = 0;
+    static const float r_in4[6] = {10.f, 10.f, 10.f, 6.f, 6.f, 10.f};
+    static const float r_dy4[6] = {0.25f, 4.f / 6.f, 4.f / 6.f, 15.f / 24.f, 15.f / 24.f, 1.f};
+    for (int a = 0; a < 36; ++a) {
+        float c = 1.f;
+        if (kind == 1) c = 4.f;
+        else if (kind == 2) c = r_in4[a / 6] * r_in4[a % 6];
+        else if (kind == 4) c = r_dy4[a / 6] * r_dy4[a % 6];
+        b.cmul[a] = c;
+    }
+    return b;
+}
+int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st) {
+    if (planes <= 0 || planes > 36 || rows_per_plane <= 0 || N <= 0 || K <= 0 || !ab.amax) return AFI_ERR_BAD_ARG;
+    if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
+    AfiGemmNT g{A, (const float*)Bimg, C, rows_per_plane, planes, N, K};
+    const long long M = rows_per_plane * planes;
+    const int ntm = (int)(M / 128), ntn = N / 128, chunk = afi_cdiv(ntm, 8);
+    const size_t stage = 16384u + 2u * 8192u, epi = sizeof(float) * 64u * (128u + 4u);
+    const size_t lds = stage > epi ? stage : epi;
+    ProfScope prof(st, 21, 2.0 * (double)M * N * K);
+    prof.m = M; prof.n = N; prof.k = K; prof.split = 2; prof.planes = planes;
+    hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
+                             hipStream_t st) {
+    if (planes <= 0 || planes > 36 || rows_per_plane <= 0 || M <= 0 || N <= 0 || !qb.amax || !vb.amax) return AFI_ERR_BAD_ARG;
+    if ((rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
+    const int ntm = M / 128, ntn = N / 128;
+    const long long tiles = (long long)ntm * ntn * planes;
+    const int slots = 768;                                 // three resident blocks per CU (two 16 KB buffers, <= 168 registers)
+    int splitK = 1;
+    {
+        const int maxsplit = (int)(rows_per_plane / (16 * 32)) > 0 ? (int)(rows_per_plane / (16 * 32)) : 1;
+        double best = -1.0;
+        for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {
+            const long long blocks = tiles * s2;
+            if (blocks < 2 * slots && s2 < maxsplit) continue;
+            if (blocks > 6 * slots && best >= 0.0) break;
+            const long long rounds = (blocks + slots - 1) / slots;
+            const double fill = (double)blocks / (double)(rounds * slots);
+            if (fill > best + 1e-3) { best = fill; splitK = s2; }
+        }
+    }
+    int kper = (int)((rows_per_plane + splitK - 1) / splitK);
+    kper = ((kper + 31) / 32) * 32;
+    splitK = (int)((rows_per_plane + kper - 1) / kper);
+    AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
+    ProfScope prof(st, 22, 2.0 * (double)rows_per_plane * planes * M * N);
+    prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK; prof.planes = planes;
+    hipLaunchKernelGGL(afi_gemm_tn_f16x3_kernel, dim3((unsigned)tiles, splitK), dim3(256), 2u * 4u * 4096u, st, g, qb, vb, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 int afi_launch_pix_gemm_sk(const AfiPixGemm& p, int b_rc, hipStream_t st);   // smallmap.hip

@@ -17,6 +17,13 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
 int afi_launch_split_bf16_tiles(const float* B, void* out, int planes, int N, int K, int split, hipStream_t st);
 int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st);
 int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st);
+int afi_launch_split_f16_tiles(const float* B, void* out, int planes, int N, int K, hipStream_t st);
+long long afi_f16_image_bytes(int planes, int N, int K);
+int afi_launch_absmax_planes(const float* X, long long per_plane, int planes, float* out, hipStream_t st);
+AfiF16Bound afi_f16_bound(const float* amax, int kind);    // kind: 0 exact per-plane maxima, 1 / 2 F(2x2) / F(4x4) input planes, 3 / 4 F(2x2) / F(4x4) dY planes
+int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st);
+int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
+                             hipStream_t st);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
 int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // igemm.hip -> smallmap.hip
 int afi_launch_wgrad_gemm_group6(const AfiWgradGemm* probs, int n, hipStream_t st);            // the wide group on the bf16 matrix cores (bf16x6)
@@ -59,14 +66,14 @@ int afi_launch_dwconv3x3(AfiView x, int N, int H, int W, int C, const float* w, 
 int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out, hipStream_t st);
 int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st);
 int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
-int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr);
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr, float* amax = nullptr);
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
-int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr);
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr, float* amax = nullptr);
 int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
-int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0);
+int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0, float* amax = nullptr);
 int afi_launch_wino4_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
-int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0);
+int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0, float* amax = nullptr);
 int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
 int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, int C, const float* bias, float alpha, AfiView out, AfiView z,
                            hipStream_t st);
@@ -77,7 +84,6 @@ int afi_launch_sum_accum(const float* v, long long n, float alpha, float* out, h
 int afi_launch_inc_i64(long long* p, hipStream_t st);
 int afi_launch_invstd(const float* var, float* invstd, int C, hipStream_t st);
 
-#define AFI_TRY(expr) do { int _s = (expr); if (_s != AFI_OK) return _s; } while (0)
 
 // ---- the caller-owned context (include/afigan_hip.h: afi_ctx_t): every piece of state that outlives one call lives here, nothing is
 //      process-global.  One context serves one stream at a time; two engines in one process use two contexts.
@@ -133,6 +139,10 @@ struct afi_ctx {
 };
 static inline long long afi_opt(const afi_ctx* cx, int o) { return cx ? cx->opt.v[o] : kDefaultOptions.v[o]; }
 static inline int afi_default_dtype() { return AFI_DTYPE_DEFAULT; }
+static inline bool afi_dtype_ok(int d) { return d == AFI_DTYPE_F32 || d == AFI_DTYPE_BF16 || d == AFI_DTYPE_F16X3 || d == AFI_DTYPE_BF16X3 || d == AFI_DTYPE_BF16X6; }
+// the small-map schedule of the interpolator (csrc/smallmap.hip) has one emulated-fp32 form, six bf16 products on pre-split weight images;
+// both fp32-grade settings of the big GEMMs take it
+static inline bool afi_dtype_smallmap6(int d) { return d == AFI_DTYPE_BF16X6 || d == AFI_DTYPE_F16X3; }
 namespace {
 // Fork/join onto the context's side stream (created on first use, on the context's device): the weight-gradient GEMMs and bias column
 // sums do not feed the data-gradient chain, so they run beside it.  Only event record / wait, so the sequence captures into a hipGraph.
@@ -225,12 +235,15 @@ static bool wino_d_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F
 static bool wino_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F4_BACKWARD) != 0; }
 // one size for both tilings: F(2x2,3x3) = 16 transform points over 2x2 tiles, F(4x4,3x3) = 36 points over 4x4 tiles
 // + the pre-split bf16 image of U the DMA GEMM stages (three 2-byte parts per element = 1.5 floats; afi_gemm_bf16.h)
+// (the f16x3 image -- a 512-byte header + two 2-byte pieces per element -- fits in it: KN >= 128 x 32)
 static long long wino_usplit_floats(int np, long long KN) { return align4((3 * np * KN + 1) / 2); }
+// + the slots the f16x3 arithmetic's transforms raise to the largest magnitude of the tensor they read (afi_gemm_f16.h), zero-filled per call
+constexpr long long kWinoAmaxFloats = 64;
 static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
     const long long T2 = wino_tpad(N, H, W), T4 = wino4_tpad(N, H, W);
     const long long a = align4(16LL * K * Nc) + align4(16 * T2 * K) + align4(16 * T2 * Nc) + wino_usplit_floats(16, (long long)K * Nc);
     const long long b = align4(36LL * K * Nc) + align4(36 * T4 * K) + align4(36 * T4 * Nc) + wino_usplit_floats(36, (long long)K * Nc);
-    return a > b ? a : b;
+    return (a > b ? a : b) + kWinoAmaxFloats;
 }
 // Any 3x3 / stride-1 conv DESCRIPTOR of the pixel GEMM (forward, b_rc = 0, or data gradient, b_rc = 1) run in Winograd form: the
 // batched GEMM writes M, the output transform applies the descriptor's own epilogue.  Eligible: 9 taps, one K phase, no up-sampled
@@ -392,6 +405,8 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     float* Vb = U + align4((long long)np * K * Nc);
     float* Mb = Vb + align4(np * Tpad * K);
     float* Usp = Mb + align4(np * Tpad * Nc);              // pre-split bf16 image of U (DMA GEMM), when it is not served from the cache
+    float* amax = Usp + wino_usplit_floats(np, (long long)K * Nc);      // f16x3: the largest magnitude of A, raised by the input transform(s)
+    const bool f16 = dtype == AFI_DTYPE_F16X3;
     // the bf16 settings run the LDS-DMA GEMM on tile-aligned shapes (every layer of the reference nets): its B operand is U split into
     // bf16 parts in LDS-image order, made once per weight transform and cached in that form
     const bool dma = dtype != AFI_DTYPE_F32 && !(Tpad % 128) && !(Nc % 128) && !(K % 32);
@@ -403,16 +418,19 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     if (!have_u) {
         AFI_TRY(f4 ? afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st)
                    : afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
-        if (dma) AFI_TRY(afi_launch_split_bf16_tiles(U, Usp, np, Nc, K, dtype, st));
+        if (dma) AFI_TRY(f16 ? afi_launch_split_f16_tiles(U, Usp, np, Nc, K, st) : afi_launch_split_bf16_tiles(U, Usp, np, Nc, K, dtype, st));
     }
+    const bool want_amax = dma && f16;
+    if (want_amax && hipMemsetAsync(amax, 0, 16, st) != hipSuccess) return AFI_ERR_LAUNCH;
     for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
         AfiView a = g.A;
         if (nph == 4) { a.p += (ph >> 1) * g.A.sH + (ph & 1) * g.A.sW; a.sH *= 2; a.sW *= 2; }
-        AFI_TRY(f4 ? afi_launch_wino4_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn)
-                   : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn));
+        AFI_TRY(f4 ? afi_launch_wino4_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn, want_amax ? amax : nullptr)
+                   : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn, want_amax ? amax : nullptr));
     }
     if (dma) {
-        AFI_TRY(afi_launch_gemm_nt_bf16_dma(Vb, Usp, Mb, np, Tpad, Nc, K, dtype, st));
+        if (f16) AFI_TRY(afi_launch_gemm_nt_f16x3(Vb, Usp, Mb, np, Tpad, Nc, K, afi_f16_bound(amax, f4 ? 2 : 1), st));
+        else AFI_TRY(afi_launch_gemm_nt_bf16_dma(Vb, Usp, Mb, np, Tpad, Nc, K, dtype, st));
         return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
     }
     if (dtype == AFI_DTYPE_F32) {                          // tile-aligned shapes: the plain batched NT GEMM on the fp32 MFMA
@@ -493,20 +511,25 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     float* dU = ws;
     float* Vb = dU + align4((long long)np * Cin * Cout);
     float* Qb = Vb + align4(np * Tpad * Cin);
+    float* amax = Qb + align4(np * Tpad * Cout);           // f16x3: [0] the largest magnitude of x, [4] of dy, raised by their transforms
+    const bool f16 = dtype == AFI_DTYPE_F16X3 && !(Tpad % 32) && !(Cout % 128) && !(Cin % 128);
     bool fresh = true, accum = false;
     if (accumulate)
         if (float* slot = wino_wgacc_slot(cx, dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
     if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
-    AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn) : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn));
+    if (f16 && hipMemsetAsync(amax, 0, 32, st) != hipSuccess) return AFI_ERR_LAUNCH;
+    AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 ? amax : nullptr) : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 ? amax : nullptr));
     const int cph = Cout / dy_phases;
     for (int ph = 0; ph < dy_phases; ++ph) {
         AfiView d = dy;
         if (dy_phases == 4) { d.p += (ph >> 1) * dy.sH + (ph & 1) * dy.sW; d.sH *= 2; d.sW *= 2; }
-        AFI_TRY(f4 ? afi_launch_wino4_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout) : afi_launch_wino_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout));
+        AFI_TRY(f4 ? afi_launch_wino4_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout, f16 ? amax + 4 : nullptr)
+                   : afi_launch_wino_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout, f16 ? amax + 4 : nullptr));
     }
     {   // tile-aligned shapes: the plain batched TN GEMM
-        const int rc = dtype == AFI_DTYPE_F32 ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st)
-                                              : afi_launch_gemm_tn_bf16(Qb, Vb, dU, np, Tpad, Cout, Cin, dtype, st);
+        const int rc = dtype == AFI_DTYPE_F32 || (dtype == AFI_DTYPE_F16X3 && !f16) ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st)
+                     : f16 ? afi_launch_gemm_tn_f16x3(Qb, Vb, dU, np, Tpad, Cout, Cin, afi_f16_bound(amax + 4, f4 ? 4 : 3), afi_f16_bound(amax, f4 ? 2 : 1), st)
+                           : afi_launch_gemm_tn_bf16(Qb, Vb, dU, np, Tpad, Cout, Cin, dtype, st);
         if (rc == AFI_OK) {
             if (accum) return AFI_OK;                      // transformed at afi_wino_wgrad_flush()
             return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
@@ -556,7 +579,7 @@ int afi_debug_wk6_convT_images(const float* W, int Cin, int Cout, int mode, void
                                        : AfiWk6ImgJob{pack_ref, 9LL * Cin, Cin, Cin, Cout, 9, 4, 1, 0, (unsigned char*)via_pack, 0, 0};
     return afi_launch_wk6_images(&job, 1, st, nullptr, nullptr);
 }
-int afi_abi_version(void) { return 5; }
+int afi_abi_version(void) { return 6; }
 
 const char* afi_status_string(int s) {
     switch (s) {
@@ -589,7 +612,7 @@ int afi_ctx_destroy(afi_ctx_t* ctx) {
     return AFI_OK;
 }
 int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype) {
-    if (!ctx || (dtype != AFI_DTYPE_F32 && dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6)) return AFI_ERR_BAD_ARG;
+    if (!ctx || !afi_dtype_ok(dtype)) return AFI_ERR_BAD_ARG;
     if (ctx->wgacc.n) return AFI_ERR_BAD_ARG;             // pending transform-domain sums belong to the tiling of the old setting
     ctx->dtype = dtype;
     return AFI_OK;
@@ -608,24 +631,52 @@ long long afi_ctx_get_option(const afi_ctx_t* ctx, int option) {
 long long afi_gemm_nt_scratch_bytes(int planes, int N, int K, int dtype) {
     if (planes <= 0 || N <= 0 || K <= 0) return -1;
     if (dtype == AFI_DTYPE_F32) return 0;
-    if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6) return -1;
+    if (!afi_dtype_ok(dtype)) return -1;
+    if (dtype == AFI_DTYPE_F16X3) return afi_f16_image_bytes(planes, N, K) + 256;      // + the per-plane maxima of A
     return (long long)planes * N * K * 2 * (dtype == AFI_DTYPE_BF16X6 ? 3 : (dtype == AFI_DTYPE_BF16X3 ? 2 : 1));
 }
 int afi_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int dtype, void* scratch, long long scratch_bytes,
                 void* stream) {
     if (!A || !B || !C) return AFI_ERR_BAD_ARG;
     if (dtype == AFI_DTYPE_F32) return afi_launch_gemm_nt(A, B, C, planes, rows_per_plane, N, K, (hipStream_t)stream);
-    if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6) return AFI_ERR_BAD_ARG;
+    if (!afi_dtype_ok(dtype)) return AFI_ERR_BAD_ARG;
     if (planes <= 0 || rows_per_plane <= 0 || N <= 0 || K <= 0) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
     if (!scratch || scratch_bytes < afi_gemm_nt_scratch_bytes(planes, N, K, dtype)) return AFI_ERR_WORKSPACE;
+    if (dtype == AFI_DTYPE_F16X3) {
+        // stand-alone: the exact per-plane maxima of both operands, by a pass over each (inside a convolution the transforms that write
+        // the planes provide a bound as a by-product and no pass exists)
+        if (planes > 36) return AFI_ERR_UNSUPPORTED;
+        hipStream_t st = (hipStream_t)stream;
+        float* amax = (float*)((unsigned char*)scratch + afi_f16_image_bytes(planes, N, K));
+        if (hipMemsetAsync(amax, 0, 256, st) != hipSuccess) return AFI_ERR_LAUNCH;
+        AFI_TRY(afi_launch_absmax_planes(A, rows_per_plane * K, planes, amax, st));
+        AFI_TRY(afi_launch_split_f16_tiles(B, scratch, planes, N, K, st));
+        return afi_launch_gemm_nt_f16x3(A, scratch, C, planes, rows_per_plane, N, K, afi_f16_bound(amax, 0), st);
+    }
     AFI_TRY(afi_launch_split_bf16_tiles(B, scratch, planes, N, K, dtype, (hipStream_t)stream));
     return afi_launch_gemm_nt_bf16_dma(A, scratch, C, planes, rows_per_plane, N, K, dtype, (hipStream_t)stream);
 }
-int afi_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int dtype, void* stream) {
+long long afi_gemm_tn_scratch_bytes(int planes, int dtype) {
+    if (planes <= 0 || !afi_dtype_ok(dtype)) return -1;
+    return dtype == AFI_DTYPE_F16X3 ? 512 : 0;
+}
+int afi_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int dtype, void* scratch, long long scratch_bytes,
+                void* stream) {
     if (!Q || !V || !dU) return AFI_ERR_BAD_ARG;
     if (dtype == AFI_DTYPE_F32) return afi_launch_gemm_tn(Q, V, dU, planes, rows_per_plane, M, N, (hipStream_t)stream);
-    if (dtype != AFI_DTYPE_BF16 && dtype != AFI_DTYPE_BF16X3 && dtype != AFI_DTYPE_BF16X6) return AFI_ERR_BAD_ARG;
+    if (!afi_dtype_ok(dtype)) return AFI_ERR_BAD_ARG;
+    if (dtype == AFI_DTYPE_F16X3) {
+        if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0) return AFI_ERR_BAD_ARG;
+        if (planes > 36 || (rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
+        if (!scratch || scratch_bytes < 512) return AFI_ERR_WORKSPACE;
+        hipStream_t st = (hipStream_t)stream;
+        float* amax = (float*)scratch;
+        if (hipMemsetAsync(amax, 0, 512, st) != hipSuccess) return AFI_ERR_LAUNCH;
+        AFI_TRY(afi_launch_absmax_planes(Q, rows_per_plane * M, planes, amax, st));
+        AFI_TRY(afi_launch_absmax_planes(V, rows_per_plane * N, planes, amax + 64, st));
+        return afi_launch_gemm_tn_f16x3(Q, V, dU, planes, rows_per_plane, M, N, afi_f16_bound(amax, 0), afi_f16_bound(amax + 64, 0), st);
+    }
     return afi_launch_gemm_tn_bf16(Q, V, dU, planes, rows_per_plane, M, N, dtype, (hipStream_t)stream);
 }
 int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* p, long long floats) {
@@ -1056,7 +1107,7 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
 
     // Small maps: the dense block in COLUMN-BATCHED form (below); under the default arithmetic its GEMMs, the head / trunk convs and the
     // conv-transpose run on the bf16 matrix cores in the six-product form, on pre-split weight images (csrc/smallmap.hip)
-    const bool six = l.n_img > 0 && (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_BF16X6;
+    const bool six = l.n_img > 0 && afi_dtype_smallmap6(cx ? cx->dtype : afi_default_dtype());
     const bool batched = l.P < afi_opt(cx, AFI_OPT_G_SMALLMAP_MAX_PIXELS) || (six && l.P <= afi_opt(cx, AFI_OPT_G_SMALLMAP6_MAX_PIXELS));
     Wk6Images im;
     bool packed = false;                                   // the packed conv-transpose weight `wp` (the backward reads it from this workspace) exists
@@ -1259,7 +1310,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // per tile shape (csrc/smallmap.hip: whole dW tiles per block, no split over pixels, no atomics, no zero-fill), instead of one
     // 7 .. 36-tile launch per layer on a side stream.  All their operands (dOut, dU, gA, gB, the per-block gradient buffers and the
     // saved activations) stay alive until the call returns.  AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS = 0 restores the per-layer launches.
-    const bool bf6 = (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_BF16X6;
+    const bool bf6 = afi_dtype_smallmap6(cx ? cx->dtype : afi_default_dtype());
     const bool grouped = l.P <= afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS) || (bf6 && s.n_img > 0 && l.P <= afi_opt(cx, AFI_OPT_G_SMALLMAP6_MAX_PIXELS));
     const bool batch_growth = !grouped && afi_opt(cx, AFI_OPT_G_BATCH_GROWTH_GRADS) != 0 && (4 * G <= C || s.n_wino == 0);   // larger maps: a block's four growth-conv weight gradients as one packed GEMM (below)
     // Small maps under the default arithmetic: the data-gradient GEMMs on pre-split weight images and the grouped weight gradients on the

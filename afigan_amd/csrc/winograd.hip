@@ -18,6 +18,29 @@
 #include "afi_epilogue.h"
 #include "afi_bn.h"
 
+// ---------------------------------------------------------------- largest magnitude of a transform's SOURCE tensor, as a by-product
+// (the f16x3 arithmetic of the batched GEMMs, afi_gemm_f16.h: every plane of a transform is bounded by a constant times this value, and the
+// GEMM derives its power-of-two operand scale from it).  A thread keeps the maximum of what it loads (after the BatchNorm affine, where
+// the tensor is read through one); at the end of its grid-stride walk the block reduces and publishes with ONE conditional atomic max on
+// the bit pattern (non-negative floats order like unsigned integers).  The slot is zero-filled before the launch.
+__device__ __forceinline__ float afi_amax4(float m, f32x4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+__device__ __forceinline__ void afi_amax_publish(float m, float* slot) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const unsigned bits = __float_as_uint(m);
+        // (a relaxed device-scope read first: after the first round of blocks most blocks cannot raise the slot, and thousands of atomics
+        //  on one word would serialise at the memory side)
+        if (bits > __hip_atomic_load((const unsigned*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) (void)atomicMax((unsigned*)slot, bits);
+    }
+}
+
 static bool afi_epilogue_is_simple_host(const AfiPixGemm& p) {
     return p.o_up == 1 && p.beta == 0.f && !p.R1.p && !p.R2.p && !p.r2_post && p.oH >= p.H && p.oW >= p.W &&
            (!p.Z.p || (p.z_lo == 0 && p.z_hi >= p.Ncols));
@@ -71,12 +94,13 @@ int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hip
 // ---------------------------------------------------------------- input: X (view, [N][H][W][C]) -> V [16][Tpad][C]
 // thread = (tile, channel quad); the 4x4 patch starts at (2*ty - 1, 2*tx - 1), zeros outside the image
 // BN: x is read through a BatchNorm affine + LeakyReLU (AfiBnLoad, afi_bn.h) -- the input is a discriminator block's saved conv output
-template <bool BN>
+template <bool BN, bool AMAX = false>
 __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T,
-                                                             long long Tpad, float* __restrict__ Vout, long long ldo, const AfiBnLoad bn) {
+                                                             long long Tpad, float* __restrict__ Vout, long long ldo, const AfiBnLoad bn, float* amax) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
+    float am = 0.f;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -102,6 +126,7 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
                     v = *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW);
                     if constexpr (BN) v = afi_bn_lrelu(v, mu, is, ga, be, AFI_LRELU_SLOPE);
+                    if constexpr (AMAX) am = afi_amax4(am, v);
                 }
                 d[i][j] = v;
             }
@@ -122,18 +147,25 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
             *(f32x4*)(dst + (4 * i + 3) * plane) = s[i][1] - s[i][3];
         }
     }
+    if constexpr (AMAX) afi_amax_publish(am, amax);
 }
 static inline bool wino_bn_ok(const AfiBnLoad* bn) {
     return !bn || !bn->mean || (bn->invstd && bn->gamma && bn->beta && !((((uintptr_t)bn->mean) | ((uintptr_t)bn->invstd) | ((uintptr_t)bn->gamma) | ((uintptr_t)bn->beta)) & 15));
 }
-int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn) {
+// amax (optional): raised to the largest magnitude of what the launch reads of x (see afi_amax_publish; zero-filled by the caller)
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn, float* amax) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !wino_bn_ok(bn)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
     const AfiBnLoad off{nullptr, nullptr, nullptr, nullptr};
-    if (bn && bn->mean) hipLaunchKernelGGL(afi_wino_input_kernel<true>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C, *bn);
-    else hipLaunchKernelGGL(afi_wino_input_kernel<false>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C, off);
+    const dim3 grid(wino_grid(Tpad * (C >> 2))), blk(256);
+    const long long ld = ldo > 0 ? ldo : (long long)C;
+    const bool b = bn && bn->mean;
+    if (b && amax) hipLaunchKernelGGL((afi_wino_input_kernel<true, true>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax);
+    else if (b) hipLaunchKernelGGL((afi_wino_input_kernel<true, false>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax);
+    else if (amax) hipLaunchKernelGGL((afi_wino_input_kernel<false, true>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax);
+    else hipLaunchKernelGGL((afi_wino_input_kernel<false, false>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -286,11 +318,13 @@ int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm&
 //   Q[a][t][co] = G' dy G'^T                     (afi_wino_dy_kernel;  G' = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]])
 //   dU[a][co][ci] = sum_t Q[a][t][co] * V[a][t][ci]     16 GEMMs with K = tiles: ONE launch of the weight-gradient kernel
 //   dW[co][ky][kx][ci] += A'^T dU A'             (afi_wino_dw_kernel;  A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]])
+template <bool AMAX>
 __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                          float* __restrict__ Q, long long ldo) {
+                                                          float* __restrict__ Q, long long ldo, float* amax) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
+    float am = 0.f;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -310,6 +344,7 @@ __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int 
             for (int j = 0; j < 2; ++j) {
                 const int yy = 2 * ty + i, xx = 2 * tx + j;
                 d[i][j] = (yy < H && xx < W) ? *(const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW) : zero;
+                if constexpr (AMAX) am = afi_amax4(am, d[i][j]);
             }
         f32x4 a[4][2];
 #pragma unroll
@@ -327,13 +362,15 @@ __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int 
             *(f32x4*)(dst + (4 * i + 3) * plane) = a[i][1];
         }
     }
+    if constexpr (AMAX) afi_amax_publish(am, amax);
 }
-int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo) {
+int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo, float* amax) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino_dy_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C);
+    if (amax) hipLaunchKernelGGL(afi_wino_dy_kernel<true>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C, amax);
+    else hipLaunchKernelGGL(afi_wino_dy_kernel<false>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C, amax);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -391,12 +428,13 @@ __device__ __forceinline__ void wino4_bt(T& d0, T& d1, T& d2, T& d3, T& d4, T& d
 }
 
 // input: X (view) -> V [36][Tpad][C]; the 6x6 patch of tile (ty, tx) starts at (4*ty - 1, 4*tx - 1)
-template <bool BN>
+template <bool BN, bool AMAX = false>
 __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                              float* __restrict__ Vout, long long ldo, const AfiBnLoad bn) {
+                                                              float* __restrict__ Vout, long long ldo, const AfiBnLoad bn, float* amax) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
+    float am = 0.f;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -422,6 +460,7 @@ __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, i
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
                     v = *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW);
                     if constexpr (BN) v = afi_bn_lrelu(v, mu, is, ga, be, AFI_LRELU_SLOPE);
+                    if constexpr (AMAX) am = afi_amax4(am, v);
                 }
                 d[i][j] = v;
             }
@@ -435,15 +474,21 @@ __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, i
             for (int j = 0; j < 6; ++j) *(f32x4*)(dst + (6 * i + j) * plane) = d[i][j];
         }
     }
+    if constexpr (AMAX) afi_amax_publish(am, amax);
 }
-int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn) {
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn, float* amax) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !wino_bn_ok(bn)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
     const AfiBnLoad off{nullptr, nullptr, nullptr, nullptr};
-    if (bn && bn->mean) hipLaunchKernelGGL(afi_wino4_input_kernel<true>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C, *bn);
-    else hipLaunchKernelGGL(afi_wino4_input_kernel<false>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ldo > 0 ? ldo : (long long)C, off);
+    const dim3 grid(wino_grid(Tpad * (C >> 2))), blk(256);
+    const long long ld = ldo > 0 ? ldo : (long long)C;
+    const bool b = bn && bn->mean;
+    if (b && amax) hipLaunchKernelGGL((afi_wino4_input_kernel<true, true>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax);
+    else if (b) hipLaunchKernelGGL((afi_wino4_input_kernel<true, false>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax);
+    else if (amax) hipLaunchKernelGGL((afi_wino4_input_kernel<false, true>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax);
+    else hipLaunchKernelGGL((afi_wino4_input_kernel<false, false>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -564,11 +609,13 @@ int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm
 }
 
 // weight gradient: Q[a][t][co] = G' e G'^T for the 4x4 block e of dY of tile t
+template <bool AMAX>
 __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                           float* __restrict__ Q, long long ldo) {
+                                                           float* __restrict__ Q, long long ldo, float* amax) {
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
+    float am = 0.f;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -597,6 +644,7 @@ __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int
                     v[i] = (yy < H && xx < W) ? __builtin_nontemporal_load((const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW)) : zero;
                 }
             }
+            if constexpr (AMAX) am = afi_amax4(afi_amax4(afi_amax4(afi_amax4(am, v[0]), v[1]), v[2]), v[3]);
             a[0][j] = 0.25f * v[0];
             a[1][j] = (-1.f / 6.f) * (v[0] + v[1] + v[2] + v[3]);
             a[2][j] = (-1.f / 6.f) * (v[0] - v[1] + v[2] - v[3]);
@@ -615,13 +663,15 @@ __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int
             *(f32x4*)(dst + (6 * i + 5) * plane) = v3;
         }
     }
+    if constexpr (AMAX) afi_amax_publish(am, amax);
 }
-int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo) {
+int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo, float* amax) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino4_dy_kernel, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C);
+    if (amax) hipLaunchKernelGGL(afi_wino4_dy_kernel<true>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C, amax);
+    else hipLaunchKernelGGL(afi_wino4_dy_kernel<false>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C, amax);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

@@ -164,7 +164,7 @@ def zeros_like_many(tensors, need):
 
 def gemm_nt(A, B, dtype, out=None):
     """afi_gemm_nt for tests and micro-benchmarks: C[g] = A[g] @ B[g]^T over the planes of dense [planes, rows, K] / [planes, N, K] tensors,
-    in the arithmetic `dtype` ("fp32", "bf16x6", "bf16x3", "bf16"); allocates the split-operand scratch the bf16 settings need."""
+    in the arithmetic `dtype` ("fp32", "f16x3", "bf16x6", "bf16x3", "bf16"); allocates the split-operand scratch the emulated settings need."""
     _check_cuda(A, B)
     planes, rows, K = A.shape
     N = B.shape[1]
@@ -186,7 +186,10 @@ def gemm_tn(Q, V, dtype, out=None):
     N = V.shape[2]
     if out is None:
         out = torch.zeros((planes, M, N), device=Q.device, dtype=torch.float32)
-    _lib.check(_lib.load().afi_gemm_tn(_p(Q), _p(V), _p(out), planes, rows, M, N, _lib.DTYPES[dtype], stream_ptr()), "afi_gemm_tn")
+    lib, dt = _lib.load(), _lib.DTYPES[dtype]
+    nb = lib.afi_gemm_tn_scratch_bytes(planes, dt)
+    scratch = torch.empty(max(int(nb), 16), device=Q.device, dtype=torch.uint8)
+    _lib.check(lib.afi_gemm_tn(_p(Q), _p(V), _p(out), planes, rows, M, N, dt, _p(scratch), nb, stream_ptr()), "afi_gemm_tn")
     return out
 
 

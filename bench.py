@@ -33,7 +33,21 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0          # MI355X_MICROARCH.md, "Peak BF16/FP16 M
 
 def gemm_peak(dtype):
     """Roof of the Winograd-domain GEMM kernels in fp32-equivalent TFLOP/s (2*M*N*K counted once per product)."""
-    return {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16": PEAK_BF16_MFMA_TFLOPS}[dtype]
+    return {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x6": PEAK_BF16_MFMA_TFLOPS / 6, "f16x3": PEAK_BF16_MFMA_TFLOPS / 3, "bf16x3": PEAK_BF16_MFMA_TFLOPS / 3,
+            "bf16": PEAK_BF16_MFMA_TFLOPS}[dtype]
+
+
+def kind_peak(name, run_dtype):
+    """Roof of one profiled kernel kind (afi_profile_kind_name): the dense bf16 / f16 MFMA peak over the MFMAs issued per fp32-equivalent product,
+    or the fp32 MFMA peak.  The f16x3 GEMMs issue three; the small-map kernels ("bf16x6 operands") always six; the bf16 Winograd GEMMs what
+    the run's dtype says."""
+    if "f16x3" in name:
+        return gemm_peak("f16x3")
+    if "bf16x6 operands" in name:
+        return gemm_peak("bf16x6")
+    if "bf16" in name:
+        return gemm_peak(run_dtype if run_dtype in ("bf16x6", "bf16x3", "bf16") else "bf16x6")
+    return PEAK_FP32_MFMA_TFLOPS
 G_FWD_FLOP_PER_INPX = 19_206_144        # SURVEY.md 8(d) / BASELINE.md section 3
 D_FWD_FLOP_PER_PX = 30_689_280
 D_FWDBWD_DETACHED_FLOP_PER_PX = 89_708_544
@@ -49,9 +63,9 @@ def parse():
     ap.add_argument("--no-interp", action="store_true", help="skip the AF-interpolator micro-benchmark")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl == RCCL; gloo only to rehearse "
                     "the multi-process path with several ranks sharing one GPU)")
-    ap.add_argument("--dtype", default=None, choices=["fp32", "bf16x6", "bf16x3", "bf16"],
+    ap.add_argument("--dtype", default=None, choices=["fp32", "f16x3", "bf16x6", "bf16x3", "bf16"],
                     help="how the big convolutions' GEMMs form their fp32 products (afi_ctx_set_compute_dtype).  Default: the library's "
-                         "(bf16x6: exact three-way bf16 split, fp32-grade); the default run also times the other settings on the same "
+                         "(f16x3: two scaled fp16 pieces per operand, three products, fp32-grade); the default run also times the other settings on the same "
                          "engine afterwards and reports them under other_dtypes")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
@@ -248,9 +262,9 @@ def interp_bench(amd, torch, N, H, W, iters=50, warmup=10, graph=True):
             kinds.append({"kernel": lib.afi_profile_kind_name(k).decode(), "launches_per_iter": out3[0] / prof_iters, "us_per_iter": out3[1] * 1e3 / prof_iters,
                           "avg_launch_us": out3[1] * 1e3 / out3[0], "tflops": out3[2] / (out3[1] * 1e-3) / 1e12 if out3[1] > 0 else 0.0})
     kinds.sort(key=lambda r: -r["us_per_iter"])
-    # a kernel's own roof: the bf16x6 kernels (names say "bf16") multiply six bf16 MFMAs per fp32-equivalent product, the others use the fp32 MFMA
+    # a kernel's own roof (kind_peak): the small-map kernels multiply six bf16 MFMAs per fp32-equivalent product, the f16x3 GEMMs three, the others use the fp32 MFMA
     for r in kinds:
-        r["peak"] = gemm_peak("bf16x6") if "bf16" in r["kernel"] else PEAK_FP32_MFMA_TFLOPS
+        r["peak"] = kind_peak(r["kernel"], _lib.current_ctx().dtype)
         r["frac"] = r["tflops"] / r["peak"]
     roof = None
     if kinds:
@@ -637,7 +651,7 @@ def main():
     other_dtypes = None
     if world == 1 and args.dtype is None and os.environ.get("AFI_BENCH_OTHER_DTYPES", "1") != "0":
         other_dtypes = {}
-        for dt in [d for d in ("fp32", "bf16x6", "bf16x3", "bf16") if d != run_dtype]:
+        for dt in [d for d in ("fp32", "f16x3", "bf16x6", "bf16x3", "bf16") if d != run_dtype]:
             step.set_dtype(dt)
             one_step()
             torch.cuda.synchronize()
@@ -670,10 +684,8 @@ def main():
     traffic = committed_traffic("traffic_dominant_kernel.json", dom["kernel"])
     # the Winograd GEMMs' own roof: the dense bf16 MFMA peak over the bf16 MFMAs issued per fp32-equivalent product (6 / 3 / 1), or the
     # fp32 MFMA peak; every other kernel multiplies on the fp32 MFMA
-    def kind_peak(name):
-        return gemm_peak(run_dtype) if "bf16" in name else PEAK_FP32_MFMA_TFLOPS
-    dom_peak = kind_peak(dom["kernel"])
-    peak_s = sum(r["flop_total"] / (kind_peak(r["kernel"]) * 1e12) for r in kinds)        # seconds the step's products take at each kernel's own peak
+    dom_peak = kind_peak(dom["kernel"], run_dtype)
+    peak_s = sum(r["flop_total"] / (kind_peak(r["kernel"], run_dtype) * 1e12) for r in kinds)        # seconds the step's products take at each kernel's own peak
     roofline = {"bound": "mfma", "kernel": dom["kernel"], "achieved": dom["tflops"], "peak": dom_peak, "unit": "TFLOP/s",
                 "frac": dom["tflops"] / dom_peak, "traffic": traffic, "launches": dom["launches"], "avg_launch_us": dom["avg_us"],
                 "share_of_step_time": dom["ms_total"] / (elapsed * 1e3),
@@ -705,7 +717,7 @@ def main():
     line = {
         "metric": "stage1_G+D_step_images_per_s", "value": n_img / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x6": "f32 emulated on the bf16 matrix cores (operands split exactly into three bf16, six bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)", "bf16x3": "bf16x3 (split-bf16 operands, three bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "f16x3": "f32 emulated on the f16 matrix cores (operands scaled by a power of two per Winograd plane and split into two fp16 pieces, three f16 MFMAs per k-step, fp32 accumulate; tensors fp32)", "bf16x6": "f32 emulated on the bf16 matrix cores (operands split exactly into three bf16, six bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)", "bf16x3": "bf16x3 (split-bf16 operands, three bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)",
                                        "bf16": "bf16 (bf16 operands, fp32 accumulate; tensors fp32)"}[run_dtype], "data": "synthetic",
         "backend": (args.backend if world > 1 else None),
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
@@ -753,7 +765,7 @@ def main():
         line["pafpn"] = fpn_bench(amd, torch, pafpn=True)
         # BASELINE configs[4] names this pyramid "bf16": the same forward + backward under each arithmetic setting of the big GEMMs
         line["pafpn"]["ms_by_dtype"] = {}
-        for dt in ("fp32", "bf16x6", "bf16x3", "bf16"):
+        for dt in ("fp32", "f16x3", "bf16x6", "bf16x3", "bf16"):
             with amd.compute_dtype(dt):
                 line["pafpn"]["ms_by_dtype"][dt] = round(fpn_bench(amd, torch, iters=5, warmup=2, pafpn=True)["ms"], 3)
         line["bifpn_inference"] = bifpn_bench(amd, torch)

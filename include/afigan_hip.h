@@ -79,6 +79,16 @@ int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
  *                     a bf16 x bf16 product is exact in fp32, and what is dropped (mid*lo, lo*mid, lo*lo <= 2^-23 of a product) is the
  *                     size of fp32's own rounding of that product.  Error 0.5e-6 .. 1.1e-6 -- at or below the fp32 MFMA's on every shape
  *                     measured -- at 1.5x its speed.  fp32-grade: every parity test of this repo runs on it at the fp32 tolerances.
+ *   AFI_DTYPE_F16X3   each operand is scaled by a power of two (per operand and Winograd plane, exact) and split into TWO fp16 pieces,
+ *                     x s = hi + lo + r with |r| <= 2^-23 |x s| (round to nearest; 11 + 11 significant bits, the residual x s - hi exact in
+ *                     fp32); the three products hi*hi, hi*lo, lo*hi are accumulated smallest first in fp32 by the f16 MFMA (same rate as
+ *                     the bf16 one), the dropped lo*lo is <= 2^-22 of a product with random sign, and the accumulator is scaled back by
+ *                     the exact inverse in the epilogue.  Half the matrix-core work of BF16X6.  The scale needs the operand's largest
+ *                     magnitude before the GEMM starts: the Winograd transforms that write the planes compute the largest magnitude of
+ *                     the tensor they read as a by-product, and every plane is bounded by a constant times it (csrc/afi_gemm_f16.h);
+ *                     elements more than ~2^18 below the plane's bound lose RELATIVE precision (their absolute error stays <= 2^-40 of
+ *                     the bound), which a max-norm comparison with fp32 does not see and a dot product does not feel.  fp32-grade on
+ *                     the operands of tests/test_gpu_bf16.py::test_f16x3_is_fp32_grade_on_hard_operands.
  *   AFI_DTYPE_F32     fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain).  Error 1.0e-6 .. 1.3e-6.
  *   AFI_DTYPE_BF16X3  x = hi + lo (16 mantissa bits), three MFMAs (hi*hi + hi*lo + lo*hi).  Error 4.5e-6; conv outputs within 2e-4,
  *                     network outputs / input gradients within 1e-3, weight gradients within 1e-2 (L2; LeakyReLU-mask flips).  Opt-in.
@@ -92,9 +102,10 @@ int afi_ctx_set_op_scratch(afi_ctx_t* ctx, float* scratch, long long floats);
  * Refused while weight-gradient sums are pending.  No environment variable changes the default. */
 #define AFI_DTYPE_F32 0
 #define AFI_DTYPE_BF16 1
+#define AFI_DTYPE_F16X3 2
 #define AFI_DTYPE_BF16X3 3
 #define AFI_DTYPE_BF16X6 6
-#define AFI_DTYPE_DEFAULT AFI_DTYPE_BF16X6
+#define AFI_DTYPE_DEFAULT AFI_DTYPE_F16X3
 int afi_ctx_set_compute_dtype(afi_ctx_t* ctx, int dtype);
 int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
 /* Algorithm options of a context.  The library reads NO environment variable: every choice that changes numerics or scheduling is made
@@ -140,8 +151,11 @@ long long afi_gemm_nt_scratch_bytes(int planes, int N, int K, int dtype);
 int afi_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, int dtype, void* scratch,
                 long long scratch_bytes, void* stream);
 /* ... and the weight-gradient form  dU[g][m][n] += sum_k Q[g][k][m] * V[g][k][n]  (both operands k-slow; rows_per_plane = K per plane,
- * % 32 == 0; M % 128 == 0, N % 128 == 0).  Split-K with fp32 atomics: the summation order varies run to run. */
-int afi_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int dtype, void* stream);
+ * % 32 == 0; M % 128 == 0, N % 128 == 0).  Split-K with fp32 atomics: the summation order varies run to run.  `scratch`
+ * (afi_gemm_tn_scratch_bytes: 512 under AFI_DTYPE_F16X3 -- the per-plane maxima of both operands --, 0 otherwise; may be NULL then). */
+long long afi_gemm_tn_scratch_bytes(int planes, int dtype);
+int afi_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int dtype, void* scratch,
+                long long scratch_bytes, void* stream);
 /* Cache of the Winograd-transformed (and packed conv-transpose) weights.  Within one phase of a training step the same weights serve up
  * to ten calls (stage1_trainer.py:336-433: five levels x real / fake); each (weight pointer, tiling, direction) is transformed once and
  * re-used until afi_ctx_wino_weight_cache_invalidate() -- which the caller MUST issue whenever weight VALUES change (optimizer step,

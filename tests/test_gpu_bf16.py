@@ -5,6 +5,7 @@ held to the same fp32 bars here and in every other test file; bf16x3 and bf16 ar
     dtype      operands                         GEMM alone (max-norm)   conv3x3 fwd / dgrad / wgrad   generator fwd+bwd, D step
     fp32       exact fp32 MFMA                  2e-6                    1e-4                          1e-3
     bf16x6     x = hi + mid + lo, 6 bf16 MFMAs  2e-6                    1e-4                          1e-3 (the default: all other tests)
+    f16x3      x s = hi + lo (fp16), 3 f16 MFMAs 2e-6                   1e-4                          1e-3
     bf16x3     x = hi + lo, 3 bf16 MFMAs        2e-5                    2e-4                          1e-3 outputs / input grads; 1e-2 (L2) weight grads
     bf16       x -> bf16(x), 1 bf16 MFMA        8e-3                    2e-2 (F(2x2) tiles only)      5e-2 outputs / input grads; 1e-1 (L2) weight grads
 """
@@ -18,10 +19,11 @@ pytestmark = pytest.mark.gpu
 
 from oracle import afigan_oracle as orc  # noqa: E402
 
-TOL_GEMM = {"fp32": 2e-6, "bf16x6": 2e-6, "bf16x3": 2e-5, "bf16": 8e-3}
-TOL_CONV = {"fp32": 1e-4, "bf16x6": 1e-4, "bf16x3": 2e-4, "bf16": 2e-2}
-TOL_NET = {"fp32": 1e-3, "bf16x6": 1e-3, "bf16x3": 1e-3, "bf16": 5e-2}
-TOL_GRAD_L2 = {"fp32": 5e-3, "bf16x6": 5e-3, "bf16x3": 1e-2, "bf16": 1e-1}
+TOL_GEMM = {"fp32": 2e-6, "bf16x6": 2e-6, "f16x3": 2e-6, "bf16x3": 2e-5, "bf16": 8e-3}
+TOL_CONV = {"fp32": 1e-4, "bf16x6": 1e-4, "f16x3": 1e-4, "bf16x3": 2e-4, "bf16": 2e-2}
+TOL_NET = {"fp32": 1e-3, "bf16x6": 1e-3, "f16x3": 1e-3, "bf16x3": 1e-3, "bf16": 5e-2}
+TOL_GRAD_L2 = {"fp32": 5e-3, "bf16x6": 5e-3, "f16x3": 5e-3, "bf16x3": 1e-2, "bf16": 1e-1}
+ALL_DTYPES = ["fp32", "bf16x6", "f16x3", "bf16x3", "bf16"]
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +33,7 @@ def amd():
     return afigan_amd
 
 
-DEFAULT_DTYPE = "bf16x6"                                   # AFI_DTYPE_DEFAULT of include/afigan_hip.h
+DEFAULT_DTYPE = "f16x3"                                   # AFI_DTYPE_DEFAULT of include/afigan_hip.h
 
 
 def _rel(a, b):
@@ -40,7 +42,7 @@ def _rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-300)).item()
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16x6", "bf16x3", "bf16"])
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_batched_gemms(amd, dtype):
     """afi_gemm_nt / afi_gemm_tn (the GEMMs every big 3x3 conv runs on) against fp64, including the last tile of the last plane."""
     from afigan_amd import _lib
@@ -56,28 +58,28 @@ def test_batched_gemms(amd, dtype):
         Q = torch.randn((planes, rows, M), device="cuda", generator=g)
         V = torch.randn((planes, rows, N), device="cuda", generator=g)
         dU = torch.ones((planes, M, N), device="cuda")                        # += semantics
-        _lib.check(lib.afi_gemm_tn(C.c_void_p(Q.data_ptr()), C.c_void_p(V.data_ptr()), C.c_void_p(dU.data_ptr()), planes, rows, M, N, dt, st), "afi_gemm_tn")
+        amd.ops.gemm_tn(Q, V, dtype, out=dU)
         assert _rel(dU, 1.0 + torch.bmm(Q.double().transpose(1, 2), V.double())) < TOL_GEMM[dtype], (planes, rows, M, N)
     # shapes the tile-aligned kernels do not take are refused, not mangled
     sc = torch.empty(1 << 20, device="cuda", dtype=torch.uint8)
     ptrs = (C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()))
     assert lib.afi_gemm_nt(*ptrs, 1, 100, 128, 32, dt, C.c_void_p(sc.data_ptr()), sc.numel(), st) == 2
-    assert lib.afi_gemm_nt(*ptrs, 1, 128, 128, 32, 2, C.c_void_p(sc.data_ptr()), sc.numel(), st) == 1
-    if dtype != "fp32":                                     # the bf16 settings need the split-operand scratch: refused without it, never allocated inside
-        assert lib.afi_gemm_nt_scratch_bytes(1, 128, 32, dt) == 128 * 32 * 2 * {"bf16x6": 3, "bf16x3": 2, "bf16": 1}[dtype]
+    assert lib.afi_gemm_nt(*ptrs, 1, 128, 128, 32, 5, C.c_void_p(sc.data_ptr()), sc.numel(), st) == 1
+    if dtype != "fp32":                                     # the emulated settings need the split-operand scratch: refused without it, never allocated inside
+        pieces = 128 * 32 * 2 * {"bf16x6": 3, "bf16x3": 2, "bf16": 1, "f16x3": 2}[dtype]
+        assert lib.afi_gemm_nt_scratch_bytes(1, 128, 32, dt) == pieces + (768 if dtype == "f16x3" else 0)       # f16x3: + scales and maxima
         assert lib.afi_gemm_nt(*ptrs, 1, 128, 128, 32, dt, None, 0, st) == 4
+        if dtype == "f16x3":
+            assert lib.afi_gemm_tn_scratch_bytes(36, dt) == 512
+            assert lib.afi_gemm_tn(*ptrs, 1, 128, 128, 128, dt, None, 0, st) == 4
     else:
         assert lib.afi_gemm_nt_scratch_bytes(1, 128, 32, dt) == 0
 
 
-@pytest.mark.parametrize("kind", ["normal", "positive_large_mean", "wide_dynamic_range", "tiny_values", "sparse_post_relu"])
-def test_bf16x6_is_fp32_grade_on_hard_operands(amd, kind):
-    """The default arithmetic against the fp32 MFMA kernel on the SAME operands, both measured against fp64: the six-product form must
-    not be worse than fp32's own rounding (bar: 1.5x the fp32 kernel's error + 1e-7), whatever the operands look like."""
-    from afigan_amd import _lib
-    lib, st = _lib.load(), amd.ops.stream_ptr()
-    g = torch.Generator(device="cuda").manual_seed(11)
-    planes, rows, N, K = 4, 512, 256, 1024
+HARD_KINDS = ["normal", "positive_large_mean", "wide_dynamic_range", "tiny_values", "sparse_post_relu"]
+
+
+def _hard_operands(kind, g, planes=4, rows=512, N=256, K=1024):
     A = torch.randn((planes, rows, K), device="cuda", generator=g)
     B = torch.randn((planes, N, K), device="cuda", generator=g)
     if kind == "positive_large_mean":
@@ -89,6 +91,53 @@ def test_bf16x6_is_fp32_grade_on_hard_operands(amd, kind):
         A, B = A * 1e-18, B * 1e-12                                  # products ~1e-30: far below bf16's precision of 1.0, inside its range
     elif kind == "sparse_post_relu":
         A, B = torch.relu(A - 1.0), B * (torch.rand(B.shape, device="cuda", generator=g) < 0.1)
+    return A, B
+
+
+@pytest.mark.parametrize("kind", HARD_KINDS + ["huge_values", "rows_of_different_scale"])
+def test_f16x3_is_fp32_grade_on_hard_operands(amd, kind):
+    """The two-piece fp16 form (AFI_DTYPE_F16X3) against the fp32 MFMA kernel on the SAME operands, both measured against fp64, NT and TN:
+    not worse than fp32's own rounding (bar: 1.5x the fp32 kernel's error + 1e-7), whatever the operands look like -- fp16's range is what
+    the per-plane power-of-two scales are there for: values far above 65504, far below 2^-24, 40 binades inside one plane, and (last
+    case) rows of one plane whose scales differ by 2^12, where the plane-wide scale leaves the small rows with fewer normal bits in `lo`."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    if kind == "huge_values":
+        A, B = _hard_operands("normal", g)
+        A, B = A * 3e9, B * 7e5                                      # far beyond fp16's largest finite value
+    elif kind == "rows_of_different_scale":
+        A, B = _hard_operands("normal", g)
+        A = A * torch.exp2(torch.randint(-12, 1, (A.shape[0], A.shape[1], 1), device="cuda", generator=g).float())
+    else:
+        A, B = _hard_operands(kind, g)
+    ref = torch.bmm(A.double(), B.double().transpose(1, 2))
+    err = {}
+    for dt in ("fp32", "f16x3"):
+        Cm = amd.ops.gemm_nt(A, B, dt)
+        err[dt] = ((Cm.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err["f16x3"] <= 1.5 * err["fp32"] + 1e-7, (kind, "NT", err)
+    assert err["fp32"] < 5e-6, (kind, err)
+    if kind == "rows_of_different_scale":                  # ... and row by row, against each row's own scale
+        for dt in ("fp32", "f16x3"):
+            Cm = amd.ops.gemm_nt(A, B, dt)
+            err[dt] = ((Cm.double() - ref).abs().amax(dim=2) / ref.abs().amax(dim=2)).max().item()
+        assert err["f16x3"] <= 1.5 * err["fp32"] + 1e-7, (kind, "NT per row", err)
+    # the weight-gradient form on the same data: dU = A^T-like contraction over the rows (K = 512 rows)
+    Q, V = A[:, :, :256].contiguous(), B.transpose(1, 2)[:, :512, :].contiguous()        # [planes, 512, 256] x [planes, 512, 256]
+    ref = torch.bmm(Q.double().transpose(1, 2), V.double())
+    for dt in ("fp32", "f16x3"):
+        dU = amd.ops.gemm_tn(Q, V, dt)
+        err[dt] = ((dU.double() - ref).abs().max() / ref.abs().max()).item()
+    assert err["f16x3"] <= 1.5 * err["fp32"] + 1e-7, (kind, "TN", err)
+
+
+@pytest.mark.parametrize("kind", HARD_KINDS)
+def test_bf16x6_is_fp32_grade_on_hard_operands(amd, kind):
+    """The default arithmetic against the fp32 MFMA kernel on the SAME operands, both measured against fp64: the six-product form must
+    not be worse than fp32's own rounding (bar: 1.5x the fp32 kernel's error + 1e-7), whatever the operands look like."""
+    from afigan_amd import _lib
+    lib, st = _lib.load(), amd.ops.stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    A, B = _hard_operands(kind, g)
     ref = torch.bmm(A.double(), B.double().transpose(1, 2))
     err = {}
     for dt in ("fp32", "bf16x6"):
@@ -98,7 +147,7 @@ def test_bf16x6_is_fp32_grade_on_hard_operands(amd, kind):
     assert err["fp32"] < 5e-6, (kind, err)
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16x6", "bf16x3", "bf16"])
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 @pytest.mark.parametrize("N,Ci,Co,H,W", [(1, 256, 256, 50, 68), (2, 256, 512, 100, 84), (1, 288, 128, 33, 47)])
 def test_conv3x3_winograd_under_dtype(amd, dtype, N, Ci, Co, H, W):
     """Forward, data gradient and weight gradient of a 3x3 conv on the Winograd path under the context's dtype, against fp64."""
@@ -124,7 +173,7 @@ def test_conv3x3_winograd_under_dtype(amd, dtype, N, Ci, Co, H, W):
         assert _rel(out, y) > 1e-4
 
 
-@pytest.mark.parametrize("dtype", ["fp32", "bf16x6", "bf16x3", "bf16"])
+@pytest.mark.parametrize("dtype", ALL_DTYPES)
 def test_generator_fwd_bwd_under_dtype(amd, dtype):
     """AF interpolator on a map large enough for the Winograd path (2 x 256 x 52 x 84), forward + full backward, against the oracle."""
     Cc = 256
@@ -160,7 +209,7 @@ def test_generator_fwd_bwd_under_dtype(amd, dtype):
     assert worst < TOL_GRAD_L2[dtype], worst
 
 
-@pytest.mark.parametrize("dtype", ["bf16x6", "bf16x3", "bf16"])
+@pytest.mark.parametrize("dtype", ["bf16x6", "f16x3", "bf16x3", "bf16"])
 def test_stage1_step_under_dtype(amd, dtype):
     """One stage-1 G+D step with the engine's dtype against the same step in fp32: losses and the parameter updates."""
     import copy
@@ -196,7 +245,7 @@ def test_dtype_api_guards(amd):
         cx.set_dtype("fp16")
     dflt = _lib.DTYPES[DEFAULT_DTYPE]
     assert cx.dtype == {v: k for k, v in _lib.DTYPES.items()}[dflt]
-    assert _lib.load().afi_ctx_set_compute_dtype(cx.handle, 2) == 1 and _lib.load().afi_ctx_get_compute_dtype(cx.handle) == dflt
+    assert _lib.load().afi_ctx_set_compute_dtype(cx.handle, 5) == 1 and _lib.load().afi_ctx_get_compute_dtype(cx.handle) == dflt
     cx.set_dtype("bf16x3")
     assert _lib.load().afi_ctx_get_compute_dtype(cx.handle) == 3 and _lib.load().afi_ctx_get_compute_dtype(None) == dflt
     cx.set_dtype("fp32")

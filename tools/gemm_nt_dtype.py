@@ -1,4 +1,4 @@
-"""Batched Winograd-plane NT GEMM in the three arithmetic settings (fp32 / bf16x3 / bf16): error against fp64 and TFLOP/s.
+"""Batched Winograd-plane NT / TN GEMMs in every arithmetic setting (fp32 / f16x3 / bf16x6 / bf16x3 / bf16): error against fp64 and TFLOP/s.
 Usage: python tools/gemm_nt_dtype.py [planes rows N K] ..."""
 import ctypes as C
 import os
@@ -42,8 +42,9 @@ def run_tn(planes, rows, M, N, iters=20):
     dU = torch.empty((planes, M, N), device="cuda")
     ref = torch.bmm(Q[:2].double().transpose(1, 2), V[:2].double())
     st = amd.ops.stream_ptr()
+    sc = torch.empty(1024, device="cuda", dtype=torch.uint8)
     for name, dt in _lib.DTYPES.items():
-        args = (C.c_void_p(Q.data_ptr()), C.c_void_p(V.data_ptr()), C.c_void_p(dU.data_ptr()), planes, rows, M, N, dt, st)
+        args = (C.c_void_p(Q.data_ptr()), C.c_void_p(V.data_ptr()), C.c_void_p(dU.data_ptr()), planes, rows, M, N, dt, C.c_void_p(sc.data_ptr()), sc.numel(), st)
         dU.zero_()
         _lib.check(_lib.load().afi_gemm_tn(*args), "afi_gemm_tn")
         torch.cuda.synchronize()
