@@ -136,6 +136,11 @@ struct afi_ctx {
     WinoWeightCache wcache;
     WinoWgradAccum wgacc;
     SideStream side;
+    // f16x3: the zero-filled slots the Winograd transforms raise to their source tensor's largest magnitude (afi_gemm_f16.h) are taken from
+    // the last kWinoAmaxFloats of the Winograd scratch a call works in, one memset per public call and scratch region (two regions: the
+    // backward passes keep a second scratch for the weight gradients) instead of one per convolution.  AFI_CTX_CHECK, which every public
+    // entry point passes, forgets both.
+    struct AmaxPool { float* p = nullptr; int next = 0; } amax[2];
 };
 static inline long long afi_opt(const afi_ctx* cx, int o) { return cx ? cx->opt.v[o] : kDefaultOptions.v[o]; }
 static inline int afi_default_dtype() { return AFI_DTYPE_DEFAULT; }
@@ -170,7 +175,8 @@ struct Fork {
 };
 constexpr long long kSideStreamMaxPixels = 12000;   // above this every GEMM fills the chip on its own (and overlapping kernels only perturb each other)
 }  // namespace
-#define AFI_CTX_CHECK(ctx) do { if (ctx) { int d_ = -1; if (hipGetDevice(&d_) != hipSuccess || d_ != ((afi_ctx*)(ctx))->device) return AFI_ERR_BAD_ARG; } } while (0)
+#define AFI_CTX_CHECK(ctx) do { if (ctx) { int d_ = -1; if (hipGetDevice(&d_) != hipSuccess || d_ != ((afi_ctx*)(ctx))->device) return AFI_ERR_BAD_ARG; \
+                                           ((afi_ctx*)(ctx))->amax[0].p = ((afi_ctx*)(ctx))->amax[1].p = nullptr; } } while (0)
 
 // per-op entry points: split-K slabs come from the context's op scratch (the whole-net calls carve theirs out of their workspace)
 static inline int launch_pix_op(afi_ctx* cx, AfiPixGemm g, int b_rc, hipStream_t st) {
@@ -239,6 +245,20 @@ static bool wino_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F4_
 static long long wino_usplit_floats(int np, long long KN) { return align4((3 * np * KN + 1) / 2); }
 // + the slots the f16x3 arithmetic's transforms raise to the largest magnitude of the tensor they read (afi_gemm_f16.h), zero-filled per call
 constexpr long long kWinoAmaxFloats = 64;
+// n consecutive slots (4 floats apart) at the tail of the scratch region [ws, ws + ws_floats); nullptr: the memset failed
+static float* wino_amax_take(afi_ctx* cx, float* ws, long long ws_floats, int n, hipStream_t st) {
+    float* pool = ws + ws_floats - kWinoAmaxFloats;
+    if (!cx) return hipMemsetAsync(pool, 0, 16 * n, st) == hipSuccess ? pool : nullptr;
+    afi_ctx::AmaxPool* e = cx->amax[0].p == pool ? &cx->amax[0] : (cx->amax[1].p == pool ? &cx->amax[1] : nullptr);
+    if (!e || 4 * (e->next + n) > kWinoAmaxFloats) {
+        if (!e) { e = cx->amax[0].p ? &cx->amax[1] : &cx->amax[0]; }
+        if (hipMemsetAsync(pool, 0, sizeof(float) * kWinoAmaxFloats, st) != hipSuccess) return nullptr;
+        e->p = pool; e->next = 0;
+    }
+    float* slot = pool + 4 * e->next;
+    e->next += n;
+    return slot;
+}
 static long long wino_ws_floats(int N, int H, int W, int K, int Nc) {
     const long long T2 = wino_tpad(N, H, W), T4 = wino4_tpad(N, H, W);
     const long long a = align4(16LL * K * Nc) + align4(16 * T2 * K) + align4(16 * T2 * Nc) + wino_usplit_floats(16, (long long)K * Nc);
@@ -405,8 +425,8 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     float* Vb = U + align4((long long)np * K * Nc);
     float* Mb = Vb + align4(np * Tpad * K);
     float* Usp = Mb + align4(np * Tpad * Nc);              // pre-split bf16 image of U (DMA GEMM), when it is not served from the cache
-    float* amax = Usp + wino_usplit_floats(np, (long long)K * Nc);      // f16x3: the largest magnitude of A, raised by the input transform(s)
     const bool f16 = dtype == AFI_DTYPE_F16X3;
+    float* amax = nullptr;                                 // f16x3: the largest magnitude of A, raised by the input transform(s)
     // the bf16 settings run the LDS-DMA GEMM on tile-aligned shapes (every layer of the reference nets): its B operand is U split into
     // bf16 parts in LDS-image order, made once per weight transform and cached in that form
     const bool dma = dtype != AFI_DTYPE_F32 && !(Tpad % 128) && !(Nc % 128) && !(K % 32);
@@ -421,7 +441,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
         if (dma) AFI_TRY(f16 ? afi_launch_split_f16_tiles(U, Usp, np, Nc, K, st) : afi_launch_split_bf16_tiles(U, Usp, np, Nc, K, dtype, st));
     }
     const bool want_amax = dma && f16;
-    if (want_amax && hipMemsetAsync(amax, 0, 16, st) != hipSuccess) return AFI_ERR_LAUNCH;
+    if (want_amax && !(amax = wino_amax_take(cx, ws, ws_floats, 1, st))) return AFI_ERR_LAUNCH;
     for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
         AfiView a = g.A;
         if (nph == 4) { a.p += (ph >> 1) * g.A.sH + (ph & 1) * g.A.sW; a.sH *= 2; a.sW *= 2; }
@@ -511,13 +531,13 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     float* dU = ws;
     float* Vb = dU + align4((long long)np * Cin * Cout);
     float* Qb = Vb + align4(np * Tpad * Cin);
-    float* amax = Qb + align4(np * Tpad * Cout);           // f16x3: [0] the largest magnitude of x, [4] of dy, raised by their transforms
     const bool f16 = dtype == AFI_DTYPE_F16X3 && !(Tpad % 32) && !(Cout % 128) && !(Cin % 128);
+    float* amax = nullptr;                                 // f16x3: [0] the largest magnitude of x, [4] of dy, raised by their transforms
     bool fresh = true, accum = false;
     if (accumulate)
         if (float* slot = wino_wgacc_slot(cx, dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
     if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
-    if (f16 && hipMemsetAsync(amax, 0, 32, st) != hipSuccess) return AFI_ERR_LAUNCH;
+    if (f16 && !(amax = wino_amax_take(cx, ws, ws_floats, 2, st))) return AFI_ERR_LAUNCH;
     AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 ? amax : nullptr) : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 ? amax : nullptr));
     const int cph = Cout / dy_phases;
     for (int ph = 0; ph < dy_phases; ++ph) {

@@ -126,10 +126,15 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
                     v = *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW);
                     if constexpr (BN) v = afi_bn_lrelu(v, mu, is, ga, be, AFI_LRELU_SLOPE);
-                    if constexpr (AMAX) am = afi_amax4(am, v);
                 }
                 d[i][j] = v;
             }
+        }
+        if constexpr (AMAX) {                                // (behind ALL the loads: a use inside a load's own branch makes every load wait for itself)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) am = afi_amax4(am, d[i][j]);
         }
         f32x4 s[4][4];
 #pragma unroll
@@ -344,8 +349,8 @@ __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int 
             for (int j = 0; j < 2; ++j) {
                 const int yy = 2 * ty + i, xx = 2 * tx + j;
                 d[i][j] = (yy < H && xx < W) ? *(const f32x4*)(base + (long long)yy * dy.sH + (long long)xx * dy.sW) : zero;
-                if constexpr (AMAX) am = afi_amax4(am, d[i][j]);
             }
+        if constexpr (AMAX) am = afi_amax4(afi_amax4(afi_amax4(afi_amax4(am, d[0][0]), d[0][1]), d[1][0]), d[1][1]);
         f32x4 a[4][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -460,10 +465,15 @@ __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, i
                 if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
                     v = *(const f32x4*)(base + (long long)yy * x.sH + (long long)xx * x.sW);
                     if constexpr (BN) v = afi_bn_lrelu(v, mu, is, ga, be, AFI_LRELU_SLOPE);
-                    if constexpr (AMAX) am = afi_amax4(am, v);
                 }
                 d[i][j] = v;
             }
+        }
+        if constexpr (AMAX) {                                // (behind ALL the loads: a use inside a load's own branch makes every load wait for itself)
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) am = afi_amax4(am, d[i][j]);
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) wino4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);      // columns
