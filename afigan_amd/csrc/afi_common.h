@@ -83,6 +83,9 @@ struct AfiPixGemm {
     // bimg_stage0 = c_lo / 32 * ntaps of that weight's image; bimg_nstages = stages per N tile of the whole image.
     const unsigned char* Bimg; int bimg_stage0, bimg_nstages;
     AfiBnLoad a_bn;                                        // Winograd form only: A is read through this affine + LeakyReLU (every other form refuses it)
+    // Winograd form under the f16x3 arithmetic only: the largest magnitude of A (device memory).  a_amax_known = 1: its producer has published it
+    // (the input transform then writes the planes split into fp16 pieces); 0: a zero-filled slot the input transform raises; null: a slot of the call's pool
+    float* a_amax; int a_amax_known;
 };
 #define AFI_WK6_STAGE_BYTES 6144
 // one weight (or weight view) to turn into such an image: the B addressing of AfiPixGemm (b_rc = 0: row n at B + n*b_sRow + tap*b_sTap + c;

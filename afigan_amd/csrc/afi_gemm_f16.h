@@ -25,42 +25,7 @@
 // fp32's range).
 #pragma once
 
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-// (AfiF16Bound: afi_common.h)
-
-// the power of two s with bound * s in [2^14, 2^15) (bound > 0, finite); bounds below 2^-100 (and zero) take s = 2^114
-__device__ __forceinline__ float afi_f16_scale(float bound) {
-    unsigned e = (__float_as_uint(bound) >> 23) & 0xffu;
-    e = e < 27u ? 27u : e;
-    return __uint_as_float((268u - e) << 23);
-}
-__device__ __forceinline__ float afi_pow2_inverse(float s) { return __uint_as_float((254u << 23) - __float_as_uint(s)); }   // s a normal power of two
-
-// a pair of values and their (power-of-two) scale -> packed fp16 pieces of x * s (x0 in the low half).  The residual is formed by one
-// fused multiply-add per element straight from the packed hi (v_fma_mix_f32 reads either half of it as an fp16 source): x * s is exact,
-// so fma(x, s, -hi) is the same number as (x * s) - hi
-__device__ __forceinline__ void afi_split2_f16_pair(float x0, float x1, float s, unsigned& hi, unsigned& lo) {
-    // four instructions per pair (left to itself hipcc forms hi twice, packed and per element: seven): v_fma_mixlo/hi_f16 round
-    // fma(f32, f32, f16-or-f32) to fp16 into the low / high half of the destination and keep the other half
-    unsigned h, l;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
-    hi = h; lo = l;
-}
-// eight values (two float4) -> the hi and lo MFMA operands / 16-byte LDS rows
-__device__ __forceinline__ void afi_split2_f16_x8(f32x4 v0, f32x4 v1, float s, u32x4& h, u32x4& l) {
-    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    afi_split2_f16_pair(v0[0], v0[1], s, h0, l0);
-    afi_split2_f16_pair(v0[2], v0[3], s, h1, l1);
-    afi_split2_f16_pair(v1[0], v1[1], s, h2, l2);
-    afi_split2_f16_pair(v1[2], v1[3], s, h3, l3);
-    h = u32x4{h0, h1, h2, h3};
-    l = u32x4{l0, l1, l2, l3};
-}
+#include "afi_f16_split.h"
 __device__ __forceinline__ f16x8 afi_tr_frag_f16(const unsigned char* base, int off_lo, int off_hi) {
     return __builtin_bit_cast(f16x8, afi_tr_frag(base, off_lo, off_hi));
 }
@@ -132,12 +97,31 @@ __global__ __launch_bounds__(256) void afi_split_f16_tiles_kernel(const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// NT GEMM  C[g][m][n] = sum_k A[g][m][k] B[g][n][k]: the structure of afi_gemm_nt_bf16_dma_kernel (afi_gemm_bf16.h: both operands staged by
-// LDS-DMA, A verbatim as fp32 with the swizzle on the source address and split when a wave reads its fragment, B pre-split in LDS-image
-// order; v_mfma_f32_16x16x32, four blocks per CU, one stage buffer and two barriers per stage) with two fp16 pieces: a 32 KB stage
-// (16 A + 2 x 8 B), 48 MFMAs per wave and stage instead of 96, the scale in the split and its inverse in the epilogue.
+// NT GEMM  C[g][m][n] = sum_k A[g][m][k] B[g][n][k].  Tile, LDS images, fragment reads and epilogue of afi_gemm_nt_bf16_dma_kernel
+// (afi_gemm_bf16.h: both operands staged by LDS-DMA, A verbatim as fp32 with the swizzle on the source address and split when a wave
+// reads its fragment, B pre-split in LDS-image order; v_mfma_f32_16x16x32, four blocks per CU, one 32 KB stage buffer: 16 A + 2 x 8 B)
+// with two fp16 pieces: 48 MFMAs per wave and stage instead of 96, the scale in the split and its inverse in the epilogue.
+//
+// With half the MFMAs per stage the stage's fixed chain shows: ablations of the first version (the bf16 kernel's loop: wait for the whole
+// stage, barrier, read + split + multiply, barrier, request the next stage; tools/micro/nt_f16_ablate.py, 36 x 8448 x 1024 x 1024: 1792 us)
+// ran 1274 us without the DMA behind the first stage, 1368 without the split, 1101 without the MFMAs and 1544 with L2-resident operands:
+// a block's DMA wait, its split and its MFMAs ran one after the other, and four blocks per CU did not interleave them away.  So the loop
+// is ordered for overlap INSIDE the block, with the same buffer and the same two barriers:
+//   * a wave's A rows are its own (4 x 1 waves of 32 x 128), so the wave that reads them also fetches them (DMA instruction i of wave w
+//     fills rows 32 w + 8 i ..): no barrier guards A, the wave's own vmcnt does, and A of stage k + 1 is requested as soon as the wave
+//     holds stage k's fragments in registers -- it arrives under the stage's 48 MFMAs;
+//   * B of stage k + 1 is requested behind the second barrier as before, and what waits for it is only the multiply phase: A's fragment
+//     reads and the split of stage k + 1 run first, under a counted vmcnt (A was requested earlier, requests complete in order).
+// The split itself: nine full-rate instructions per pair (v_cvt_pk_f16_f32 and friends) beat four v_fma_mix{lo,hi}_f16 (1648 against
+// 1792 us): the mix forms do not issue at the full rate.
+// ABL (micro-benchmark ablations, a bit mask; results wrong but for bit 4): 1 every block reads the operands of tile (0, 0) (L2-resident),
+// 2 no DMA behind the first stage, 4 no MFMAs, 8 no split (the fragment registers are reinterpreted), 16 the split from v_fma_mix instructions
 // ------------------------------------------------------------------------------------------------
-template <int MINW>
+// APRE: A arrives already split by its producer (winograd.hip, afi_store_split4): a row's 128 bytes per stage are [hi: 32 x fp16 | lo: 32 x fp16]
+// instead of 32 fp32, staged by the same DMA pattern into the same 16 KB image (16-byte chunk c of row r at c ^ ((r >> 1) & 7): conflict-free
+// for the two fragment reads of a lane, chunk q of hi and chunk 4 + q of lo; exhaustive search over the linear swizzles), and the loop
+// has no conversion instruction left.
+template <int MINW, int ABL = 0, bool APRE = false>
 __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_f16x3_kernel(const AfiGemmNT p, const AfiF16Bound ab, int ntile_n, int ntile_m, int chunk) {
     constexpr int BM = 128, BN = 128, BK = 32;
     constexpr int MI = 2, NI = 8;                            // 4 x 1 waves of 32 x 128: a wave's A rows are its own
@@ -156,22 +140,28 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_f16x3_kernel(const AfiG
     const int nK = p.K / BK;
     typedef const __attribute__((address_space(1))) void* gptr;
     typedef __attribute__((address_space(3))) void* lptr;
-    const int a_row0 = 8 * wave + (lane >> 3);
-    const int a_swz = ((lane >> 4) & 1) | ((wave & 1) << 2);                    // ((row >> 1) & 5) of every row this lane fills
-    const float* a_src = p.A + (m0 + a_row0) * p.K + 4 * ((lane & 7) ^ a_swz);
-    const long long a_step = 32LL * p.K;                     // 32 rows per DMA instruction
+    // A: DMA instruction i of wave w fills rows 32 w + 8 i .. + 7 -- the wave's own rows (lane >> 3 = row, lane & 7 = physical chunk; source
+    // chunk = physical ^ swizzle, ((row >> 1) & 5) of row 32 w + 8 i + (lane >> 3): bit 0 = lane bit 4, bit 2 = i bit 0)
+    const float* a_src = p.A + (((ABL & 1) ? 0 : m0) + 32 * wave + (lane >> 3)) * p.K;
+    // (APRE: ((row >> 1) & 7) = lane bits 4..5 | i bit 0 << 2)
+    const int a_c0 = 4 * ((lane & 7) ^ (APRE ? (lane >> 4) : ((lane >> 4) & 1))), a_c1 = a_c0 ^ 16;                   // even / odd i (in floats)
+    const long long a_step = 8LL * p.K;
     const unsigned char* b_hdr = (const unsigned char*)p.B;
-    const unsigned char* b_src = b_hdr + AFI_F16_HDR_BYTES + (((long long)plane * ntile_n + tile_n) * nK) * (long long)(2 * TILE_B) + 16 * tid;
-    auto issue = [&](int kc) {
-        unsigned char* dst = smem_b;
+    const unsigned char* b_src = b_hdr + AFI_F16_HDR_BYTES + ((ABL & 1) ? 0 : (((long long)plane * ntile_n + tile_n) * nK)) * (long long)(2 * TILE_B) + 16 * tid;
+    auto issue_a = [&](int kc) {
+        if ((ABL & 2) && kc > 0) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr)(a_src + i * a_step + kc * BK), (lptr)(dst + (4 * i + wave) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr)(b_src + (long long)kc * (2 * TILE_B) + i * 4096), (lptr)(dst + OFF_B + (4 * i + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr)(a_src + i * a_step + kc * BK + ((i & 1) ? a_c1 : a_c0)), (lptr)(smem_b + (4 * wave + i) * 1024), 16, 0, 0);
     };
-    issue(0);
+    auto issue_b = [&](int kc) {
+        if ((ABL & 2) && kc > 0) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr)(b_src + (long long)kc * (2 * TILE_B) + i * 4096), (lptr)(smem_b + OFF_B + (4 * i + wave) * 1024), 16, 0, 0);
+    };
+    issue_a(0);
+    issue_b(0);
     // the plane's scales (block-uniform: scalar loads, under the first stage's flight)
     const float s_a = afi_f16_scale(ab.amax[(long long)plane * ab.stride] * ab.cmul[plane]);
     const float inv_a = afi_pow2_inverse(s_a), inv_b = afi_pow2_inverse(((const float*)b_hdr)[plane]);
@@ -182,32 +172,56 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_f16x3_kernel(const AfiG
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     int fa_off[MI], fb_off[NI];
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) { const int row = (wave * MI + mi) * 16 + l15; fa_off[mi] = row * 128 + (((2 * lq) ^ ((row >> 1) & 5)) << 4); }
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = (wave * MI + mi) * 16 + l15;
+        fa_off[mi] = APRE ? row * 128 + ((lq ^ ((row >> 1) & 7)) << 4) : row * 128 + (((2 * lq) ^ ((row >> 1) & 5)) << 4);
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) { const int row = ni * 16 + l15; fb_off[ni] = OFF_B + row * 64 + (((lq ^ (-(row >> 2))) & 3) << 4); }
     auto mfma = [](f16x8 x, f16x8 y, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0); };
 
+    // vmcnt bookkeeping (requests complete in order; 4 DMA instructions per operand and stage): at the top of stage k the wave has at most
+    // A(k), B(k) outstanding -> vmcnt(4) = A(k) has landed; behind the request of A(k + 1): B(k), A(k + 1) -> vmcnt(4) = B(k) has landed
+    // (vmcnt(0) in the last stage, where nothing is requested behind it).  Nothing but these waits orders a ds_read behind an LDS-DMA.
     for (int kc = 0; kc < nK; ++kc) {
-        // the stage has landed: this wave's DMA by the explicit wait, the other waves' by the barrier behind it.  (Nothing else orders a
-        // ds_read behind a pending LDS-DMA; hipcc puts this wait in front of the barrier of afi_gemm_nt_bf16_dma_kernel by itself and did
-        // NOT in this kernel -- every stage after the first was read while it was still arriving.)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        const bool more = kc + 1 < nK;
+        if (ABL & 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         const unsigned char* sm = smem_b;
         f16x8 ah[MI], al[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+            if (APRE) {
+                ah[mi] = *(const f16x8*)(sm + fa_off[mi]);
+                al[mi] = *(const f16x8*)(sm + (fa_off[mi] ^ 64));
+                continue;
+            }
             const f32x4 c0 = *(const f32x4*)(sm + fa_off[mi]);
             const f32x4 c1 = *(const f32x4*)(sm + (fa_off[mi] ^ 16));
             u32x4 h, l;
-            afi_split2_f16_x8(c0, c1, s_a, h, l);
+            if (ABL & 8) { h = __builtin_bit_cast(u32x4, c0); l = __builtin_bit_cast(u32x4, c1); }
+            else if (ABL & 16) afi_split2_f16_x8(c0, c1, s_a, h, l);
+            else afi_split2_f16_x8_cvt(c0, c1, s_a, h, l);
             ah[mi] = __builtin_bit_cast(f16x8, h);
             al[mi] = __builtin_bit_cast(f16x8, l);
         }
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the wave's A rows are in registers: their LDS rows are free
+            issue_a(kc + 1);
+        }
+        // (pin the split in front of the wait for B: left alone, hipcc sinks it behind the wait and the barrier, where nothing covers it)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) asm volatile("" :: "v"(ah[mi]), "v"(al[mi]));
+        if (more && !(ABL & 2)) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // every wave's share of B(k) has landed
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const f16x8 bh = *(const f16x8*)(sm + fb_off[ni]);
             const f16x8 bl = *(const f16x8*)(sm + TILE_B + fb_off[ni]);
+            if (ABL & 4) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) asm volatile("" :: "v"(al[mi]), "v"(ah[mi]), "v"(bh), "v"(bl));
+                continue;
+            }
             // smallest terms first; consecutive MFMAs go to different accumulators
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
@@ -216,8 +230,9 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_f16x3_kernel(const AfiG
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
         }
-        __syncthreads();
-        if (kc + 1 < nK) issue(kc + 1);                      // the buffer is free again
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's B reads have returned
+        __builtin_amdgcn_s_barrier();                        // ... and every wave's: B's buffer is free
+        if (more) issue_b(kc + 1);
     }
     // epilogue: accumulators / (s_a s_b) -> LDS -> float4 rows of C, 16 rows of every wave per pass
     constexpr int LDC = BN + 4, C_F4 = BN / 4;
@@ -236,6 +251,135 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_f16x3_kernel(const AfiG
             __builtin_nontemporal_store(*(const f32x4*)(Cs + rloc * LDC + 4 * c4), (f32x4*)(c_base + (long long)rl * p.N + 4 * c4));
         }
         if (mi + 1 < MI) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same GEMM on a 256 x 256 tile: SIXTEEN waves of the kernel above in one 1024-thread block (8 x 2 waves of 32 x 128; the per-wave
+// work -- fragment reads, split, 48 MFMAs per stage, 64 accumulator registers, 4 waves per SIMD -- is the same).  Why: the ablations of the
+// 128 x 128 kernel (tools/micro/nt_f16_ablate.py, 36 x 8448 x 1024 x 1024, 1790 us) say that with three products per k-step the kernel
+// has TWO resources that each need ~1100 us: the DMA transfers alone (no MFMAs, no split) take 1085 us -- 20 GB from L2 into LDS at
+// 18.4 TB/s, the chip's LDS-DMA ceiling for L2-resident rows --, the MFMAs with their fragment reads and barriers alone 1138 us.  Four
+// independent 128 x 128 blocks per CU fetch each operand tile twice into the same CU; one 256 x 256 block fetches it once: half the bytes
+// per product.  Two 64 KB stage buffers ([A fp32: 256 rows x 128 B][B hi: 256 rows x 64 B][B lo]), ONE barrier per stage: it says that
+// stage k has landed for every wave and that every wave has left stage k - 1's buffer, so stage k + 1 is requested right behind it (four
+// DMA instructions per wave) and lands under the 48 MFMAs of stage k.  The epilogue stages a 16-row strip per wave (16 x 8448 B).
+// One block per CU.  Rows beyond a plane's end (rows_per_plane is a multiple of 128, not 256) are read from the plane's last row and never
+// stored.  B comes from the two 128-column images 2 tile_n, 2 tile_n + 1 ([hi 8 KB | lo 8 KB] per stage each).
+// ------------------------------------------------------------------------------------------------
+template <bool APRE>
+__global__ __launch_bounds__(1024, 4) void afi_gemm_nt_f16x3_w16_kernel(const AfiGemmNT p, const AfiF16Bound ab, int ntile_n, int ntile_m, int chunk, int tiles_per_plane) {
+    constexpr int BM = 256, BK = 32;
+    constexpr int MI = 2, NI = 8;
+    constexpr int TILE_A = BM * 128;                         // fp32 image, 32 KB
+    constexpr int HALF_B = 128 * 64;                         // one fp16 piece of one 128-column image, 8 KB
+    constexpr int PART_B = 256 * 64;                         // one piece of the block's 256 columns, 16 KB
+    constexpr int OFF_B = TILE_A;
+    constexpr int STAGE = TILE_A + 2 * PART_B;               // 64 KB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int tile_n = jb % ntile_n, tile_m = xcd * chunk + jb / ntile_n;
+    if (tile_m >= ntile_m) return;
+    const int plane = tile_m / tiles_per_plane, tp = tile_m - plane * tiles_per_plane;
+    const long long row0 = (long long)plane * p.rows_per_plane + (long long)tp * BM;
+    const int valid = (int)(p.rows_per_plane - (long long)tp * BM < BM ? p.rows_per_plane - (long long)tp * BM : BM);      // 128 or 256 rows of this tile exist
+    const int n0 = tile_n * 256;
+    const int nK = p.K / BK;
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    // A: DMA instruction i (0, 1) of wave w fills KB 2 w + i of the image = rows 8 (2 w + i) .. + 7 (lane >> 3 = row, lane & 7 = physical chunk;
+    // source chunk = physical ^ ((row >> 1) & 5): bit 0 = lane bit 4, bit 2 = i)
+    int ar0 = 16 * wave + (lane >> 3), ar1 = ar0 + 8;
+    ar0 = ar0 < valid ? ar0 : valid - 1; ar1 = ar1 < valid ? ar1 : valid - 1;
+    // (APRE, afi_gemm_nt_f16x3_kernel: swizzle (row >> 1) & 7 = lane bits 4..5 | i << 2)
+    const float* a_src0 = p.A + (row0 + ar0) * p.K + 4 * ((lane & 7) ^ (APRE ? (lane >> 4) : ((lane >> 4) & 1)));
+    const float* a_src1 = p.A + (row0 + ar1) * p.K + 4 * ((lane & 7) ^ (APRE ? (lane >> 4) : ((lane >> 4) & 1)) ^ 4);
+    // B: DMA instruction j (0, 1) of wave w fills KB 16 j + w of the stage's B region: piece j, 128-column half w >> 3, KB w & 7 of that half
+    const unsigned char* b_hdr = (const unsigned char*)p.B;
+    const long long b_tile = (long long)nK * (2 * HALF_B);   // bytes of one 128-column image of one plane
+    const unsigned char* b_src = b_hdr + AFI_F16_HDR_BYTES + ((long long)plane * (2 * ntile_n) + 2 * tile_n + (wave >> 3)) * b_tile + (wave & 7) * 1024 + 16 * lane;
+    auto issue = [&](int kc) {
+        unsigned char* dst = smem_b + (kc & 1) * STAGE;
+        __builtin_amdgcn_global_load_lds((gptr)(a_src0 + kc * BK), (lptr)(dst + (2 * wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(a_src1 + kc * BK), (lptr)(dst + (2 * wave + 1) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(b_src + (long long)kc * (2 * HALF_B)), (lptr)(dst + OFF_B + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr)(b_src + (long long)kc * (2 * HALF_B) + HALF_B), (lptr)(dst + OFF_B + PART_B + wave * 1024), 16, 0, 0);
+    };
+    issue(0);
+    const float s_a = afi_f16_scale(ab.amax[(long long)plane * ab.stride] * ab.cmul[plane]);
+    const float inv_a = afi_pow2_inverse(s_a), inv_b = afi_pow2_inverse(((const float*)b_hdr)[plane]);
+    f32x4 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int fa_off[MI], fb_off[NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int row = (wm * MI + mi) * 16 + l15;
+        fa_off[mi] = APRE ? row * 128 + ((lq ^ ((row >> 1) & 7)) << 4) : row * 128 + (((2 * lq) ^ ((row >> 1) & 5)) << 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) { const int row = (wn * NI + ni) * 16 + l15; fb_off[ni] = OFF_B + row * 64 + (((lq ^ (-(row >> 2))) & 3) << 4); }
+    auto mfma = [](f16x8 x, f16x8 y, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(x, y, c, 0, 0, 0); };
+
+    for (int kc = 0; kc < nK; ++kc) {
+        // this wave's share of stage k has landed (the wait), every wave's has, and every wave has left stage k - 1's buffer (the barrier).
+        // Nothing but a wave's own vmcnt orders a ds_read behind an LDS-DMA.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kc + 1 < nK) issue(kc + 1);
+        const unsigned char* sm = smem_b + (kc & 1) * STAGE;
+        f16x8 ah[MI], al[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            if (APRE) {
+                ah[mi] = *(const f16x8*)(sm + fa_off[mi]);
+                al[mi] = *(const f16x8*)(sm + (fa_off[mi] ^ 64));
+                continue;
+            }
+            const f32x4 c0 = *(const f32x4*)(sm + fa_off[mi]);
+            const f32x4 c1 = *(const f32x4*)(sm + (fa_off[mi] ^ 16));
+            u32x4 h, l;
+            afi_split2_f16_x8_cvt(c0, c1, s_a, h, l);
+            ah[mi] = __builtin_bit_cast(f16x8, h);
+            al[mi] = __builtin_bit_cast(f16x8, l);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const f16x8 bh = *(const f16x8*)(sm + fb_off[ni]);
+            const f16x8 bl = *(const f16x8*)(sm + PART_B + fb_off[ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's reads of the stage have returned before it can reach the next barrier)
+    }
+    __builtin_amdgcn_s_barrier();                            // every wave has left the stage buffers: they become the C staging area
+    // epilogue: a wave stages 16 of its rows x its 128 columns at a time in its own LDS strip and stores them as float4 rows
+    constexpr int LDC = 128 + 4;
+    float* Cs = (float*)smem_b + wave * 16 * LDC;
+    float* c_base = p.C + row0 * p.N + n0 + wn * 128;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(lq * 4 + r) * LDC + ni * 16 + l15] = (acc[mi][ni][r] * inv_a) * inv_b;
+        const int rbase = (wm * MI + mi) * 16;
+        if (rbase < valid) {                                 // (valid is 128 or 256: whole 16-row groups)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int item = it * 64 + lane, rloc = item >> 5, c4 = item & 31;
+                __builtin_nontemporal_store(*(const f32x4*)(Cs + rloc * LDC + 4 * c4), (f32x4*)(c_base + (long long)(rbase + rloc) * p.N + 4 * c4));
+            }
+        }
     }
 }
 
@@ -295,7 +439,7 @@ __global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_kernel(const AfiGemm
             const f32x4 v0 = op ? b_reg[S][0] : a_reg[S][0], v1 = op ? b_reg[S][1] : a_reg[S][1];
             unsigned char* base = buf + op * 2 * PART + st_off;
             u32x4 h, l;
-            afi_split2_f16_x8(v0, v1, s, h, l);
+            afi_split2_f16_x8_cvt(v0, v1, s, h, l);
             *(u32x4*)base = h; *(u32x4*)(base + PART) = l;
         }
     };
@@ -363,6 +507,148 @@ __global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_kernel(const AfiGemm
     for (int h = 0; h < nH; h += 2) {
         half_stage(S1(), h);
         if (h + 1 < nH) half_stage(S0(), h + 1);             // (uniform)
+    }
+    const bool use_atomic = gridDim.y > 1;
+    float* out = p.dU + (long long)plane * p.M * p.N;
+    const long long ldn = p.N;
+    if (use_atomic) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    __builtin_amdgcn_global_atomic_fadd_f32((__attribute__((address_space(1))) float*)(out + (long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr),
+                                                            (acc[mi][ni][r] * inv_q) * inv_v);
+                }
+    } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float old[NI][16];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    old[ni][r] = out[(long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr];
+                }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + (wm * MI + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    out[(long long)row * ldn + n0 + (wn * NI + ni) * 32 + lr] = old[ni][r] + (acc[mi][ni][r] * inv_q) * inv_v;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The weight-gradient GEMM on operands that arrive ALREADY SPLIT (winograd.hip, afi_store_split4: a row of a plane is
+// [32-channel block][hi: 32 x fp16 | lo: 32 x fp16]): nothing is converted or staged through registers -- four LDS-DMA instructions per
+// wave and half stage copy the [16 k][128 columns] fp16 images of Q hi, Q lo, V hi, V lo (wave w copies image w) with the transposed-read
+// swizzle on the SOURCE address, three 16 KB buffers go round (half stage h + 2 is requested behind the barrier of h, which also says
+// that every wave has left h - 1), fragments by ds_read_b64_tr_b16, 12 MFMAs (32x32x16) per wave and half stage.  One barrier per half stage.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_pre_kernel(const AfiGemmTN p, const AfiF16Bound qb, const AfiF16Bound vb, int ntile_m, int ntile_n, int kper) {
+    constexpr int BM = 128, BN = 128, HK = 16, WN = 2, MI = 2, NI = 2;
+    constexpr int PART = HK * BM * 2;                        // 4 KB: [16 k][128 columns] fp16
+    constexpr int BUF = 4 * PART;                            // [Q hi | Q lo | V hi | V lo]
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    int t;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    }
+    const int tile_n = t % ntile_n; t /= ntile_n;
+    const int tile_m = t % ntile_m; const int plane = t / ntile_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const long long k_begin = (long long)blockIdx.y * kper;
+    const long long k_end = (k_begin + kper < p.rows_per_plane) ? k_begin + kper : p.rows_per_plane;
+    if (k_begin >= k_end) return;                            // (whole block: EXEC stays full for the transposed reads below)
+    const int nH = (int)((k_end - k_begin) / HK);
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    // wave w copies image w: operand w >> 1 (Q, V), piece w & 1 (hi, lo).  DMA instruction i fills k rows 4 i .. 4 i + 3 of the image
+    // (lane >> 4 = row, lane & 15 = physical 16-byte chunk); the image's chunk ch of row r sits at ch ^ (((r & 3) << 2) | ((r >> 2) & 3)),
+    // so the lane fetches logical chunk (lane & 15) ^ ((lane >> 4) << 2 | i): columns 8 ch .. 8 ch + 7 of the tile = 32-channel block ch >> 2,
+    // 16 bytes (ch & 3) of its hi or lo half
+    const int op = wave >> 1, piece = wave & 1;
+    const long long ld = op ? p.N : p.M;                     // floats (= 4-byte units) per row of the operand
+    const unsigned char* src_row = (const unsigned char*)((op ? p.V : p.Q) + ((long long)plane * p.rows_per_plane + k_begin + (lane >> 4)) * ld) +
+                                   (long long)((op ? n0 : m0) >> 5) * 128 + piece * 64;
+    int ch_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int ch = (lane & 15) ^ (((lane >> 4) << 2) | i); ch_off[i] = (ch >> 2) * 128 + (ch & 3) * 16; }
+    const long long row_bytes = ld * 4;
+    auto issue = [&](int h) {
+        unsigned char* dst = smem_b + (h % 3) * BUF + wave * PART;
+        const unsigned char* s0 = src_row + (long long)h * HK * row_bytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr)(s0 + (long long)(4 * i) * row_bytes + ch_off[i]), (lptr)(dst + i * 1024), 16, 0, 0);
+    };
+    issue(0);
+    if (1 < nH) issue(1);
+    const float s_q = afi_f16_scale(qb.amax[(long long)plane * qb.stride] * qb.cmul[plane]);
+    const float s_v = afi_f16_scale(vb.amax[(long long)plane * vb.stride] * vb.cmul[plane]);
+    const float inv_q = afi_pow2_inverse(s_q), inv_v = afi_pow2_inverse(s_v);
+    int fa_off[MI][2], fb_off[NI][2];
+    {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {
+            const int r = 8 * (g >> 1) + 4 * rd + q;
+            const int swz = ((r & 3) << 2) | ((r >> 2) & 3);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) fa_off[mi][rd] = 256 * r + 16 * ((4 * (wm * MI + mi) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) fb_off[ni][rd] = 2 * PART + 256 * r + 16 * ((4 * (wn * NI + ni) + 2 * (g & 1) + (pp >> 1)) ^ swz) + 8 * (pp & 1);
+        }
+    }
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    auto mm = [](f16x8 x, f16x8 y, f32x16 c) -> f32x16 { return __builtin_amdgcn_mfma_f32_32x32x16_f16(x, y, c, 0, 0, 0); };
+
+    for (int h = 0; h < nH; ++h) {
+        // requests complete in order, four per half stage: with h + 1 requested too, vmcnt(4) = half stage h has landed
+        if (h + 1 < nH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // ... for every wave's image; and every wave has left half stage h - 1
+        if (h + 2 < nH) issue(h + 2);
+        const unsigned char* cur = smem_b + (h % 3) * BUF;
+        f16x8 ah[MI], al[MI], bh[NI], bl[NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            ah[mi] = afi_tr_frag_f16(cur, fa_off[mi][0], fa_off[mi][1]);
+            al[mi] = afi_tr_frag_f16(cur + PART, fa_off[mi][0], fa_off[mi][1]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            bh[ni] = afi_tr_frag_f16(cur, fb_off[ni][0], fb_off[ni][1]);
+            bl[ni] = afi_tr_frag_f16(cur + PART, fb_off[ni][0], fb_off[ni][1]);
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(al[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bl[ni], acc[mi][ni]);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mm(ah[mi], bh[ni], acc[mi][ni]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (the wave's fragment reads have returned before it reaches the next barrier)
     }
     const bool use_atomic = gridDim.y > 1;
     float* out = p.dU + (long long)plane * p.M * p.N;

@@ -499,14 +499,38 @@ __global__ void afi_bn_stats_finalize_kernel(const float* __restrict__ partial, 
 }
 
 // y = lrelu_slope((x - mean) * invstd * gamma + beta); slope 1 = the plain affine (BiFPN's norms have no activation behind them)
+// largest magnitude of what a pass WRITES, raised into a zero-filled slot as a by-product (the f16x3 arithmetic of the Winograd GEMMs scales
+// its operands by a power of two derived from it, csrc/afi_gemm_f16.h; the slot is then known BEFORE the next convolution's transforms
+// run, which lets them write their planes already split into fp16 pieces).  One conditional atomic max per block.
+__device__ __forceinline__ float afi_ew_amax4(float m, f32x4 v) {
+    return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+__device__ __forceinline__ void afi_ew_amax_publish(float m, float* slot) {
+    __shared__ float red[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const unsigned bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load((const unsigned*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) (void)atomicMax((unsigned*)slot, bits);
+    }
+}
+template <bool AMAX>
 __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ mean,
                                           const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                          long long P, int C, float slope) {
+                                          long long P, int C, float slope, float* amax) {
     const long long total4 = P * C / 4;
     const int C4 = C / 4;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    auto apply = [slope](f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) { return afi_bn_lrelu(v, mu, is, ga, be, slope); };
+    float am = 0.f;
+    auto apply = [slope, &am](f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be) {
+        const f32x4 r = afi_bn_lrelu(v, mu, is, ga, be, slope);
+        if (AMAX) am = afi_ew_amax4(am, r);
+        return r;
+    };
     if (stride % C4 == 0) {
         // a thread stays on one channel group: its four parameter vectors are loaded once, and four independent 16-B loads are
         // kept in flight per thread (a streaming kernel needs ~37 KB outstanding per CU to cover the HBM latency)
@@ -521,6 +545,7 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
             for (int u = 0; u < 4; ++u) *(f32x4*)(y + (i + u * stride) * 4) = apply(v[u], mu, is, ga, be);
         }
         for (; i < total4; i += stride) *(f32x4*)(y + i * 4) = apply(*(const f32x4*)(x + i * 4), mu, is, ga, be);
+        if (AMAX) afi_ew_amax_publish(am, amax);
         return;
     }
     for (; i < total4; i += stride) {
@@ -528,6 +553,7 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
         *(f32x4*)(y + i * 4) = apply(*(const f32x4*)(x + i * 4), *(const f32x4*)(mean + c), *(const f32x4*)(invstd + c),
                                      *(const f32x4*)(gamma + c), *(const f32x4*)(beta + c));
     }
+    if (AMAX) afi_ew_amax_publish(am, amax);
 }
 
 // BatchNorm backward finalize: dgamma += sum g*xhat ; dbeta += sum g ; stash the two sums for the apply pass
@@ -541,23 +567,26 @@ __global__ void afi_bn_bwd_finalize_kernel(const float* __restrict__ partial, in
 }
 // dx = gamma * invstd * (g - sum_g/P - xhat * sum_gx/P)   (in place on g allowed)
 // MASK: g is the gradient w.r.t. the activation; it is first multiplied by the LeakyReLU' mask recomputed from x (see MODE 3 above)
-template <bool MASK>
+template <bool MASK, bool AMAX = false>
 __global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dx,
                                         const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                        const float* __restrict__ sums, long long P, int C, const float* __restrict__ beta, float slope) {
+                                        const float* __restrict__ sums, long long P, int C, const float* __restrict__ beta, float slope, float* amax) {
     const long long total4 = P * C / 4;
     const int C4 = C / 4;
     const float inv_n = 1.f / (float)P;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    auto apply = [inv_n, slope](f32x4 gv, f32x4 xv, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be, f32x4 sg, f32x4 sgx) {
+    float am = 0.f;
+    auto apply = [inv_n, slope, &am](f32x4 gv, f32x4 xv, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be, f32x4 sg, f32x4 sgx) {
         if (MASK) {
             const f32x4 z = afi_bn_affine(xv, mu, is, ga, be);
 #pragma unroll
             for (int j = 0; j < 4; ++j) gv[j] = z[j] > 0.f ? gv[j] : gv[j] * slope;
         }
         const f32x4 xh = (xv - mu) * is;
-        return ga * is * (gv - sg * inv_n - xh * (sgx * inv_n));
+        const f32x4 r = ga * is * (gv - sg * inv_n - xh * (sgx * inv_n));
+        if (AMAX) am = afi_ew_amax4(am, r);
+        return r;
     };
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if (stride % C4 == 0) {          // one channel group per thread: parameters hoisted, two element pairs in flight (see bn_apply)
@@ -573,6 +602,7 @@ __global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float
         }
         for (; i < total4; i += stride)
             *(f32x4*)(dx + i * 4) = apply(*(const f32x4*)(g + i * 4), *(const f32x4*)(x + i * 4), mu, is, ga, be, sg, sgx);
+        if (AMAX) afi_ew_amax_publish(am, amax);
         return;
     }
     for (; i < total4; i += stride) {
@@ -580,6 +610,7 @@ __global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float
         *(f32x4*)(dx + i * 4) = apply(*(const f32x4*)(g + i * 4), *(const f32x4*)(x + i * 4), *(const f32x4*)(mean + c), *(const f32x4*)(invstd + c),
                                       *(const f32x4*)(gamma + c), MASK ? *(const f32x4*)(beta + c) : zero, *(const f32x4*)(sums + c), *(const f32x4*)(sums + C + c));
     }
+    if (AMAX) afi_ew_amax_publish(am, amax);
 }
 // bias gradient finalize: db += alpha * sum
 __global__ void afi_colsum_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float alpha, float* __restrict__ db) {
@@ -634,16 +665,19 @@ int afi_launch_bn_stats_from_partials(const double* partial, int rows, long long
                        var_out, running_mean, running_var, num_batches_tracked, eps, momentum);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
+// amax (optional): raised to the largest magnitude of y (zero-filled by the caller)
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                              long long P, int C, hipStream_t st, float slope) {
+                              long long P, int C, hipStream_t st, float slope, float* amax) {
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_bn_apply_lrelu_kernel, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, x, y, mean, invstd, gamma, beta, P, C, slope);
+    if (amax) hipLaunchKernelGGL(afi_bn_apply_lrelu_kernel<true>, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, x, y, mean, invstd, gamma, beta, P, C, slope, amax);
+    else hipLaunchKernelGGL(afi_bn_apply_lrelu_kernel<false>, dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, x, y, mean, invstd, gamma, beta, P, C, slope, amax);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 // mask_beta != nullptr: g is the gradient w.r.t. lrelu_slope(BN(x)) and the LeakyReLU' mask is recomputed from x (mask_beta = the norm's beta)
+// amax (optional): raised to the largest magnitude of dx (zero-filled by the caller)
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma,
                       float* dgamma, float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st, const float* mask_beta,
-                      float slope) {
+                      float slope, float* amax) {
     if (P <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     int chunks, rpc; afi_red_geometry(P, chunks, rpc);
     float* sums = scratch + (long long)AFI_RED_MAX_CHUNKS * 4 * C;
@@ -651,8 +685,10 @@ int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* me
     if (mask_beta) hipLaunchKernelGGL((afi_colred_partial_kernel<3>), rgrid, dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch, gamma, mask_beta, slope);
     else hipLaunchKernelGGL((afi_colred_partial_kernel<1>), rgrid, dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch, (const float*)nullptr, (const float*)nullptr, 1.f);
     hipLaunchKernelGGL(afi_bn_bwd_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, C, gscale, dgamma, dbeta, sums);
-    if (mask_beta) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, mask_beta, slope);
-    else hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f);
+    if (mask_beta && amax) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true, true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, mask_beta, slope, amax);
+    else if (mask_beta) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, mask_beta, slope, amax);
+    else if (amax) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false, true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f, amax);
+    else hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f, amax);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st) {

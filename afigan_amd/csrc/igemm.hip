@@ -858,7 +858,15 @@ AfiF16Bound afi_f16_bound(const float* amax, int kind) {
     }
     return b;
 }
-int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st) {
+// smallest number of 256 x 256 tiles from which the NT GEMM takes the large-tile kernel (0: never); a process-wide A/B knob of the
+// micro-benchmarks (afi_debug_set_nt256_min_tiles), not an option of the product path
+static long long g_nt256 = 512;
+static int g_nt_abl = 0;
+extern "C" void afi_debug_set_nt256_min_tiles(long long v) { g_nt256 = v; }
+extern "C" void afi_debug_set_nt_ablation(int v) { g_nt_abl = v; }
+// a_pre: A holds the planes already split into fp16 pieces (winograd.hip, afi_store_split4) with the scales of `ab`
+int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st,
+                             bool a_pre) {
     if (planes <= 0 || planes > 36 || rows_per_plane <= 0 || N <= 0 || K <= 0 || !ab.amax) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
     AfiGemmNT g{A, (const float*)Bimg, C, rows_per_plane, planes, N, K};
@@ -868,11 +876,38 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
     const size_t lds = stage > epi ? stage : epi;
     ProfScope prof(st, 21, 2.0 * (double)M * N * K);
     prof.m = M; prof.n = N; prof.k = K; prof.split = 2; prof.planes = planes;
-    hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    // the 256 x 256 tile (half the operand bytes per product) where it fills the chip: 256-column multiples, at least two rounds of CUs
+    const int tpp = afi_cdiv(rows_per_plane, 256);
+    const long long tiles256 = (long long)planes * tpp * (N / 256);
+    if (g_nt256 && !(N % 256) && tiles256 >= g_nt256) {
+        if (!afi_opt_in_big_lds(a_pre ? (const void*)afi_gemm_nt_f16x3_w16_kernel<true> : (const void*)afi_gemm_nt_f16x3_w16_kernel<false>)) return AFI_ERR_LAUNCH;
+        const int ntm2 = planes * tpp, ntn2 = N / 256, chunk2 = afi_cdiv(ntm2, 8);
+        prof.split = 3;
+        if (a_pre) hipLaunchKernelGGL(afi_gemm_nt_f16x3_w16_kernel<true>, dim3(chunk2 * ntn2 * 8), dim3(1024), 16 * 16 * 132 * 4, st, g, ab, ntn2, ntm2, chunk2, tpp);
+        else hipLaunchKernelGGL(afi_gemm_nt_f16x3_w16_kernel<false>, dim3(chunk2 * ntn2 * 8), dim3(1024), 16 * 16 * 132 * 4, st, g, ab, ntn2, ntm2, chunk2, tpp);
+        return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+    }
+    if (a_pre) {
+        hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 0, true>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+        return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+    }
+    if (g_nt_abl == 1) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 2) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 2>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 4) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 8) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 8>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 16) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 16>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 12) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 12>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 6) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 6>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 14) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 14>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 10) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 10>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 20) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 20>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (g_nt_abl == 24) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 24>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
+// pre: Q and V hold the planes already split into fp16 pieces
 int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
-                             hipStream_t st) {
+                             hipStream_t st, bool pre) {
     if (planes <= 0 || planes > 36 || rows_per_plane <= 0 || M <= 0 || N <= 0 || !qb.amax || !vb.amax) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
     const int ntm = M / 128, ntn = N / 128;
@@ -897,7 +932,8 @@ int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int plan
     AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
     ProfScope prof(st, 22, 2.0 * (double)rows_per_plane * planes * M * N);
     prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK; prof.planes = planes;
-    hipLaunchKernelGGL(afi_gemm_tn_f16x3_kernel, dim3((unsigned)tiles, splitK), dim3(256), 2u * 4u * 4096u, st, g, qb, vb, ntm, ntn, kper);
+    if (pre) hipLaunchKernelGGL(afi_gemm_tn_f16x3_pre_kernel, dim3((unsigned)tiles, splitK), dim3(256), 3u * 4u * 4096u, st, g, qb, vb, ntm, ntn, kper);
+    else hipLaunchKernelGGL(afi_gemm_tn_f16x3_kernel, dim3((unsigned)tiles, splitK), dim3(256), 2u * 4u * 4096u, st, g, qb, vb, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 int afi_launch_pix_gemm_sk(const AfiPixGemm& p, int b_rc, hipStream_t st);   // smallmap.hip

@@ -21,9 +21,10 @@ int afi_launch_split_f16_tiles(const float* B, void* out, int planes, int N, int
 long long afi_f16_image_bytes(int planes, int N, int K);
 int afi_launch_absmax_planes(const float* X, long long per_plane, int planes, float* out, hipStream_t st);
 AfiF16Bound afi_f16_bound(const float* amax, int kind);    // kind: 0 exact per-plane maxima, 1 / 2 F(2x2) / F(4x4) input planes, 3 / 4 F(2x2) / F(4x4) dY planes
-int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st);
+int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st,
+                             bool a_pre = false);
 int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
-                             hipStream_t st);
+                             hipStream_t st, bool pre = false);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
 int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // igemm.hip -> smallmap.hip
 int afi_launch_wgrad_gemm_group6(const AfiWgradGemm* probs, int n, hipStream_t st);            // the wide group on the bf16 matrix cores (bf16x6)
@@ -50,10 +51,10 @@ int afi_launch_bn_stats_from_partials(const double* partial, int rows, long long
 int afi_wino_stats_rows(long long T, int C);               // winograd.hip: rows of fp64 partials a STATS output transform writes (0: not fused)
 #define AFI_STATS_MAX_ROWS 1024
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
-                              long long P, int C, hipStream_t st, float slope = AFI_LRELU_SLOPE);
+                              long long P, int C, hipStream_t st, float slope = AFI_LRELU_SLOPE, float* amax = nullptr);
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                       float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st, const float* mask_beta = nullptr,
-                      float slope = AFI_LRELU_SLOPE);
+                      float slope = AFI_LRELU_SLOPE, float* amax = nullptr);
 int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st);
 int afi_launch_stencil9_sum(const float* d9, int ld, const float* bias, float* out, int N, int H, int W, hipStream_t st);
 int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, int H, int W, hipStream_t st);
@@ -66,14 +67,16 @@ int afi_launch_dwconv3x3(AfiView x, int N, int H, int W, int C, const float* w, 
 int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out, hipStream_t st);
 int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st);
 int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
-int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr, float* amax = nullptr);
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr, float* amax = nullptr,
+                           const AfiF16Bound* pre = nullptr);
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
-int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr, float* amax = nullptr);
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr, float* amax = nullptr,
+                           const AfiF16Bound* pre = nullptr);
 int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
-int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0, float* amax = nullptr);
+int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0, float* amax = nullptr, const AfiF16Bound* pre = nullptr);
 int afi_launch_wino4_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
-int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0, float* amax = nullptr);
+int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0, float* amax = nullptr, const AfiF16Bound* pre = nullptr);
 int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
 int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, int C, const float* bias, float alpha, AfiView out, AfiView z,
                            hipStream_t st);
@@ -144,6 +147,9 @@ struct afi_ctx {
 };
 static inline long long afi_opt(const afi_ctx* cx, int o) { return cx ? cx->opt.v[o] : kDefaultOptions.v[o]; }
 static inline int afi_default_dtype() { return AFI_DTYPE_DEFAULT; }
+// micro-benchmark A/B knob (process-wide, not an option of the product path): 0 = no transform writes its planes split, whatever is known
+static int g_presplit = 1;
+extern "C" void afi_debug_set_presplit(int v) { g_presplit = v; }
 static inline bool afi_dtype_ok(int d) { return d == AFI_DTYPE_F32 || d == AFI_DTYPE_BF16 || d == AFI_DTYPE_F16X3 || d == AFI_DTYPE_BF16X3 || d == AFI_DTYPE_BF16X6; }
 // the small-map schedule of the interpolator (csrc/smallmap.hip) has one emulated-fp32 form, six bf16 products on pre-split weight images;
 // both fp32-grade settings of the big GEMMs take it
@@ -440,16 +446,23 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
                    : afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
         if (dma) AFI_TRY(f16 ? afi_launch_split_f16_tiles(U, Usp, np, Nc, K, st) : afi_launch_split_bf16_tiles(U, Usp, np, Nc, K, dtype, st));
     }
+    // f16x3: the largest magnitude of A.  g.a_amax given and known (its producer published it): the transform writes the planes already
+    // split into fp16 pieces; given and not known: a zero-filled slot of the caller's that the transform raises (the caller keeps it, e.g. for
+    // the backward pass); not given: a slot of the call's pool.
     const bool want_amax = dma && f16;
-    if (want_amax && !(amax = wino_amax_take(cx, ws, ws_floats, 1, st))) return AFI_ERR_LAUNCH;
+    const bool a_pre = g_presplit && want_amax && g.a_amax && g.a_amax_known && nph == 1 && !(g.Ck & 31) && !g.a_bn.mean;
+    if (want_amax && !(amax = g.a_amax ? g.a_amax : wino_amax_take(cx, ws, ws_floats, 1, st))) return AFI_ERR_LAUNCH;
+    const AfiF16Bound abound = afi_f16_bound(amax, f4 ? 2 : 1);
     for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
         AfiView a = g.A;
         if (nph == 4) { a.p += (ph >> 1) * g.A.sH + (ph & 1) * g.A.sW; a.sH *= 2; a.sW *= 2; }
-        AFI_TRY(f4 ? afi_launch_wino4_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn, want_amax ? amax : nullptr)
-                   : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn, want_amax ? amax : nullptr));
+        // (a caller's not-yet-known slot is raised under every arithmetic: a later pass may read it)
+        float* raise = g.a_amax ? (g.a_amax_known ? nullptr : g.a_amax) : (want_amax ? amax : nullptr);
+        AFI_TRY(f4 ? afi_launch_wino4_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn, raise, a_pre ? &abound : nullptr)
+                   : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn, raise, a_pre ? &abound : nullptr));
     }
     if (dma) {
-        if (f16) AFI_TRY(afi_launch_gemm_nt_f16x3(Vb, Usp, Mb, np, Tpad, Nc, K, afi_f16_bound(amax, f4 ? 2 : 1), st));
+        if (f16) AFI_TRY(afi_launch_gemm_nt_f16x3(Vb, Usp, Mb, np, Tpad, Nc, K, abound, st, a_pre));
         else AFI_TRY(afi_launch_gemm_nt_bf16_dma(Vb, Usp, Mb, np, Tpad, Nc, K, dtype, st));
         return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
     }
@@ -475,10 +488,11 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
 // in_bn: `in` is read through a BatchNorm affine + LeakyReLU (AfiBnLoad): the activation of the block that produced it is never written
 static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
                      float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false,
-                     double* stats = nullptr, int* stats_rows = nullptr, const AfiBnLoad* in_bn = nullptr) {
+                     double* stats = nullptr, int* stats_rows = nullptr, const AfiBnLoad* in_bn = nullptr, float* in_amax = nullptr, bool in_amax_known = false) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
     if (in_bn) g.a_bn = *in_bn;
+    g.a_amax = in_amax; g.a_amax_known = in_amax_known ? 1 : 0;
     if (mode && z.p) { g.Z = z; g.z_lo = 0; g.z_hi = Nc; }
     if (stats_rows) *stats_rows = 0;
     if (stats && stats_rows && !mode) {
@@ -521,7 +535,8 @@ static float* wino_wgacc_slot(afi_ctx* cx, float* dw, int f4, int O, int I, floa
 // phase accumulator (its dw is a per-call scratch that is unpacked right away).
 // x_bn: x is read through a BatchNorm affine + LeakyReLU (AfiBnLoad)
 static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws, long long ws_floats,
-                      hipStream_t st, int dy_phases = 1, bool accumulate = true, const AfiBnLoad* x_bn = nullptr) {
+                      hipStream_t st, int dy_phases = 1, bool accumulate = true, const AfiBnLoad* x_bn = nullptr, const float* dy_amax = nullptr,
+                      const float* x_amax = nullptr) {
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
     const int dtype = cx ? cx->dtype : afi_default_dtype();
@@ -537,18 +552,24 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     if (accumulate)
         if (float* slot = wino_wgacc_slot(cx, dw, f4, Cout, Cin, alpha, align4((long long)np * Cin * Cout), fresh)) { dU = slot; accum = true; }
     if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
-    if (f16 && !(amax = wino_amax_take(cx, ws, ws_floats, 2, st))) return AFI_ERR_LAUNCH;
-    AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 ? amax : nullptr) : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 ? amax : nullptr));
+    // dy_amax, x_amax (f16x3): the largest magnitudes of the two source tensors where their producers published them: both transforms then
+    // write their planes already split into fp16 pieces and the GEMM stages them by DMA alone; otherwise the transforms raise two slots of the pool
+    const bool pre = g_presplit && f16 && dy_amax && x_amax && dy_phases == 1 && !(x_bn && x_bn->mean);
+    const bool known = f16 && dy_amax && x_amax;           // (known but not split: the in-register kernel with the known maxima; nothing is raised)
+    if (f16 && !known && !(amax = wino_amax_take(cx, ws, ws_floats, 2, st))) return AFI_ERR_LAUNCH;
+    const AfiF16Bound vbound = afi_f16_bound(known ? x_amax : amax, f4 ? 2 : 1), qbound = afi_f16_bound(known ? dy_amax : amax + 4, f4 ? 4 : 3);
+    AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 && !known ? amax : nullptr, pre ? &vbound : nullptr)
+               : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 && !known ? amax : nullptr, pre ? &vbound : nullptr));
     const int cph = Cout / dy_phases;
     for (int ph = 0; ph < dy_phases; ++ph) {
         AfiView d = dy;
         if (dy_phases == 4) { d.p += (ph >> 1) * dy.sH + (ph & 1) * dy.sW; d.sH *= 2; d.sW *= 2; }
-        AFI_TRY(f4 ? afi_launch_wino4_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout, f16 ? amax + 4 : nullptr)
-                   : afi_launch_wino_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout, f16 ? amax + 4 : nullptr));
+        AFI_TRY(f4 ? afi_launch_wino4_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout, f16 && !known ? amax + 4 : nullptr, pre ? &qbound : nullptr)
+                   : afi_launch_wino_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout, f16 && !known ? amax + 4 : nullptr, pre ? &qbound : nullptr));
     }
     {   // tile-aligned shapes: the plain batched TN GEMM
         const int rc = dtype == AFI_DTYPE_F32 || (dtype == AFI_DTYPE_F16X3 && !f16) ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st)
-                     : f16 ? afi_launch_gemm_tn_f16x3(Qb, Vb, dU, np, Tpad, Cout, Cin, afi_f16_bound(amax + 4, f4 ? 4 : 3), afi_f16_bound(amax, f4 ? 2 : 1), st)
+                     : f16 ? afi_launch_gemm_tn_f16x3(Qb, Vb, dU, np, Tpad, Cout, Cin, qbound, vbound, st, pre)
                            : afi_launch_gemm_tn_bf16(Qb, Vb, dU, np, Tpad, Cout, Cin, dtype, st);
         if (rc == AFI_OK) {
             if (accum) return AFI_OK;                      // transformed at afi_wino_wgrad_flush()
@@ -1633,7 +1654,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
 // forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][y2 P*F3][d9 P*16][mean,invstd x3][red]
 struct DiscWs {
     long long P;
-    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_part, n_part, o_wino, n_wino, total;
+    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_amax, o_part, n_part, o_wino, n_wino, total;
 };
 static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     DiscWs w;
@@ -1652,6 +1673,7 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     }
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));
     w.o_stats = o; o += 4LL * AFI_STATS_MAX_ROWS * fmax;  // fp64 partial rows [rows][2][C] of the statistics fused into the output transforms
+    w.o_amax = o; o += 16;                                // [4 n]: the largest magnitude of block n's INPUT (x, y0, y1), raised by its producer (Winograd path; kept for the backward)
     w.n_part = part_floats({w.P * F[1], w.P * F[2], w.P * F[3]});
     w.o_part = o; o += w.n_part;
     w.n_wino = disc_wino_floats(F, N, H, W);              // transient: Winograd U / V / M buffers, shared by the three convs
@@ -1673,7 +1695,7 @@ int afi_discriminator_saved_activations(const afi_ctx_t* ctx, const int F[4], in
     const DiscWs l = disc_ws(F, N, H, W);
     return (l.n_wino > 0 && use_wino(ctx, l.P) && afi_opt(ctx, AFI_OPT_D_FOLD_BN_APPLY) != 0) ? 4 : 7;
 }
-struct DiscBwdWs { long long o_g[3], o_dd9, o_red, o_red2, o_part, n_part, o_wino, n_wino, o_wino2, total; };
+struct DiscBwdWs { long long o_g[3], o_dd9, o_amax, o_red, o_red2, o_part, n_part, o_wino, n_wino, o_wino2, total; };
 static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     DiscBwdWs w;
     const long long P = (long long)N * H * W;
@@ -1682,6 +1704,7 @@ static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     long long o = 0;
     for (int n = 0; n < 3; ++n) { w.o_g[n] = o; o += align4(P * F[n + 1]); }   // one gradient buffer per block (no ping-pong reuse)
     w.o_dd9 = o; o += align4(P * 16);
+    w.o_amax = o; o += 16;                                // [4 n]: the largest magnitude of d(conv output of block n), raised by the BatchNorm backward (Winograd path)
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));       // BatchNorm backward (main stream)
     w.o_red2 = o; o += align4(afi_reduce_scratch_floats(fmax));      // bias column sums (side stream)
     w.n_part = part_floats({P * F[0], P * F[1], P * F[2], P * F[3]});
@@ -1726,6 +1749,11 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
     const bool wino = l.n_wino > 0 && use_wino(cx, P);
     const bool fold = wino && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0;
     AfiBnLoad in_bn{nullptr, nullptr, nullptr, nullptr};
+    // the largest magnitude of every block's input, for the f16x3 arithmetic of this pass and of the backward pass that may follow (whatever
+    // arithmetic THIS pass runs in: the backward trusts the slots): x's by the first input transform, y0's / y1's by the BatchNorm apply passes
+    float* amax = ws + l.o_amax;
+    const bool slots = wino && !fold;
+    if (slots && hipMemsetAsync(amax, 0, 16 * sizeof(float), st) != hipSuccess) return AFI_ERR_LAUNCH;
     for (int n = 0; n < 3; ++n) {       // Conv2d 3x3 + bias -> BN -> LeakyReLU (feature_patch_discriminator.py:35-38)
         const int ci = prm->F[n], co = prm->F[n + 1];
         float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];
@@ -1735,7 +1763,8 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
         const bool fuse_stats = training && afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0 && (((uintptr_t)stats) & 7) == 0;
         if (wino) {
             AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
-                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx), fuse_stats ? stats : nullptr, &stats_rows, in_bn.mean ? &in_bn : nullptr));
+                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx), fuse_stats ? stats : nullptr, &stats_rows, in_bn.mean ? &in_bn : nullptr,
+                              slots ? amax + 4 * n : nullptr, /*known=*/n > 0));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
@@ -1751,7 +1780,7 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
             AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
             mean_used = prm->running_mean[n];
         }
-        if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean_used, invstd, prm->gamma[n], prm->beta[n], P, co, st));
+        if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean_used, invstd, prm->gamma[n], prm->beta[n], P, co, st, AFI_LRELU_SLOPE, slots && n < 2 ? amax + 4 * (n + 1) : nullptr));
         if (fold && n < 2) {
             in = dense_view(c, H, W, co);
             in_bn = AfiBnLoad{mean_used, invstd, prm->gamma[n], prm->beta[n]};
@@ -1796,6 +1825,12 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
     hipStream_t sd = fk.side;                              // weight / bias gradients run beside the data-gradient chain
     const bool wino = s.n_wino > 0 && use_wino(cx, P);
     const int F3 = prm->F[3];
+    // f16x3: the largest magnitude of every d(conv output), raised by the BatchNorm backward that writes it; with the forward's slots
+    // (DiscWs::o_amax) every Winograd transform of this pass knows its source's maximum beforehand and writes its planes split into fp16 pieces
+    float* gmax = scratch + s.o_amax;
+    const bool slots = wino && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) == 0 && (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_F16X3;
+    if (slots && hipMemsetAsync(gmax, 0, 16 * sizeof(float), st) != hipSuccess) return AFI_ERR_LAUNCH;
+    const float* xmax = ws + l.o_amax;
     // ---- last conv
     if (gr->b3) AFI_TRY(afi_launch_sum_accum(dlogits, P, 1.f, gr->b3, sd));
     AFI_TRY(afi_launch_stencil9_scatter(dlogits, dd9, 16, N, H, W, st));
@@ -1822,7 +1857,7 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
         // evaluated: bit-identical decisions) inside the two passes that read it anyway, instead of streaming the activation through
         // the producing data gradient's output transform as a third operand
         AFI_TRY(afi_launch_bn_bwd(g_, c, g_, ws + l.o_mean[n], ws + l.o_invstd[n], prm->gamma[n], gr->gamma[n], gr->beta[n], 1.f, P, co,
-                                  red, st, prm->beta[n], AFI_LRELU_SLOPE));          // in place: g_ = d(conv output)
+                                  red, st, prm->beta[n], AFI_LRELU_SLOPE, slots ? gmax + 4 * n : nullptr));          // in place: g_ = d(conv output)
         fk.after_main();                              // g_ = d(conv output) is complete
         // d(loss)/d(bias) of a conv that feeds a train-mode BatchNorm is EXACTLY zero: g_ = BN backward's dx, whose sum over the pixels
         // of a channel vanishes identically (the BN output does not change when a constant is added to its input).  The reference
@@ -1836,16 +1871,17 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
         AfiView xin = (n == 0) ? V(xv) : dense_view(ws + (xin_folded ? l.o_c[n - 1] : l.o_y[n - 1]), H, W, ci);
         AfiBnLoad x_bn{nullptr, nullptr, nullptr, nullptr};
         if (xin_folded) x_bn = AfiBnLoad{ws + l.o_mean[n - 1], ws + l.o_invstd[n - 1], prm->gamma[n - 1], prm->beta[n - 1]};
-        if (gr->w[n] && wino) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd, 1, true, xin_folded ? &x_bn : nullptr));
+        if (gr->w[n] && wino) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd, 1, true, xin_folded ? &x_bn : nullptr,
+                                                 slots ? gmax + 4 * n : nullptr, slots ? xmax + 4 * n : nullptr));
         else if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0 && wino) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), null_view(), scratch + s.o_wino,
-                              s.n_wino, part_, part_n_, st));
+                              s.n_wino, part_, part_n_, st, false, nullptr, nullptr, nullptr, slots ? gmax + 4 * n : nullptr, /*known=*/true));
         } else if (n > 0) {
             AFI_TRY(PG(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(scratch + s.o_g[n - 1], H, W, ci)), 1));
         } else if (dx && wino) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(dx, H, W, ci), null_view(), scratch + s.o_wino, s.n_wino, part_,
-                              part_n_, st));
+                              part_n_, st, false, nullptr, nullptr, nullptr, slots ? gmax + 4 * n : nullptr, /*known=*/true));
         } else if (dx) {
             AFI_TRY(PG(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(dx, H, W, ci)), 1));
         }

@@ -17,6 +17,7 @@
 #include "afi_common.h"
 #include "afi_epilogue.h"
 #include "afi_bn.h"
+#include "afi_f16_split.h"
 
 // ---------------------------------------------------------------- largest magnitude of a transform's SOURCE tensor, as a by-product
 // (the f16x3 arithmetic of the batched GEMMs, afi_gemm_f16.h: every plane of a transform is bounded by a constant times this value, and the
@@ -39,6 +40,21 @@ __device__ __forceinline__ void afi_amax_publish(float m, float* slot) {
         //  on one word would serialise at the memory side)
         if (bits > __hip_atomic_load((const unsigned*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) (void)atomicMax((unsigned*)slot, bits);
     }
+}
+
+// ---------------------------------------------------------------- planes written already split (f16x3, source maximum known beforehand)
+// Where the producer of the source tensor has published its largest magnitude (the BatchNorm passes of the discriminator do, as a
+// by-product), a transform knows every plane's scale s_a = 2^(14 - floor(log2(c_a amax))) before it starts and writes x s_a as two fp16
+// pieces instead of one fp32: the row keeps its 4 K bytes -- [32-channel block][hi: 32 x fp16 | lo: 32 x fp16] -- and the GEMMs stage the
+// pieces by LDS-DMA with no conversion instruction left in their loops.  A thread's float4 (channels c .. c + 3) becomes 8 bytes of hi
+// and 8 bytes of lo; dst_row = the row's first float in the fp32 layout (same address arithmetic, same pitch).
+__device__ __forceinline__ void afi_store_split4(float* dst_row, int c, f32x4 v, float s) {
+    unsigned char* b = (unsigned char*)dst_row + (c >> 5) * 128 + (c & 31) * 2;
+    unsigned h0, h1, l0, l1;
+    afi_split2_f16_pair_cvt(v[0], v[1], s, h0, l0);
+    afi_split2_f16_pair_cvt(v[2], v[3], s, h1, l1);
+    *(u32x2*)b = u32x2{h0, h1};
+    *(u32x2*)(b + 64) = u32x2{l0, l1};
 }
 
 static bool afi_epilogue_is_simple_host(const AfiPixGemm& p) {
@@ -94,9 +110,12 @@ int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hip
 // ---------------------------------------------------------------- input: X (view, [N][H][W][C]) -> V [16][Tpad][C]
 // thread = (tile, channel quad); the 4x4 patch starts at (2*ty - 1, 2*tx - 1), zeros outside the image
 // BN: x is read through a BatchNorm affine + LeakyReLU (AfiBnLoad, afi_bn.h) -- the input is a discriminator block's saved conv output
-template <bool BN, bool AMAX = false>
+// AM: 0 fp32 planes; 1 fp32 planes + the source's largest magnitude raised into *amax; 2 planes split into fp16 pieces with the scales of `bnd`
+template <bool BN, int AM = 0>
 __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T,
-                                                             long long Tpad, float* __restrict__ Vout, long long ldo, const AfiBnLoad bn, float* amax) {
+                                                             long long Tpad, float* __restrict__ Vout, long long ldo, const AfiBnLoad bn, float* amax, const AfiF16Bound bnd) {
+    constexpr bool AMAX = AM == 1;
+    const float src_max = AM == 2 ? bnd.amax[0] : 0.f;
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
@@ -105,10 +124,15 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
         float* dst = Vout + t * ldo + c;
+        float* drow = Vout + t * ldo;
+        auto put = [&](int a, f32x4 v) {
+            if (AM == 2) afi_store_split4(drow + a * plane, c, v, afi_f16_scale(src_max * bnd.cmul[a]));
+            else *(f32x4*)(dst + a * plane) = v;
+        };
         if (t >= T) {                                        // padding tiles: zeros (their GEMM rows are never read back)
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int a = 0; a < 16; ++a) *(f32x4*)(dst + a * plane) = z;
+            for (int a = 0; a < 16; ++a) *(f32x4*)(dst + a * plane) = z;       // (all-zero bits are zeros in either layout)
             continue;
         }
         const int tx = (int)(t % Tw); const long long r = t / Tw; const int ty = (int)(r % Th); const int n = (int)(r / Th);
@@ -146,10 +170,10 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {                        // (B^T d) B
-            *(f32x4*)(dst + (4 * i + 0) * plane) = s[i][0] - s[i][2];
-            *(f32x4*)(dst + (4 * i + 1) * plane) = s[i][1] + s[i][2];
-            *(f32x4*)(dst + (4 * i + 2) * plane) = s[i][2] - s[i][1];
-            *(f32x4*)(dst + (4 * i + 3) * plane) = s[i][1] - s[i][3];
+            put(4 * i + 0, s[i][0] - s[i][2]);
+            put(4 * i + 1, s[i][1] + s[i][2]);
+            put(4 * i + 2, s[i][2] - s[i][1]);
+            put(4 * i + 3, s[i][1] - s[i][3]);
         }
     }
     if constexpr (AMAX) afi_amax_publish(am, amax);
@@ -157,8 +181,11 @@ __global__ __launch_bounds__(256) void afi_wino_input_kernel(const AfiView x, in
 static inline bool wino_bn_ok(const AfiBnLoad* bn) {
     return !bn || !bn->mean || (bn->invstd && bn->gamma && bn->beta && !((((uintptr_t)bn->mean) | ((uintptr_t)bn->invstd) | ((uintptr_t)bn->gamma) | ((uintptr_t)bn->beta)) & 15));
 }
-// amax (optional): raised to the largest magnitude of what the launch reads of x (see afi_amax_publish; zero-filled by the caller)
-int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn, float* amax) {
+// amax (optional): raised to the largest magnitude of what the launch reads of x (see afi_amax_publish; zero-filled by the caller).
+// pre (optional, instead): the planes are written split into fp16 pieces with the scales pre->amax[0] x pre->cmul[plane] (ldo, C multiples of 32)
+static const AfiF16Bound kNoBound = {nullptr, 0, 0, {0}};
+int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn, float* amax,
+                          const AfiF16Bound* pre) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !wino_bn_ok(bn)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
     const long long T = (long long)N * Th * Tw;
@@ -167,10 +194,14 @@ int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad,
     const dim3 grid(wino_grid(Tpad * (C >> 2))), blk(256);
     const long long ld = ldo > 0 ? ldo : (long long)C;
     const bool b = bn && bn->mean;
-    if (b && amax) hipLaunchKernelGGL((afi_wino_input_kernel<true, true>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax);
-    else if (b) hipLaunchKernelGGL((afi_wino_input_kernel<true, false>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax);
-    else if (amax) hipLaunchKernelGGL((afi_wino_input_kernel<false, true>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax);
-    else hipLaunchKernelGGL((afi_wino_input_kernel<false, false>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax);
+    if (pre) {
+        if (!pre->amax || (ld & 31) || (C & 31) || amax) return AFI_ERR_BAD_ARG;
+        if (b) hipLaunchKernelGGL((afi_wino_input_kernel<true, 2>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax, *pre);
+        else hipLaunchKernelGGL((afi_wino_input_kernel<false, 2>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax, *pre);
+    } else if (b && amax) hipLaunchKernelGGL((afi_wino_input_kernel<true, 1>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax, kNoBound);
+    else if (b) hipLaunchKernelGGL((afi_wino_input_kernel<true, 0>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax, kNoBound);
+    else if (amax) hipLaunchKernelGGL((afi_wino_input_kernel<false, 1>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax, kNoBound);
+    else hipLaunchKernelGGL((afi_wino_input_kernel<false, 0>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax, kNoBound);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -323,9 +354,11 @@ int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm&
 //   Q[a][t][co] = G' dy G'^T                     (afi_wino_dy_kernel;  G' = [[1,0],[1/2,1/2],[1/2,-1/2],[0,1]])
 //   dU[a][co][ci] = sum_t Q[a][t][co] * V[a][t][ci]     16 GEMMs with K = tiles: ONE launch of the weight-gradient kernel
 //   dW[co][ky][kx][ci] += A'^T dU A'             (afi_wino_dw_kernel;  A'^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,-1]])
-template <bool AMAX>
+template <int AM>
 __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                          float* __restrict__ Q, long long ldo, float* amax) {
+                                                          float* __restrict__ Q, long long ldo, float* amax, const AfiF16Bound bnd) {
+    constexpr bool AMAX = AM == 1;
+    const float src_max = AM == 2 ? bnd.amax[0] : 0.f;
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
@@ -334,6 +367,11 @@ __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int 
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
         float* dst = Q + t * ldo + c;
+        float* drow = Q + t * ldo;
+        auto put = [&](int a, f32x4 v) {
+            if (AM == 2) afi_store_split4(drow + a * plane, c, v, afi_f16_scale(src_max * bnd.cmul[a]));
+            else *(f32x4*)(dst + a * plane) = v;
+        };
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (t >= T) {
 #pragma unroll
@@ -361,21 +399,25 @@ __global__ __launch_bounds__(256) void afi_wino_dy_kernel(const AfiView dy, int 
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *(f32x4*)(dst + (4 * i + 0) * plane) = a[i][0];
-            *(f32x4*)(dst + (4 * i + 1) * plane) = 0.5f * (a[i][0] + a[i][1]);
-            *(f32x4*)(dst + (4 * i + 2) * plane) = 0.5f * (a[i][0] - a[i][1]);
-            *(f32x4*)(dst + (4 * i + 3) * plane) = a[i][1];
+            put(4 * i + 0, a[i][0]);
+            put(4 * i + 1, 0.5f * (a[i][0] + a[i][1]));
+            put(4 * i + 2, 0.5f * (a[i][0] - a[i][1]));
+            put(4 * i + 3, a[i][1]);
         }
     }
     if constexpr (AMAX) afi_amax_publish(am, amax);
 }
-int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo, float* amax) {
+int afi_launch_wino_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo, float* amax, const AfiF16Bound* pre) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 1) / 2, Tw = (W + 1) / 2;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    if (amax) hipLaunchKernelGGL(afi_wino_dy_kernel<true>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C, amax);
-    else hipLaunchKernelGGL(afi_wino_dy_kernel<false>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C, amax);
+    const long long ld = ldo > 0 ? ldo : (long long)C;
+    if (pre) {
+        if (!pre->amax || (ld & 31) || (C & 31) || amax) return AFI_ERR_BAD_ARG;
+        hipLaunchKernelGGL(afi_wino_dy_kernel<2>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ld, amax, *pre);
+    } else if (amax) hipLaunchKernelGGL(afi_wino_dy_kernel<1>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ld, amax, kNoBound);
+    else hipLaunchKernelGGL(afi_wino_dy_kernel<0>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ld, amax, kNoBound);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -433,9 +475,11 @@ __device__ __forceinline__ void wino4_bt(T& d0, T& d1, T& d2, T& d3, T& d4, T& d
 }
 
 // input: X (view) -> V [36][Tpad][C]; the 6x6 patch of tile (ty, tx) starts at (4*ty - 1, 4*tx - 1)
-template <bool BN, bool AMAX = false>
+template <bool BN, int AM = 0>
 __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                              float* __restrict__ Vout, long long ldo, const AfiBnLoad bn, float* amax) {
+                                                              float* __restrict__ Vout, long long ldo, const AfiBnLoad bn, float* amax, const AfiF16Bound bnd) {
+    constexpr bool AMAX = AM == 1;
+    const float src_max = AM == 2 ? bnd.amax[0] : 0.f;
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
@@ -481,12 +525,16 @@ __global__ __launch_bounds__(256) void afi_wino4_input_kernel(const AfiView x, i
         for (int i = 0; i < 6; ++i) {                                                                   // rows, stored at once
             wino4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *(f32x4*)(dst + (6 * i + j) * plane) = d[i][j];
+            for (int j = 0; j < 6; ++j) {
+                if (AM == 2) afi_store_split4(Vout + t * ldo + (6 * i + j) * plane, c, d[i][j], afi_f16_scale(src_max * bnd.cmul[6 * i + j]));
+                else *(f32x4*)(dst + (6 * i + j) * plane) = d[i][j];
+            }
         }
     }
     if constexpr (AMAX) afi_amax_publish(am, amax);
 }
-int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn, float* amax) {
+int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo, const AfiBnLoad* bn, float* amax,
+                           const AfiF16Bound* pre) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !wino_bn_ok(bn)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
     const long long T = (long long)N * Th * Tw;
@@ -495,10 +543,14 @@ int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad
     const dim3 grid(wino_grid(Tpad * (C >> 2))), blk(256);
     const long long ld = ldo > 0 ? ldo : (long long)C;
     const bool b = bn && bn->mean;
-    if (b && amax) hipLaunchKernelGGL((afi_wino4_input_kernel<true, true>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax);
-    else if (b) hipLaunchKernelGGL((afi_wino4_input_kernel<true, false>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax);
-    else if (amax) hipLaunchKernelGGL((afi_wino4_input_kernel<false, true>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax);
-    else hipLaunchKernelGGL((afi_wino4_input_kernel<false, false>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax);
+    if (pre) {
+        if (!pre->amax || (ld & 31) || (C & 31) || amax) return AFI_ERR_BAD_ARG;
+        if (b) hipLaunchKernelGGL((afi_wino4_input_kernel<true, 2>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax, *pre);
+        else hipLaunchKernelGGL((afi_wino4_input_kernel<false, 2>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax, *pre);
+    } else if (b && amax) hipLaunchKernelGGL((afi_wino4_input_kernel<true, 1>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax, kNoBound);
+    else if (b) hipLaunchKernelGGL((afi_wino4_input_kernel<true, 0>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, *bn, amax, kNoBound);
+    else if (amax) hipLaunchKernelGGL((afi_wino4_input_kernel<false, 1>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax, kNoBound);
+    else hipLaunchKernelGGL((afi_wino4_input_kernel<false, 0>), grid, blk, 0, st, x, N, H, W, C, Th, Tw, T, Tpad, V, ld, off, amax, kNoBound);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -619,9 +671,11 @@ int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm
 }
 
 // weight gradient: Q[a][t][co] = G' e G'^T for the 4x4 block e of dY of tile t
-template <bool AMAX>
+template <int AM>
 __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int N, int H, int W, int C, int Th, int Tw, long long T, long long Tpad,
-                                                           float* __restrict__ Q, long long ldo, float* amax) {
+                                                           float* __restrict__ Q, long long ldo, float* amax, const AfiF16Bound bnd) {
+    constexpr bool AMAX = AM == 1;
+    const float src_max = AM == 2 ? bnd.amax[0] : 0.f;
     const int C4 = C >> 2;
     const long long total = Tpad * C4;
     const long long plane = Tpad * ldo;                    // ldo: row pitch of the plane (>= C: this call may fill a channel slice)
@@ -665,23 +719,31 @@ __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const f32x4 v0 = a[i][0], v1 = a[i][1], v2 = a[i][2], v3 = a[i][3];
-            *(f32x4*)(dst + (6 * i + 0) * plane) = 0.25f * v0;
-            *(f32x4*)(dst + (6 * i + 1) * plane) = (-1.f / 6.f) * (v0 + v1 + v2 + v3);
-            *(f32x4*)(dst + (6 * i + 2) * plane) = (-1.f / 6.f) * (v0 - v1 + v2 - v3);
-            *(f32x4*)(dst + (6 * i + 3) * plane) = (1.f / 24.f) * v0 + (1.f / 12.f) * v1 + (1.f / 6.f) * v2 + (1.f / 3.f) * v3;
-            *(f32x4*)(dst + (6 * i + 4) * plane) = (1.f / 24.f) * v0 - (1.f / 12.f) * v1 + (1.f / 6.f) * v2 - (1.f / 3.f) * v3;
-            *(f32x4*)(dst + (6 * i + 5) * plane) = v3;
+            auto put = [&](int pl, f32x4 v) {
+                if (AM == 2) afi_store_split4(Q + t * ldo + pl * plane, c, v, afi_f16_scale(src_max * bnd.cmul[pl]));
+                else *(f32x4*)(dst + pl * plane) = v;
+            };
+            put(6 * i + 0, 0.25f * v0);
+            put(6 * i + 1, (-1.f / 6.f) * (v0 + v1 + v2 + v3));
+            put(6 * i + 2, (-1.f / 6.f) * (v0 - v1 + v2 - v3));
+            put(6 * i + 3, (1.f / 24.f) * v0 + (1.f / 12.f) * v1 + (1.f / 6.f) * v2 + (1.f / 3.f) * v3);
+            put(6 * i + 4, (1.f / 24.f) * v0 - (1.f / 12.f) * v1 + (1.f / 6.f) * v2 - (1.f / 3.f) * v3);
+            put(6 * i + 5, v3);
         }
     }
     if constexpr (AMAX) afi_amax_publish(am, amax);
 }
-int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo, float* amax) {
+int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo, float* amax, const AfiF16Bound* pre) {
     if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (H + 3) / 4, Tw = (W + 3) / 4;
     const long long T = (long long)N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    if (amax) hipLaunchKernelGGL(afi_wino4_dy_kernel<true>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C, amax);
-    else hipLaunchKernelGGL(afi_wino4_dy_kernel<false>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ldo > 0 ? ldo : (long long)C, amax);
+    const long long ld = ldo > 0 ? ldo : (long long)C;
+    if (pre) {
+        if (!pre->amax || (ld & 31) || (C & 31) || amax) return AFI_ERR_BAD_ARG;
+        hipLaunchKernelGGL(afi_wino4_dy_kernel<2>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ld, amax, *pre);
+    } else if (amax) hipLaunchKernelGGL(afi_wino4_dy_kernel<1>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ld, amax, kNoBound);
+    else hipLaunchKernelGGL(afi_wino4_dy_kernel<0>, dim3(wino_grid(Tpad * (C >> 2))), dim3(256), 0, st, dy, N, H, W, C, Th, Tw, T, Tpad, Q, ld, amax, kNoBound);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 

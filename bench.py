@@ -67,6 +67,8 @@ def parse():
                     help="how the big convolutions' GEMMs form their fp32 products (afi_ctx_set_compute_dtype).  Default: the library's "
                          "(f16x3: two scaled fp16 pieces per operand, three products, fp32-grade); the default run also times the other settings on the same "
                          "engine afterwards and reports them under other_dtypes")
+    ap.add_argument("--debug-knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="process-wide A/B knobs of the micro-benchmarks (afi_debug_set_<NAME>(VALUE)): nt256_min_tiles, presplit, nt_ablation")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
     ap.add_argument("--one-stream", action="store_true", help="Stage1Step(overlap_d=False, overlap_g=False): every kernel alone on the chip (the "
@@ -510,6 +512,12 @@ def main():
     from afigan_amd import _lib
     from afigan_amd.guide import GuideR50FPN
     lib = _lib.load()
+    for kv in args.debug_knob:
+        name, _, val = kv.partition("=")
+        import ctypes
+        fn = getattr(lib, "afi_debug_set_" + name)
+        fn.restype = None
+        fn(ctypes.c_longlong(int(val)) if name == "nt256_min_tiles" else ctypes.c_int(int(val)))
 
     B = args.batch_per_gpu
     torch.manual_seed(1234)                       # same init on every rank (and rank 0's weights are broadcast anyway)

@@ -16,7 +16,10 @@ def run(planes, rows, N, K, iters=20):
     Cm = torch.empty((planes, rows, N), device="cuda")
     ref = torch.bmm(A[:2, :256].double(), B[:2].double().transpose(1, 2))
     st = amd.ops.stream_ptr()
-    for name, dt in _lib.DTYPES.items():
+    variants = list(_lib.DTYPES.items()) + [("f16x3/128", _lib.DTYPES["f16x3"])]       # the last: the 128 x 128 tile kernel on every shape
+    for name, dt in variants:
+        import ctypes
+        _lib.load().afi_debug_set_nt256_min_tiles(ctypes.c_longlong(0 if name == "f16x3/128" else 512))
         nb = _lib.load().afi_gemm_nt_scratch_bytes(planes, N, K, dt)
         sc = torch.empty(max(int(nb), 16), device="cuda", dtype=torch.uint8)
         args = (C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), planes, rows, N, K, dt, C.c_void_p(sc.data_ptr()), nb, st)
@@ -32,7 +35,7 @@ def run(planes, rows, N, K, iters=20):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        print(f"{planes}x{rows}x{N}x{K} {name:7s} max-norm err {err:.2e} (tail {tail:.2e})  {ms:.3f} ms  {2.0 * planes * rows * N * K / ms / 1e9:.1f} TFLOP/s", flush=True)
+        print(f"{planes}x{rows}x{N}x{K} {name:9s} max-norm err {err:.2e} (tail {tail:.2e})  {ms:.3f} ms  {2.0 * planes * rows * N * K / ms / 1e9:.1f} TFLOP/s", flush=True)
 
 
 def run_tn(planes, rows, M, N, iters=20):
