@@ -69,11 +69,12 @@ __global__ __launch_bounds__(256) void afi_absmax_planes_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------
 // B[plane][n][k] fp32 -> [header: the plane scales s_b][fp16 pieces in the LDS-image order of the NT kernel below]:
 // [plane][N / 128][K / 32][hi | lo][128 rows x 64 bytes], 16-byte chunk ch of row r at ch ^ ((-(r >> 2)) & 3) (afi_bf16_tile16_off).
-// bmax[plane]: the plane's largest magnitude (afi_absmax_planes_kernel).  One thread per float4.
+// bb: the planes' bounds -- their exact maxima (afi_absmax_planes_kernel), or the weight tensor's largest magnitude times the transform's constants.
+// One thread per float4.
 // ------------------------------------------------------------------------------------------------
 #define AFI_F16_HDR_BYTES 512                               // floats [0, 64): the plane scales; [64, 128): the plane maxima they were made from
 template <int BN>
-__global__ __launch_bounds__(256) void afi_split_f16_tiles_kernel(const float* __restrict__ B, unsigned char* __restrict__ out, const float* __restrict__ bmax,
+__global__ __launch_bounds__(256) void afi_split_f16_tiles_kernel(const float* __restrict__ B, unsigned char* __restrict__ out, const AfiF16Bound bb,
                                                                   int planes, int N, int K) {
     constexpr int TILE_B = BN * 64;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void afi_split_f16_tiles_kernel(const float* _
     const int kq = (int)(i % kq4);
     const long long rowg = i / kq4;                         // plane * N + n
     const int n = (int)(rowg % N), plane = (int)(rowg / N);
-    const float s = afi_f16_scale(bmax[plane]);
+    const float s = afi_f16_scale(bb.amax[(long long)plane * bb.stride] * bb.cmul[plane]);
     if (n == 0 && kq == 0) ((float*)out)[plane] = s;
     const f32x4 v = *(const f32x4*)(B + rowg * K + 4 * kq);
     const int tile_n = n / BN, row = n - tile_n * BN, kc = kq >> 3;
@@ -348,16 +349,22 @@ __global__ __launch_bounds__(1024, 4) void afi_gemm_nt_f16x3_w16_kernel(const Af
             ah[mi] = __builtin_bit_cast(f16x8, h);
             al[mi] = __builtin_bit_cast(f16x8, l);
         }
+        // B fragments one column group ahead: the reads of group ni + 1 are in flight under the six MFMAs of group ni (all sixteen waves
+        // leave the barrier together, so nothing else covers an LDS round trip in front of every group)
+        f16x8 bh = *(const f16x8*)(sm + fb_off[0]), bl = *(const f16x8*)(sm + PART_B + fb_off[0]);
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
-            const f16x8 bh = *(const f16x8*)(sm + fb_off[ni]);
-            const f16x8 bl = *(const f16x8*)(sm + PART_B + fb_off[ni]);
+            f16x8 nh = bh, nl = bl;
+            if (ni + 1 < NI) { nh = *(const f16x8*)(sm + fb_off[ni + 1]); nl = *(const f16x8*)(sm + PART_B + fb_off[ni + 1]); }
+            __builtin_amdgcn_sched_barrier(0);               // (the reads are ISSUED here; left alone hipcc sinks them to just in front of their use)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
+            bh = nh; bl = nl;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's reads of the stage have returned before it can reach the next barrier)
     }

@@ -829,31 +829,42 @@ int afi_launch_absmax_planes(const float* X, long long per_plane, int planes, fl
     hipLaunchKernelGGL(afi_absmax_planes_kernel, dim3((unsigned)g, planes), dim3(256), 0, st, X, per_plane, out);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
-// B (transformed weights) [planes][N][K] fp32 -> header (scales, maxima) + fp16 pieces in the NT kernel's LDS-image order: three launches
-// (zero the header, per-plane maxima, split), once per weight transform
+// B (transformed weights) [planes][N][K] fp32 -> header (scales, maxima) + fp16 pieces in the NT kernel's LDS-image order.
+// wkind = 0: the exact per-plane maxima of B by a pass of their own (three launches: zero the header, maxima, split; the stand-alone GEMM entry point).
+// wkind = 5 / 6 (F(2x2) / F(4x4) weight planes): the header's slot [64] already holds the largest magnitude of the weight tensor the planes were
+// transformed from -- the caller zero-filled the header (afi_f16_image_begin) and the weight transform raised it -- one launch.
 long long afi_f16_image_bytes(int planes, int N, int K) { return AFI_F16_HDR_BYTES + (long long)planes * N * K * 4; }
-int afi_launch_split_f16_tiles(const float* B, void* out, int planes, int N, int K, hipStream_t st) {
+AfiF16Bound afi_f16_bound(const float* amax, int kind);
+int afi_f16_image_begin(void* out, hipStream_t st) { return hipMemsetAsync(out, 0, AFI_F16_HDR_BYTES, st) == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH; }
+float* afi_f16_image_wmax(void* out) { return (float*)out + 64; }
+int afi_launch_split_f16_tiles(const float* B, void* out, int planes, int N, int K, hipStream_t st, int wkind) {
     if (!B || !out || planes <= 0 || planes > 36 || (N % 128) || (K % 32)) return AFI_ERR_BAD_ARG;
-    if (hipMemsetAsync(out, 0, AFI_F16_HDR_BYTES, st) != hipSuccess) return AFI_ERR_LAUNCH;
     float* bmax = (float*)out + 64;
-    AFI_TRY(afi_launch_absmax_planes(B, (long long)N * K, planes, bmax, st));
+    if (wkind == 0) {
+        AFI_TRY(afi_f16_image_begin(out, st));
+        AFI_TRY(afi_launch_absmax_planes(B, (long long)N * K, planes, bmax, st));
+    }
     const long long total = (long long)planes * N * (K / 4);
-    hipLaunchKernelGGL((afi_split_f16_tiles_kernel<128>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, (unsigned char*)out, (const float*)bmax, planes, N, K);
+    hipLaunchKernelGGL((afi_split_f16_tiles_kernel<128>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, B, (unsigned char*)out, afi_f16_bound(bmax, wkind), planes, N, K);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 // the bounds of the Winograd transforms' planes relative to the largest magnitude of the tensor they transform (afi_gemm_f16.h): the
 // product of the absolute row sums of the transform matrix.  kind: 0 exact per-plane maxima (stride 1, factor 1), 1 F(2x2) input
-// (B^T d B), 2 F(4x4) input, 3 F(2x2) dY (G' e G'^T), 4 F(4x4) dY
+// (B^T d B), 2 F(4x4) input, 3 F(2x2) dY (G' e G'^T), 4 F(4x4) dY, 5 F(2x2) weights (G g G^T), 6 F(4x4) weights
 AfiF16Bound afi_f16_bound(const float* amax, int kind) {
     AfiF16Bound b;
     b.amax = amax; b.stride = kind == 0 ? 1 : 0; b.pad_ = 0;
     static const float r_in4[6] = {10.f, 10.f, 10.f, 6.f, 6.f, 10.f};
     static const float r_dy4[6] = {0.25f, 4.f / 6.f, 4.f / 6.f, 15.f / 24.f, 15.f / 24.f, 1.f};
+    static const float r_w2[4] = {1.f, 1.5f, 1.5f, 1.f};
+    static const float r_w4[6] = {0.25f, 0.5f, 0.5f, 7.f / 24.f, 7.f / 24.f, 1.f};
     for (int a = 0; a < 36; ++a) {
         float c = 1.f;
         if (kind == 1) c = 4.f;
         else if (kind == 2) c = r_in4[a / 6] * r_in4[a % 6];
         else if (kind == 4) c = r_dy4[a / 6] * r_dy4[a % 6];
+        else if (kind == 5) c = a < 16 ? r_w2[a / 4] * r_w2[a % 4] : 1.f;
+        else if (kind == 6) c = r_w4[a / 6] * r_w4[a % 6];
         b.cmul[a] = c;
     }
     return b;

@@ -17,7 +17,9 @@ int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, lon
 int afi_launch_split_bf16_tiles(const float* B, void* out, int planes, int N, int K, int split, hipStream_t st);
 int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st);
 int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st);
-int afi_launch_split_f16_tiles(const float* B, void* out, int planes, int N, int K, hipStream_t st);
+int afi_launch_split_f16_tiles(const float* B, void* out, int planes, int N, int K, hipStream_t st, int wkind = 0);
+int afi_f16_image_begin(void* out, hipStream_t st);       // zero-fills the image's header: in front of the weight transform that raises its maximum slot
+float* afi_f16_image_wmax(void* out);
 long long afi_f16_image_bytes(int planes, int N, int K);
 int afi_launch_absmax_planes(const float* X, long long per_plane, int planes, float* out, hipStream_t st);
 AfiF16Bound afi_f16_bound(const float* amax, int kind);    // kind: 0 exact per-plane maxima, 1 / 2 F(2x2) / F(4x4) input planes, 3 / 4 F(2x2) / F(4x4) dY planes
@@ -66,13 +68,13 @@ int afi_launch_relu_bwd(const float* g, const float* act, float* out, long long 
 int afi_launch_dwconv3x3(AfiView x, int N, int H, int W, int C, const float* w, float* out, hipStream_t st);
 int afi_launch_maxpool3s2_same(AfiView x, int N, int H, int W, int C, float* out, hipStream_t st);
 int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const float* w, float* out, long long n, hipStream_t st);
-int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
+int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st, float* wmax = nullptr);
 int afi_launch_wino_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr, float* amax = nullptr,
                            const AfiF16Bound* pre = nullptr);
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
 int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad, float* V, hipStream_t st, long long ldo = 0, const AfiBnLoad* bn = nullptr, float* amax = nullptr,
                            const AfiF16Bound* pre = nullptr);
-int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st);
+int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st, float* wmax = nullptr);
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st);
 int afi_launch_wino4_dy(AfiView dy, int N, int H, int W, int C, long long Tpad, float* Q, hipStream_t st, long long ldo = 0, float* amax = nullptr, const AfiF16Bound* pre = nullptr);
 int afi_launch_wino4_dw(const float* dU, float* dW, int O, int I, float alpha, hipStream_t st);
@@ -442,9 +444,12 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
         if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc | (dtype << 4), b_rc ? K : Nc, b_rc ? Nc : K, wino_usplit_floats(np, (long long)K * Nc), have_u)) Usp = slot;
     } else if (float* slot = wino_wcache_slot(cx, g.B, f4, b_rc, b_rc ? K : Nc, b_rc ? Nc : K, align4((long long)np * K * Nc), have_u)) U = slot;
     if (!have_u) {
-        AFI_TRY(f4 ? afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st)
-                   : afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st));
-        if (dma) AFI_TRY(f16 ? afi_launch_split_f16_tiles(U, Usp, np, Nc, K, st) : afi_launch_split_bf16_tiles(U, Usp, np, Nc, K, dtype, st));
+        // (f16x3: the weight transform raises the image header's maximum slot as it reads w, and the split takes every plane's scale from it)
+        float* wmax = dma && f16 ? afi_f16_image_wmax(Usp) : nullptr;
+        if (wmax) AFI_TRY(afi_f16_image_begin(Usp, st));
+        AFI_TRY(f4 ? afi_launch_wino4_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st, wmax)
+                   : afi_launch_wino_weight(g.B, U, b_rc ? K : Nc, b_rc ? Nc : K, b_rc, st, wmax));
+        if (dma) AFI_TRY(f16 ? afi_launch_split_f16_tiles(U, Usp, np, Nc, K, st, f4 ? 6 : 5) : afi_launch_split_bf16_tiles(U, Usp, np, Nc, K, dtype, st));
     }
     // f16x3: the largest magnitude of A.  g.a_amax given and known (its producer published it): the transform writes the planes already
     // split into fp16 pieces; given and not known: a zero-filled slot of the caller's that the transform raises (the caller keeps it, e.g. for

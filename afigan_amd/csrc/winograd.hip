@@ -28,13 +28,14 @@ __device__ __forceinline__ float afi_amax4(float m, f32x4 v) {
     return fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
 }
 __device__ __forceinline__ void afi_amax_publish(float m, float* slot) {
-    __shared__ float red[4];
+    __shared__ float red[16];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    const int tid = threadIdx.x + blockDim.x * threadIdx.y, nw = (blockDim.x * blockDim.y + 63) >> 6;
+    if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (tid == 0) {
+        for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
         const unsigned bits = __float_as_uint(m);
         // (a relaxed device-scope read first: after the first round of blocks most blocks cannot raise the slot, and thousands of atomics
         //  on one word would serialise at the memory side)
@@ -71,8 +72,10 @@ static unsigned wino_grid(long long work_items) {
 // ---------------------------------------------------------------- weights: w [O][3][3][I] (memory order) -> U
 // mode 0 (forward):   U[a][o][i] from g[ky][kx] = w[o][ky][kx][i]            GEMM columns = O, K = I
 // mode 1 (data grad): U[a][i][o] from g[ky][kx] = w[o][2-ky][2-kx][i]        GEMM columns = I, K = O  (flipped taps, swapped roles)
-__global__ void afi_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I, int mode) {
+// wmax (optional): raised to the largest magnitude of w (the f16x3 arithmetic bounds every plane of U by a constant times it; zero-filled by the caller)
+__global__ void afi_wino_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I, int mode, float* wmax) {
     const long long total = (long long)O * I;
+    float am = 0.f;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int i = (int)(e % I), o = (int)(e / I);
         float g[3][3];
@@ -80,6 +83,7 @@ __global__ void afi_wino_weight_kernel(const float* __restrict__ w, float* __res
         for (int t = 0; t < 9; ++t) {
             const int tt = mode ? 8 - t : t;
             g[t / 3][t % 3] = w[((long long)o * 9 + tt) * I + i];
+            am = fmaxf(am, fabsf(g[t / 3][t % 3]));
         }
         float a[4][3];
 #pragma unroll
@@ -100,10 +104,11 @@ __global__ void afi_wino_weight_kernel(const float* __restrict__ w, float* __res
             U[(4 * r + 3) * plane + off] = u3;
         }
     }
+    if (wmax) afi_amax_publish(am, wmax);                    // (uniform)
 }
-int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st) {
+int afi_launch_wino_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st, float* wmax) {
     if (O <= 0 || I <= 0) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino_weight_kernel, dim3(wino_grid((long long)O * I)), dim3(256), 0, st, w, U, O, I, mode);
+    hipLaunchKernelGGL(afi_wino_weight_kernel, dim3(wino_grid((long long)O * I)), dim3(256), 0, st, w, U, O, I, mode, wmax);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -557,14 +562,16 @@ int afi_launch_wino4_input(AfiView x, int N, int H, int W, int C, long long Tpad
 // weights for the data gradient: U[a][i][o] = G g' G^T with g'[ky][kx] = w[o][2-ky][2-kx][i]   (36 planes).
 // A 32 x 32 (o, i) tile per 1024-thread block: w is read with i fastest (its memory order), each plane is transposed through
 // LDS and written with o fastest (U's order) -- both sides coalesced (the direct form wrote with a stride of O floats).
-__global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I, int mode) {
+__global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __restrict__ w, float* __restrict__ U, int O, int I, int mode, float* wmax) {
     __shared__ float tile[32][33];
     const int ti = threadIdx.x, to = threadIdx.y;
     const int i = blockIdx.x * 32 + ti, o = blockIdx.y * 32 + to;
     const bool ok = i < I && o < O;
     float g[3][3];
+    float am = 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) g[t / 3][t % 3] = ok ? w[((long long)o * 9 + (mode ? 8 - t : t)) * I + i] : 0.f;   // mode 0: forward (no flip)
+    for (int t = 0; t < 9; ++t) { g[t / 3][t % 3] = ok ? w[((long long)o * 9 + (mode ? 8 - t : t)) * I + i] : 0.f; am = fmaxf(am, fabsf(g[t / 3][t % 3])); }   // mode 0: forward (no flip)
+    if (wmax) afi_amax_publish(am, wmax);                    // (uniform; its barrier comes before the tile's)
     float a[6][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -604,9 +611,9 @@ __global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __r
         }
     }
 }
-int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st) {
+int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hipStream_t st, float* wmax) {
     if (O <= 0 || I <= 0) return AFI_ERR_BAD_ARG;
-    hipLaunchKernelGGL(afi_wino4_weight_kernel, dim3((I + 31) / 32, (O + 31) / 32), dim3(32, 32), 0, st, w, U, O, I, mode);
+    hipLaunchKernelGGL(afi_wino4_weight_kernel, dim3((I + 31) / 32, (O + 31) / 32), dim3(32, 32), 0, st, w, U, O, I, mode, wmax);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
