@@ -55,6 +55,7 @@ _GP, _DP = C.POINTER(GenParams), C.POINTER(DiscParams)
 # name -> (restype, argtypes); every symbol declared in include/afigan_hip.h
 SIGNATURES = {
     "afi_abi_version": (_i, []),
+    "afi_build_id": (C.c_char_p, []),
     "afi_status_string": (C.c_char_p, [_i]),
     "afi_ctx_create": (_i, [C.POINTER(C.c_void_p)]),
     "afi_ctx_destroy": (_i, [_vp]),
@@ -158,8 +159,35 @@ def load():
         fn.argtypes = args
     if lib.afi_abi_version() != ABI_VERSION:
         raise AfiError(f"ABI mismatch: library {lib.afi_abi_version()} != binding {ABI_VERSION}")
+    # which binary is this?  The library carries the digest of the sources it was compiled from; the tree next to it says what it should be.
+    # (An A/B library given by AFI_LIB_PATH is somebody's deliberate other build: reported by build_id(), not refused.)
+    if not os.environ.get("AFI_LIB_PATH"):
+        want, have = tree_digest(), lib.afi_build_id().decode()
+        if want is not None and have != want:
+            raise AfiError(f"{LIB_PATH} was built from other sources than this tree (library {have[:16]}, tree {want[:16]}): "
+                           "rebuild it with `python -c 'import __graft_entry__ as g; g.build()'`")
     _lib = lib
     return lib
+
+
+def tree_digest():
+    """The digest afi_build_id() must return for the sources of this tree (__graft_entry__.source_digest), None when they are not there."""
+    import glob
+    import hashlib
+    csrc = os.path.join(_HERE, "csrc")
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "afigan_hip.h")
+    files = sorted(glob.glob(os.path.join(csrc, "*.hip")) + [f for f in glob.glob(os.path.join(csrc, "*.h")) if os.path.basename(f) != "afi_build_id.h"])
+    if not files or not os.path.exists(hdr):
+        return None
+    h = hashlib.sha256()
+    for f in files + [hdr]:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+def build_id():
+    return load().afi_build_id().decode()
 
 
 def check(status: int, what: str = ""):

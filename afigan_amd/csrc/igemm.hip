@@ -618,10 +618,15 @@ __global__ __launch_bounds__(256) void afi_gemm_tn_kernel(const AfiGemmTN p, int
 // optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)
 // ------------------------------------------------------------------------------------------------
 #include <vector>
+#include <atomic>
+#include <mutex>
 namespace {
 struct ProfRec { hipEvent_t a, b; int kind; double flops; long long m; int n, k, split, planes; };
+// (process-wide by design: the launchers below see a stream, not a context.  One switch for the whole process, its records under a mutex:
+//  launches of several threads may be bracketed at once; the readers are meant for one benchmarking thread after a synchronisation.)
 struct ProfState {
-    bool on = false;
+    std::atomic<bool> on{false};
+    std::mutex mu;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
@@ -641,7 +646,7 @@ const char* kKindNames[] = {
     "gemm_nt_f16x3<128x128> (batched Winograd GEMM on the f16 MFMA: two scaled fp16 pieces per operand, three products, fp32 accumulate)",
     "gemm_tn_f16x3<128x128> (Winograd weight-gradient GEMM on the f16 MFMA: two scaled fp16 pieces per operand, three products, fp32 accumulate)"};   // one kind per kernel, as rocprofv3 lists them
 constexpr int kNumKinds = 23;
-hipEvent_t prof_event() {
+hipEvent_t prof_event() {                                   // (callers hold g_prof.mu)
     if (g_prof.used == g_prof.pool.size()) {
         hipEvent_t e;
         (void)hipEventCreate(&e);
@@ -653,19 +658,20 @@ struct ProfScope {
     hipStream_t st; int kind; double flops; hipEvent_t a{};
     long long m = 0; int n = 0, k = 0, split = 1, planes = 1;   // GEMM shape of the launch (rows over all planes, columns, K; split-K factor; planes), for afi_profile_dump
     ProfScope(hipStream_t s, int kd, double f) : st(s), kind(kd), flops(f) {
-        if (g_prof.on) { a = prof_event(); (void)hipEventRecord(a, st); }
+        if (g_prof.on) { std::lock_guard<std::mutex> lk(g_prof.mu); a = prof_event(); (void)hipEventRecord(a, st); started = true; }
     }
-    bool live = true;
+    bool live = true, started = false;
     void cancel() { live = false; }                        // nothing was launched under this scope (the caller falls back to another kernel)
     ~ProfScope() {
-        if (g_prof.on && live) { hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops, m, n, k, split, planes}); }
+        if (started && live) { std::lock_guard<std::mutex> lk(g_prof.mu); hipEvent_t b = prof_event(); (void)hipEventRecord(b, st); g_prof.recs.push_back({a, b, kind, flops, m, n, k, split, planes}); }
     }
 };
 }  // namespace
 
 extern "C" int afi_profile_enable(int on) {
-    g_prof.on = on != 0;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
     if (on) { g_prof.recs.clear(); g_prof.used = 0; }
+    g_prof.on = on != 0;
     return AFI_OK;
 }
 extern "C" int afi_profile_num_kinds(void) { return kNumKinds; }
@@ -1014,6 +1020,10 @@ int afi_launch_pix_gemm(const AfiPixGemm& p_in, int b_rc, hipStream_t st) {
         if (rc != AFI_ERR_UNSUPPORTED || p.Bimg) return rc;  // (a problem that carries a weight image is defined by it: never fall back to reading B)
         prof.cancel();
     }
+    // the kernels below read p.B.  A problem that exists only as a weight image (the dense block's four growth convs side by side as one data
+    // gradient: nets.hip gives it a null B) cannot run on them: refuse instead of reading some other matrix out of bounds.  (A problem that
+    // carries an image AND a valid B of its own shape -- every other small-map descriptor on a map too large for the small-map rule -- runs here.)
+    if (!p.B) return AFI_ERR_UNSUPPORTED;
     // halo variant: 3x3 stride-1 gathers on maps big enough that the 8x16 patch grid wastes < 12 % of the MFMA work
     const long long padded = (long long)p.N * afi_cdiv(p.H, AFI_HALO_TY) * AFI_HALO_TY * afi_cdiv(p.W, AFI_HALO_TX) * AFI_HALO_TX;
     const bool halo = p.ntaps == 9 && p.nKphase == 1 && p.a_up == 1 && !smallM && p.Ncols > 64 && padded * 100 <= M * 112;

@@ -357,6 +357,13 @@ static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, floa
     if (side_done) *side_done = false;
     if (ct_built) *ct_built = false;
     if (n > kWk6MaxReq) return AFI_OK;
+    // the cache entries this call registers are committed only once their images are written: every exit that builds nothing (no room,
+    // too many jobs, a failed launch) rolls the cache back, or a later call would find the entries and multiply by unwritten images
+    struct CacheRollback {
+        afi_ctx* cx; int n0; long long used0; bool keep = false;
+        explicit CacheRollback(afi_ctx* c) : cx(c), n0(c ? c->wcache.n : 0), used0(c ? c->wcache.used : 0) {}
+        ~CacheRollback() { if (cx && !keep) { cx->wcache.n = n0; cx->wcache.used = used0; } }
+    } rollback(cx);
     AfiWk6ImgJob jobs[kWk6MaxJobs];
     AfiWk6ConvT ct;
     bool have_ct = false;
@@ -393,6 +400,7 @@ static int wk6_build(afi_ctx* cx, Wk6Images& im, const Wk6Req* reqs, int n, floa
         if (side && side_done) *side_done = true;
         if (have_ct && ct_built) *ct_built = true;
     }
+    rollback.keep = true;
     im.on = true;
     return AFI_OK;
 }
@@ -626,6 +634,15 @@ int afi_debug_wk6_convT_images(const float* W, int Cin, int Cout, int mode, void
     return afi_launch_wk6_images(&job, 1, st, nullptr, nullptr);
 }
 int afi_abi_version(void) { return 6; }
+// digest of the sources this binary was compiled from (__graft_entry__.build() writes csrc/afi_build_id.h in front of the compile:
+// sha256 over every *.hip / *.h of csrc/ and include/afigan_hip.h, the generated header excluded).  The Python binding recomputes it from the
+// tree it sits in and refuses a library built from other sources; smoke() prints it.
+#if __has_include("afi_build_id.h")
+#include "afi_build_id.h"
+#else
+#define AFI_BUILD_ID "unknown"
+#endif
+const char* afi_build_id(void) { return AFI_BUILD_ID; }
 
 const char* afi_status_string(int s) {
     switch (s) {
@@ -1558,7 +1575,8 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
                 }
                 im.attach(g, prm->rdb_w[r][0], 0, /*tag: the four growth convs side by side*/ 2);
                 if (!g.Bimg) return AFI_ERR_LAUNCH;
-                AFI_TRY(PG(g, 1));
+                g.B = nullptr;                              // this problem is DEFINED by its image: rdb_w[r][0] alone is not a [4G rows] matrix, so a
+                AFI_TRY(PG(g, 1));                          // launcher that would read B instead (afi_launch_pix_gemm) refuses a null B loudly
             }
             if (gr->rdb_w[r][0] || gr->rdb_w[r][1] || gr->rdb_w[r][2] || gr->rdb_w[r][3]) {
                 AFI_TRY(defer(conv_wgrad_desc(Gc, b, N, H, W, 4 * G, L, scratch + s.o_rdbw + (long long)r * s.n_rdbw, 1.f)));

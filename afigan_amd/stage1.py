@@ -25,6 +25,8 @@ import ctypes as C
 import os
 from typing import Dict, List, Optional, Sequence
 
+import time
+
 import numpy as np
 import torch
 
@@ -147,6 +149,7 @@ class _FlatOptim:
         self.flat_grad = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.flat_mom = torch.zeros(self.total, device=dev, dtype=torch.float32)
         self.grad_ptrs = []
+        self.weight_decays = [weight_decay_norm if ".norm." in n else weight_decay for n in self.names]
         self._offs = [int(o) for o in offs[:-1]]
         descs = (SgdDesc * len(self.params))()
         for i, ((name, p), n) in enumerate(zip(named_params, sizes)):
@@ -210,7 +213,7 @@ class Stage1Step:
                  warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2,
                  reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: Optional[str] = None,
                  overlap_d: bool = True, overlap_g: bool = True, weight_cache: bool = True, wgrad_accum: bool = True,
-                 g_bwd_small_first: bool = True, overlap_comm: bool = True):
+                 g_bwd_small_first: bool = True, overlap_comm: Optional[bool] = None):
         self.G, self.D = G, D
         self.gnet, self.dnet = G, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
@@ -224,7 +227,13 @@ class Stage1Step:
         self.g_bwd_small_first = g_bwd_small_first          # G-phase backward passes on the second stream: smallest level first (see _run_phases)
         # data-parallel runs: the two gradient all-reduces are issued asynchronously and run beside work that does not need them -- D's
         # beside G's five backward passes (second stream), G's beside the G phase's D forwards (see _run_phases); False = blocking, in place
+        # Default (None): on where the asynchronous path has been exercised -- the gloo backend (two-rank tests, CPU and two ranks on one GPU) -- and
+        # OFF under nccl / RCCL until an RCCL run exists (tests/test_gpu_stage1.py::test_stage1_data_parallel_rccl passes overlap_comm=True and
+        # records the result where >= 2 GPUs are visible); blocking costs ~1 ms of exposed exchange per step (92.7 MB over xGMI)
         self.overlap_comm = overlap_comm
+        self._pending_work = []                             # collectives issued and not yet waited for (an error path waits for them: see run_step)
+        self.comm_exposed_ms = None                         # measure_comm = True: [D, G] time the consuming stream waited for the collective, last step
+        self.measure_comm = False
         # per-phase cache of transformed weights / transform-domain sum of the weight gradients of a phase (pure re-orderings; off = per call)
         self.weight_cache, self.wgrad_accum = weight_cache, wgrad_accum
         self._bstream = None
@@ -235,6 +244,9 @@ class Stage1Step:
                 torch.distributed.get_world_size(process_group) > 1
         self.distributed = distributed
         self.world = torch.distributed.get_world_size(process_group) if distributed else 1
+        self.backend = torch.distributed.get_backend(process_group) if distributed else None
+        if self.overlap_comm is None:
+            self.overlap_comm = bool(distributed) and self.backend == "gloo"
         for p in list(G.parameters()) + list(D.parameters()):
             ops._check_cuda(p)
         if self.distributed:        # DistributedDataParallel(...) ctor semantics: rank 0's weights everywhere (:80-89)
@@ -302,11 +314,74 @@ class Stage1Step:
 
     def load_state_dict(self, sd: Dict[str, object]):
         """Inverse of ``state_dict``; the networks' parameters / BN buffers are loaded by the caller into G and D (in place: the engine
-        holds their storage).  The learning-rate schedule itself is a constructor argument and stays this engine's."""
+        holds their storage).  The learning-rate schedule is a constructor argument and stays this engine's: a stored schedule that differs
+        from it is refused (``ValueError``) rather than silently ignored.  Under data parallelism every rank loads the same file."""
         self._join_bstream()
+        sch = sd.get("scheduler")
+        if sch is not None:
+            mine = self.state_dict()["scheduler"]
+            for k in ("base_lr", "steps", "gamma", "warmup_factor", "warmup_iters"):
+                if k in sch and (list(sch[k]) != list(mine[k]) if k == "steps" else abs(float(sch[k]) - float(mine[k])) > 1e-12 * max(1.0, abs(float(mine[k])))):
+                    raise ValueError(f"checkpoint scheduler {k} = {sch[k]!r} differs from this engine's {mine[k]!r}: construct Stage1Step with the stored schedule")
+            if "last_epoch" in sch and int(sch["last_epoch"]) != int(sd["iteration"]):
+                raise ValueError(f"checkpoint scheduler.last_epoch {sch['last_epoch']} != iteration {sd['iteration']}")
         self.g_opt.load_state_dict(sd["G_optimizer"]["momentum_buffer"])
         self.d_opt.load_state_dict(sd["D_optimizer"]["momentum_buffer"])
         self.iter = int(sd["iteration"])
+
+    # ---- the reference's own checkpoint layout (stage1_trainer.py:129-174: one DetectionCheckpointer per network, each saving
+    #      {"model", "optimizer", "scheduler", "iteration"} with torch.optim.SGD / WarmupMultiStepLR state dicts; resume_or_load returns
+    #      checkpoint["iteration"] -- the iteration that FINISHED -- and the loop restarts at + 1, :167-172)
+    def to_reference_checkpoints(self) -> Dict[str, Dict[str, object]]:
+        """{"G": ..., "D": ...}: what ``G_checkpointer.save`` / ``D_checkpointer.save`` write besides "model" after this engine's last step:
+        "optimizer" = a torch.optim.SGD state_dict (state keyed by the parameter's index in ``model.parameters()`` order, momentum buffers in
+        the parameter's logical shape; param_groups as detectron2 v0.1.1's build_optimizer makes them: ONE group per parameter with its own
+        weight decay), "scheduler" = WarmupMultiStepLR.state_dict() essentials, "iteration" = the index of the iteration that just finished
+        (``self.iter - 1``: this engine counts steps DONE)."""
+        out = {}
+        for tag, net, opt in (("G", self.G, self.g_opt), ("D", self.D, self.d_opt)):
+            names = [n for n, _ in net.named_parameters()]
+            mom = opt.state_dict()
+            wds = dict(zip(opt.names, opt.weight_decays))
+            lr = self.lr_at(self.iter)
+            state = {i: {"momentum_buffer": mom[n]} for i, n in enumerate(names)} if self.iter > 0 else {}
+            groups = [{"lr": lr, "initial_lr": self.base_lr, "momentum": self.momentum, "dampening": 0, "weight_decay": wds[n], "nesterov": False,
+                       "params": [i]} for i, n in enumerate(names)]
+            out[tag] = {"optimizer": {"state": state, "param_groups": groups},
+                        "scheduler": {"last_epoch": int(self.iter), "_step_count": int(self.iter) + 1, "base_lrs": [self.base_lr] * len(names),
+                                      "milestones": list(self.lr_steps), "gamma": self.lr_gamma, "warmup_factor": self.warmup_factor,
+                                      "warmup_iters": self.warmup_iters, "warmup_method": "linear"},
+                        "iteration": int(self.iter) - 1}
+        return out
+
+    def load_reference_checkpoints(self, ckpts: Dict[str, Dict[str, object]]):
+        """Inverse of ``to_reference_checkpoints`` (the "model" entries are the caller's: ``G.load_state_dict`` / ``D.load_state_dict``).  Takes
+        what the reference's two checkpointers wrote: SGD state keyed by parameter index -- mapped through ``named_parameters()`` order --, and
+        resumes at ``iteration + 1`` like ``resume_or_load`` does.  Both files must agree on the iteration; the stored schedule is checked
+        against this engine's."""
+        self._join_bstream()
+        its = {int(ckpts[t]["iteration"]) for t in ("G", "D")}
+        if len(its) != 1:
+            raise ValueError(f"G and D checkpoints disagree on the iteration: {sorted(its)}")
+        it = its.pop() + 1
+        for tag, net, opt in (("G", self.G, self.g_opt), ("D", self.D, self.d_opt)):
+            ck = ckpts[tag]
+            names = [n for n, _ in net.named_parameters()]
+            st = ck["optimizer"]["state"]
+            if st and sorted(int(k) for k in st) != list(range(len(names))):
+                raise KeyError(f"{tag} optimizer state: indices {sorted(st)} do not cover the {len(names)} parameters")
+            if st:
+                opt.load_state_dict({n: st[i if i in st else str(i)]["momentum_buffer"] for i, n in enumerate(names)})
+            else:
+                opt.flat_mom.zero_()
+            sch = ck.get("scheduler")
+            if sch is not None:
+                if list(sch.get("milestones", self.lr_steps)) != list(self.lr_steps) or abs(float(sch.get("gamma", self.lr_gamma)) - self.lr_gamma) > 1e-12 or \
+                        int(sch.get("warmup_iters", self.warmup_iters)) != self.warmup_iters or abs(float(sch.get("warmup_factor", self.warmup_factor)) - self.warmup_factor) > 1e-12:
+                    raise ValueError(f"{tag} checkpoint's schedule differs from this engine's (milestones / gamma / warm-up)")
+                if "last_epoch" in sch and int(sch["last_epoch"]) != it:
+                    raise ValueError(f"{tag} scheduler.last_epoch {sch['last_epoch']} != iteration + 1 = {it}")
+        self.iter = it
 
     def lr_at(self, it: int) -> float:
         return warmup_multistep_lr(self.base_lr, it, self.lr_steps, self.lr_gamma, self.warmup_factor, self.warmup_iters)
@@ -360,16 +435,59 @@ class Stage1Step:
         """Issue the collective behind what the CURRENT stream has queued and return at once (``async_op``: RCCL runs it on its own
         stream); nothing may touch ``opt.flat_grad`` until ``_allreduce_finish``."""
         if self.distributed and self.overlap_comm:
-            return torch.distributed.all_reduce(opt.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+            work = torch.distributed.all_reduce(opt.flat_grad, op=torch.distributed.ReduceOp.SUM, group=self.pg, async_op=True)
+            self._pending_work.append(work)
+            return work
         if self.distributed:
-            allreduce_sum_(opt.flat_grad, self.pg)
+            if self.measure_comm:                          # blocking: the whole exchange is exposed
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                allreduce_sum_(opt.flat_grad, self.pg)
+                e1.record()
+                self._comm_events.append(("D" if opt is self.d_opt else "G", e0, e1))
+            else:
+                allreduce_sum_(opt.flat_grad, self.pg)
         return None
 
     def _allreduce_finish(self, opt: _FlatOptim, work):
         if work is not None:
-            work.wait()                            # (nccl: the current stream waits for the collective; gloo: the host does)
+            if self.measure_comm:                          # what the consumer's stream really waits: events on it either side of the wait
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                t0 = time.perf_counter()
+                work.wait()                                # (nccl: the current stream waits for the collective; gloo: the host does)
+                host_ms = (time.perf_counter() - t0) * 1e3
+                e1.record()
+                self._comm_events.append(("D" if opt is self.d_opt else "G", e0, e1, host_ms))
+            else:
+                work.wait()
+            if work in self._pending_work:
+                self._pending_work.remove(work)
         if self.after_allreduce is not None:       # observation point for tests: `opt.flat_grad` holds the SUM over ranks here
             self.after_allreduce("D" if opt is self.d_opt else "G", opt)
+
+    def _drain_pending_comm(self):
+        """Error path: a phase raised with a collective in flight.  Wait for it before anything (the next step's zero_grad) touches the
+        buffer it is still writing."""
+        for w in self._pending_work:
+            try:
+                w.wait()
+            except Exception:
+                pass
+        self._pending_work = []
+
+    def comm_exposure(self):
+        """After a step run with ``measure_comm = True``: {"D": ms, "G": ms} the consuming stream spent waiting for each exchange (device
+        time between two events around the wait; under gloo, where the HOST waits, the host time of that wait), and the sum."""
+        torch.cuda.synchronize()
+        out = {}
+        for rec in self._comm_events:
+            ms = rec[1].elapsed_time(rec[2])
+            if len(rec) > 3 and self.backend != "nccl":
+                ms = max(ms, rec[3])
+            out[rec[0]] = out.get(rec[0], 0.0) + ms
+        out["total"] = sum(out.values())
+        return out
 
     # ------------------------------------------------------------------------------------------------ the step
     def run_step(self, lr_features: Sequence[torch.Tensor], hr_features: Sequence[torch.Tensor]):
@@ -392,6 +510,7 @@ class Stage1Step:
         self.losses.zero_()
         lptr = self.losses.data_ptr()
         lr_now = self.lr_at(self.iter)
+        self._comm_events = []
         # transformed conv weights are shared by the calls of a phase (weights only change at the two optimizer steps)
         cx, bx = self.ctx, self.bctx
         with _lib.use_ctx(cx):
@@ -413,6 +532,7 @@ class Stage1Step:
                     self._join_bstream()
                 except Exception:
                     pass
+                self._drain_pending_comm()                 # a collective issued before the failure may still be writing flat_grad
                 self._lib.afi_ctx_wino_wgrad_discard(bx.handle)
                 self._lib.afi_ctx_set_wino_wgrad_accum(bx.handle, None, 0)
                 self._lib.afi_ctx_set_wino_weight_cache(cx.handle, None, 0)

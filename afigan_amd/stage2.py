@@ -186,8 +186,15 @@ class Stage2Adversarial:
                               "warmup_factor": wf, "warmup_iters": wi}}
 
     def load_state_dict(self, sd: Dict[str, object]):
+        """Inverse of ``state_dict``.  The schedule is a constructor argument: a stored one that differs is refused, not ignored."""
         if self._bstream is not None:
             torch.cuda.current_stream().wait_stream(self._bstream)
+        sch = sd.get("scheduler")
+        if sch is not None:
+            mine = self.state_dict()["scheduler"]
+            for k in ("base_lr", "steps", "gamma", "warmup_factor", "warmup_iters"):
+                if k in sch and (list(sch[k]) != list(mine[k]) if k == "steps" else abs(float(sch[k]) - float(mine[k])) > 1e-12 * max(1.0, abs(float(mine[k])))):
+                    raise ValueError(f"checkpoint scheduler {k} = {sch[k]!r} differs from this engine's {mine[k]!r}")
         self.opt.load_state_dict(sd["D_optimizer"]["momentum_buffer"])
         self.iter = int(sd["iteration"])
 

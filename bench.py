@@ -67,6 +67,11 @@ def parse():
                     help="how the big convolutions' GEMMs form their fp32 products (afi_ctx_set_compute_dtype).  Default: the library's "
                          "(f16x3: two scaled fp16 pieces per operand, three products, fp32-grade); the default run also times the other settings on the same "
                          "engine afterwards and reports them under other_dtypes")
+    ap.add_argument("--overlap-comm", type=int, default=None, choices=[0, 1], help="N > 1: issue the two gradient all-reduces asynchronously beside independent work "
+                    "(Stage1Step(overlap_comm=...)); default: the engine's (on under gloo, off under nccl until an RCCL run has exercised it)")
+    ap.add_argument("--profile-timed", action="store_true", help="record the library's per-launch HIP events INSIDE the timed region (default: over a repeat of "
+                    "the same K steps right behind it, so that the headline number carries no event records); the rocprofv3 passes use it: their traces "
+                    "then hold exactly the timed launches")
     ap.add_argument("--debug-knob", action="append", default=[], metavar="NAME=VALUE",
                     help="process-wide A/B knobs of the micro-benchmarks (afi_debug_set_<NAME>(VALUE)): nt256_min_tiles, presplit, nt_ablation")
     ap.add_argument("--synthetic-pyramid", action="store_true",
@@ -171,7 +176,7 @@ def committed_traffic(fname, dom_kernel):
     measurement of the same command when there is one (the newest profiles/rNN/<fname>), else None.  The record names the kernel it was
     taken on -- another dominant kernel nulls it -- and is tied to the kernel SOURCE it was measured on by a sha256: a later edit of that
     file nulls it too."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tpath = os.path.join(ROOT, "profiles", rnd, fname)
         if not os.path.exists(tpath):
             continue
@@ -530,6 +535,32 @@ def main():
         name, _, val = kv.partition("=")
         step.ctx.set_option(name, int(val)); step.bctx.set_option(name, int(val))
     run_dtype = step.dtype                             # the library's default when --dtype is not given
+    # data-parallel runs: what the process group says it is, and what the two gradient exchanges of a step cost with nothing beside them
+    # (the engine's own flat gradient buffers: D 61.4 MB, G 31.3 MB), before any step runs -- SURVEY 8e (2), (3)
+    comm = None
+    if dist is not None:
+        if args.overlap_comm is not None:
+            step.overlap_comm = bool(args.overlap_comm)
+        comm = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(dev),
+                "overlap_comm": bool(step.overlap_comm), "allreduce_alone": {}}
+        for tag, buf in (("D", step.d_opt.flat_grad), ("G", step.g_opt.flat_grad)):
+            for _ in range(2):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / reps * 1e3
+            tm = torch.tensor([ms], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            nbytes = buf.numel() * 4
+            comm["allreduce_alone"][tag] = {"bytes": nbytes, "ms": round(float(tm.item()), 4),
+                                            "bus_gb_per_s": round(2.0 * (world - 1) / world * nbytes / (float(tm.item()) * 1e-3) / 1e9, 2)}
+            buf.zero_()
+        log(f"process group: backend {comm['backend']}, world {comm['world_size_reported']}; all-reduce alone: " +
+            ", ".join(f"{k} {v['ms']:.3f} ms ({v['bus_gb_per_s']} GB/s bus)" for k, v in comm["allreduce_alone"].items()))
     guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
     gen = torch.Generator(device=dev).manual_seed(100 + rank)     # each rank owns a different shard of the global batch
     images = torch.rand((B, 3, 800, 1333), device=dev, generator=gen) * 255.0
@@ -586,7 +617,9 @@ def main():
         assert [tuple(t.shape[2:]) for t in hr] == hr_shapes and [tuple(t.shape[2:]) for t in lr] == lr_shapes, \
             ([t.shape for t in hr], [t.shape for t in lr])
     sync()
-    if rank == 0:
+    # The timed region carries no event records unless --profile-timed is given: the per-launch HIP events of the roofline leg (two per GEMM
+    # launch on the launch stream) are taken over a REPEAT of the same K steps right behind it, same inputs, same schedule.
+    if rank == 0 and args.profile_timed:
         lib.afi_profile_enable(1)
     t0 = time.perf_counter()
     # K guide pairs inside the K timed steps either way: after a warm-up the first step consumes the pair the warm-up launched and every
@@ -597,6 +630,25 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
+    profiled_ms_per_step = None
+    if not args.profile_timed:
+        if rank == 0:
+            lib.afi_profile_enable(1)
+        step.measure_comm = dist is not None               # events either side of each exchange's wait, on the stream that waits (last step's are kept)
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            one_step(last=(args.warmup == 0 and i == args.steps - 1))
+        sync()
+        profiled_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
+        if dist is not None:
+            ex = step.comm_exposure()
+            te = torch.tensor([ex.get("D", 0.0), ex.get("G", 0.0)], device=dev, dtype=torch.float64)
+            dist.all_reduce(te, op=dist.ReduceOp.MAX)
+            comm["comm_exposed_ms"] = {"D": round(float(te[0]), 4), "G": round(float(te[1]), 4), "total": round(float(te.sum()), 4),
+                                       "note": "time the consuming stream waited for each gradient exchange in the last step of the profiled repeat (max over ranks); "
+                                               "blocking exchanges (overlap_comm false) are exposed whole"}
+        step.measure_comm = False
+        log(f"profiled repeat done: {profiled_ms_per_step:.2f} ms/step with the event brackets on")
     if rank == 0:
         lib.afi_profile_enable(0)
         if os.environ.get("AFI_PROFILE_DUMP"):            # per-launch CSV (shape, split, ms) for offline analysis
@@ -710,7 +762,10 @@ def main():
                 "frac_step_executed": peak_s / elapsed,
                 "all_gemm_kernels": {"tflops": gemm_flop / (gemm_ms * 1e-3) / 1e12, "frac": peak_s / (gemm_ms * 1e-3),
                                      "share_of_step_time": gemm_ms / (elapsed * 1e3)},
-                "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "flop_total"} for r in kinds]}
+                "per_kernel": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items() if k != "flop_total"} for r in kinds],
+                "measured_over": ("the timed region itself (--profile-timed)" if args.profile_timed else
+                                  f"a repeat of the timed region's {args.steps} steps right behind it with the library's per-launch HIP events on "
+                                  f"({profiled_ms_per_step:.2f} ms/step there): the timed region carries no event records")}
 
     # algorithmic work of one step per image: D fwd 4x hr px + D bwd on 2x hr px; G fwd 2x lr px + G bwd 1x lr px
     hr_px = sum(h * w for h, w in hr_shapes)
@@ -727,7 +782,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"fp32": "f32", "f16x3": "f32 emulated on the f16 matrix cores (operands scaled by a power of two per Winograd plane and split into two fp16 pieces, three f16 MFMAs per k-step, fp32 accumulate; tensors fp32)", "bf16x6": "f32 emulated on the bf16 matrix cores (operands split exactly into three bf16, six bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)", "bf16x3": "bf16x3 (split-bf16 operands, three bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)",
                                        "bf16": "bf16 (bf16 operands, fp32 accumulate; tensors fp32)"}[run_dtype], "data": "synthetic",
-        "backend": (args.backend if world > 1 else None),
+        "backend": (args.backend if world > 1 else None), "comm": comm,
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
                                f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",
                    "global_batch": world * B, "parallelism": f"dp{world}", "guide": "r50fpn (GEMM 1x1 via hipBLASLt + own 3x3 MFMA conv)" if guide is not None else "synthetic-pyramid",
@@ -767,6 +822,13 @@ def main():
             r_ = interp_bench(amd, torch, n_, h_, w_, iters=20, warmup=5)          # (eager or hipGraph replay, whichever is faster: as cfg1)
             sweep[f"{n_}x256x{h_}x{w_}"] = {"ms": round(r_["ms"], 4), "out_mpix_per_s": round(r_["out_mpix_per_s"], 3), "tflops": round(r_["tflops"], 1)}
         line["af_interpolator"]["sweep"] = sweep
+        # BASELINE.json's FIRST metric where the driver's record keeps it (it preserves the `roofline` and `cpu_baseline` objects whole)
+        c1 = line["af_interpolator"]["cfg1"]
+        line["roofline"]["af_interpolator_cfg1"] = {
+            "ms": round(c1["ms"], 4), "out_mpix_per_s": round(c1["out_mpix_per_s"], 3), "in_mpix_per_s": round(c1["in_mpix_per_s"], 3), "tflops": round(c1["tflops"], 2),
+            "frac_of_fp32_mfma_peak": round(c1["frac_of_fp32_mfma_peak"], 4), "launch": c1["launch"],
+            "dominant_kernel": None if not c1["roofline"] else {k: c1["roofline"][k] for k in ("kernel", "achieved", "peak", "frac", "launches", "avg_launch_us")},
+            "note": "AF interpolator forward + full backward, 1x256x25x34 -> 1x256x50x68 through the C-ABI, SURVEY 8(d) metric 1: 48.98 GFLOP algorithmic per call"}
     if micro:
         log("FPN_AFIGAN top-down merge (SURVEY 8f row 1)")
         line["fpn_topdown"] = fpn_bench(amd, torch)
@@ -784,6 +846,12 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(torch, B)
         line["gpu_over_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        if "af_interpolator" in line:                      # metric 1, GPU beside CPU, in the object the driver keeps
+            c1 = line["af_interpolator"]["cfg1"]
+            cb = line["cpu_baseline"]
+            cb["af_interpolator_gpu_ms"] = round(c1["ms"], 4)
+            cb["af_interpolator_gpu_out_mpix_per_s"] = round(c1["out_mpix_per_s"], 3)
+            cb["af_interpolator_gpu_over_cpu"] = round(c1["out_mpix_per_s"] / cb["af_interpolator_out_mpix_per_s"], 1)
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

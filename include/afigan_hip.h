@@ -62,6 +62,10 @@ const char* afi_status_string(int status);
  *   - The library never allocates device memory: the three buffers are the caller's and must stay alive and unchanged in meaning while
  *     registered (floats == 0 unregisters).  The side stream and its events are created on first use and released by afi_ctx_destroy. */
 typedef struct afi_ctx afi_ctx_t;
+/* sha256 (hex) of the sources the binary was compiled from -- every *.hip / *.h under afigan_amd/csrc and this header, in sorted order of
+ * their names -- written into the build by __graft_entry__.build(); "unknown" for a build that bypassed it.  afigan_amd/_lib.py recomputes it
+ * from the tree and refuses a library that was built from other sources: "which binary ran" has one answer. */
+const char* afi_build_id(void);
 int afi_ctx_create(afi_ctx_t** out);
 int afi_ctx_destroy(afi_ctx_t* ctx);                       /* refused (AFI_ERR_BAD_ARG) while weight-gradient sums are pending */
 /* Scratch for the PER-OP convolution entry points (afi_conv3x3_*, afi_conv1x1_*, afi_conv3x3s2_*, afi_convT6s2_*): with it, mid-size maps
@@ -411,7 +415,9 @@ int afi_normalize_pad_u8(const unsigned char* img_chw, int C, int H, int W, cons
 /* ------------------------------------------------------------------ measurement support (bench.py)
  * When enabled, every MFMA GEMM launch is bracketed by two hipEvents recorded on the launch stream.
  * afi_profile_get(kind, out): out[0] launches, out[1] total ms, out[2] total algorithmic FLOP of that kernel since
- * the last afi_profile_enable(1).  Not thread-safe; meant for one benchmarking thread. */
+ * the last afi_profile_enable(1).  One switch for the process (the launchers see streams, not contexts); its records are kept under a mutex, so
+ * launches of several threads may be bracketed at once; the readers are meant for one benchmarking thread after a device synchronisation.
+ * Off unless enabled: bench.py enables it for a separate pass of the same steps behind its timed region, not inside it (bench.py --profile-timed does). */
 int afi_profile_enable(int on);
 int afi_profile_num_kinds(void);
 const char* afi_profile_kind_name(int kind);

@@ -188,9 +188,13 @@ def _dp_gpu_worker(rank, world, port, tmp, backend="gloo", overlap_comm=True):
     solo.run_step(lr_f, hr_f)
     snap = {}
     step.after_allreduce = lambda which, opt: snap.__setitem__(which, opt.flat_grad.detach().clone())   # right after the collective
+    step.measure_comm = True                                   # what the consuming stream (gloo: the host) waits for each exchange
     step.run_step(lr_f, hr_f)
     torch.cuda.synchronize()
-    out = {"w0": {k: v.cpu() for k, v in w0.items()},
+    exposure = step.comm_exposure()
+    assert not step._pending_work                              # every issued collective was waited for
+    out = {"comm_exposed_ms": exposure, "backend": step.backend,
+           "w0": {k: v.cpu() for k, v in w0.items()},
            "w1": {k: v.detach().cpu() for k, v in list(G.state_dict().items()) + list(D.state_dict().items())},
            "g_sum": {k: p.grad.detach().cpu().clone() for k, p in G.named_parameters()},
            "g_solo": {k: p.grad.detach().cpu().clone() for k, p in G1.named_parameters()},
@@ -251,6 +255,9 @@ def test_stage1_data_parallel_two_ranks_one_gpu(amd, tmp_path):
         r0, r1 = torch.load(d / "r0.pt"), torch.load(d / "r1.pt")
         _check_dp_results(r0, r1)
         res[overlap] = r0
+        ex = r0["comm_exposed_ms"]
+        assert set(ex) == {"D", "G", "total"} and all(v >= 0.0 for v in ex.values()), ex
+        print(f"[two ranks, one GPU, {r0['backend']}] overlap_comm={overlap}: exchange exposed to the consumer D {ex['D']:.3f} ms, G {ex['G']:.3f} ms")
     for k, v in res[True]["w1"].items():
         if "num_batches" in k:
             assert torch.equal(v, res[False]["w1"][k]), k
@@ -265,7 +272,9 @@ def test_stage1_data_parallel_rccl(amd, tmp_path):
     import torch.multiprocessing as mp
     port = 29900 + (os.getpid() % 1000)
     mp.spawn(_dp_gpu_worker, args=(2, port, str(tmp_path), "nccl", True), nprocs=2, join=True)
-    _check_dp_results(torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt"))
+    r0 = torch.load(tmp_path / "r0.pt")
+    _check_dp_results(r0, torch.load(tmp_path / "r1.pt"))
+    print(f"[RCCL, two GPUs] overlap_comm=True: exchange exposed to the consumer {r0['comm_exposed_ms']}")
 
 
 def test_stage1_engine_state_round_trip(amd):
@@ -491,3 +500,73 @@ def test_guide_prefetcher_keeps_its_inputs_alive(amd):
             assert torch.equal(a, b), how
         del fresh, feats
     torch.cuda.synchronize()
+
+
+def test_stage1_reference_checkpoint_layout_round_trips_through_torch_sgd(amd):
+    """Stage1Step.to_reference_checkpoints / load_reference_checkpoints: the layout the reference's two DetectionCheckpointers write
+    (stage1_trainer.py:129-174: "optimizer" = torch.optim.SGD.state_dict() keyed by parameter index, "scheduler", "iteration" = the iteration
+    that just FINISHED; resume at + 1, :167-172).  (1) a real torch.optim.SGD over the modules' parameters accepts the optimizer entry and
+    holds the engine's momentum afterwards; (2) what that SGD saves loads back and two more steps land where four uninterrupted ones do;
+    (3) the iteration convention; (4) a stored schedule that differs from the engine's is refused by both loaders."""
+    import copy
+    C, g = 16, 4
+    torch.manual_seed(31)
+    G0 = amd.Generator(in_channels=C, n_residual_dense_blocks=2, growth_rate=g).cuda()
+    D0 = amd.Discriminator(in_filters=C).cuda()
+    gen = torch.Generator().manual_seed(32)
+    batches = [([torch.randn((2, C, 7, 11), generator=gen).cuda(), torch.randn((2, C, 4, 6), generator=gen).cuda()],
+                [torch.randn((2, C, 13, 21), generator=gen).cuda(), torch.randn((2, C, 8, 12), generator=gen).cuda()]) for _ in range(4)]
+    sched = dict(base_lr=0.05, lr_steps=(3,), lr_gamma=0.5, warmup_factor=0.1, warmup_iters=2)
+
+    def flat(G, D):
+        return torch.cat([v.detach().double().reshape(-1).cpu() for v in list(G.state_dict().values()) + list(D.state_dict().values())])
+
+    Ga, Da = copy.deepcopy(G0), copy.deepcopy(D0)
+    ref = amd.Stage1Step(Ga, Da, **sched)
+    for lr_f, hr_f in batches:
+        ref.run_step(lr_f, hr_f)
+    want = flat(Ga, Da)
+
+    Gb, Db = copy.deepcopy(G0), copy.deepcopy(D0)
+    first = amd.Stage1Step(Gb, Db, **sched)
+    for lr_f, hr_f in batches[:2]:
+        first.run_step(lr_f, hr_f)
+    torch.cuda.synchronize()
+    ck = first.to_reference_checkpoints()
+    assert ck["G"]["iteration"] == 1 and ck["D"]["iteration"] == 1            # two steps done: iteration index 1 just finished
+    assert ck["G"]["scheduler"]["last_epoch"] == 2 and ck["G"]["scheduler"]["milestones"] == [3]
+    # (1) torch's own optimizer takes it: one group per parameter (detectron2 v0.1.1 build_optimizer), norm parameters without weight decay
+    saved = {}
+    for tag, net, opt in (("G", Gb, first.g_opt), ("D", Db, first.d_opt)):
+        params = list(net.parameters())
+        names = [n for n, _ in net.named_parameters()]
+        tsgd = torch.optim.SGD([{"params": [q], "weight_decay": 0.0 if ".norm." in n else 1e-4} for n, q in zip(names, params)], lr=0.05, momentum=0.9)
+        tsgd.load_state_dict(ck[tag]["optimizer"])
+        for n, q in zip(names, params):
+            mb = tsgd.state[q]["momentum_buffer"]
+            assert tuple(mb.shape) == tuple(q.shape), n
+            assert torch.equal(mb.cpu(), opt.state_dict()[n].cpu()), n
+        assert [gr["weight_decay"] for gr in tsgd.param_groups] == [0.0 if ".norm." in n else 1e-4 for n in names]
+        assert abs(tsgd.param_groups[0]["lr"] - first.lr_at(2)) < 1e-12
+        saved[tag] = {"optimizer": copy.deepcopy(tsgd.state_dict()), "scheduler": ck[tag]["scheduler"], "iteration": ck[tag]["iteration"],
+                      "model": {k: v.cpu() for k, v in net.state_dict().items()}}
+    # (2) resume from what torch saved
+    Gc = amd.Generator(in_channels=C, n_residual_dense_blocks=2, growth_rate=g).cuda()
+    Dc = amd.Discriminator(in_filters=C).cuda()
+    Gc.load_state_dict(saved["G"]["model"]); Dc.load_state_dict(saved["D"]["model"])
+    eng = amd.Stage1Step(Gc, Dc, **sched)
+    eng.load_reference_checkpoints(saved)
+    assert eng.iter == 2                                                       # (3) resumes at the finished iteration + 1
+    for lr_f, hr_f in batches[2:]:
+        eng.run_step(lr_f, hr_f)
+    got = flat(Gc, Dc)
+    assert ((got - want).norm() / want.norm()).item() < 1e-5
+    # (4) a schedule that is not this engine's is refused
+    other = amd.Stage1Step(copy.deepcopy(G0), copy.deepcopy(D0), **dict(sched, lr_steps=(5,)))
+    with pytest.raises(ValueError):
+        other.load_reference_checkpoints(saved)
+    with pytest.raises(ValueError):
+        other.load_state_dict(first.state_dict())
+    bad = copy.deepcopy(saved); bad["D"]["iteration"] = 7
+    with pytest.raises(ValueError):
+        eng.load_reference_checkpoints(bad)
