@@ -976,8 +976,9 @@ __global__ __launch_bounds__(256) void afi_sum_accum_kernel(const float* __restr
     if (threadIdx.x == 0) atomicAdd(out, alpha * (red[0] + red[1] + red[2] + red[3]));
 }
 int afi_launch_sum_accum(const float* v, long long n, float alpha, float* out, hipStream_t st) {
-    long long g = (n + 255) / 256; if (g > 64) g = 64; if (g < 1) g = 1;
-    hipLaunchKernelGGL(afi_sum_accum_kernel, dim3((unsigned)g), dim3(256), 0, st, v, n, alpha, out);
+    // ONE block: its threads' partial sums meet in a fixed order, so the result does not depend on which of several blocks' atomics lands
+    // first (the vector is one logit gradient per pixel: 134 K floats at most, off the critical path)
+    hipLaunchKernelGGL(afi_sum_accum_kernel, dim3(1), dim3(256), 0, st, v, n, alpha, out);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 __global__ void afi_inc_i64_kernel(long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }

@@ -924,7 +924,7 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
 }
 // pre: Q and V hold the planes already split into fp16 pieces
 int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
-                             hipStream_t st, bool pre) {
+                             hipStream_t st, bool pre, bool deterministic) {
     if (planes <= 0 || planes > 36 || rows_per_plane <= 0 || M <= 0 || N <= 0 || !qb.amax || !vb.amax) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
     const int ntm = M / 128, ntn = N / 128;
@@ -943,6 +943,7 @@ int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int plan
             if (fill > best + 1e-3) { best = fill; splitK = s2; }
         }
     }
+    if (deterministic) splitK = 1;
     int kper = (int)((rows_per_plane + splitK - 1) / splitK);
     kper = ((kper + 31) / 32) * 32;
     splitK = (int)((rows_per_plane + kper - 1) / kper);
@@ -1087,7 +1088,8 @@ static int launch_wgrad(const AfiWgradGemm& p, hipStream_t st) {
 }
 
 // batched TN GEMM of the Winograd weight gradient; AFI_ERR_UNSUPPORTED when a dimension is not tile-aligned (caller falls back)
-int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st) {
+// deterministic: one block per tile over the whole K range (no split, no atomics: the same bits every run)
+int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st, bool deterministic) {
     if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % AFI_BK) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
     const int ntm = M / 128, ntn = N / 128;
@@ -1106,6 +1108,7 @@ int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, lo
             if (fill > best + 1e-3) { best = fill; splitK = s2; }
         }
     }
+    if (deterministic) splitK = 1;
     int kper = (int)((rows_per_plane + splitK - 1) / splitK);
     kper = ((kper + AFI_BK - 1) / AFI_BK) * AFI_BK;
     splitK = (int)((rows_per_plane + kper - 1) / kper);
@@ -1116,7 +1119,7 @@ int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, lo
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
-int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st) {
+int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st, bool deterministic) {
     if (planes <= 0 || rows_per_plane <= 0 || M <= 0 || N <= 0 || (split != 1 && split != 3 && split != 6)) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
     const int ntm = M / 128, ntn = N / 128;
@@ -1137,6 +1140,7 @@ int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int plane
             if (fill > best + 1e-3) { best = fill; splitK = s2; }
         }
     }
+    if (deterministic) splitK = 1;
     int kper = (int)((rows_per_plane + splitK - 1) / splitK);
     kper = ((kper + 31) / 32) * 32;
     splitK = (int)((rows_per_plane + kper - 1) / kper);

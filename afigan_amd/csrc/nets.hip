@@ -12,11 +12,11 @@
 
 // ---- launchers implemented in igemm.hip / elementwise.hip
 int afi_launch_pix_gemm(const AfiPixGemm& p, int b_rc, hipStream_t st);
-int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st);
+int afi_launch_gemm_tn(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, hipStream_t st, bool deterministic = false);
 int afi_launch_gemm_nt(const float* A, const float* B, float* C, int planes, long long rows_per_plane, int N, int K, hipStream_t st);
 int afi_launch_split_bf16_tiles(const float* B, void* out, int planes, int N, int K, int split, hipStream_t st);
 int afi_launch_gemm_nt_bf16_dma(const float* A, const void* Bsplit, float* C, int planes, long long rows_per_plane, int N, int K, int split, hipStream_t st);
-int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st);
+int afi_launch_gemm_tn_bf16(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, int split, hipStream_t st, bool deterministic = false);
 int afi_launch_split_f16_tiles(const float* B, void* out, int planes, int N, int K, hipStream_t st, int wkind = 0);
 int afi_f16_image_begin(void* out, hipStream_t st);       // zero-fills the image's header: in front of the weight transform that raises its maximum slot
 float* afi_f16_image_wmax(void* out);
@@ -26,7 +26,7 @@ AfiF16Bound afi_f16_bound(const float* amax, int kind);    // kind: 0 exact per-
 int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st,
                              bool a_pre = false);
 int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
-                             hipStream_t st, bool pre = false);
+                             hipStream_t st, bool pre = false, bool deterministic = false);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
 int afi_launch_wgrad_gemm_group(const AfiWgradGemm* probs, int n, int wide, hipStream_t st);   // igemm.hip -> smallmap.hip
 int afi_launch_wgrad_gemm_group6(const AfiWgradGemm* probs, int n, hipStream_t st);            // the wide group on the bf16 matrix cores (bf16x6)
@@ -132,7 +132,7 @@ struct WinoWgradAccum {
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ 0, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
-                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0}};
+                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0, /*DETERMINISTIC*/ 0}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -186,6 +186,12 @@ constexpr long long kSideStreamMaxPixels = 12000;   // above this every GEMM fil
 #define AFI_CTX_CHECK(ctx) do { if (ctx) { int d_ = -1; if (hipGetDevice(&d_) != hipSuccess || d_ != ((afi_ctx*)(ctx))->device) return AFI_ERR_BAD_ARG; \
                                            ((afi_ctx*)(ctx))->amax[0].p = ((afi_ctx*)(ctx))->amax[1].p = nullptr; } } while (0)
 
+// weight-gradient GEMM of the direct kernels under the context's options: AFI_OPT_DETERMINISTIC pins the pixel split to one block per tile
+static inline bool afi_det(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_DETERMINISTIC) != 0; }
+static inline int wgrad_launch(const afi_ctx* cx, AfiWgradGemm g, hipStream_t st) {
+    if (afi_det(cx)) g.splitK = 1;
+    return afi_launch_wgrad_gemm(g, st);
+}
 // per-op entry points: split-K slabs come from the context's op scratch (the whole-net calls carve theirs out of their workspace)
 static inline int launch_pix_op(afi_ctx* cx, AfiPixGemm g, int b_rc, hipStream_t st) {
     if (cx && cx->op_scratch && !g.partial) { g.partial = cx->op_scratch; g.partial_floats = cx->op_scratch_floats; }
@@ -581,9 +587,10 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
                    : afi_launch_wino_dy(d, N, H, W, cph, Tpad, Qb + ph * cph, st, Cout, f16 && !known ? amax + 4 : nullptr, pre ? &qbound : nullptr));
     }
     {   // tile-aligned shapes: the plain batched TN GEMM
-        const int rc = dtype == AFI_DTYPE_F32 || (dtype == AFI_DTYPE_F16X3 && !f16) ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st)
-                     : f16 ? afi_launch_gemm_tn_f16x3(Qb, Vb, dU, np, Tpad, Cout, Cin, qbound, vbound, st, pre)
-                           : afi_launch_gemm_tn_bf16(Qb, Vb, dU, np, Tpad, Cout, Cin, dtype, st);
+        const bool det = afi_det(cx);
+        const int rc = dtype == AFI_DTYPE_F32 || (dtype == AFI_DTYPE_F16X3 && !f16) ? afi_launch_gemm_tn(Qb, Vb, dU, np, Tpad, Cout, Cin, st, det)
+                     : f16 ? afi_launch_gemm_tn_f16x3(Qb, Vb, dU, np, Tpad, Cout, Cin, qbound, vbound, st, pre, det)
+                           : afi_launch_gemm_tn_bf16(Qb, Vb, dU, np, Tpad, Cout, Cin, dtype, st, det);
         if (rc == AFI_OK) {
             if (accum) return AFI_OK;                      // transformed at afi_wino_wgrad_flush()
             return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
@@ -598,7 +605,7 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     g.X = AfiView{Vb, 0, 0, Cin}; g.x_stride = 1; g.xH = 1; g.xW = (int)Tpad; g.x_sTap = Tpad * Cin;
     g.DW = dU; g.dw_sRow = Cin; g.dw_sTap = (long long)Cout * Cin;
     g.alpha = 1.f; g.splitK = 0;
-    AFI_TRY(afi_launch_wgrad_gemm(g, st));
+    AFI_TRY(wgrad_launch(cx, g, st));
     if (accum) return AFI_OK;
     return f4 ? afi_launch_wino4_dw(dU, dw, Cout, Cin, alpha, st) : afi_launch_wino_dw(dU, dw, Cout, Cin, alpha, st);
 }
@@ -808,7 +815,7 @@ int afi_conv3x3_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H,
     afi_ctx* cx = ctx; (void)cx;
     AFI_CTX_CHECK(ctx);
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
-    return afi_launch_wgrad_gemm(conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha), (hipStream_t)stream);
+    return wgrad_launch(cx, conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha), (hipStream_t)stream);
 }
 
 long long afi_conv3x3_wino_ws_floats(int N, int H, int W, int Cin, int Cout) { return wino_ws_floats(N, H, W, Cin, Cout); }
@@ -874,7 +881,7 @@ int afi_conv1x1_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H,
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     AfiWgradGemm g = conv_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dw, alpha);
     g.ntaps = 1; g.dw_sRow = Cin; g.dw_sTap = 0;
-    return afi_launch_wgrad_gemm(g, (hipStream_t)stream);
+    return wgrad_launch(cx, g, (hipStream_t)stream);
 }
 
 // ---- Conv2d(k=3, stride=2, padding=1): the PAFPN bottom-up downsample (pafpn_sr.py:105-117,178-183) ----
@@ -937,7 +944,7 @@ int afi_conv3x3s2_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int 
     if (Hi < 1 || Wi < 1) return AFI_ERR_BAD_ARG;
     AfiWgradGemm g = conv_wgrad_desc(V(dy), V(x), N, (Hi + 1) / 2, (Wi + 1) / 2, Cout, Cin, dw, alpha);
     g.x_stride = 2; g.xH = Hi; g.xW = Wi;
-    return afi_launch_wgrad_gemm(g, (hipStream_t)stream);
+    return wgrad_launch(cx, g, (hipStream_t)stream);
 }
 int afi_relu_bwd(const float* g, const float* act, float* out, long long n, float scale, void* stream) {
     return afi_launch_relu_bwd(g, act, out, n, scale, (hipStream_t)stream);
@@ -1001,7 +1008,7 @@ int afi_convT6s2_wgrad(afi_ctx_t* ctx, afi_view_t dy, afi_view_t x, int N, int H
     afi_ctx* cx = ctx; (void)cx;
     AFI_CTX_CHECK(ctx);
     if ((Cout & 3) || (Cin & 3)) return AFI_ERR_UNSUPPORTED;
-    return afi_launch_wgrad_gemm(convT_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dwp, alpha), (hipStream_t)stream);
+    return wgrad_launch(cx, convT_wgrad_desc(V(dy), V(x), N, H, W, Cout, Cin, dwp, alpha), (hipStream_t)stream);
 }
 
 int afi_bilinear2x_add_fwd(afi_view_t x, int N, int H, int W, int C, float beta, float* out, void* stream) {
@@ -1374,7 +1381,8 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     // 7 .. 36-tile launch per layer on a side stream.  All their operands (dOut, dU, gA, gB, the per-block gradient buffers and the
     // saved activations) stay alive until the call returns.  AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS = 0 restores the per-layer launches.
     const bool bf6 = afi_dtype_smallmap6(cx ? cx->dtype : afi_default_dtype());
-    const bool grouped = l.P <= afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS) || (bf6 && s.n_img > 0 && l.P <= afi_opt(cx, AFI_OPT_G_SMALLMAP6_MAX_PIXELS));
+    // (AFI_OPT_DETERMINISTIC: the grouped stream-K launches add the tiles two runs share by atomics -- the per-layer launches instead)
+    const bool grouped = !afi_det(cx) && (l.P <= afi_opt(cx, AFI_OPT_G_GROUPED_WGRAD_MAX_PIXELS) || (bf6 && s.n_img > 0 && l.P <= afi_opt(cx, AFI_OPT_G_SMALLMAP6_MAX_PIXELS)));
     const bool batch_growth = !grouped && afi_opt(cx, AFI_OPT_G_BATCH_GROWTH_GRADS) != 0 && (4 * G <= C || s.n_wino == 0);   // larger maps: a block's four growth-conv weight gradients as one packed GEMM (below)
     // Small maps under the default arithmetic: the data-gradient GEMMs on pre-split weight images and the grouped weight gradients on the
     // bf16 matrix cores in the six-product form (csrc/smallmap.hip).  The four growth convs' weight gradients of a block then run as ONE
@@ -1391,14 +1399,14 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
     auto defer = [&](const AfiWgradGemm& g) {
         if (g.Mrows <= 32 && n_narrow < 4 * AFI_MAX_RDB) { wg_narrow[n_narrow++] = g; return AFI_OK; }
         if (g.Mrows > 32 && n_wide < kWide) { wg_wide[n_wide++] = g; return AFI_OK; }
-        return afi_launch_wgrad_gemm(g, (hipStream_t)stream);       // table full (unusual shapes): launch it on its own
+        return wgrad_launch(cx, g, (hipStream_t)stream);       // table full (unusual shapes): launch it on its own
     };
     // weight gradient of a 3x3 conv: Winograd F(3x3,2x2) when both channel counts and the map are large enough, else direct
     auto WG = [&](AfiView dyv, AfiView xin, int n_, int h_, int w_, int co, int ci, float* dw, float alpha, hipStream_t s_) {
         if (grouped) return defer(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha));
         if (s.n_wino > 0 && co >= 128 && ci >= 128 && (long long)n_ * h_ * w_ >= wino_g_minpix(cx) && afi_opt(cx, AFI_OPT_WINOGRAD))
             return wino_wgrad(cx, dyv, xin, n_, h_, w_, co, ci, dw, alpha, scratch + s.o_wino2, s.n_wino, s_);
-        return afi_launch_wgrad_gemm(conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha), s_);
+        return wgrad_launch(cx, conv_wgrad_desc(dyv, xin, n_, h_, w_, co, ci, dw, alpha), s_);
     };
     auto CS = [&](const float* g, long long rows, int Cc, long long ld, float* db, hipStream_t s_) {
         if (grouped) { cs[n_cs++] = AfiColsumProb{g, db, rows, ld, Cc, 1.f}; return AFI_OK; }
@@ -1505,7 +1513,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
         } else if (s.n_wino > 0 && C >= 128 && P >= wino_g_minpix(cx) && afi_opt(cx, AFI_OPT_WINOGRAD)) {    // the four phases as channel blocks of one Winograd weight gradient
             AFI_TRY(wino_wgrad(cx, dU, a7, N, H, W, 4 * C, C, dwp, 1.f, scratch + s.o_wino2, s.n_wino, sd, /*dy_phases=*/4, /*accumulate=*/false));
         } else {
-            AFI_TRY(afi_launch_wgrad_gemm(convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));
+            AFI_TRY(wgrad_launch(cx, convT_wgrad_desc(dU, a7, N, H, W, C, C, dwp, 1.f), sd));
         }
         if (!grouped) AFI_TRY(afi_launch_convT_unpack_grad(dwp, gr->wT, C, C, sd));
     }
@@ -1592,7 +1600,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
             if (!grouped) fk.after_main();                               // dyk's slice was finalised by the previous dgrad
             if (gr->rdb_w[r][k - 1] && !batch_growth && !pack_growth6) {
                 const AfiWgradGemm wd = conv_wgrad_desc(dyk, b, N, H, W, G, cin, gr->rdb_w[r][k - 1], 1.f);
-                AFI_TRY(grouped ? defer(wd) : afi_launch_wgrad_gemm(wd, sd));
+                AFI_TRY(grouped ? defer(wd) : wgrad_launch(cx, wd, sd));
             }
             if (batch_growth) {
                 // larger maps: only the part of conv_k's data gradient that lands on y_1 .. y_{k-1} (channels [C, cin): (k-1) G columns) runs
@@ -1650,7 +1658,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
             const bool wino_ok = s.n_wino > 0 && 4 * G >= 128 && L >= 128 && P >= wino_g_minpix(cx) && afi_opt(cx, AFI_OPT_WINOGRAD) &&
                                  s.n_wino >= wino_ws_floats(N, H, W, L, 4 * G);
             if (wino_ok) AFI_TRY(wino_wgrad(cx, dy4, b, N, H, W, 4 * G, L, packed, 1.f, scratch + s.o_wino2, s.n_wino, sd, /*dy_phases=*/1, /*accumulate=*/false));
-            else AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(dy4, b, N, H, W, 4 * G, L, packed, 1.f), sd));
+            else AFI_TRY(wgrad_launch(cx, conv_wgrad_desc(dy4, b, N, H, W, 4 * G, L, packed, 1.f), sd));
             float* const dws[4] = {gr->rdb_w[r][0], gr->rdb_w[r][1], gr->rdb_w[r][2], gr->rdb_w[r][3]};
             AFI_TRY(afi_launch_rdb_wgrad_unpack(packed, dws, C, G, 1.f, sd));
         }
@@ -1862,7 +1870,7 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
     if (gr->w3) {
         AfiWgradGemm g = conv_wgrad_desc(dense_view(dd9, H, W, 16), y2, N, H, W, 9, F3, gr->w3, 1.f);
         g.ntaps = 1; g.dw_sRow = F3; g.dw_sTap = 0;
-        AFI_TRY(afi_launch_wgrad_gemm(g, sd));
+        AFI_TRY(wgrad_launch(cx, g, sd));
     }
     {
         AfiPixGemm g = pix_default(N, H, W);
@@ -1896,7 +1904,7 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
         if (xin_folded) x_bn = AfiBnLoad{ws + l.o_mean[n - 1], ws + l.o_invstd[n - 1], prm->gamma[n - 1], prm->beta[n - 1]};
         if (gr->w[n] && wino) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd, 1, true, xin_folded ? &x_bn : nullptr,
                                                  slots ? gmax + 4 * n : nullptr, slots ? xmax + 4 * n : nullptr));
-        else if (gr->w[n]) AFI_TRY(afi_launch_wgrad_gemm(conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
+        else if (gr->w[n]) AFI_TRY(wgrad_launch(cx, conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0 && wino) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), null_view(), scratch + s.o_wino,
                               s.n_wino, part_, part_n_, st, false, nullptr, nullptr, nullptr, slots ? gmax + 4 * n : nullptr, /*known=*/true));

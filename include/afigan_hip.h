@@ -143,7 +143,13 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                * activation is never written (afi_discriminator_saved_activations) -- bit-identical results, one full read + write of
                                                * the activation less per block, and measured SLOWER: the transforms re-apply the affine on every overlapping tile read
                                                * (stage-1 step 103.7 against 103.5 ms, 113.6 against 113.2 with every kernel alone on the chip) */
-#define AFI_OPT_COUNT 12
+#define AFI_OPT_DETERMINISTIC 12              /* 0 (default): weight-gradient GEMMs whose pixel range is split over blocks add their partial tiles by fp32 atomics
+                                               * (summation order varies run to run: results agree to ~1e-6, not bit for bit).  1: no weight gradient is split
+                                               * over blocks -- the Winograd TN GEMM and the direct weight-gradient kernel run one block per tile over the whole
+                                               * pixel range, the interpolator's small-map backward takes the per-layer launches instead of the grouped
+                                               * stream-K ones, bias sums take the two-stage fixed-order reduction -- so that two runs from the same state produce
+                                               * the same bits (a resumed run continues bit for bit: tests/test_gpu_stage1.py).  Slower: for reproducing, not for speed. */
+#define AFI_OPT_COUNT 13
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over

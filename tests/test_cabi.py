@@ -130,7 +130,7 @@ def test_option_defaults_without_a_context():
     lib = _lib.load()
     want = {"winograd": 1, "winograd_f4_backward": 1, "winograd_f4_forward": 0, "bn_stats_fp64": 1, "d_winograd_min_pixels": 1024,
             "g_winograd_min_pixels": 2048, "g_smallmap_max_pixels": 2048, "g_grouped_wgrad_max_pixels": 3000,
-            "g_batch_growth_grads": 1, "g_smallmap6_max_pixels": 4096, "g_rdb_chain": 0, "d_fold_bn_apply": 0}
+            "g_batch_growth_grads": 1, "g_smallmap6_max_pixels": 4096, "g_rdb_chain": 0, "d_fold_bn_apply": 0, "deterministic": 0}
     assert set(want) == set(_lib.OPTIONS)
     for k, v in want.items():
         assert lib.afi_ctx_get_option(None, _lib.OPTIONS[k]) == v, k
@@ -142,3 +142,40 @@ def test_option_defaults_without_a_context():
         syms = subprocess.run([nm, "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
         assert "fopen" in syms or "hip" in syms             # (the listing worked)
         assert "getenv" not in syms, "the library must not read the environment (options live in afi_ctx_t)"
+
+
+def test_build_id_names_the_sources_of_this_tree():
+    """afi_build_id(): the library carries the sha256 of the sources it was compiled from (written by __graft_entry__.build()), the binding
+    recomputes it from the tree and refuses another build -- 'which binary ran' has one answer."""
+    _build()
+    import __graft_entry__ as ge
+    from afigan_amd import _lib
+    assert _lib.build_id() == ge.source_digest() == _lib.tree_digest() and len(_lib.build_id()) == 64
+    # a library whose digest differs is refused (the check itself, on a doctored expectation)
+    import pytest
+    real = _lib.tree_digest
+    _lib._lib = None
+    try:
+        _lib.tree_digest = lambda: "0" * 64
+        with pytest.raises(_lib.AfiError, match="built from other sources"):
+            _lib.load()
+    finally:
+        _lib.tree_digest = real
+        _lib._lib = None
+        _lib.load()
+
+
+def test_host_entry_points_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY 5 ('-fsanitize=address host builds'), VERDICT r4 missing 3: the HOST side of the library -- workspace layouts, the option /
+    context API, the stream-K plan, status strings, scratch-size queries: ~1,900 lines of pointer and offset arithmetic in nets.hip -- built with
+    -fsanitize=address,undefined (host code only: GPU sanitizers are not available on this pool) and driven by tests/host_sanitizer_driver.cpp,
+    which walks the same calls as the tests above over a sweep of shapes.  `make -C afigan_amd/csrc sanitize-check` is the target."""
+    import shutil
+    import subprocess
+    if not shutil.which("make") or not os.path.exists("/opt/rocm/bin/hipcc"):
+        import pytest
+        pytest.skip("needs make and hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "afigan_amd", "csrc"), "sanitize-check", f"BUILD={tmp_path}"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "host sanitizer driver: ok" in r.stdout, r.stdout[-2000:]

@@ -570,3 +570,54 @@ def test_stage1_reference_checkpoint_layout_round_trips_through_torch_sgd(amd):
     bad = copy.deepcopy(saved); bad["D"]["iteration"] = 7
     with pytest.raises(ValueError):
         eng.load_reference_checkpoints(bad)
+
+
+def test_stage1_deterministic_option_resumes_bit_for_bit(amd):
+    """AFI_OPT_DETERMINISTIC on both of the engine's contexts: no weight gradient is split over blocks that meet in atomics, so (1) two runs
+    from the same state produce the same bits, and (2) a run that is saved after 2 steps and resumed in fresh modules continues bit for bit
+    where 4 uninterrupted steps land (without the option: 1e-5, test_stage1_engine_state_round_trip).  Maps large enough for the Winograd
+    weight gradients (the split-K TN GEMM) on the first level, small-map kernels on the second."""
+    import copy
+    C = 128
+    torch.manual_seed(41)
+    G0 = amd.Generator(in_channels=C, n_residual_dense_blocks=1, growth_rate=32).cuda()
+    D0 = amd.Discriminator(in_filters=C).cuda()
+    gen = torch.Generator().manual_seed(42)
+    batches = [([torch.randn((1, C, 24, 44), generator=gen).cuda(), torch.randn((1, C, 7, 11), generator=gen).cuda()],
+                [torch.randn((1, C, 47, 87), generator=gen).cuda(), torch.randn((1, C, 13, 21), generator=gen).cuda()]) for _ in range(4)]
+    sched = dict(base_lr=0.01, lr_steps=(3,), lr_gamma=0.5, warmup_factor=0.1, warmup_iters=2)
+
+    def engine(G, D):
+        e = amd.Stage1Step(G, D, **sched)
+        for cx in (e.ctx, e.bctx):
+            cx.set_option("deterministic", 1)
+        return e
+
+    def flat(G, D):
+        return torch.cat([v.detach().reshape(-1).float().cpu() for v in list(G.state_dict().values()) + list(D.state_dict().values())])
+
+    runs = []
+    for _ in range(2):
+        Ga, Da = copy.deepcopy(G0), copy.deepcopy(D0)
+        e = engine(Ga, Da)
+        for lr_f, hr_f in batches:
+            e.run_step(lr_f, hr_f)
+        torch.cuda.synchronize()
+        runs.append(flat(Ga, Da))
+    assert torch.equal(runs[0], runs[1])                       # (1)
+    Gb, Db = copy.deepcopy(G0), copy.deepcopy(D0)
+    first = engine(Gb, Db)
+    for lr_f, hr_f in batches[:2]:
+        first.run_step(lr_f, hr_f)
+    torch.cuda.synchronize()
+    ck = {"G": {k: v.cpu() for k, v in Gb.state_dict().items()}, "D": {k: v.cpu() for k, v in Db.state_dict().items()}, "engine": first.state_dict()}
+    Gc = amd.Generator(in_channels=C, n_residual_dense_blocks=1, growth_rate=32).cuda()
+    Dc = amd.Discriminator(in_filters=C).cuda()
+    Gc.load_state_dict(ck["G"]); Dc.load_state_dict(ck["D"])
+    second = engine(Gc, Dc)
+    second.load_state_dict(ck["engine"])
+    for lr_f, hr_f in batches[2:]:
+        second.run_step(lr_f, hr_f)
+    torch.cuda.synchronize()
+    assert torch.equal(flat(Gc, Dc), runs[0])                  # (2)
+    assert float((runs[0] - flat(G0, D0)).abs().max()) > 0     # (the steps moved the weights)
