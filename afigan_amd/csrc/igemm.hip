@@ -875,15 +875,13 @@ AfiF16Bound afi_f16_bound(const float* amax, int kind) {
     }
     return b;
 }
-// smallest number of 256 x 256 tiles from which the NT GEMM takes the large-tile kernel (0: never); a process-wide A/B knob of the
-// micro-benchmarks (afi_debug_set_nt256_min_tiles), not an option of the product path
-static long long g_nt256 = 512;
+// the ONE process-wide switch of this file, for the micro-benchmark tools/micro/nt_f16_ablate.py only: which ablated instantiation of the
+// 128 x 128 kernel the next launches take (afi_gemm_f16.h: ABL, wrong results but for bit 16), + 32 = never the 256 x 256 tile.  0 = the product.
 static int g_nt_abl = 0;
-extern "C" void afi_debug_set_nt256_min_tiles(long long v) { g_nt256 = v; }
 extern "C" void afi_debug_set_nt_ablation(int v) { g_nt_abl = v; }
 // a_pre: A holds the planes already split into fp16 pieces (winograd.hip, afi_store_split4) with the scales of `ab`
 int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st,
-                             bool a_pre) {
+                             bool a_pre, long long nt256_min_tiles) {
     if (planes <= 0 || planes > 36 || rows_per_plane <= 0 || N <= 0 || K <= 0 || !ab.amax) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
     AfiGemmNT g{A, (const float*)Bimg, C, rows_per_plane, planes, N, K};
@@ -896,7 +894,7 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
     // the 256 x 256 tile (half the operand bytes per product) where it fills the chip: 256-column multiples, at least two rounds of CUs
     const int tpp = afi_cdiv(rows_per_plane, 256);
     const long long tiles256 = (long long)planes * tpp * (N / 256);
-    if (g_nt256 && !(N % 256) && tiles256 >= g_nt256) {
+    if (nt256_min_tiles > 0 && !(g_nt_abl & 32) && !(N % 256) && tiles256 >= nt256_min_tiles) {
         if (!afi_opt_in_big_lds(a_pre ? (const void*)afi_gemm_nt_f16x3_w16_kernel<true> : (const void*)afi_gemm_nt_f16x3_w16_kernel<false>)) return AFI_ERR_LAUNCH;
         const int ntm2 = planes * tpp, ntn2 = N / 256, chunk2 = afi_cdiv(ntm2, 8);
         prof.split = 3;
@@ -908,17 +906,18 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
         hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 0, true>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }
-    if (g_nt_abl == 1) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 2) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 2>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 4) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 8) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 8>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 16) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 16>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 12) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 12>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 6) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 6>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 14) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 14>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 10) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 10>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 20) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 20>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else if (g_nt_abl == 24) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 24>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    const int abl = g_nt_abl & 31;
+    if (abl == 1) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 2) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 2>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 4) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 8) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 8>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 16) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 16>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 12) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 12>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 6) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 6>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 14) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 14>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 10) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 10>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 20) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 20>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else if (abl == 24) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 24>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
     else hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }

@@ -24,7 +24,7 @@ long long afi_f16_image_bytes(int planes, int N, int K);
 int afi_launch_absmax_planes(const float* X, long long per_plane, int planes, float* out, hipStream_t st);
 AfiF16Bound afi_f16_bound(const float* amax, int kind);    // kind: 0 exact per-plane maxima, 1 / 2 F(2x2) / F(4x4) input planes, 3 / 4 F(2x2) / F(4x4) dY planes
 int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st,
-                             bool a_pre = false);
+                             bool a_pre = false, long long nt256_min_tiles = 512);
 int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
                              hipStream_t st, bool pre = false, bool deterministic = false);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
@@ -132,7 +132,7 @@ struct WinoWgradAccum {
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ 0, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
-                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0, /*DETERMINISTIC*/ 0}};
+                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0, /*DETERMINISTIC*/ 0, /*F16_PRESPLIT*/ 1, /*F16_NT256_MIN_TILES*/ 512}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -149,9 +149,7 @@ struct afi_ctx {
 };
 static inline long long afi_opt(const afi_ctx* cx, int o) { return cx ? cx->opt.v[o] : kDefaultOptions.v[o]; }
 static inline int afi_default_dtype() { return AFI_DTYPE_DEFAULT; }
-// micro-benchmark A/B knob (process-wide, not an option of the product path): 0 = no transform writes its planes split, whatever is known
-static int g_presplit = 1;
-extern "C" void afi_debug_set_presplit(int v) { g_presplit = v; }
+
 static inline bool afi_dtype_ok(int d) { return d == AFI_DTYPE_F32 || d == AFI_DTYPE_BF16 || d == AFI_DTYPE_F16X3 || d == AFI_DTYPE_BF16X3 || d == AFI_DTYPE_BF16X6; }
 // the small-map schedule of the interpolator (csrc/smallmap.hip) has one emulated-fp32 form, six bf16 products on pre-split weight images;
 // both fp32-grade settings of the big GEMMs take it
@@ -469,7 +467,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     // split into fp16 pieces; given and not known: a zero-filled slot of the caller's that the transform raises (the caller keeps it, e.g. for
     // the backward pass); not given: a slot of the call's pool.
     const bool want_amax = dma && f16;
-    const bool a_pre = g_presplit && want_amax && g.a_amax && g.a_amax_known && nph == 1 && !(g.Ck & 31) && !g.a_bn.mean;
+    const bool a_pre = afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 && want_amax && g.a_amax && g.a_amax_known && nph == 1 && !(g.Ck & 31) && !g.a_bn.mean;
     if (want_amax && !(amax = g.a_amax ? g.a_amax : wino_amax_take(cx, ws, ws_floats, 1, st))) return AFI_ERR_LAUNCH;
     const AfiF16Bound abound = afi_f16_bound(amax, f4 ? 2 : 1);
     for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
@@ -481,7 +479,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
                    : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn, raise, a_pre ? &abound : nullptr));
     }
     if (dma) {
-        if (f16) AFI_TRY(afi_launch_gemm_nt_f16x3(Vb, Usp, Mb, np, Tpad, Nc, K, abound, st, a_pre));
+        if (f16) AFI_TRY(afi_launch_gemm_nt_f16x3(Vb, Usp, Mb, np, Tpad, Nc, K, abound, st, a_pre, afi_opt(cx, AFI_OPT_F16_NT256_MIN_TILES)));
         else AFI_TRY(afi_launch_gemm_nt_bf16_dma(Vb, Usp, Mb, np, Tpad, Nc, K, dtype, st));
         return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
     }
@@ -573,7 +571,7 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
     // dy_amax, x_amax (f16x3): the largest magnitudes of the two source tensors where their producers published them: both transforms then
     // write their planes already split into fp16 pieces and the GEMM stages them by DMA alone; otherwise the transforms raise two slots of the pool
-    const bool pre = g_presplit && f16 && dy_amax && x_amax && dy_phases == 1 && !(x_bn && x_bn->mean);
+    const bool pre = afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 && f16 && dy_amax && x_amax && dy_phases == 1 && !(x_bn && x_bn->mean);
     const bool known = f16 && dy_amax && x_amax;           // (known but not split: the in-register kernel with the known maxima; nothing is raised)
     if (f16 && !known && !(amax = wino_amax_take(cx, ws, ws_floats, 2, st))) return AFI_ERR_LAUNCH;
     const AfiF16Bound vbound = afi_f16_bound(known ? x_amax : amax, f4 ? 2 : 1), qbound = afi_f16_bound(known ? dy_amax : amax + 4, f4 ? 4 : 3);

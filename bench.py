@@ -72,8 +72,6 @@ def parse():
     ap.add_argument("--profile-timed", action="store_true", help="record the library's per-launch HIP events INSIDE the timed region (default: over a repeat of "
                     "the same K steps right behind it, so that the headline number carries no event records); the rocprofv3 passes use it: their traces "
                     "then hold exactly the timed launches")
-    ap.add_argument("--debug-knob", action="append", default=[], metavar="NAME=VALUE",
-                    help="process-wide A/B knobs of the micro-benchmarks (afi_debug_set_<NAME>(VALUE)): nt256_min_tiles, presplit, nt_ablation")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
     ap.add_argument("--one-stream", action="store_true", help="Stage1Step(overlap_d=False, overlap_g=False): every kernel alone on the chip (the "
@@ -517,12 +515,6 @@ def main():
     from afigan_amd import _lib
     from afigan_amd.guide import GuideR50FPN
     lib = _lib.load()
-    for kv in args.debug_knob:
-        name, _, val = kv.partition("=")
-        import ctypes
-        fn = getattr(lib, "afi_debug_set_" + name)
-        fn.restype = None
-        fn(ctypes.c_longlong(int(val)) if name == "nt256_min_tiles" else ctypes.c_int(int(val)))
 
     B = args.batch_per_gpu
     torch.manual_seed(1234)                       # same init on every rank (and rank 0's weights are broadcast anyway)

@@ -149,7 +149,13 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                * pixel range, the interpolator's small-map backward takes the per-layer launches instead of the grouped
                                                * stream-K ones, bias sums take the two-stage fixed-order reduction -- so that two runs from the same state produce
                                                * the same bits (a resumed run continues bit for bit: tests/test_gpu_stage1.py).  Slower: for reproducing, not for speed. */
-#define AFI_OPT_COUNT 13
+#define AFI_OPT_F16_PRESPLIT 13               /* 1 (default): under AFI_DTYPE_F16X3, a Winograd transform whose source tensor's largest magnitude is known before it
+                                               * runs (the discriminator's activations and gradients: published by the BatchNorm passes that write them) writes
+                                               * its planes already split into the two fp16 pieces and the GEMM stages them by DMA alone.  0: every plane is
+                                               * written in fp32 and split when the GEMM reads its fragments (same results; stage-1 step 86.6 against 84.4 ms) */
+#define AFI_OPT_F16_NT256_MIN_TILES 14        /* 512: the f16x3 NT GEMM takes its 256 x 256 tile (sixteen waves per block, half the operand bytes per product)
+                                               * from this many tiles on (and 256-column multiples); 0: never (the 128 x 128 tile everywhere) */
+#define AFI_OPT_COUNT 15
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over

@@ -19,7 +19,7 @@ def run(planes, rows, N, K, iters=20):
     variants = list(_lib.DTYPES.items()) + [("f16x3/128", _lib.DTYPES["f16x3"])]       # the last: the 128 x 128 tile kernel on every shape
     for name, dt in variants:
         import ctypes
-        _lib.load().afi_debug_set_nt256_min_tiles(ctypes.c_longlong(0 if name == "f16x3/128" else 512))
+        _lib.load().afi_debug_set_nt_ablation(32 if name == "f16x3/128" else 0)
         nb = _lib.load().afi_gemm_nt_scratch_bytes(planes, N, K, dt)
         sc = torch.empty(max(int(nb), 16), device="cuda", dtype=torch.uint8)
         args = (C.c_void_p(A.data_ptr()), C.c_void_p(B.data_ptr()), C.c_void_p(Cm.data_ptr()), planes, rows, N, K, dt, C.c_void_p(sc.data_ptr()), nb, st)

@@ -1,4 +1,4 @@
-# A/B of process-wide debug knobs on ONE box: the stage-1 step (two-stream wall time, 3 alternating rounds) for each argument string.
+# A/B of bench.py argument strings (context options: --option name=value; --dtype) on ONE box: the stage-1 step (two-stream wall time, 3 alternating rounds) for each argument string.
 # Usage: bash tools/micro/knob_ab.sh "<bench args A>" "<bench args B>" ...
 set -e
 R=${GRAFT_REPO_ROOT:-.}

@@ -39,9 +39,8 @@ def main():
         out = torch.empty((planes, rows, N), device="cuda")
         fl = 2.0 * planes * rows * N * K
         for tiles256, tag in ((0, "128x128"), (512, "256x256")):
-            lib.afi_debug_set_nt256_min_tiles(C.c_longlong(tiles256))
             for abl in ([0, 2, 4, 8] if tiles256 == 0 else [0]):
-                lib.afi_debug_set_nt_ablation(abl)
+                lib.afi_debug_set_nt_ablation(abl + (32 if tiles256 == 0 else 0))
                 ms = kernel_ms(lib, lambda: amd.ops.gemm_nt(A, B, "f16x3", out=out))
                 print(f"{planes}x{rows}x{N}x{K} {tag} {NAMES[abl]:55s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TFLOP/s", flush=True)
         lib.afi_debug_set_nt_ablation(0)
@@ -51,12 +50,12 @@ def main():
         # the same kernels on operands that cost the multipliers nothing: how much of the time is the clock the chip holds under random data
         for name, (A2, B2) in (("all-zero operands", (torch.zeros_like(A), torch.zeros_like(B))), ("small integers (|x| <= 2)", (torch.randint(-2, 3, A.shape, device="cuda").float(), torch.randint(-2, 3, B.shape, device="cuda").float()))):
             for tiles256, tag in ((0, "128x128"), (512, "256x256")):
-                lib.afi_debug_set_nt256_min_tiles(C.c_longlong(tiles256))
+                lib.afi_debug_set_nt_ablation(32 if tiles256 == 0 else 0)
                 ms = kernel_ms(lib, lambda: amd.ops.gemm_nt(A2, B2, "f16x3", out=out))
                 print(f"{planes}x{rows}x{N}x{K} f16x3 {tag} on {name:44s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TFLOP/s", flush=True)
             ms = kernel_ms(lib, lambda: amd.ops.gemm_nt(A2, B2, "bf16x6", out=out))
             print(f"{planes}x{rows}x{N}x{K} bf16x6 on {name:52s} {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TFLOP/s", flush=True)
-        lib.afi_debug_set_nt256_min_tiles(C.c_longlong(512))
+        lib.afi_debug_set_nt_ablation(0)
 
 
 if __name__ == "__main__":
