@@ -125,6 +125,8 @@ SIGNATURES = {
     "afi_bn_stats": (_i, [_vp, _ll, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "afi_bn_apply_lrelu_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp]),
     "afi_bn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp]),
+    "afi_bn_bwd_sums": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _i, _vp, _vp]),
+    "afi_bn_bwd_apply": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _i, _vp]),
     "afi_colsum_accum": (_i, [_vp, _ll, _i, _ll, _f, _vp, _vp, _vp]),
     "afi_bce_logits_fwd_bwd": (_i, [_vp, _ll, _f, _f, _vp, _f, _vp, _vp]),
     "afi_l1_fwd_bwd": (_i, [View, View, _i, _i, _i, _i, _i, _i, _f, _vp, _f, _vp, _vp]),

@@ -21,8 +21,9 @@ synchronisation, so it can be captured into a hipGraph (``bench.py`` measures bo
 In training mode nothing is folded: each piece is a torch.autograd.Function over its HIP forward and backward
 (afi_fuse_swish_bwd, afi_dwconv3x3_fwd with reversed taps + afi_dwconv3x3_wgrad, afi_conv1x1_{dgrad,wgrad}, afi_maxpool3s2_same_bwd,
 the interpolator's own backward), and the norms use batch statistics with the reference's eps / momentum (afi_bn_stats_ex,
-afi_bn_apply_fwd, afi_bn_bwd).  "SyncBN" is taken as per-process BatchNorm: statistics are NOT exchanged between ranks (the reference
-has no multi-GPU training recipe for this backbone; with world_size 1 the two are the same function).
+afi_bn_apply_fwd, afi_bn_bwd).  norm = "SyncBN" (the reference default) under a process group of several ranks takes the batch statistics of
+ALL ranks' pixels, as detectron2's / torch's SyncBatchNorm do: one all_gather of (mean, variance, count) per norm in the forward, one all_reduce
+of (sum g, sum g xhat) in the backward (_SyncBatchNormTrainFn; afi_bn_bwd_sums / afi_bn_bwd_apply); with one rank it is plain BatchNorm.
 """
 import math
 
@@ -58,6 +59,7 @@ def _make_norm(norm, ch, eps=1e-5, momentum=0.1):
     if norm not in ("BN", "SyncBN"):
         raise _lib.AfiError(f'norm "{norm}" is not supported on the BiFPN path (BN / SyncBN / "")')
     bn = nn.BatchNorm2d(ch, eps=eps, momentum=momentum)      # SyncBN == BN within one process; same state_dict entries
+    bn._afi_sync = norm == "SyncBN"                           # several ranks: batch statistics over all of them (_SyncBatchNormTrainFn)
     return bn
 
 
@@ -184,10 +186,71 @@ class _BatchNormTrainFn(torch.autograd.Function):
         return dx.view(N, H, W, C_).permute(0, 3, 1, 2), dgamma, dbeta, None
 
 
+class _SyncBatchNormTrainFn(torch.autograd.Function):
+    """norm = "SyncBN" (the reference default, bifpn_sr.py:210,279-280: detectron2's NaiveSyncBatchNorm / nn.SyncBatchNorm) in training mode
+    under a process group of several ranks: the batch statistics are those of ALL ranks' pixels.  Forward: this rank's mean / biased
+    variance / pixel count (afi_bn_stats_ex), ONE all_gather of the [2 C + 1] vector, combined as torch.batch_norm_gather_stats_with_counts
+    does (mean = sum n_r mean_r / N, var = sum n_r (var_r + mean_r^2) / N - mean^2), running buffers updated with the global statistics
+    (unbiased variance over N).  Backward: this rank's (sum g, sum g xhat) (afi_bn_bwd_sums; dbeta / dgamma stay per rank, as torch keeps them
+    for the data-parallel wrapper to average), ONE all_reduce, then dx with the global sums over N pixels (afi_bn_bwd_apply)."""
+
+    @staticmethod
+    @_lib.ctx_forward
+    def forward(ctx, x, gamma, beta, bn):
+        import torch.distributed as dist
+        x = _dense_pm(x.detach())
+        N, C_, H, W = x.shape
+        x2d = x.permute(0, 2, 3, 1).reshape(N * H * W, C_)
+        mean_l, _inv_l, var_l = ops.bn_stats_ex(x2d, bn.eps, 0.0, None, None, None, want_var=True)
+        mine = torch.cat([mean_l, var_l, torch.tensor([float(N * H * W)], device=x.device)])
+        allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(allv, mine)
+        st = torch.stack(allv).double()                      # [world, 2 C + 1]
+        cnt = st[:, -1:]
+        total = cnt.sum()
+        mean = (st[:, :C_] * cnt).sum(0) / total
+        var = ((st[:, C_:2 * C_] + st[:, :C_] ** 2) * cnt).sum(0) / total - mean ** 2
+        var = var.clamp_min(0.0)
+        invstd = torch.rsqrt(var + bn.eps).float()
+        mean = mean.float()
+        if bn.track_running_stats and bn.running_mean is not None:
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(int(bn.num_batches_tracked) + 1)
+            unb = (var * (total / (total - 1).clamp_min(1.0))).float()
+            bn.running_mean.mul_(1.0 - mom).add_(mean, alpha=mom)
+            bn.running_var.mul_(1.0 - mom).add_(unb, alpha=mom)
+            bn.num_batches_tracked.add_(1)
+        g, b = gamma.detach().contiguous(), beta.detach().contiguous()
+        y = ops.bn_apply(x2d, mean, invstd, g, b)
+        ctx.save_for_backward(x, mean, invstd, g)
+        ctx.total = int(total.item())
+        return y.view(N, H, W, C_).permute(0, 3, 1, 2)
+
+    @staticmethod
+    @_lib.ctx_backward
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, mean, invstd, g = ctx.saved_tensors
+        N, C_, H, W = x.shape
+        dy2d = _dense_pm(dy).permute(0, 2, 3, 1).reshape(N * H * W, C_)
+        x2d = x.permute(0, 2, 3, 1).reshape(N * H * W, C_)
+        dgamma, dbeta = torch.zeros_like(g), torch.zeros_like(g)
+        sums = ops.bn_bwd_sums(dy2d, x2d, mean, invstd, dgamma, dbeta)
+        dist.all_reduce(sums)
+        dx = ops.bn_bwd_apply(dy2d, x2d, mean, invstd, g, sums, ctx.total)
+        return dx.view(N, H, W, C_).permute(0, 3, 1, 2), dgamma, dbeta, None
+
+
+def _sync_active(bn):
+    return getattr(bn, "_afi_sync", False) and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+
 def _norm_train(x, bn):
-    """A norm layer inside the autograd graph: batch statistics when the layer is in training mode, its running ones otherwise."""
+    """A norm layer inside the autograd graph: batch statistics when the layer is in training mode (of all ranks' pixels for a "SyncBN" layer
+    under a process group of several ranks), its running ones otherwise."""
     if bn is None:
         return x
+    if bn.training and _sync_active(bn):
+        return _SyncBatchNormTrainFn.apply(x, bn.weight, bn.bias, bn)
     if bn.training:
         return _BatchNormTrainFn.apply(x, bn.weight, bn.bias, bn)
     return torch.nn.functional.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
@@ -278,14 +341,10 @@ class BiFPN_AFIGAN(nn.Module):
         return f
 
     def _check_syncbn(self):
-        """norm="SyncBN" (the reference default, bifpn_sr.py:210) exchanges batch statistics between ranks; this path computes them per
-        process.  With one rank the two are the same function; with more they are not, so a TRAINING-mode forward under an initialised
-        process group of more than one rank is refused instead of silently differing (the reference ships no multi-GPU recipe for this
-        backbone; pass norm="BN" to train with per-rank statistics on purpose)."""
-        if self._norm == "SyncBN" and self.training and torch.distributed.is_available() and torch.distributed.is_initialized() \
-                and torch.distributed.get_world_size() > 1:
-            raise _lib.AfiError('BiFPN_AFIGAN(norm="SyncBN") in training mode with world_size > 1: cross-rank batch statistics are not '
-                                'implemented on this path; construct it with norm="BN" for per-rank statistics')
+        """norm="SyncBN" (the reference default, bifpn_sr.py:210) exchanges batch statistics between ranks in training mode: the node norms
+        (built by _make_norm) do, through _SyncBatchNormTrainFn -- one all_gather in the forward, one all_reduce in the backward per norm.
+        Nothing to refuse any more; kept as the one place that says so."""
+        return None
 
     # ------------------------------------------------------------------------------------------------ forward (inference)
     def forward(self, x):

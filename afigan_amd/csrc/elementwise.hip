@@ -570,10 +570,12 @@ __global__ void afi_bn_bwd_finalize_kernel(const float* __restrict__ partial, in
 template <bool MASK, bool AMAX = false>
 __global__ void afi_bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ x, float* __restrict__ dx,
                                         const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                        const float* __restrict__ sums, long long P, int C, const float* __restrict__ beta, float slope, float* amax) {
+                                        const float* __restrict__ sums, long long P, int C, const float* __restrict__ beta, float slope, float* amax,
+                                        long long Pn) {
+    // Pn: the number of rows the two sums were taken over (= P, or the batch of ALL ranks when the caller all-reduced them: SyncBatchNorm)
     const long long total4 = P * C / 4;
     const int C4 = C / 4;
-    const float inv_n = 1.f / (float)P;
+    const float inv_n = 1.f / (float)Pn;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     float am = 0.f;
@@ -685,10 +687,29 @@ int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* me
     if (mask_beta) hipLaunchKernelGGL((afi_colred_partial_kernel<3>), rgrid, dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch, gamma, mask_beta, slope);
     else hipLaunchKernelGGL((afi_colred_partial_kernel<1>), rgrid, dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch, (const float*)nullptr, (const float*)nullptr, 1.f);
     hipLaunchKernelGGL(afi_bn_bwd_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, C, gscale, dgamma, dbeta, sums);
-    if (mask_beta && amax) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true, true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, mask_beta, slope, amax);
-    else if (mask_beta) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, mask_beta, slope, amax);
-    else if (amax) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false, true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f, amax);
-    else hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f, amax);
+    if (mask_beta && amax) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true, true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, mask_beta, slope, amax, P);
+    else if (mask_beta) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, mask_beta, slope, amax, P);
+    else if (amax) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false, true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f, amax, P);
+    else hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f, amax, P);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// The two halves of afi_launch_bn_bwd for a caller that exchanges the sums between ranks in between (SyncBatchNorm, bifpn_sr.py:210):
+// sums2C[0..C) = sum_rows g, sums2C[C..2C) = sum_rows g * xhat (and dbeta / dgamma += them: those stay per-rank, as torch's SyncBatchNorm keeps them);
+// then dx = gamma * invstd * (g - sums[0] / Pn - xhat * sums[1] / Pn) with the caller's (all-reduced) sums over Pn rows in all.
+int afi_launch_bn_bwd_sums(const float* g, const float* x, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* sums2C, long long P, int C,
+                           float* scratch, hipStream_t st) {
+    if (P <= 0 || C <= 0 || (C & 3) || !sums2C) return AFI_ERR_BAD_ARG;
+    int chunks, rpc; afi_red_geometry(P, chunks, rpc);
+    hipLaunchKernelGGL((afi_colred_partial_kernel<1>), dim3(afi_cdiv(C, 128), chunks), dim3(256), 0, st, x, g, mean, invstd, P, C, (long long)C, rpc, scratch,
+                       (const float*)nullptr, (const float*)nullptr, 1.f);
+    hipLaunchKernelGGL(afi_bn_bwd_finalize_kernel, dim3(afi_cdiv(C, AFI_FIN_CH)), dim3(256), 0, st, scratch, chunks, C, 1.f, dgamma, dbeta, sums2C);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+int afi_launch_bn_bwd_apply(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, const float* sums2C, long long P,
+                            long long P_total, int C, hipStream_t st) {
+    if (P <= 0 || P_total < P || C <= 0 || (C & 3) || !sums2C) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false>), dim3(afi_ew_grid(P * C / 4)), dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums2C, P, C, (const float*)nullptr, 1.f,
+                       (float*)nullptr, P_total);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st) {

@@ -58,6 +58,10 @@ int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* me
                       float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st, const float* mask_beta = nullptr,
                       float slope = AFI_LRELU_SLOPE, float* amax = nullptr);
 int afi_launch_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, hipStream_t st);
+int afi_launch_bn_bwd_sums(const float* g, const float* x, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* sums2C, long long P, int C,
+                           float* scratch, hipStream_t st);
+int afi_launch_bn_bwd_apply(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, const float* sums2C, long long P,
+                            long long P_total, int C, hipStream_t st);
 int afi_launch_stencil9_sum(const float* d9, int ld, const float* bias, float* out, int N, int H, int W, hipStream_t st);
 int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, int H, int W, hipStream_t st);
 int afi_launch_bce_logits(const float* z, long long n, float target, float lscale, float* loss, float gscale, float* dz, hipStream_t st);
@@ -1035,6 +1039,16 @@ int afi_bn_apply_fwd(const float* x, float* y, const float* mean, const float* i
 int afi_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,
                float* dbeta, long long P, int C, float* scratch, void* stream) {
     return afi_launch_bn_bwd(g, x, dx, mean, invstd, gamma, dgamma, dbeta, 1.f, P, C, scratch, (hipStream_t)stream);
+}
+int afi_bn_bwd_sums(const float* g, const float* x, const float* mean, const float* invstd, float* dgamma, float* dbeta, float* sums2C, long long P, int C, float* scratch,
+                    void* stream) {
+    if (!g || !x || !mean || !invstd) return AFI_ERR_BAD_ARG;
+    return afi_launch_bn_bwd_sums(g, x, mean, invstd, dgamma, dbeta, sums2C, P, C, scratch, (hipStream_t)stream);
+}
+int afi_bn_bwd_apply(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, const float* sums2C, long long P,
+                     long long P_total, int C, void* stream) {
+    if (!g || !x || !dx || !mean || !invstd || !gamma) return AFI_ERR_BAD_ARG;
+    return afi_launch_bn_bwd_apply(g, x, dx, mean, invstd, gamma, sums2C, P, P_total, C, (hipStream_t)stream);
 }
 int afi_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, void* stream) {
     return afi_launch_colsum_accum(g, P, C, ld, alpha, db, scratch, (hipStream_t)stream);

@@ -516,13 +516,15 @@ def maxpool3s2_same_bwd(dout, idx, in_hw):
     return dx
 
 
-def bn_stats_ex(x2d, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
-    """Train-mode statistics of a dense [P, C] matrix with the norm's own eps / momentum; updates the running buffers in place."""
+def bn_stats_ex(x2d, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None, want_var=False):
+    """Train-mode statistics of a dense [P, C] matrix with the norm's own eps / momentum; updates the running buffers in place.
+    want_var: also the biased batch variance (for a caller that combines the statistics of several ranks)."""
     P, C_ = x2d.shape
     mean, invstd = torch.empty(C_, device=x2d.device), torch.empty(C_, device=x2d.device)
-    call("afi_bn_stats_ex", _p(x2d), P, C_, float(eps), float(momentum), _p(mean), _p(invstd), _p(None), _p(running_mean), _p(running_var),
+    var = torch.empty(C_, device=x2d.device) if want_var else None
+    call("afi_bn_stats_ex", _p(x2d), P, C_, float(eps), float(momentum), _p(mean), _p(invstd), _p(var), _p(running_mean), _p(running_var),
          _p(num_batches_tracked), _p(reduce_scratch(C_, x2d.device)), stream_ptr())
-    return mean, invstd
+    return (mean, invstd, var) if want_var else (mean, invstd)
 
 
 def bn_apply(x2d, mean, invstd, gamma, beta, slope=1.0):
@@ -646,6 +648,22 @@ def bn_bwd(g2d, x2d, mean, invstd, gamma, dgamma, dbeta):
     dx = torch.empty_like(x2d)
     call("afi_bn_bwd", _p(g2d), _p(x2d), _p(dx), _p(mean), _p(invstd), _p(gamma), _p(dgamma), _p(dbeta), P, C_,
          _p(reduce_scratch(C_, x2d.device)), stream_ptr())
+    return dx
+
+
+def bn_bwd_sums(g2d, x2d, mean, invstd, dgamma, dbeta):
+    """First half of bn_bwd (afi_bn_bwd_sums): [2, C] = (sum g, sum g * xhat) over this tensor's rows; dbeta / dgamma += them."""
+    P, C_ = x2d.shape
+    sums = torch.empty((2, C_), device=x2d.device)
+    call("afi_bn_bwd_sums", _p(g2d), _p(x2d), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(sums), P, C_, _p(reduce_scratch(C_, x2d.device)), stream_ptr())
+    return sums
+
+
+def bn_bwd_apply(g2d, x2d, mean, invstd, gamma, sums, P_total):
+    """Second half (afi_bn_bwd_apply): dx from sums taken over P_total rows in all (the caller's all-reduce of bn_bwd_sums)."""
+    P, C_ = x2d.shape
+    dx = torch.empty_like(x2d)
+    call("afi_bn_bwd_apply", _p(g2d), _p(x2d), _p(dx), _p(mean), _p(invstd), _p(gamma), _p(sums), P, int(P_total), C_, stream_ptr())
     return dx
 
 

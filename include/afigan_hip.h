@@ -381,6 +381,14 @@ int afi_bn_apply_fwd(const float* x, float* y, const float* mean, const float* i
                      long long P, int C, float slope, void* stream);
 int afi_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma,
                float* dgamma, float* dbeta, long long P, int C, float* scratch, void* stream);
+/* afi_bn_bwd in two halves, for a norm whose batch statistics span several ranks (norm = "SyncBN", bifpn_sr.py:210,279-280; torch.nn.SyncBatchNorm):
+ * the sums of this rank's rows -- sums2C[0..C) = sum g, sums2C[C..2C) = sum g * xhat, xhat from the GLOBAL mean / invstd; dbeta / dgamma (optional) +=
+ * them, per rank as torch keeps them --, which the caller all-reduces, then dx = gamma invstd (g - sums[0] / P_total - xhat sums[1] / P_total) over
+ * this rank's P rows.  scratch: afi_reduce_scratch_floats(C). */
+int afi_bn_bwd_sums(const float* g, const float* x, const float* mean, const float* invstd, float* dgamma_or_null, float* dbeta_or_null, float* sums2C,
+                    long long P, int C, float* scratch, void* stream);
+int afi_bn_bwd_apply(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, const float* sums2C,
+                     long long P, long long P_total, int C, void* stream);
 /* db[C] += alpha * column sums of the [P][C] matrix g with row stride ld */
 int afi_colsum_accum(const float* g, long long P, int C, long long ld, float alpha, float* db, float* scratch, void* stream);
 

@@ -344,3 +344,68 @@ def test_bifpn_hipgraph_capture(amd):
     for k in eager:
         assert torch.equal(captured[k], eager2[k]), k
         assert not torch.equal(captured[k], eager[k]), k
+
+
+def _syncbn_worker(rank, world, port, tmp):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from afigan_amd import bifpn_sr
+    C_ = 24
+    torch.manual_seed(7)                                       # the same layer on every rank
+    bn = bifpn_sr._make_norm("SyncBN", C_, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)         # (CPU generator: the same values in the checking process)
+    bn = bn.cuda().train()
+    assert bn._afi_sync
+    g = torch.Generator().manual_seed(100)                     # the GLOBAL batch, of which this rank takes its (unequal) share
+    xg = torch.randn((5, C_, 9, 13), generator=g) * 2.0 + 0.7
+    rg = torch.randn((5, C_, 9, 13), generator=g)
+    sl = slice(0, 2) if rank == 0 else slice(2, 5)
+    x = xg[sl].cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = bifpn_sr._norm_train(x, bn)
+    (y * rg[sl].cuda()).sum().backward()
+    torch.cuda.synchronize()
+    torch.save({"y": y.detach().cpu(), "dx": x.grad.cpu(), "dgamma": bn.weight.grad.cpu(), "dbeta": bn.bias.grad.cpu(),
+                "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked)}, os.path.join(tmp, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_syncbn_statistics_span_the_ranks(tmp_path):
+    """norm = "SyncBN" (bifpn_sr.py:210,279-280) in training mode under two ranks (gloo, both on the test GPU, shares of 2 and 3 images): outputs,
+    input gradients, running buffers and the SUM of the ranks' parameter gradients equal one nn.BatchNorm2d over the whole batch of five
+    (what SyncBatchNorm computes); with per-rank statistics they would not."""
+    import torch.multiprocessing as mp
+    import os
+    port = 29400 + (os.getpid() % 500)
+    mp.spawn(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    C_ = 24
+    torch.manual_seed(7)
+    ref = torch.nn.BatchNorm2d(C_, eps=1e-3, momentum=0.01).double().train()
+    from afigan_amd import bifpn_sr
+    proto = bifpn_sr._make_norm("SyncBN", C_, eps=1e-3, momentum=0.01)
+    with torch.no_grad():
+        proto.weight.uniform_(0.5, 1.5); proto.bias.uniform_(-0.5, 0.5)
+        ref.weight.copy_(proto.weight.double()); ref.bias.copy_(proto.bias.double())
+    g = torch.Generator().manual_seed(100)
+    xg = (torch.randn((5, C_, 9, 13), generator=g) * 2.0 + 0.7).double().requires_grad_(True)
+    rg = torch.randn((5, C_, 9, 13), generator=g).double()
+    y = ref(xg)
+    (y * rg).sum().backward()
+    rel = lambda a, b: ((a.double() - b).abs().max() / b.abs().max()).item()      # noqa: E731
+    assert rel(torch.cat([r0["y"], r1["y"]]), y.detach()) < 1e-5
+    assert rel(torch.cat([r0["dx"], r1["dx"]]), xg.grad) < 1e-4
+    assert rel(r0["dgamma"] + r1["dgamma"], ref.weight.grad) < 1e-4 and rel(r0["dbeta"] + r1["dbeta"], ref.bias.grad) < 1e-4
+    for r in (r0, r1):
+        assert rel(r["rm"], ref.running_mean) < 1e-5 and rel(r["rv"], ref.running_var) < 1e-5 and r["nbt"] == 1
+    # and the test can tell: rank 0's own two images alone give other outputs
+    solo = torch.nn.BatchNorm2d(C_, eps=1e-3, momentum=0.01).double().train()
+    with torch.no_grad():
+        solo.weight.copy_(ref.weight); solo.bias.copy_(ref.bias)
+    assert rel(r0["y"], solo(xg.detach()[:2]).detach()) > 1e-2
