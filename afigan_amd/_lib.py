@@ -83,6 +83,8 @@ SIGNATURES = {
     "afi_discriminator_saved_activations": (_i, [_vp, C.POINTER(C.c_int), _i, _i, _i]),
     "afi_discriminator_fwd": (_i, [_vp, _DP, View, _i, _i, _i, _vp, _i, _vp, _ll, _vp]),
     "afi_discriminator_bwd": (_i, [_vp, _DP, _DP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "afi_discriminator_fwd_paired": (_i, [_vp, _DP, View, _i, _i, _i, _vp, _i, _vp, _ll, _vp]),
+    "afi_discriminator_bwd_paired": (_i, [_vp, _DP, _DP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_conv3x3_fwd": (_i, [_vp, View, _i, _i, _i, _i, _vp, _vp, _i, View, _f, _f, _i, _vp]),
     "afi_conv3x3_dgrad": (_i, [_vp, View, _i, _i, _i, _i, _vp, _i, View, _f, _f, View, _vp]),
     "afi_conv3x3_wgrad": (_i, [_vp, View, View, _i, _i, _i, _i, _i, _vp, _f, _vp]),

@@ -1697,7 +1697,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
 // forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][y2 P*F3][d9 P*16][mean,invstd x3][red]
 struct DiscWs {
     long long P;
-    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_amax, o_part, n_part, o_wino, n_wino, total;
+    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_amax, o_part, n_part, o_wino, n_wino, o_mean_b[3], o_invstd_b[3], total;
 };
 static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     DiscWs w;
@@ -1721,6 +1721,10 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     w.o_part = o; o += w.n_part;
     w.n_wino = disc_wino_floats(F, N, H, W);              // transient: Winograd U / V / M buffers, shared by the three convs
     w.o_wino = o; o += w.n_wino;
+    for (int n = 0; n < 3; ++n) {                         // the second half's batch statistics of a paired call (afi_discriminator_fwd_paired)
+        w.o_mean_b[n] = o; o += align4(F[n + 1]);
+        w.o_invstd_b[n] = o; o += align4(F[n + 1]);
+    }
     w.total = o;
     return w;
 }
@@ -1769,13 +1773,20 @@ static int disc_check(const afi_disc_params_t* p) {
     return AFI_OK;
 }
 
-int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv, int N, int H, int W, float* logits, int training, float* ws,
-                          long long ws_floats, void* stream) {
+}  // extern "C"
+
+// `halves` = 1: the reference's call.  `halves` = 2 (afi_discriminator_fwd_paired): images [0, N/2) and [N/2, N) are two calls of the reference made one
+// after the other (D(real) then D(fake) in the D phase, stage1_trainer.py:349-359; D(fake) then D(real) in the G phase, :399-403) -- every conv
+// runs once over all N images, every BatchNorm takes its batch statistics per half and moves the running statistics twice, first half first.
+static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv, int N, int H, int W, int halves, float* logits, int training, float* ws,
+                    long long ws_floats, void* stream) {
     afi_ctx* cx = ctx; (void)cx;
     AFI_CTX_CHECK(ctx);
     AFI_TRY(disc_check(prm));
     const bool stats_only = training == 3;                 // BatchNorm side effects only: no last activation, last conv or logits
     if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || (!logits && !stats_only)) return AFI_ERR_BAD_ARG;
+    if (halves != 1 && halves != 2) return AFI_ERR_BAD_ARG;
+    if (N % halves) return AFI_ERR_BAD_ARG;
     const DiscWs l = disc_ws(prm->F, N, H, W);
     if (ws_floats < l.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1791,6 +1802,8 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
     // activation feeds the last conv (a direct GEMM) and is always written.
     const bool wino = l.n_wino > 0 && use_wino(cx, P);
     const bool fold = wino && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0;
+    if (fold && halves > 1) return AFI_ERR_UNSUPPORTED;   // (the folded affine is one per tensor)
+    const long long Ph = P / halves;
     AfiBnLoad in_bn{nullptr, nullptr, nullptr, nullptr};
     // the largest magnitude of every block's input, for the f16x3 arithmetic of this pass and of the backward pass that may follow (whatever
     // arithmetic THIS pass runs in: the backward trusts the slots): x's by the first input transform, y0's / y1's by the BatchNorm apply passes
@@ -1803,7 +1816,7 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
         float* mean = ws + l.o_mean[n]; float* invstd = ws + l.o_invstd[n];
         int stats_rows = 0;
         double* stats = (double*)(ws + l.o_stats);          // (8-byte aligned: every offset of the layout is a multiple of 4 floats and ws comes from an allocator)
-        const bool fuse_stats = training && afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0 && (((uintptr_t)stats) & 7) == 0;
+        const bool fuse_stats = training && halves == 1 && afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0 && (((uintptr_t)stats) & 7) == 0;
         if (wino) {
             AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
                               part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx), fuse_stats ? stats : nullptr, &stats_rows, in_bn.mean ? &in_bn : nullptr,
@@ -1813,17 +1826,24 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
         }
         const bool skip_apply = (stats_only && n == 2) || (fold && n < 2);       // nothing reads the last block's activation / the next block reads c through the affine
         const float* mean_used = mean;
-        if (training && stats_rows > 0) {                   // the output transform accumulated the sums while it stored c: only the finalizer is left
-            AFI_TRY(afi_launch_bn_stats_from_partials(stats, stats_rows, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], st,
-                                                      prm->num_batches_tracked[n]));
-        } else if (training) {
-            AFI_TRY(afi_launch_bn_stats(c, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], red, st,
-                                        prm->num_batches_tracked[n], -1.f, -1.f, afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0));      // the counter ticks inside the statistics finalizer
-        } else {
+        if (!training) {
             AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
             mean_used = prm->running_mean[n];
         }
-        if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(c, y, mean_used, invstd, prm->gamma[n], prm->beta[n], P, co, st, AFI_LRELU_SLOPE, slots && n < 2 ? amax + 4 * (n + 1) : nullptr));
+        for (int h = 0; h < halves; ++h) {
+            float* mean_h = h ? ws + l.o_mean_b[n] : mean;
+            float* invstd_h = h ? ws + l.o_invstd_b[n] : invstd;
+            const float* ch = c + (long long)h * Ph * co;
+            if (training && stats_rows > 0) {               // the output transform accumulated the sums while it stored c: only the finalizer is left
+                AFI_TRY(afi_launch_bn_stats_from_partials(stats, stats_rows, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], st,
+                                                          prm->num_batches_tracked[n]));
+            } else if (training) {
+                AFI_TRY(afi_launch_bn_stats(ch, Ph, co, mean_h, invstd_h, nullptr, prm->running_mean[n], prm->running_var[n], red, st,
+                                            prm->num_batches_tracked[n], -1.f, -1.f, afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0));  // the counter ticks inside the statistics finalizer
+            }
+            if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(ch, y + (long long)h * Ph * co, training ? mean_h : mean_used, training ? invstd_h : invstd, prm->gamma[n],
+                                                               prm->beta[n], Ph, co, st, AFI_LRELU_SLOPE, slots && n < 2 ? amax + 4 * (n + 1) : nullptr));
+        }
         if (fold && n < 2) {
             in = dense_view(c, H, W, co);
             in_bn = AfiBnLoad{mean_used, invstd, prm->gamma[n], prm->beta[n]};
@@ -1845,12 +1865,14 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
     return AFI_OK;
 }
 
-int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
-                          const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream) {
+static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* gr, afi_view_t xv, int N, int H, int W, int halves, const float* ws,
+                    const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream) {
     afi_ctx* cx = ctx; (void)cx;
     AFI_CTX_CHECK(ctx);
     AFI_TRY(disc_check(prm));
     if (!gr || N <= 0 || H <= 0 || W <= 0 || !ws || !dlogits || !scratch) return AFI_ERR_BAD_ARG;
+    if ((halves != 1 && halves != 2) || N % halves) return AFI_ERR_BAD_ARG;
+    if (halves > 1 && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0) return AFI_ERR_UNSUPPORTED;
     const DiscWs l = disc_ws(prm->F, N, H, W);
     const DiscBwdWs s = disc_bwd_ws(prm->F, N, H, W);
     if (scratch_floats < s.total) return AFI_ERR_WORKSPACE;
@@ -1899,8 +1921,12 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
         // LeakyReLU' and BatchNorm backward in one: the mask is recomputed from the saved conv output (the same pinned affine the forward
         // evaluated: bit-identical decisions) inside the two passes that read it anyway, instead of streaming the activation through
         // the producing data gradient's output transform as a third operand
-        AFI_TRY(afi_launch_bn_bwd(g_, c, g_, ws + l.o_mean[n], ws + l.o_invstd[n], prm->gamma[n], gr->gamma[n], gr->beta[n], 1.f, P, co,
-                                  red, st, prm->beta[n], AFI_LRELU_SLOPE, slots ? gmax + 4 * n : nullptr));          // in place: g_ = d(conv output)
+        for (int h = 0; h < halves; ++h) {            // (a paired call: each half against its own batch statistics; the parameter gradients add up)
+            const long long Ph = P / halves, o = (long long)h * Ph * co;
+            AFI_TRY(afi_launch_bn_bwd(g_ + o, c + o, g_ + o, ws + (h ? l.o_mean_b[n] : l.o_mean[n]), ws + (h ? l.o_invstd_b[n] : l.o_invstd[n]), prm->gamma[n],
+                                      gr->gamma[n], gr->beta[n], 1.f, Ph, co, red, st, prm->beta[n], AFI_LRELU_SLOPE,
+                                      slots ? gmax + 4 * n : nullptr));                                              // in place: g_ = d(conv output)
+        }
         fk.after_main();                              // g_ = d(conv output) is complete
         // d(loss)/d(bias) of a conv that feeds a train-mode BatchNorm is EXACTLY zero: g_ = BN backward's dx, whose sum over the pixels
         // of a channel vanishes identically (the BN output does not change when a constant is added to its input).  The reference
@@ -1931,6 +1957,25 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
     }
     fk.join();
     return AFI_OK;
+}
+
+extern "C" {
+
+int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv, int N, int H, int W, float* logits, int training, float* ws,
+                          long long ws_floats, void* stream) {
+    return disc_fwd(ctx, prm, xv, N, H, W, 1, logits, training, ws, ws_floats, stream);
+}
+int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
+                          const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream) {
+    return disc_bwd(ctx, prm, gr, xv, N, H, W, 1, ws, dlogits, dx, scratch, scratch_floats, stream);
+}
+int afi_discriminator_fwd_paired(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv, int N, int H, int W, float* logits, int training, float* ws,
+                                 long long ws_floats, void* stream) {
+    return disc_fwd(ctx, prm, xv, N, H, W, 2, logits, training, ws, ws_floats, stream);
+}
+int afi_discriminator_bwd_paired(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* gr, afi_view_t xv, int N, int H, int W, const float* ws,
+                                 const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream) {
+    return disc_bwd(ctx, prm, gr, xv, N, H, W, 2, ws, dlogits, dx, scratch, scratch_floats, stream);
 }
 
 }  // extern "C"

@@ -213,7 +213,7 @@ class Stage1Step:
                  warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2,
                  reuse_generator_forward: bool = True, process_group=None, distributed: Optional[bool] = None, dtype: Optional[str] = None,
                  overlap_d: bool = True, overlap_g: bool = True, weight_cache: bool = True, wgrad_accum: bool = True,
-                 g_bwd_small_first: bool = True, overlap_comm: Optional[bool] = None):
+                 g_bwd_small_first: bool = True, overlap_comm: Optional[bool] = None, pair_d_max_pixels: int = 40000):
         self.G, self.D = G, D
         self.gnet, self.dnet = G, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
@@ -225,6 +225,10 @@ class Stage1Step:
         # are power-bound and leave room beside the bandwidth-bound passes (129.5 -> 126.4 -> 123.9 ms); `overlap_d` / `overlap_g` (attributes too)
         self.overlap_d, self.overlap_g = overlap_d, overlap_g
         self.g_bwd_small_first = g_bwd_small_first          # G-phase backward passes on the second stream: smallest level first (see _run_phases)
+        # levels whose cropped map has at most this many pixels (N*h*w) run their two D calls of a phase as ONE call over both batches with
+        # per-batch BatchNorm statistics (afi_discriminator_fwd_paired): half the launches of the latency-bound small levels; 0 = never.  Same-box
+        # A/B at the reference sizes: 0 -> 83.6 ms, 3000 -> 82.3, 10000 -> 82.2, 40000 (levels p3..p6) -> 81.9, every level -> 84.5 ms per step
+        self.pair_d_max_pixels = pair_d_max_pixels
         # data-parallel runs: the two gradient all-reduces are issued asynchronously and run beside work that does not need them -- D's
         # beside G's five backward passes (second stream), G's beside the G phase's D forwards (see _run_phases); False = blocking, in place
         # Default (None): on where the asynchronous path has been exercised -- the gloo backend (two-rank tests, CPU and two ranks on one GPU) -- and
@@ -399,7 +403,22 @@ class Stage1Step:
              ops.stream_ptr())
         return out, ws
 
-    def _d_forward(self, x: torch.Tensor, ws_key: str, backward_follows: bool = True, stats_only: bool = False):
+    def _paired(self, x: torch.Tensor) -> bool:
+        return 0 < x.shape[0] * x.shape[2] * x.shape[3] <= self.pair_d_max_pixels
+
+    def _pair(self, level: int, first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:
+        """[first; second] along the batch, pixel-major, in a buffer kept per level (the D phase's backward reads it later)."""
+        N, Cc, H, W = first.shape
+        key = f"pair{level}"
+        t = self._buf.get(key)
+        if t is None or tuple(t.shape) != (2 * N, Cc, H, W):
+            t = ops.new_pixel_major(2 * N, Cc, H, W, first.device)
+            self._buf[key] = t
+        t[:N].copy_(first)
+        t[N:].copy_(second)
+        return t
+
+    def _d_forward(self, x: torch.Tensor, ws_key: str, backward_follows: bool = True, stats_only: bool = False, paired: bool = False):
         """training = 1: train-mode forward whose saved activations feed afi_discriminator_bwd; 2: train-mode statistics and
         logits only (the G phase, stage1_trainer.py:399-403: no gradient ever flows through these two calls, Q1); 3: the BatchNorm
         side effects only (the G phase's D(real) call, :401-403: nothing reads its logits -- the running statistics advance exactly as
@@ -409,18 +428,18 @@ class Stage1Step:
         n = self._lib.afi_discriminator_fwd_ws_floats(F, N, H, W)
         ws = self._scratch(ws_key, n, x.device)
         logits = self._scratch(ws_key + "_logits", N * H * W, x.device)
-        call("afi_discriminator_fwd", C.byref(self._dprm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()),
-             1 if backward_follows else (3 if stats_only else 2), C.c_void_p(ws.data_ptr()), n, ops.stream_ptr())
+        call("afi_discriminator_fwd_paired" if paired else "afi_discriminator_fwd", C.byref(self._dprm), ops.view_of(x), N, H, W,
+             C.c_void_p(logits.data_ptr()), 1 if backward_follows else (3 if stats_only else 2), C.c_void_p(ws.data_ptr()), n, ops.stream_ptr())
         return logits, ws
 
-    def _d_backward(self, x: torch.Tensor, ws: torch.Tensor, dlogits: torch.Tensor):
+    def _d_backward(self, x: torch.Tensor, ws: torch.Tensor, dlogits: torch.Tensor, paired: bool = False):
         N, _, H, W = x.shape
         F = (C.c_int * 4)(*self.dnet.F)
         n = self._lib.afi_discriminator_bwd_ws_floats(F, N, H, W)
         sc = self._scratch("d_bwd", n, x.device)
         with _lib.use_ctx(self.bctx):                      # the backward passes' own context (they may be on the second stream)
-            call("afi_discriminator_bwd", C.byref(self._dprm), C.byref(self._dgrad), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()),
-                 C.c_void_p(dlogits.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n, ops.stream_ptr())
+            call("afi_discriminator_bwd_paired" if paired else "afi_discriminator_bwd", C.byref(self._dprm), C.byref(self._dgrad), ops.view_of(x), N, H, W,
+                 C.c_void_p(ws.data_ptr()), C.c_void_p(dlogits.data_ptr()), C.c_void_p(None), C.c_void_p(sc.data_ptr()), n, ops.stream_ptr())
 
     @staticmethod
     def _crop_pair(tr: torch.Tensor, hr: torch.Tensor):
@@ -557,13 +576,17 @@ class Stage1Step:
             tr, ws = self._g_forward(i, lrs[i], "g_ws")                              # :339-341 (.detach(): no graph anyway)
             trs.append((tr, ws))
             tr_c, hr_c = self._crop_pair(tr, hrs[i])                                  # :345-346
-            for x, target, key in ((hr_c, 1.0, "d_ws"), (tr_c, 0.0, "d_ws")):        # :349-353, :355-359
+            paired = self._paired(hr_c)
+            calls = ((self._pair(i, hr_c, tr_c), (1.0, 0.0), "d_ws"),) if paired else ((hr_c, (1.0,), "d_ws"), (tr_c, (0.0,), "d_ws"))
+            for x, targets, key in calls:                                            # :349-353, :355-359 (real, then fake)
                 if self.overlap_d:
-                    key = f"d_ws_{i}_{int(target)}"                                   # lives until its backward has run
-                logits, dws = self._d_forward(x, key)
-                dz = self._scratch("dlogits" + (key if self.overlap_d else ""), logits.numel(), dev)
-                call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], target, 1.0,
-                     C.c_void_p(lptr + 4 * (3 * i)), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
+                    key = f"d_ws_{i}_{'p' if paired else int(targets[0])}"           # lives until its backward has run
+                logits, dws = self._d_forward(x, key, paired=paired)
+                half = hr_c.shape[0] * hr_c.shape[2] * hr_c.shape[3]                # (scratch tensors may be larger than asked for)
+                dz = self._scratch("dlogits" + (key if self.overlap_d else ""), half * len(targets), dev)
+                for h, target in enumerate(targets):
+                    call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr() + 4 * h * half), half, target, 1.0,
+                         C.c_void_p(lptr + 4 * (3 * i)), 1.0, C.c_void_p(dz.data_ptr() + 4 * h * half), ops.stream_ptr())
                 if self.overlap_d:
                     # all forwards stay in order on the caller's stream (BatchNorm running statistics), all backwards in
                     # order on a second one (gradient accumulation): same results, and a backward's GEMMs run beside the
@@ -572,9 +595,9 @@ class Stage1Step:
                         self._bstream = torch.cuda.Stream(device=dev)
                     self._bstream.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(self._bstream):
-                        self._d_backward(x, dws, dz)
+                        self._d_backward(x, dws, dz, paired=paired)
                 else:
-                    self._d_backward(x, dws, dz)                                     # :375 (accumulates into the flat grads)
+                    self._d_backward(x, dws, dz, paired=paired)                      # :375 (accumulates into the flat grads)
         if self.overlap_d:
             self._join_bstream()
         call("afi_ctx_wino_wgrad_flush", self.bctx.handle, ops.stream_ptr())         # (joined: the backward context's sums, on the caller's stream)
@@ -630,11 +653,17 @@ class Stage1Step:
             else:
                 tr, ws = self._g_forward(i, lrs[i], "g_ws")                          # :389-391
             tr_c, hr_c = self._crop_pair(tr, hrs[i])
-            for x, key in ((tr_c, "adv"), (hr_c, None)):                             # :399-403 (fake first, then real)
-                logits, _ = self._d_forward(x, "d_ws", backward_follows=False, stats_only=(key != "adv"))
-                if key == "adv":                                                     # :408, no gradient (Q1)
-                    call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], 1.0, 1.0,
-                         C.c_void_p(lptr + 4 * (3 * i + 1)), 0.0, C.c_void_p(None), ops.stream_ptr())
+            if self._paired(tr_c):                                                   # :399-403 (fake first, then real), one call
+                x = self._pair(i, tr_c, hr_c)
+                logits, _ = self._d_forward(x, "d_ws", backward_follows=False, paired=True)
+                call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), tr_c.shape[0] * tr_c.shape[2] * tr_c.shape[3], 1.0, 1.0,
+                     C.c_void_p(lptr + 4 * (3 * i + 1)), 0.0, C.c_void_p(None), ops.stream_ptr())
+            else:
+                for x, key in ((tr_c, "adv"), (hr_c, None)):                         # :399-403 (fake first, then real)
+                    logits, _ = self._d_forward(x, "d_ws", backward_follows=False, stats_only=(key != "adv"))
+                    if key == "adv":                                                 # :408, no gradient (Q1)
+                        call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * x.shape[2] * x.shape[3], 1.0, 1.0,
+                             C.c_void_p(lptr + 4 * (3 * i + 1)), 0.0, C.c_void_p(None), ops.stream_ptr())
             if not side:
                 with _lib.use_ctx(self.bctx):
                     g_backward(i, tr, ws)

@@ -74,6 +74,8 @@ def parse():
                     "then hold exactly the timed launches")
     ap.add_argument("--synthetic-pyramid", action="store_true",
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
+    ap.add_argument("--pair-d-max-pixels", type=int, default=None, help="Stage1Step(pair_d_max_pixels=...): levels up to this many pixels run D(real) and D(fake) "
+                    "of a phase as one call (per-batch BatchNorm statistics); default: the engine's")
     ap.add_argument("--one-stream", action="store_true", help="Stage1Step(overlap_d=False, overlap_g=False): every kernel alone on the chip (the "
                     "profiling passes of tools/prof_r03.sh: per-kernel durations comparable across rounds)")
     ap.add_argument("--no-guide-prefetch", action="store_true", help="run the frozen guide network's two forwards at the head of every step on the step's own "
@@ -523,6 +525,8 @@ def main():
     G.train(); D.train()
     step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype, overlap_d=not args.one_stream, overlap_g=not args.one_stream,
                           g_bwd_small_first=os.environ.get("AFI_BENCH_G_BWD_ORDER", "small-first") != "level-order")   # (A/B of the G-phase schedule)
+    if args.pair_d_max_pixels is not None:
+        step.pair_d_max_pixels = args.pair_d_max_pixels
     for kv in args.option:
         name, _, val = kv.partition("=")
         step.ctx.set_option(name, int(val)); step.bctx.set_option(name, int(val))

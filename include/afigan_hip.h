@@ -267,6 +267,19 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
 int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* grads, afi_view_t x, int N, int H, int W,
                           const float* ws, const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream);
 
+/* TWO consecutive calls of the reference as one: x holds N images (N even), images [0, N/2) are the first call's batch and [N/2, N) the
+ * second's -- D(real) then D(fake) in the D phase (stage1_trainer.py:349-359), D(fake) then D(real) in the G phase (:399-403).  Every
+ * convolution runs once over all N images (half the launches, twice the rows per GEMM: what the small levels lack); every BatchNorm takes
+ * its batch statistics over each half alone and moves the running statistics / num_batches_tracked twice, first half first, so the
+ * parameters, buffers and logits come out as from the two calls (to fp32 rounding: under f16x3 the two halves share one operand scale).
+ * Workspace sizes are those of the N-image call; `logits` / `dlogits` are [N, H, W]; the parameter gradients of both halves add up, as
+ * two backward calls would leave them.  The second half's batch statistics sit behind the layout afi_discriminator_ws_layout reports.
+ * Not available under AFI_OPT_D_FOLD_BN_APPLY (AFI_ERR_UNSUPPORTED). */
+int afi_discriminator_fwd_paired(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t x, int N, int H, int W, float* logits, int training,
+                                 float* ws, long long ws_floats, void* stream);
+int afi_discriminator_bwd_paired(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* grads, afi_view_t x, int N, int H, int W,
+                                 const float* ws, const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream);
+
 /* ------------------------------------------------------------------ per-op entry points (also used by the tests) */
 
 /* out[.., c_out] = act(alpha*conv3x3(x, w) + bias + beta*out);  w [Cout][3][3][Cin]  (generator_rdb.py:39-55,91-99,107)

@@ -28,7 +28,10 @@ def _digest(t, nsample=64):
     return np.array([f.sum().item(), f.norm().item(), f.abs().max().item()]), f[::stride][:nsample].float().numpy()
 
 
-def test_stage1_step_vs_reference_replay(amd, golden_dir):
+@pytest.mark.parametrize("pair", [0, 600, 10 ** 9])
+def test_stage1_step_vs_reference_replay(amd, golden_dir, pair):
+    """`pair` > 0: the two D calls per level and phase run as ONE call with per-batch BatchNorm statistics (Stage1Step(pair_d_max_pixels=...),
+    afi_discriminator_fwd_paired): the same replay, the same tolerances."""
     fx = dict(np.load(os.path.join(golden_dir, "stage1_step.npz")))
     G = amd.Generator(n_residual_dense_blocks=3).cuda()
     D = amd.Discriminator().cuda()
@@ -39,7 +42,7 @@ def test_stage1_step_vs_reference_replay(amd, golden_dir):
     lr_f = [torch.randn((2, 256, 13, 21), generator=gen), torch.randn((2, 256, 7, 11), generator=gen)]
     hr_f = [torch.randn((2, 256, 25, 42), generator=gen), torch.randn((2, 256, 13, 21), generator=gen)]
     step = amd.Stage1Step(G, D, base_lr=float(fx["lr"][0]), momentum=float(fx["mom"][0]), weight_decay=float(fx["wd"][0]),
-                          warmup_iters=0)          # the golden replay uses a constant lr
+                          warmup_iters=0, pair_d_max_pixels=pair)          # the golden replay uses a constant lr
     step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
     m = step.metrics()
     for k in ("d_loss_p2", "d_loss_p3", "adv_loss_p2", "adv_loss_p3", "content_loss_p2", "content_loss_p3", "g_loss_p2", "g_loss_p3"):
@@ -119,7 +122,8 @@ def test_stage1_small_ragged_vs_oracle(amd, reuse):
     assert all(np.isfinite(v) for v in step.metrics().values())
 
 
-def test_stage1_trajectory_four_iterations_vs_oracle(amd):
+@pytest.mark.parametrize("pair", [0, 600, 10 ** 9])
+def test_stage1_trajectory_four_iterations_vs_oracle(amd, pair):
     """Four consecutive iterations with the LR warm-up and a decay step inside the window, momentum and weight decay
     (stage1_trainer.py:110-125,336-433): per-iteration losses and the final weights / BN running statistics follow the
     oracle's trajectory, i.e. the optimizer state, the schedule and the buffer updates carry over correctly between steps."""
@@ -131,7 +135,7 @@ def test_stage1_trajectory_four_iterations_vs_oracle(amd):
     G.load_state_dict(gp); D.load_state_dict(dp)
     gen = torch.Generator().manual_seed(11)
     sched = dict(lr_steps=(3,), lr_gamma=0.5, warmup_factor=0.1, warmup_iters=2)
-    step = amd.Stage1Step(G, D, base_lr=0.02, **sched)
+    step = amd.Stage1Step(G, D, base_lr=0.02, pair_d_max_pixels=pair, **sched)
     g_bufs, d_bufs_m = {}, {}
     for it in range(4):
         lr_f = [torch.randn((2, C, 7, 11), generator=gen), torch.randn((2, C, 4, 6), generator=gen)]
