@@ -643,7 +643,7 @@ const char* kKindNames[] = {
     "gemm_tn_bf16<128x128> (Winograd weight-gradient GEMM on the bf16 MFMA: bf16x6 / bf16x3 / bf16 operands, fp32 accumulate)",
     "wgrad_group6 (grouped weight gradients of a small-map backward pass on the bf16 MFMA, bf16x6 operands, fp32 accumulate)",
     "pix_gemm_wk6 (small-map pixel GEMM on the bf16 MFMA, bf16x6 operands on pre-split weight images, fp32 accumulate; grouped launches included)",
-    "gemm_nt_f16x3<128x128> (batched Winograd GEMM on the f16 MFMA: two scaled fp16 pieces per operand, three products, fp32 accumulate)",
+    "gemm_nt_f16x3 (batched Winograd GEMM on the f16 MFMA, 256x256 tiles where the grid fills the chip and 128x128 below: two scaled fp16 pieces per operand, three products, fp32 accumulate)",
     "gemm_tn_f16x3<128x128> (Winograd weight-gradient GEMM on the f16 MFMA: two scaled fp16 pieces per operand, three products, fp32 accumulate)"};   // one kind per kernel, as rocprofv3 lists them
 constexpr int kNumKinds = 23;
 hipEvent_t prof_event() {                                   // (callers hold g_prof.mu)
