@@ -4,7 +4,8 @@ batch into the P2..P6 pyramid, the role ``RCNN_FPN_only`` plays in the reference
 contains the same work as stage1_trainer.py:320-321 (two guide forwards per iteration).
 
 To keep a fresh GPU box from spending minutes in MIOpen's just-in-time kernel builds, the guide avoids MIOpen entirely:
-1x1 convs are plain GEMMs on the pixel-major tensor (torch.matmul -> hipBLASLt), the 7x7 stem is unfold + GEMM, every 3x3
+1x1 convs run on this package's pixel GEMM (afi_conv1x1_fwd: bias, the residual / top-down addend and the ReLU in its epilogue; a stride-2
+conv reads every second pixel in place), the 7x7 stem is unfold + GEMM, every 3x3
 conv (stride 1 under detectron2's STRIDE_IN_1X1=True) runs on this package's own fp32-MFMA conv kernels with a fused
 bias + ReLU epilogue (the >= 128-channel ones in the inference Winograd form, afi_conv3x3_wino_infer), and the frozen BatchNorms are folded into weights / biases at construction.
 """
@@ -28,17 +29,13 @@ class _Conv1x1(nn.Module):
     def __init__(self, cin, cout, stride=1, relu=False, gain=1.0):
         super().__init__()
         self.stride, self.relu = stride, relu
-        self.register_buffer("w", _kaiming((cin, cout), cin, gain))     # [Cin, Cout] (frozen-BN scale folded in)
+        self.register_buffer("w", _kaiming((cin, cout), cin, gain).t().contiguous())     # [Cout, Cin] (frozen-BN scale folded in)
         self.register_buffer("b", torch.zeros(cout))
 
-    def forward(self, x):                                               # x: [N,C,H,W] pixel-major
+    def forward(self, x, add=None, relu=None):                          # x: [N,C,H,W] pixel-major; out = act(conv(x) + b + add)
         if self.stride != 1:
-            x = x[:, :, ::self.stride, ::self.stride]
-        N, C, H, W = x.shape
-        y = torch.addmm(self.b, x.permute(0, 2, 3, 1).reshape(-1, C), self.w)
-        if self.relu:
-            y = F.relu_(y)
-        return y.view(N, H, W, -1).permute(0, 3, 1, 2)
+            x = x[:, :, ::self.stride, ::self.stride]                   # (a view: the kernel walks the strides)
+        return ops.conv1x1_fwd(x, self.w, self.b, add=add, act=2 if (self.relu if relu is None else relu) else 0)
 
 
 class _Conv3x3(nn.Module):
@@ -64,9 +61,8 @@ class _Bottleneck(nn.Module):
         self.short = _Conv1x1(cin, cout, stride) if (cin != cout or stride != 1) else None
 
     def forward(self, x):
-        y = self.c3(self.c2(self.c1(x)))
         s = x if self.short is None else self.short(x)
-        return F.relu_(y + s)
+        return self.c3(self.c2(self.c1(x)), add=s, relu=True)           # relu(conv + shortcut) in the GEMM's epilogue
 
 
 class GuideR50FPN(nn.Module):
@@ -106,7 +102,7 @@ class GuideR50FPN(nn.Module):
         outs = [self.output[3](prev)]
         for i in (2, 1, 0):
             up = F.interpolate(prev, scale_factor=2, mode="nearest")
-            prev = (self.lateral[i](feats[i]) + up).contiguous(memory_format=torch.channels_last)
+            prev = self.lateral[i](feats[i], add=up)            # lateral + top-down in the GEMM's epilogue
             outs.insert(0, self.output[i](prev))
         outs.append(outs[-1][:, :, ::2, ::2].contiguous(memory_format=torch.channels_last))   # LastLevelMaxPool(k=1,s=2) -> p6
         return {f"p{i + 2}": o for i, o in enumerate(outs)}

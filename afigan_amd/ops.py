@@ -356,8 +356,9 @@ def relu_bwd(g, act, scale=1.0):
     return out
 
 
-def conv1x1_fwd(x, w, bias=None, add=None, add_scale=1.0, alpha=1.0, out=None):
-    """out = alpha*conv1x1(x, w) + bias + add_scale*add;  w: [Cout, Cin] or [Cout, Cin, 1, 1]."""
+def conv1x1_fwd(x, w, bias=None, add=None, add_scale=1.0, alpha=1.0, out=None, act=0):
+    """out = act(alpha*conv1x1(x, w) + bias + add_scale*add);  w: [Cout, Cin] or [Cout, Cin, 1, 1];  act: 0 none, 1 LeakyReLU(0.2), 2 ReLU.
+    ``x`` may be a strided view of a pixel-major tensor (a crop, or every second pixel: a stride-2 1x1 conv reads it in place)."""
     _check_cuda(x, w, bias, add, out)
     _ensure_op_scratch(x.device)
     N, Cin, H, W = x.shape
@@ -366,7 +367,7 @@ def conv1x1_fwd(x, w, bias=None, add=None, add_scale=1.0, alpha=1.0, out=None):
     if out is None:
         out = new_pixel_major(N, Cout, H, W, x.device)
     call("afi_conv1x1_fwd", view_of(x), N, H, W, Cin, _p(w2), _p(bias), Cout, view_of(out), float(alpha), 0.0,
-         view_of(add) if add is not None else _NULL_VIEW, float(add_scale), 0, stream_ptr())
+         view_of(add) if add is not None else _NULL_VIEW, float(add_scale), int(act), stream_ptr())
     return out
 
 
