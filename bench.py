@@ -608,6 +608,11 @@ def main():
     # pair and ONE training step (the pair it launches is consumed by the next step; the first one is launched by the warm-up).
     prefetch = amd.GuidePrefetcher(dev) if (guide is not None and not args.no_guide_prefetch and not args.one_stream) else None
 
+    # where in the step the NEXT batch's guide forwards are queued: before level index 3 (P5) of the D phase, beside the latency-bound small
+    # levels (same-box A/B, ms per step: at the head of the step 81.8 / 81.9, level 1 82.5, level 2 81.4 / 81.3, level 3 81.0, level 4 81.2)
+    guide_at_level = int(os.environ.get("AFI_BENCH_GUIDE_AT_LEVEL", "3"))
+    host_ms = {"guide_enqueue": [], "step_enqueue": []}     # host time spent enqueueing (no sync inside): the last steps' values are reported
+
     def one_step(last=False, solo=False):
         """solo: nothing runs beside the step (the `kernel_alone` leg): a pending prefetched pair is used up, none is launched."""
         if guide is None:
@@ -618,9 +623,17 @@ def main():
             if not prefetch.pending:
                 prefetch.submit(guide_pair)                        # (first call only)
             hr, lr = prefetch.take()
+            th0 = time.perf_counter()
+            step.on_d_level = None
             if not (last or solo):
-                prefetch.submit(guide_pair)                        # the next batch's features, beside this step
+                if guide_at_level > 0:                             # ... queued from inside the step, before that level of the D phase
+                    step.on_d_level = lambda i: prefetch.submit(guide_pair) if i == guide_at_level else None
+                else:
+                    prefetch.submit(guide_pair)                    # the next batch's features, beside this step
+            host_ms["guide_enqueue"].append((time.perf_counter() - th0) * 1e3)
+        th1 = time.perf_counter()
         step.run_step(lr, hr)
+        host_ms["step_enqueue"].append((time.perf_counter() - th1) * 1e3)
         return hr, lr
 
     def sync():
@@ -657,6 +670,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
+    host_timed = {k: list(v[-args.steps:]) for k, v in host_ms.items()}      # (the profiled repeat below appends its own)
     profiled_ms_per_step = None
     if not args.profile_timed:
         if rank == 0:
@@ -812,8 +826,9 @@ def main():
         "backend": (args.backend if world > 1 else None), "comm": comm,
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
                                f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",
-                   "global_batch": world * B, "parallelism": f"dp{world}", "guide": "r50fpn (GEMM 1x1 via hipBLASLt + own 3x3 MFMA conv)" if guide is not None else "synthetic-pyramid",
+                   "global_batch": world * B, "parallelism": f"dp{world}", "guide": "r50fpn (1x1 and 3x3 convs on this library's kernels, stem GEMM via hipBLASLt)" if guide is not None else "synthetic-pyramid",
                    "guide_prefetch": prefetch is not None, "options": args.option or None,
+                   "host_enqueue_ms": {k: round(sum(v) / max(1, len(v)), 2) for k, v in host_timed.items() if v},
                    "reuse_generator_forward": True},
         "algorithmic_tflop_per_image": flop_img / 1e12,
         "step_tflops_per_gpu": flop_img * B * args.steps / elapsed / 1e12,

@@ -1,4 +1,5 @@
-"""Per-stream timeline of a rocprofv3 kernel trace of bench.py (two-stream stage-1 step): for the last step in the trace, each stream's busy
+"""Per-stream timeline of a rocprofv3 kernel trace of bench.py (two-stream stage-1 step): for the second-to-last step in the trace (the last
+one issues no guide forwards for a following batch when the run has no warm-up), each stream's busy
 time, the wall time, and the time during which only ONE stream has a kernel running, by kernel family.
 Usage: python tools/stream_timeline.py <kernel_trace.csv> [steps_in_trace]"""
 import csv
@@ -20,7 +21,8 @@ def main():
     sgd = [e for e in ev if "sgd" in e[3]]
     if len(sgd) < 5:
         print("not enough steps in the trace"); return
-    t1 = sgd[-1][1]; t0 = sgd[-3][1]          # two SGD launches per step (D, G)
+    back = 2 if len(sgd) >= 5 else 0          # two SGD launches per step (D, G)
+    t1 = sgd[-1 - back][1]; t0 = sgd[-3 - back][1]
     win = [e for e in ev if e[0] >= t0 and e[1] <= t1]
     wall = (t1 - t0) / 1e6
     busy = defaultdict(float)
