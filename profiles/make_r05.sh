@@ -14,7 +14,7 @@ python profiles/summarize_pmc.py $(find $P/pmc_sq_serial -name "*counter_collect
 cp $(find $P/trace_fp32 -name "*kernel_stats.csv" | head -1) $D/kernel_stats_bench_steps3_warmup0_dtype_fp32.csv
 cp $(find $P/trace_bf16x6 -name "*kernel_stats.csv" | head -1) $D/kernel_stats_bench_steps3_warmup0_one_stream_dtype_bf16x6.csv
 grep '^{' $P/bench_trace_bf16x6.log > $D/bench_line_under_rocprof_steps3_warmup0_one_stream_dtype_bf16x6.json
-for f in stream_timeline_two_stream.txt nt_f16_ablations.txt gemm_dtypes.txt knob_ab.txt; do [ -f $P/$f ] && grep -v "amdgpu.ids" $P/$f > $D/$f || true; done
+for f in stream_timeline_two_stream.txt nt_f16_ablations.txt gemm_dtypes.txt knob_ab.txt host_enqueue_probe.txt guide_overlap_probe.txt; do [ -f $P/$f ] && grep -v "amdgpu.ids" $P/$f > $D/$f || true; done
 grep '^{' $P/bench_trace_fp32.log > $D/bench_line_under_rocprof_steps3_warmup0_dtype_fp32.json
 grep '^{' $P/bench_default.log > $D/bench_line_default_run.json
 python profiles/summarize_pmc.py $(find $P/pmc_fetch -name "*counter_collection.csv" | head -1) $(find $P/pmc_write -name "*counter_collection.csv" | head -1) > $D/pmc_hbm_fetch_write_steps1_one_stream.csv

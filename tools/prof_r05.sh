@@ -25,6 +25,8 @@ python3 $R/tools/stream_timeline.py $(find $O/trace -name "*kernel_trace.csv" | 
 python3 $R/tools/micro/nt_f16_ablate.py 36 8448 1024 1024 16 33664 1024 512 > $O/nt_f16_ablations.txt 2>&1 || true
 python3 $R/tools/gemm_nt_dtype.py > $O/gemm_dtypes.txt 2>&1 || true
 bash $R/tools/micro/knob_ab.sh "" "--option f16_presplit=0" "--option f16_presplit=0 --option f16_nt256_min_tiles=0" "--dtype bf16x6" "--pair-d-max-pixels 0" > $O/knob_ab.txt 2>&1 || true
+python3 $R/tools/micro/host_enqueue_probe.py 6 > $O/host_enqueue_probe.txt 2>&1 || true
+python3 $R/tools/micro/guide_overlap_probe.py 5 > $O/guide_overlap_probe.txt 2>&1 || true
 echo micro done
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/cfg1_trace -o cfg1 -- $L 100 > $O/cfg1_trace.log 2>&1
 timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/cfg1_fetch -o cfg1 -- $L 20 > $O/cfg1_fetch.log 2>&1
