@@ -897,12 +897,13 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
     if (nt256_min_tiles > 0 && !(g_nt_abl & 32) && !(N % 256) && tiles256 >= nt256_min_tiles) {
         if (!afi_opt_in_big_lds(a_pre ? (const void*)afi_gemm_nt_f16x3_w16_kernel<true> : (const void*)afi_gemm_nt_f16x3_w16_kernel<false>)) return AFI_ERR_LAUNCH;
         const int ntm2 = planes * tpp, ntn2 = N / 256, chunk2 = afi_cdiv(ntm2, 8);
-        prof.split = 3;
+        prof.split = a_pre ? 4 : 3;                        // (afi_profile_dump: 2 / 3 = the 128 / 256 tile splitting A in registers, 5 / 4 = on pre-split planes)
         if (a_pre) hipLaunchKernelGGL(afi_gemm_nt_f16x3_w16_kernel<true>, dim3(chunk2 * ntn2 * 8), dim3(1024), 16 * 16 * 132 * 4, st, g, ab, ntn2, ntm2, chunk2, tpp);
         else hipLaunchKernelGGL(afi_gemm_nt_f16x3_w16_kernel<false>, dim3(chunk2 * ntn2 * 8), dim3(1024), 16 * 16 * 132 * 4, st, g, ab, ntn2, ntm2, chunk2, tpp);
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }
     if (a_pre) {
+        prof.split = 5;
         hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 0, true>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }

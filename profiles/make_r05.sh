@@ -46,10 +46,10 @@ dom, out = record(f'{D}/pmc_hbm_fetch_write_steps1_one_stream.csv', lambda k: 'a
                   'bench.py --steps 1 --warmup 0 --no-interp --no-cpu-baseline --one-stream')
 # algorithmic bytes per launch from the per-launch shapes of the one-stream trace pass (afi_profile_dump): A rows x K fp32 read, the
 # pre-split weights planes x N x K x 2 bytes x parts read, C rows x N fp32 written
-# (the f16x3 NT GEMM runs as two kernels -- the 256 x 256 tile on the large shapes, kind split = 3 in the per-launch dump, the 128 x 128 tile on the rest --: the record is the
+# (the f16x3 NT GEMM runs as four kernels -- the 256 x 256 tile on the large shapes and the 128 x 128 tile on the rest, each on fp32 or on pre-split A planes; the per-launch dump's `split` column says which --: the record is the
 #  one with the larger traffic, and its algorithmic bytes are those of ITS launches)
-big = 'w16' in dom['kernel']
-ln = [r for r in csv.DictReader(open(f'{D}/launches_bench_steps3_one_stream.csv')) if r['kind'].startswith('gemm_nt_f16x3') and (int(r['split']) == 3) == big]
+code = {(False, False): 2, (True, False): 3, (True, True): 4, (False, True): 5}[('w16' in dom['kernel'], '<true>' in dom['kernel'] or 'true>' in dom['kernel'])]   # (igemm.hip: the dump's `split` column names the kernel)
+ln = [r for r in csv.DictReader(open(f'{D}/launches_bench_steps3_one_stream.csv')) if r['kind'].startswith('gemm_nt_f16x3') and int(r['split']) == code]
 if ln:
     alg = [4 * int(r['rows']) * int(r['k']) + 4 * int(r['planes']) * int(r['cols']) * int(r['k']) + 4 * int(r['rows']) * int(r['cols']) for r in ln]
     out["algorithmic_bytes_per_launch"] = sum(alg) / len(alg)
