@@ -793,11 +793,11 @@ def main():
                 # `achieved` above is over the timed region, where the D phase runs on two streams: a launch's duration includes the time it
                 # shares the chip with the other stream's kernels (sum of durations > wall time).  The kernel with the chip to itself:
                 "kernel_alone": (dict(kernel_alone, frac=kernel_alone["achieved"] / dom_peak,
-                                      note="two extra steps with the engine's overlap_d / overlap_g and the guide prefetch off (one stream), same HIP-event brackets; profiles/r03 holds both traces")
+                                      note="two extra steps with the engine's overlap_d / overlap_g and the guide prefetch off (one stream), same HIP-event brackets; profiles/r05 holds both traces")
                                  if kernel_alone else None),
                 # fp32-equivalent rate of the dominant kernel against the fp32 MFMA roof it replaces (> 1 is the point of the emulated forms)
                 "achieved_over_fp32_mfma_peak": dom["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                "peak_note": "fp32-equivalent TFLOP/s: 2*M*N*K once per product; peak = dense bf16 MFMA 2500 (quoted at 2.4 GHz) / bf16 MFMAs per product (6, 3 or 1), or the fp32 MFMA 157.3.  Dense bf16 MFMA work is power-limited on this chip: traffic.held_clock_ghz / traffic.mfma_busy_at_held_clock are the clock it holds under this kernel and the matrix-pipe duty there (SQ_BUSY_CYCLES, SQ_VALU_MFMA_BUSY_CYCLES of the one-stream counter pass): DESIGN.md 4b",
+                "peak_note": "fp32-equivalent TFLOP/s: 2*M*N*K once per product; peak = dense bf16 / f16 MFMA 2500 (quoted at 2.4 GHz) / MFMAs per product (6, 3 or 1), or the fp32 MFMA 157.3.  `achieved` is taken in the two-stream step, where a launch shares the chip with the other stream's kernels and its HIP-event duration stretches; `kernel_alone` is the same kernel with the chip to itself.  The library's own plain-fp16 GEMM (hipBLASLt) reaches 922 TFLOP/s on the largest shape of this step with random operands = 307 fp32-equivalent at three products (profiles/r05/hipblaslt_f16_ceiling.txt).  Dense f16 / bf16 MFMA work is power-limited on this chip: traffic.held_clock_ghz / traffic.mfma_busy_at_held_clock are the clock it holds under this kernel and the matrix-pipe duty there (SQ_BUSY_CYCLES, SQ_VALU_MFMA_BUSY_CYCLES of the one-stream counter pass): DESIGN.md 4b",
                 # the whole step in EXECUTED matrix-core products (what the GEMM launches multiplied, Winograd-domain for the big convs): the time
                 # they need at each kernel's own peak over the wall time -- the one <= 1 "achieved roofline" figure of the step
                 "frac_step_executed": peak_s / elapsed,
