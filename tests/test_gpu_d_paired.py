@@ -107,3 +107,18 @@ def test_paired_call_refuses_odd_batches_and_the_folded_affine(amd):
     with pytest.raises(_lib.AfiError):
         _lib.call("afi_discriminator_fwd_paired", C.byref(prm), ops.view_of(x), 3, 8, 12, C.c_void_p(logits.data_ptr()), 1, C.c_void_p(ws.data_ptr()), n,
                   ops.stream_ptr())
+    # the folded BatchNorm affine is one per tensor: a paired call under it is refused, not silently given the first half's statistics
+    cx = _lib.Ctx()
+    cx.set_option("d_fold_bn_apply", 1)
+    lg4 = torch.empty(4 * 40 * 40, device="cuda")
+    D2 = amd.Discriminator(in_filters=128).cuda()
+    net2 = D2.Discriminators[0]
+    prm2, keep2 = net2._param_struct(net2._ordered_params())
+    F2 = (C.c_int * 4)(*net2.F)
+    xb = ops.new_pixel_major(4, 128, 40, 40, "cuda", zero=True)
+    nb = lib.afi_discriminator_fwd_ws_floats(F2, 4, 40, 40)
+    wsb = torch.empty(nb, device="cuda")
+    with _lib.use_ctx(cx), pytest.raises(_lib.AfiError):
+        _lib.call("afi_discriminator_fwd_paired", C.byref(prm2), ops.view_of(xb), 4, 40, 40, C.c_void_p(lg4.data_ptr()), 1, C.c_void_p(wsb.data_ptr()), nb,
+                  ops.stream_ptr())
+    torch.cuda.synchronize()

@@ -90,7 +90,11 @@ def test_stage1_small_ragged_vs_oracle(amd, reuse):
     hr_f = [torch.randn((2, C, 25, 42), generator=gen), torch.randn((2, C, 13, 21), generator=gen), torch.randn((2, C, 8, 12), generator=gen)]
     lr0 = 0.01
     step = amd.Stage1Step(G, D, base_lr=lr0, warmup_iters=0, reuse_generator_forward=reuse)
+    seen = []
+    step.on_d_level = seen.append                     # the caller's hook: once per level of the D phase, largest level first, while the step is enqueued
     step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
+    assert seen == [0, 1, 2]
+    step.on_d_level = None
     m = step.metrics()
     d_losses, d_grads, d_bufs = orc.stage1_d_phase(gp, dp, lr_f, hr_f, first_level=2)
     for k, v in d_losses.items():
