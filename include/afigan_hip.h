@@ -271,7 +271,9 @@ int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const af
  * second's -- D(real) then D(fake) in the D phase (stage1_trainer.py:349-359), D(fake) then D(real) in the G phase (:399-403).  Every
  * convolution runs once over all N images (half the launches, twice the rows per GEMM: what the small levels lack); every BatchNorm takes
  * its batch statistics over each half alone and moves the running statistics / num_batches_tracked twice, first half first, so the
- * parameters, buffers and logits come out as from the two calls (to fp32 rounding: under f16x3 the two halves share one operand scale).
+ * parameters, buffers and logits come out as from the two calls (to fp32 rounding: under f16x3 the two halves share one operand scale per
+ * Winograd plane -- a half whose largest magnitude lies 2^k below the other's keeps 22 - k significand bits in the FIRST conv; behind it every
+ * BatchNorm has normalised the halves separately.  Pair tensors of like scale, as D(real) / D(fake) under an L1 term are).
  * Workspace sizes are those of the N-image call; `logits` / `dlogits` are [N, H, W]; the parameter gradients of both halves add up, as
  * two backward calls would leave them.  The second half's batch statistics sit behind the layout afi_discriminator_ws_layout reports.
  * Not available under AFI_OPT_D_FOLD_BN_APPLY (AFI_ERR_UNSUPPORTED). */
