@@ -86,6 +86,10 @@ struct AfiPixGemm {
     // Winograd form under the f16x3 arithmetic only: the largest magnitude of A (device memory).  a_amax_known = 1: its producer has published it
     // (the input transform then writes the planes split into fp16 pieces); 0: a zero-filled slot the input transform raises; null: a slot of the call's pool
     float* a_amax; int a_amax_known;
+    // Winograd form: caller-owned home for the input planes (at least 36 * Tpad * Ck floats) instead of the call's scratch, honoured only when
+    // the planes are F(4x4) and written split into fp16 pieces -- the form the weight-gradient GEMM of the same conv reads, so a backward
+    // pass can take them instead of transforming the input again (nets.hip: disc_v_shared decides on both sides)
+    float* v_keep;
 };
 #define AFI_WK6_STAGE_BYTES 6144
 // one weight (or weight view) to turn into such an image: the B addressing of AfiPixGemm (b_rc = 0: row n at B + n*b_sRow + tap*b_sTap + c;

@@ -134,7 +134,10 @@ struct WinoWgradAccum {
 // Per-context options (afi_ctx_set_option; include/afigan_hip.h lists them).  Nothing in the library reads the environment: a choice that
 // changes numerics or scheduling is made by the caller, per context, and can be changed between calls.  Context-less calls use the defaults.
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
-static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ 0, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
+#ifndef AFI_DEFAULT_F4_FORWARD
+#define AFI_DEFAULT_F4_FORWARD 1                          // (A/B builds: -DAFI_DEFAULT_F4_FORWARD=0 / 8 ...)
+#endif
+static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ AFI_DEFAULT_F4_FORWARD, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
                                             /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0, /*DETERMINISTIC*/ 0, /*F16_PRESPLIT*/ 1, /*F16_NT256_MIN_TILES*/ 512}};
 struct afi_ctx {
@@ -253,7 +256,8 @@ static long long wino_tpad(int N, int H, int W) { return (((long long)N * ((H + 
 static long long wino4_tpad(int N, int H, int W) { return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4) + 127) / 128) * 128; }
 // AFI_OPT_WINOGRAD_F4_FORWARD: F(4x4) tiles also for the forwards a backward follows (faster; its ~3e-5 rounding moves ~30x more activations
 // across the LeakyReLU kink than an F(2x2)/direct forward does -- DESIGN.md "Winograd" has the measurement).  Off by default.
-static bool wino_d_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F4_FORWARD) != 0; }
+// value 1: every block; otherwise bit n + 1 selects block n (2: block 0, 4: block 1, 8: block 2; sums combine)
+static bool wino_d_f4(const afi_ctx* cx, int n) { const long long v = afi_opt(cx, AFI_OPT_WINOGRAD_F4_FORWARD); return (v & 1) || ((v >> (n + 1)) & 1); }
 static bool wino_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F4_BACKWARD) != 0; }
 // one size for both tilings: F(2x2,3x3) = 16 transform points over 2x2 tiles, F(4x4,3x3) = 36 points over 4x4 tiles
 // + the pre-split bf16 image of U the DMA GEMM stages (three 2-byte parts per element = 1.5 floats; afi_gemm_bf16.h)
@@ -474,6 +478,8 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     const bool a_pre = afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 && want_amax && g.a_amax && g.a_amax_known && nph == 1 && !(g.Ck & 31) && !g.a_bn.mean;
     if (want_amax && !(amax = g.a_amax ? g.a_amax : wino_amax_take(cx, ws, ws_floats, 1, st))) return AFI_ERR_LAUNCH;
     const AfiF16Bound abound = afi_f16_bound(amax, f4 ? 2 : 1);
+    if (g.v_keep && !(f4 && a_pre)) return AFI_ERR_BAD_ARG; // (the caller's predicate and this function's disagree: the backward would read planes nobody wrote)
+    if (g.v_keep) Vb = g.v_keep;                           // kept for the weight gradient of the same conv
     for (int ph = 0; ph < nph; ++ph) {                     // phase ph = (py, px): pixel (y, x) of its view is (2y + py, 2x + px) of A
         AfiView a = g.A;
         if (nph == 4) { a.p += (ph >> 1) * g.A.sH + (ph & 1) * g.A.sW; a.sH *= 2; a.sW *= 2; }
@@ -509,11 +515,13 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
 // in_bn: `in` is read through a BatchNorm affine + LeakyReLU (AfiBnLoad): the activation of the block that produced it is never written
 static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
                      float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false,
-                     double* stats = nullptr, int* stats_rows = nullptr, const AfiBnLoad* in_bn = nullptr, float* in_amax = nullptr, bool in_amax_known = false) {
+                     double* stats = nullptr, int* stats_rows = nullptr, const AfiBnLoad* in_bn = nullptr, float* in_amax = nullptr, bool in_amax_known = false,
+                     float* v_keep = nullptr) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
     if (in_bn) g.a_bn = *in_bn;
     g.a_amax = in_amax; g.a_amax_known = in_amax_known ? 1 : 0;
+    g.v_keep = v_keep;
     if (mode && z.p) { g.Z = z; g.z_lo = 0; g.z_hi = Nc; }
     if (stats_rows) *stats_rows = 0;
     if (stats && stats_rows && !mode) {
@@ -557,7 +565,7 @@ static float* wino_wgacc_slot(afi_ctx* cx, float* dw, int f4, int O, int I, floa
 // x_bn: x is read through a BatchNorm affine + LeakyReLU (AfiBnLoad)
 static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, int Cout, int Cin, float* dw, float alpha, float* ws, long long ws_floats,
                       hipStream_t st, int dy_phases = 1, bool accumulate = true, const AfiBnLoad* x_bn = nullptr, const float* dy_amax = nullptr,
-                      const float* x_amax = nullptr) {
+                      const float* x_amax = nullptr, const float* v_have = nullptr) {
     if ((Cin & 3) || (Cout & 3)) return AFI_ERR_UNSUPPORTED;
     if (ws_floats < wino_ws_floats(N, H, W, Cin, Cout)) return AFI_ERR_WORKSPACE;
     const int dtype = cx ? cx->dtype : afi_default_dtype();
@@ -579,6 +587,10 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     const bool known = f16 && dy_amax && x_amax;           // (known but not split: the in-register kernel with the known maxima; nothing is raised)
     if (f16 && !known && !(amax = wino_amax_take(cx, ws, ws_floats, 2, st))) return AFI_ERR_LAUNCH;
     const AfiF16Bound vbound = afi_f16_bound(known ? x_amax : amax, f4 ? 2 : 1), qbound = afi_f16_bound(known ? dy_amax : amax + 4, f4 ? 4 : 3);
+    // v_have: the forward of this conv kept its F(4x4) input planes, split with the very bound used here (x_amax): nothing to transform
+    if (v_have && f4 && pre) Vb = (float*)v_have;
+    else if (v_have) return AFI_ERR_BAD_ARG;               // (the caller's predicate and this function's disagree: never read planes that were not written)
+    else
     AFI_TRY(f4 ? afi_launch_wino4_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 && !known ? amax : nullptr, pre ? &vbound : nullptr)
                : afi_launch_wino_input(x, N, H, W, Cin, Tpad, Vb, st, 0, x_bn, f16 && !known ? amax : nullptr, pre ? &vbound : nullptr));
     const int cph = Cout / dy_phases;
@@ -1697,7 +1709,7 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
 // forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][y2 P*F3][d9 P*16][mean,invstd x3][red]
 struct DiscWs {
     long long P;
-    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_amax, o_part, n_part, o_wino, n_wino, o_mean_b[3], o_invstd_b[3], total;
+    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_amax, o_part, n_part, o_wino, n_wino, o_mean_b[3], o_invstd_b[3], o_vkeep[3], total;
 };
 static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     DiscWs w;
@@ -1724,6 +1736,11 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     for (int n = 0; n < 3; ++n) {                         // the second half's batch statistics of a paired call (afi_discriminator_fwd_paired)
         w.o_mean_b[n] = o; o += align4(F[n + 1]);
         w.o_invstd_b[n] = o; o += align4(F[n + 1]);
+    }
+    // the F(4x4) input planes of blocks 1 and 2, kept by a forward that a backward follows for that block's weight gradient (disc_v_shared)
+    for (int n = 0; n < 3; ++n) {
+        w.o_vkeep[n] = o;
+        if (n > 0 && w.P >= 8192 && w.n_wino > 0) o += align4(36 * wino4_tpad(N, H, W) * F[n]);
     }
     w.total = o;
     return w;
@@ -1763,6 +1780,15 @@ static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     return w;
 }
 long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W) { return disc_bwd_ws(F, N, H, W).total; }
+
+// Does the forward (training == 1) of block n keep its input planes for the backward's weight gradient?  Evaluated by BOTH passes, which is why
+// afi_discriminator_bwd must run under the options and the arithmetic of its forward: F(4x4) forward in that block, f16x3 with pre-split planes
+// (the block's input maximum is known before its transform runs: blocks 1 and 2), channel counts the DMA GEMMs take
+static bool disc_v_shared(const afi_ctx* cx, const int F[4], int n, long long P, bool wino) {
+    const int dtype = cx ? cx->dtype : afi_default_dtype();
+    return wino && n > 0 && wino_d_f4(cx, n) && wino_f4(cx) && dtype == AFI_DTYPE_F16X3 && P >= 8192 && afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 &&
+           afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) == 0 && !(F[n] % 128) && !(F[n + 1] % 128);
+}
 
 static int disc_check(const afi_disc_params_t* p) {
     if (!p) return AFI_ERR_BAD_ARG;
@@ -1819,8 +1845,9 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
         const bool fuse_stats = training && halves == 1 && afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0 && (((uintptr_t)stats) & 7) == 0;
         if (wino) {
             AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
-                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx), fuse_stats ? stats : nullptr, &stats_rows, in_bn.mean ? &in_bn : nullptr,
-                              slots ? amax + 4 * n : nullptr, /*known=*/n > 0));
+                              part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx, n), fuse_stats ? stats : nullptr, &stats_rows, in_bn.mean ? &in_bn : nullptr,
+                              slots ? amax + 4 * n : nullptr, /*known=*/n > 0,
+                              training == 1 && slots && disc_v_shared(cx, prm->F, n, P, wino) ? ws + l.o_vkeep[n] : nullptr));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
@@ -1941,7 +1968,8 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
         AfiBnLoad x_bn{nullptr, nullptr, nullptr, nullptr};
         if (xin_folded) x_bn = AfiBnLoad{ws + l.o_mean[n - 1], ws + l.o_invstd[n - 1], prm->gamma[n - 1], prm->beta[n - 1]};
         if (gr->w[n] && wino) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd, 1, true, xin_folded ? &x_bn : nullptr,
-                                                 slots ? gmax + 4 * n : nullptr, slots ? xmax + 4 * n : nullptr));
+                                                 slots ? gmax + 4 * n : nullptr, slots ? xmax + 4 * n : nullptr,
+                                                 slots && disc_v_shared(cx, prm->F, n, P, wino) ? ws + l.o_vkeep[n] : nullptr));
         else if (gr->w[n]) AFI_TRY(wgrad_launch(cx, conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0 && wino) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), null_view(), scratch + s.o_wino,

@@ -9,7 +9,9 @@ import afigan_amd as amd
 
 tag, H, W = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 _cx = amd._lib.current_ctx()
-for _k, _v in {"direct": {"winograd": 0}, "f4fwd": {"winograd_f4_forward": 1}, "f2all": {"winograd_f4_backward": 0}}.get(tag, {}).items():
+for _k, _v in {"direct": {"winograd": 0}, "f4fwd": {"winograd_f4_forward": 1}, "f2all": {"winograd_f4_backward": 0},
+               "f4b0": {"winograd_f4_forward": 2}, "f4b1": {"winograd_f4_forward": 4}, "f4b2": {"winograd_f4_forward": 8},
+               "f4b12": {"winograd_f4_forward": 12}, "f4b02": {"winograd_f4_forward": 10}, "f4b01": {"winograd_f4_forward": 6}}.get(tag, {}).items():
     _cx.set_option(_k, _v)
 torch.manual_seed(0)
 D = amd.Discriminator().cuda()
