@@ -135,7 +135,7 @@ struct WinoWgradAccum {
 // changes numerics or scheduling is made by the caller, per context, and can be changed between calls.  Context-less calls use the defaults.
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 #ifndef AFI_DEFAULT_F4_FORWARD
-#define AFI_DEFAULT_F4_FORWARD 1                          // (A/B builds: -DAFI_DEFAULT_F4_FORWARD=0 / 8 ...)
+#define AFI_DEFAULT_F4_FORWARD 12                         // blocks 1 and 2 (A/B builds: -DAFI_DEFAULT_F4_FORWARD=0 / 1 / 8 ...)
 #endif
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ AFI_DEFAULT_F4_FORWARD, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
@@ -254,8 +254,10 @@ static AfiWgradGemm conv_wgrad_desc(AfiView dy, AfiView x, int N, int H, int W, 
 //      mode 1 = data gradient (K = Cout, columns = Cin, flipped taps).  ws: [U 16*K*Nc][V 16*Tpad*K][M 16*Tpad*Nc].
 static long long wino_tpad(int N, int H, int W) { return (((long long)N * ((H + 1) / 2) * ((W + 1) / 2) + 127) / 128) * 128; }
 static long long wino4_tpad(int N, int H, int W) { return (((long long)N * ((H + 3) / 4) * ((W + 3) / 4) + 127) / 128) * 128; }
-// AFI_OPT_WINOGRAD_F4_FORWARD: F(4x4) tiles also for the forwards a backward follows (faster; its ~3e-5 rounding moves ~30x more activations
-// across the LeakyReLU kink than an F(2x2)/direct forward does -- DESIGN.md "Winograd" has the measurement).  Off by default.
+// AFI_OPT_WINOGRAD_F4_FORWARD: F(4x4) tiles also for the discriminator forwards a backward follows, per block.  Their conv outputs decide LeakyReLU
+// masks, so the forward's rounding shows up in the gradients as flipped masks (DESIGN.md 4 has the study): with the interpolation points of
+// csrc/winograd.hip, blocks 1 and 2 on F(4x4) leave the gradients as far from an fp64 evaluation as the exact-fp32 direct kernels do (and as
+// torch's own fp32 ops do); block 0 (256 input channels: the shortest sums) costs the most accuracy and buys the least time, and stays on F(2x2).
 // value 1: every block; otherwise bit n + 1 selects block n (2: block 0, 4: block 1, 8: block 2; sums combine)
 static bool wino_d_f4(const afi_ctx* cx, int n) { const long long v = afi_opt(cx, AFI_OPT_WINOGRAD_F4_FORWARD); return (v & 1) || ((v >> (n + 1)) & 1); }
 static bool wino_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F4_BACKWARD) != 0; }

@@ -468,15 +468,101 @@ int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hi
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]                                 (4x4 outputs)
 //   G'  = [1/4 0 0 0; -1/6(1 1 1 1); -1/6(1 -1 1 -1); 1/24(1 2 4 8); 1/24(1 -2 4 -8); 0 0 0 1]     (4x4 block of dY, weight gradient)
 //   A'^T= [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 1]                                                 (3x3 weight taps)
+// AFI_WINO4_POINTS = 1 (default since round 5, when the discriminator's mask-deciding forwards moved to this form): interpolation points
+// {0, 1, -1, 1/2, -2, inf} instead of the textbook {0, +-1, +-2, inf}: the largest row sums of B^T and A^T fall from 10 / 19 to 7 / 11.1 and the
+// fp32 rounding of a conv with them (every constant is still exact in fp32 except the 1/3 and 1/15 multiples of G, G').
+//   B^T = [1 -3/2 -2 3/2 1 0; 0 -1 1/2 5/2 1 0; 0 1 -5/2 1/2 1 0; 0 -2 -1 2 1 0; 0 1/2 -1 -1/2 1 0; 0 1 -3/2 -2 3/2 1]
+//   G   = [1 0 0; 1/3(1 1 1); -1/3(1 -1 1); -16/15(1 1/2 1/4); 1/15(1 -2 4); 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 1/2 -2 0; 0 1 1 1/4 4 0; 0 1 -1 1/8 -8 1]
+//   G'  = [1 0 0 0; 1/3(1 1 1 1); -1/3(1 -1 1 -1); -16/15(1 1/2 1/4 1/8); 1/15(1 -2 4 -8); 0 0 0 1]
+//   A'^T= [1 1 1 1 1 0; 0 1 -1 1/2 -2 0; 0 1 1 1/4 4 1]
+#ifndef AFI_WINO4_POINTS
+#define AFI_WINO4_POINTS 1
+#endif
 template <typename T>
 __device__ __forceinline__ void wino4_bt(T& d0, T& d1, T& d2, T& d3, T& d4, T& d5) {      // in place: B^T d
+#if AFI_WINO4_POINTS == 1
+    const T t0 = d0 + 1.5f * (d3 - d1) - 2.f * d2 + d4;
+    const T t1 = -d1 + 0.5f * d2 + 2.5f * d3 + d4;
+    const T t2 = d1 - 2.5f * d2 + 0.5f * d3 + d4;
+    const T t3 = 2.f * (d3 - d1) - d2 + d4;
+    const T t4 = 0.5f * (d1 - d3) - d2 + d4;
+    const T t5 = d1 + 1.5f * (d4 - d2) - 2.f * d3 + d5;
+#else
     const T t0 = 4.f * d0 - 5.f * d2 + d4;
     const T t1 = -4.f * (d1 + d2) + d3 + d4;
     const T t2 = 4.f * (d1 - d2) - d3 + d4;
     const T t3 = -2.f * d1 - d2 + 2.f * d3 + d4;
     const T t4 = 2.f * d1 - d2 - 2.f * d3 + d4;
     const T t5 = 4.f * d1 - 5.f * d3 + d5;
+#endif
     d0 = t0; d1 = t1; d2 = t2; d3 = t3; d4 = t4; d5 = t5;
+}
+// G applied to three taps, G' to four samples (one definition for the weight and the dY transforms)
+template <typename T>
+__device__ __forceinline__ void wino4_g3(const T g0, const T g1, const T g2, T (&a)[6]) {
+#if AFI_WINO4_POINTS == 1
+    a[0] = g0;
+    a[1] = (1.f / 3.f) * (g0 + g1 + g2);
+    a[2] = (-1.f / 3.f) * (g0 - g1 + g2);
+    a[3] = (-16.f / 15.f) * g0 + (-8.f / 15.f) * g1 + (-4.f / 15.f) * g2;
+    a[4] = (1.f / 15.f) * g0 + (-2.f / 15.f) * g1 + (4.f / 15.f) * g2;
+    a[5] = g2;
+#else
+    a[0] = 0.25f * g0;
+    a[1] = (-1.f / 6.f) * (g0 + g1 + g2);
+    a[2] = (-1.f / 6.f) * (g0 - g1 + g2);
+    a[3] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    a[4] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
+    a[5] = g2;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void wino4_g4(const T v0, const T v1, const T v2, const T v3, T (&a)[6]) {
+#if AFI_WINO4_POINTS == 1
+    a[0] = v0;
+    a[1] = (1.f / 3.f) * (v0 + v1 + v2 + v3);
+    a[2] = (-1.f / 3.f) * (v0 - v1 + v2 - v3);
+    a[3] = (-16.f / 15.f) * v0 + (-8.f / 15.f) * v1 + (-4.f / 15.f) * v2 + (-2.f / 15.f) * v3;
+    a[4] = (1.f / 15.f) * v0 + (-2.f / 15.f) * v1 + (4.f / 15.f) * v2 + (-8.f / 15.f) * v3;
+    a[5] = v3;
+#else
+    a[0] = 0.25f * v0;
+    a[1] = (-1.f / 6.f) * (v0 + v1 + v2 + v3);
+    a[2] = (-1.f / 6.f) * (v0 - v1 + v2 - v3);
+    a[3] = (1.f / 24.f) * v0 + (1.f / 12.f) * v1 + (1.f / 6.f) * v2 + (1.f / 3.f) * v3;
+    a[4] = (1.f / 24.f) * v0 - (1.f / 12.f) * v1 + (1.f / 6.f) * v2 - (1.f / 3.f) * v3;
+    a[5] = v3;
+#endif
+}
+// A^T m (four outputs) and A'^T m (three weight taps) of six transform-domain values
+template <typename T>
+__device__ __forceinline__ void wino4_at(const T m0, const T m1, const T m2, const T m3, const T m4, const T m5, T& y0, T& y1, T& y2, T& y3) {
+    const T p12 = m1 + m2, d12 = m1 - m2;
+#if AFI_WINO4_POINTS == 1
+    y0 = m0 + p12 + m3 + m4;
+    y1 = d12 + 0.5f * m3 - 2.f * m4;
+    y2 = p12 + 0.25f * m3 + 4.f * m4;
+    y3 = d12 + 0.125f * m3 - 8.f * m4 + m5;
+#else
+    const T p34 = m3 + m4, d34 = m3 - m4;
+    y0 = m0 + p12 + p34;
+    y1 = d12 + 2.f * d34;
+    y2 = p12 + 4.f * p34;
+    y3 = d12 + 8.f * d34 + m5;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ void wino4_at3(const T m0, const T m1, const T m2, const T m3, const T m4, const T m5, T& y0, T& y1, T& y2) {
+#if AFI_WINO4_POINTS == 1
+    y0 = m0 + m1 + m2 + m3 + m4;
+    y1 = (m1 - m2) + 0.5f * m3 - 2.f * m4;
+    y2 = (m1 + m2) + 0.25f * m3 + 4.f * m4 + m5;
+#else
+    y0 = m0 + m1 + m2 + m3 + m4;
+    y1 = (m1 - m2) + 2.f * (m3 - m4);
+    y2 = (m1 + m2) + 4.f * (m3 + m4) + m5;
+#endif
 }
 
 // input: X (view) -> V [36][Tpad][C]; the 6x6 patch of tile (ty, tx) starts at (4*ty - 1, 4*tx - 1)
@@ -575,27 +661,18 @@ __global__ __launch_bounds__(1024) void afi_wino4_weight_kernel(const float* __r
     float a[6][3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const float g0 = g[0][j], g1 = g[1][j], g2 = g[2][j];
-        a[0][j] = 0.25f * g0;
-        a[1][j] = (-1.f / 6.f) * (g0 + g1 + g2);
-        a[2][j] = (-1.f / 6.f) * (g0 - g1 + g2);
-        a[3][j] = (1.f / 24.f) * g0 + (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-        a[4][j] = (1.f / 24.f) * g0 - (1.f / 12.f) * g1 + (1.f / 6.f) * g2;
-        a[5][j] = g2;
+        float col[6];
+        wino4_g3(g[0][j], g[1][j], g[2][j], col);
+#pragma unroll
+        for (int r = 0; r < 6; ++r) a[r][j] = col[r];
     }
     const long long plane = (long long)O * I;
     const int oi = blockIdx.x * 32 + to, oo = blockIdx.y * 32 + ti;      // transposed roles for the store: ti walks o
     const bool ok2 = oi < I && oo < O;
 #pragma unroll
     for (int r = 0; r < 6; ++r) {
-        const float a0 = a[r][0], a1 = a[r][1], a2 = a[r][2];
         float u[6];
-        u[0] = 0.25f * a0;
-        u[1] = (-1.f / 6.f) * (a0 + a1 + a2);
-        u[2] = (-1.f / 6.f) * (a0 - a1 + a2);
-        u[3] = (1.f / 24.f) * a0 + (1.f / 12.f) * a1 + (1.f / 6.f) * a2;
-        u[4] = (1.f / 24.f) * a0 - (1.f / 12.f) * a1 + (1.f / 6.f) * a2;
-        u[5] = a2;
+        wino4_g3(a[r][0], a[r][1], a[r][2], u);
         if (!mode) {                                         // forward: U[a][o][i], the thread's own (o, i): already coalesced
 #pragma unroll
             for (int c = 0; c < 6; ++c)
@@ -637,18 +714,14 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
             const f32x4 m0 = __builtin_nontemporal_load((const f32x4*)(src + (0 * 6 + j) * plane)), m1 = __builtin_nontemporal_load((const f32x4*)(src + (1 * 6 + j) * plane));
             const f32x4 m2 = __builtin_nontemporal_load((const f32x4*)(src + (2 * 6 + j) * plane)), m3 = __builtin_nontemporal_load((const f32x4*)(src + (3 * 6 + j) * plane));
             const f32x4 m4 = __builtin_nontemporal_load((const f32x4*)(src + (4 * 6 + j) * plane)), m5 = __builtin_nontemporal_load((const f32x4*)(src + (5 * 6 + j) * plane));
-            const f32x4 p12 = m1 + m2, d12 = m1 - m2, p34 = m3 + m4, d34 = m3 - m4;
-            s[0][j] = m0 + p12 + p34;
-            s[1][j] = d12 + 2.f * d34;
-            s[2][j] = p12 + 4.f * p34;
-            s[3][j] = d12 + 8.f * d34 + m5;
+            wino4_at(m0, m1, m2, m3, m4, m5, s[0][j], s[1][j], s[2][j], s[3][j]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int yy = 4 * ty + i;
             if (yy >= p.H) continue;
-            const f32x4 p12 = s[i][1] + s[i][2], d12 = s[i][1] - s[i][2], p34 = s[i][3] + s[i][4], d34 = s[i][3] - s[i][4];
-            const f32x4 y0 = s[i][0] + p12 + p34, y1 = d12 + 2.f * d34, y2 = p12 + 4.f * p34, y3 = d12 + 8.f * d34 + s[i][5];
+            f32x4 y0, y1, y2, y3;
+            wino4_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], y0, y1, y2, y3);
             const int xx = 4 * tx;
             auto put = [&](int xo, f32x4 v) {
                 if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xo, c, v); if (STATS) afi_stats_acc(st0, st1, o); }
@@ -716,12 +789,10 @@ __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int
                 }
             }
             if constexpr (AMAX) am = afi_amax4(afi_amax4(afi_amax4(afi_amax4(am, v[0]), v[1]), v[2]), v[3]);
-            a[0][j] = 0.25f * v[0];
-            a[1][j] = (-1.f / 6.f) * (v[0] + v[1] + v[2] + v[3]);
-            a[2][j] = (-1.f / 6.f) * (v[0] - v[1] + v[2] - v[3]);
-            a[3][j] = (1.f / 24.f) * v[0] + (1.f / 12.f) * v[1] + (1.f / 6.f) * v[2] + (1.f / 3.f) * v[3];
-            a[4][j] = (1.f / 24.f) * v[0] - (1.f / 12.f) * v[1] + (1.f / 6.f) * v[2] - (1.f / 3.f) * v[3];
-            a[5][j] = v[3];
+            f32x4 col[6];
+            wino4_g4(v[0], v[1], v[2], v[3], col);
+#pragma unroll
+            for (int r = 0; r < 6; ++r) a[r][j] = col[r];
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -730,12 +801,10 @@ __global__ __launch_bounds__(256) void afi_wino4_dy_kernel(const AfiView dy, int
                 if (AM == 2) afi_store_split4(Q + t * ldo + pl * plane, c, v, afi_f16_scale(src_max * bnd.cmul[pl]));
                 else *(f32x4*)(dst + pl * plane) = v;
             };
-            put(6 * i + 0, 0.25f * v0);
-            put(6 * i + 1, (-1.f / 6.f) * (v0 + v1 + v2 + v3));
-            put(6 * i + 2, (-1.f / 6.f) * (v0 - v1 + v2 - v3));
-            put(6 * i + 3, (1.f / 24.f) * v0 + (1.f / 12.f) * v1 + (1.f / 6.f) * v2 + (1.f / 3.f) * v3);
-            put(6 * i + 4, (1.f / 24.f) * v0 - (1.f / 12.f) * v1 + (1.f / 6.f) * v2 - (1.f / 3.f) * v3);
-            put(6 * i + 5, v3);
+            f32x4 row[6];
+            wino4_g4(v0, v1, v2, v3, row);
+#pragma unroll
+            for (int c2 = 0; c2 < 6; ++c2) put(6 * i + c2, row[c2]);
         }
     }
     if constexpr (AMAX) afi_amax_publish(am, amax);
@@ -765,16 +834,16 @@ __global__ void afi_wino4_dw_kernel(const float* __restrict__ dU, float* __restr
         for (int j = 0; j < 6; ++j) {
             const float m0 = dU[(0 * 6 + j) * plane + e], m1 = dU[(1 * 6 + j) * plane + e], m2 = dU[(2 * 6 + j) * plane + e];
             const float m3 = dU[(3 * 6 + j) * plane + e], m4 = dU[(4 * 6 + j) * plane + e], m5 = dU[(5 * 6 + j) * plane + e];
-            s[0][j] = m0 + m1 + m2 + m3 + m4;
-            s[1][j] = (m1 - m2) + 2.f * (m3 - m4);
-            s[2][j] = (m1 + m2) + 4.f * (m3 + m4) + m5;
+            wino4_at3(m0, m1, m2, m3, m4, m5, s[0][j], s[1][j], s[2][j]);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float* dst = dW + ((long long)o * 9 + 3 * k) * I + i;
-            dst[0] += alpha * (s[k][0] + s[k][1] + s[k][2] + s[k][3] + s[k][4]);
-            dst[I] += alpha * ((s[k][1] - s[k][2]) + 2.f * (s[k][3] - s[k][4]));
-            dst[2 * I] += alpha * ((s[k][1] + s[k][2]) + 4.f * (s[k][3] + s[k][4]) + s[k][5]);
+            float w0, w1, w2;
+            wino4_at3(s[k][0], s[k][1], s[k][2], s[k][3], s[k][4], s[k][5], w0, w1, w2);
+            dst[0] += alpha * w0;
+            dst[I] += alpha * w1;
+            dst[2 * I] += alpha * w2;
         }
     }
 }

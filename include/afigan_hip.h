@@ -118,12 +118,12 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                  thresholds below; 0: direct implicit GEMM on the fp32 MFMA everywhere */
 #define AFI_OPT_WINOGRAD_F4_BACKWARD 1        /* 1 (default): F(4x4,3x3) / F(3x3,4x4) for data and weight gradients and for forwards no backward follows,
                                                  from 8192 pixels; 0: F(2x2,3x3) everywhere */
-#define AFI_OPT_WINOGRAD_F4_FORWARD 2         /* the discriminator forwards a backward follows (their conv outputs decide LeakyReLU masks):
-                                                 1 (default since round 5): F(4x4) in every block; 0: F(2x2) (1e-6 rounding against F(4x4)'s 3e-5);
-                                                 otherwise bit n + 1 puts block n on F(4x4) (2: block 0, 4: block 1, 8: block 2; sums combine).
-                                                 Measured (DESIGN.md 4, D fwd+bwd at P3 against fp64, relative L2 of dx / worst tensor): torch's fp32
-                                                 ops 0.9-1.0e-3 / 1.3-1.4e-3, F(2x2) 6.4e-4 / 8.8e-4, F(4x4) 2.0e-3 / 2.5e-3, block 2 alone 1.2e-3 /
-                                                 1.9e-3; every parity bar of tests/test_gpu_d_parity.py holds under each; 9 % of a stage-1 step */
+#define AFI_OPT_WINOGRAD_F4_FORWARD 2         /* the discriminator forwards a backward follows (their conv outputs decide LeakyReLU masks), per block:
+                                                 bit n + 1 puts block n on F(4x4) (2: block 0, 4: block 1, 8: block 2; sums combine); 1: every block;
+                                                 0: F(2x2) everywhere.  Default 12 (blocks 1 and 2) since round 5.  Measured (D fwd+bwd at
+                                                 P3 against fp64, relative L2 of dx / worst parameter gradient): torch's fp32 ops 0.9-1.0e-3 / 1.3-1.4e-3,
+                                                 the exact-fp32 direct kernels 1.04e-3 / 1.49e-3, F(2x2) 6.4e-4 / 8.8e-4, blocks 1 + 2 1.09e-3 / 1.50e-3,
+                                                 every block 1.44e-3 / 1.89e-3; stage-1 step 80.8 / 72.4 / 71.5 ms for 0 / 12 / 1 */
 #define AFI_OPT_BN_STATS_FP64 3               /* 1 (default): BatchNorm batch statistics accumulated in fp64 (torch's CPU accumulation type) */
 #define AFI_OPT_D_WINOGRAD_MIN_PIXELS 4       /* 1024: discriminator calls of fewer pixels stay direct (values below 1024 act as 1024) */
 #define AFI_OPT_G_WINOGRAD_MIN_PIXELS 5       /* 2048: the same for a convolution of the interpolator */

@@ -1,5 +1,6 @@
 """D forward+backward on one seeded input under the conv algorithm the tag names -- context options of the library (afi_ctx_set_option):
-direct (winograd off), f2fwd (the default: F(2x2) forwards, F(4x4) gradients), f4fwd (F(4x4) forwards too), f2all (F(2x2) everywhere) --
+direct (winograd off), f2fwd (F(2x2) forwards, F(4x4) gradients), f4fwd (F(4x4) forwards too: the default since round 5), f4bK (F(4x4) forward in the
+blocks K names only), f2all (F(2x2) everywhere) --
 or torch's own fp32 / fp64 ops (torch32 / torch64); dumps the gradients so tools/dflip_cmp.py can compare the variants."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,7 +10,7 @@ import afigan_amd as amd
 
 tag, H, W = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 _cx = amd._lib.current_ctx()
-for _k, _v in {"direct": {"winograd": 0}, "f4fwd": {"winograd_f4_forward": 1}, "f2all": {"winograd_f4_backward": 0},
+for _k, _v in {"direct": {"winograd": 0}, "f2fwd": {"winograd_f4_forward": 0}, "f4fwd": {"winograd_f4_forward": 1}, "f2all": {"winograd_f4_forward": 0, "winograd_f4_backward": 0},
                "f4b0": {"winograd_f4_forward": 2}, "f4b1": {"winograd_f4_forward": 4}, "f4b2": {"winograd_f4_forward": 8},
                "f4b12": {"winograd_f4_forward": 12}, "f4b02": {"winograd_f4_forward": 10}, "f4b01": {"winograd_f4_forward": 6}}.get(tag, {}).items():
     _cx.set_option(_k, _v)
