@@ -1,7 +1,8 @@
 """The stage-1 loop under two arithmetic settings from identical initial weights and inputs: the loss trajectories side by side over a few hundred
 iterations (does the default `f16x3` train like the fp32 MFMA kernels?).  GAN training amplifies rounding differences through LeakyReLU decisions,
 so the trajectories separate slowly; what is checked is that they stay finite and close in the sense a re-seeded fp32 run would.
-Usage: python tools/long_run_dtypes.py [iterations] [dtype_a] [dtype_b]"""
+A setting is `dtype` or `dtype:option=value[,option=value]` (context options of both of the engine's contexts), e.g. `fp32:winograd_f4_forward=0`.
+Usage: python tools/long_run_dtypes.py [iterations] [setting_a] [setting_b]"""
 import copy
 import os
 import sys
@@ -29,7 +30,11 @@ traj = {}
 for dt in dts:
     G, D = copy.deepcopy(G0), copy.deepcopy(D0)
     G.train(); D.train()
-    eng = amd.Stage1Step(G, D, base_lr=1e-3, dtype=dt)
+    name, _, opts = dt.partition(":")
+    eng = amd.Stage1Step(G, D, base_lr=1e-3, dtype=name)
+    for kv in filter(None, opts.split(",")):
+        k, _, v = kv.partition("=")
+        eng.ctx.set_option(k, int(v)); eng.bctx.set_option(k, int(v))
     rows = []
     for it in range(n_iter):
         lrs, hrs = batches[it % len(batches)]

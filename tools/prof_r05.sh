@@ -24,7 +24,7 @@ echo step pmc done
 python3 $R/tools/stream_timeline.py $(find $O/trace -name "*kernel_trace.csv" | head -1) > $O/stream_timeline_two_stream.txt 2>&1 || true
 python3 $R/tools/micro/nt_f16_ablate.py 36 8448 1024 1024 16 33664 1024 512 > $O/nt_f16_ablations.txt 2>&1 || true
 python3 $R/tools/gemm_nt_dtype.py > $O/gemm_dtypes.txt 2>&1 || true
-bash $R/tools/micro/knob_ab.sh "" "--option f16_presplit=0" "--option f16_presplit=0 --option f16_nt256_min_tiles=0" "--dtype bf16x6" "--pair-d-max-pixels 0" > $O/knob_ab.txt 2>&1 || true
+bash $R/tools/micro/knob_ab.sh "" "--option f16_presplit=0" "--option f16_presplit=0 --option f16_nt256_min_tiles=0" "--dtype bf16x6" "--pair-d-max-pixels 0" "--option winograd_f4_forward=0" "--option winograd_f4_forward=1" > $O/knob_ab.txt 2>&1 || true
 python3 $R/tools/micro/host_enqueue_probe.py 6 > $O/host_enqueue_probe.txt 2>&1 || true
 python3 $R/tools/micro/guide_overlap_probe.py 5 > $O/guide_overlap_probe.txt 2>&1 || true
 echo micro done
