@@ -267,7 +267,12 @@ int afi_discriminator_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view
  * steps the BatchNorm affine between the two calls gets masks of ANOTHER affine and no error (the weights w[n] may not move either:
  * the data gradients read them).  Both reference loops run backward before any optimizer step (stage1_trainer.py:374-381,
  * stage2_trainer.py:335-342).  tests/test_gpu_d_parity.py::test_masks_recomputed_in_backward_match_the_forward counts the
- * disagreeing masks on un-nudged inputs. */
+ * disagreeing masks on un-nudged inputs.
+ * PRECONDITION: the backward runs under the OPTIONS and the ARITHMETIC (compute dtype) its forward ran under -- on another context they must be set
+ * alike.  Both passes derive from them what the workspace holds: under f16x3 the forward of blocks 1 and 2 (AFI_OPT_WINOGRAD_F4_FORWARD) keeps its
+ * F(4x4) input planes, split into fp16 pieces, for the weight gradient of the same conv, and the backward reads them instead of transforming the
+ * activation again; a backward that expects planes a differently-configured forward never wrote is refused where the library can see it
+ * (AFI_ERR_BAD_ARG) and undefined where it cannot. */
 int afi_discriminator_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc_params_t* grads, afi_view_t x, int N, int H, int W,
                           const float* ws, const float* dlogits, float* dx, float* scratch, long long scratch_floats, void* stream);
 
