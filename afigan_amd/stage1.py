@@ -297,6 +297,22 @@ class Stage1Step:
             self._buf[key] = t
         return t
 
+    def set_option(self, name: str, value: int) -> None:
+        """A library option (afi_ctx_set_option) on BOTH of the engine's contexts: a backward pass must run under the options of its forward
+        (include/afigan_hip.h, afi_discriminator_bwd), and the forwards run under ``ctx``, the backwards under ``bctx``."""
+        self.ctx.set_option(name, value)
+        self.bctx.set_option(name, value)
+
+    _PAIRED_OPTIONS = ("winograd", "winograd_f4_backward", "winograd_f4_forward", "d_winograd_min_pixels", "d_fold_bn_apply", "f16_presplit")
+
+    def _check_contexts_agree(self) -> None:
+        if self.ctx.dtype != self.bctx.dtype:
+            raise _lib.AfiError(f"the engine's two contexts run different arithmetic ({self.ctx.dtype} / {self.bctx.dtype})")
+        for k in self._PAIRED_OPTIONS:
+            if self.ctx.get_option(k) != self.bctx.get_option(k):
+                raise _lib.AfiError(f"option {k!r} differs between the forward and the backward context ({self.ctx.get_option(k)} / "
+                                    f"{self.bctx.get_option(k)}): set options with Stage1Step.set_option")
+
     @property
     def dtype(self) -> str:
         return self.ctx.dtype
@@ -536,6 +552,7 @@ class Stage1Step:
         self.losses.zero_()
         lptr = self.losses.data_ptr()
         lr_now = self.lr_at(self.iter)
+        self._check_contexts_agree()
         self._comm_events = []
         # transformed conv weights are shared by the calls of a phase (weights only change at the two optimizer steps)
         cx, bx = self.ctx, self.bctx

@@ -560,7 +560,7 @@ def main():
         step.pair_d_max_pixels = args.pair_d_max_pixels
     for kv in args.option:
         name, _, val = kv.partition("=")
-        step.ctx.set_option(name, int(val)); step.bctx.set_option(name, int(val))
+        step.set_option(name, int(val))
     run_dtype = step.dtype                             # the library's default when --dtype is not given
     # data-parallel runs: what the process group says it is, and what the two gradient exchanges of a step cost with nothing beside them
     # (the engine's own flat gradient buffers: D 61.4 MB, G 31.3 MB), before any step runs -- SURVEY 8e (2), (3)

@@ -124,6 +124,13 @@ def test_stage1_small_ragged_vs_oracle(amd, reuse):
     # second iteration keeps working on the same buffers (momentum path) and stays finite
     step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
     assert all(np.isfinite(v) for v in step.metrics().values())
+    # an option set on one of the engine's two contexts only is refused before anything is launched (a backward must run under its forward's options)
+    step.ctx.set_option("winograd_f4_forward", 0)
+    with pytest.raises(amd.AfiError):
+        step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
+    step.set_option("winograd_f4_forward", 0)             # ... and on both it is a legal setting
+    step.run_step([t.cuda() for t in lr_f], [t.cuda() for t in hr_f])
+    assert all(np.isfinite(v) for v in step.metrics().values())
 
 
 @pytest.mark.parametrize("pair", [0, 600, 10 ** 9])

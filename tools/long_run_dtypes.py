@@ -34,7 +34,7 @@ for dt in dts:
     eng = amd.Stage1Step(G, D, base_lr=1e-3, dtype=name)
     for kv in filter(None, opts.split(",")):
         k, _, v = kv.partition("=")
-        eng.ctx.set_option(k, int(v)); eng.bctx.set_option(k, int(v))
+        eng.set_option(k, int(v))
     rows = []
     for it in range(n_iter):
         lrs, hrs = batches[it % len(batches)]
