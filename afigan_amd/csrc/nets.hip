@@ -1189,7 +1189,8 @@ int afi_generator_fwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, afi_view_t xv
     float* const part_ = ws + l.o_part;
     const long long part_n_ = l.n_part;
     auto PG = [&](AfiPixGemm g, int b_rc) {
-        if (!g.Bimg && l.n_wino > 0 && wino_eligible(cx, g, b_rc)) return wino_run(cx, g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st);
+        // (value 16 of AFI_OPT_WINOGRAD_F4_FORWARD: the interpolator's own forwards on F(4x4) as well -- measured, off: DESIGN.md 9)
+        if (!g.Bimg && l.n_wino > 0 && wino_eligible(cx, g, b_rc)) return wino_run(cx, g, b_rc, ws + l.o_wino, l.n_wino, part_, part_n_, st, (afi_opt(cx, AFI_OPT_WINOGRAD_F4_FORWARD) & 16) != 0);
         g.partial = part_; g.partial_floats = part_n_;
         return afi_launch_pix_gemm(g, b_rc, st);
     };

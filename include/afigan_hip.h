@@ -123,7 +123,8 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                  0: F(2x2) everywhere.  Default 12 (blocks 1 and 2) since round 5.  Measured (D fwd+bwd at
                                                  P3 against fp64, relative L2 of dx / worst parameter gradient): torch's fp32 ops 0.9-1.0e-3 / 1.3-1.4e-3,
                                                  the exact-fp32 direct kernels 1.04e-3 / 1.49e-3, F(2x2) 6.4e-4 / 8.8e-4, blocks 1 + 2 1.09e-3 / 1.50e-3,
-                                                 every block 1.44e-3 / 1.89e-3; stage-1 step 80.8 / 72.4 / 71.5 ms for 0 / 12 / 1 */
+                                                 every block 1.44e-3 / 1.89e-3; stage-1 step 80.8 / 72.4 / 71.5 ms for 0 / 12 / 1.  Bit 16: the interpolator's own
+                                                 forwards too (off: 15x the deviation on its worst parameter gradient for 1 ms) */
 #define AFI_OPT_BN_STATS_FP64 3               /* 1 (default): BatchNorm batch statistics accumulated in fp64 (torch's CPU accumulation type) */
 #define AFI_OPT_D_WINOGRAD_MIN_PIXELS 4       /* 1024: discriminator calls of fewer pixels stay direct (values below 1024 act as 1024) */
 #define AFI_OPT_G_WINOGRAD_MIN_PIXELS 5       /* 2048: the same for a convolution of the interpolator */
