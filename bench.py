@@ -76,6 +76,7 @@ def parse():
                     help="feed seeded randn pyramids instead of running the R-50-FPN guide (debug only; not the headline config)")
     ap.add_argument("--pair-d-max-pixels", type=int, default=None, help="Stage1Step(pair_d_max_pixels=...): levels up to this many pixels run D(real) and D(fake) "
                     "of a phase as one call (per-batch BatchNorm statistics); default: the engine's")
+    ap.add_argument("--debug-nt-ablation", type=int, default=0, help="afi_debug_set_nt_ablation(N): kernel A/B switches of csrc/igemm.hip (tools only)")
     ap.add_argument("--one-stream", action="store_true", help="Stage1Step(overlap_d=False, overlap_g=False): every kernel alone on the chip (the "
                     "profiling passes of tools/prof_r03.sh: per-kernel durations comparable across rounds)")
     ap.add_argument("--no-guide-prefetch", action="store_true", help="run the frozen guide network's two forwards at the head of every step on the step's own "
@@ -556,6 +557,8 @@ def main():
     G.train(); D.train()
     step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype, overlap_d=not args.one_stream, overlap_g=not args.one_stream,
                           g_bwd_small_first=os.environ.get("AFI_BENCH_G_BWD_ORDER", "small-first") != "level-order")   # (A/B of the G-phase schedule)
+    if args.debug_nt_ablation:
+        _lib.load().afi_debug_set_nt_ablation(args.debug_nt_ablation)
     if args.pair_d_max_pixels is not None:
         step.pair_d_max_pixels = args.pair_d_max_pixels
     for kv in args.option:
