@@ -142,6 +142,11 @@ struct AfiWgradGemm {
 // f16x3 arithmetic of the batched Winograd GEMMs (afi_gemm_f16.h): where an operand's power-of-two scale comes from.  amax[plane * stride]
 // (device memory, written by the kernel that produced the operand) times cmul[plane] bounds the plane's largest magnitude.  stride = 0: one
 // value for all planes (the largest magnitude of the tensor the planes are a transform of).
+// interpolation points of the F(4x4, 3x3) / F(3x3, 4x4) transforms (csrc/winograd.hip): 1 = {0, 1, -1, 1/2, -2, inf} (the product), 0 = the
+// textbook {0, +-1, +-2, inf} (A/B builds).  One definition: the transforms AND the plane bounds of afi_f16_bound (igemm.hip) follow it.
+#ifndef AFI_WINO4_POINTS
+#define AFI_WINO4_POINTS 1
+#endif
 struct AfiF16Bound { const float* amax; int stride; int pad_; float cmul[36]; };
 
 // one bias-gradient problem of afi_launch_colsum_group: db[c] += alpha * sum_rows g[row*ld + c], c < C

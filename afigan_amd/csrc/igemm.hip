@@ -861,10 +861,16 @@ AfiF16Bound afi_f16_bound(const float* amax, int kind) {
     AfiF16Bound b;
     b.amax = amax; b.stride = kind == 0 ? 1 : 0; b.pad_ = 0;
     // (absolute row sums of B^T, G', G for the interpolation points of csrc/winograd.hip, AFI_WINO4_POINTS = 1: {0, 1, -1, 1/2, -2, inf})
+#if AFI_WINO4_POINTS == 1
     static const float r_in4[6] = {7.f, 5.f, 5.f, 6.f, 3.f, 7.f};
     static const float r_dy4[6] = {1.f, 4.f / 3.f, 4.f / 3.f, 2.f, 1.f, 1.f};
-    static const float r_w2[4] = {1.f, 1.5f, 1.5f, 1.f};
     static const float r_w4[6] = {1.f, 1.f, 1.f, 28.f / 15.f, 7.f / 15.f, 1.f};
+#else
+    static const float r_in4[6] = {10.f, 10.f, 10.f, 6.f, 6.f, 10.f};
+    static const float r_dy4[6] = {0.25f, 4.f / 6.f, 4.f / 6.f, 15.f / 24.f, 15.f / 24.f, 1.f};
+    static const float r_w4[6] = {0.25f, 0.5f, 0.5f, 7.f / 24.f, 7.f / 24.f, 1.f};
+#endif
+    static const float r_w2[4] = {1.f, 1.5f, 1.5f, 1.f};
     for (int a = 0; a < 36; ++a) {
         float c = 1.f;
         if (kind == 1) c = 4.f;

@@ -443,8 +443,8 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     const int nph = g.nKphase;                             // 1, or 4 phase views of a pixel-shuffled A (conv-transpose data gradient)
     const int K = g.Ck * nph, Nc = g.Ncols;
     if (ws_floats < wino_ws_floats(g.N, g.H, g.W, K, Nc)) return AFI_ERR_WORKSPACE;
-    // data gradients take F(4x4,3x3) (their error does not decide a LeakyReLU mask); forwards stay on F(2x2,3x3)
-    // fwd_f4: a forward whose activations feed no backward pass (its masks decide no gradient) may take F(4x4) too
+    // data gradients take F(4x4,3x3) (their error does not decide a LeakyReLU mask); forwards take F(2x2,3x3) unless the caller says
+    // fwd_f4: a forward whose activations feed no backward pass (its masks decide no gradient), or one of the blocks AFI_OPT_WINOGRAD_F4_FORWARD names
     // bf16 operands (2^-9) cannot carry the F(4x4) transforms (their 1/24 .. 8 coefficient range costs two more digits: 3 % error);
     // split-bf16 (2^-17) can
     const int dtype = cx ? cx->dtype : afi_default_dtype();

@@ -457,12 +457,13 @@ int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hi
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
-// ================================================================ F(4x4, 3x3) / F(3x3, 4x4): data and weight gradients
+// ================================================================ F(4x4, 3x3) / F(3x3, 4x4): data and weight gradients, forwards that feed no
+// backward, and (round 5) the forwards of the discriminator's blocks the caller selects (nets.hip: AFI_OPT_WINOGRAD_F4_FORWARD)
 // 36 products per (cin, cout) pair and 4x4 output tile instead of 144 (4x fewer matrix-core FLOPs than direct, 1.78x fewer than
-// F(2x2)) and 2.25x (not 4x) transform traffic.  Interpolation points {0, +-1, +-2, inf}: the fp32 result is accurate to ~3e-5
-// of the output scale (vs ~1e-6 for F(2x2)), which is fine for gradients but would flip LeakyReLU masks behind a BatchNorm
-// ~30x more often than fp32 rounding does -- so the FORWARD convs stay on F(2x2) and only the two backward GEMMs, whose
-// errors do not pass through a mask decision, use this form.
+// F(2x2)) and 2.25x (not 4x) transform traffic.  Its fp32 result is less accurate than F(2x2)'s (1e-6 of the output scale): that is
+// nothing for gradients, but a forward whose output decides LeakyReLU masks behind a BatchNorm shows it as flipped masks, which is why the
+// blocks that take it are chosen by measurement and why the interpolation points below replaced the textbook ones.
+// Textbook points {0, +-1, +-2, inf} (AFI_WINO4_POINTS = 0, kept for A/B):
 //   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 //   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]           (weights, data gradient)
 //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]                                 (4x4 outputs)
@@ -476,9 +477,7 @@ int afi_launch_wino_dw(const float* dU, float* dW, int O, int I, float alpha, hi
 //   A^T = [1 1 1 1 1 0; 0 1 -1 1/2 -2 0; 0 1 1 1/4 4 0; 0 1 -1 1/8 -8 1]
 //   G'  = [1 0 0 0; 1/3(1 1 1 1); -1/3(1 -1 1 -1); -16/15(1 1/2 1/4 1/8); 1/15(1 -2 4 -8); 0 0 0 1]
 //   A'^T= [1 1 1 1 1 0; 0 1 -1 1/2 -2 0; 0 1 1 1/4 4 1]
-#ifndef AFI_WINO4_POINTS
-#define AFI_WINO4_POINTS 1
-#endif
+// (AFI_WINO4_POINTS is defined in afi_common.h: igemm.hip's plane bounds follow the same choice)
 template <typename T>
 __device__ __forceinline__ void wino4_bt(T& d0, T& d1, T& d2, T& d3, T& d4, T& d5) {      // in place: B^T d
 #if AFI_WINO4_POINTS == 1

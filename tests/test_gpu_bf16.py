@@ -251,3 +251,36 @@ def test_dtype_api_guards(amd):
     cx.set_dtype("fp32")
     assert _lib.load().afi_ctx_get_compute_dtype(cx.handle) == 0
     assert _lib.load().afi_ctx_set_compute_dtype(None, 0) == 1
+
+
+@pytest.mark.parametrize("plane", [(0, 0), (0, 5), (3, 3), (5, 1)])
+def test_f16x3_plane_bounds_hold_on_the_worst_patch(amd, plane):
+    """f16x3 scales every F(4x4) input plane from a BOUND -- the source tensor's largest magnitude times the product of the absolute row sums of
+    B^T (csrc/igemm.hip: afi_f16_bound) -- not from a measured maximum.  A 6 x 6 patch of +-1 whose signs follow rows r and c of B^T drives plane
+    (r, c) of its tile to exactly that bound (49 x the source maximum for (0, 0)); with a bound too small by 2x the fp16 piece would overflow and the
+    conv would come back non-finite or wrong.  Checked against the direct fp32 kernels on the whole map."""
+    import numpy as np
+    BT = np.array([[1, -1.5, -2, 1.5, 1, 0], [0, -1, 0.5, 2.5, 1, 0], [0, 1, -2.5, 0.5, 1, 0], [0, -2, -1, 2, 1, 0], [0, 0.5, -1, -0.5, 1, 0],
+                   [0, 1, -1.5, -2, 1.5, 1]])                # (csrc/winograd.hip, AFI_WINO4_POINTS = 1)
+    r, c = plane
+    sgn = lambda v: np.where(v < 0, -1.0, 1.0)
+    patch = np.outer(sgn(BT[r]), sgn(BT[c]))                 # zeros of B^T count as +1: they do not enter the plane
+    Ci, Co, H, W = 128, 128, 96, 96                          # 9216 pixels: the F(4x4) tiling
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand((1, Ci, H, W), generator=g) * 2 - 1) * 0.25
+    for ty, tx in ((1, 1), (5, 9), (20, 3)):                 # tile (ty, tx) reads rows 4 ty - 1 .. 4 ty + 4
+        x[0, :, 4 * ty - 1:4 * ty + 5, 4 * tx - 1:4 * tx + 5] = torch.from_numpy(patch).float()
+    w = torch.randn((Co, Ci, 3, 3), generator=g) / (3 * Ci ** 0.5)
+    b = torch.randn((Co,), generator=g)
+    xc, wc = amd.ops.pixel_major(x.cuda()), amd.ops.ohwi(w.cuda())
+    with amd.compute_dtype("f16x3"):
+        got = amd.ops.conv3x3_wino_infer(xc, wc, b.cuda())
+    cx = amd._lib.current_ctx()
+    cx.set_option("winograd", 0)
+    try:
+        ref = amd.ops.conv3x3_fwd(xc, wc, b.cuda())
+    finally:
+        cx.set_option("winograd", 1)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= 2e-5, err                                  # (F(4x4) rounding; an overflowed plane gives O(1) or inf)
