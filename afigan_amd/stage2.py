@@ -79,7 +79,7 @@ class Stage2Adversarial:
     def __init__(self, D: Discriminator, base_lr: float = 1e-2, momentum: float = 0.9, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, lr_steps: Sequence[int] = (120000, 160000), lr_gamma: float = 0.1,
                  warmup_factor: float = 1e-3, warmup_iters: int = 1000, first_level: int = 2, process_group=None, dtype=None,
-                 overlap_d: bool = True, weight_cache: bool = True):
+                 overlap_d: bool = True, weight_cache: bool = True, pair_d_max_pixels: int = 40000):
         self.D, self.dnet = D, D.Discriminators[0]
         self.base_lr, self.momentum = base_lr, momentum
         self.sched = (tuple(lr_steps), lr_gamma, warmup_factor, warmup_iters)
@@ -98,6 +98,8 @@ class Stage2Adversarial:
         self._helper._lib, self._helper._buf = _lib.load(), {}
         self._helper.ctx, self._helper.bctx = _lib.Ctx(dtype), _lib.Ctx(dtype)     # forward / backward stream (stage1.py)
         self._helper.weight_cache = weight_cache
+        # levels up to this many pixels (N*h*w): D(real) and D(fake) of a step as ONE call with per-batch BatchNorm statistics (stage1.py)
+        self._helper.pair_d_max_pixels = pair_d_max_pixels
         self.overlap_d = overlap_d                               # forwards on the caller's stream, backwards on a second one (stage1.py)
         self.iter = 0
         self.losses = None
@@ -133,21 +135,26 @@ class Stage2Adversarial:
             real = ops.pixel_major(nearest_half(ops.pixel_major(g.detach())))
             fake = ops.pixel_major(f.detach())
             hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
-            for x, target in ((real[:, :, :hh, :ww], 1.0), (fake[:, :, :hh, :ww], 0.0)):
-                key = f"d_ws_{i}_{int(target)}" if overlap else "d_ws"          # (overlap: a workspace lives until its backward has run)
-                logits, dws = h._d_forward(x, key)
-                dz = h._scratch("dlogits" + (key if overlap else ""), logits.numel(), dev)
-                call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), x.shape[0] * hh * ww, target, 1.0,
-                     C.c_void_p(self.losses.data_ptr() + 4 * i), 1.0, C.c_void_p(dz.data_ptr()), ops.stream_ptr())
+            rc, fc = real[:, :, :hh, :ww], fake[:, :, :hh, :ww]
+            paired = h._paired(rc)
+            calls = ((h._pair(i, rc, fc), (1.0, 0.0)),) if paired else ((rc, (1.0,)), (fc, (0.0,)))      # :306-318 (real, then fake)
+            for x, targets in calls:
+                key = f"d_ws_{i}_{'p' if paired else int(targets[0])}" if overlap else "d_ws"       # (overlap: a workspace lives until its backward has run)
+                logits, dws = h._d_forward(x, key, paired=paired)
+                half = rc.shape[0] * hh * ww
+                dz = h._scratch("dlogits" + (key if overlap else ""), half * len(targets), dev)
+                for k, target in enumerate(targets):
+                    call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr() + 4 * k * half), half, target, 1.0,
+                         C.c_void_p(self.losses.data_ptr() + 4 * i), 1.0, C.c_void_p(dz.data_ptr() + 4 * k * half), ops.stream_ptr())
                 if overlap:
                     if self._bstream is None:
                         self._bstream = torch.cuda.Stream(device=dev)
                     self._bstream.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(self._bstream):
                         x.record_stream(self._bstream)
-                        h._d_backward(x, dws, dz)
+                        h._d_backward(x, dws, dz, paired=paired)
                 else:
-                    h._d_backward(x, dws, dz)
+                    h._d_backward(x, dws, dz, paired=paired)
 
     def g_losses(self, guide_feats: Sequence[torch.Tensor], fpn_feats: Sequence[torch.Tensor]) -> Dict[str, torch.Tensor]:
         """stage2_trainer.py:344-364: {g_loss_p{lv}: 1e-3 * adv + content}; `content` carries gradient into fpn_feats."""
@@ -160,10 +167,15 @@ class Stage2Adversarial:
                 fake = ops.pixel_major(f.detach())
                 hh, ww = min(real.shape[2], fake.shape[2]), min(real.shape[3], fake.shape[3])
                 adv = torch.zeros(1, device=f.device)
-                logits, _ = h._d_forward(fake[:, :, :hh, :ww], "d_ws", backward_follows=False)   # fake first, then real (:350-354)
+                fc, rc = fake[:, :, :hh, :ww], real[:, :, :hh, :ww]
+                if h._paired(fc):                                                            # fake first, then real (:350-354), one call
+                    logits, _ = h._d_forward(h._pair(i, fc, rc), "d_ws", backward_follows=False, paired=True)
+                else:
+                    logits, _ = h._d_forward(fc, "d_ws", backward_follows=False)
                 call("afi_bce_logits_fwd_bwd", C.c_void_p(logits.data_ptr()), f.shape[0] * hh * ww, 1.0, 1.0, C.c_void_p(adv.data_ptr()),
                      0.0, C.c_void_p(None), ops.stream_ptr())
-                h._d_forward(real[:, :, :hh, :ww], "d_ws", backward_follows=False)           # only its BN side effects matter (Q2)
+                if not h._paired(fc):
+                    h._d_forward(rc, "d_ws", backward_follows=False, stats_only=True)       # only its BN side effects matter (Q2)
                 content = l1_loss_common(f, real)
                 out[f"g_loss_p{lv}"] = adv.reshape(()) * 1e-3 + content
         return out
