@@ -820,7 +820,7 @@ def main():
     # SURVEY 8(d)'s algorithmic (direct-convolution) FLOP count of the step over wall time and peak.  It can pass 1: the big 3x3 convs
     # run in Winograd form, which executes 2.25x (F(2x2,3x3)) / 4x (F(4x4,3x3)) fewer multiplies than the count assumes
     roofline["algorithmic_over_peak"] = flop_img * B * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS
-    roofline["winograd_multiply_reduction"] = "2.25x F(2x2,3x3) forwards with a backward behind them, 4x F(4x4,3x3) data / weight gradients and forwards without one"
+    roofline["winograd_multiply_reduction"] = "4x F(4x4,3x3): data / weight gradients, forwards without a backward, the discriminator's blocks 1 and 2; 2.25x F(2x2,3x3): the other forwards with a backward behind them"
     line = {
         "metric": "stage1_G+D_step_images_per_s", "value": n_img / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -839,7 +839,7 @@ def main():
         # which EXECUTES 2.25x / 4x fewer products than this count, so the ratio can pass 1; `roofline` below is in executed products of
         # the dominant kernel (the batched Winograd GEMM) against that kernel's own roof.
         "step_algorithmic_tflops_over_fp32_mfma_peak": flop_img * B * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-        "conv_algorithm": "Winograd F(2x2,3x3) forwards that a backward follows, F(4x4,3x3) / F(3x3,4x4) data and weight gradients and forward-only passes, for every 3x3 conv with >= 128 channels on both sides and >= 1024 pixels (fp32 planes; their batched GEMMs in the arithmetic named by `dtype`); direct implicit GEMM on the fp32 MFMA elsewhere",
+        "conv_algorithm": "Winograd F(4x4,3x3) / F(3x3,4x4) (interpolation points {0, 1, -1, 1/2, -2, inf}) for data and weight gradients, forward-only passes and the discriminator's forwards of blocks 1 and 2 (winograd_f4_forward = 12: gradient deviation from fp64 equal to the exact-fp32 direct kernels'); F(2x2,3x3) for the other forwards a backward follows (the discriminator's block 0, the interpolator); for every 3x3 conv with >= 128 channels on both sides and >= 1024 pixels (planes fp32, or split into two fp16 pieces by the transforms under f16x3; their batched GEMMs in the arithmetic named by `dtype`); direct implicit GEMM on the fp32 MFMA elsewhere",
         "roofline": roofline,
         # opt-in arithmetic of the big convolutions, same engine / inputs / K (afi_ctx_set_compute_dtype; tolerances: tests/test_gpu_bf16.py).
         # Not the headline: the reference is fp32-only.  Their GEMM kernels are priced against the dense bf16 MFMA peak.
