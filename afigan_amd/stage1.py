@@ -75,13 +75,21 @@ class GuidePrefetcher:
     prefetch stream, so the caching allocator must not hand their blocks to a new caller-stream allocation before the guide forward is done.
     ``submit`` therefore (1) marks every tensor passed as ``inputs`` and every tensor found in ``fn``'s closure cells / ``functools.partial``
     arguments with ``record_stream(prefetch stream)`` and (2) keeps references to them until ``take()``; a caller whose ``fn`` reaches its
-    inputs some other way (a global, an attribute) passes them explicitly.  The caller may drop its own references right after ``submit``."""
+    inputs some other way (a global, an attribute) passes them explicitly.  The caller may drop its own references right after ``submit``.
 
-    def __init__(self, device=None):
+    Library state: ``fn`` runs under the prefetcher's OWN ``afi_ctx_t`` (``self.ctx``, arithmetic ``dtype``), never under the
+    context that happens to be current where ``submit`` is called -- a context serves one stream at a time (include/afigan_hip.h), and
+    ``submit`` is typically called from ``Stage1Step.on_d_level``, i.e. while the engine's forward context, with the phase's cache of
+    transformed weights registered on it, is the active one.  Guide work placed in that cache would be overwritten by the G phase's refill
+    on the step's stream while the prefetch stream still reads it."""
+
+    def __init__(self, device=None, dtype=None):
         # (stream priorities measured: the step's streams on the high priority with this one on the default, 82.9 vs 82.0 ms per step -- the
         #  library's own side streams then starve; nothing to gain)
         self.stream = torch.cuda.Stream(device=device)
         self._pending = None
+        with torch.cuda.device(self.stream.device):
+            self.ctx = _lib.Ctx(dtype)
 
     @staticmethod
     def _tensors(o):
@@ -117,7 +125,7 @@ class GuidePrefetcher:
         self.stream.wait_stream(torch.cuda.current_stream())
         for t in held:
             t.record_stream(self.stream)                    # read by the prefetch stream: not recyclable before its work is done
-        with torch.cuda.stream(self.stream), torch.no_grad():
+        with torch.cuda.stream(self.stream), torch.no_grad(), _lib.use_ctx(self.ctx):
             out = fn()
         self._pending = (out, held)                         # the references live until take()
 
@@ -519,16 +527,21 @@ class Stage1Step:
         self._pending_work = []
 
     def comm_exposure(self):
-        """After a step run with ``measure_comm = True``: {"D": ms, "G": ms} the consuming stream spent waiting for each exchange (device
-        time between two events around the wait; under gloo, where the HOST waits, the host time of that wait), and the sum."""
+        """After a step run with ``measure_comm = True``: {"D": ms, "G": ms, "total": ms} the CONSUMING STREAM spent waiting for each exchange
+        (device time between two events either side of the wait), and under ``"host_blocked_ms"`` the time the HOST spent inside the wait.
+        Under nccl / RCCL the host does not block (``wait`` only orders streams) and the device figure is the exposure.  Under gloo ``wait``
+        blocks the host until the exchange is done, and that exchange cannot start before the device has caught up with everything the
+        host had queued ahead of it (the whole D phase): the host figure there measures the host's LEAD over the device plus the exchange
+        (182 ms against an 18.8 ms exchange in round 5's two-ranks-one-GPU rehearsal), not an exposure -- it is reported apart and never
+        folded into the device figure."""
         torch.cuda.synchronize()
-        out = {}
+        out, host = {}, {}
         for rec in self._comm_events:
-            ms = rec[1].elapsed_time(rec[2])
-            if len(rec) > 3 and self.backend != "nccl":
-                ms = max(ms, rec[3])
-            out[rec[0]] = out.get(rec[0], 0.0) + ms
+            out[rec[0]] = out.get(rec[0], 0.0) + rec[1].elapsed_time(rec[2])
+            if len(rec) > 3:
+                host[rec[0]] = host.get(rec[0], 0.0) + rec[3]
         out["total"] = sum(out.values())
+        out["host_blocked_ms"] = host
         return out
 
     # ------------------------------------------------------------------------------------------------ the step
@@ -556,6 +569,7 @@ class Stage1Step:
         self._comm_events = []
         # transformed conv weights are shared by the calls of a phase (weights only change at the two optimizer steps)
         cx, bx = self.ctx, self.bctx
+        self._outer_ctx = _lib.current_ctx()               # what the caller's own calls go to: the hooks run under it, not under cx / bx
         with _lib.use_ctx(cx):
             if self.weight_cache:
                 for c_, key in ((cx, "wino_wcache"), (bx, "wino_wcache_b")):
@@ -598,7 +612,10 @@ class Stage1Step:
         trs = []
         for i in range(nlev):
             if self.on_d_level is not None:
-                self.on_d_level(i)
+                # the caller's hook queues the CALLER's work (possibly on another stream): under the context the caller had, never under the
+                # engine's, whose phase weight cache and op scratch belong to the step's own streams
+                with _lib.use_ctx(self._outer_ctx):
+                    self.on_d_level(i)
             tr, ws = self._g_forward(i, lrs[i], "g_ws")                              # :339-341 (.detach(): no graph anyway)
             trs.append((tr, ws))
             tr_c, hr_c = self._crop_pair(tr, hrs[i])                                  # :345-346
@@ -701,17 +718,27 @@ class Stage1Step:
         self._allreduce_finish(self.g_opt, g_work)
         self.g_opt.step(lr_now, self.momentum, gscale=1.0 / self.world)              # :433
 
-    def metrics(self, check_finite: bool = True, reduce: bool = False) -> Dict[str, float]:
+    def metrics(self, check_finite: bool = True, reduce: bool = False, data_time: Optional[float] = None) -> Dict[str, float]:
         """Loss values of the last step (one device sync).  g_loss_p = 1e-3*adv + content (stage1_trainer.py:411).
         ``reduce=True`` in a data-parallel run: the MEAN over the ranks -- the reference's ``_write_metrics`` gathers every rank's dict by
         pickle on every iteration and averages on rank 0 (stage1_trainer.py:453-492); here it is ONE all-reduce of the 3-per-level loss
         vector, whenever the caller asks (every logging period, not every iteration), and every rank gets the averages.  Collective:
-        all ranks must call it together."""
+        all ranks must call it together.
+
+        The names ``_write_metrics`` puts into the event storage are all here: the per-level losses, ``total_loss`` -- the reference writes
+        it twice per iteration, the sum of the d_loss_p* after the D phase (:363-368) and the sum of the g_loss_p* after the G phase
+        (:413-420); the storage keeps the later one, so ``total_loss`` is the G-phase sum and the D-phase sum is ``d_total_loss`` -- and, when
+        the caller passes the seconds its loader took (``data_time``, :315), ``data_time`` / ``G_data_time`` / ``D_data_time``: the MAXIMUM over
+        the ranks under ``reduce`` (:468-483), not the mean."""
         vec = self.losses.detach()
         if reduce and self.distributed:
             vec = vec.clone()
             torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM, group=self.pg)
             vec = vec / self.world
+            if data_time is not None:
+                dt = torch.tensor([float(data_time)], device=vec.device)
+                torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX, group=self.pg)
+                data_time = float(dt.item())
         vals = vec.cpu().tolist()
         out = dict(zip(self._loss_names, vals))
         for k in list(out):
@@ -720,4 +747,8 @@ class Stage1Step:
                 out[f"g_loss_p{lv}"] = out[k] * 1e-3 + out[f"content_loss_p{lv}"]
         if check_finite and not all(np.isfinite(v) for v in out.values()):          # _detect_anomaly (:445-451)
             raise FloatingPointError(f"Loss became infinite or NaN at iteration={self.iter}!\nloss_dict = {out}")
+        out["d_total_loss"] = sum(v for k, v in out.items() if k.startswith("d_loss_p"))
+        out["total_loss"] = sum(v for k, v in out.items() if k.startswith("g_loss_p"))
+        if data_time is not None:
+            out["data_time"] = out["G_data_time"] = out["D_data_time"] = float(data_time)
         return out

@@ -84,6 +84,9 @@ def parse():
                     "afigan_amd.GuidePrefetcher; one guide pair and one training step per timed step either way)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="afi_ctx_set_option on the engine's contexts (A/B runs), "
                     "e.g. --option g_batch_growth_grads=0; names: afigan_amd._lib.OPTIONS")
+    ap.add_argument("--dist-world-1", action="store_true", help="--gpus 1 only: run the distributed code path anyway, on a ONE-rank process group of "
+                    "--backend (a real RCCL communicator under nccl): broadcast, both all-reduces, the `comm` object and the overlap_comm A/B leg "
+                    "execute on a one-GPU box.  Not the headline configuration")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="launch path only (no GPU work, no metric): spawn / rendezvous / all-reduce / invariant checks of the N-rank job with "
                          "CPU tensors; what tests/test_host_logic.py runs with --gpus 2 --backend gloo in a container without a GPU")
@@ -135,36 +138,107 @@ def spawn_ranks(args):
     raise SystemExit(rc)
 
 
+def allreduce_alone(dist, torch, bufs, dev, world, reps=5):
+    """Each gradient exchange of a step with nothing beside it: {tag: {bytes, ms (max over ranks), bus_gb_per_s}} for the flat buffers
+    in `bufs`.  Zeroes the buffers afterwards.  Used by the real run (device buffers) and by --rehearse-launch
+    (CPU buffers of the same sizes)."""
+    cuda = dev is not None and dev.type == "cuda"
+    out = {}
+    for tag, buf in bufs.items():
+        for _ in range(2):
+            dist.all_reduce(buf)
+        if cuda:
+            torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        if cuda:
+            torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        tm = torch.tensor([ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        nbytes = buf.numel() * 4
+        out[tag] = {"bytes": nbytes, "ms": round(float(tm.item()), 4),
+                    "bus_gb_per_s": round(2.0 * (world - 1) / world * nbytes / (float(tm.item()) * 1e-3) / 1e9, 2)}
+        buf.zero_()
+    return out
+
+
+def identical_across_ranks(dist, torch, tensors):
+    """Data-parallel invariant (stage1_trainer.py:80-89 + the all-reduce): the same values on every rank.  One fp64 checksum per
+    tensor, MIN and MAX over the ranks compared bit for bit."""
+    chk = torch.stack([t.detach().reshape(-1).double().sum() for t in tensors])
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
+def per_rank_rates(dist, torch, images, seconds, dev, world):
+    """[images/s of rank 0, rank 1, ...] from every rank's own clock around the timed steps (the job's `value` uses the MAX time)."""
+    mine = torch.tensor([images / seconds], device=dev, dtype=torch.float64)
+    got = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    return [round(float(t.item()), 3) for t in got]
+
+
+D_GRAD_FLOATS, G_GRAD_FLOATS = 15_352_324, 7_834_624        # flat gradient buffers of the reference-width D and G (61.4 MB, 31.3 MB)
+
+
 def rehearse_launch(args, world, rank):
-    """--rehearse-launch: everything bench.py does AROUND the GPU work for an N-rank job -- rendezvous, barrier, an all-reduce(SUM) of a
-    flat buffer the size class of the real exchange, MAX-over-ranks timing, the cross-rank identity check, one JSON line from rank 0 --
-    on CPU tensors.  Reports no metric."""
+    """--rehearse-launch: everything bench.py does AROUND the GPU work for an N-rank job, on CPU tensors over gloo: rendezvous, the `comm`
+    object (backend, world size as the group reports it, the two exchanges alone on buffers of the real sizes: the same
+    `allreduce_alone` the real run calls), K "steps" whose only content is the two all-reduces of a step in the engine's order (blocking,
+    or asynchronous and waited for where the engine waits: `--overlap-comm`), barrier + MAX-over-ranks timing, per-rank images/s, the
+    cross-rank identity check (`identical_across_ranks`, as the real run), ONE JSON line from rank 0.  Reports no metric."""
     import torch
     import torch.distributed as dist
     if os.environ.get("AFI_BENCH_REHEARSE_FAIL_RANK") == str(rank):   # fault injection for the test of the failure path
         raise SystemExit(3)
+    B = args.batch_per_gpu
+    comm, same, rates, ok = None, None, None, True
+    params = [torch.full((1 << 12,), 1.0), torch.full((1 << 10,), 2.0)]        # "G" and "D": rank 0's values everywhere after the broadcast
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    g = torch.full((1 << 16,), float(rank + 1))
-    t0 = time.perf_counter()
-    if world > 1:
+        for p_ in params:
+            p_.add_(float(rank))                                   # different per rank before the broadcast (DDP ctor semantics: rank 0's win)
+            dist.broadcast(p_, src=0)
+        small = os.environ.get("AFI_BENCH_REHEARSE_SMALL", "1") != "0"       # 1/64 of the real sizes: 8 ranks on this container's 8 cores
+        bufs = {"D": torch.zeros(D_GRAD_FLOATS // (64 if small else 1)), "G": torch.zeros(G_GRAD_FLOATS // (64 if small else 1))}
+        overlap = bool(args.overlap_comm) if args.overlap_comm is not None else True        # (gloo: the engine's default is on)
+        comm = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(), "rank0_device": "cpu (rehearsal)",
+                "overlap_comm": overlap, "allreduce_alone": allreduce_alone(dist, torch, bufs, None, world, reps=2)}
         dist.barrier()
-        dist.all_reduce(g)                                         # SUM, as Stage1Step does on the flat gradient buffers
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    ok = bool((g == world * (world + 1) / 2).all())
-    same = None
-    if world > 1:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            for tag in ("D", "G"):
+                bufs[tag].fill_(float(rank + 1))
+            wd = dist.all_reduce(bufs["D"], async_op=overlap)      # D's exchange behind the D phase ...
+            wg = dist.all_reduce(bufs["G"], async_op=overlap)      # ... G's behind G's last backward pass, issued before D's is waited for
+            for w_ in (wd, wg):
+                if w_ is not None:
+                    w_.wait()
+            ok = ok and all(bool((bufs[tag] == world * (world + 1) / 2).all()) for tag in ("D", "G"))
+            for p_, tag in zip(params, ("G", "D")):
+                p_.sub_(1e-3 / world * bufs[tag][:p_.numel()])     # "SGD" on the averaged gradient: identical on every rank
+        mine = time.perf_counter() - t0
+        dist.barrier()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        lo, hi = g[:4].double().clone(), g[:4].double().clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        same = bool(torch.equal(lo, hi))
+        rates = per_rank_rates(dist, torch, B * args.steps, mine, None, world)
+        same = identical_across_ranks(dist, torch, params)
         dist.barrier()
         dist.destroy_process_group()
+        elapsed = float(el.item())
+    else:
+        elapsed = 0.0
     if rank == 0:
-        print(json.dumps({"metric": "launch_rehearsal (no GPU work, no measurement)", "value": None, "n_gpus": world, "backend": "gloo" if world > 1 else None,
-                          "allreduce_sum_ok": ok, "params_identical_across_ranks": same, "max_over_ranks_s": float(el.item()),
+        print(json.dumps({"metric": "launch_rehearsal (no GPU work, no measurement)", "value": None, "n_gpus": world, "steps": args.steps,
+                          "backend": "gloo" if world > 1 else None, "comm": comm, "allreduce_sum_ok": ok,
+                          "params_identical_across_ranks": same, "per_rank_images_per_s": rates, "max_over_ranks_s": elapsed,
+                          "config": {"global_batch": world * B, "parallelism": f"dp{world}"},
                           "spawned_by_bench": os.environ.get("AFI_BENCH_SPAWNED") == "1"}), flush=True)
     raise SystemExit(0 if ok and same is not False else 1)
 
@@ -533,9 +607,10 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_world_1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29611")         # (set by every launcher; only --dist-world-1 without one gets here unset)
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -556,6 +631,7 @@ def main():
     D = amd.Discriminator().to(dev)
     G.train(); D.train()
     step = amd.Stage1Step(G, D, base_lr=1e-3, dtype=args.dtype, overlap_d=not args.one_stream, overlap_g=not args.one_stream,
+                          distributed=(True if args.dist_world_1 else None),
                           g_bwd_small_first=os.environ.get("AFI_BENCH_G_BWD_ORDER", "small-first") != "level-order")   # (A/B of the G-phase schedule)
     if args.debug_nt_ablation:
         _lib.load().afi_debug_set_nt_ablation(args.debug_nt_ablation)
@@ -572,23 +648,8 @@ def main():
         if args.overlap_comm is not None:
             step.overlap_comm = bool(args.overlap_comm)
         comm = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(), "rank0_device": torch.cuda.get_device_name(dev),
-                "overlap_comm": bool(step.overlap_comm), "allreduce_alone": {}}
-        for tag, buf in (("D", step.d_opt.flat_grad), ("G", step.g_opt.flat_grad)):
-            for _ in range(2):
-                dist.all_reduce(buf)
-            torch.cuda.synchronize(); dist.barrier()
-            t0 = time.perf_counter()
-            reps = 5
-            for _ in range(reps):
-                dist.all_reduce(buf)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / reps * 1e3
-            tm = torch.tensor([ms], device=dev, dtype=torch.float64)
-            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-            nbytes = buf.numel() * 4
-            comm["allreduce_alone"][tag] = {"bytes": nbytes, "ms": round(float(tm.item()), 4),
-                                            "bus_gb_per_s": round(2.0 * (world - 1) / world * nbytes / (float(tm.item()) * 1e-3) / 1e9, 2)}
-            buf.zero_()
+                "overlap_comm": bool(step.overlap_comm),
+                "allreduce_alone": allreduce_alone(dist, torch, {"D": step.d_opt.flat_grad, "G": step.g_opt.flat_grad}, dev, world)}
         log(f"process group: backend {comm['backend']}, world {comm['world_size_reported']}; all-reduce alone: " +
             ", ".join(f"{k} {v['ms']:.3f} ms ({v['bus_gb_per_s']} GB/s bus)" for k, v in comm["allreduce_alone"].items()))
     guide = None if args.synthetic_pyramid else GuideR50FPN().to(dev)
@@ -670,6 +731,7 @@ def main():
     # step launches its own pair first and the last one launches none
     for i in range(args.steps):
         one_step(last=(args.warmup == 0 and i == args.steps - 1))
+    elapsed_rank = time.perf_counter() - t0               # this rank's own steps (before the closing barrier): per_rank_images_per_s
     sync()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {args.steps} steps in {elapsed:.3f} s")
@@ -686,13 +748,38 @@ def main():
         profiled_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
         if dist is not None:
             ex = step.comm_exposure()
-            te = torch.tensor([ex.get("D", 0.0), ex.get("G", 0.0)], device=dev, dtype=torch.float64)
+            hb = ex.get("host_blocked_ms", {})
+            te = torch.tensor([ex.get("D", 0.0), ex.get("G", 0.0), hb.get("D", 0.0), hb.get("G", 0.0)], device=dev, dtype=torch.float64)
             dist.all_reduce(te, op=dist.ReduceOp.MAX)
-            comm["comm_exposed_ms"] = {"D": round(float(te[0]), 4), "G": round(float(te[1]), 4), "total": round(float(te.sum()), 4),
-                                       "note": "time the consuming stream waited for each gradient exchange in the last step of the profiled repeat (max over ranks); "
-                                               "blocking exchanges (overlap_comm false) are exposed whole"}
+            comm["comm_exposed_ms"] = {"D": round(float(te[0]), 4), "G": round(float(te[1]), 4), "total": round(float(te[:2].sum()), 4),
+                                       "note": "device time the consuming stream waited for each gradient exchange in the last step of the "
+                                               "profiled repeat (events either side of the wait; max over ranks); blocking exchanges "
+                                               "(overlap_comm false) are exposed whole"}
+            comm["host_blocked_ms"] = {"D": round(float(te[2]), 4), "G": round(float(te[3]), 4),
+                                       "note": "host time inside the wait: ~0 under nccl (the wait orders streams); under gloo the host's lead "
+                                               "over the device plus the exchange -- not an exposure"}
         step.measure_comm = False
         log(f"profiled repeat done: {profiled_ms_per_step:.2f} ms/step with the event brackets on")
+    if dist is not None and os.environ.get("AFI_BENCH_OVERLAP_AB", "1") != "0":
+        # the other setting of overlap_comm on the same engine, same inputs, same K (never the headline): the first RCCL run measures both
+        other = not step.overlap_comm
+        ab = {("overlapped" if step.overlap_comm else "blocking") + "_ms_per_step": round(elapsed / args.steps * 1e3, 3)}
+        try:
+            step.overlap_comm = other
+            one_step(); sync()
+            t2 = time.perf_counter()
+            for i in range(args.steps):
+                one_step(last=(args.warmup == 0 and i == args.steps - 1))
+            sync()
+            tm = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            ab[("overlapped" if other else "blocking") + "_ms_per_step"] = round(float(tm.item()) / args.steps * 1e3, 3)
+        except Exception as e:                             # (recorded, not fatal: the headline is already measured)
+            ab["error"] = f"{type(e).__name__}: {e}"[:300]
+        finally:
+            step.overlap_comm = not other
+        comm["overlap_ab"] = ab
+        log(f"overlap_comm A/B: {ab}")
     if rank == 0:
         lib.afi_profile_enable(0)
         if os.environ.get("AFI_PROFILE_DUMP"):            # per-launch CSV (shape, split, ms) for offline analysis
@@ -709,11 +796,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         # data-parallel invariant (stage1_trainer.py:80-89 + the all-reduce): after K steps every rank holds the same G and D weights
-        chk = torch.stack([torch.cat([p.detach().reshape(-1).double() for p in m.parameters()]).sum() for m in (G, D)])
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        params_identical = bool(torch.equal(lo, hi))
+        params_identical = identical_across_ranks(dist, torch, [torch.cat([p.detach().reshape(-1) for p in m.parameters()]) for m in (G, D)])
+        comm["per_rank_images_per_s"] = per_rank_rates(dist, torch, B * args.steps, elapsed_rank, dev, world)
         assert params_identical, "parameters differ across ranks after the timed steps (all-reduce / broadcast broken)"
     if rank != 0:
         if dist is not None:
@@ -826,7 +910,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"fp32": "f32", "f16x3": "f32 emulated on the f16 matrix cores (operands scaled by a power of two per Winograd plane and split into two fp16 pieces, three f16 MFMAs per k-step, fp32 accumulate; tensors fp32)", "bf16x6": "f32 emulated on the bf16 matrix cores (operands split exactly into three bf16, six bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)", "bf16x3": "bf16x3 (split-bf16 operands, three bf16 MFMAs per k-step, fp32 accumulate; tensors fp32)",
                                        "bf16": "bf16 (bf16 operands, fp32 accumulate; tensors fp32)"}[run_dtype], "data": "synthetic",
-        "backend": (args.backend if world > 1 else None), "comm": comm,
+        "backend": (args.backend if dist is not None else None), "comm": comm,
         "config": {"workload": "configs[1]: stage-1 AFI-GAN G+D step, R-50-FPN guide random-init (eval), "
                                f"{B}x3x800x1333 synthetic images per GPU, P2..P6, G n_rdb=3",
                    "global_batch": world * B, "parallelism": f"dp{world}", "guide": "r50fpn (1x1 and 3x3 convs on this library's kernels, stem GEMM via hipBLASLt)" if guide is not None else "synthetic-pyramid",

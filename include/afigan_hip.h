@@ -120,11 +120,13 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                  from 8192 pixels; 0: F(2x2,3x3) everywhere */
 #define AFI_OPT_WINOGRAD_F4_FORWARD 2         /* the discriminator forwards a backward follows (their conv outputs decide LeakyReLU masks), per block:
                                                  bit n + 1 puts block n on F(4x4) (2: block 0, 4: block 1, 8: block 2; sums combine); 1: every block;
-                                                 0: F(2x2) everywhere.  Default 12 (blocks 1 and 2) since round 5.  Measured (D fwd+bwd at
-                                                 P3 against fp64, relative L2 of dx / worst parameter gradient): torch's fp32 ops 0.9-1.0e-3 / 1.3-1.4e-3,
-                                                 the exact-fp32 direct kernels 1.04e-3 / 1.49e-3, F(2x2) 6.4e-4 / 8.8e-4, blocks 1 + 2 1.09e-3 / 1.50e-3,
-                                                 every block 1.44e-3 / 1.89e-3; stage-1 step 80.8 / 72.4 / 71.5 ms for 0 / 12 / 1.  Bit 16: the interpolator's own
-                                                 forwards too (off: 15x the deviation on its worst parameter gradient for 1 ms) */
+                                                 0: F(2x2) everywhere.  Default 8 (block 2 only): the largest block set whose gradient deviation from fp64
+                                                 stays below torch's own fp32 ops on the same inputs at P2 and at P3 (profiles/r06/dflip_p2_*.txt,
+                                                 dflip_p3_*.txt: D fwd+bwd, relative L2 of dx / worst parameter gradient, means over seeds; P3 | P2):
+                                                 torch fp32 1.03e-3 / 1.38e-3 | 1.24e-3 / 1.68e-3; = 0: 0.77e-3 / 1.07e-3 | 0.86e-3 / 1.21e-3;
+                                                 = 8: 0.87e-3 / 1.24e-3 | 1.14e-3 / 1.48e-3; = 12 (round 5's default): 1.19e-3 / 1.62e-3 | 1.48e-3 / 1.90e-3;
+                                                 = 1: 1.39e-3 / 1.81e-3 | 1.65e-3 / 2.09e-3.  tests/test_gpu_d_parity.py holds the default to that bar.
+                                                 Bit 16: the interpolator's own forwards too (off: 15x the deviation on its worst parameter gradient for 1 ms) */
 #define AFI_OPT_BN_STATS_FP64 3               /* 1 (default): BatchNorm batch statistics accumulated in fp64 (torch's CPU accumulation type) */
 #define AFI_OPT_D_WINOGRAD_MIN_PIXELS 4       /* 1024: discriminator calls of fewer pixels stay direct (values below 1024 act as 1024) */
 #define AFI_OPT_G_WINOGRAD_MIN_PIXELS 5       /* 2048: the same for a convolution of the interpolator */

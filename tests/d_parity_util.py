@@ -59,10 +59,16 @@ def l2(a, b):
 class DProbe:
     """One discriminator call at [N,256,H,W] with closed-form weights: fp64 reference (with autograd), fp32 CPU forward, HIP forward."""
 
-    def __init__(self, amd, N, H, W, seed, in_filters=256):
+    def __init__(self, amd, N, H, W, seed, in_filters=256, options=None):
+        """`options`: {name: value} of afi_ctx_set_option for this probe's calls (its own context); None = the library's defaults."""
         from afigan_amd import _lib, ops
         self._lib, self.ops = _lib, ops
         lib = _lib.load()
+        self.cx = None
+        if options is not None:
+            self.cx = _lib.Ctx()
+            for k, v in options.items():
+                self.cx.set_option(k, v)
         self.N, self.H, self.W, self.Cin = N, H, W, in_filters
         dp = orc.closed_form_discriminator_params(in_filters)
         self.dp = dp
@@ -88,12 +94,18 @@ class DProbe:
         self.ws = torch.empty(self.nf, device="cuda")
         self.sc = torch.empty(self.nb, device="cuda")
         self.logits = torch.empty((N, 1, H, W), device="cuda")
-        _lib.call("afi_discriminator_fwd", C.byref(self.prm), ops.view_of(self.xp), N, H, W, C.c_void_p(self.logits.data_ptr()), 1,
-                  C.c_void_p(self.ws.data_ptr()), self.nf, ops.stream_ptr())
+        self._call("afi_discriminator_fwd", C.byref(self.prm), ops.view_of(self.xp), N, H, W, C.c_void_p(self.logits.data_ptr()), 1,
+                   C.c_void_p(self.ws.data_ptr()), self.nf, ops.stream_ptr())
         self.off = (C.c_longlong * 12)()
         _lib.call("afi_discriminator_ws_layout", self.Fa, N, H, W, self.off)
-        self.written = lib.afi_discriminator_saved_activations(None, self.Fa, N, H, W)      # bit n: the forward wrote y[n]
+        self.written = lib.afi_discriminator_saved_activations(self.cx.handle if self.cx else None, self.Fa, N, H, W)      # bit n: the forward wrote y[n]
         self.P = N * H * W
+
+    def _call(self, name, *args):
+        if self.cx is None:
+            return self._lib.call(name, *args)
+        with self._lib.use_ctx(self.cx):
+            return self._lib.call(name, *args)
 
     def ws_mat(self, o, ch):
         """[P][ch] block of the workspace as a logical NCHW tensor"""
@@ -163,8 +175,8 @@ class DProbe:
         gst, _ = self.net._param_struct(grads, already_packed=True, grads=True)
         dx = ops.new_pixel_major(self.N, self.Cin, self.H, self.W, "cuda")
         dl = self.R.cuda().contiguous()
-        _lib.call("afi_discriminator_bwd", C.byref(self.prm), C.byref(gst), ops.view_of(self.xp), self.N, self.H, self.W, C.c_void_p(self.ws.data_ptr()),
-                  C.c_void_p(dl.data_ptr()), C.c_void_p(dx.data_ptr()), C.c_void_p(self.sc.data_ptr()), self.nb, ops.stream_ptr())
+        self._call("afi_discriminator_bwd", C.byref(self.prm), C.byref(gst), ops.view_of(self.xp), self.N, self.H, self.W, C.c_void_p(self.ws.data_ptr()),
+                   C.c_void_p(dl.data_ptr()), C.c_void_p(dx.data_ptr()), C.c_void_p(self.sc.data_ptr()), self.nb, ops.stream_ptr())
         torch.cuda.synchronize()
         return dx, dict(zip(NAMES, grads))
 

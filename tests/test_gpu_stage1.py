@@ -271,13 +271,73 @@ def test_stage1_data_parallel_two_ranks_one_gpu(amd, tmp_path):
         _check_dp_results(r0, r1)
         res[overlap] = r0
         ex = r0["comm_exposed_ms"]
-        assert set(ex) == {"D", "G", "total"} and all(v >= 0.0 for v in ex.values()), ex
-        print(f"[two ranks, one GPU, {r0['backend']}] overlap_comm={overlap}: exchange exposed to the consumer D {ex['D']:.3f} ms, G {ex['G']:.3f} ms")
+        assert set(ex) == {"D", "G", "total", "host_blocked_ms"} and all(ex[k] >= 0.0 for k in ("D", "G", "total")), ex
+        print(f"[two ranks, one GPU, {r0['backend']}] overlap_comm={overlap}: exchange exposed to the consuming stream D {ex['D']:.3f} ms, G {ex['G']:.3f} ms; "
+              f"host inside the waits {ex['host_blocked_ms']}")
     for k, v in res[True]["w1"].items():
         if "num_batches" in k:
             assert torch.equal(v, res[False]["w1"][k]), k
         else:
             assert ((v - res[False]["w1"][k]).abs().max() / (v.abs().max() + 1e-30)).item() < 1e-5, k
+
+
+def _rccl_single_rank_worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import copy
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import afigan_amd as amd
+    C, g = 16, 4
+    torch.manual_seed(50)
+    G = amd.Generator(in_channels=C, n_residual_dense_blocks=2, growth_rate=g).cuda()
+    D = amd.Discriminator(in_filters=C).cuda()
+    gen = torch.Generator().manual_seed(1000)
+    lr_f = [torch.randn((2, C, 7, 11), generator=gen).cuda(), torch.randn((2, C, 4, 6), generator=gen).cuda()]
+    hr_f = [torch.randn((2, C, 13, 21), generator=gen).cuda(), torch.randn((2, C, 8, 12), generator=gen).cuda()]
+    out = {}
+    for tag, kw in (("solo", dict(distributed=False)), ("rccl_overlapped", dict(distributed=True, overlap_comm=True)),
+                    ("rccl_blocking", dict(distributed=True, overlap_comm=False))):
+        G1, D1 = copy.deepcopy(G), copy.deepcopy(D)
+        st = amd.Stage1Step(G1, D1, base_lr=0.01, warmup_iters=0, **kw)
+        if kw["distributed"]:
+            assert st.backend == "nccl" and st.world == 1 and st.overlap_comm == kw["overlap_comm"]
+        st.measure_comm = bool(kw["distributed"])
+        for _ in range(3):
+            st.run_step(lr_f, hr_f)
+        torch.cuda.synchronize()
+        assert not st._pending_work
+        out[tag] = {"w": {k: v.detach().cpu() for k, v in list(G1.state_dict().items()) + list(D1.state_dict().items())},
+                    "metrics": st.metrics(reduce=bool(kw["distributed"])), "exposure": st.comm_exposure() if kw["distributed"] else None}
+    torch.save(out, os.path.join(tmp, "r0.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stage1_rccl_single_rank_group_runs_both_exchange_paths(amd, tmp_path):
+    """One GPU is all this box has, and RCCL wants one GPU per rank -- but a ONE-rank `nccl` group is a real RCCL communicator: the
+    engine's distributed path (broadcast at construction, `all_reduce(async_op=True)` issued from the caller's stream for D and from the
+    engine's second stream for G, `work.wait()` ordering the consuming stream behind RCCL's, the 1/world factor in the fused SGD kernel,
+    `metrics(reduce=True)`) runs on ProcessGroupNCCL with overlap_comm on and off.  Three steps each way land where the non-distributed
+    engine lands (a sum over one rank is the identity), the host never blocks in a wait (what hid the gloo figure
+    cannot hide here), and no collective is left pending.  (stage1_trainer.py:80-89.)"""
+    import torch.multiprocessing as mp
+    port = 29300 + (os.getpid() % 500)
+    mp.spawn(_rccl_single_rank_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "r0.pt")
+    for tag in ("rccl_overlapped", "rccl_blocking"):
+        for k, v in r["solo"]["w"].items():
+            if "num_batches" in k:
+                assert torch.equal(v, r[tag]["w"][k]), (tag, k)
+            else:
+                assert ((v - r[tag]["w"][k]).abs().max() / (v.abs().max() + 1e-30)).item() < 1e-5, (tag, k)
+        for k, v in r["solo"]["metrics"].items():
+            assert abs(r[tag]["metrics"][k] - v) <= 1e-5 * max(1.0, abs(v)), (tag, k)
+        print(f"[RCCL, one-rank group] {tag}: exchange exposed to the consuming stream {r[tag]['exposure']}")
+    hb = r["rccl_overlapped"]["exposure"]["host_blocked_ms"]
+    assert all(v < 5.0 for v in hb.values()), hb              # nccl: wait() orders streams, the host goes on
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank: runs where the box has >= 2 devices")
@@ -515,6 +575,72 @@ def test_guide_prefetcher_keeps_its_inputs_alive(amd):
             assert torch.equal(a, b), how
         del fresh, feats
     torch.cuda.synchronize()
+
+
+def test_guide_forward_queued_from_the_step_hook_is_isolated_from_the_engine(amd):
+    """``Stage1Step.on_d_level`` is called while the engine's forward context (phase weight cache registered) is the active one,
+    and bench.py uses the hook to ``GuidePrefetcher.submit`` the next batch's guide forwards onto another stream.  That work must never
+    land on the engine's contexts: (1) every context-taking library call made from the hook goes to the prefetcher's own context (observed
+    call by call); (2) the features of a FULL-SIZE guide forward (2 x 3 x 800 x 1333, image and image_x0.5) queued from the hook beside a
+    full-size step equal a stand-alone forward's bit for bit; (3) the engine's own results do not depend on the hook's work."""
+    from afigan_amd import _lib
+    from afigan_amd.guide import GuideR50FPN
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    guide = GuideR50FPN().to(dev)
+    G = amd.Generator(in_channels=256, n_residual_dense_blocks=3).to(dev)
+    D = amd.Discriminator().to(dev)
+    gen = torch.Generator(device=dev).manual_seed(11)
+    img = torch.rand((2, 3, 800, 1333), device=dev, generator=gen) * 255.0
+    half = torch.nn.functional.interpolate(img, size=(400, 666), mode="bilinear", align_corners=False)
+
+    def guide_pair():
+        hr, lr = guide(img), guide(half)
+        return [hr[f"p{d}"] for d in range(2, 7)], [lr[f"p{d}"] for d in range(2, 7)]
+    with torch.no_grad():
+        hr0, lr0 = guide_pair()
+        hr0, lr0 = [t.clone() for t in hr0], [t.clone() for t in lr0]
+    torch.cuda.synchronize()
+
+    step = amd.Stage1Step(G, D, base_lr=1e-3)
+    pf = amd.GuidePrefetcher(dev)
+    assert pf.ctx is not step.ctx and pf.ctx is not step.bctx and pf.ctx is not _lib.current_ctx()
+    in_hook, foreign = [False], []
+
+    def observer(name, cx):
+        if in_hook[0] and cx is not pf.ctx:
+            foreign.append((name, "engine fwd" if cx is step.ctx else "engine bwd" if cx is step.bctx else "other"))
+
+    def hook(i):
+        if i == 3:                                          # beside the small levels, where bench.py places it
+            in_hook[0] = True
+            try:
+                pf.submit(guide_pair)
+            finally:
+                in_hook[0] = False
+    _lib._observers.append(observer)
+    try:
+        step.on_d_level = hook
+        step.run_step(lr0, hr0)
+        hr1, lr1 = pf.take()
+        torch.cuda.synchronize()
+    finally:
+        _lib._observers.remove(observer)
+        step.on_d_level = None
+    assert foreign == [], foreign[:4]
+    for a, b in zip(hr1 + lr1, hr0 + lr0):
+        assert torch.equal(a, b)
+    with_hook = step.metrics()
+    # the same step without the hook, from the same weights: the engine's numbers do not depend on what the hook queued
+    torch.manual_seed(5)
+    _ = GuideR50FPN()                                       # (consumes the same random numbers as above)
+    G2 = amd.Generator(in_channels=256, n_residual_dense_blocks=3).to(dev)
+    D2 = amd.Discriminator().to(dev)
+    step2 = amd.Stage1Step(G2, D2, base_lr=1e-3)
+    step2.run_step(lr0, hr0)
+    without = step2.metrics()
+    for k, v in without.items():
+        assert abs(with_hook[k] - v) <= 1e-5 * abs(v) + 1e-7, (k, with_hook[k], v)
 
 
 def test_stage1_reference_checkpoint_layout_round_trips_through_torch_sgd(amd):

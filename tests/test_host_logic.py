@@ -421,6 +421,27 @@ def test_bench_gpus_n_spawns_n_ranks():
     assert line["n_gpus"] == 2 and line["spawned_by_bench"] and line["allreduce_sum_ok"] and line["params_identical_across_ranks"] is True
 
 
+def test_bench_gpus_8_rehearsal_reports_the_world_and_every_rank():
+    """the 8-GPU launch as a formality.  `python bench.py --gpus 8` under a fake 8-rank gloo world (CPU tensors, no GPU
+    work): the line carries `comm.world_size_reported == 8`, the two exchanges alone on buffers cut from the real sizes (the same
+    `allreduce_alone` the real run calls on the engine's flat gradient buffers), `params_identical_across_ranks` (the same
+    `identical_across_ranks`), one images/s figure per rank, `config.parallelism == "dp8"`, with the exchanges issued asynchronously and
+    blocking (--overlap-comm 1 / 0: the first real run can measure both)."""
+    import json
+    for overlap in ("1", "0"):
+        r = _run_bench(["--gpus", "8", "--backend", "gloo", "--rehearse-launch", "--steps", "2", "--overlap-comm", overlap], timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        line = json.loads(lines[0])
+        assert line["n_gpus"] == 8 and line["comm"]["world_size_reported"] == 8 and line["comm"]["backend"] == "gloo"
+        assert line["comm"]["overlap_comm"] is (overlap == "1")
+        assert set(line["comm"]["allreduce_alone"]) == {"D", "G"} and all(v["ms"] > 0 for v in line["comm"]["allreduce_alone"].values())
+        assert line["params_identical_across_ranks"] is True and line["allreduce_sum_ok"] is True
+        assert len(line["per_rank_images_per_s"]) == 8 and all(v > 0 for v in line["per_rank_images_per_s"])
+        assert line["config"] == {"global_batch": 16, "parallelism": "dp8"}
+
+
 def test_bench_rejects_a_world_that_is_not_gpus_and_fails_with_its_ranks():
     r = _run_bench(["--gpus", "4", "--rehearse-launch"], {"WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr
