@@ -186,25 +186,75 @@ class _BatchNormTrainFn(torch.autograd.Function):
         return dx.view(N, H, W, C_).permute(0, 3, 1, 2), dgamma, dbeta, None
 
 
+class _SyncTotals:
+    """Pixel counts of ALL ranks for the maps of one forward, exchanged ONCE: a SyncBN layer needs the global count N of its map on
+    the HOST (afi_bn_bwd_apply takes it by value), and reading it back from the device per norm was one host synchronisation per
+    BatchNorm of every BiFPN node -- a serialised, uncapturable forward.  ``BiFPN_AFIGAN._forward_train`` opens one of these around its
+    seven layers: ONE all_gather of the local counts of its five pyramid levels and ONE read-back; each norm then looks its map's global
+    count up by its local count.  A norm run outside such a block (or on a map the block did not announce) falls back to its own read-back."""
+    _tls = __import__("threading").local()
+
+    def __init__(self, local_counts, group=None):
+        import torch.distributed as dist
+        self.group = group
+        counts = sorted(set(int(c) for c in local_counts))
+        dev = torch.device("cuda", torch.cuda.current_device())
+        mine = torch.tensor(counts, device=dev, dtype=torch.int64)
+        allc = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(allc, mine, group=group)
+        tot = torch.stack(allc).sum(0).tolist()               # the one host read-back of this forward
+        self.totals = dict(zip(counts, tot))
+
+    def __enter__(self):
+        self.prev = getattr(_SyncTotals._tls, "cur", None)
+        _SyncTotals._tls.cur = self
+        return self
+
+    def __exit__(self, *exc):
+        _SyncTotals._tls.cur = self.prev
+        return False
+
+    @staticmethod
+    def lookup(local_count, group):
+        cur = getattr(_SyncTotals._tls, "cur", None)
+        if cur is not None and cur.group is group:
+            return cur.totals.get(int(local_count))
+        return None
+
+
+_count_cache = {}
+
+
+def _count_tensor(device, count):
+    """[float(count)] on `device`, made once per (device, count): no host-to-device copy per norm."""
+    key = (device, int(count))
+    t = _count_cache.get(key)
+    if t is None:
+        t = _count_cache[key] = torch.tensor([float(count)], device=device)
+    return t
+
+
 class _SyncBatchNormTrainFn(torch.autograd.Function):
     """norm = "SyncBN" (the reference default, bifpn_sr.py:210,279-280: detectron2's NaiveSyncBatchNorm / nn.SyncBatchNorm) in training mode
     under a process group of several ranks: the batch statistics are those of ALL ranks' pixels.  Forward: this rank's mean / biased
     variance / pixel count (afi_bn_stats_ex), ONE all_gather of the [2 C + 1] vector, combined as torch.batch_norm_gather_stats_with_counts
     does (mean = sum n_r mean_r / N, var = sum n_r (var_r + mean_r^2) / N - mean^2), running buffers updated with the global statistics
     (unbiased variance over N).  Backward: this rank's (sum g, sum g xhat) (afi_bn_bwd_sums; dbeta / dgamma stay per rank, as torch keeps them
-    for the data-parallel wrapper to average), ONE all_reduce, then dx with the global sums over N pixels (afi_bn_bwd_apply)."""
+    for the data-parallel wrapper to average), ONE all_reduce, then dx with the global sums over N pixels (afi_bn_bwd_apply).
+    The ranks are those of the layer's process group (``bn._afi_group``, None = the default group; nn.SyncBatchNorm's ``process_group``)."""
 
     @staticmethod
     @_lib.ctx_forward
     def forward(ctx, x, gamma, beta, bn):
         import torch.distributed as dist
+        group = getattr(bn, "_afi_group", None)
         x = _dense_pm(x.detach())
         N, C_, H, W = x.shape
         x2d = x.permute(0, 2, 3, 1).reshape(N * H * W, C_)
         mean_l, _inv_l, var_l = ops.bn_stats_ex(x2d, bn.eps, 0.0, None, None, None, want_var=True)
-        mine = torch.cat([mean_l, var_l, torch.tensor([float(N * H * W)], device=x.device)])
-        allv = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-        dist.all_gather(allv, mine)
+        mine = torch.cat([mean_l, var_l, _count_tensor(x.device, N * H * W)])
+        allv = [torch.empty_like(mine) for _ in range(dist.get_world_size(group))]
+        dist.all_gather(allv, mine, group=group)
         st = torch.stack(allv).double()                      # [world, 2 C + 1]
         cnt = st[:, -1:]
         total = cnt.sum()
@@ -222,7 +272,9 @@ class _SyncBatchNormTrainFn(torch.autograd.Function):
         g, b = gamma.detach().contiguous(), beta.detach().contiguous()
         y = ops.bn_apply(x2d, mean, invstd, g, b)
         ctx.save_for_backward(x, mean, invstd, g)
-        ctx.total = int(total.item())
+        known = _SyncTotals.lookup(N * H * W, group)         # exchanged once per forward by the caller (BiFPN_AFIGAN._forward_train) ...
+        ctx.total = int(known) if known is not None else int(total.item())      # ... else this norm's own read-back (one host sync)
+        ctx.group = group
         return y.view(N, H, W, C_).permute(0, 3, 1, 2)
 
     @staticmethod
@@ -235,13 +287,15 @@ class _SyncBatchNormTrainFn(torch.autograd.Function):
         x2d = x.permute(0, 2, 3, 1).reshape(N * H * W, C_)
         dgamma, dbeta = torch.zeros_like(g), torch.zeros_like(g)
         sums = ops.bn_bwd_sums(dy2d, x2d, mean, invstd, dgamma, dbeta)
-        dist.all_reduce(sums)
+        dist.all_reduce(sums, group=ctx.group)
         dx = ops.bn_bwd_apply(dy2d, x2d, mean, invstd, g, sums, ctx.total)
         return dx.view(N, H, W, C_).permute(0, 3, 1, 2), dgamma, dbeta, None
 
 
 def _sync_active(bn):
-    return getattr(bn, "_afi_sync", False) and torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+    if not (getattr(bn, "_afi_sync", False) and torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return False
+    return torch.distributed.get_world_size(getattr(bn, "_afi_group", None)) > 1
 
 
 def _norm_train(x, bn):
@@ -340,6 +394,15 @@ class BiFPN_AFIGAN(nn.Module):
         self._folded, self._folded_key = f, key
         return f
 
+    def set_process_group(self, group):
+        """The ranks whose pixels a "SyncBN" layer of this module normalises over (nn.SyncBatchNorm's ``process_group``; None = the default
+        group): a model trained under a sub-group must not exchange statistics with the ranks outside it."""
+        self.process_group = group
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm2d) and getattr(m, "_afi_sync", False):
+                m._afi_group = group
+        return self
+
     def _check_syncbn(self):
         """norm="SyncBN" (the reference default, bifpn_sr.py:210) exchanges batch statistics between ranks in training mode: the node norms
         (built by _make_norm) do, through _SyncBatchNormTrainFn -- one all_gather in the forward, one all_reduce in the backward per norm.
@@ -362,6 +425,18 @@ class BiFPN_AFIGAN(nn.Module):
             bottom_up_features = self.bottom_up(x)
         self._check_syncbn()
         c3, c4, c5 = [bottom_up_features[k] for k in self.in_features]       # (the Functions below make their own pixel-major copies)
+        group = getattr(self, "process_group", None)
+        sync = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d) and m.training and _sync_active(m)]
+        if sync and getattr(_SyncTotals._tls, "cur", None) is None:
+            # SyncBN over several ranks: every rank's pixel count per pyramid level, exchanged ONCE for the whole forward (p3..p7; the "same"-padded
+            # 3x3 / 2 max-pools halve with ceil) -- the 60-odd norms below then run without a host synchronisation each
+            n, (h, w) = c5.shape[0], c5.shape[-2:]
+            counts = [c3.shape[0] * c3.shape[-2] * c3.shape[-1], c4.shape[0] * c4.shape[-2] * c4.shape[-1], n * h * w]
+            for _ in range(2):
+                h, w = (h + 1) // 2, (w + 1) // 2
+                counts.append(n * h * w)
+            with _SyncTotals(counts, group):
+                return self._forward_train(x, bottom_up_features)
 
         def lat(t, seq):
             return _norm_train(_LateralMergeFn.apply(t, seq[0].weight, seq[0].bias, None), seq[1])

@@ -334,7 +334,7 @@ static float* wino_wcache_slot(afi_ctx* cx, const float* w, int f4, int mode, in
 // when one is registered (built on first use, found again until the cache is invalidated) or builds it into the call's own workspace, all
 // missing ones in ONE launch, and attaches the image to each GEMM descriptor; a descriptor without an image runs on the fp32-MFMA kernel.
 #define AFI_WG6_WIDE 16                                    // wide weight-gradient problems of one small-map backward pass (7 + one per dense block)
-constexpr long long kWk6MaxPixels = 4096;                  // workspaces reserve the image arena for calls up to this many low-res pixels
+constexpr long long kWk6MaxPixels = 8192;                  // workspaces reserve the image arena for calls up to this many low-res pixels
 constexpr int kWk6MaxReq = 24, kWk6MaxJobs = 40;
 // One image request: `key` names it in the cache (with `tag`: 0 forward / K-contiguous weights, 1 data gradient / row-contiguous weights,
 // 2 a dense block's four growth convs side by side along K: the data gradient 4G -> C of their block-input columns); njob source weights,

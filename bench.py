@@ -486,6 +486,74 @@ def bifpn_bench(amd, torch, iters=10, warmup=3):
             "interpolator_tflop": flop / 1e12, "interpolator_tflops_lower_bound": flop / best / 1e12}
 
 
+def bifpn_train_bench(amd, torch, iters=5, warmup=2):
+    """SURVEY 8(f) row 4, the TRAINING path (bifpn_sr.py:569-733 with batch-statistics norms): forward + backward of BiFPN_AFIGAN in train
+    mode for one 896x1408 image, Swin-L stage3..5 feature shapes, loss = sum of the five outputs: 28 interpolator forwards AND backwards
+    (input gradients and all weight gradients), 56 separable-conv nodes and 61 training-mode norms, every piece a HIP forward + backward
+    behind torch autograd.  Reported: wall time per iteration, the forward / backward split (events), and the GEMM launches of one iteration by
+    kernel family (the library's own HIP-event brackets); the per-kernel table of the whole pass is profiles/r06/kernel_stats_bifpn_train_*.csv
+    (rocprofv3 over tools/bifpn_train_loop.py).  norm "SyncBN" with one rank is plain batch statistics."""
+    class BottomUp(torch.nn.Module):
+        _out_feature_strides = {"stage3": 8, "stage4": 16, "stage5": 32}
+        _out_feature_channels = {"stage3": 384, "stage4": 768, "stage5": 1536}
+
+        def forward(self, feats):
+            return feats
+
+    torch.manual_seed(0)
+    net = amd.BiFPN_AFIGAN(BottomUp(), ["stage3", "stage4", "stage5"], 256, 7, norm="SyncBN", top_block=amd.LastLevelP6P7(1536, 256, "SyncBN")).cuda().train()
+    feats = {f"stage{i + 3}": torch.randn((1, c, 112 // 2 ** i, 176 // 2 ** i), device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for i, c in enumerate([384, 768, 1536])}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+
+    def one(timed=False):
+        for p_ in net.parameters():
+            p_.grad = None
+        for f_ in feats.values():
+            f_.grad = None
+        if timed:
+            ev[0].record()
+        out = net(feats)
+        loss = sum(v.sum() for v in out.values())
+        if timed:
+            ev[1].record()
+        loss.backward()
+        if timed:
+            ev[2].record()
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    one(timed=True)
+    torch.cuda.synchronize()
+    fwd_ms, bwd_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+    # GEMM launches of one iteration by kernel family (the library's HIP-event brackets)
+    lib = amd._lib.load()
+    lib.afi_profile_enable(1)
+    one()
+    torch.cuda.synchronize()
+    lib.afi_profile_enable(0)
+    fam = []
+    for k in range(lib.afi_profile_num_kinds()):
+        o3 = (C.c_double * 3)()
+        amd._lib.check(lib.afi_profile_get(k, o3), "afi_profile_get")
+        if o3[0] > 0:
+            fam.append({"kernel": lib.afi_profile_kind_name(k).decode(), "launches": int(o3[0]), "ms_total": round(o3[1], 3),
+                        "tflops": round(o3[2] / (o3[1] * 1e-3) / 1e12, 1) if o3[1] > 0 else 0.0})
+    fam.sort(key=lambda r: -r["ms_total"])
+    g_px = sum(7 * (7 * 2 ** i) * (11 * 2 ** i) for i in range(4))               # 7 layers x (p7, p6, p5, p4 inputs)
+    flop = 3 * g_px * G_FWD_FLOP_PER_INPX                                         # fwd + dgrad + wgrad of the 28 interpolator calls
+    return {"workload": "BiFPN_AFIGAN TRAINING forward + backward, 1 image 896x1408, Swin-L stage3..5 shapes (28 interpolator fwd+bwd, 61 batch-statistics norms)",
+            "ms": dt * 1e3, "ms_forward": fwd_ms, "ms_backward": bwd_ms, "images_per_s": 1.0 / dt, "norm": "SyncBN (one rank: plain batch statistics)",
+            "interpolator_tflop": flop / 1e12, "interpolator_tflops_lower_bound": flop / dt / 1e12,
+            "gemm_ms_per_iteration": round(sum(r["ms_total"] for r in fam), 3), "gemm_kernel_families": fam[:8]}
+
+
 def stage2_bench(amd, torch, iters=5, warmup=2):
     """the AFI-specific part of one stage-2 iteration (stage2_trainer.py:299-364) for a per-GPU batch of two
     images: guide features at full size (P2..P6 of 800x1344), the AFI detector's FPN features at half size (416x672 input);
@@ -971,6 +1039,7 @@ def main():
             with amd.compute_dtype(dt):
                 line["pafpn"]["ms_by_dtype"][dt] = round(fpn_bench(amd, torch, iters=5, warmup=2, pafpn=True)["ms"], 3)
         line["bifpn_inference"] = bifpn_bench(amd, torch)
+        line["bifpn_training"] = bifpn_train_bench(amd, torch)
         line["stage2_adversarial"] = stage2_bench(amd, torch)
         from tools import dual_scale_bench                       # the mapper's uint8 resize pair + normalise/pad
         line["dual_scale_data_path"] = dual_scale_bench.run(iters=100, warm=10, cpu_iters=3)

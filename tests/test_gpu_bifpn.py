@@ -370,8 +370,33 @@ def _syncbn_worker(rank, world, port, tmp):
     y = bifpn_sr._norm_train(x, bn)
     (y * rg[sl].cuda()).sum().backward()
     torch.cuda.synchronize()
-    torch.save({"y": y.detach().cpu(), "dx": x.grad.cpu(), "dgamma": bn.weight.grad.cpu(), "dbeta": bn.bias.grad.cpu(),
-                "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked)}, os.path.join(tmp, f"r{rank}.pt"))
+    out = {"y": y.detach().cpu(), "dx": x.grad.cpu(), "dgamma": bn.weight.grad.cpu(), "dbeta": bn.bias.grad.cpu(),
+           "rm": bn.running_mean.cpu(), "rv": bn.running_var.cpu(), "nbt": int(bn.num_batches_tracked)}
+    # (a) inside a _SyncTotals block (what BiFPN_AFIGAN._forward_train opens once per forward) the norm reads nothing back from the
+    # device -- Tensor.item is counted; (b) the layer's own process group is the one both collectives use
+    grp = dist.new_group([0, 1])
+    bn._afi_group = grp
+    x2 = xg[sl].cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    calls = []
+    orig_item = torch.Tensor.item
+    torch.Tensor.item = lambda self: (calls.append(1), orig_item(self))[1]
+    try:
+        with bifpn_sr._SyncTotals([x2.shape[0] * 9 * 13], grp) as tot:
+            assert tot.totals == {x2.shape[0] * 9 * 13: 5 * 9 * 13}
+            n_before = len(calls)
+            y2 = bifpn_sr._norm_train(x2, bn)
+            out["item_calls_inside_block"] = len(calls) - n_before
+        bn._afi_group = None
+        with bifpn_sr._SyncTotals([x2.shape[0] * 9 * 13], grp):          # another group's block: not this layer's -> its own read-back
+            n_before = len(calls)
+            bifpn_sr._norm_train(x2.detach(), bn)
+            out["item_calls_other_group"] = len(calls) - n_before
+    finally:
+        torch.Tensor.item = orig_item
+    (y2 * rg[sl].cuda()).sum().backward()
+    torch.cuda.synchronize()
+    out.update({"y2": y2.detach().cpu(), "dx2": x2.grad.cpu()})
+    torch.save(out, os.path.join(tmp, f"r{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -404,6 +429,8 @@ def test_syncbn_statistics_span_the_ranks(tmp_path):
     assert rel(r0["dgamma"] + r1["dgamma"], ref.weight.grad) < 1e-4 and rel(r0["dbeta"] + r1["dbeta"], ref.bias.grad) < 1e-4
     for r in (r0, r1):
         assert rel(r["rm"], ref.running_mean) < 1e-5 and rel(r["rv"], ref.running_var) < 1e-5 and r["nbt"] == 1
+        assert r["item_calls_inside_block"] == 0 and r["item_calls_other_group"] >= 1, (r["item_calls_inside_block"], r["item_calls_other_group"])
+    assert rel(torch.cat([r0["y2"], r1["y2"]]), y.detach()) < 1e-5 and rel(torch.cat([r0["dx2"], r1["dx2"]]), xg.grad) < 1e-4      # (sub-group, totals looked up)
     # and the test can tell: rank 0's own two images alone give other outputs
     solo = torch.nn.BatchNorm2d(C_, eps=1e-3, momentum=0.01).double().train()
     with torch.no_grad():
