@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AFI_LIB_PATH") or os.path.join(_HERE, "csrc", "libafigan_hip.so")   # override: A/B kernel builds
 
 AFI_MAX_RDB = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class AfiError(RuntimeError):
@@ -78,6 +78,7 @@ SIGNATURES = {
     "afi_generator_fwd": (_i, [_vp, _GP, View, _i, _i, _i, View, _vp, _ll, _vp]),
     "afi_generator_bwd": (_i, [_vp, _GP, _GP, View, _i, _i, _i, _vp, _vp, _vp, _vp, _ll, _vp]),
     "afi_discriminator_fwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
+    "afi_discriminator_fwd_ws_floats_ex": (_ll, [_vp, C.POINTER(C.c_int), _i, _i, _i, _i]),
     "afi_discriminator_bwd_ws_floats": (_ll, [C.POINTER(C.c_int), _i, _i, _i]),
     "afi_discriminator_ws_layout": (_i, [C.POINTER(C.c_int), _i, _i, _i, C.POINTER(C.c_longlong)]),
     "afi_discriminator_saved_activations": (_i, [_vp, C.POINTER(C.c_int), _i, _i, _i]),

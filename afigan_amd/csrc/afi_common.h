@@ -76,6 +76,10 @@ struct AfiPixGemm {
     // map otherwise): fp64 partial sums [stats_rows][2][Ncols] (sum, sum of squares per channel), one row per block of that launch; the
     // launcher fills stats_rows.  Taken only by the plain-store epilogue on 256 / 512 / 1024-channel outputs; null = off.
     double* stats; int stats_rows;
+    // ... and, beside them, the per-channel MINIMUM and MAXIMUM of the stored output as fp32 rows [stats_rows][2][Ncols] (min, max), one row per
+    // block: from them the statistics finalizer derives the largest magnitude of the block's ACTIVATION lrelu(affine(c)) -- the affine is
+    // monotonic per channel, so it is attained at one of the two -- before any kernel has evaluated it (AFI_OPT_D_FOLD_BN_APPLY).  Null = off.
+    float* stats_mm;
     int no_wcache;                             // Winograd form: B is a per-call scratch (its pointer says nothing about its contents): never cache its transform
     // Small-map bf16x6 form (csrc/smallmap.hip, afi_pix_gemm_wk6): the weights pre-split into bf16 MFMA-fragment images,
     // [N tile of 32][K stage of 32][n half][hi | mid | lo][lane] x 16 B, K stages in the kernel's own order (channel chunk, K phase, tap);

@@ -556,6 +556,34 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
     if (AMAX) afi_ew_amax_publish(am, amax);
 }
 
+// The largest magnitude of an activation y = lrelu(affine(c)) that NO kernel has evaluated yet, from the per-channel minimum / maximum of the
+// conv output c (fp32 rows [rows][2][C] the Winograd output transforms leave beside their statistics partials): the pinned affine of
+// afi_bn.h is monotonic per channel in c, every one of its fp32 operations is monotonic under rounding, and LeakyReLU is increasing, so the
+// extreme activations of a channel are the affine's values at its two extreme conv outputs -- attained values, hence the EXACT maximum the
+// apply pass would have published.  One 256-thread block per 8 channels (32 lanes per channel over the rows), one conditional atomic per block.
+__global__ __launch_bounds__(256) void afi_bn_act_amax_kernel(const float* __restrict__ mm, int rows, int C, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float slope, float* amax) {
+    const int cl = threadIdx.x & 7, ln = threadIdx.x >> 3;
+    const int c = blockIdx.x * 8 + cl;
+    float mn = INFINITY, mx = -INFINITY;
+    if (c < C)
+        for (int i = ln; i < rows; i += 32) { mn = fminf(mn, mm[(long long)i * 2 * C + c]); mx = fmaxf(mx, mm[(long long)i * 2 * C + C + c]); }
+    float am = 0.f;
+    if (c < C && mn <= mx) {
+        const f32x4 mu = {mean[c], 0.f, 0.f, 0.f}, is = {invstd[c], 0.f, 0.f, 0.f}, ga = {gamma[c], 0.f, 0.f, 0.f}, be = {beta[c], 0.f, 0.f, 0.f};
+        const f32x4 lo = afi_bn_lrelu(f32x4{mn, 0.f, 0.f, 0.f}, mu, is, ga, be, slope), hi = afi_bn_lrelu(f32x4{mx, 0.f, 0.f, 0.f}, mu, is, ga, be, slope);
+        am = fmaxf(fabsf(lo[0]), fabsf(hi[0]));
+    }
+    afi_ew_amax_publish(am, amax);
+}
+int afi_launch_bn_act_amax(const float* mm, int rows, int C, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                           float* amax, hipStream_t st) {
+    if (!mm || rows <= 0 || C <= 0 || !amax) return AFI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(afi_bn_act_amax_kernel, dim3(afi_cdiv(C, 8)), dim3(256), 0, st, mm, rows, C, mean, invstd, gamma, beta, slope, amax);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // BatchNorm backward finalize: dgamma += sum g*xhat ; dbeta += sum g ; stash the two sums for the apply pass
 __global__ void afi_bn_bwd_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float gscale,
                                            float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums) {
@@ -987,19 +1015,27 @@ int afi_launch_fuse_swish(const float* a, const float* b, const float* c, const 
 
 // ---------------------------------------------------------------- small helpers
 // *out += alpha * sum(v[0..n))
-__global__ __launch_bounds__(256) void afi_sum_accum_kernel(const float* __restrict__ v, long long n, float alpha, float* __restrict__ out) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void afi_sum_accum_kernel(const float* __restrict__ v, long long n, float alpha, float* __restrict__ out) {
+    __shared__ float red[16];
     float s = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += v[i];
+    const long long n4 = ((((uintptr_t)v) & 15) == 0) ? n >> 2 : 0;           // 16-byte loads where the vector allows them (it comes from an allocator: always)
+    for (long long i = threadIdx.x; i < n4; i += blockDim.x) { const f32x4 q = *(const f32x4*)(v + 4 * i); s += (q[0] + q[1]) + (q[2] + q[3]); }
+    for (long long i = 4 * n4 + threadIdx.x; i < n; i += blockDim.x) s += v[i];
     s = afi_wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, alpha * (red[0] + red[1] + red[2] + red[3]));
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];           // fixed order
+        atomicAdd(out, alpha * t);
+    }
 }
 int afi_launch_sum_accum(const float* v, long long n, float alpha, float* out, hipStream_t st) {
     // ONE block: its threads' partial sums meet in a fixed order, so the result does not depend on which of several blocks' atomics lands
-    // first (the vector is one logit gradient per pixel: 134 K floats at most, off the critical path)
-    hipLaunchKernelGGL(afi_sum_accum_kernel, dim3(1), dim3(256), 0, st, v, n, alpha, out);
+    // first.  The vector is one logit gradient per pixel (134 K floats at most); on the large levels this launch sits ON the main stream
+    // (no side stream above kSideStreamMaxPixels), so the block is 1024 threads of 16-byte loads: 33 dependent loads per thread instead of
+    // the 525 of a 256-thread scalar walk (58 us -> a few us per launch at P2)
+    hipLaunchKernelGGL(afi_sum_accum_kernel, dim3(1), dim3(1024), 0, st, v, n, alpha, out);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 __global__ void afi_inc_i64_kernel(long long* p) { if (threadIdx.x == 0 && blockIdx.x == 0) *p += 1; }

@@ -50,6 +50,8 @@ int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* 
                         float momentum = -1.f, bool fp64 = true);
 int afi_launch_bn_stats_from_partials(const double* partial, int rows, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
                                       float* running_var, hipStream_t st, long long* num_batches_tracked = nullptr, float eps = -1.f, float momentum = -1.f);
+int afi_launch_bn_act_amax(const float* mm, int rows, int C, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
+                           float* amax, hipStream_t st);
 int afi_wino_stats_rows(long long T, int C);               // winograd.hip: rows of fp64 partials a STATS output transform writes (0: not fused)
 #define AFI_STATS_MAX_ROWS 1024
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
@@ -482,7 +484,9 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     // split into fp16 pieces; given and not known: a zero-filled slot of the caller's that the transform raises (the caller keeps it, e.g. for
     // the backward pass); not given: a slot of the call's pool.
     const bool want_amax = dma && f16;
-    const bool a_pre = afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 && want_amax && g.a_amax && g.a_amax_known && nph == 1 && !(g.Ck & 31) && !g.a_bn.mean;
+    // (an input read through a BatchNorm affine -- AFI_OPT_D_FOLD_BN_APPLY -- is split like any other once its maximum is known: the statistics
+    //  finalizer derives it from the conv output's per-channel extremes, afi_launch_bn_act_amax)
+    const bool a_pre = afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 && want_amax && g.a_amax && g.a_amax_known && nph == 1 && !(g.Ck & 31);
     if (want_amax && !(amax = g.a_amax ? g.a_amax : wino_amax_take(cx, ws, ws_floats, 1, st))) return AFI_ERR_LAUNCH;
     const AfiF16Bound abound = afi_f16_bound(amax, f4 ? 2 : 1);
     if (g.v_keep && !(f4 && a_pre)) return AFI_ERR_BAD_ARG; // (the caller's predicate and this function's disagree: the backward would read planes nobody wrote)
@@ -523,7 +527,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
 static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
                      float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false,
                      double* stats = nullptr, int* stats_rows = nullptr, const AfiBnLoad* in_bn = nullptr, float* in_amax = nullptr, bool in_amax_known = false,
-                     float* v_keep = nullptr) {
+                     float* v_keep = nullptr, float* stats_mm = nullptr) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
     if (in_bn) g.a_bn = *in_bn;
@@ -536,7 +540,7 @@ static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int
         const bool f4 = fwd_f4 && wino_f4(cx) && dtype != AFI_DTYPE_BF16 && (long long)N * H * W >= 8192;     // (the tiling wino_run will pick)
         const long long T = f4 ? (long long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
         const int rows = afi_wino_stats_rows(T, Nc);
-        if (rows > 0) { g.stats = stats; *stats_rows = rows; }
+        if (rows > 0) { g.stats = stats; g.stats_mm = stats_mm; *stats_rows = rows; }
     }
     return wino_run(cx, g, mode, ws, ws_floats, part, part_floats, st, fwd_f4);
 }
@@ -590,7 +594,7 @@ static int wino_wgrad(afi_ctx* cx, AfiView dy, AfiView x, int N, int H, int W, i
     if (fresh && hipMemsetAsync(dU, 0, sizeof(float) * np * (size_t)Cin * Cout, st) != hipSuccess) return AFI_ERR_LAUNCH;
     // dy_amax, x_amax (f16x3): the largest magnitudes of the two source tensors where their producers published them: both transforms then
     // write their planes already split into fp16 pieces and the GEMM stages them by DMA alone; otherwise the transforms raise two slots of the pool
-    const bool pre = afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 && f16 && dy_amax && x_amax && dy_phases == 1 && !(x_bn && x_bn->mean);
+    const bool pre = afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 && f16 && dy_amax && x_amax && dy_phases == 1;
     const bool known = f16 && dy_amax && x_amax;           // (known but not split: the in-register kernel with the known maxima; nothing is raised)
     if (f16 && !known && !(amax = wino_amax_take(cx, ws, ws_floats, 2, st))) return AFI_ERR_LAUNCH;
     const AfiF16Bound vbound = afi_f16_bound(known ? x_amax : amax, f4 ? 2 : 1), qbound = afi_f16_bound(known ? dy_amax : amax + 4, f4 ? 4 : 3);
@@ -661,7 +665,7 @@ int afi_debug_wk6_convT_images(const float* W, int Cin, int Cout, int mode, void
                                        : AfiWk6ImgJob{pack_ref, 9LL * Cin, Cin, Cin, Cout, 9, 4, 1, 0, (unsigned char*)via_pack, 0, 0};
     return afi_launch_wk6_images(&job, 1, st, nullptr, nullptr);
 }
-int afi_abi_version(void) { return 6; }
+int afi_abi_version(void) { return 7; }
 // digest of the sources this binary was compiled from (__graft_entry__.build() writes csrc/afi_build_id.h in front of the compile:
 // sha256 over every *.hip / *.h of csrc/ and include/afigan_hip.h, the generated header excluded).  The Python binding recomputes it from the
 // tree it sits in and refuses a library built from other sources; smoke() prints it.
@@ -1717,9 +1721,13 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
 // forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][y2 P*F3][d9 P*16][mean,invstd x3][red]
 struct DiscWs {
     long long P;
-    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_amax, o_part, n_part, o_wino, n_wino, o_mean_b[3], o_invstd_b[3], o_vkeep[3], total;
+    long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_stats_mm, o_amax, o_part, n_part, o_wino, n_wino, o_mean_b[3], o_invstd_b[3], o_vkeep[3], total;
 };
-static DiscWs disc_ws(const int F[4], int N, int H, int W) {
+// keep_mask: bit n reserves the kept F(4x4) input planes of block n (disc_v_shared).  The planes sit at the END of the layout, so every other
+// offset is the same under every mask; the context-free size query reserves both (an upper bound every context's call fits into), the
+// context-aware one (afi_discriminator_fwd_ws_floats_ex) and the two passes what disc_keep_mask says (an fp32 / bf16x6 context, a
+// forward no backward follows and the F(2x2) blocks paid 0.6 + 1.25 GB per workspace at P2 for planes nobody writes)
+static DiscWs disc_ws(const int F[4], int N, int H, int W, int keep_mask = 6) {
     DiscWs w;
     w.P = (long long)N * H * W;
     long long o = 0;
@@ -1736,6 +1744,7 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     }
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));
     w.o_stats = o; o += 4LL * AFI_STATS_MAX_ROWS * fmax;  // fp64 partial rows [rows][2][C] of the statistics fused into the output transforms
+    w.o_stats_mm = o; o += 2LL * AFI_STATS_MAX_ROWS * fmax;      // fp32 rows [rows][2][C]: per-channel minimum / maximum of the conv output, beside them (the folded apply pass)
     w.o_amax = o; o += 16;                                // [4 n]: the largest magnitude of block n's INPUT (x, y0, y1), raised by its producer (Winograd path; kept for the backward)
     w.n_part = part_floats({w.P * F[1], w.P * F[2], w.P * F[3]});
     w.o_part = o; o += w.n_part;
@@ -1748,12 +1757,17 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W) {
     // the F(4x4) input planes of blocks 1 and 2, kept by a forward that a backward follows for that block's weight gradient (disc_v_shared)
     for (int n = 0; n < 3; ++n) {
         w.o_vkeep[n] = o;
-        if (n > 0 && w.P >= 8192 && w.n_wino > 0) o += align4(36 * wino4_tpad(N, H, W) * F[n]);
+        if (n > 0 && ((keep_mask >> n) & 1) && w.P >= 8192 && w.n_wino > 0) o += align4(36 * wino4_tpad(N, H, W) * F[n]);
     }
     w.total = o;
     return w;
 }
 long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W) { return disc_ws(F, N, H, W).total; }
+static int disc_keep_mask(const afi_ctx* cx, const int F[4], int N, int H, int W, int training, int halves);
+long long afi_discriminator_fwd_ws_floats_ex(const afi_ctx_t* ctx, const int F[4], int N, int H, int W, int training) {
+    if (!F || N <= 0 || H <= 0 || W <= 0) return 0;
+    return disc_ws(F, N, H, W, disc_keep_mask(ctx, F, N, H, W, training, 1) | disc_keep_mask(ctx, F, N, H, W, training, 2)).total;     // (plain or paired call)
+}
 // where the forward keeps what the backward reads (offsets in floats into the forward workspace): 12 entries,
 // conv outputs c[0..2] ([P][F_{n+1}]), activations y[0..2], batch means [F_{n+1}], 1/sqrt(var + eps) [F_{n+1}]
 int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* off12) {
@@ -1792,10 +1806,29 @@ long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W) {
 // Does the forward (training == 1) of block n keep its input planes for the backward's weight gradient?  Evaluated by BOTH passes, which is why
 // afi_discriminator_bwd must run under the options and the arithmetic of its forward: F(4x4) forward in that block, f16x3 with pre-split planes
 // (the block's input maximum is known before its transform runs: blocks 1 and 2), channel counts the DMA GEMMs take
-static bool disc_v_shared(const afi_ctx* cx, const int F[4], int n, long long P, bool wino) {
+static bool disc_fold_opt(const afi_ctx* cx, bool wino, int halves) {
+    // AFI_OPT_D_FOLD_BN_APPLY in force for this call: Winograd form, and ONE affine per tensor (a paired call normalises its halves separately:
+    // it runs unfolded, whatever the option says)
+    return wino && halves == 1 && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0;
+}
+static bool disc_stats_fusable(const afi_ctx* cx, int C) { return afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0 && (C == 256 || C == 512 || C == 1024); }
+static bool disc_v_shared(const afi_ctx* cx, const int F[4], int n, long long P, bool wino, int halves = 1) {
     const int dtype = cx ? cx->dtype : afi_default_dtype();
+    // (under the folded apply pass the input's maximum is known beforehand only where the producing block's statistics -- and with them the
+    //  conv output's extremes -- were fused into its output transform: a training forward, which is the only kind that keeps planes)
+    const bool known = !disc_fold_opt(cx, wino, halves) || disc_stats_fusable(cx, F[n]);
     return wino && n > 0 && wino_d_f4(cx, n) && wino_f4(cx) && dtype == AFI_DTYPE_F16X3 && P >= 8192 && afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 &&
-           afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) == 0 && !(F[n] % 128) && !(F[n + 1] % 128);
+           known && !(F[n] % 128) && !(F[n + 1] % 128);
+}
+
+// the blocks whose planes a forward of this context keeps (training == 1 only: the other forwards feed no backward)
+static int disc_keep_mask(const afi_ctx* cx, const int F[4], int N, int H, int W, int training, int halves = 1) {
+    if (training != 1) return 0;
+    const long long P = (long long)N * H * W;
+    const bool wino = disc_wino_floats(F, N, H, W) > 0 && use_wino(cx, P);
+    int m = 0;
+    for (int n = 1; n < 3; ++n) if (disc_v_shared(cx, F, n, P, wino, halves)) m |= 1 << n;
+    return m;
 }
 
 static int disc_check(const afi_disc_params_t* p) {
@@ -1821,7 +1854,7 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
     if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || (!logits && !stats_only)) return AFI_ERR_BAD_ARG;
     if (halves != 1 && halves != 2) return AFI_ERR_BAD_ARG;
     if (N % halves) return AFI_ERR_BAD_ARG;
-    const DiscWs l = disc_ws(prm->F, N, H, W);
+    const DiscWs l = disc_ws(prm->F, N, H, W, disc_keep_mask(cx, prm->F, N, H, W, training, 1) | disc_keep_mask(cx, prm->F, N, H, W, training, 2));     // (the layout afi_discriminator_fwd_ws_floats_ex sizes)
     if (ws_floats < l.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* const part_ = ws + l.o_part;
@@ -1835,15 +1868,17 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
     // (AfiBnLoad: the arithmetic of the apply pass, bit for bit), and so do the backward's weight-gradient input transforms.  Block 2's
     // activation feeds the last conv (a direct GEMM) and is always written.
     const bool wino = l.n_wino > 0 && use_wino(cx, P);
-    const bool fold = wino && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0;
-    if (fold && halves > 1) return AFI_ERR_UNSUPPORTED;   // (the folded affine is one per tensor)
+    const bool fold = disc_fold_opt(cx, wino, halves);     // (a paired call runs unfolded: one affine per HALF there)
     const long long Ph = P / halves;
     AfiBnLoad in_bn{nullptr, nullptr, nullptr, nullptr};
     // the largest magnitude of every block's input, for the f16x3 arithmetic of this pass and of the backward pass that may follow (whatever
-    // arithmetic THIS pass runs in: the backward trusts the slots): x's by the first input transform, y0's / y1's by the BatchNorm apply passes
+    // arithmetic THIS pass runs in: the backward trusts the slots): x's by the first input transform; y0's / y1's by the BatchNorm apply passes, or --
+    // where the apply pass is folded into the readers -- by the statistics finalizer, from the conv output's per-channel extremes (the exact
+    // maximum, before any kernel has evaluated the activation); where neither exists (an eval-mode folded call) by the transform that reads it
     float* amax = ws + l.o_amax;
-    const bool slots = wino && !fold;
+    const bool slots = wino;
     if (slots && hipMemsetAsync(amax, 0, 16 * sizeof(float), st) != hipSuccess) return AFI_ERR_LAUNCH;
+    bool in_known = false;                                  // block n's input maximum is published before its transform runs
     for (int n = 0; n < 3; ++n) {       // Conv2d 3x3 + bias -> BN -> LeakyReLU (feature_patch_discriminator.py:35-38)
         const int ci = prm->F[n], co = prm->F[n + 1];
         float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];
@@ -1851,20 +1886,24 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
         int stats_rows = 0;
         double* stats = (double*)(ws + l.o_stats);          // (8-byte aligned: every offset of the layout is a multiple of 4 floats and ws comes from an allocator)
         const bool fuse_stats = training && halves == 1 && afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0 && (((uintptr_t)stats) & 7) == 0;
+        const bool fold_n = fold && n < 2;                  // this block's activation is never written: its readers evaluate it
         if (wino) {
+            const bool keep = training == 1 && slots && disc_v_shared(cx, prm->F, n, P, wino, halves);
+            if (keep && !in_known) return AFI_ERR_LAUNCH;   // (disc_v_shared promised a known maximum: never hand the backward planes this pass cannot split)
             AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
                               part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx, n), fuse_stats ? stats : nullptr, &stats_rows, in_bn.mean ? &in_bn : nullptr,
-                              slots ? amax + 4 * n : nullptr, /*known=*/n > 0,
-                              training == 1 && slots && disc_v_shared(cx, prm->F, n, P, wino) ? ws + l.o_vkeep[n] : nullptr));
+                              slots ? amax + 4 * n : nullptr, /*known=*/in_known, keep ? ws + l.o_vkeep[n] : nullptr,
+                              fuse_stats && fold_n ? ws + l.o_stats_mm : nullptr));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
-        const bool skip_apply = (stats_only && n == 2) || (fold && n < 2);       // nothing reads the last block's activation / the next block reads c through the affine
+        const bool skip_apply = (stats_only && n == 2) || fold_n;       // nothing reads the last block's activation / the next block reads c through the affine
         const float* mean_used = mean;
         if (!training) {
             AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
             mean_used = prm->running_mean[n];
         }
+        in_known = false;
         for (int h = 0; h < halves; ++h) {
             float* mean_h = h ? ws + l.o_mean_b[n] : mean;
             float* invstd_h = h ? ws + l.o_invstd_b[n] : invstd;
@@ -1872,14 +1911,21 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
             if (training && stats_rows > 0) {               // the output transform accumulated the sums while it stored c: only the finalizer is left
                 AFI_TRY(afi_launch_bn_stats_from_partials(stats, stats_rows, P, co, mean, invstd, nullptr, prm->running_mean[n], prm->running_var[n], st,
                                                           prm->num_batches_tracked[n]));
+                if (fold_n && slots) {                      // ... and, the apply pass being folded away, the activation's maximum from the extremes of c
+                    AFI_TRY(afi_launch_bn_act_amax(ws + l.o_stats_mm, stats_rows, co, mean, invstd, prm->gamma[n], prm->beta[n], AFI_LRELU_SLOPE, amax + 4 * (n + 1), st));
+                    in_known = true;
+                }
             } else if (training) {
                 AFI_TRY(afi_launch_bn_stats(ch, Ph, co, mean_h, invstd_h, nullptr, prm->running_mean[n], prm->running_var[n], red, st,
                                             prm->num_batches_tracked[n], -1.f, -1.f, afi_opt(cx, AFI_OPT_BN_STATS_FP64) != 0));  // the counter ticks inside the statistics finalizer
             }
-            if (!skip_apply) AFI_TRY(afi_launch_bn_apply_lrelu(ch, y + (long long)h * Ph * co, training ? mean_h : mean_used, training ? invstd_h : invstd, prm->gamma[n],
-                                                               prm->beta[n], Ph, co, st, AFI_LRELU_SLOPE, slots && n < 2 ? amax + 4 * (n + 1) : nullptr));
+            if (!skip_apply) {
+                AFI_TRY(afi_launch_bn_apply_lrelu(ch, y + (long long)h * Ph * co, training ? mean_h : mean_used, training ? invstd_h : invstd, prm->gamma[n],
+                                                  prm->beta[n], Ph, co, st, AFI_LRELU_SLOPE, slots && n < 2 ? amax + 4 * (n + 1) : nullptr));
+                in_known = slots && n < 2;                  // (published by the pass that wrote the activation)
+            }
         }
-        if (fold && n < 2) {
+        if (fold_n) {
             in = dense_view(c, H, W, co);
             in_bn = AfiBnLoad{mean_used, invstd, prm->gamma[n], prm->beta[n]};
         } else {
@@ -1907,8 +1953,7 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
     AFI_TRY(disc_check(prm));
     if (!gr || N <= 0 || H <= 0 || W <= 0 || !ws || !dlogits || !scratch) return AFI_ERR_BAD_ARG;
     if ((halves != 1 && halves != 2) || N % halves) return AFI_ERR_BAD_ARG;
-    if (halves > 1 && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0) return AFI_ERR_UNSUPPORTED;
-    const DiscWs l = disc_ws(prm->F, N, H, W);
+    const DiscWs l = disc_ws(prm->F, N, H, W, disc_keep_mask(cx, prm->F, N, H, W, 1, 1) | disc_keep_mask(cx, prm->F, N, H, W, 1, 2));   // the layout its forward (training == 1, same context settings) wrote
     const DiscBwdWs s = disc_bwd_ws(prm->F, N, H, W);
     if (scratch_floats < s.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -1928,7 +1973,9 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
     // f16x3: the largest magnitude of every d(conv output), raised by the BatchNorm backward that writes it; with the forward's slots
     // (DiscWs::o_amax) every Winograd transform of this pass knows its source's maximum beforehand and writes its planes split into fp16 pieces
     float* gmax = scratch + s.o_amax;
-    const bool slots = wino && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) == 0 && (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_F16X3;
+    // (folded apply pass or not: the forward left every block input's maximum in its slots either way)
+    const bool slots = wino && (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_F16X3;
+    const bool fold = disc_fold_opt(cx, wino, halves);
     if (slots && hipMemsetAsync(gmax, 0, 16 * sizeof(float), st) != hipSuccess) return AFI_ERR_LAUNCH;
     const float* xmax = ws + l.o_amax;
     // ---- last conv
@@ -1971,13 +2018,13 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
         AfiView gy = dense_view(g_, H, W, co);
         // (Winograd path: the forward never wrote the activations of blocks 0 and 1 -- the input transform reads block n - 1's saved conv
         //  output through its affine + LeakyReLU, as the forward's did)
-        const bool xin_folded = wino && n > 0 && afi_opt(cx, AFI_OPT_D_FOLD_BN_APPLY) != 0;
+        const bool xin_folded = fold && n > 0;
         AfiView xin = (n == 0) ? V(xv) : dense_view(ws + (xin_folded ? l.o_c[n - 1] : l.o_y[n - 1]), H, W, ci);
         AfiBnLoad x_bn{nullptr, nullptr, nullptr, nullptr};
         if (xin_folded) x_bn = AfiBnLoad{ws + l.o_mean[n - 1], ws + l.o_invstd[n - 1], prm->gamma[n - 1], prm->beta[n - 1]};
         if (gr->w[n] && wino) AFI_TRY(wino_wgrad(cx, gy, xin, N, H, W, co, ci, gr->w[n], 1.f, scratch + s.o_wino2, s.n_wino, sd, 1, true, xin_folded ? &x_bn : nullptr,
                                                  slots ? gmax + 4 * n : nullptr, slots ? xmax + 4 * n : nullptr,
-                                                 slots && disc_v_shared(cx, prm->F, n, P, wino) ? ws + l.o_vkeep[n] : nullptr));
+                                                 slots && disc_v_shared(cx, prm->F, n, P, wino, halves) ? ws + l.o_vkeep[n] : nullptr));
         else if (gr->w[n]) AFI_TRY(wgrad_launch(cx, conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
         if (n > 0 && wino) {
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), null_view(), scratch + s.o_wino,

@@ -275,20 +275,31 @@ int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, 
 // (afi_bn_stats_partial_kernel: 1.85 ms of a stage-1 step).
 #define AFI_STATS_MAX_ROWS 1024
 typedef double f64x4w __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void afi_stats_acc(f64x4w& s0, f64x4w& s1, f32x4 v) {
+__device__ __forceinline__ void afi_stats_acc(f64x4w& s0, f64x4w& s1, f32x4& mn, f32x4& mx, f32x4 v) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; s0[j] += d; s1[j] += d * d; }
+    for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; s0[j] += d; s1[j] += d * d; mn[j] = fminf(mn[j], v[j]); mx[j] = fmaxf(mx[j], v[j]); }
 }
-__device__ __forceinline__ void afi_stats_block_write(const AfiPixGemm& p, f64x4w s0, f64x4w s1) {
+__device__ __forceinline__ void afi_stats_block_write(const AfiPixGemm& p, f64x4w s0, f64x4w s1, f32x4 mn, f32x4 mx) {
     __shared__ f64x4w red[2][256];
+    __shared__ f32x4 redm[2][256];
     const int C4 = p.Ncols >> 2;
     red[0][threadIdx.x] = s0; red[1][threadIdx.x] = s1;
+    redm[0][threadIdx.x] = mn; redm[1][threadIdx.x] = mx;
     __syncthreads();
     if ((int)threadIdx.x < C4) {
-        for (int k = threadIdx.x + C4; k < 256; k += C4) { s0 += red[0][k]; s1 += red[1][k]; }      // fixed order: bit-reproducible
+        for (int k = threadIdx.x + C4; k < 256; k += C4) {                                           // fixed order: bit-reproducible
+            s0 += red[0][k]; s1 += red[1][k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mn[j] = fminf(mn[j], redm[0][k][j]); mx[j] = fmaxf(mx[j], redm[1][k][j]); }
+        }
         double* row = p.stats + (long long)blockIdx.x * 2 * p.Ncols;
         *(f64x4w*)(row + 4 * threadIdx.x) = s0;
         *(f64x4w*)(row + p.Ncols + 4 * threadIdx.x) = s1;
+        if (p.stats_mm) {                                                                            // (a thread that stored nothing leaves +-inf: neutral)
+            float* mrow = p.stats_mm + (long long)blockIdx.x * 2 * p.Ncols;
+            *(f32x4*)(mrow + 4 * threadIdx.x) = mn;
+            *(f32x4*)(mrow + p.Ncols + 4 * threadIdx.x) = mx;
+        }
     }
 }
 // rows of partials (= blocks) the STATS launch of an output transform over T tiles x C channels uses; 0 = this shape is not fused
@@ -307,6 +318,7 @@ __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* _
     const long long total = T * C4;
     const long long plane = Tpad * C;
     f64x4w st0 = {0, 0, 0, 0}, st1 = {0, 0, 0, 0};
+    f32x4 smn = {INFINITY, INFINITY, INFINITY, INFINITY}, smx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -330,12 +342,12 @@ __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* _
                 const int xx = 2 * tx + j;
                 if (xx >= p.W) continue;
                 const f32x4 v = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
-                if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xx, c, v); if (STATS) afi_stats_acc(st0, st1, o); }
+                if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xx, c, v); if (STATS) afi_stats_acc(st0, st1, smn, smx, o); }
                 else afi_epilogue_store(p, n, yy, xx, c, v);
             }
         }
     }
-    if (STATS) afi_stats_block_write(p, st0, st1);
+    if (STATS) afi_stats_block_write(p, st0, st1, smn, smx);
 }
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st) {
     if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.Ncols <= 0 || (p.Ncols & 3)) return AFI_ERR_BAD_ARG;
@@ -701,6 +713,7 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
     const long long total = T * C4;
     const long long plane = Tpad * C;
     f64x4w st0 = {0, 0, 0, 0}, st1 = {0, 0, 0, 0};
+    f32x4 smn = {INFINITY, INFINITY, INFINITY, INFINITY}, smx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -723,7 +736,7 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
             wino4_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], y0, y1, y2, y3);
             const int xx = 4 * tx;
             auto put = [&](int xo, f32x4 v) {
-                if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xo, c, v); if (STATS) afi_stats_acc(st0, st1, o); }
+                if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xo, c, v); if (STATS) afi_stats_acc(st0, st1, smn, smx, o); }
                 else afi_epilogue_store(p, n, yy, xo, c, v);
             };
             if (xx < p.W) put(xx, y0);
@@ -732,7 +745,7 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
             if (xx + 3 < p.W) put(xx + 3, y3);
         }
     }
-    if (STATS) afi_stats_block_write(p, st0, st1);
+    if (STATS) afi_stats_block_write(p, st0, st1, smn, smx);
 }
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st) {
     if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.Ncols <= 0 || (p.Ncols & 3)) return AFI_ERR_BAD_ARG;

@@ -53,13 +53,13 @@ class _DiscriminatorFn(torch.autograd.Function):
         lib = _lib.load()
         prm, keep = net._param_struct(params)
         F = (C.c_int * 4)(*net.F)
-        ws_floats = lib.afi_discriminator_fwd_ws_floats(F, N, H, W)
-        ws = ops.new_workspace(ws_floats, x.device)
-        logits = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
         # 0 eval; 1 train mode with a backward to come; 2 train-mode statistics only (no input of this call needs a gradient)
         # net._grad_mode: torch.is_grad_enabled() as the module's forward saw it (inside Function.forward it is always off, and
         # needs_input_grad still reports requires_grad under no_grad)
         mode = 0 if not net.training else (1 if (net._grad_mode and any(ctx.needs_input_grad)) else 2)
+        ws_floats = lib.afi_discriminator_fwd_ws_floats_ex(_lib.current_ctx().handle, F, N, H, W, mode)     # what this context's call of this kind writes
+        ws = ops.new_workspace(ws_floats, x.device)
+        logits = torch.empty((N, 1, H, W), device=x.device, dtype=torch.float32)
         call("afi_discriminator_fwd", C.byref(prm), ops.view_of(xp), N, H, W, C.c_void_p(logits.data_ptr()), mode,
              C.c_void_p(ws.data_ptr()), ws_floats, ops.stream_ptr())
         ctx.net, ctx.shape, ctx.x_needs_grad, ctx.was_training = net, (N, H, W), x.requires_grad, net.training

@@ -456,11 +456,13 @@ class Stage1Step:
         in the reference, the last activation / last conv / logits are not computed)."""
         N, _, H, W = x.shape
         F = (C.c_int * 4)(*self.dnet.F)
-        n = self._lib.afi_discriminator_fwd_ws_floats(F, N, H, W)
+        mode = 1 if backward_follows else (3 if stats_only else 2)
+        # what THIS context's call of this kind writes (ABI v7): the kept F(4x4) input planes only where a backward reads them
+        n = self._lib.afi_discriminator_fwd_ws_floats_ex(_lib.current_ctx().handle, F, N, H, W, mode)
         ws = self._scratch(ws_key, n, x.device)
         logits = self._scratch(ws_key + "_logits", N * H * W, x.device)
         call("afi_discriminator_fwd_paired" if paired else "afi_discriminator_fwd", C.byref(self._dprm), ops.view_of(x), N, H, W,
-             C.c_void_p(logits.data_ptr()), 1 if backward_follows else (3 if stats_only else 2), C.c_void_p(ws.data_ptr()), n, ops.stream_ptr())
+             C.c_void_p(logits.data_ptr()), mode, C.c_void_p(ws.data_ptr()), n, ops.stream_ptr())
         return logits, ws
 
     def _d_backward(self, x: torch.Tensor, ws: torch.Tensor, dlogits: torch.Tensor, paired: bool = False):

@@ -236,6 +236,13 @@ typedef struct afi_disc_params {
 } afi_disc_params_t;
 
 long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W);
+/* ABI v7.  The same for ONE context and ONE kind of call (`training` as afi_discriminator_fwd takes it): what that call really writes.  The
+ * context-free query above is an upper bound for every context and mode -- it reserves the F(4x4) input planes a training forward of blocks 1 and
+ * 2 may keep for its backward's weight gradient (36 x tiles x F[n] floats each: 0.6 + 1.25 GB at 2x200x336) -- this one reserves them only
+ * where the context's arithmetic, AFI_OPT_WINOGRAD_F4_FORWARD / F16_PRESPLIT / D_FOLD_BN_APPLY and training == 1 make the forward keep them
+ * (the default context: block 2 only).  Every other offset of the layout (afi_discriminator_ws_layout) is the same either way, and a workspace
+ * sized by either query serves afi_discriminator_fwd / _bwd under that context. */
+long long afi_discriminator_fwd_ws_floats_ex(const afi_ctx_t* ctx, const int F[4], int N, int H, int W, int training);
 long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W);
 /* Where afi_discriminator_fwd (training != 0) keeps what afi_discriminator_bwd reads, as offsets in floats into the forward
  * workspace: off12 = { c[0..2] conv outputs [P][F(n+1)], y[0..2] activations, mean[0..2], invstd[0..2] }.  For parity tooling

@@ -94,7 +94,7 @@ def test_paired_call_equals_two_calls(amd, Cf, N, H, W, training):
             assert (g1[k] - ref).abs().max().item() <= 2e-3 * den, (k, (g1[k] - ref).abs().max().item(), den)
 
 
-def test_paired_call_refuses_odd_batches_and_the_folded_affine(amd):
+def test_paired_call_refuses_odd_batches_and_ignores_the_folded_affine(amd):
     from afigan_amd import _lib, ops
     D = amd.Discriminator(in_filters=16).cuda()
     net = D.Discriminators[0]
@@ -107,18 +107,24 @@ def test_paired_call_refuses_odd_batches_and_the_folded_affine(amd):
     with pytest.raises(_lib.AfiError):
         _lib.call("afi_discriminator_fwd_paired", C.byref(prm), ops.view_of(x), 3, 8, 12, C.c_void_p(logits.data_ptr()), 1, C.c_void_p(ws.data_ptr()), n,
                   ops.stream_ptr())
-    # the folded BatchNorm affine is one per tensor: a paired call under it is refused, not silently given the first half's statistics
-    cx = _lib.Ctx()
-    cx.set_option("d_fold_bn_apply", 1)
-    lg4 = torch.empty(4 * 40 * 40, device="cuda")
+    # the folded BatchNorm affine is one per tensor: a paired call under AFI_OPT_D_FOLD_BN_APPLY runs UNFOLDED (each half has its own affine) and gives
+    # the results of the same call without the option, bit for bit
     D2 = amd.Discriminator(in_filters=128).cuda()
     net2 = D2.Discriminators[0]
-    prm2, keep2 = net2._param_struct(net2._ordered_params())
     F2 = (C.c_int * 4)(*net2.F)
-    xb = ops.new_pixel_major(4, 128, 40, 40, "cuda", zero=True)
+    xb = ops.pixel_major(torch.randn((4, 128, 40, 40), generator=torch.Generator().manual_seed(3)).cuda())
     nb = lib.afi_discriminator_fwd_ws_floats(F2, 4, 40, 40)
-    wsb = torch.empty(nb, device="cuda")
-    with _lib.use_ctx(cx), pytest.raises(_lib.AfiError):
-        _lib.call("afi_discriminator_fwd_paired", C.byref(prm2), ops.view_of(xb), 4, 40, 40, C.c_void_p(lg4.data_ptr()), 1, C.c_void_p(wsb.data_ptr()), nb,
-                  ops.stream_ptr())
-    torch.cuda.synchronize()
+    outs = []
+    for flag in (0, 1):
+        cx = _lib.Ctx()
+        cx.set_option("d_fold_bn_apply", flag)
+        D2.load_state_dict({k: v.clone() for k, v in D2.state_dict().items()})      # (fresh running statistics each way)
+        prm2, keep2 = net2._param_struct(net2._ordered_params())
+        lg4 = torch.empty(4 * 40 * 40, device="cuda")
+        wsb = torch.empty(nb, device="cuda")
+        with _lib.use_ctx(cx):
+            _lib.call("afi_discriminator_fwd_paired", C.byref(prm2), ops.view_of(xb), 4, 40, 40, C.c_void_p(lg4.data_ptr()), 2, C.c_void_p(wsb.data_ptr()), nb,
+                      ops.stream_ptr())
+        torch.cuda.synchronize()
+        outs.append(lg4.clone())
+    assert torch.equal(outs[0], outs[1])

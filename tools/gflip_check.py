@@ -51,6 +51,6 @@ runs = {"torch fp32 ops": torch_run(torch.float32), "direct (winograd = 0)": hip
         "F(2x2) forwards in G": hip_run({"winograd_f4_forward": f4 & ~16}), "F(4x4) forwards in G": hip_run({"winograd_f4_forward": f4 | 16})}
 live = [k for k in ref if ref[k].norm() > 1e-9 * ref[k].numel() ** 0.5]
 for tag, o in runs.items():
-    worst = max(((o[k] - ref[k]).norm() / ref[k].norm()).item() for k in live)
+    worst, wname = max((((o[k] - ref[k]).norm() / ref[k].norm()).item(), k) for k in live)
     dx = ((o["dx"] - ref["dx"]).norm() / ref["dx"].norm()).item()
-    print(f"{tag:26s} vs fp64: dx rel-L2 {dx:.3e}   worst tensor rel-L2 {worst:.3e}", flush=True)
+    print(f"{tag:26s} vs fp64: dx rel-L2 {dx:.3e}   worst tensor rel-L2 {worst:.3e} ({wname})", flush=True)
