@@ -882,10 +882,16 @@ AfiF16Bound afi_f16_bound(const float* amax, int kind) {
     }
     return b;
 }
-// the ONE process-wide switch of this file, for the micro-benchmark tools/micro/nt_f16_ablate.py only: which ablated instantiation of the
-// 128 x 128 kernel the next launches take (afi_gemm_f16.h: ABL, wrong results but for bit 16), + 32 = never the 256 x 256 tile.  0 = the product.
+// A/B builds only (-DAFI_ABLATIONS, e.g. AFI_HIPCC_FLAGS=-DAFI_ABLATIONS python __graft_entry__.py --force into a copy selected through AFI_LIB_PATH;
+// tools/micro/nt_f16_ablate.py): ONE process-wide switch naming which ablated instantiation of the 128 x 128 kernel the next launches take
+// (afi_gemm_f16.h: ABL, wrong results but for bit 16), + 32 = never the 256 x 256 tile.  The product build compiles neither the setter nor the
+// eleven ablated kernels: nothing in the shipped library is process-global (include/afigan_hip.h), and no exported call can make the GEMM wrong.
+#ifdef AFI_ABLATIONS
 static int g_nt_abl = 0;
 extern "C" void afi_debug_set_nt_ablation(int v) { g_nt_abl = v; }
+#else
+static constexpr int g_nt_abl = 0;
+#endif
 // a_pre: A holds the planes already split into fp16 pieces (winograd.hip, afi_store_split4) with the scales of `ab`
 int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st,
                              bool a_pre, long long nt256_min_tiles) {
@@ -914,6 +920,7 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
         hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 0, true>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
         return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
     }
+#ifdef AFI_ABLATIONS
     const int abl = g_nt_abl & 31;
     if (abl == 1) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 1>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
     else if (abl == 2) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 2>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
@@ -926,7 +933,9 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
     else if (abl == 10) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 10>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
     else if (abl == 20) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 20>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
     else if (abl == 24) hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4, 24>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
-    else hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
+    else
+#endif
+    hipLaunchKernelGGL((afi_gemm_nt_f16x3_kernel<4>), dim3(chunk * ntn * 8), dim3(256), lds, st, g, ab, ntn, ntm, chunk);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 // pre: Q and V hold the planes already split into fp16 pieces

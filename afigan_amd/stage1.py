@@ -434,7 +434,8 @@ class Stage1Step:
         return out, ws
 
     def _paired(self, x: torch.Tensor) -> bool:
-        # (a separate threshold for the G phase's two forwards was measured: never / 40,000 / always = 81.0-81.1 / 80.5-81.3 / 81.1-82.1 ms per step: one knob)
+        # (a separate threshold for the G phase's two forwards was measured: never / 40,000 / always = 81.0-81.1 / 80.5-81.3 / 81.1-82.1 ms per step:
+        # one knob)
         return 0 < x.shape[0] * x.shape[2] * x.shape[3] <= self.pair_d_max_pixels
 
     def _pair(self, level: int, first: torch.Tensor, second: torch.Tensor) -> torch.Tensor:

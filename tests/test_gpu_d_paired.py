@@ -128,3 +128,31 @@ def test_paired_call_refuses_odd_batches_and_ignores_the_folded_affine(amd):
         torch.cuda.synchronize()
         outs.append(lg4.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("k", [0, 10])
+def test_paired_halves_of_unlike_scale_bound(amd, k):
+    """under f16x3 the two halves of a paired call share ONE operand scale per Winograd plane in the first conv (behind it every
+    BatchNorm has normalised the halves separately).  A half whose largest magnitude lies 2^k below the other's keeps 22 - k significand bits
+    there.  Measured here at 2 x 256 x 25 x 42 per half (the Winograd path) with the second half scaled by 2^-k: logits of BOTH halves against
+    the two separate calls.  k = 0: 2e-5 (rounding).  k = 10: the small half's first-conv operands carry 12 bits -> its logits agree to <= 2e-3
+    (2^-12 relative on c0, amplified by nothing: BatchNorm rescales it), the large half's stay at 2e-5.  The stage-1 engine pairs D(real) with
+    D(fake) -- guide features and the interpolator's reconstruction of them: like scale by construction; a caller with halves of unlike
+    scale pairs nothing (Stage1Step(pair_d_max_pixels=0)) or runs the pair under fp32 / bf16x6, which split exactly."""
+    Cf, N, H, W = 256, 2, 25, 42
+    D0 = amd.Discriminator(in_filters=Cf).cuda()
+    D0.load_state_dict(orc.closed_form_discriminator_params(Cf))
+    D0.train()
+    gen = torch.Generator().manual_seed(9)
+    xs = [torch.randn((N, Cf, H, W), generator=gen).cuda(), (torch.randn((N, Cf, H, W), generator=gen) * 2.0 ** -k).cuda()]
+    res = {}
+    for paired in (False, True):
+        res[paired] = _run(amd, copy.deepcopy(D0), xs, (1.0, 0.0), paired, training=2)[0]
+    half = N * H * W
+    big = lambda t: t[:half]            # noqa: E731
+    small = lambda t: t[half:]          # noqa: E731
+    e_big = ((big(res[True]) - big(res[False])).abs().max() / big(res[False]).abs().max()).item()
+    e_small = ((small(res[True]) - small(res[False])).abs().max() / small(res[False]).abs().max()).item()
+    print(f"halves 2^{k} apart: paired vs separate logits, large half {e_big:.2e}, small half {e_small:.2e}")
+    assert e_big <= 2e-5 + 1e-6
+    assert e_small <= (2e-5 if k == 0 else 2e-3)

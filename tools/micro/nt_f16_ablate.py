@@ -30,6 +30,9 @@ def kernel_ms(lib, fn, iters=10):
 
 def main():
     lib = _lib.load()
+    if not hasattr(lib, "afi_debug_set_nt_ablation"):
+        raise SystemExit("this library was built without -DAFI_ABLATIONS: build an A/B copy (AFI_HIPCC_FLAGS=-DAFI_ABLATIONS, see csrc/igemm.hip) and select it "
+                         "with AFI_LIB_PATH -- the product build carries neither the ablated kernels nor their process-wide switch")
     a = [int(v) for v in sys.argv[1:]]
     cases = [tuple(a[i:i + 4]) for i in range(0, len(a), 4)] or [(36, 8448, 1024, 1024), (16, 33664, 1024, 512), (36, 2176, 1024, 1024)]
     for planes, rows, N, K in cases:
