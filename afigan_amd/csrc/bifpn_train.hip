@@ -56,13 +56,22 @@ __global__ __launch_bounds__(256) void afi_fuse_swish_bwd_kernel(const float* __
     if (threadIdx.x < 3)
         partial[(long long)blockIdx.x * 4 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
-// dw[k] = sum over blocks, fp64, fixed order
-__global__ void afi_fuse_swish_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int nw, float* __restrict__ dw) {
-    const int k = threadIdx.x;
-    if (k >= nw) return;
+// dw[k] = sum over blocks, fp64, fixed order: 64 lanes per weight, each summing every 64th block's partial (independent loads in flight), the
+// lanes meeting through LDS in lane order -- bit-reproducible, and 40 us -> a few (the one-thread-per-weight walk was 2048 dependent loads:
+// 2.3 ms of a BiFPN training pass over its 56 nodes, profiles/r06/kernel_stats_bifpn_train_5iters.csv of the first pass)
+__global__ __launch_bounds__(256) void afi_fuse_swish_bwd_finalize_kernel(const float* __restrict__ partial, int blocks, int nw, float* __restrict__ dw) {
+    __shared__ double red[4][64];
+    const int k = threadIdx.x & 3, ln = threadIdx.x >> 2;
     double s = 0.0;
-    for (int i = 0; i < blocks; ++i) s += (double)partial[(long long)i * 4 + k];
-    dw[k] = (float)s;
+    if (k < nw)
+        for (int i = ln; i < blocks; i += 64) s += (double)partial[(long long)i * 4 + k];
+    red[k][ln] = s;
+    __syncthreads();
+    if (ln == 0 && k < nw) {
+        double t = 0.0;
+        for (int j = 0; j < 64; ++j) t += red[k][j];
+        dw[k] = (float)t;
+    }
 }
 extern "C" long long afi_fuse_swish_bwd_scratch_floats(void) { return (long long)AFI_BT_MAX_BLOCKS * 4; }
 extern "C" int afi_fuse_swish_bwd(const float* a, const float* b, const float* c_or_null, const float* w_dev, const float* dout, float* da_or_null,
@@ -74,7 +83,7 @@ extern "C" int afi_fuse_swish_bwd(const float* a, const float* b, const float* c
     hipLaunchKernelGGL(afi_fuse_swish_bwd_kernel, dim3(blocks), dim3(256), 0, st, a, b, c_or_null, w_dev, dout, da_or_null, db_or_null, dc_or_null, scratch,
                        n >> 2);
     if (dw_or_null)
-        hipLaunchKernelGGL(afi_fuse_swish_bwd_finalize_kernel, dim3(1), dim3(64), 0, st, (const float*)scratch, (int)blocks, c_or_null ? 3 : 2, dw_or_null);
+        hipLaunchKernelGGL(afi_fuse_swish_bwd_finalize_kernel, dim3(1), dim3(256), 0, st, (const float*)scratch, (int)blocks, c_or_null ? 3 : 2, dw_or_null);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
@@ -124,9 +133,16 @@ __global__ __launch_bounds__(256) void afi_dwconv3x3_wgrad_kernel(const float* _
 __global__ void afi_dwconv3x3_wgrad_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ dw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (tap, channel)
     if (i >= 9 * C) return;
-    double s = 0.0;
-    for (int k = 0; k < chunks; ++k) s += (double)partial[(long long)k * 9 * C + i];
-    dw[i] = (float)s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;              // four independent chains (fixed assignment of chunks: bit-reproducible), four loads in flight
+    int k = 0;
+    for (; k + 3 < chunks; k += 4) {
+        s0 += (double)partial[(long long)k * 9 * C + i];
+        s1 += (double)partial[(long long)(k + 1) * 9 * C + i];
+        s2 += (double)partial[(long long)(k + 2) * 9 * C + i];
+        s3 += (double)partial[(long long)(k + 3) * 9 * C + i];
+    }
+    for (; k < chunks; ++k) s0 += (double)partial[(long long)k * 9 * C + i];
+    dw[i] = (float)((s0 + s1) + (s2 + s3));
 }
 extern "C" long long afi_dwconv3x3_wgrad_scratch_floats(int C) { return (long long)AFI_DWW_MAX_CHUNKS * 9 * C; }
 extern "C" int afi_dwconv3x3_wgrad(const float* dy, const float* x, int N, int H, int W, int C, float* dw9c, float* scratch, void* stream) {
