@@ -106,6 +106,11 @@ class Stage2Adversarial:
         self._names = []
         self._bstream = None
 
+    def set_option(self, name: str, value: int) -> None:
+        """A library option (afi_ctx_set_option) on both of the engine's contexts, forward and backward (Stage1Step.set_option)."""
+        self._helper.ctx.set_option(name, value)
+        self._helper.bctx.set_option(name, value)
+
     def d_step(self, guide_feats: Sequence[torch.Tensor], fpn_feats: Sequence[torch.Tensor]):
         """stage2_trainer.py:306-342: BCE(D(real),1) + BCE(D(fake.detach()),0) over the levels, backward, D optimizer step."""
         if not self.D.training:

@@ -586,13 +586,13 @@ def test_interpolator_default_gradient_deviation_not_above_torch_fp32(amd):
     sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
 
     def torch_run(dt):
-        p = {k: v.to(dt).contiguous().requires_grad_(True) for k, v in sd.items()}
-        xx = x0.to(dt).requires_grad_(True)
+        p = {k: v.detach().clone().to(dt).contiguous().requires_grad_(True) for k, v in sd.items()}       # (clone: .to(same dtype) is the tensor itself)
+        xx = x0.detach().clone().to(dt).requires_grad_(True)
         (orc.generator_forward(xx, p, n_rdb=3) * r.to(dt)).sum().backward()
         return {"dx": xx.grad.double(), **{n: p[n].grad.double() for n in names}}
 
     ref, t32 = torch_run(torch.float64), torch_run(torch.float32)
-    x = x0.clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = x0.detach().clone().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     (G(x) * r).sum().backward()
     lib = {"dx": x.grad.double(), **{n: q.grad.double() for n, q in G.named_parameters()}}
     live = [k for k in ref if ref[k].norm() > 1e-9 * ref[k].numel() ** 0.5]

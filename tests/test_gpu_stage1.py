@@ -372,12 +372,14 @@ def test_stage1_engine_state_round_trip(amd):
 
     Ga, Da = copy.deepcopy(G0), copy.deepcopy(D0)
     ref = amd.Stage1Step(Ga, Da, **sched)
+    ref.set_option("deterministic", 1)                   # (every engine of this test: it is about the state that travels, not about the atomics' summation order)
     for lr_f, hr_f in batches:
         ref.run_step(lr_f, hr_f)
     want = flat(Ga, Da)
 
     Gb, Db = copy.deepcopy(G0), copy.deepcopy(D0)
     first = amd.Stage1Step(Gb, Db, **sched)
+    first.set_option("deterministic", 1)
     for lr_f, hr_f in batches[:2]:
         first.run_step(lr_f, hr_f)
     torch.cuda.synchronize()
@@ -396,6 +398,7 @@ def test_stage1_engine_state_round_trip(amd):
         Dc = amd.Discriminator(in_filters=C).cuda()
         Gc.load_state_dict(ckpt["G"]); Dc.load_state_dict(ckpt["D"])
         eng = amd.Stage1Step(Gc, Dc, **sched)
+        eng.set_option("deterministic", 1)
         sd = copy.deepcopy(ckpt["engine"])
         if not with_momentum:
             for net in ("G_optimizer", "D_optimizer"):

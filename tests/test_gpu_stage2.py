@@ -235,11 +235,13 @@ def test_stage2_adversarial_state_round_trip(amd):
 
     def flat(D):
         return torch.cat([v.detach().double().reshape(-1).cpu() for v in D.state_dict().values()])
-    Da = fresh(); ea = amd.Stage2Adversarial(Da, **kw)
+    # (AFI_OPT_DETERMINISTIC on every engine of this test: it is about the state that travels, and with atomics-summed weight gradients one
+    #  LeakyReLU mask flipped by the summation order moves "where three steps land" by 3e-5 -- seen once in a full-suite run of round 6)
+    Da = fresh(); ea = amd.Stage2Adversarial(Da, **kw); ea.set_option("deterministic", 1)
     for g, f in batches:
         ea.d_step(g, f)
     want = flat(Da)
-    Db = fresh(); eb = amd.Stage2Adversarial(Db, **kw)
+    Db = fresh(); eb = amd.Stage2Adversarial(Db, **kw); eb.set_option("deterministic", 1)
     for g, f in batches[:2]:
         eb.d_step(g, f)
     torch.cuda.synchronize()
@@ -250,6 +252,7 @@ def test_stage2_adversarial_state_round_trip(amd):
         Dc = amd.Discriminator(in_filters=C).cuda()
         Dc.load_state_dict(ck["D"])
         ec = amd.Stage2Adversarial(Dc, **kw)
+        ec.set_option("deterministic", 1)
         sd = copy.deepcopy(ck["engine"])
         if not with_momentum:
             sd["D_optimizer"]["momentum_buffer"] = {k: torch.zeros_like(v) for k, v in sd["D_optimizer"]["momentum_buffer"].items()}
