@@ -94,6 +94,7 @@ struct AfiPixGemm {
     // the planes are F(4x4) and written split into fp16 pieces -- the form the weight-gradient GEMM of the same conv reads, so a backward
     // pass can take them instead of transforming the input again (nets.hip: disc_v_shared decides on both sides)
     float* v_keep;
+    int nt_local_sums;                                        // Winograd form under f16x3: the NT GEMM sums each k-step in a fresh fragment (AFI_OPT_F16_LOCAL_SUMS)
 };
 #define AFI_WK6_STAGE_BYTES 6144
 // one weight (or weight view) to turn into such an image: the B addressing of AfiPixGemm (b_rc = 0: row n at B + n*b_sRow + tap*b_sTap + c;

@@ -268,7 +268,15 @@ __global__ __launch_bounds__(256, MINW) void afi_gemm_nt_f16x3_kernel(const AfiG
 // One block per CU.  Rows beyond a plane's end (rows_per_plane is a multiple of 128, not 256) are read from the plane's last row and never
 // stored.  B comes from the two 128-column images 2 tile_n, 2 tile_n + 1 ([hi 8 KB | lo 8 KB] per stage each).
 // ------------------------------------------------------------------------------------------------
-template <bool APRE>
+// LOCAL (AFI_OPT_F16_LOCAL_SUMS): the three products of a k-step are summed in a FRESH fragment (the first MFMA takes a zero C) and that
+// fragment is added to the accumulator by one fp32 vector add, instead of three MFMAs accumulating into it.  Same products; what changes
+// is how often the large accumulator is rounded: an fp32 accumulate rounds at the magnitude of the accumulator, whatever the addend, so
+// three accumulating MFMAs per k-step (each with its own internal passes) round it 3+ times per k-step and the local form ONCE -- the
+// fresh fragment holds one k-step's 96 products, 1 / sqrt(K / 32) of the final magnitude, where roundings cost nothing.  Measured on the
+// discriminator's gradients (their LeakyReLU masks are decided by the forward convs' rounding): DESIGN.md 4b.  8 more registers, 64 vector
+// adds per wave and stage beside 48 MFMAs, no extra staging (a two-walk form -- all cross products first, then all hi x hi -- bought the
+// same accuracy for 1.5x the staging and was 1.7x slower: profiles/r06/two_walk_gemm_rejected.txt).
+template <bool APRE, bool LOCAL = false>
 __global__ __launch_bounds__(1024, 4) void afi_gemm_nt_f16x3_w16_kernel(const AfiGemmNT p, const AfiF16Bound ab, int ntile_n, int ntile_m, int chunk, int tiles_per_plane) {
     constexpr int BM = 256, BK = 32;
     constexpr int MI = 2, NI = 8;
@@ -357,12 +365,25 @@ __global__ __launch_bounds__(1024, 4) void afi_gemm_nt_f16x3_w16_kernel(const Af
             f16x8 nh = bh, nl = bl;
             if (ni + 1 < NI) { nh = *(const f16x8*)(sm + fb_off[ni + 1]); nl = *(const f16x8*)(sm + PART_B + fb_off[ni + 1]); }
             __builtin_amdgcn_sched_barrier(0);               // (the reads are ISSUED here; left alone hipcc sinks them to just in front of their use)
+            if (LOCAL) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                f32x4 t[MI];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
+                for (int mi = 0; mi < MI; ++mi) t[mi] = mfma(al[mi], bh, z);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
+                for (int mi = 0; mi < MI; ++mi) t[mi] = mfma(ah[mi], bl, t[mi]);
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
+                for (int mi = 0; mi < MI; ++mi) t[mi] = mfma(ah[mi], bh, t[mi]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] += t[mi];
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(al[mi], bh, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bl, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = mfma(ah[mi], bh, acc[mi][ni]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             bh = nh; bl = nl;
         }

@@ -894,7 +894,7 @@ static constexpr int g_nt_abl = 0;
 #endif
 // a_pre: A holds the planes already split into fp16 pieces (winograd.hip, afi_store_split4) with the scales of `ab`
 int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st,
-                             bool a_pre, long long nt256_min_tiles) {
+                             bool a_pre, long long nt256_min_tiles, bool local_sums) {
     if (planes <= 0 || planes > 36 || rows_per_plane <= 0 || N <= 0 || K <= 0 || !ab.amax) return AFI_ERR_BAD_ARG;
     if ((rows_per_plane % 128) || (N % 128) || (K % 32)) return AFI_ERR_UNSUPPORTED;
     AfiGemmNT g{A, (const float*)Bimg, C, rows_per_plane, planes, N, K};
@@ -907,6 +907,13 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
     // the 256 x 256 tile (half the operand bytes per product) where it fills the chip: 256-column multiples, at least two rounds of CUs
     const int tpp = afi_cdiv(rows_per_plane, 256);
     const long long tiles256 = (long long)planes * tpp * (N / 256);
+    if (local_sums && a_pre && !(N % 256)) {              // the k-step-local summation order lives in the 256 x 256 kernel on pre-split planes: taken whatever the tile count
+        if (!afi_opt_in_big_lds((const void*)afi_gemm_nt_f16x3_w16_kernel<true, true>)) return AFI_ERR_LAUNCH;
+        const int ntm2 = planes * tpp, ntn2 = N / 256, chunk2 = afi_cdiv(ntm2, 8);
+        prof.split = 7;                                    // (afi_profile_dump: 7 = the k-step-local form)
+        hipLaunchKernelGGL((afi_gemm_nt_f16x3_w16_kernel<true, true>), dim3(chunk2 * ntn2 * 8), dim3(1024), 16 * 16 * 132 * 4, st, g, ab, ntn2, ntm2, chunk2, tpp);
+        return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+    }
     if (nt256_min_tiles > 0 && !(g_nt_abl & 32) && !(N % 256) && tiles256 >= nt256_min_tiles) {
         if (!afi_opt_in_big_lds(a_pre ? (const void*)afi_gemm_nt_f16x3_w16_kernel<true> : (const void*)afi_gemm_nt_f16x3_w16_kernel<false>)) return AFI_ERR_LAUNCH;
         const int ntm2 = planes * tpp, ntn2 = N / 256, chunk2 = afi_cdiv(ntm2, 8);

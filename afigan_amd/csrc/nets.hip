@@ -24,7 +24,7 @@ long long afi_f16_image_bytes(int planes, int N, int K);
 int afi_launch_absmax_planes(const float* X, long long per_plane, int planes, float* out, hipStream_t st);
 AfiF16Bound afi_f16_bound(const float* amax, int kind);    // kind: 0 exact per-plane maxima, 1 / 2 F(2x2) / F(4x4) input planes, 3 / 4 F(2x2) / F(4x4) dY planes
 int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int planes, long long rows_per_plane, int N, int K, const AfiF16Bound& ab, hipStream_t st,
-                             bool a_pre = false, long long nt256_min_tiles = 512);
+                             bool a_pre = false, long long nt256_min_tiles = 512, bool local_sums = false);
 int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
                              hipStream_t st, bool pre = false, bool deterministic = false);
 int afi_launch_wgrad_gemm(const AfiWgradGemm& p, hipStream_t st);
@@ -136,17 +136,22 @@ struct WinoWgradAccum {
 // Per-context options (afi_ctx_set_option; include/afigan_hip.h lists them).  Nothing in the library reads the environment: a choice that
 // changes numerics or scheduling is made by the caller, per context, and can be changed between calls.  Context-less calls use the defaults.
 struct AfiOptions { long long v[AFI_OPT_COUNT]; };
+#ifndef AFI_DEFAULT_LOCAL_SUMS
+#define AFI_DEFAULT_LOCAL_SUMS 12
+#endif
 #ifndef AFI_DEFAULT_F4_FORWARD
-// Block 2 only.  Round 6 decided it from profiles/r06/dflip_p{2,3}_*.txt (D fwd+bwd against fp64 at P2 and P3, 2-3 seeds each): the default is
-// the largest block set whose dx AND worst-parameter-gradient deviation stay below torch's own fp32 ops on the same inputs.  = 8 does (P3 0.87e-3 /
-// 1.24e-3 against torch 1.03e-3 / 1.38e-3; P2 1.14e-3 / 1.48e-3 against 1.24e-3 / 1.68e-3); = 12 (round 5's default) does not (1.19e-3 / 1.62e-3;
-// 1.48e-3 / 1.90e-3) and triples the LeakyReLU mask flips at 2x50x84 (42 against 19 over three seeds; torch-CPU fp32: 9).
-// tests/test_gpu_d_parity.py enforces both.  (A/B builds: -DAFI_DEFAULT_F4_FORWARD=0 / 1 / 12 ...)
-#define AFI_DEFAULT_F4_FORWARD 8
+// Blocks 1 and 2, with the k-step-local sums of AFI_OPT_F16_LOCAL_SUMS in both.  Round 6 decided it from profiles/r06/dflip_p{2,3}_*_6seeds_local_sums.txt
+// (D fwd+bwd against fp64 at P2 and P3, six seeds each): the default is the largest block set whose dx AND worst-parameter-gradient deviation stay
+// below torch's own fp32 ops on the same inputs.  Plain summation order: = 8 does (P3 0.97e-3 / 1.31e-3 against torch 1.15e-3 / 1.54e-3; P2 1.14e-3 /
+// 1.51e-3 against 1.21e-3 / 1.54e-3), = 12 -- round 5's default -- does not (1.27e-3 / 1.73e-3; 1.45e-3 / 1.91e-3) and triples the LeakyReLU mask
+// flips at 2x50x84.  With the local sums = 12 is BELOW = 8 (P3 0.88e-3 / 1.26e-3; P2 1.04e-3 / 1.33e-3) for 2.7 ms less per step; = 1 still fails
+// (block 0's planes are not pre-split: no local sums there).  tests/test_gpu_d_parity.py enforces the bar.  (A/B builds: -DAFI_DEFAULT_F4_FORWARD=..)
+#define AFI_DEFAULT_F4_FORWARD 12
 #endif
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ AFI_DEFAULT_F4_FORWARD, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
-                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0, /*DETERMINISTIC*/ 0, /*F16_PRESPLIT*/ 1, /*F16_NT256_MIN_TILES*/ 512}};
+                                            /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0, /*DETERMINISTIC*/ 0, /*F16_PRESPLIT*/ 1, /*F16_NT256_MIN_TILES*/ 512,
+                                            /*F16_LOCAL_SUMS*/ AFI_DEFAULT_LOCAL_SUMS}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -267,6 +272,7 @@ static long long wino4_tpad(int N, int H, int W) { return (((long long)N * ((H +
 // torch's own fp32 ops do); block 0 (256 input channels: the shortest sums) costs the most accuracy and buys the least time, and stays on F(2x2).
 // value 1: every block; otherwise bit n + 1 selects block n (2: block 0, 4: block 1, 8: block 2; sums combine)
 static bool wino_d_f4(const afi_ctx* cx, int n) { const long long v = afi_opt(cx, AFI_OPT_WINOGRAD_F4_FORWARD); return (v & 1) || ((v >> (n + 1)) & 1); }
+static bool disc_local_sums(const afi_ctx* cx, int n) { const long long v = afi_opt(cx, AFI_OPT_F16_LOCAL_SUMS); return (v & 1) || ((v >> (n + 1)) & 1); }
 static bool wino_f4(const afi_ctx* cx) { return afi_opt(cx, AFI_OPT_WINOGRAD_F4_BACKWARD) != 0; }
 // one size for both tilings: F(2x2,3x3) = 16 transform points over 2x2 tiles, F(4x4,3x3) = 36 points over 4x4 tiles
 // + the pre-split bf16 image of U the DMA GEMM stages (three 2-byte parts per element = 1.5 floats; afi_gemm_bf16.h)
@@ -500,7 +506,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
                    : afi_launch_wino_input(a, g.N, g.H, g.W, g.Ck, Tpad, Vb + ph * g.Ck, st, K, &g.a_bn, raise, a_pre ? &abound : nullptr));
     }
     if (dma) {
-        if (f16) AFI_TRY(afi_launch_gemm_nt_f16x3(Vb, Usp, Mb, np, Tpad, Nc, K, abound, st, a_pre, afi_opt(cx, AFI_OPT_F16_NT256_MIN_TILES)));
+        if (f16) AFI_TRY(afi_launch_gemm_nt_f16x3(Vb, Usp, Mb, np, Tpad, Nc, K, abound, st, a_pre, afi_opt(cx, AFI_OPT_F16_NT256_MIN_TILES), g.nt_local_sums != 0));
         else AFI_TRY(afi_launch_gemm_nt_bf16_dma(Vb, Usp, Mb, np, Tpad, Nc, K, dtype, st));
         return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
     }
@@ -527,12 +533,13 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
 static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
                      float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false,
                      double* stats = nullptr, int* stats_rows = nullptr, const AfiBnLoad* in_bn = nullptr, float* in_amax = nullptr, bool in_amax_known = false,
-                     float* v_keep = nullptr, float* stats_mm = nullptr) {
+                     float* v_keep = nullptr, float* stats_mm = nullptr, bool local_sums = false) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
     if (in_bn) g.a_bn = *in_bn;
     g.a_amax = in_amax; g.a_amax_known = in_amax_known ? 1 : 0;
     g.v_keep = v_keep;
+    g.nt_local_sums = local_sums ? 1 : 0;
     if (mode && z.p) { g.Z = z; g.z_lo = 0; g.z_hi = Nc; }
     if (stats_rows) *stats_rows = 0;
     if (stats && stats_rows && !mode) {
@@ -1893,7 +1900,7 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
             AFI_TRY(wino_conv(cx, 0, in, N, H, W, ci, prm->w[n], co, prm->b[n], dense_view(c, H, W, co), null_view(), ws + l.o_wino, l.n_wino, part_,
                               part_n_, st, /*fwd_f4=*/training != 1 || wino_d_f4(cx, n), fuse_stats ? stats : nullptr, &stats_rows, in_bn.mean ? &in_bn : nullptr,
                               slots ? amax + 4 * n : nullptr, /*known=*/in_known, keep ? ws + l.o_vkeep[n] : nullptr,
-                              fuse_stats && fold_n ? ws + l.o_stats_mm : nullptr));
+                              fuse_stats && fold_n ? ws + l.o_stats_mm : nullptr, /*local_sums=*/training == 1 && disc_local_sums(cx, n)));
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }

@@ -120,12 +120,13 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                  from 8192 pixels; 0: F(2x2,3x3) everywhere */
 #define AFI_OPT_WINOGRAD_F4_FORWARD 2         /* the discriminator forwards a backward follows (their conv outputs decide LeakyReLU masks), per block:
                                                  bit n + 1 puts block n on F(4x4) (2: block 0, 4: block 1, 8: block 2; sums combine); 1: every block;
-                                                 0: F(2x2) everywhere.  Default 8 (block 2 only): the largest block set whose gradient deviation from fp64
-                                                 stays below torch's own fp32 ops on the same inputs at P2 and at P3 (profiles/r06/dflip_p2_*.txt,
-                                                 dflip_p3_*.txt: D fwd+bwd, relative L2 of dx / worst parameter gradient, means over seeds; P3 | P2):
-                                                 torch fp32 1.03e-3 / 1.38e-3 | 1.24e-3 / 1.68e-3; = 0: 0.77e-3 / 1.07e-3 | 0.86e-3 / 1.21e-3;
-                                                 = 8: 0.87e-3 / 1.24e-3 | 1.14e-3 / 1.48e-3; = 12 (round 5's default): 1.19e-3 / 1.62e-3 | 1.48e-3 / 1.90e-3;
-                                                 = 1: 1.39e-3 / 1.81e-3 | 1.65e-3 / 2.09e-3.  tests/test_gpu_d_parity.py holds the default to that bar.
+                                                 0: F(2x2) everywhere.  Default 12 (blocks 1 and 2, with AFI_OPT_F16_LOCAL_SUMS = 12): the largest block set whose gradient
+                                                 deviation from fp64 stays below torch's own fp32 ops on the same inputs at P2 and at P3
+                                                 (profiles/r06/dflip_p2_*_6seeds_local_sums.txt, dflip_p3_*: D fwd+bwd, relative L2 of dx / worst parameter gradient, means
+                                                 over six seeds; P3 | P2): torch fp32 1.15e-3 / 1.54e-3 | 1.21e-3 / 1.54e-3; = 0: 0.79e-3 / 1.06e-3 | 0.88e-3 / 1.18e-3;
+                                                 = 8: 0.97e-3 / 1.31e-3 | 1.14e-3 / 1.51e-3; = 12 in the plain summation order (round 5's default): 1.27e-3 / 1.73e-3 |
+                                                 1.45e-3 / 1.91e-3; = 12 with the local sums: 0.88e-3 / 1.26e-3 | 1.04e-3 / 1.33e-3; = 1 with them: 1.32e-3 / 1.79e-3 |
+                                                 1.40e-3 / 1.76e-3.  tests/test_gpu_d_parity.py holds the default to that bar.
                                                  Bit 16: the interpolator's own forwards too (off: 15x the deviation on its worst parameter gradient for 1 ms) */
 #define AFI_OPT_BN_STATS_FP64 3               /* 1 (default): BatchNorm batch statistics accumulated in fp64 (torch's CPU accumulation type) */
 #define AFI_OPT_D_WINOGRAD_MIN_PIXELS 4       /* 1024: discriminator calls of fewer pixels stay direct (values below 1024 act as 1024) */
@@ -162,7 +163,13 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                * written in fp32 and split when the GEMM reads its fragments (same results; stage-1 step 86.6 against 84.4 ms) */
 #define AFI_OPT_F16_NT256_MIN_TILES 14        /* 512: the f16x3 NT GEMM takes its 256 x 256 tile (sixteen waves per block, half the operand bytes per product)
                                                * from this many tiles on (and 256-column multiples); 0: never (the 128 x 128 tile everywhere) */
-#define AFI_OPT_COUNT 15
+#define AFI_OPT_F16_LOCAL_SUMS 15             /* under AFI_DTYPE_F16X3, which of the discriminator's forward convs that a backward follows (training == 1: their rounding
+                                               * decides LeakyReLU masks) sum the three products of every k-step in a fresh fragment and add that fragment to the
+                                               * accumulator with ONE fp32 addition, instead of three accumulating MFMAs: bit n + 1 = block n, 1 = every block, 0 = none.
+                                               * Same products, fewer roundings of the large accumulator (an fp32 accumulate rounds at the accumulator's magnitude,
+                                               * whatever the addend).  Pre-split planes and 256-column multiples only (blocks 1 and 2 at the reference's widths; other
+                                               * shapes keep the plain order).  Default and measurements: DESIGN.md 0 / 4b */
+#define AFI_OPT_COUNT 16
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over

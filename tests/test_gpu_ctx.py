@@ -122,7 +122,7 @@ def test_context_options_replace_the_environment(amd):
     variable).  Winograd off / on for one discriminator call on one context: same logits to fp32 rounding, and the defaults come back."""
     from afigan_amd import _lib
     cx = _lib.Ctx()
-    assert cx.get_option("winograd") == 1 and cx.get_option("winograd_f4_forward") == 8 and cx.get_option("d_winograd_min_pixels") == 1024
+    assert cx.get_option("winograd") == 1 and cx.get_option("winograd_f4_forward") == 12 and cx.get_option("d_winograd_min_pixels") == 1024
     assert cx.get_option("g_winograd_min_pixels") == 2048 and cx.get_option("g_grouped_wgrad_max_pixels") == 3000 and cx.get_option("bn_stats_fp64") == 1
     lib = _lib.load()
     assert lib.afi_ctx_set_option(cx.handle, 99, 1) == 1 and lib.afi_ctx_set_option(cx.handle, 0, -1) == 1 and lib.afi_ctx_get_option(None, 0) == 1

@@ -17,17 +17,25 @@ import torch.nn.functional as F
 
 import afigan_amd as amd
 
-H, W = int(sys.argv[1]), int(sys.argv[2])
-seeds = [int(s) for s in sys.argv[3:]] or [0]
+_args = [a for a in sys.argv[1:] if not a.startswith("--dtype=")]
+_dtype = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--dtype=")), None)      # arithmetic of the big GEMMs (default: the library's)
+H, W = int(_args[0]), int(_args[1])
+seeds = [int(s) for s in _args[2:]] or [0]
 VARIANTS = [("torch32", None),
             ("direct", {"winograd": 0}),
             ("f2fwd (=0)", {"winograd_f4_forward": 0}),
             ("f4 block 2 (=8)", {"winograd_f4_forward": 8}),
             ("f4 block 1 (=4)", {"winograd_f4_forward": 4}),
             ("f4 blocks 1,2 (=12)", {"winograd_f4_forward": 12}),
-            ("f4 all (=1)", {"winograd_f4_forward": 1})]
+            ("f4 all (=1)", {"winograd_f4_forward": 1}),
+            ("=8, local sums blk 2", {"winograd_f4_forward": 8, "f16_local_sums": 8}),
+            ("=12, local sums blk 1", {"winograd_f4_forward": 12, "f16_local_sums": 4}),
+            ("=12, local sums blk 1,2", {"winograd_f4_forward": 12, "f16_local_sums": 12}),
+            ("=1, local sums blk 1,2", {"winograd_f4_forward": 1, "f16_local_sums": 12})]
 cx = amd._lib.current_ctx()
-defaults = {k: cx.get_option(k) for k in ("winograd", "winograd_f4_forward")}
+if _dtype:
+    cx.set_dtype(_dtype)
+defaults = {k: cx.get_option(k) for k in ("winograd", "winograd_f4_forward", "f16_local_sums")}
 
 
 def torch_grads(D, x, r, dt):
@@ -86,8 +94,8 @@ for k, v in defaults.items():
 print(f"D fwd+bwd at 2x256x{H}x{W}, dtype {cx.dtype}, seeds {seeds}: relative L2 against fp64 (dx | worst parameter gradient)")
 print(f"library default winograd_f4_forward = {defaults['winograd_f4_forward']}")
 hdr = "".join(f"  seed {s}: dx / worst " for s in seeds)
-print(f"{'forward convs':22s}{hdr}  mean: dx / worst")
+print(f"{'forward convs':24s}{hdr}  mean: dx / worst")
 for name, _ in VARIANTS:
     v = rows[name]
     cells = "".join(f"  {a:.3e} / {b:.3e}" for a, b in v)
-    print(f"{name:22s}{cells}  {sum(a for a, _ in v) / len(v):.3e} / {sum(b for _, b in v) / len(v):.3e}")
+    print(f"{name:24s}{cells}  {sum(a for a, _ in v) / len(v):.3e} / {sum(b for _, b in v) / len(v):.3e}")
