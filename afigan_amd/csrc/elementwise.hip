@@ -556,6 +556,31 @@ __global__ void afi_bn_apply_lrelu_kernel(const float* __restrict__ x, float* __
     if (AMAX) afi_ew_amax_publish(am, amax);
 }
 
+// The largest magnitude of a tensor given as a view ([N][H][W][C], C contiguous, any pixel strides): one streaming pass, one conditional atomic
+// per block into a zero-filled slot.  For the discriminator's FIRST conv under f16x3: its input arrives from outside the library (guide
+// features, or the interpolator's output cropped by _reshape_stage1), so no producer has published its maximum; with this pass in front the
+// first block's planes are written pre-split like every other block's and its GEMM can take the k-step-local sums.
+__global__ __launch_bounds__(256) void afi_view_absmax_kernel(const AfiView x, int N, int H, int W, int C, float* amax) {
+    const int C4 = C >> 2;
+    const long long total = (long long)N * H * W * C4;
+    float am = 0.f;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C4) * 4;
+        long long r = e / C4;
+        const int xx = (int)(r % W); r /= W;
+        const int yy = (int)(r % H); const int n = (int)(r / H);
+        am = afi_ew_amax4(am, __builtin_nontemporal_load((const f32x4*)(x.p + (long long)n * x.sN + (long long)yy * x.sH + (long long)xx * x.sW + c)));
+    }
+    afi_ew_amax_publish(am, amax);
+}
+int afi_launch_view_absmax(AfiView x, int N, int H, int W, int C, float* amax, hipStream_t st) {
+    if (!x.p || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || !amax) return AFI_ERR_BAD_ARG;
+    long long grid = ((long long)N * H * W * (C >> 2) + 255) / 256;
+    grid = grid > 2048 ? 2048 : (grid < 1 ? 1 : grid);      // 256 CUs x 8 blocks, grid-stride the rest (afi_ew_grid, defined further down)
+    hipLaunchKernelGGL(afi_view_absmax_kernel, dim3((unsigned)grid), dim3(256), 0, st, x, N, H, W, C, amax);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // The largest magnitude of an activation y = lrelu(affine(c)) that NO kernel has evaluated yet, from the per-channel minimum / maximum of the
 // conv output c (fp32 rows [rows][2][C] the Winograd output transforms leave beside their statistics partials): the pinned affine of
 // afi_bn.h is monotonic per channel in c, every one of its fp32 operations is monotonic under rounding, and LeakyReLU is increasing, so the

@@ -50,6 +50,7 @@ int afi_launch_bn_stats(const float* x, long long P, int C, float* mean, float* 
                         float momentum = -1.f, bool fp64 = true);
 int afi_launch_bn_stats_from_partials(const double* partial, int rows, long long P, int C, float* mean, float* invstd, float* var_out, float* running_mean,
                                       float* running_var, hipStream_t st, long long* num_batches_tracked = nullptr, float eps = -1.f, float momentum = -1.f);
+int afi_launch_view_absmax(AfiView x, int N, int H, int W, int C, float* amax, hipStream_t st);
 int afi_launch_bn_act_amax(const float* mm, int rows, int C, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                            float* amax, hipStream_t st);
 int afi_wino_stats_rows(long long T, int C);               // winograd.hip: rows of fp64 partials a STATS output transform writes (0: not fused)
@@ -1886,6 +1887,13 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
     const bool slots = wino;
     if (slots && hipMemsetAsync(amax, 0, 16 * sizeof(float), st) != hipSuccess) return AFI_ERR_LAUNCH;
     bool in_known = false;                                  // block n's input maximum is published before its transform runs
+    // the first block's input comes from outside the library: where its GEMM is to take the k-step-local sums (pre-split planes only) its
+    // maximum is measured first, one streaming pass over x (137 MB, ~30 us at 2x200x336)
+    if (slots && training == 1 && disc_local_sums(cx, 0) && (cx ? cx->dtype : afi_default_dtype()) == AFI_DTYPE_F16X3 &&
+        afi_opt(cx, AFI_OPT_F16_PRESPLIT) != 0 && !(prm->F[0] & 31)) {
+        AFI_TRY(afi_launch_view_absmax(in, N, H, W, prm->F[0], amax, st));
+        in_known = true;
+    }
     for (int n = 0; n < 3; ++n) {       // Conv2d 3x3 + bias -> BN -> LeakyReLU (feature_patch_discriminator.py:35-38)
         const int ci = prm->F[n], co = prm->F[n + 1];
         float* c = ws + l.o_c[n]; float* y = ws + l.o_y[n];

@@ -89,9 +89,11 @@ def test_paired_call_equals_two_calls(amd, Cf, N, H, W, training):
             if den == 0.0:
                 assert g1[k].abs().max().item() == 0.0, k
                 continue
-            # LeakyReLU masks are recomputed from conv outputs that differ in the last fp32 bits between the two schedules: a flipped mask
-            # moves a gradient by one pixel's contribution (tests/test_gpu_d_parity.py measures the same effect against the reference)
-            assert (g1[k] - ref).abs().max().item() <= 2e-3 * den, (k, (g1[k] - ref).abs().max().item(), den)
+            # LeakyReLU masks are recomputed from conv outputs that differ in the last fp32 bits between the two schedules (at 4 x 13 x 21 the pair
+            # runs in Winograd form, the two single calls on the direct kernels): a flipped mask moves a gradient by one pixel's contribution --
+            # ONE flipped element moves a weight gradient by up to 1.3e-2 max-norm at these sizes (tests/test_gpu_d_parity.py, header).  The bar
+            # admits one such flip; a wrong half, a wrong statistic or a lost term moves a gradient by O(1)
+            assert (g1[k] - ref).abs().max().item() <= 1.5e-2 * den, (k, (g1[k] - ref).abs().max().item(), den)
 
 
 def test_paired_call_refuses_odd_batches_and_ignores_the_folded_affine(amd):

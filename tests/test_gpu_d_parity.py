@@ -15,7 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from d_parity_util import DProbe, rel  # noqa: E402
+from d_parity_util import DProbe, l2, rel  # noqa: E402
 
 TOL_GIVEN_MASKS_MAXNORM = 1e-4     # backward with the reference's masks: measured 1-2e-6 (fixture sizes), 2e-5 at 8400 px (Winograd F(4x4) gradients)
 TOL_FORWARD_MAXNORM = 1e-5         # saved conv outputs / activations vs fp64: measured <= 1.7e-6
@@ -89,6 +89,21 @@ def test_forward_statistics_and_mask_flips_on_the_winograd_forwards(amd, f4):
     tot_g, tot_c = sum(map(sum, lib_flips)), sum(map(sum, cpu_flips))
     print(f"winograd_f4_forward={f4}: flips {lib_flips} = {tot_g}; torch-CPU fp32 {cpu_flips} = {tot_c}")
     assert tot_g <= FLIP_FACTOR_WINOGRAD * tot_c + FLIP_SLACK, (lib_flips, cpu_flips)
+
+
+def test_local_sums_round_the_conv_outputs_less(amd):
+    """AFI_OPT_F16_LOCAL_SUMS (csrc/afi_gemm_f16.h: the three products of a k-step are summed in a fresh fragment and added to the accumulator by
+    one fp32 addition, instead of three accumulating MFMAs): the same products in an order that rounds the large accumulator once per k-step.
+    At 2x256x50x84 with F(4x4) forwards in blocks 1 and 2, the saved conv outputs of those blocks against the fp64 oracle: the relative-L2
+    rounding error with the local sums is below the plain order's (measured ~0.6x), both inside the forward bar."""
+    err = {}
+    for ls in (0, 12):
+        pr = DProbe(amd, 2, 50, 84, 5, options={"winograd_f4_forward": 12, "f16_local_sums": ls})
+        _check_forward(pr)
+        err[ls] = [l2(pr.saved(n)[0], pr.r64["c"][n].detach()) for n in range(3)]
+        del pr
+    print(f"conv-output rounding (relative L2 vs fp64) per block: plain order {err[0]}, local sums {err[12]}")
+    assert err[12][1] < 0.85 * err[0][1] and err[12][2] < 0.85 * err[0][2], err
 
 
 def test_default_forward_gradient_deviation_not_above_torch_fp32(amd):

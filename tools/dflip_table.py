@@ -28,10 +28,10 @@ VARIANTS = [("torch32", None),
             ("f4 block 1 (=4)", {"winograd_f4_forward": 4}),
             ("f4 blocks 1,2 (=12)", {"winograd_f4_forward": 12}),
             ("f4 all (=1)", {"winograd_f4_forward": 1}),
-            ("=8, local sums blk 2", {"winograd_f4_forward": 8, "f16_local_sums": 8}),
-            ("=12, local sums blk 1", {"winograd_f4_forward": 12, "f16_local_sums": 4}),
             ("=12, local sums blk 1,2", {"winograd_f4_forward": 12, "f16_local_sums": 12}),
-            ("=1, local sums blk 1,2", {"winograd_f4_forward": 1, "f16_local_sums": 12})]
+            ("=12, local sums all", {"winograd_f4_forward": 12, "f16_local_sums": 1}),
+            ("=1, local sums blk 1,2", {"winograd_f4_forward": 1, "f16_local_sums": 12}),
+            ("=1, local sums all", {"winograd_f4_forward": 1, "f16_local_sums": 1})]
 cx = amd._lib.current_ctx()
 if _dtype:
     cx.set_dtype(_dtype)
