@@ -45,8 +45,9 @@ PEAK_NOTE = ("fp32-equivalent TFLOP/s (2*M*N*K once per product); peak = dense f
              "GEMM on this step's largest shape: 922 TFLOP/s = 307 at three products (profiles/r05/hipblaslt_f16_ceiling.txt); the chip is "
              "power-limited under dense MFMA work (traffic.held_clock_ghz, traffic.mfma_busy_at_held_clock): DESIGN.md 4b")
 CONV_NOTE = ("3x3 convs with >= 128 channels both sides and >= 1024 pixels: Winograd.  F(4x4,3x3) (points {0,1,-1,1/2,-2,inf}) for data and "
-             "weight gradients, forward-only passes and D's block 2 (winograd_f4_forward = 8, decided from profiles/r06/dflip_p2/p3); "
-             "F(2x2,3x3) for the other forwards a backward follows.  Direct implicit GEMM on the fp32 MFMA elsewhere")
+             "weight gradients, forward-only passes and D's blocks 1 and 2 (winograd_f4_forward = 12 with k-step-local sums, f16_local_sums = 12: "
+             "below torch fp32's gradient deviation at P2 and P3, profiles/r06/dflip_*); F(2x2,3x3) for the other forwards a backward follows.  "
+             "Direct implicit GEMM on the fp32 MFMA elsewhere")
 
 
 def parse():
@@ -406,7 +407,7 @@ def main():
     # SURVEY 8(d)'s algorithmic (direct-convolution) FLOP count of the step over wall time and peak.  It can pass 1: the big 3x3 convs
     # run in Winograd form, which executes 2.25x (F(2x2,3x3)) / 4x (F(4x4,3x3)) fewer multiplies than the count assumes
     roofline["algorithmic_over_peak"] = flop_img * B * args.steps / elapsed / 1e12 / PEAK_FP32_MFMA_TFLOPS
-    roofline["winograd_multiply_reduction"] = ("4x F(4x4,3x3): data / weight gradients, forwards without a backward, D's block 2; "
+    roofline["winograd_multiply_reduction"] = ("4x F(4x4,3x3): data / weight gradients, forwards without a backward, D's blocks 1 and 2; "
                                                "2.25x F(2x2,3x3): the other forwards a backward follows")
     line = {
         "metric": "stage1_G+D_step_images_per_s", "value": n_img / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,

@@ -51,7 +51,9 @@ dom, out = record(f'{D}/pmc_hbm_fetch_write_steps1_one_stream.csv', lambda k: 'a
 # pre-split weights planes x N x K x 2 bytes x parts read, C rows x N fp32 written
 # (the f16x3 NT GEMM runs as four kernels -- the 256 x 256 tile on the large shapes and the 128 x 128 tile on the rest, each on fp32 or on pre-split A planes; the per-launch dump's `split` column says which --: the record is the
 #  one with the larger traffic, and its algorithmic bytes are those of ITS launches)
-code = {(False, False): 2, (True, False): 3, (True, True): 4, (False, True): 5}[('w16' in dom['kernel'], '<true>' in dom['kernel'] or 'true>' in dom['kernel'])]   # (igemm.hip: the dump's `split` column names the kernel)
+kn = dom['kernel']
+w16, pre, local = 'w16' in kn, ('<true' in kn or 'true>' in kn), '<true, true>' in kn     # (w16 kernel: <APRE, LOCAL>; 128-tile kernel: <MINW, ABL, APRE>)
+code = 7 if (w16 and local) else {(False, False): 2, (True, False): 3, (True, True): 4, (False, True): 5}[(w16, pre)]   # (igemm.hip: the dump's `split` column names the kernel)
 ln = [r for r in csv.DictReader(open(f'{D}/launches_bench_steps3_one_stream.csv')) if r['kind'].startswith('gemm_nt_f16x3') and int(r['split']) == code]
 if ln:
     alg = [4 * int(r['rows']) * int(r['k']) + 4 * int(r['planes']) * int(r['cols']) * int(r['k']) + 4 * int(r['rows']) * int(r['cols']) for r in ln]

@@ -23,7 +23,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tra
 echo step pmc done
 python3 $R/tools/stream_timeline.py $(find $O/trace -name "*kernel_trace.csv" | head -1) > $O/stream_timeline_two_stream.txt 2>&1 || true
 python3 $R/tools/gemm_nt_dtype.py > $O/gemm_dtypes.txt 2>&1 || true
-bash $R/tools/micro/knob_ab.sh "" "--option winograd_f4_forward=12" "--option winograd_f4_forward=0" "--option d_fold_bn_apply=1" "--dtype bf16x6" > $O/knob_ab.txt 2>&1 || true
+bash $R/tools/micro/knob_ab.sh "" "--option f16_local_sums=0" "--option winograd_f4_forward=8 --option f16_local_sums=0" "--option winograd_f4_forward=0" "--option winograd_f4_forward=1 --option f16_local_sums=1" "--option d_fold_bn_apply=1" "--dtype bf16x6" > $O/knob_ab.txt 2>&1 || true
 python3 $R/tools/micro/host_enqueue_probe.py 6 > $O/host_enqueue_probe.txt 2>&1 || true
 python3 $R/tools/micro/guide_overlap_probe.py 5 > $O/guide_overlap_probe.txt 2>&1 || true
 echo micro done
