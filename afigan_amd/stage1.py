@@ -241,9 +241,10 @@ class Stage1Step:
         self.pair_d_max_pixels = pair_d_max_pixels
         # data-parallel runs: the two gradient all-reduces are issued asynchronously and run beside work that does not need them -- D's
         # beside G's five backward passes (second stream), G's beside the G phase's D forwards (see _run_phases); False = blocking, in place
-        # Default (None): on where the asynchronous path has been exercised -- the gloo backend (two-rank tests, CPU and two ranks on one GPU) -- and
-        # OFF under nccl / RCCL until an RCCL run exists (tests/test_gpu_stage1.py::test_stage1_data_parallel_rccl passes overlap_comm=True and
-        # records the result where >= 2 GPUs are visible); blocking costs ~1 ms of exposed exchange per step (92.7 MB over xGMI)
+        # Default (None): OFF, under every backend.  Both placements are exercised (a one-rank RCCL communicator, two-rank gloo groups: tests/test_gpu_stage1.py)
+        # and both are measured wherever more than one rank runs (bench.py: comm.overlap_ab) -- the measurements that exist say blocking: two ranks on one
+        # GPU under gloo 186 against 213 ms per step (its wait blocks the HOST, which then cannot queue the G phase), a one-rank RCCL group 78.4 against
+        # 80.9 ms; no multi-GPU RCCL measurement exists.  Blocking costs at most the exchange itself (92.7 MB: ~1 ms per step over xGMI)
         self.overlap_comm = overlap_comm
         self._pending_work = []                             # collectives issued and not yet waited for (an error path waits for them: see run_step)
         self.comm_exposed_ms = None                         # measure_comm = True: [D, G] time the consuming stream waited for the collective, last step
@@ -264,7 +265,7 @@ class Stage1Step:
         self.world = torch.distributed.get_world_size(process_group) if distributed else 1
         self.backend = torch.distributed.get_backend(process_group) if distributed else None
         if self.overlap_comm is None:
-            self.overlap_comm = bool(distributed) and self.backend == "gloo"
+            self.overlap_comm = False
         for p in list(G.parameters()) + list(D.parameters()):
             ops._check_cuda(p)
         if self.distributed:        # DistributedDataParallel(...) ctor semantics: rank 0's weights everywhere (:80-89)

@@ -124,7 +124,7 @@ def rehearse_launch(args, world, rank):
             dist.broadcast(p_, src=0)
         small = os.environ.get("AFI_BENCH_REHEARSE_SMALL", "1") != "0"       # 1/64 of the real sizes: 8 ranks on this container's 8 cores
         bufs = {"D": torch.zeros(D_GRAD_FLOATS // (64 if small else 1)), "G": torch.zeros(G_GRAD_FLOATS // (64 if small else 1))}
-        overlap = bool(args.overlap_comm) if args.overlap_comm is not None else True        # (gloo: the engine's default is on)
+        overlap = bool(args.overlap_comm) if args.overlap_comm is not None else False       # (the engine's default: blocking)
         comm = {"backend": dist.get_backend(), "world_size_reported": dist.get_world_size(), "rank0_device": "cpu (rehearsal)",
                 "overlap_comm": overlap, "allreduce_alone": allreduce_alone(dist, torch, bufs, None, world, reps=2)}
         dist.barrier()
