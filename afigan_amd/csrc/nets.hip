@@ -54,7 +54,9 @@ int afi_launch_view_absmax(AfiView x, int N, int H, int W, int C, float* amax, h
 int afi_launch_bn_act_amax(const float* mm, int rows, int C, const float* mean, const float* invstd, const float* gamma, const float* beta, float slope,
                            float* amax, hipStream_t st);
 int afi_wino_stats_rows(long long T, int C);               // winograd.hip: rows of fp64 partials a STATS output transform writes (0: not fused)
+#ifndef AFI_STATS_MAX_ROWS
 #define AFI_STATS_MAX_ROWS 1024
+#endif
 int afi_launch_bn_apply_lrelu(const float* x, float* y, const float* mean, const float* invstd, const float* gamma, const float* beta,
                               long long P, int C, hipStream_t st, float slope = AFI_LRELU_SLOPE, float* amax = nullptr);
 int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* mean, const float* invstd, const float* gamma, float* dgamma,

@@ -273,7 +273,9 @@ int afi_launch_wino_output(const float* M, long long Tpad, int N, int H, int W, 
 // threads that share a channel quad (blockDim % (C / 4) == 0: a thread's quad never changes along its grid-stride walk) and writes ONE
 // row of partials [2][C]; afi_launch_bn_stats_from_partials sums the rows in a fixed order.  Replaces a full pass over the map
 // (afi_bn_stats_partial_kernel: 1.85 ms of a stage-1 step).
+#ifndef AFI_STATS_MAX_ROWS
 #define AFI_STATS_MAX_ROWS 1024
+#endif
 typedef double f64x4w __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void afi_stats_acc(f64x4w& s0, f64x4w& s1, f32x4& mn, f32x4& mx, f32x4 v) {
 #pragma unroll
