@@ -386,7 +386,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 4 ? 3 : 4)) void afi_pix_
 // ------------------------------------------------------------------------------------------------
 // Plain batched "NT" GEMM for the Winograd planes:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k]   (both operands K-contiguous),
 // every dimension tile-aligned (rows per plane % 128 == 0, N % 128 == 0, K % 32 == 0): no row table, no tap masks, no bounds
-// checks, no zero page, one 64-bit base per operand: a leaner instruction stream than the general kernel, which leaves room for a second fragment register set (152 registers)
+// checks, no zero page, one 64-bit base per operand: a leaner instruction stream than the general kernel, which leaves room for a second fragment register set
+// (152 registers)
 // (+4-5 % on the Winograd GEMMs).
 // Same tile, LDS layout, fragment order and MFMA loop as afi_pix_gemm_kernel<128,128,2,2,KC>.
 // ------------------------------------------------------------------------------------------------

@@ -241,7 +241,8 @@ class Stage1Step:
         self.pair_d_max_pixels = pair_d_max_pixels
         # data-parallel runs: the two gradient all-reduces are issued asynchronously and run beside work that does not need them -- D's
         # beside G's five backward passes (second stream), G's beside the G phase's D forwards (see _run_phases); False = blocking, in place
-        # Default (None): OFF, under every backend.  Both placements are exercised (a one-rank RCCL communicator, two-rank gloo groups: tests/test_gpu_stage1.py)
+        # Default (None): OFF, under every backend.  Both placements are exercised (a one-rank RCCL communicator, two-rank gloo groups:
+        # tests/test_gpu_stage1.py)
         # and both are measured wherever more than one rank runs (bench.py: comm.overlap_ab) -- the measurements that exist say blocking: two ranks on one
         # GPU under gloo 186 against 213 ms per step (its wait blocks the HOST, which then cannot queue the G phase), a one-rank RCCL group 78.4 against
         # 80.9 ms; no multi-GPU RCCL measurement exists.  Blocking costs at most the exchange itself (92.7 MB: ~1 ms per step over xGMI)

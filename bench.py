@@ -262,10 +262,27 @@ def main():
                                                "over the device plus the exchange -- not an exposure"}
         step.measure_comm = False
         log(f"profiled repeat done: {profiled_ms_per_step:.2f} ms/step with the event brackets on")
-    if dist is not None and os.environ.get("AFI_BENCH_OVERLAP_AB", "1") != "0":
-        # the other setting of overlap_comm on the same engine, same inputs, same K (never the headline): the first RCCL run measures both
+    def overlap_ab_leg(emit_on_timeout=None):
+        """The other setting of overlap_comm on the same engine, same inputs, same K (never the headline): the first multi-GPU run measures both.
+        It is the one leg of an N > 1 run that issues collectives no multi-GPU box has run yet, so for world > 1 it is the LAST thing every rank does,
+        behind a watchdog: if it has not finished within AFI_BENCH_AB_TIMEOUT_S (default 90) the rank leaves -- rank 0 after printing the line it
+        had already completed (`emit_on_timeout`), with the time-out recorded in comm.overlap_ab -- instead of taking the measured headline down."""
+        if dist is None or os.environ.get("AFI_BENCH_OVERLAP_AB", "1") == "0":
+            return
+        import threading
         other = not step.overlap_comm
         ab = {("overlapped" if step.overlap_comm else "blocking") + "_ms_per_step": round(elapsed / args.steps * 1e3, 3)}
+        comm["overlap_ab"] = ab
+
+        def bail():
+            ab["error"] = "timed out: abandoned (the headline above was measured before this leg started)"
+            if emit_on_timeout is not None:
+                emit_on_timeout()
+            os._exit(0)
+        dog = threading.Timer(float(os.environ.get("AFI_BENCH_AB_TIMEOUT_S", "90")), bail) if world > 1 else None
+        if dog is not None:
+            dog.daemon = True
+            dog.start()
         try:
             step.overlap_comm = other
             one_step(); sync()
@@ -280,8 +297,12 @@ def main():
             ab["error"] = f"{type(e).__name__}: {e}"[:300]
         finally:
             step.overlap_comm = not other
-        comm["overlap_ab"] = ab
+            if dog is not None:
+                dog.cancel()
         log(f"overlap_comm A/B: {ab}")
+
+    if world == 1:
+        overlap_ab_leg()                                   # (--dist-world-1: the engine is released before the single-GPU legs below)
     if rank == 0:
         lib.afi_profile_enable(0)
         if os.environ.get("AFI_PROFILE_DUMP"):            # per-launch CSV (shape, split, ms) for offline analysis
@@ -303,6 +324,7 @@ def main():
         assert params_identical, "parameters differ across ranks after the timed steps (all-reduce / broadcast broken)"
     if rank != 0:
         if dist is not None:
+            overlap_ab_leg()                               # (rank 0 joins it once its line is complete, below)
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -489,6 +511,8 @@ def main():
             cb["af_interpolator_gpu_ms"] = round(c1["ms"], 4)
             cb["af_interpolator_gpu_out_mpix_per_s"] = round(c1["out_mpix_per_s"], 3)
             cb["af_interpolator_gpu_over_cpu"] = round(c1["out_mpix_per_s"] / cb["af_interpolator_out_mpix_per_s"], 1)
+    if world > 1:
+        overlap_ab_leg(emit_on_timeout=lambda: print(json.dumps(line), flush=True))
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
