@@ -576,10 +576,16 @@ __global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_kernel(const AfiGemm
 // The weight-gradient GEMM on operands that arrive ALREADY SPLIT (winograd.hip, afi_store_split4: a row of a plane is
 // [32-channel block][hi: 32 x fp16 | lo: 32 x fp16]): nothing is converted or staged through registers -- four LDS-DMA instructions per
 // wave and half stage copy the [16 k][128 columns] fp16 images of Q hi, Q lo, V hi, V lo (wave w copies image w) with the transposed-read
-// swizzle on the SOURCE address, three 16 KB buffers go round (half stage h + 2 is requested behind the barrier of h, which also says
+// swizzle on the SOURCE address, AFI_TN_RING 16 KB buffers go round (half stage h + RING - 1 is requested behind the barrier of h, which also says
 // that every wave has left h - 1), fragments by ds_read_b64_tr_b16, 12 MFMAs (32x32x16) per wave and half stage.  One barrier per half stage.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_pre_kernel(const AfiGemmTN p, const AfiF16Bound qb, const AfiF16Bound vb, int ntile_m, int ntile_n, int kper) {
+#ifndef AFI_TN_RING
+// LDS buffers of the ring = half stages in flight + 1.  Round 6 A/B (same box, stage-1 step, three alternating rounds): 4 buffers / two blocks per CU
+// 72.6-73.9 against 71.3-72.4 ms for 3 buffers / three blocks (slower: occupancy matters more than prefetch depth); 2 buffers / FOUR blocks per CU
+// (128 registers, 7 of them spilled outside the loop) 72.6-73.3 against 73.4-73.9, one-stream 82.0-82.6 against 82.9: kept.
+#define AFI_TN_RING 2
+#endif
+__global__ __launch_bounds__(256, AFI_TN_RING == 3 ? 3 : (AFI_TN_RING == 2 ? 4 : 2)) void afi_gemm_tn_f16x3_pre_kernel(const AfiGemmTN p, const AfiF16Bound qb, const AfiF16Bound vb, int ntile_m, int ntile_n, int kper) {
     constexpr int BM = 128, BN = 128, HK = 16, WN = 2, MI = 2, NI = 2;
     constexpr int PART = HK * BM * 2;                        // 4 KB: [16 k][128 columns] fp16
     constexpr int BUF = 4 * PART;                            // [Q hi | Q lo | V hi | V lo]
@@ -614,14 +620,15 @@ __global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_pre_kernel(const Afi
     for (int i = 0; i < 4; ++i) { const int ch = (lane & 15) ^ (((lane >> 4) << 2) | i); ch_off[i] = (ch >> 2) * 128 + (ch & 3) * 16; }
     const long long row_bytes = ld * 4;
     auto issue = [&](int h) {
-        unsigned char* dst = smem_b + (h % 3) * BUF + wave * PART;
+        unsigned char* dst = smem_b + (h % AFI_TN_RING) * BUF + wave * PART;
         const unsigned char* s0 = src_row + (long long)h * HK * row_bytes;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gptr)(s0 + (long long)(4 * i) * row_bytes + ch_off[i]), (lptr)(dst + i * 1024), 16, 0, 0);
     };
     issue(0);
-    if (1 < nH) issue(1);
+    if (AFI_TN_RING > 2 && 1 < nH) issue(1);
+    if (AFI_TN_RING > 3 && 2 < nH) issue(2);
     const float s_q = afi_f16_scale(qb.amax[(long long)plane * qb.stride] * qb.cmul[plane]);
     const float s_v = afi_f16_scale(vb.amax[(long long)plane * vb.stride] * vb.cmul[plane]);
     const float inv_q = afi_pow2_inverse(s_q), inv_v = afi_pow2_inverse(s_v);
@@ -649,10 +656,11 @@ __global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_pre_kernel(const Afi
 
     for (int h = 0; h < nH; ++h) {
         // requests complete in order, four per half stage: with h + 1 requested too, vmcnt(4) = half stage h has landed
-        if (h + 1 < nH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (AFI_TN_RING > 3 && h + 2 < nH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (AFI_TN_RING > 2 && h + 1 < nH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // ... for every wave's image; and every wave has left half stage h - 1
-        if (h + 2 < nH) issue(h + 2);
-        const unsigned char* cur = smem_b + (h % 3) * BUF;
+        if (h + AFI_TN_RING - 1 < nH) issue(h + AFI_TN_RING - 1);
+        const unsigned char* cur = smem_b + (h % AFI_TN_RING) * BUF;
         f16x8 ah[MI], al[MI], bh[NI], bl[NI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
