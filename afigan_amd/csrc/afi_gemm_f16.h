@@ -585,8 +585,17 @@ __global__ __launch_bounds__(256, 3) void afi_gemm_tn_f16x3_kernel(const AfiGemm
 // (128 registers, 7 of them spilled outside the loop) 72.6-73.3 against 73.4-73.9, one-stream 82.0-82.6 against 82.9: kept.
 #define AFI_TN_RING 2
 #endif
-__global__ __launch_bounds__(256, AFI_TN_RING == 3 ? 3 : (AFI_TN_RING == 2 ? 4 : 2)) void afi_gemm_tn_f16x3_pre_kernel(const AfiGemmTN p, const AfiF16Bound qb, const AfiF16Bound vb, int ntile_m, int ntile_n, int kper) {
-    constexpr int BM = 128, BN = 128, HK = 16, WN = 2, MI = 2, NI = 2;
+#ifndef AFI_TN_WAVES
+// waves per 128 x 128 block: 4 (64 x 64 per wave) or, A/B, 8 (32 x 64 per wave: half the accumulators, six waves per SIMD at 80 registers with 34
+// spilled): round 6, same box, 72.2-73.2 against 72.2-72.5 ms per step, one-stream 82.1-82.7 against 82.0-82.7: no gain, 4 kept
+#define AFI_TN_WAVES 4
+#endif
+#ifndef AFI_TN_MINW
+#define AFI_TN_MINW (AFI_TN_WAVES == 8 ? 6 : (AFI_TN_RING == 3 ? 3 : (AFI_TN_RING == 2 ? 4 : 2)))
+#endif
+__global__ __launch_bounds__(64 * AFI_TN_WAVES, AFI_TN_MINW) void afi_gemm_tn_f16x3_pre_kernel(const AfiGemmTN p, const AfiF16Bound qb, const AfiF16Bound vb, int ntile_m, int ntile_n, int kper) {
+    constexpr int BM = 128, BN = 128, HK = 16, WN = 2, MI = AFI_TN_WAVES == 8 ? 1 : 2, NI = 2;
+    constexpr int IPW = 16 / AFI_TN_WAVES;                   // DMA instructions per wave and half stage (16 in all: four 4 KB images of four 1 KB instructions)
     constexpr int PART = HK * BM * 2;                        // 4 KB: [16 k][128 columns] fp16
     constexpr int BUF = 4 * PART;                            // [Q hi | Q lo | V hi | V lo]
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
@@ -611,7 +620,8 @@ __global__ __launch_bounds__(256, AFI_TN_RING == 3 ? 3 : (AFI_TN_RING == 2 ? 4 :
     // (lane >> 4 = row, lane & 15 = physical 16-byte chunk); the image's chunk ch of row r sits at ch ^ (((r & 3) << 2) | ((r >> 2) & 3)),
     // so the lane fetches logical chunk (lane & 15) ^ ((lane >> 4) << 2 | i): columns 8 ch .. 8 ch + 7 of the tile = 32-channel block ch >> 2,
     // 16 bytes (ch & 3) of its hi or lo half
-    const int op = wave >> 1, piece = wave & 1;
+    const int img = AFI_TN_WAVES == 8 ? wave >> 1 : wave, i0 = AFI_TN_WAVES == 8 ? 2 * (wave & 1) : 0;     // (eight waves: two per image, instructions i0, i0 + 1)
+    const int op = img >> 1, piece = img & 1;
     const long long ld = op ? p.N : p.M;                     // floats (= 4-byte units) per row of the operand
     const unsigned char* src_row = (const unsigned char*)((op ? p.V : p.Q) + ((long long)plane * p.rows_per_plane + k_begin + (lane >> 4)) * ld) +
                                    (long long)((op ? n0 : m0) >> 5) * 128 + piece * 64;
@@ -620,11 +630,13 @@ __global__ __launch_bounds__(256, AFI_TN_RING == 3 ? 3 : (AFI_TN_RING == 2 ? 4 :
     for (int i = 0; i < 4; ++i) { const int ch = (lane & 15) ^ (((lane >> 4) << 2) | i); ch_off[i] = (ch >> 2) * 128 + (ch & 3) * 16; }
     const long long row_bytes = ld * 4;
     auto issue = [&](int h) {
-        unsigned char* dst = smem_b + (h % AFI_TN_RING) * BUF + wave * PART;
+        unsigned char* dst = smem_b + (h % AFI_TN_RING) * BUF + img * PART;
         const unsigned char* s0 = src_row + (long long)h * HK * row_bytes;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < IPW; ++j) {
+            const int i = i0 + j;
             __builtin_amdgcn_global_load_lds((gptr)(s0 + (long long)(4 * i) * row_bytes + ch_off[i]), (lptr)(dst + i * 1024), 16, 0, 0);
+        }
     };
     issue(0);
     if (AFI_TN_RING > 2 && 1 < nH) issue(1);
@@ -656,8 +668,9 @@ __global__ __launch_bounds__(256, AFI_TN_RING == 3 ? 3 : (AFI_TN_RING == 2 ? 4 :
 
     for (int h = 0; h < nH; ++h) {
         // requests complete in order, four per half stage: with h + 1 requested too, vmcnt(4) = half stage h has landed
-        if (AFI_TN_RING > 3 && h + 2 < nH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (AFI_TN_RING > 2 && h + 1 < nH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (AFI_TN_RING > 3 && h + 2 < nH) { if (IPW == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+        else if (AFI_TN_RING > 2 && h + 1 < nH) { if (IPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // ... for every wave's image; and every wave has left half stage h - 1
         if (h + AFI_TN_RING - 1 < nH) issue(h + AFI_TN_RING - 1);
         const unsigned char* cur = smem_b + (h % AFI_TN_RING) * BUF;

@@ -953,7 +953,7 @@ int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int plan
     if ((rows_per_plane % 32) || (M % 128) || (N % 128)) return AFI_ERR_UNSUPPORTED;
     const int ntm = M / 128, ntn = N / 128;
     const long long tiles = (long long)ntm * ntn * planes;
-    const int slots = AFI_TN_RING == 3 ? 768 : (AFI_TN_RING == 2 ? 1024 : 512);        // three resident blocks per CU (three 16 KB buffers, <= 168 registers); A/B ring of four: two
+    const int slots = AFI_TN_WAVES == 8 ? 768 : (AFI_TN_RING == 3 ? 768 : (AFI_TN_RING == 2 ? 1024 : 512));        // three resident blocks per CU (three 16 KB buffers, <= 168 registers); A/B ring of four: two
     int splitK = 1;
     {
         const int maxsplit = (int)(rows_per_plane / (16 * 32)) > 0 ? (int)(rows_per_plane / (16 * 32)) : 1;
@@ -974,7 +974,7 @@ int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int plan
     AfiGemmTN g{Q, V, dU, rows_per_plane, planes, M, N};
     ProfScope prof(st, 22, 2.0 * (double)rows_per_plane * planes * M * N);
     prof.m = (long long)M * planes; prof.n = N; prof.k = (int)rows_per_plane; prof.split = splitK; prof.planes = planes;
-    if (pre) hipLaunchKernelGGL(afi_gemm_tn_f16x3_pre_kernel, dim3((unsigned)tiles, splitK), dim3(256), (unsigned)AFI_TN_RING * 4u * 4096u, st, g, qb, vb, ntm, ntn, kper);
+    if (pre) hipLaunchKernelGGL(afi_gemm_tn_f16x3_pre_kernel, dim3((unsigned)tiles, splitK), dim3(64 * AFI_TN_WAVES), (unsigned)AFI_TN_RING * 4u * 4096u, st, g, qb, vb, ntm, ntn, kper);
     else hipLaunchKernelGGL(afi_gemm_tn_f16x3_kernel, dim3((unsigned)tiles, splitK), dim3(256), 2u * 4u * 4096u, st, g, qb, vb, ntm, ntn, kper);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
