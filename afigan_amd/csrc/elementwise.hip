@@ -816,6 +816,248 @@ int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, 
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 
+// ---------------------------------------------------------------- the discriminator's tail without its two largest tensors
+// Block 2's BatchNorm apply + LeakyReLU, the last conv (F3 -> 1) and their backward, with neither the activation y2 nor the gradient with
+// respect to it ever written (AFI_OPT_D_FUSE_TAIL; at 2 x 200 x 336 x 1024 each is 550 MB):
+//   forward   D9[q][t] = <lrelu(affine(c2[q][:])), w3[t][:]>      one read of c2 (the apply pass read it, wrote y2, and the GEMM read y2)
+//   backward  g[q][c] = sum_t dD9[q][t] * w3[t][c] is nine multiply-adds per element from 64 bytes of dD9 per pixel, so both BatchNorm-backward
+//             passes GENERATE it instead of reading it: the sums pass reads c2 only (and takes the last conv's weight gradient
+//             dw3[t][c] = sum_q dD9[q][t] * y2[q][c] along, y2 being recomputed there for the mask anyway), the apply pass reads c2 and writes
+//             d(conv output).  3.85 GB -> 1.65 GB of traffic per backward at that size, 1.65 -> 0.55 per forward.
+// One wave owns one pixel row x 256 channels at a time (lane = four channels, 1 KB coalesced), so a row's nine dD9 values are wave-uniform
+// (scalar loads); four waves of a block take the C / 256 channel groups of a row (C <= 1024) or four rows.  The affine and the mask are
+// afi_bn.h's (the decisions of the forward, bit for bit).
+#define AFI_TAIL_MAX_C 1024
+#define AFI_TAIL_ROWS 64                                    /* forward: pixel rows per block (one barrier per block) */
+#define AFI_TAIL_MAX_CHUNKS 512                             /* backward sums: partial rows [chunks][11][C] */
+extern "C" long long afi_disc_tail_scratch_floats(int C) { return (long long)AFI_TAIL_MAX_CHUNKS * 11 * C + 2 * C; }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float afi_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
+}
+// the sum over the 64 lanes, valid in lane 63: rotations inside the rows of 16 (every lane of a row ends with the row's sum), then the two
+// row broadcasts -- six VALU instructions, nothing through the LDS queue
+__device__ __forceinline__ float afi_wave_sum_dpp(float v) {
+    v = afi_dpp_add<0x128, 0xf>(v);                         // row_ror:8
+    v = afi_dpp_add<0x124, 0xf>(v);                         // row_ror:4
+    v = afi_dpp_add<0x122, 0xf>(v);                         // row_ror:2
+    v = afi_dpp_add<0x121, 0xf>(v);                         // row_ror:1
+    v = afi_dpp_add<0x142, 0xa>(v);                         // row_bcast:15 into rows 1 and 3
+    v = afi_dpp_add<0x143, 0xc>(v);                         // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// the gradient with respect to the activation, from the row's nine dD9 values: ONE definition for the two passes that generate it
+__device__ __forceinline__ f32x4 afi_tail_g(const float d[9], const f32x4 w[9]) {
+    f32x4 g = w[0] * d[0];
+#pragma unroll
+    for (int t = 1; t < 9; ++t) g = __builtin_elementwise_fma(w[t], f32x4{d[t], d[t], d[t], d[t]}, g);
+    return g;
+}
+struct AfiTailLane { int grp, rl, RL, c; bool cok; };
+__device__ __forceinline__ AfiTailLane afi_tail_lane(int C, int wave, int lane) {
+    const int G = C > 512 ? 4 : (C > 256 ? 2 : 1);          // waves per pixel row
+    AfiTailLane t;
+    t.grp = wave % G; t.rl = wave / G; t.RL = 4 / G; t.c = t.grp * 256 + lane * 4; t.cok = t.c < C;
+    return t;
+}
+template <bool BN>
+__global__ __launch_bounds__(256) void afi_disc_tail_fwd_kernel(const float* __restrict__ x, const AfiBnLoad bn, float slope, const float* __restrict__ w3,
+                                                                float* __restrict__ d9, long long P, int C) {
+    __shared__ float part[AFI_TAIL_ROWS][4][9];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const AfiTailLane L = afi_tail_lane(C, wave, lane);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 w[9], mu = zero, is = zero, ga = zero, be = zero;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = L.cok ? *(const f32x4*)(w3 + (long long)t * C + L.c) : zero;
+    if (BN && L.cok) { mu = *(const f32x4*)(bn.mean + L.c); is = *(const f32x4*)(bn.invstd + L.c); ga = *(const f32x4*)(bn.gamma + L.c); be = *(const f32x4*)(bn.beta + L.c); }
+    const long long r0 = (long long)blockIdx.x * AFI_TAIL_ROWS;
+    const int nr = (int)((P - r0 < AFI_TAIL_ROWS) ? P - r0 : AFI_TAIL_ROWS);
+    for (int i = L.rl; i < nr; i += 4 * L.RL) {             // four rows in flight per wave
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (L.cok && i + u * L.RL < nr) ? __builtin_nontemporal_load((const f32x4*)(x + (r0 + i + u * L.RL) * C + L.c)) : zero;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * L.RL >= nr) break;                  // (uniform)
+            const f32x4 y = BN ? afi_bn_lrelu(v[u], mu, is, ga, be, slope) : v[u];
+            float s[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) s[t] = afi_wave_sum_dpp(y[0] * w[t][0] + y[1] * w[t][1] + y[2] * w[t][2] + y[3] * w[t][3]);
+            if (lane == 63) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) part[i + u * L.RL][L.grp][t] = s[t];
+            }
+        }
+    }
+    __syncthreads();
+    const int G = 4 / L.RL, t = threadIdx.x & 15;
+    for (int i = threadIdx.x >> 4; i < nr; i += 16) {       // D9 rows of 16 floats (columns 9 .. 15: zeros)
+        float s = 0.f;
+        if (t < 9) for (int g = 0; g < G; ++g) s += part[i][g][t];
+        d9[(r0 + i) * 16 + t] = s;
+    }
+}
+// partial[chunk][q][C]: q = 0 sum g m, 1 sum g m xhat, 2 + t sum dD9[.][t] y   (g m: the gradient through the LeakyReLU mask m)
+template <bool WQ>
+__global__ __launch_bounds__(256) void afi_disc_tail_bwd_sums_kernel(const float* __restrict__ x, const float* __restrict__ dd9, const AfiBnLoad bn, float slope,
+                                                                     const float* __restrict__ w3, long long P, int C, int rows_per_chunk,
+                                                                     float* __restrict__ partial) {
+    __shared__ f32x4 red[3][4][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = blockIdx.x * 256 + lane * 4;
+    const bool cok = c < C;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 w[9], mu = zero, is = zero, ga = zero, be = zero, s0 = zero, s1 = zero, wq[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { w[t] = cok ? *(const f32x4*)(w3 + (long long)t * C + c) : zero; wq[t] = zero; }
+    if (cok) { mu = *(const f32x4*)(bn.mean + c); is = *(const f32x4*)(bn.invstd + c); ga = *(const f32x4*)(bn.gamma + c); be = *(const f32x4*)(bn.beta + c); }
+    const long long r0 = (long long)blockIdx.y * rows_per_chunk;
+    const long long r1 = (r0 + rows_per_chunk < P) ? r0 + rows_per_chunk : P;
+    for (long long r = r0 + wave; r < r1; r += 8) {         // two rows in flight per wave
+        const bool two = r + 4 < r1;                        // (uniform)
+        const f32x4 xa = cok ? __builtin_nontemporal_load((const f32x4*)(x + r * C + c)) : zero;
+        const f32x4 xb = (cok && two) ? __builtin_nontemporal_load((const f32x4*)(x + (r + 4) * C + c)) : zero;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u && !two) break;
+            const f32x4 xv = u ? xb : xa;
+            const float* dr = dd9 + (r + 4 * u) * 16;
+            float d[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) d[t] = dr[t];
+            f32x4 gv = afi_tail_g(d, w);
+            const f32x4 z = afi_bn_affine(xv, mu, is, ga, be);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = z[j] > 0.f ? gv[j] : gv[j] * slope;
+            const f32x4 xh = (xv - mu) * is;
+            s0 += gv; s1 += gv * xh;
+            if (WQ) {
+                f32x4 y = z;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) y[j] = z[j] > 0.f ? z[j] : z[j] * slope;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) wq[t] = __builtin_elementwise_fma(y, f32x4{d[t], d[t], d[t], d[t]}, wq[t]);
+            }
+        }
+    }
+    // the four waves' sums meet in LDS, four quantities at a time, in a fixed order
+    float* dst = partial + (long long)blockIdx.y * 11 * C;
+    constexpr int NQ = WQ ? 11 : 2;
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += 4) {
+        if (q0) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = q0 + k;
+            if (q < NQ && wave > 0) red[wave - 1][k][lane] = q == 0 ? s0 : (q == 1 ? s1 : wq[q < 2 ? 0 : q - 2]);
+        }
+        __syncthreads();
+        if (wave == 0 && cok) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = q0 + k;
+                if (q >= NQ) continue;
+                f32x4 v = q == 0 ? s0 : (q == 1 ? s1 : wq[q < 2 ? 0 : q - 2]);
+                v += red[0][k][lane]; v += red[1][k][lane]; v += red[2][k][lane];
+                *(f32x4*)(dst + (long long)q * C + c) = v;
+            }
+        }
+    }
+}
+// grid (C / 32, nq): quantity q of 32 channels summed over the chunks (eight lanes per channel, fixed order)
+__global__ __launch_bounds__(256) void afi_disc_tail_finalize_kernel(const float* __restrict__ partial, int chunks, int C, float* __restrict__ sums,
+                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dw3) {
+    __shared__ float red[8][32];
+    const int cl = threadIdx.x & 31, ln = threadIdx.x >> 5, q = blockIdx.y;
+    const int c = blockIdx.x * 32 + cl;
+    float a = 0.f;
+    if (c < C)
+        for (int i = ln; i < chunks; i += 8) a += partial[((long long)i * 11 + q) * C + c];
+    red[ln][cl] = a;
+    __syncthreads();
+    if (ln != 0 || c >= C) return;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += red[j][cl];
+    if (q == 0) { sums[c] = s; if (dbeta) dbeta[c] += s; }
+    else if (q == 1) { sums[C + c] = s; if (dgamma) dgamma[c] += s; }
+    else if (dw3) dw3[(long long)(q - 2) * C + c] += s;
+}
+// d(conv output) = gamma invstd (g m - sum_gm / P - xhat sum_gmx / P): afi_bn_bwd_apply_kernel<true> with g generated
+template <bool AMAX>
+__global__ __launch_bounds__(256) void afi_disc_tail_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dd9, const AfiBnLoad bn, float slope,
+                                                                      const float* __restrict__ w3, const float* __restrict__ sums, float* __restrict__ dx,
+                                                                      long long P, int C, float* amax) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const AfiTailLane L = afi_tail_lane(C, wave, lane);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 w[9], mu = zero, is = zero, ga = zero, be = zero, sg = zero, sgx = zero;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) w[t] = L.cok ? *(const f32x4*)(w3 + (long long)t * C + L.c) : zero;
+    if (L.cok) {
+        mu = *(const f32x4*)(bn.mean + L.c); is = *(const f32x4*)(bn.invstd + L.c); ga = *(const f32x4*)(bn.gamma + L.c); be = *(const f32x4*)(bn.beta + L.c);
+        sg = *(const f32x4*)(sums + L.c); sgx = *(const f32x4*)(sums + C + L.c);
+    }
+    const float inv_n = 1.f / (float)P;
+    float am = 0.f;
+    const long long step = (long long)gridDim.x * L.RL;
+    for (long long r = (long long)blockIdx.x * L.RL + L.rl; r < P; r += 2 * step) {     // two rows in flight per wave
+        const bool two = r + step < P;                      // (uniform)
+        const f32x4 xa = L.cok ? __builtin_nontemporal_load((const f32x4*)(x + r * C + L.c)) : zero;
+        const f32x4 xb = (L.cok && two) ? __builtin_nontemporal_load((const f32x4*)(x + (r + step) * C + L.c)) : zero;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u && !two) break;
+            const f32x4 xv = u ? xb : xa;
+            const long long rr = r + u * step;
+            const float* dr = dd9 + rr * 16;
+            float d[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) d[t] = dr[t];
+            f32x4 gv = afi_tail_g(d, w);
+            const f32x4 z = afi_bn_affine(xv, mu, is, ga, be);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gv[j] = z[j] > 0.f ? gv[j] : gv[j] * slope;
+            const f32x4 xh = (xv - mu) * is;
+            const f32x4 o = ga * is * (gv - sg * inv_n - xh * (sgx * inv_n));
+            if (AMAX) am = afi_ew_amax4(am, o);
+            if (L.cok) *(f32x4*)(dx + rr * C + L.c) = o;
+        }
+    }
+    if (AMAX) afi_ew_amax_publish(am, amax);
+}
+static bool afi_tail_ok(long long P, int C) { return P > 0 && C > 0 && !(C & 3) && C <= AFI_TAIL_MAX_C; }
+// bn == nullptr: x is the activation itself (nothing applied on load)
+int afi_launch_disc_tail_fwd(const float* x, const AfiBnLoad* bn, float slope, const float* w3, float* d9, long long P, int C, hipStream_t st) {
+    if (!x || !w3 || !d9 || !afi_tail_ok(P, C)) return AFI_ERR_BAD_ARG;
+    const unsigned grid = (unsigned)((P + AFI_TAIL_ROWS - 1) / AFI_TAIL_ROWS);
+    const AfiBnLoad off{nullptr, nullptr, nullptr, nullptr};
+    if (bn && bn->mean) hipLaunchKernelGGL(afi_disc_tail_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, x, *bn, slope, w3, d9, P, C);
+    else hipLaunchKernelGGL(afi_disc_tail_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, x, off, slope, w3, d9, P, C);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+// x = the block's saved conv output, dd9 = the scattered logit gradients [P][16]; dx = d(conv output) (amax: raised to its largest magnitude);
+// dgamma / dbeta / dw3 (+=, each optional); scratch: afi_disc_tail_scratch_floats(C)
+int afi_launch_disc_tail_bwd(const float* x, const float* dd9, const AfiBnLoad bn, float slope, const float* w3, float* dx, float* dgamma, float* dbeta, float* dw3,
+                             long long P, int C, float* scratch, float* amax, hipStream_t st) {
+    if (!x || !dd9 || !w3 || !dx || !scratch || !bn.mean || !afi_tail_ok(P, C)) return AFI_ERR_BAD_ARG;
+    long long want = (P + 31) / 32;
+    if (want > AFI_TAIL_MAX_CHUNKS) want = AFI_TAIL_MAX_CHUNKS;
+    const int rpc = (int)((P + want - 1) / want), chunks = (int)((P + rpc - 1) / rpc);
+    float* sums = scratch + (long long)AFI_TAIL_MAX_CHUNKS * 11 * C;
+    const dim3 sgrid(afi_cdiv(C, 256), chunks);
+    if (dw3) hipLaunchKernelGGL(afi_disc_tail_bwd_sums_kernel<true>, sgrid, dim3(256), 0, st, x, dd9, bn, slope, w3, P, C, rpc, scratch);
+    else hipLaunchKernelGGL(afi_disc_tail_bwd_sums_kernel<false>, sgrid, dim3(256), 0, st, x, dd9, bn, slope, w3, P, C, rpc, scratch);
+    hipLaunchKernelGGL(afi_disc_tail_finalize_kernel, dim3(afi_cdiv(C, 32), dw3 ? 11 : 2), dim3(256), 0, st, scratch, chunks, C, sums, dgamma, dbeta, dw3);
+    const int G = C > 512 ? 4 : (C > 256 ? 2 : 1);
+    long long agrid = (P * G + 3) / 4;                      // one wave per (row, channel group), grid-stride beyond 256 CUs x 8 blocks
+    if (agrid > 2048) agrid = 2048;
+    if (amax) hipLaunchKernelGGL(afi_disc_tail_bwd_apply_kernel<true>, dim3((unsigned)agrid), dim3(256), 0, st, x, dd9, bn, slope, w3, sums, dx, P, C, amax);
+    else hipLaunchKernelGGL(afi_disc_tail_bwd_apply_kernel<false>, dim3((unsigned)agrid), dim3(256), 0, st, x, dd9, bn, slope, w3, sums, dx, P, C, amax);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
+
 // ---------------------------------------------------------------- losses
 // BCE-with-logits (mean) against a constant target t:  loss += lscale * mean(max(z,0) - z t + log1p(exp(-|z|)))
 // dz = gscale * (sigmoid(z) - t) / n   (written only if dz != null)

@@ -69,6 +69,10 @@ int afi_launch_bn_bwd_apply(const float* g, const float* x, float* dx, const flo
                             long long P_total, int C, hipStream_t st);
 int afi_launch_stencil9_sum(const float* d9, int ld, const float* bias, float* out, int N, int H, int W, hipStream_t st);
 int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, int H, int W, hipStream_t st);
+extern "C" long long afi_disc_tail_scratch_floats(int C);
+int afi_launch_disc_tail_fwd(const float* x, const AfiBnLoad* bn, float slope, const float* w3, float* d9, long long P, int C, hipStream_t st);
+int afi_launch_disc_tail_bwd(const float* x, const float* dd9, const AfiBnLoad bn, float slope, const float* w3, float* dx, float* dgamma, float* dbeta, float* dw3,
+                             long long P, int C, float* scratch, float* amax, hipStream_t st);
 int afi_launch_bce_logits(const float* z, long long n, float target, float lscale, float* loss, float gscale, float* dz, hipStream_t st);
 int afi_launch_l1(AfiView a, AfiView b, int N, int h, int w, int C, int Ha, int Wa, float lscale, float* loss, float gscale, float* da,
                   hipStream_t st);
@@ -154,7 +158,7 @@ struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ AFI_DEFAULT_F4_FORWARD, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
                                             /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0, /*DETERMINISTIC*/ 0, /*F16_PRESPLIT*/ 1, /*F16_NT256_MIN_TILES*/ 512,
-                                            /*F16_LOCAL_SUMS*/ AFI_DEFAULT_LOCAL_SUMS}};
+                                            /*F16_LOCAL_SUMS*/ AFI_DEFAULT_LOCAL_SUMS, /*D_FUSE_TAIL*/ 1}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -675,7 +679,7 @@ int afi_debug_wk6_convT_images(const float* W, int Cin, int Cout, int mode, void
                                        : AfiWk6ImgJob{pack_ref, 9LL * Cin, Cin, Cin, Cout, 9, 4, 1, 0, (unsigned char*)via_pack, 0, 0};
     return afi_launch_wk6_images(&job, 1, st, nullptr, nullptr);
 }
-int afi_abi_version(void) { return 7; }
+int afi_abi_version(void) { return 8; }
 // digest of the sources this binary was compiled from (__graft_entry__.build() writes csrc/afi_build_id.h in front of the compile:
 // sha256 over every *.hip / *.h of csrc/ and include/afigan_hip.h, the generated header excluded).  The Python binding recomputes it from the
 // tree it sits in and refuses a library built from other sources; smoke() prints it.
@@ -1778,6 +1782,10 @@ long long afi_discriminator_fwd_ws_floats_ex(const afi_ctx_t* ctx, const int F[4
     if (!F || N <= 0 || H <= 0 || W <= 0) return 0;
     return disc_ws(F, N, H, W, disc_keep_mask(ctx, F, N, H, W, training, 1) | disc_keep_mask(ctx, F, N, H, W, training, 2)).total;     // (plain or paired call)
 }
+// AFI_OPT_D_FUSE_TAIL in force for a discriminator of F3 last-block channels: block 2's apply pass, the last conv and their backward run as the
+// fused passes of csrc/elementwise.hip (afi_launch_disc_tail_*): y[2] and the gradient with respect to it are never written.  Evaluated by
+// the forward AND the backward (one more reason afi_discriminator_bwd runs under its forward's options).
+static bool disc_tail_fused(const afi_ctx* cx, int F3) { return afi_opt(cx, AFI_OPT_D_FUSE_TAIL) != 0 && !(F3 & 3) && F3 <= 1024; }
 // where the forward keeps what the backward reads (offsets in floats into the forward workspace): 12 entries,
 // conv outputs c[0..2] ([P][F_{n+1}]), activations y[0..2], batch means [F_{n+1}], 1/sqrt(var + eps) [F_{n+1}]
 int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* off12) {
@@ -1789,9 +1797,10 @@ int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* 
 int afi_discriminator_saved_activations(const afi_ctx_t* ctx, const int F[4], int N, int H, int W) {
     if (!F || N <= 0 || H <= 0 || W <= 0) return -1;
     const DiscWs l = disc_ws(F, N, H, W);
-    return (l.n_wino > 0 && use_wino(ctx, l.P) && afi_opt(ctx, AFI_OPT_D_FOLD_BN_APPLY) != 0) ? 4 : 7;
+    const int tail = disc_tail_fused(ctx, F[3]) ? 0 : 4;     // (y[2]: read by the last conv only)
+    return ((l.n_wino > 0 && use_wino(ctx, l.P) && afi_opt(ctx, AFI_OPT_D_FOLD_BN_APPLY) != 0) ? 0 : 3) | tail;
 }
-struct DiscBwdWs { long long o_g[3], o_dd9, o_amax, o_red, o_red2, o_part, n_part, o_wino, n_wino, o_wino2, total; };
+struct DiscBwdWs { long long o_g[3], o_dd9, o_amax, o_red, o_red2, o_tail, o_part, n_part, o_wino, n_wino, o_wino2, total; };
 static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     DiscBwdWs w;
     const long long P = (long long)N * H * W;
@@ -1803,6 +1812,7 @@ static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     w.o_amax = o; o += 16;                                // [4 n]: the largest magnitude of d(conv output of block n), raised by the BatchNorm backward (Winograd path)
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));       // BatchNorm backward (main stream)
     w.o_red2 = o; o += align4(afi_reduce_scratch_floats(fmax));      // bias column sums (side stream)
+    w.o_tail = o; o += align4(afi_disc_tail_scratch_floats(F[3]));   // the fused tail's partial sums (AFI_OPT_D_FUSE_TAIL)
     w.n_part = part_floats({P * F[0], P * F[1], P * F[2], P * F[3]});
     w.o_part = o; o += w.n_part;
     w.n_wino = disc_wino_floats(F, N, H, W);
@@ -1879,6 +1889,7 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
     // activation feeds the last conv (a direct GEMM) and is always written.
     const bool wino = l.n_wino > 0 && use_wino(cx, P);
     const bool fold = disc_fold_opt(cx, wino, halves);     // (a paired call runs unfolded: one affine per HALF there)
+    const bool tail = disc_tail_fused(cx, prm->F[3]);
     const long long Ph = P / halves;
     AfiBnLoad in_bn{nullptr, nullptr, nullptr, nullptr};
     // the largest magnitude of every block's input, for the f16x3 arithmetic of this pass and of the backward pass that may follow (whatever
@@ -1914,7 +1925,8 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
         } else {
             AFI_TRY(PG(conv_fwd_desc(in, N, H, W, ci, prm->w[n], prm->b[n], co, dense_view(c, H, W, co)), 0));
         }
-        const bool skip_apply = (stats_only && n == 2) || fold_n;       // nothing reads the last block's activation / the next block reads c through the affine
+        // nothing reads the last block's activation / the next block reads c through the affine / the last conv does
+        const bool skip_apply = (stats_only && n == 2) || fold_n || (n == 2 && tail);
         const float* mean_used = mean;
         if (!training) {
             AFI_TRY(afi_launch_invstd(prm->running_var[n], invstd, co, st));
@@ -1950,7 +1962,16 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
             in_bn = AfiBnLoad{nullptr, nullptr, nullptr, nullptr};
         }
     }
-    if (!stats_only) {   // last conv 3x3 F3 -> 1 (:40-41): D9[q][t] = <y2[q], w3[t]> on the MFMA kernel (1x1, 9 columns), then the 9-tap stencil
+    if (!stats_only && tail) {   // last conv 3x3 F3 -> 1 (:40-41) reading c2 through block 2's affine + LeakyReLU (y2 is never written), then the 9-tap stencil
+        const int F3 = prm->F[3];
+        float* d9 = ws + l.o_d9;
+        for (int h = 0; h < halves; ++h) {                  // (a paired call: each half through its own batch statistics)
+            const AfiBnLoad bn{training ? (h ? ws + l.o_mean_b[2] : ws + l.o_mean[2]) : prm->running_mean[2], training && h ? ws + l.o_invstd_b[2] : ws + l.o_invstd[2],
+                               prm->gamma[2], prm->beta[2]};
+            AFI_TRY(afi_launch_disc_tail_fwd(ws + l.o_c[2] + (long long)h * Ph * F3, &bn, AFI_LRELU_SLOPE, prm->w3, d9 + (long long)h * Ph * 16, Ph, F3, st));
+        }
+        AFI_TRY(afi_launch_stencil9_sum(d9, 16, prm->b3, logits, N, H, W, st));
+    } else if (!stats_only) {   // ... D9[q][t] = <y2[q], w3[t]> on the MFMA kernel (1x1, 9 columns)
         const int F3 = prm->F[3];
         float* d9 = ws + l.o_d9;
         AfiPixGemm g = pix_default(N, H, W);
@@ -1999,13 +2020,14 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
     if (gr->b3) AFI_TRY(afi_launch_sum_accum(dlogits, P, 1.f, gr->b3, sd));
     AFI_TRY(afi_launch_stencil9_scatter(dlogits, dd9, 16, N, H, W, st));
     fk.after_main();                                       // dd9 is complete
+    const bool tail = disc_tail_fused(cx, F3);              // (the forward wrote no y2: its readers below are the fused passes)
     AfiView y2 = dense_view(ws + l.o_y[2], H, W, F3);
-    if (gr->w3) {
+    if (gr->w3 && !tail) {
         AfiWgradGemm g = conv_wgrad_desc(dense_view(dd9, H, W, 16), y2, N, H, W, 9, F3, gr->w3, 1.f);
         g.ntaps = 1; g.dw_sRow = F3; g.dw_sTap = 0;
         AFI_TRY(wgrad_launch(cx, g, sd));
     }
-    {
+    if (!tail) {
         AfiPixGemm g = pix_default(N, H, W);
         g.ntaps = 1; g.a_sgn = -1; g.Ck = 9; g.Ncols = F3; g.CoutPhase = F3;
         g.A = dense_view(dd9, H, W, 16); g.B = prm->w3; g.b_sRow = F3; g.b_sTap = 0;
@@ -2022,6 +2044,12 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
         // the producing data gradient's output transform as a third operand
         for (int h = 0; h < halves; ++h) {            // (a paired call: each half against its own batch statistics; the parameter gradients add up)
             const long long Ph = P / halves, o = (long long)h * Ph * co;
+            if (n == 2 && tail) {                     // the gradient w.r.t. y2 is generated from dd9, the last conv's weight gradient rides with the sums
+                const AfiBnLoad bn{ws + (h ? l.o_mean_b[n] : l.o_mean[n]), ws + (h ? l.o_invstd_b[n] : l.o_invstd[n]), prm->gamma[n], prm->beta[n]};
+                AFI_TRY(afi_launch_disc_tail_bwd(c + o, dd9 + (long long)h * Ph * 16, bn, AFI_LRELU_SLOPE, prm->w3, g_ + o, gr->gamma[n], gr->beta[n], gr->w3, Ph, co,
+                                                 scratch + s.o_tail, slots ? gmax + 4 * n : nullptr, st));
+                continue;
+            }
             AFI_TRY(afi_launch_bn_bwd(g_ + o, c + o, g_ + o, ws + (h ? l.o_mean_b[n] : l.o_mean[n]), ws + (h ? l.o_invstd_b[n] : l.o_invstd[n]), prm->gamma[n],
                                       gr->gamma[n], gr->beta[n], 1.f, Ph, co, red, st, prm->beta[n], AFI_LRELU_SLOPE,
                                       slots ? gmax + 4 * n : nullptr));                                              // in place: g_ = d(conv output)

@@ -169,7 +169,13 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                * Same products, fewer roundings of the large accumulator (an fp32 accumulate rounds at the accumulator's magnitude,
                                                * whatever the addend).  Pre-split planes and 256-column multiples only (blocks 1 and 2 at the reference's widths; other
                                                * shapes keep the plain order).  Default and measurements: DESIGN.md 0 / 4b */
-#define AFI_OPT_COUNT 16
+#define AFI_OPT_D_FUSE_TAIL 16                /* 1 (default): the discriminator's last block and last conv (F3 -> 1, F3 <= 1024) run fused -- the last conv reads the
+                                               * block's saved conv output through its BatchNorm affine + LeakyReLU (the activation y[2] is never written:
+                                               * afi_discriminator_saved_activations), and the block's BatchNorm backward GENERATES the gradient with respect to that
+                                               * activation from the nine logit gradients of each pixel instead of reading it, taking the last conv's weight gradient
+                                               * along: at 2 x 200 x 336 x 1024, 1.1 GB less traffic per forward and 2.2 GB less per backward.  Same decisions of
+                                               * the LeakyReLU masks (the pinned affine), sums in another order.  0: the separate passes of rounds 1-5 */
+#define AFI_OPT_COUNT 17
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over
@@ -261,7 +267,8 @@ int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* 
  * transform -- and the backward's weight-gradient input transforms -- read the saved conv output c[n] through the block's BatchNorm affine
  * and LeakyReLU, y = lrelu_0.2(((c - mean) * invstd) * gamma + beta) with every operation rounded to fp32 on its own (the arithmetic the
  * apply pass has; a reader of the workspace reproduces y[n] bit for bit from c[n], mean[n], invstd[n] and the block's gamma / beta that
- * way: tests/d_parity_util.py).  The mask is 4 (y[2] only) there and 7 everywhere else (the default).
+ * way: tests/d_parity_util.py).  Bits 0 and 1 are clear there and set everywhere else (the default).  Bit 2 (y[2], which only the last conv
+ * reads) is clear under AFI_OPT_D_FUSE_TAIL (the default: the mask is 3; 7 with that option off).
  * ctx may be NULL (defaults).
  * afi_discriminator_bwd must run under the same options as its forward. */
 int afi_discriminator_saved_activations(const afi_ctx_t* ctx, const int F[4], int N, int H, int W);

@@ -9,7 +9,7 @@
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "host sanitizer driver: FAILED %s (line %d)\n", #c, __LINE__); return 1; } } while (0)
 
 int main() {
-    CHECK(afi_abi_version() == 7);
+    CHECK(afi_abi_version() == 8);
     CHECK(std::strlen(afi_build_id()) > 0);
     for (int s = -1; s < 8; ++s) CHECK(afi_status_string(s) != nullptr);
     // workspace layouts over a sweep of shapes (small maps, the Winograd thresholds, the benchmark's five levels, odd sizes)
@@ -29,7 +29,7 @@ int main() {
             CHECK(afi_discriminator_fwd_ws_floats(F, N, H, W) > 0 && afi_discriminator_bwd_ws_floats(F, N, H, W) > 0);
             CHECK(afi_discriminator_ws_layout(F, N, H, W, off) == 0);
             for (int i = 1; i < 6; ++i) CHECK(off[i] >= 0);
-            CHECK(afi_discriminator_saved_activations(nullptr, F, N, H, W) == 7);
+            CHECK(afi_discriminator_saved_activations(nullptr, F, N, H, W) == 3);        // (y[2] is never written: AFI_OPT_D_FUSE_TAIL)
             // the context-aware size query (ABI v7): never above the context-free upper bound; forwards no backward follows keep no planes; the default
             // context's training forward keeps the planes of blocks 1 and 2 (AFI_OPT_WINOGRAD_F4_FORWARD = 12) where the Winograd F(4x4) forward runs
             const long long all = afi_discriminator_fwd_ws_floats(F, N, H, W);

@@ -513,6 +513,64 @@ def test_generator_chain_kernel_schedule_matches_the_per_link_schedule(amd):
             assert _rel(a, b) < 2e-5, (mode, i)
 
 
+@pytest.mark.parametrize("F0,N,H,W,train", [(256, 2, 13, 21, 1), (256, 2, 50, 84, 1), (256, 1, 32, 40, 0), (16, 2, 9, 11, 1), (96, 1, 17, 5, 1)])
+def test_discriminator_fused_tail_is_the_same_network(amd, F0, N, H, W, train):
+    """Option d_fuse_tail (default on): block 2's BatchNorm apply + LeakyReLU, the last conv and their backward without y[2] and without the
+    gradient w.r.t. it in memory (feature_patch_discriminator.py:38-41; csrc/elementwise.hip, afi_launch_disc_tail_*).  Against the separate
+    passes (option off) on the same inputs: the same LeakyReLU decisions (the pinned affine on the same conv output), sums in another order --
+    logits, input gradient and every parameter gradient to fp32 rounding; y[2]'s region of the workspace stays untouched and the mask of
+    afi_discriminator_saved_activations says so.  Channel counts that fill a wave's 256 channels (1024), a part of one (64: masked lanes)
+    and one and a half (384); batch statistics and running statistics (eval)."""
+    import ctypes as C
+    from afigan_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(11)
+    D = amd.Discriminator(in_filters=F0).cuda()
+    D.train(bool(train))
+    net = D.Discriminators[0]
+    if not train:                                           # running statistics that are not the initial (0, 1)
+        for m in net.modules():
+            if hasattr(m, "running_mean") and m.running_mean is not None:
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0)
+    x = ops.pixel_major(torch.randn(N, F0, H, W).cuda())
+    dl = torch.randn(N * H * W, device="cuda")
+    params = net._ordered_params()
+    Fa = (C.c_int * 4)(*net.F)
+    nf, nb = lib.afi_discriminator_fwd_ws_floats(Fa, N, H, W), lib.afi_discriminator_bwd_ws_floats(Fa, N, H, W)
+    off = (C.c_longlong * 12)()
+    _lib.call("afi_discriminator_ws_layout", Fa, N, H, W, off)
+    res = {}
+    for flag in (0, 1):
+        cx = _lib.Ctx()
+        cx.set_option("d_fuse_tail", flag)
+        cx.set_option("deterministic", 1)
+        assert lib.afi_discriminator_saved_activations(cx.handle, Fa, N, H, W) == (3 if flag else 7)
+        with _lib.use_ctx(cx):
+            prm, keep = net._param_struct(params)
+            grads = [torch.zeros_like(t) for t in keep]
+            gst, _k2 = net._param_struct(grads, already_packed=True, grads=True)
+            ws, sc = torch.full((nf,), float("nan"), device="cuda"), torch.zeros(nb, device="cuda")
+            logits = torch.empty(N * H * W, device="cuda")
+            dx = ops.new_pixel_major(N, F0, H, W, "cuda")
+            st = ops.stream_ptr()
+            _lib.call("afi_discriminator_fwd", C.byref(prm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), 1 if train else 0, C.c_void_p(ws.data_ptr()), nf, st)
+            y2_written = not bool(torch.isnan(ws[off[5]:off[5] + 8]).any())
+            if train:
+                _lib.call("afi_discriminator_bwd", C.byref(prm), C.byref(gst), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()), C.c_void_p(dl.data_ptr()),
+                          C.c_void_p(dx.data_ptr()), C.c_void_p(sc.data_ptr()), nb, st)
+            torch.cuda.synchronize()
+        assert y2_written == (flag == 0)
+        res[flag] = (logits.clone(), dx.clone(), [g.clone() for g in grads])
+    assert _rel(res[1][0], res[0][0]) < 2e-6, "logits"
+    if train:
+        assert _rel(res[1][1], res[0][1]) < 1e-5, "input gradient"
+        for i, (a, b) in enumerate(zip(res[1][2], res[0][2])):
+            if float(b.abs().max()) == 0.0:
+                assert float(a.abs().max()) == 0.0, i
+            else:
+                assert _rel(a, b) < 2e-5, i
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 32, 40), (2, 50, 84)])
 def test_discriminator_bn_apply_folded_into_its_readers_is_the_same_network(amd, N, H, W):
     """Option d_fold_bn_apply: under the Winograd path the BatchNorm apply + LeakyReLU of blocks 0 and 1 is evaluated by the READERS of the
@@ -541,7 +599,7 @@ def test_discriminator_bn_apply_folded_into_its_readers_is_the_same_network(amd,
     for flag in (0, 1):
         cx = _lib.Ctx()
         cx.set_option("d_fold_bn_apply", flag)
-        assert lib.afi_discriminator_saved_activations(cx.handle, Fa, N, H, W) == (4 if flag else 7)
+        assert lib.afi_discriminator_saved_activations(cx.handle, Fa, N, H, W) == (0 if flag else 3)      # (bit 2: never, d_fuse_tail)
         assert lib.afi_discriminator_fwd_ws_floats_ex(cx.handle, Fa, N, H, W, 1) <= nf
         with _lib.use_ctx(cx):
             prm, keep = net._param_struct(params)
@@ -558,7 +616,7 @@ def test_discriminator_bn_apply_folded_into_its_readers_is_the_same_network(amd,
             torch.cuda.synchronize()
         assert y0_written == (flag == 0)
         res[flag] = (logits.clone(), dx.clone(), [g.clone() for g in grads])
-    assert lib.afi_discriminator_saved_activations(None, Fa, N, H, W) == (4 if lib.afi_ctx_get_option(None, _lib.OPTIONS["d_fold_bn_apply"]) else 7)
+    assert lib.afi_discriminator_saved_activations(None, Fa, N, H, W) == (0 if lib.afi_ctx_get_option(None, _lib.OPTIONS["d_fold_bn_apply"]) else 3)
     assert torch.equal(res[0][0], res[1][0]), "logits"
     assert torch.equal(res[0][1], res[1][1]), "input gradient"
     for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
