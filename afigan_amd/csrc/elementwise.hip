@@ -825,27 +825,12 @@ int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, 
 //             dw3[t][c] = sum_q dD9[q][t] * y2[q][c] along, y2 being recomputed there for the mask anyway), the apply pass reads c2 and writes
 //             d(conv output).  3.85 GB -> 1.65 GB of traffic per backward at that size, 1.65 -> 0.55 per forward.
 // One wave owns one pixel row x 256 channels at a time (lane = four channels, 1 KB coalesced), so a row's nine dD9 values are wave-uniform
-// (scalar loads); four waves of a block take the C / 256 channel groups of a row (C <= 1024) or four rows.  The affine and the mask are
-// afi_bn.h's (the decisions of the forward, bit for bit).
+// (scalar loads); four waves of a block take the C / 256 channel groups of a row (C <= 1024, C % 16 == 0) or four rows.  The affine and the
+// mask are afi_bn.h's (the decisions of the forward, bit for bit).
 #define AFI_TAIL_MAX_C 1024
-#define AFI_TAIL_ROWS 64                                    /* forward: pixel rows per block (one barrier per block) */
+typedef float afi_f32x2 __attribute__((ext_vector_type(2)));
 #define AFI_TAIL_MAX_CHUNKS 512                             /* backward sums: partial rows [chunks][11][C] */
 extern "C" long long afi_disc_tail_scratch_floats(int C) { return (long long)AFI_TAIL_MAX_CHUNKS * 11 * C + 2 * C; }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float afi_dpp_add(float v) {
-    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true));
-}
-// the sum over the 64 lanes, valid in lane 63: rotations inside the rows of 16 (every lane of a row ends with the row's sum), then the two
-// row broadcasts -- six VALU instructions, nothing through the LDS queue
-__device__ __forceinline__ float afi_wave_sum_dpp(float v) {
-    v = afi_dpp_add<0x128, 0xf>(v);                         // row_ror:8
-    v = afi_dpp_add<0x124, 0xf>(v);                         // row_ror:4
-    v = afi_dpp_add<0x122, 0xf>(v);                         // row_ror:2
-    v = afi_dpp_add<0x121, 0xf>(v);                         // row_ror:1
-    v = afi_dpp_add<0x142, 0xa>(v);                         // row_bcast:15 into rows 1 and 3
-    v = afi_dpp_add<0x143, 0xc>(v);                         // row_bcast:31 into rows 2 and 3
-    return v;
-}
 // the gradient with respect to the activation, from the row's nine dD9 values: ONE definition for the two passes that generate it
 __device__ __forceinline__ f32x4 afi_tail_g(const float d[9], const f32x4 w[9]) {
     f32x4 g = w[0] * d[0];
@@ -860,42 +845,109 @@ __device__ __forceinline__ AfiTailLane afi_tail_lane(int C, int wave, int lane) 
     t.grp = wave % G; t.rl = wave / G; t.RL = 4 / G; t.c = t.grp * 256 + lane * 4; t.cok = t.c < C;
     return t;
 }
+// The forward product on the fp32 matrix cores (C % 16 == 0): D9^T[t][row] = sum_c W[t][c] * Y[c][row] as v_mfma_f32_16x16x4_f32 with the
+// taps as the 16 rows of A (nine live), sixteen pixel rows as the columns of B and four channels per instruction -- the reduction over the
+// channels happens inside the MFMA accumulators, so nothing crosses lanes and the VALU only evaluates the affine (a first form with one
+// wave per pixel row and a DPP reduction of the nine dot products per row ran at 2.3 TB/s: 240 us at 2 x 200 x 336 x 1024).  Lane (j = lane & 15,
+// k = lane >> 4) loads the 16 bytes of pixel row j at channels 16 s + 4 k .. + 3 (64 contiguous bytes per row and instruction) and feeds
+// them to four MFMAs; its A operands (tap j, the same four channels) and its four parameter vectors come from LDS (9 x C weights +
+// 4 x C parameters: 52 KB at C = 1024).  A wave owns sixteen rows, a block of eight waves 128, and walks its share of the 128-row tiles.
+#ifndef AFI_TAIL_UNROLL
+#define AFI_TAIL_UNROLL 4
+#endif
+#ifndef AFI_TAIL_ABLATE
+#define AFI_TAIL_ABLATE 0                                   /* tools/micro/tail_probe.py builds only: 1 no MFMAs, 2 no affine, 4 no weight reads (wrong results) */
+#endif
+#ifndef AFI_TAIL_WAVES
+#define AFI_TAIL_WAVES 4                                     /* waves per block: sixteen pixel rows each, one set of LDS images (eight: 201 against 158 us) */
+#endif
+// lrelu(z) as max(z, z * slope): the value of afi_bn_lrelu's select for every z (0 < slope < 1: z * slope < z exactly when z > 0; both forms
+// return -0 for -0 and NaN for NaN) in half the instructions
+__device__ __forceinline__ f32x4 afi_tail_act(f32x4 v, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be, float slope) {
+    const f32x4 z = afi_bn_affine(v, mu, is, ga, be);
+    const f32x4 zs = z * slope;
+    return f32x4{fmaxf(z[0], zs[0]), fmaxf(z[1], zs[1]), fmaxf(z[2], zs[2]), fmaxf(z[3], zs[3])};
+}
 template <bool BN>
-__global__ __launch_bounds__(256) void afi_disc_tail_fwd_kernel(const float* __restrict__ x, const AfiBnLoad bn, float slope, const float* __restrict__ w3,
-                                                                float* __restrict__ d9, long long P, int C) {
-    __shared__ float part[AFI_TAIL_ROWS][4][9];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const AfiTailLane L = afi_tail_lane(C, wave, lane);
+__global__ __launch_bounds__(64 * AFI_TAIL_WAVES) void afi_disc_tail_fwd_mfma_kernel(const float* __restrict__ x, const AfiBnLoad bn, float slope, const float* __restrict__ w3,
+                                                                                     float* __restrict__ d9, long long P, int C) {
+    extern __shared__ __attribute__((aligned(16))) float tail_lds[];
+    const int ldw = C + 4;                                  // (row stride of the weights: the sixteen taps of a quarter wave on distinct banks)
+    float* Ws = tail_lds;                                   // [9][C + 4], then four zeros (what the lanes of taps 9 .. 15 read)
+    float* Zs = tail_lds + 9 * ldw;
+    float* Ps = Zs + 4;                                     // [4][C]: mean, invstd, gamma, beta
+    for (int e = threadIdx.x; e < 9 * (C >> 2); e += 64 * AFI_TAIL_WAVES) {
+        const int t = e / (C >> 2), c4 = e - t * (C >> 2);
+        *(f32x4*)(Ws + t * ldw + 4 * c4) = *(const f32x4*)(w3 + (long long)t * C + 4 * c4);
+    }
+    if (threadIdx.x == 0) *(f32x4*)Zs = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (BN)
+        for (int e = threadIdx.x; e < (C >> 2); e += 64 * AFI_TAIL_WAVES) {
+            *(f32x4*)(Ps + 4 * e) = *(const f32x4*)(bn.mean + 4 * e); *(f32x4*)(Ps + C + 4 * e) = *(const f32x4*)(bn.invstd + 4 * e);
+            *(f32x4*)(Ps + 2 * C + 4 * e) = *(const f32x4*)(bn.gamma + 4 * e); *(f32x4*)(Ps + 3 * C + 4 * e) = *(const f32x4*)(bn.beta + 4 * e);
+        }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, k = lane >> 4;
+    const bool live = j < 9;
+    const float* wr = live ? Ws + j * ldw + 4 * k : Zs;     // this lane's A operands: + wstep per 16-channel step (0 for the zero lanes)
+    const int wstep = live ? 16 : 0;
+    const float* pr = Ps + 4 * k;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 w[9], mu = zero, is = zero, ga = zero, be = zero;
+    const int nS = C >> 4;
+    constexpr int TR = 16 * AFI_TAIL_WAVES;                // pixel rows per tile
+    const long long ntile = (P + TR - 1) / TR;
+    for (long long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {       // (the LDS images serve every tile of the block)
+        const long long row = tile * TR + wave * 16 + j;
+        const bool rok = row < P;
+        const float* xr = x + (rok ? row : P - 1) * C + 4 * k;                 // (rows past the end re-read the last one and store nothing)
+        f32x4 acc = zero;
+        // a batch of AFI_TAIL_UNROLL 16-channel steps: this batch's LDS operands and the NEXT batch's rows are requested first, then the batch is
+        // multiplied -- the MFMAs wait for neither (a step that read its weights just before its MFMAs ran at 157 us, without the MFMAs 113,
+        // without the weight reads 121: the LDS round trip in front of every group of four MFMAs was what it paid)
+        auto step = [&](f32x4 y, const f32x4 wv, const f32x4 p0, const f32x4 p1, const f32x4 p2, const f32x4 p3) {
+            if (BN && !(AFI_TAIL_ABLATE & 2)) y = afi_tail_act(y, p0, p1, p2, p3, slope);
+            if (AFI_TAIL_ABLATE & 1) { acc += wv * y; return; }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) w[t] = L.cok ? *(const f32x4*)(w3 + (long long)t * C + L.c) : zero;
-    if (BN && L.cok) { mu = *(const f32x4*)(bn.mean + L.c); is = *(const f32x4*)(bn.invstd + L.c); ga = *(const f32x4*)(bn.gamma + L.c); be = *(const f32x4*)(bn.beta + L.c); }
-    const long long r0 = (long long)blockIdx.x * AFI_TAIL_ROWS;
-    const int nr = (int)((P - r0 < AFI_TAIL_ROWS) ? P - r0 : AFI_TAIL_ROWS);
-    for (int i = L.rl; i < nr; i += 4 * L.RL) {             // four rows in flight per wave
-        f32x4 v[4];
+            for (int m = 0; m < 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[m], y[m], acc, 0, 0, 0);
+        };
+        auto lds_w = [&](int sidx) { return (AFI_TAIL_ABLATE & 4) ? f32x4{1.f, 1.f, 1.f, 1.f} : *(const f32x4*)(wr + sidx * wstep); };
+        int s0 = 0;
+        f32x4 v[AFI_TAIL_UNROLL];
+        if (AFI_TAIL_UNROLL <= nS) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (L.cok && i + u * L.RL < nr) ? __builtin_nontemporal_load((const f32x4*)(x + (r0 + i + u * L.RL) * C + L.c)) : zero;
+            for (int u = 0; u < AFI_TAIL_UNROLL; ++u) v[u] = __builtin_nontemporal_load((const f32x4*)(xr + 16 * u));
+        }
+        for (; s0 + AFI_TAIL_UNROLL <= nS; s0 += AFI_TAIL_UNROLL) {
+            f32x4 wv[AFI_TAIL_UNROLL], pp[AFI_TAIL_UNROLL][4], vn[AFI_TAIL_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i + u * L.RL >= nr) break;                  // (uniform)
-            const f32x4 y = BN ? afi_bn_lrelu(v[u], mu, is, ga, be, slope) : v[u];
-            float s[9];
+            for (int u = 0; u < AFI_TAIL_UNROLL; ++u) {
+                wv[u] = lds_w(s0 + u);
+                if (BN) {
+                    const float* q = pr + 16 * (s0 + u);
+                    pp[u][0] = *(const f32x4*)q; pp[u][1] = *(const f32x4*)(q + C); pp[u][2] = *(const f32x4*)(q + 2 * C); pp[u][3] = *(const f32x4*)(q + 3 * C);
+                }
+            }
+            const bool more = s0 + 2 * AFI_TAIL_UNROLL <= nS;                  // (uniform)
+            if (more) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) s[t] = afi_wave_sum_dpp(y[0] * w[t][0] + y[1] * w[t][1] + y[2] * w[t][2] + y[3] * w[t][3]);
-            if (lane == 63) {
+                for (int u = 0; u < AFI_TAIL_UNROLL; ++u) vn[u] = __builtin_nontemporal_load((const f32x4*)(xr + 16 * (s0 + AFI_TAIL_UNROLL + u)));
+            }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) part[i + u * L.RL][L.grp][t] = s[t];
+            for (int u = 0; u < AFI_TAIL_UNROLL; ++u) step(v[u], wv[u], pp[u][0], pp[u][1], pp[u][2], pp[u][3]);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < AFI_TAIL_UNROLL; ++u) v[u] = vn[u];
             }
         }
-    }
-    __syncthreads();
-    const int G = 4 / L.RL, t = threadIdx.x & 15;
-    for (int i = threadIdx.x >> 4; i < nr; i += 16) {       // D9 rows of 16 floats (columns 9 .. 15: zeros)
-        float s = 0.f;
-        if (t < 9) for (int g = 0; g < G; ++g) s += part[i][g][t];
-        d9[(r0 + i) * 16 + t] = s;
+        for (; s0 < nS; ++s0) {
+            const float* q = pr + 16 * s0;
+            const f32x4 z4 = zero;
+            step(__builtin_nontemporal_load((const f32x4*)(xr + 16 * s0)), lds_w(s0), BN ? *(const f32x4*)q : z4, BN ? *(const f32x4*)(q + C) : z4,
+                 BN ? *(const f32x4*)(q + 2 * C) : z4, BN ? *(const f32x4*)(q + 3 * C) : z4);
+        }
+        // acc[r] = D9[row j][tap 4 k + r]: one 16-byte store per lane (taps 9 .. 15: zeros)
+        if (rok) *(f32x4*)(d9 + row * 16 + 4 * k) = acc;
     }
 }
 // partial[chunk][q][C]: q = 0 sum g m, 1 sum g m xhat, 2 + t sum dD9[.][t] y   (g m: the gradient through the LeakyReLU mask m)
@@ -1027,14 +1079,17 @@ __global__ __launch_bounds__(256) void afi_disc_tail_bwd_apply_kernel(const floa
     }
     if (AMAX) afi_ew_amax_publish(am, amax);
 }
-static bool afi_tail_ok(long long P, int C) { return P > 0 && C > 0 && !(C & 3) && C <= AFI_TAIL_MAX_C; }
+static bool afi_tail_ok(long long P, int C) { return P > 0 && C > 0 && !(C & 15) && C <= AFI_TAIL_MAX_C; }
 // bn == nullptr: x is the activation itself (nothing applied on load)
 int afi_launch_disc_tail_fwd(const float* x, const AfiBnLoad* bn, float slope, const float* w3, float* d9, long long P, int C, hipStream_t st) {
     if (!x || !w3 || !d9 || !afi_tail_ok(P, C)) return AFI_ERR_BAD_ARG;
-    const unsigned grid = (unsigned)((P + AFI_TAIL_ROWS - 1) / AFI_TAIL_ROWS);
     const AfiBnLoad off{nullptr, nullptr, nullptr, nullptr};
-    if (bn && bn->mean) hipLaunchKernelGGL(afi_disc_tail_fwd_kernel<true>, dim3(grid), dim3(256), 0, st, x, *bn, slope, w3, d9, P, C);
-    else hipLaunchKernelGGL(afi_disc_tail_fwd_kernel<false>, dim3(grid), dim3(256), 0, st, x, off, slope, w3, d9, P, C);
+    const size_t lds = sizeof(float) * (9 * (size_t)(C + 4) + 4 + 4 * (size_t)C);
+    const long long tiles = (P + 16 * AFI_TAIL_WAVES - 1) / (16 * AFI_TAIL_WAVES);
+    const long long per = (tiles + 767) / 768;              // 256 CUs x (up to) 3 blocks of LDS images: every block takes `per` tiles (or one fewer)
+    const unsigned grid = (unsigned)((tiles + per - 1) / per);
+    if (bn && bn->mean) hipLaunchKernelGGL(afi_disc_tail_fwd_mfma_kernel<true>, dim3(grid), dim3(64 * AFI_TAIL_WAVES), lds, st, x, *bn, slope, w3, d9, P, C);
+    else hipLaunchKernelGGL(afi_disc_tail_fwd_mfma_kernel<false>, dim3(grid), dim3(64 * AFI_TAIL_WAVES), lds, st, x, off, slope, w3, d9, P, C);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 // x = the block's saved conv output, dd9 = the scattered logit gradients [P][16]; dx = d(conv output) (amax: raised to its largest magnitude);

@@ -1785,7 +1785,7 @@ long long afi_discriminator_fwd_ws_floats_ex(const afi_ctx_t* ctx, const int F[4
 // AFI_OPT_D_FUSE_TAIL in force for a discriminator of F3 last-block channels: block 2's apply pass, the last conv and their backward run as the
 // fused passes of csrc/elementwise.hip (afi_launch_disc_tail_*): y[2] and the gradient with respect to it are never written.  Evaluated by
 // the forward AND the backward (one more reason afi_discriminator_bwd runs under its forward's options).
-static bool disc_tail_fused(const afi_ctx* cx, int F3) { return afi_opt(cx, AFI_OPT_D_FUSE_TAIL) != 0 && !(F3 & 3) && F3 <= 1024; }
+static bool disc_tail_fused(const afi_ctx* cx, int F3) { return afi_opt(cx, AFI_OPT_D_FUSE_TAIL) != 0 && !(F3 & 15) && F3 <= 1024; }
 // where the forward keeps what the backward reads (offsets in floats into the forward workspace): 12 entries,
 // conv outputs c[0..2] ([P][F_{n+1}]), activations y[0..2], batch means [F_{n+1}], 1/sqrt(var + eps) [F_{n+1}]
 int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* off12) {

@@ -169,7 +169,7 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                * Same products, fewer roundings of the large accumulator (an fp32 accumulate rounds at the accumulator's magnitude,
                                                * whatever the addend).  Pre-split planes and 256-column multiples only (blocks 1 and 2 at the reference's widths; other
                                                * shapes keep the plain order).  Default and measurements: DESIGN.md 0 / 4b */
-#define AFI_OPT_D_FUSE_TAIL 16                /* 1 (default): the discriminator's last block and last conv (F3 -> 1, F3 <= 1024) run fused -- the last conv reads the
+#define AFI_OPT_D_FUSE_TAIL 16                /* 1 (default): the discriminator's last block and last conv (F3 -> 1, F3 <= 1024, F3 % 16 == 0) run fused -- the last conv reads the
                                                * block's saved conv output through its BatchNorm affine + LeakyReLU (the activation y[2] is never written:
                                                * afi_discriminator_saved_activations), and the block's BatchNorm backward GENERATES the gradient with respect to that
                                                * activation from the nine logit gradients of each pixel instead of reading it, taking the last conv's weight gradient
