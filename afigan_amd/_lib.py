@@ -213,7 +213,7 @@ CTX_FIRST = frozenset(n for n, (_, a) in SIGNATURES.items() if n.startswith(("af
 DTYPES = {"fp32": 0, "bf16": 1, "f16x3": 2, "bf16x3": 3, "bf16x6": 6}             # AFI_DTYPE_* of include/afigan_hip.h
 OPTIONS = {"winograd": 0, "winograd_f4_backward": 1, "winograd_f4_forward": 2, "bn_stats_fp64": 3, "d_winograd_min_pixels": 4,
            "g_winograd_min_pixels": 5, "g_smallmap_max_pixels": 6, "g_grouped_wgrad_max_pixels": 7, "g_batch_growth_grads": 8,
-           "g_smallmap6_max_pixels": 9, "g_rdb_chain": 10, "d_fold_bn_apply": 11, "deterministic": 12, "f16_presplit": 13, "f16_nt256_min_tiles": 14, "f16_local_sums": 15, "d_fuse_tail": 16}      # AFI_OPT_*
+           "g_smallmap6_max_pixels": 9, "g_rdb_chain": 10, "d_fold_bn_apply": 11, "deterministic": 12, "f16_presplit": 13, "f16_nt256_min_tiles": 14, "f16_local_sums": 15, "d_fuse_tail": 16, "d_fuse_bwd_sums": 17}      # AFI_OPT_*
 
 
 class Ctx:

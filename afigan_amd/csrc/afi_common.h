@@ -80,6 +80,11 @@ struct AfiPixGemm {
     // block: from them the statistics finalizer derives the largest magnitude of the block's ACTIVATION lrelu(affine(c)) -- the affine is
     // monotonic per channel, so it is attained at one of the two -- before any kernel has evaluated it (AFI_OPT_D_FOLD_BN_APPLY).  Null = off.
     float* stats_mm;
+    // The BatchNorm BACKWARD sums of the stored output, for an output that is the gradient with respect to a discriminator block's ACTIVATION (the
+    // data gradient of the next block): fp64 rows [stats_rows][2][Ncols] of sum g m and sum g m xhat per channel, m the LeakyReLU' factor and
+    // xhat the normalised value, both recomputed from the block's saved conv output bstats_c (dense [pixels][Ncols], the output's geometry)
+    // through bstats_bn (csrc/afi_bn.h) -- the pass afi_colred_partial_kernel<3> makes over both tensors otherwise.  Same shapes as `stats`; null = off.
+    double* bstats; const float* bstats_c; AfiBnLoad bstats_bn; float bstats_slope;
     int no_wcache;                             // Winograd form: B is a per-call scratch (its pointer says nothing about its contents): never cache its transform
     // Small-map bf16x6 form (csrc/smallmap.hip, afi_pix_gemm_wk6): the weights pre-split into bf16 MFMA-fragment images,
     // [N tile of 32][K stage of 32][n half][hi | mid | lo][lane] x 16 B, K stages in the kernel's own order (channel chunk, K phase, tap);

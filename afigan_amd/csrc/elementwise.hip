@@ -746,6 +746,36 @@ int afi_launch_bn_bwd(const float* g, const float* x, float* dx, const float* me
     else hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<false>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums, P, C, (const float*)nullptr, 1.f, amax, P);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
+// ... with the two sums already accumulated, as fp64 rows [rows][2][C], by the kernel that WROTE g (the data gradient's Winograd output
+// transform: AfiPixGemm::bstats): the finalizer adds the rows in a fixed order, the apply pass is afi_launch_bn_bwd's
+__global__ __launch_bounds__(256) void afi_bn_bwd_finalize64_kernel(const double* __restrict__ partial, int rows, int C, float gscale, float* __restrict__ dgamma,
+                                                                    float* __restrict__ dbeta, float* __restrict__ sums) {
+    __shared__ double red[2][32][8];
+    const int cl = threadIdx.x & 7, ln = threadIdx.x >> 3;  // eight channels per block, 32 lanes per channel over the rows
+    const int c = blockIdx.x * 8 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int i = ln; i < rows; i += 32) { a0 += partial[(long long)i * 2 * C + c]; a1 += partial[(long long)i * 2 * C + C + c]; }
+    red[0][ln][cl] = a0; red[1][ln][cl] = a1;
+    __syncthreads();
+    if (ln != 0 || c >= C) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int j = 0; j < 32; ++j) { s0 += red[0][j][cl]; s1 += red[1][j][cl]; }
+    sums[c] = (float)s0; sums[C + c] = (float)s1;
+    if (dbeta) dbeta[c] += gscale * (float)s0;
+    if (dgamma) dgamma[c] += gscale * (float)s1;
+}
+int afi_launch_bn_bwd_from_partials(const double* partial, int rows, const float* g, const float* x, float* dx, const float* mean, const float* invstd,
+                                    const float* gamma, float* dgamma, float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st,
+                                    const float* mask_beta, float slope, float* amax) {
+    if (!partial || rows <= 0 || P <= 0 || C <= 0 || (C & 3) || !scratch || !mask_beta) return AFI_ERR_BAD_ARG;
+    float* sums2C = scratch + (long long)AFI_RED_MAX_CHUNKS * 4 * C;         // (where afi_launch_bn_bwd keeps them: afi_reduce_scratch_floats)
+    hipLaunchKernelGGL(afi_bn_bwd_finalize64_kernel, dim3(afi_cdiv(C, 8)), dim3(256), 0, st, partial, rows, C, gscale, dgamma, dbeta, sums2C);
+    const dim3 agrid(afi_ew_grid(P * C / 4));
+    if (amax) hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true, true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums2C, P, C, mask_beta, slope, amax, P);
+    else hipLaunchKernelGGL((afi_bn_bwd_apply_kernel<true>), agrid, dim3(256), 0, st, g, x, dx, mean, invstd, gamma, sums2C, P, C, mask_beta, slope, amax, P);
+    return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
+}
 // The two halves of afi_launch_bn_bwd for a caller that exchanges the sums between ranks in between (SyncBatchNorm, bifpn_sr.py:210):
 // sums2C[0..C) = sum_rows g, sums2C[C..2C) = sum_rows g * xhat (and dbeta / dgamma += them: those stay per-rank, as torch's SyncBatchNorm keeps them);
 // then dx = gamma * invstd * (g - sums[0] / Pn - xhat * sums[1] / Pn) with the caller's (all-reduced) sums over Pn rows in all.

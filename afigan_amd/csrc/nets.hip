@@ -69,6 +69,9 @@ int afi_launch_bn_bwd_apply(const float* g, const float* x, float* dx, const flo
                             long long P_total, int C, hipStream_t st);
 int afi_launch_stencil9_sum(const float* d9, int ld, const float* bias, float* out, int N, int H, int W, hipStream_t st);
 int afi_launch_stencil9_scatter(const float* dlogit, float* dd9, int ld, int N, int H, int W, hipStream_t st);
+int afi_launch_bn_bwd_from_partials(const double* partial, int rows, const float* g, const float* x, float* dx, const float* mean, const float* invstd,
+                                    const float* gamma, float* dgamma, float* dbeta, float gscale, long long P, int C, float* scratch, hipStream_t st,
+                                    const float* mask_beta, float slope, float* amax);
 extern "C" long long afi_disc_tail_scratch_floats(int C);
 int afi_launch_disc_tail_fwd(const float* x, const AfiBnLoad* bn, float slope, const float* w3, float* d9, long long P, int C, hipStream_t st);
 int afi_launch_disc_tail_bwd(const float* x, const float* dd9, const AfiBnLoad bn, float slope, const float* w3, float* dx, float* dgamma, float* dbeta, float* dw3,
@@ -158,7 +161,7 @@ struct AfiOptions { long long v[AFI_OPT_COUNT]; };
 static const AfiOptions kDefaultOptions = {{/*WINOGRAD*/ 1, /*F4_BACKWARD*/ 1, /*F4_FORWARD*/ AFI_DEFAULT_F4_FORWARD, /*BN_STATS_FP64*/ 1, /*D_WINOGRAD_MIN_PIXELS*/ 1024,
                                             /*G_WINOGRAD_MIN_PIXELS*/ 2048, /*G_SMALLMAP_MAX_PIXELS*/ 2048, /*G_GROUPED_WGRAD_MAX_PIXELS*/ 3000,
                                             /*G_BATCH_GROWTH_GRADS*/ 1, /*G_SMALLMAP6_MAX_PIXELS*/ 4096, /*G_RDB_CHAIN*/ 0, /*D_FOLD_BN_APPLY*/ 0, /*DETERMINISTIC*/ 0, /*F16_PRESPLIT*/ 1, /*F16_NT256_MIN_TILES*/ 512,
-                                            /*F16_LOCAL_SUMS*/ AFI_DEFAULT_LOCAL_SUMS, /*D_FUSE_TAIL*/ 1}};
+                                            /*F16_LOCAL_SUMS*/ AFI_DEFAULT_LOCAL_SUMS, /*D_FUSE_TAIL*/ 1, /*D_FUSE_BWD_SUMS*/ 0}};
 struct afi_ctx {
     int device = -1;                                       // the device the context was created on; calls on another one are refused
     float* op_scratch = nullptr; long long op_scratch_floats = 0;
@@ -533,6 +536,8 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
     return f4 ? afi_launch_wino4_output_epi(Mb, Tpad, g, st) : afi_launch_wino_output_epi(Mb, Tpad, g, st);
 }
 
+// what a data gradient's output transform needs to take the BatchNorm-backward sums of its output along (AfiPixGemm::bstats)
+struct AfiBwdSums { double* rows; const float* c; AfiBnLoad bn; float slope; };
 // forward (mode 0: out = conv(in, w) + bias) or data gradient (mode 1: out = conv^T(in, w) * lrelu'(z)) by descriptor
 // stats (forward only): fp64 partial rows for the BatchNorm statistics of the output, accumulated by the output transform (afi_common.h);
 // *stats_rows receives the number of rows written, 0 when this call did not fuse them (the caller then runs the separate pass)
@@ -540,7 +545,7 @@ static int wino_run(afi_ctx* cx, const AfiPixGemm& g, int b_rc, float* ws, long 
 static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int K, const float* w, int Nc, const float* bias, AfiView out, AfiView z,
                      float* ws, long long ws_floats, float* part, long long part_floats, hipStream_t st, bool fwd_f4 = false,
                      double* stats = nullptr, int* stats_rows = nullptr, const AfiBnLoad* in_bn = nullptr, float* in_amax = nullptr, bool in_amax_known = false,
-                     float* v_keep = nullptr, float* stats_mm = nullptr, bool local_sums = false) {
+                     float* v_keep = nullptr, float* stats_mm = nullptr, bool local_sums = false, const AfiBwdSums* bsums = nullptr, int* bsums_rows = nullptr) {
     if ((K & 3) || (Nc & 3)) return AFI_ERR_UNSUPPORTED;
     AfiPixGemm g = mode ? conv_dgrad_desc(in, N, H, W, K, w, Nc, out) : conv_fwd_desc(in, N, H, W, K, w, bias, Nc, out);
     if (in_bn) g.a_bn = *in_bn;
@@ -555,6 +560,14 @@ static int wino_conv(afi_ctx* cx, int mode, AfiView in, int N, int H, int W, int
         const long long T = f4 ? (long long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
         const int rows = afi_wino_stats_rows(T, Nc);
         if (rows > 0) { g.stats = stats; g.stats_mm = stats_mm; *stats_rows = rows; }
+    }
+    if (bsums_rows) *bsums_rows = 0;
+    if (bsums && bsums_rows && mode && bsums->rows && !z.p) {   // the BatchNorm-backward sums of the gradient this call writes, by its output transform
+        const int dtype = cx ? cx->dtype : afi_default_dtype();
+        const bool f4 = wino_f4(cx) && dtype != AFI_DTYPE_BF16 && (long long)N * H * W >= 8192;               // (the tiling wino_run will pick)
+        const long long T = f4 ? (long long)N * ((H + 3) / 4) * ((W + 3) / 4) : (long long)N * ((H + 1) / 2) * ((W + 1) / 2);
+        const int rows = afi_wino_stats_rows(T, Nc);
+        if (rows > 0) { g.bstats = bsums->rows; g.bstats_c = bsums->c; g.bstats_bn = bsums->bn; g.bstats_slope = bsums->slope; *bsums_rows = rows; }
     }
     return wino_run(cx, g, mode, ws, ws_floats, part, part_floats, st, fwd_f4);
 }
@@ -1800,7 +1813,7 @@ int afi_discriminator_saved_activations(const afi_ctx_t* ctx, const int F[4], in
     const int tail = disc_tail_fused(ctx, F[3]) ? 0 : 4;     // (y[2]: read by the last conv only)
     return ((l.n_wino > 0 && use_wino(ctx, l.P) && afi_opt(ctx, AFI_OPT_D_FOLD_BN_APPLY) != 0) ? 0 : 3) | tail;
 }
-struct DiscBwdWs { long long o_g[3], o_dd9, o_amax, o_red, o_red2, o_tail, o_part, n_part, o_wino, n_wino, o_wino2, total; };
+struct DiscBwdWs { long long o_g[3], o_dd9, o_amax, o_red, o_red2, o_tail, o_bsums, o_part, n_part, o_wino, n_wino, o_wino2, total; };
 static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     DiscBwdWs w;
     const long long P = (long long)N * H * W;
@@ -1813,6 +1826,7 @@ static DiscBwdWs disc_bwd_ws(const int F[4], int N, int H, int W) {
     w.o_red = o; o += align4(afi_reduce_scratch_floats(fmax));       // BatchNorm backward (main stream)
     w.o_red2 = o; o += align4(afi_reduce_scratch_floats(fmax));      // bias column sums (side stream)
     w.o_tail = o; o += align4(afi_disc_tail_scratch_floats(F[3]));   // the fused tail's partial sums (AFI_OPT_D_FUSE_TAIL)
+    w.o_bsums = o; o += 4LL * AFI_STATS_MAX_ROWS * fmax;             // fp64 rows [rows][2][C]: BatchNorm-backward sums taken by a data gradient's output transform (AFI_OPT_D_FUSE_BWD_SUMS)
     w.n_part = part_floats({P * F[0], P * F[1], P * F[2], P * F[3]});
     w.o_part = o; o += w.n_part;
     w.n_wino = disc_wino_floats(F, N, H, W);
@@ -2035,6 +2049,10 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
         AFI_TRY(PG(g, 1));
     }
     // ---- conv + BN + LReLU blocks, last first
+    // AFI_OPT_D_FUSE_BWD_SUMS (off: measured, no gain): the data gradient of block n + 1 leaves the BatchNorm-backward sums of block n beside the
+    // gradient it writes (one affine per tensor: not a paired call)
+    const bool fuse_bsums = wino && halves == 1 && afi_opt(cx, AFI_OPT_D_FUSE_BWD_SUMS) != 0 && (((uintptr_t)(scratch + s.o_bsums)) & 7) == 0;
+    int bsums_rows = 0;                               // rows the previous iteration's data gradient left for THIS block (0: the separate pass)
     for (int n = 2; n >= 0; --n) {
         const int ci = prm->F[n], co = prm->F[n + 1];
         float* g_ = scratch + s.o_g[n];               // d(activation of block n)
@@ -2048,6 +2066,12 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
                 const AfiBnLoad bn{ws + (h ? l.o_mean_b[n] : l.o_mean[n]), ws + (h ? l.o_invstd_b[n] : l.o_invstd[n]), prm->gamma[n], prm->beta[n]};
                 AFI_TRY(afi_launch_disc_tail_bwd(c + o, dd9 + (long long)h * Ph * 16, bn, AFI_LRELU_SLOPE, prm->w3, g_ + o, gr->gamma[n], gr->beta[n], gr->w3, Ph, co,
                                                  scratch + s.o_tail, slots ? gmax + 4 * n : nullptr, st));
+                continue;
+            }
+            if (bsums_rows > 0) {                     // (halves == 1) the sums came with g_: finalize + apply
+                AFI_TRY(afi_launch_bn_bwd_from_partials((const double*)(scratch + s.o_bsums), bsums_rows, g_, c, g_, ws + l.o_mean[n], ws + l.o_invstd[n], prm->gamma[n],
+                                                        gr->gamma[n], gr->beta[n], 1.f, P, co, red, st, prm->beta[n],
+                                                        AFI_LRELU_SLOPE, slots ? gmax + 4 * n : nullptr));
                 continue;
             }
             AFI_TRY(afi_launch_bn_bwd(g_ + o, c + o, g_ + o, ws + (h ? l.o_mean_b[n] : l.o_mean[n]), ws + (h ? l.o_invstd_b[n] : l.o_invstd[n]), prm->gamma[n],
@@ -2071,9 +2095,13 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
                                                  slots ? gmax + 4 * n : nullptr, slots ? xmax + 4 * n : nullptr,
                                                  slots && disc_v_shared(cx, prm->F, n, P, wino, halves) ? ws + l.o_vkeep[n] : nullptr));
         else if (gr->w[n]) AFI_TRY(wgrad_launch(cx, conv_wgrad_desc(gy, xin, N, H, W, co, ci, gr->w[n], 1.f), sd));
+        bsums_rows = 0;
         if (n > 0 && wino) {
+            const AfiBwdSums bs{fuse_bsums ? (double*)(scratch + s.o_bsums) : nullptr, ws + l.o_c[n - 1],
+                                AfiBnLoad{ws + l.o_mean[n - 1], ws + l.o_invstd[n - 1], prm->gamma[n - 1], prm->beta[n - 1]}, AFI_LRELU_SLOPE};
             AFI_TRY(wino_conv(cx, 1, gy, N, H, W, co, prm->w[n], ci, nullptr, dense_view(scratch + s.o_g[n - 1], H, W, ci), null_view(), scratch + s.o_wino,
-                              s.n_wino, part_, part_n_, st, false, nullptr, nullptr, nullptr, slots ? gmax + 4 * n : nullptr, /*known=*/true));
+                              s.n_wino, part_, part_n_, st, false, nullptr, nullptr, nullptr, slots ? gmax + 4 * n : nullptr, /*known=*/true, nullptr, nullptr, false,
+                              &bs, &bsums_rows));
         } else if (n > 0) {
             AFI_TRY(PG(conv_dgrad_desc(gy, N, H, W, co, prm->w[n], ci, dense_view(scratch + s.o_g[n - 1], H, W, ci)), 1));
         } else if (dx && wino) {

@@ -281,7 +281,17 @@ __device__ __forceinline__ void afi_stats_acc(f64x4w& s0, f64x4w& s1, f32x4& mn,
 #pragma unroll
     for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; s0[j] += d; s1[j] += d * d; mn[j] = fminf(mn[j], v[j]); mx[j] = fmaxf(mx[j], v[j]); }
 }
-__device__ __forceinline__ void afi_stats_block_write(const AfiPixGemm& p, f64x4w s0, f64x4w s1, f32x4 mn, f32x4 mx) {
+// the backward sums of one stored float4 (AfiPixGemm::bstats): o = d(loss)/d(activation) at (pixel row, channel quad c), cv the conv output there
+__device__ __forceinline__ void afi_bstats_acc(f64x4w& s0, f64x4w& s1, f32x4 o, f32x4 cv, f32x4 mu, f32x4 is, f32x4 ga, f32x4 be, float slope) {
+    const f32x4 z = afi_bn_affine(cv, mu, is, ga, be);
+    const f32x4 xh = (cv - mu) * is;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const double gm = (double)(z[j] > 0.f ? o[j] : o[j] * slope);
+        s0[j] += gm; s1[j] += gm * (double)xh[j];
+    }
+}
+__device__ __forceinline__ void afi_stats_block_write(const AfiPixGemm& p, f64x4w s0, f64x4w s1, f32x4 mn, f32x4 mx, double* dst_rows = nullptr) {
     __shared__ f64x4w red[2][256];
     __shared__ f32x4 redm[2][256];
     const int C4 = p.Ncols >> 2;
@@ -294,10 +304,10 @@ __device__ __forceinline__ void afi_stats_block_write(const AfiPixGemm& p, f64x4
 #pragma unroll
             for (int j = 0; j < 4; ++j) { mn[j] = fminf(mn[j], redm[0][k][j]); mx[j] = fmaxf(mx[j], redm[1][k][j]); }
         }
-        double* row = p.stats + (long long)blockIdx.x * 2 * p.Ncols;
+        double* row = (dst_rows ? dst_rows : p.stats) + (long long)blockIdx.x * 2 * p.Ncols;
         *(f64x4w*)(row + 4 * threadIdx.x) = s0;
         *(f64x4w*)(row + p.Ncols + 4 * threadIdx.x) = s1;
-        if (p.stats_mm) {                                                                            // (a thread that stored nothing leaves +-inf: neutral)
+        if (p.stats_mm && !dst_rows) {                                                                            // (a thread that stored nothing leaves +-inf: neutral)
             float* mrow = p.stats_mm + (long long)blockIdx.x * 2 * p.Ncols;
             *(f32x4*)(mrow + 4 * threadIdx.x) = mn;
             *(f32x4*)(mrow + p.Ncols + 4 * threadIdx.x) = mx;
@@ -311,9 +321,10 @@ int afi_wino_stats_rows(long long T, int C) {
     if (g > AFI_STATS_MAX_ROWS) g = AFI_STATS_MAX_ROWS;
     return (int)(g < 1 ? 1 : g);
 }
-static bool afi_stats_fusable(const AfiPixGemm& p) { return p.stats && (p.Ncols == 256 || p.Ncols == 512 || p.Ncols == 1024); }
+static bool afi_stats_fusable(const AfiPixGemm& p) { return (p.stats || p.bstats) && (p.Ncols == 256 || p.Ncols == 512 || p.Ncols == 1024); }
 
-template <bool SIMPLE, bool STATS = false>
+// STATS: 0 none, 1 the forward's statistics of the stored output, 2 the BatchNorm-backward sums of it (AfiPixGemm::bstats)
+template <bool SIMPLE, int STATS = 0>
 __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* __restrict__ Min, long long Tpad, int Th, int Tw, long long T,
                                                                   const AfiPixGemm p) {
     const int C = p.Ncols, C4 = C >> 2;
@@ -321,6 +332,12 @@ __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* _
     const long long plane = Tpad * C;
     f64x4w st0 = {0, 0, 0, 0}, st1 = {0, 0, 0, 0};
     f32x4 smn = {INFINITY, INFINITY, INFINITY, INFINITY}, smx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 bmu = {0, 0, 0, 0}, bis = bmu, bga = bmu, bbe = bmu;   // STATS == 2: this thread's channel quad never changes along its walk (blockDim % C4 == 0)
+    if (STATS == 2) {
+        const int cq = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % C4) * 4;
+        bmu = *(const f32x4*)(p.bstats_bn.mean + cq); bis = *(const f32x4*)(p.bstats_bn.invstd + cq);
+        bga = *(const f32x4*)(p.bstats_bn.gamma + cq); bbe = *(const f32x4*)(p.bstats_bn.beta + cq);
+    }
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -344,23 +361,27 @@ __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* _
                 const int xx = 2 * tx + j;
                 if (xx >= p.W) continue;
                 const f32x4 v = (j == 0) ? s[i][0] + s[i][1] + s[i][2] : s[i][1] - s[i][2] - s[i][3];
-                if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xx, c, v); if (STATS) afi_stats_acc(st0, st1, smn, smx, o); }
-                else afi_epilogue_store(p, n, yy, xx, c, v);
+                if (SIMPLE) {
+                    const f32x4 o = afi_epilogue_store_simple(p, n, yy, xx, c, v);
+                    if (STATS == 1) afi_stats_acc(st0, st1, smn, smx, o);
+                    if (STATS == 2) afi_bstats_acc(st0, st1, o, __builtin_nontemporal_load((const f32x4*)(p.bstats_c + (((long long)n * p.H + yy) * p.W + xx) * C + c)), bmu, bis, bga, bbe, p.bstats_slope);
+                } else afi_epilogue_store(p, n, yy, xx, c, v);
             }
         }
     }
-    if (STATS) afi_stats_block_write(p, st0, st1, smn, smx);
+    if (STATS) afi_stats_block_write(p, st0, st1, smn, smx, STATS == 2 ? p.bstats : nullptr);
 }
 int afi_launch_wino_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st) {
     if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.Ncols <= 0 || (p.Ncols & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (p.H + 1) / 2, Tw = (p.W + 1) / 2;
     const long long T = (long long)p.N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    if (p.stats) {                                          // (the caller asked for fused statistics: afi_wino_stats_rows said this shape takes them)
-        if (!afi_epilogue_is_simple_host(p) || !afi_stats_fusable(p)) return AFI_ERR_BAD_ARG;
+    if (p.stats || p.bstats) {                              // (the caller asked for fused statistics: afi_wino_stats_rows said this shape takes them)
+        if (!afi_epilogue_is_simple_host(p) || !afi_stats_fusable(p) || (p.stats && p.bstats) || (p.bstats && (!p.bstats_c || !p.bstats_bn.mean))) return AFI_ERR_BAD_ARG;
         AfiPixGemm q = p;
         q.stats_rows = afi_wino_stats_rows(T, p.Ncols);
-        hipLaunchKernelGGL((afi_wino_output_epi_kernel<true, true>), dim3(q.stats_rows), dim3(256), 0, st, M, Tpad, Th, Tw, T, q);
+        if (p.stats) hipLaunchKernelGGL((afi_wino_output_epi_kernel<true, 1>), dim3(q.stats_rows), dim3(256), 0, st, M, Tpad, Th, Tw, T, q);
+        else hipLaunchKernelGGL((afi_wino_output_epi_kernel<true, 2>), dim3(q.stats_rows), dim3(256), 0, st, M, Tpad, Th, Tw, T, q);
     } else if (afi_epilogue_is_simple_host(p)) hipLaunchKernelGGL((afi_wino_output_epi_kernel<true>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     else hipLaunchKernelGGL((afi_wino_output_epi_kernel<false>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
@@ -708,7 +729,7 @@ int afi_launch_wino4_weight(const float* w, float* U, int O, int I, int mode, hi
 }
 
 // output: M [36][Tpad][C] -> 4x4 pixels per tile through the descriptor's epilogue
-template <bool SIMPLE, bool STATS = false>
+template <bool SIMPLE, int STATS = 0>
 __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* __restrict__ Min, long long Tpad, int Th, int Tw, long long T,
                                                                    const AfiPixGemm p) {
     const int C = p.Ncols, C4 = C >> 2;
@@ -716,6 +737,12 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
     const long long plane = Tpad * C;
     f64x4w st0 = {0, 0, 0, 0}, st1 = {0, 0, 0, 0};
     f32x4 smn = {INFINITY, INFINITY, INFINITY, INFINITY}, smx = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    f32x4 bmu = {0, 0, 0, 0}, bis = bmu, bga = bmu, bbe = bmu;   // STATS == 2: this thread's channel quad never changes along its walk (blockDim % C4 == 0)
+    if (STATS == 2) {
+        const int cq = (int)(((long long)blockIdx.x * blockDim.x + threadIdx.x) % C4) * 4;
+        bmu = *(const f32x4*)(p.bstats_bn.mean + cq); bis = *(const f32x4*)(p.bstats_bn.invstd + cq);
+        bga = *(const f32x4*)(p.bstats_bn.gamma + cq); bbe = *(const f32x4*)(p.bstats_bn.beta + cq);
+    }
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(e % C4) * 4;
         const long long t = e / C4;
@@ -738,8 +765,11 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
             wino4_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], y0, y1, y2, y3);
             const int xx = 4 * tx;
             auto put = [&](int xo, f32x4 v) {
-                if (SIMPLE) { const f32x4 o = afi_epilogue_store_simple(p, n, yy, xo, c, v); if (STATS) afi_stats_acc(st0, st1, smn, smx, o); }
-                else afi_epilogue_store(p, n, yy, xo, c, v);
+                if (SIMPLE) {
+                    const f32x4 o = afi_epilogue_store_simple(p, n, yy, xo, c, v);
+                    if (STATS == 1) afi_stats_acc(st0, st1, smn, smx, o);
+                    if (STATS == 2) afi_bstats_acc(st0, st1, o, __builtin_nontemporal_load((const f32x4*)(p.bstats_c + (((long long)n * p.H + yy) * p.W + xo) * C + c)), bmu, bis, bga, bbe, p.bstats_slope);
+                } else afi_epilogue_store(p, n, yy, xo, c, v);
             };
             if (xx < p.W) put(xx, y0);
             if (xx + 1 < p.W) put(xx + 1, y1);
@@ -747,18 +777,19 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
             if (xx + 3 < p.W) put(xx + 3, y3);
         }
     }
-    if (STATS) afi_stats_block_write(p, st0, st1, smn, smx);
+    if (STATS) afi_stats_block_write(p, st0, st1, smn, smx, STATS == 2 ? p.bstats : nullptr);
 }
 int afi_launch_wino4_output_epi(const float* M, long long Tpad, const AfiPixGemm& p, hipStream_t st) {
     if (p.N <= 0 || p.H <= 0 || p.W <= 0 || p.Ncols <= 0 || (p.Ncols & 3)) return AFI_ERR_BAD_ARG;
     const int Th = (p.H + 3) / 4, Tw = (p.W + 3) / 4;
     const long long T = (long long)p.N * Th * Tw;
     if (Tpad < T) return AFI_ERR_BAD_ARG;
-    if (p.stats) {
-        if (!afi_epilogue_is_simple_host(p) || !afi_stats_fusable(p)) return AFI_ERR_BAD_ARG;
+    if (p.stats || p.bstats) {
+        if (!afi_epilogue_is_simple_host(p) || !afi_stats_fusable(p) || (p.stats && p.bstats) || (p.bstats && (!p.bstats_c || !p.bstats_bn.mean))) return AFI_ERR_BAD_ARG;
         AfiPixGemm q = p;
         q.stats_rows = afi_wino_stats_rows(T, p.Ncols);
-        hipLaunchKernelGGL((afi_wino4_output_epi_kernel<true, true>), dim3(q.stats_rows), dim3(256), 0, st, M, Tpad, Th, Tw, T, q);
+        if (p.stats) hipLaunchKernelGGL((afi_wino4_output_epi_kernel<true, 1>), dim3(q.stats_rows), dim3(256), 0, st, M, Tpad, Th, Tw, T, q);
+        else hipLaunchKernelGGL((afi_wino4_output_epi_kernel<true, 2>), dim3(q.stats_rows), dim3(256), 0, st, M, Tpad, Th, Tw, T, q);
     } else if (afi_epilogue_is_simple_host(p)) hipLaunchKernelGGL((afi_wino4_output_epi_kernel<true>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     else hipLaunchKernelGGL((afi_wino4_output_epi_kernel<false>), dim3(wino_grid(T * (p.Ncols >> 2))), dim3(256), 0, st, M, Tpad, Th, Tw, T, p);
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;

@@ -314,7 +314,7 @@ class Stage1Step:
         self.bctx.set_option(name, value)
 
     _PAIRED_OPTIONS = ("winograd", "winograd_f4_backward", "winograd_f4_forward", "d_winograd_min_pixels", "d_fold_bn_apply", "f16_presplit",
-                       "f16_local_sums", "d_fuse_tail")
+                       "f16_local_sums", "d_fuse_tail", "d_fuse_bwd_sums")
 
     def _check_contexts_agree(self) -> None:
         if self.ctx.dtype != self.bctx.dtype:

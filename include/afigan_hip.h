@@ -175,7 +175,13 @@ int afi_ctx_get_compute_dtype(const afi_ctx_t* ctx);
                                                * activation from the nine logit gradients of each pixel instead of reading it, taking the last conv's weight gradient
                                                * along: at 2 x 200 x 336 x 1024, 1.1 GB less traffic per forward and 2.2 GB less per backward.  Same decisions of
                                                * the LeakyReLU masks (the pinned affine), sums in another order.  0: the separate passes of rounds 1-5 */
-#define AFI_OPT_COUNT 17
+#define AFI_OPT_D_FUSE_BWD_SUMS 17            /* 0 (default).  1: where the discriminator's data gradients run in Winograd form (and the call is not a paired one), the output
+                                               * transform that writes the gradient with respect to a block's activation also takes that block's two BatchNorm-backward
+                                               * sums (the LeakyReLU' mask and the normalised value recomputed from the saved conv output, fp64 partial rows), so the
+                                               * separate sums pass -- one read of the gradient and one of the conv output -- becomes one read of the conv output.
+                                               * Same gradients to fp32 rounding; measured: the transform with the sums takes 213 us more per call where the pass it
+                                               * replaces took 185 (2 x 200 x 336, four calls per step), 69.5-69.7 against 69.1-69.5 ms per step -- off */
+#define AFI_OPT_COUNT 18
 int afi_ctx_set_option(afi_ctx_t* ctx, int option, long long value);
 long long afi_ctx_get_option(const afi_ctx_t* ctx, int option);
 /* The batched "NT" GEMM those convolutions run on, for tests and micro-benchmarks:  C[g][m][n] = sum_k A[g][m][k] * B[g][n][k] over

@@ -131,7 +131,7 @@ def test_option_defaults_without_a_context():
     want = {"winograd": 1, "winograd_f4_backward": 1, "winograd_f4_forward": 12, "bn_stats_fp64": 1, "d_winograd_min_pixels": 1024,
             "g_winograd_min_pixels": 2048, "g_smallmap_max_pixels": 2048, "g_grouped_wgrad_max_pixels": 3000,
             "g_batch_growth_grads": 1, "g_smallmap6_max_pixels": 4096, "g_rdb_chain": 0, "d_fold_bn_apply": 0, "deterministic": 0, "f16_presplit": 1, "f16_nt256_min_tiles": 512, "f16_local_sums": 12,
-            "d_fuse_tail": 1}
+            "d_fuse_tail": 1, "d_fuse_bwd_sums": 0}
     assert set(want) == set(_lib.OPTIONS)
     for k, v in want.items():
         assert lib.afi_ctx_get_option(None, _lib.OPTIONS[k]) == v, k

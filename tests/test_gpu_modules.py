@@ -571,6 +571,51 @@ def test_discriminator_fused_tail_is_the_same_network(amd, F0, N, H, W, train):
                 assert _rel(a, b) < 2e-5, i
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 50, 84), (1, 40, 36)])
+def test_discriminator_bn_backward_sums_taken_by_the_data_gradient_are_the_same_network(amd, N, H, W):
+    """Option d_fuse_bwd_sums (off by default: measured, no gain): the Winograd output transform that writes d(loss)/d(activation of block n) also accumulates block
+    n's two BatchNorm-backward sums (mask and normalised value recomputed from the saved conv output, fp64 rows), instead of a separate pass over
+    both tensors (csrc/winograd.hip: AfiPixGemm::bstats; feature_patch_discriminator.py:35-38 is the block).  Against the separate pass:
+    the same masks, sums in another order and width -- every gradient to fp32 rounding.  8400 pixels: F(4x4) data gradients; 1440: F(2x2)."""
+    import ctypes as C
+    from afigan_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(12)
+    D = amd.Discriminator(in_filters=256).cuda()
+    D.train()
+    net = D.Discriminators[0]
+    x = ops.pixel_major(torch.randn(N, 256, H, W).cuda())
+    dl = torch.randn(N * H * W, device="cuda")
+    params = net._ordered_params()
+    Fa = (C.c_int * 4)(*net.F)
+    nf, nb = lib.afi_discriminator_fwd_ws_floats(Fa, N, H, W), lib.afi_discriminator_bwd_ws_floats(Fa, N, H, W)
+    res = {}
+    for flag in (0, 1):
+        cx = _lib.Ctx()
+        cx.set_option("d_fuse_bwd_sums", flag)
+        cx.set_option("deterministic", 1)
+        with _lib.use_ctx(cx):
+            prm, keep = net._param_struct(params)
+            grads = [torch.zeros_like(t) for t in keep]
+            gst, _k2 = net._param_struct(grads, already_packed=True, grads=True)
+            ws, sc = torch.full((nf,), float("nan"), device="cuda"), torch.full((nb,), float("nan"), device="cuda")
+            logits = torch.empty(N * H * W, device="cuda")
+            dx = ops.new_pixel_major(N, 256, H, W, "cuda")
+            st = ops.stream_ptr()
+            _lib.call("afi_discriminator_fwd", C.byref(prm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), 1, C.c_void_p(ws.data_ptr()), nf, st)
+            _lib.call("afi_discriminator_bwd", C.byref(prm), C.byref(gst), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()), C.c_void_p(dl.data_ptr()),
+                      C.c_void_p(dx.data_ptr()), C.c_void_p(sc.data_ptr()), nb, st)
+            torch.cuda.synchronize()
+        res[flag] = (dx.clone(), [g.clone() for g in grads])
+    assert bool(torch.isfinite(res[1][0]).all())
+    assert _rel(res[1][0], res[0][0]) < 1e-5, "input gradient"
+    for i, (a, b) in enumerate(zip(res[1][1], res[0][1])):
+        if float(b.abs().max()) == 0.0:
+            assert float(a.abs().max()) == 0.0, i
+        else:
+            assert _rel(a, b) < 2e-5, i
+
+
 @pytest.mark.parametrize("N,H,W", [(1, 32, 40), (2, 50, 84)])
 def test_discriminator_bn_apply_folded_into_its_readers_is_the_same_network(amd, N, H, W):
     """Option d_fold_bn_apply: under the Winograd path the BatchNorm apply + LeakyReLU of blocks 0 and 1 is evaluated by the READERS of the
