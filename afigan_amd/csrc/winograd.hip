@@ -364,7 +364,10 @@ __global__ __launch_bounds__(256) void afi_wino_output_epi_kernel(const float* _
                 if (SIMPLE) {
                     const f32x4 o = afi_epilogue_store_simple(p, n, yy, xx, c, v);
                     if (STATS == 1) afi_stats_acc(st0, st1, smn, smx, o);
-                    if (STATS == 2) afi_bstats_acc(st0, st1, o, __builtin_nontemporal_load((const f32x4*)(p.bstats_c + (((long long)n * p.H + yy) * p.W + xx) * C + c)), bmu, bis, bga, bbe, p.bstats_slope);
+                    if (STATS == 2) {
+                        const f32x4 cv = __builtin_nontemporal_load((const f32x4*)(p.bstats_c + (((long long)n * p.H + yy) * p.W + xx) * C + c));
+                        afi_bstats_acc(st0, st1, o, cv, bmu, bis, bga, bbe, p.bstats_slope);
+                    }
                 } else afi_epilogue_store(p, n, yy, xx, c, v);
             }
         }
@@ -768,7 +771,10 @@ __global__ __launch_bounds__(256) void afi_wino4_output_epi_kernel(const float* 
                 if (SIMPLE) {
                     const f32x4 o = afi_epilogue_store_simple(p, n, yy, xo, c, v);
                     if (STATS == 1) afi_stats_acc(st0, st1, smn, smx, o);
-                    if (STATS == 2) afi_bstats_acc(st0, st1, o, __builtin_nontemporal_load((const f32x4*)(p.bstats_c + (((long long)n * p.H + yy) * p.W + xo) * C + c)), bmu, bis, bga, bbe, p.bstats_slope);
+                    if (STATS == 2) {
+                        const f32x4 cv = __builtin_nontemporal_load((const f32x4*)(p.bstats_c + (((long long)n * p.H + yy) * p.W + xo) * C + c));
+                        afi_bstats_acc(st0, st1, o, cv, bmu, bis, bga, bbe, p.bstats_slope);
+                    }
                 } else afi_epilogue_store(p, n, yy, xo, c, v);
             };
             if (xx < p.W) put(xx, y0);
