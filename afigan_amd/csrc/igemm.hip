@@ -947,6 +947,11 @@ int afi_launch_gemm_nt_f16x3(const float* A, const void* Bimg, float* C, int pla
     return hipGetLastError() == hipSuccess ? AFI_OK : AFI_ERR_LAUNCH;
 }
 // pre: Q and V hold the planes already split into fp16 pieces
+#ifndef AFI_TN_MAX_ROUNDS
+// the split-K plan looks at no more than this many rounds of resident blocks (10: split 4 / 8 instead of 2 / 5 on D's largest layers fills the last
+// round, and pays for it in atomics: 70.3-70.5 against 70.0-70.2 ms per step, three alternating rounds)
+#define AFI_TN_MAX_ROUNDS 6
+#endif
 int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int planes, long long rows_per_plane, int M, int N, const AfiF16Bound& qb, const AfiF16Bound& vb,
                              hipStream_t st, bool pre, bool deterministic) {
     if (planes <= 0 || planes > 36 || rows_per_plane <= 0 || M <= 0 || N <= 0 || !qb.amax || !vb.amax) return AFI_ERR_BAD_ARG;
@@ -961,7 +966,7 @@ int afi_launch_gemm_tn_f16x3(const float* Q, const float* V, float* dU, int plan
         for (int s2 = 1; s2 <= maxsplit && s2 <= 128; ++s2) {
             const long long blocks = tiles * s2;
             if (blocks < 2 * slots && s2 < maxsplit) continue;
-            if (blocks > 6 * slots && best >= 0.0) break;
+            if (blocks > AFI_TN_MAX_ROUNDS * slots && best >= 0.0) break;
             const long long rounds = (blocks + slots - 1) / slots;
             const double fill = (double)blocks / (double)(rounds * slots);
             if (fill > best + 1e-3) { best = fill; splitK = s2; }
