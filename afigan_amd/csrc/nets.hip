@@ -1745,23 +1745,29 @@ int afi_generator_bwd(afi_ctx_t* ctx, const afi_gen_params_t* prm, const afi_gen
 }
 
 // ------------------------------------------------------------------------------------------------ discriminator
-// forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][y2 P*F3][d9 P*16][mean,invstd x3][red]
+// forward workspace (floats): [c0 P*F1][y0 P*F1][c1 P*F2][y1 P*F2][c2 P*F3][d9 P*16][mean,invstd x3][red] ... [y2 P*F3, where it is written][kept planes]
 struct DiscWs {
     long long P;
     long long o_c[3], o_y[3], o_d9, o_mean[3], o_invstd[3], o_red, o_stats, o_stats_mm, o_amax, o_part, n_part, o_wino, n_wino, o_mean_b[3], o_invstd_b[3], o_vkeep[3], total;
 };
+// AFI_OPT_D_FUSE_TAIL in force for a discriminator of F3 last-block channels: block 2's apply pass, the last conv and their backward run as the
+// fused passes of csrc/elementwise.hip (afi_launch_disc_tail_*): y[2] and the gradient with respect to it are never written.  Evaluated by
+// the forward AND the backward (one more reason afi_discriminator_bwd runs under its forward's options).
+static bool disc_tail_fused(const afi_ctx* cx, int F3) { return afi_opt(cx, AFI_OPT_D_FUSE_TAIL) != 0 && !(F3 & 15) && F3 <= 1024; }
 // keep_mask: bit n reserves the kept F(4x4) input planes of block n (disc_v_shared).  The planes sit at the END of the layout, so every other
 // offset is the same under every mask; the context-free size query reserves both (an upper bound every context's call fits into), the
 // context-aware one (afi_discriminator_fwd_ws_floats_ex) and the two passes what disc_keep_mask says (an fp32 / bf16x6 context, a
 // forward no backward follows and the F(2x2) blocks paid 0.6 + 1.25 GB per workspace at P2 for planes nobody writes)
-static DiscWs disc_ws(const int F[4], int N, int H, int W, int keep_mask = 6) {
+// y2: reserve the last block's activation (P x F3 floats, the largest tensor of the network): not under AFI_OPT_D_FUSE_TAIL, where nobody writes
+// it.  It sits behind every fixed region (its offset is the same either way: afi_discriminator_ws_layout is context-free) and in front of the kept planes.
+static DiscWs disc_ws(const int F[4], int N, int H, int W, int keep_mask = 6, bool y2 = true) {
     DiscWs w;
     w.P = (long long)N * H * W;
     long long o = 0;
     int fmax = 4;
     for (int n = 0; n < 3; ++n) {
         w.o_c[n] = o; o += align4(w.P * F[n + 1]);
-        w.o_y[n] = o; o += align4(w.P * F[n + 1]);
+        if (n < 2) { w.o_y[n] = o; o += align4(w.P * F[n + 1]); }
         if (F[n + 1] > fmax) fmax = F[n + 1];
     }
     w.o_d9 = o; o += align4(w.P * 16);
@@ -1781,6 +1787,8 @@ static DiscWs disc_ws(const int F[4], int N, int H, int W, int keep_mask = 6) {
         w.o_mean_b[n] = o; o += align4(F[n + 1]);
         w.o_invstd_b[n] = o; o += align4(F[n + 1]);
     }
+    w.o_y[2] = o;
+    if (y2) o += align4(w.P * F[3]);
     // the F(4x4) input planes of blocks 1 and 2, kept by a forward that a backward follows for that block's weight gradient (disc_v_shared)
     for (int n = 0; n < 3; ++n) {
         w.o_vkeep[n] = o;
@@ -1793,12 +1801,8 @@ long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W) {
 static int disc_keep_mask(const afi_ctx* cx, const int F[4], int N, int H, int W, int training, int halves);
 long long afi_discriminator_fwd_ws_floats_ex(const afi_ctx_t* ctx, const int F[4], int N, int H, int W, int training) {
     if (!F || N <= 0 || H <= 0 || W <= 0) return 0;
-    return disc_ws(F, N, H, W, disc_keep_mask(ctx, F, N, H, W, training, 1) | disc_keep_mask(ctx, F, N, H, W, training, 2)).total;     // (plain or paired call)
+    return disc_ws(F, N, H, W, disc_keep_mask(ctx, F, N, H, W, training, 1) | disc_keep_mask(ctx, F, N, H, W, training, 2), !disc_tail_fused(ctx, F[3])).total;     // (plain or paired call)
 }
-// AFI_OPT_D_FUSE_TAIL in force for a discriminator of F3 last-block channels: block 2's apply pass, the last conv and their backward run as the
-// fused passes of csrc/elementwise.hip (afi_launch_disc_tail_*): y[2] and the gradient with respect to it are never written.  Evaluated by
-// the forward AND the backward (one more reason afi_discriminator_bwd runs under its forward's options).
-static bool disc_tail_fused(const afi_ctx* cx, int F3) { return afi_opt(cx, AFI_OPT_D_FUSE_TAIL) != 0 && !(F3 & 15) && F3 <= 1024; }
 // where the forward keeps what the backward reads (offsets in floats into the forward workspace): 12 entries,
 // conv outputs c[0..2] ([P][F_{n+1}]), activations y[0..2], batch means [F_{n+1}], 1/sqrt(var + eps) [F_{n+1}]
 int afi_discriminator_ws_layout(const int F[4], int N, int H, int W, long long* off12) {
@@ -1888,7 +1892,8 @@ static int disc_fwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, afi_view_t xv,
     if (N <= 0 || H <= 0 || W <= 0 || !ws || !xv.p || (!logits && !stats_only)) return AFI_ERR_BAD_ARG;
     if (halves != 1 && halves != 2) return AFI_ERR_BAD_ARG;
     if (N % halves) return AFI_ERR_BAD_ARG;
-    const DiscWs l = disc_ws(prm->F, N, H, W, disc_keep_mask(cx, prm->F, N, H, W, training, 1) | disc_keep_mask(cx, prm->F, N, H, W, training, 2));     // (the layout afi_discriminator_fwd_ws_floats_ex sizes)
+    // (the layout afi_discriminator_fwd_ws_floats_ex sizes)
+    const DiscWs l = disc_ws(prm->F, N, H, W, disc_keep_mask(cx, prm->F, N, H, W, training, 1) | disc_keep_mask(cx, prm->F, N, H, W, training, 2), !disc_tail_fused(cx, prm->F[3]));
     if (ws_floats < l.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* const part_ = ws + l.o_part;
@@ -2005,7 +2010,8 @@ static int disc_bwd(afi_ctx_t* ctx, const afi_disc_params_t* prm, const afi_disc
     AFI_TRY(disc_check(prm));
     if (!gr || N <= 0 || H <= 0 || W <= 0 || !ws || !dlogits || !scratch) return AFI_ERR_BAD_ARG;
     if ((halves != 1 && halves != 2) || N % halves) return AFI_ERR_BAD_ARG;
-    const DiscWs l = disc_ws(prm->F, N, H, W, disc_keep_mask(cx, prm->F, N, H, W, 1, 1) | disc_keep_mask(cx, prm->F, N, H, W, 1, 2));   // the layout its forward (training == 1, same context settings) wrote
+    // the layout its forward (training == 1, same context settings) wrote
+    const DiscWs l = disc_ws(prm->F, N, H, W, disc_keep_mask(cx, prm->F, N, H, W, 1, 1) | disc_keep_mask(cx, prm->F, N, H, W, 1, 2), !disc_tail_fused(cx, prm->F[3]));
     const DiscBwdWs s = disc_bwd_ws(prm->F, N, H, W);
     if (scratch_floats < s.total) return AFI_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;

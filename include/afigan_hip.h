@@ -259,7 +259,9 @@ long long afi_discriminator_fwd_ws_floats(const int F[4], int N, int H, int W);
  * context-free query above is an upper bound for every context and mode -- it reserves the F(4x4) input planes a training forward of blocks 1 and
  * 2 may keep for its backward's weight gradient (36 x tiles x F[n] floats each: 0.6 + 1.25 GB at 2x200x336) -- this one reserves them only
  * where the context's arithmetic, AFI_OPT_WINOGRAD_F4_FORWARD / F16_PRESPLIT / D_FOLD_BN_APPLY and training == 1 make the forward keep them
- * (the default context: block 2 only).  Every other offset of the layout (afi_discriminator_ws_layout) is the same either way, and a workspace
+ * (the default context: block 2 only).  Likewise the last block's activation y[2] (P x F[3] floats, the largest tensor of the network) is reserved
+ * only where it is written: not under AFI_OPT_D_FUSE_TAIL (ABI v8: 0.55 GB per workspace at 2 x 200 x 336 x 1024).  Every offset that
+ * afi_discriminator_ws_layout reports is the same either way (y[2] sits behind the fixed regions, the kept planes behind it), and a workspace
  * sized by either query serves afi_discriminator_fwd / _bwd under that context. */
 long long afi_discriminator_fwd_ws_floats_ex(const afi_ctx_t* ctx, const int F[4], int N, int H, int W, int training);
 long long afi_discriminator_bwd_ws_floats(const int F[4], int N, int H, int W);

@@ -518,8 +518,8 @@ def test_discriminator_fused_tail_is_the_same_network(amd, F0, N, H, W, train):
     """Option d_fuse_tail (default on): block 2's BatchNorm apply + LeakyReLU, the last conv and their backward without y[2] and without the
     gradient w.r.t. it in memory (feature_patch_discriminator.py:38-41; csrc/elementwise.hip, afi_launch_disc_tail_*).  Against the separate
     passes (option off) on the same inputs: the same LeakyReLU decisions (the pinned affine on the same conv output), sums in another order --
-    logits, input gradient and every parameter gradient to fp32 rounding; y[2]'s region of the workspace stays untouched and the mask of
-    afi_discriminator_saved_activations says so.  Channel counts that fill a wave's 256 channels (1024), a part of one (64: masked lanes)
+    logits, input gradient and every parameter gradient to fp32 rounding; y[2] is not even reserved (the context's workspace is P x F3 floats
+    smaller, and the call stays inside it) and the mask of afi_discriminator_saved_activations says so.  Channel counts that fill a wave's 256 channels (1024), a part of one (64: masked lanes)
     and one and a half (384); batch statistics and running statistics (eval)."""
     import ctypes as C
     from afigan_amd import _lib, ops
@@ -539,28 +539,31 @@ def test_discriminator_fused_tail_is_the_same_network(amd, F0, N, H, W, train):
     nf, nb = lib.afi_discriminator_fwd_ws_floats(Fa, N, H, W), lib.afi_discriminator_bwd_ws_floats(Fa, N, H, W)
     off = (C.c_longlong * 12)()
     _lib.call("afi_discriminator_ws_layout", Fa, N, H, W, off)
-    res = {}
+    res, nfx = {}, {}
     for flag in (0, 1):
         cx = _lib.Ctx()
         cx.set_option("d_fuse_tail", flag)
         cx.set_option("deterministic", 1)
         assert lib.afi_discriminator_saved_activations(cx.handle, Fa, N, H, W) == (3 if flag else 7)
+        nfx[flag] = lib.afi_discriminator_fwd_ws_floats_ex(cx.handle, Fa, N, H, W, 1 if train else 0)     # what THIS context's call needs
         with _lib.use_ctx(cx):
             prm, keep = net._param_struct(params)
             grads = [torch.zeros_like(t) for t in keep]
             gst, _k2 = net._param_struct(grads, already_packed=True, grads=True)
-            ws, sc = torch.full((nf,), float("nan"), device="cuda"), torch.zeros(nb, device="cuda")
+            ws, sc = torch.full((nfx[flag] + 4096,), float("nan"), device="cuda"), torch.zeros(nb, device="cuda")      # (+ a guard behind it)
             logits = torch.empty(N * H * W, device="cuda")
             dx = ops.new_pixel_major(N, F0, H, W, "cuda")
             st = ops.stream_ptr()
-            _lib.call("afi_discriminator_fwd", C.byref(prm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), 1 if train else 0, C.c_void_p(ws.data_ptr()), nf, st)
-            y2_written = not bool(torch.isnan(ws[off[5]:off[5] + 8]).any())
+            _lib.call("afi_discriminator_fwd", C.byref(prm), ops.view_of(x), N, H, W, C.c_void_p(logits.data_ptr()), 1 if train else 0, C.c_void_p(ws.data_ptr()), nfx[flag], st)
+            y2_written = flag == 0 and not bool(torch.isnan(ws[off[5]:off[5] + 8]).any())
             if train:
                 _lib.call("afi_discriminator_bwd", C.byref(prm), C.byref(gst), ops.view_of(x), N, H, W, C.c_void_p(ws.data_ptr()), C.c_void_p(dl.data_ptr()),
                           C.c_void_p(dx.data_ptr()), C.c_void_p(sc.data_ptr()), nb, st)
             torch.cuda.synchronize()
         assert y2_written == (flag == 0)
+        assert bool(torch.isnan(ws[nfx[flag]:]).all()), "the call wrote behind the workspace its context asked for"
         res[flag] = (logits.clone(), dx.clone(), [g.clone() for g in grads])
+    assert nfx[0] - nfx[1] == N * H * W * net.F[3] and nfx[0] <= nf
     assert _rel(res[1][0], res[0][0]) < 2e-6, "logits"
     if train:
         assert _rel(res[1][1], res[0][1]) < 1e-5, "input gradient"
