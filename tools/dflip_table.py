@@ -23,14 +23,15 @@ H, W = int(_args[0]), int(_args[1])
 seeds = [int(s) for s in _args[2:]] or [0]
 VARIANTS = [("torch32", None),
             ("direct", {"winograd": 0}),
-            ("f2fwd (=0)", {"winograd_f4_forward": 0}),
-            ("f4 block 2 (=8)", {"winograd_f4_forward": 8}),
-            ("f4 block 1 (=4)", {"winograd_f4_forward": 4}),
-            ("f4 blocks 1,2 (=12)", {"winograd_f4_forward": 12}),
-            ("f4 all (=1)", {"winograd_f4_forward": 1}),
+            ("f2fwd (=0), plain order", {"winograd_f4_forward": 0, "f16_local_sums": 0}),
+            ("f4 block 2 (=8), plain", {"winograd_f4_forward": 8, "f16_local_sums": 0}),
+            ("f4 block 1 (=4), plain", {"winograd_f4_forward": 4, "f16_local_sums": 0}),
+            ("f4 blocks 1,2 (=12), plain", {"winograd_f4_forward": 12, "f16_local_sums": 0}),
+            ("f4 all (=1), plain", {"winograd_f4_forward": 1, "f16_local_sums": 0}),
+            ("=0, local sums blk 1,2", {"winograd_f4_forward": 0, "f16_local_sums": 12}),
+            ("=8, local sums blk 1,2", {"winograd_f4_forward": 8, "f16_local_sums": 12}),
             ("=12, local sums blk 1,2", {"winograd_f4_forward": 12, "f16_local_sums": 12}),
             ("=12, local sums all", {"winograd_f4_forward": 12, "f16_local_sums": 1}),
-            ("=1, local sums blk 1,2", {"winograd_f4_forward": 1, "f16_local_sums": 12}),
             ("=1, local sums all", {"winograd_f4_forward": 1, "f16_local_sums": 1})]
 cx = amd._lib.current_ctx()
 if _dtype:
@@ -92,10 +93,10 @@ for k, v in defaults.items():
     cx.set_option(k, v)
 
 print(f"D fwd+bwd at 2x256x{H}x{W}, dtype {cx.dtype}, seeds {seeds}: relative L2 against fp64 (dx | worst parameter gradient)")
-print(f"library default winograd_f4_forward = {defaults['winograd_f4_forward']}")
+print(f"library defaults: winograd_f4_forward = {defaults['winograd_f4_forward']}, f16_local_sums = {defaults['f16_local_sums']} (every row sets both)")
 hdr = "".join(f"  seed {s}: dx / worst " for s in seeds)
-print(f"{'forward convs':24s}{hdr}  mean: dx / worst")
+print(f"{'forward convs':28s}{hdr}  mean: dx / worst")
 for name, _ in VARIANTS:
     v = rows[name]
     cells = "".join(f"  {a:.3e} / {b:.3e}" for a, b in v)
-    print(f"{name:24s}{cells}  {sum(a for a, _ in v) / len(v):.3e} / {sum(b for _, b in v) / len(v):.3e}")
+    print(f"{name:28s}{cells}  {sum(a for a, _ in v) / len(v):.3e} / {sum(b for _, b in v) / len(v):.3e}")
